@@ -1,0 +1,288 @@
+"""oracle/oracle.py -- ctypes front-end of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product (mp-gadget_amd/) never does.  See gravtree_oracle.c for the
+reference file:line each routine restates and for how the oracle is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+TABLE_PATH = os.path.join(_HERE, "..", "mp-gadget_amd", "data", "shortrange_force_kernels.f64")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile liboracle.so / liboracle_fast.so (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(os.path.join(_BUILD, "liboracle.so")) or not os.path.exists(
+            os.path.join(_BUILD, "liboracle_fast.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+
+
+class GravParams(C.Structure):
+    """ograv_params of gravtree_oracle.c (gravity.h:9-22 + GravShortPriv gravshort.h:25-43)."""
+    _fields_ = [("ErrTolForceAcc", C.c_double), ("BHOpeningAngle", C.c_double), ("MaxBHOpeningAngle", C.c_double),
+                ("TreeUseBH", C.c_int), ("Rcut", C.c_double), ("h", C.c_double), ("cellsize", C.c_double),
+                ("G", C.c_double), ("cbrtrho0", C.c_double)]
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """One loaded oracle library (strict or the reference-flags 'fast' build)."""
+
+    def __init__(self, fast=False):
+        build()
+        path = os.path.join(_BUILD, "liboracle_fast.so" if fast else "liboracle.so")
+        L = self.lib = C.CDLL(path)
+        L.ot_build.restype = C.c_void_p
+        L.ot_build.argtypes = [C.c_int64, _dp, _fp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.ot_calc_moments.argtypes = [C.c_void_p]
+        L.ot_free.argtypes = [C.c_void_p]
+        for f in ("ot_numnodes", "ot_firstnode", "ot_ninserted"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.ot_father.restype = C.POINTER(C.c_int)
+        L.ot_father.argtypes = [C.c_void_p]
+        L.ot_export.argtypes = [C.c_void_p, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _ip, _ip]
+        L.og_fill_ntab.argtypes = [_dp, C.c_int, C.c_double]
+        L.og_fill_ntab.restype = C.c_int
+        L.og_get_ntab.argtypes = [_fp, _fp]
+        L.og_grav_short_tree.argtypes = [C.c_void_p, C.POINTER(GravParams), C.c_int64, C.c_void_p, C.c_void_p, _dp,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.og_grav_short_pair.argtypes = [C.c_int64, _dp, _fp, C.c_double, C.POINTER(GravParams), C.c_double, _dp]
+        L.og_force_direct.argtypes = [C.c_int64, _dp, _fp, C.c_double, C.c_double, C.c_double, _dp]
+        L.og_num_threads.restype = C.c_int
+        self.table = np.fromfile(TABLE_PATH, dtype="<f8").reshape(512, 5).copy()
+
+    # -- window (gravity.c:22-51) --
+    def fill_ntab(self, wtype=0, Asmth=1.5):
+        if self.lib.og_fill_ntab(np.ascontiguousarray(self.table.ravel()), wtype, Asmth) != 0:
+            raise ValueError("exact window is calibrated for Asmth = 1.5")
+
+    def get_ntab(self):
+        f = np.zeros(512, np.float32)
+        p = np.zeros(512, np.float32)
+        self.lib.og_get_ntab(f, p)
+        return f, p
+
+    def num_threads(self):
+        return self.lib.og_num_threads()
+
+    # -- tree (forcetree.c) --
+    def tree(self, pos, mass, box, type=None, hsml=None, hydro_active=None, mask=63, alloc_factor=0.9,
+             moments=True, father=True):
+        return OracleTree(self, pos, mass, box, type, hsml, hydro_active, mask, alloc_factor, moments, father)
+
+    def grav_short_pair(self, pos, mass, box, par, rcut_abs):
+        pos = np.ascontiguousarray(pos, np.float64)
+        mass = np.ascontiguousarray(mass, np.float32)
+        acc = np.zeros_like(pos)
+        self.lib.og_grav_short_pair(len(pos), pos, mass, box, C.byref(par), rcut_abs, acc)
+        return acc
+
+    def force_direct(self, pos, mass, box, h, G):
+        pos = np.ascontiguousarray(pos, np.float64)
+        mass = np.ascontiguousarray(mass, np.float32)
+        acc = np.zeros_like(pos)
+        self.lib.og_force_direct(len(pos), pos, mass, box, h, G, acc)
+        return acc
+
+
+class OracleTree:
+    def __init__(self, orc, pos, mass, box, type, hsml, hydro_active, mask, alloc_factor, moments, father):
+        self.orc = orc
+        self.pos = np.ascontiguousarray(pos, np.float64)
+        self.mass = np.ascontiguousarray(mass, np.float32)
+        self.type = None if type is None else np.ascontiguousarray(type, np.int32)
+        self.hsml = None if hsml is None else np.ascontiguousarray(hsml, np.float64)
+        self.hact = None if hydro_active is None else np.ascontiguousarray(hydro_active, np.uint8)
+        self.box = float(box)
+        self.N = len(self.pos)
+        self.h = orc.lib.ot_build(self.N, self.pos, self.mass, _vp(self.type), _vp(self.hsml), _vp(self.hact), mask,
+                                  self.box, alloc_factor, 1 if father else 0)
+        if moments:
+            orc.lib.ot_calc_moments(self.h)
+
+    def calc_moments(self):
+        self.orc.lib.ot_calc_moments(self.h)
+
+    @property
+    def numnodes(self):
+        return self.orc.lib.ot_numnodes(self.h)
+
+    @property
+    def ninserted(self):
+        return self.orc.lib.ot_ninserted(self.h)
+
+    def father(self):
+        p = self.orc.lib.ot_father(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.N,)).copy()
+
+    def export(self):
+        n = self.numnodes
+        d = dict(live=np.zeros(n, np.int32), level=np.zeros(n, np.int32), center=np.zeros((n, 3)), len=np.zeros(n),
+                 cofm=np.zeros((n, 3)), mass=np.zeros(n), hmax=np.zeros(n), childtype=np.zeros(n, np.int32),
+                 noccupied=np.zeros(n, np.int32), sibling=np.zeros(n, np.int32), father=np.zeros(n, np.int32),
+                 suns=np.zeros((n, 8), np.int32))
+        self.orc.lib.ot_export(self.h, d["live"], d["level"], d["center"], d["len"], d["cofm"], d["mass"], d["hmax"],
+                               d["childtype"], d["noccupied"], d["sibling"], d["father"], d["suns"])
+        d["firstnode"] = self.orc.lib.ot_firstnode(self.h)
+        return d
+
+    def grav_short_tree(self, par, oldacc=None, active=None, want_pot=False, per_particle=False):
+        """grav_short_tree (gravshort-tree.c:96-154). Returns (accel[N,3], pot|None, counters[3], ninter|None)."""
+        acc = np.zeros((self.N, 3))
+        pot = np.zeros(self.N) if want_pot else None
+        cnt = np.zeros(3, np.int64)
+        nin = np.zeros(self.N, np.int64) if per_particle else None
+        act = None if active is None else np.ascontiguousarray(active, np.int32)
+        old = None if oldacc is None else np.ascontiguousarray(oldacc, np.float64)
+        self.orc.lib.og_grav_short_tree(self.h, C.byref(par), 0 if act is None else len(act), _vp(act), _vp(old), acc,
+                                        _vp(pot), _vp(cnt), _vp(nin))
+        return acc, pot, cnt, nin
+
+    def free(self):
+        if self.h:
+            self.orc.lib.ot_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def make_grav_params(box, nmesh, npart_cbrt=None, mean_sep=None, Asmth=1.5, TreeRcut=6.0, ErrTolForceAcc=0.002,
+                     BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, FracSoftening=1.0 / 30., G=43.0071,
+                     rho0=0.0):
+    """Parameter block as the reference derives it (gravshort-tree.c:37-47,101-104; params.c defaults)."""
+    if mean_sep is None:
+        mean_sep = box / npart_cbrt
+    p = GravParams()
+    p.ErrTolForceAcc = ErrTolForceAcc
+    p.BHOpeningAngle = BHOpeningAngle
+    p.MaxBHOpeningAngle = MaxBHOpeningAngle
+    p.TreeUseBH = TreeUseBH
+    p.cellsize = box / nmesh
+    p.Rcut = TreeRcut * Asmth * p.cellsize
+    p.h = 2.8 * (FracSoftening * mean_sep)
+    p.G = G
+    p.cbrtrho0 = rho0 ** (1.0 / 3)
+    return p
+
+
+# ------------------------------------------------------------------------------------------
+# Long-range PM oracle (numpy).  Restates petapm.c / gravpm.c on a single rank, where the
+# region/pencil machinery (petapm.c:584-930) reduces to depositing straight into the global
+# mesh.  PFFT (third party, 1.0.8-alpha3-fftw3-2don2d, not vendored) is a
+# plain unnormalised DFT; numpy.fft (pocketfft) is used in its place -- parity at the FFT call
+# boundary is "unpinned" (no reference test inspects FFT output); it is pinned end-to-end by the
+# reference's test_gravity.c direct-sum bounds (tests/test_oracle_kat.py).
+# ------------------------------------------------------------------------------------------
+
+def _sinc_unnormed(x):
+    """gravpm.c:295-302"""
+    x = np.asarray(x, np.float64)
+    small = np.abs(x) < 1e-5
+    xs = np.where(small, 1.0, x)
+    x2 = x * x
+    return np.where(small, 1.0 - x2 / 6. + x2 * x2 / 120., np.sin(xs) / xs)
+
+
+def pm_cic_deposit(pos, mass, box, nmesh):
+    """put_particle_to_mesh through pm_iterate_one (petapm.c:955-1020,1138-1144), periodic wrap of petapm.c:903-918."""
+    cell = box / nmesh
+    tmp = pos / cell
+    ic = np.floor(tmp)
+    res = tmp - ic
+    ic = ic.astype(np.int64)
+    rho = np.zeros(nmesh ** 3)
+    m = mass.astype(np.float64)
+    for conn in range(8):
+        w = np.ones(len(pos))
+        lin = np.zeros(len(pos), np.int64)
+        for k in range(3):
+            off = (conn >> k) & 1
+            idx = (ic[:, k] + off) % nmesh
+            lin = lin * nmesh + idx
+            w = w * (res[:, k] if off else (1 - res[:, k]))
+        rho += np.bincount(lin, weights=w * m, minlength=nmesh ** 3)
+    return rho.reshape(nmesh, nmesh, nmesh)
+
+
+def pm_readout(mesh, pos, box, nmesh):
+    """readout_* through pm_iterate_one (gravpm.c:499-510)."""
+    cell = box / nmesh
+    tmp = pos / cell
+    ic = np.floor(tmp)
+    res = tmp - ic
+    ic = ic.astype(np.int64)
+    flat = mesh.reshape(-1)
+    out = np.zeros(len(pos))
+    for conn in range(8):
+        w = np.ones(len(pos))
+        lin = np.zeros(len(pos), np.int64)
+        for k in range(3):
+            off = (conn >> k) & 1
+            idx = (ic[:, k] + off) % nmesh
+            lin = lin * nmesh + idx
+            w = w * (res[:, k] if off else (1 - res[:, k]))
+        out += w * flat[lin]
+    return out
+
+
+def pm_transfer_arrays(box, nmesh, Asmth, G):
+    """potential_transfer (gravpm.c:383-454) and force_transfer (:458-489) as broadcastable arrays on the rfft mesh."""
+    kx = np.fft.fftfreq(nmesh, 1.0 / nmesh).astype(np.int64)   # 0..N/2-1, -N/2.. ; petapm_mesh_to_k maps N/2 -> +N/2
+    kx[nmesh // 2] = nmesh // 2
+    kz = np.arange(nmesh // 2 + 1, dtype=np.int64)
+    KX, KY, KZ = kx[:, None, None], kx[None, :, None], kz[None, None, :]
+    k2 = (KX * KX + KY * KY + KZ * KZ).astype(np.float64)
+    asmth2 = ((2 * np.pi) * Asmth / nmesh) ** 2
+    f = 1.0
+    for K in (KX, KY, KZ):
+        t = _sinc_unnormed(K * np.pi / nmesh)
+        f = f * (1.0 / (t * t))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        smth = np.exp(-k2 * asmth2) / k2
+    pot_factor = -G / (np.pi * box)
+    fac = pot_factor * smth * f * f
+    fac[0, 0, 0] = 0.0
+
+    def diff(k):
+        w = k * (2 * np.pi / nmesh)
+        return -1 * (1 / 6.0 * (8 * np.sin(w) - np.sin(2 * w))) * (nmesh / box)
+    return fac, (diff(KX.astype(np.float64)), diff(KY.astype(np.float64)), diff(KZ.astype(np.float64)))
+
+
+def gravpm_force(pos, mass, box, nmesh, Asmth=1.5, G=43.0071, want_potential=True):
+    """gravpm_force (gravpm.c:61-119) -> (GravPM[N,3], PMpotential[N]) for a single rank, all particles active.
+
+    r2c unnormalised, transfer, c2r unnormalised (PFFT convention; numpy's irfftn divides by N^3, undone here)."""
+    pos = np.asarray(pos, np.float64)
+    rho = pm_cic_deposit(pos, np.asarray(mass), box, nmesh)
+    rho_k = np.fft.rfftn(rho)
+    fac, diffs = pm_transfer_arrays(box, nmesh, Asmth, G)
+    pot_k = rho_k * fac
+    n3 = float(nmesh) ** 3
+    out = np.zeros((len(pos), 3))
+    potential = None
+    if want_potential:
+        potential = pm_readout(np.fft.irfftn(pot_k, s=(nmesh,) * 3) * n3, pos, box, nmesh)
+    for d in range(3):
+        # (re, im) <- (-im*fac, re*fac)  == multiply by i*fac   (gravpm.c:476-489)
+        fk = pot_k * (1j * diffs[d])
+        out[:, d] = pm_readout(np.fft.irfftn(fk, s=(nmesh,) * 3) * n3, pos, box, nmesh)
+    return out, potential
