@@ -1,0 +1,169 @@
+/* include/mpgadget_hip.h -- C-ABI of the MI355X (gfx950) TreePM + SPH force engine.
+ *
+ * The reference (MP-Gadget, plain C, statically linked) has no FFI: its "operator API" is the set of C
+ * entry points run.c / timestep.c / init.c / runtests.c call.  Each function below replaces one of
+ * those entry points (cited as libgadget/<file>:<line>) with plain pointers and sizes, so that a
+ * 30-line shim compiled inside the reference tree can forward the reference symbols
+ *   gravpm_init_periodic, gravpm_force, force_tree_full, force_tree_rebuild_mask, force_tree_free,
+ *   grav_short_tree, gravshort_fill_ntab, gravshort_set_softenings, set_gravshort_treepar, FORCE_SOFTENING,
+ *   density, hydro_force
+ * to this library.  No torch / C++ types appear in any signature.
+ *
+ * Conventions
+ *   - every call returns 0 on success, non-zero on failure; mpg_last_error() gives the message
+ *     (the shim maps it to endrun(), utils/endrun.h:4-7 -- the reference has no return codes on this path);
+ *   - "host" calls take the reference's AoS particle table through an mpg_particle_view (base pointer,
+ *     stride and byte offsets: the same idea as PetaPMParticleStruct, petapm.h:86-99), copy what they
+ *     need to HBM, run, and scatter results back into the caller's structs;
+ *   - "dev" calls take device pointers (SoA, fp64) already resident in HBM and leave results in HBM;
+ *     they are what bench.py times;
+ *   - all arithmetic on the path is fp64 (MyFloat = double, types.h:13-17); P.Mass is float
+ *     (partmanager.h:15) and the short-range window tables are float (gravity.c:20).
+ */
+#ifndef MPGADGET_HIP_H
+#define MPGADGET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpg_engine mpg_engine;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+/* Create an engine bound to HIP device `device` (one engine per GPU / MPI rank). */
+int mpg_engine_create(mpg_engine **out, int device);
+void mpg_engine_destroy(mpg_engine *eng);
+/* Last error message of the calling thread ("" if none). */
+const char *mpg_last_error(void);
+/* Library / build identification string. */
+const char *mpg_version(void);
+/* Use an existing HIP stream (hipStream_t passed as void*) for all engine work; NULL = engine's own. */
+int mpg_engine_set_stream(mpg_engine *eng, void *hip_stream);
+void *mpg_engine_get_stream(mpg_engine *eng);
+/* Block until all engine work is complete. */
+int mpg_engine_synchronize(mpg_engine *eng);
+
+/* ---- module parameters ----------------------------------------------------------------------- */
+/* struct gravshort_tree_params, libgadget/gravity.h:9-22 (same fields, same order). */
+typedef struct mpg_gravshort_tree_params {
+    double ErrTolForceAcc;
+    double BHOpeningAngle;
+    double MaxBHOpeningAngle;
+    int TreeUseBH;
+    double Rcut;
+    double FractionalGravitySoftening;
+} mpg_gravshort_tree_params;
+
+/* set_gravshort_treepar / get_gravshort_treepar, libgadget/gravshort-tree.c:53-61 */
+int mpg_set_gravshort_treepar(mpg_engine *eng, const mpg_gravshort_tree_params *par);
+int mpg_get_gravshort_treepar(mpg_engine *eng, mpg_gravshort_tree_params *par);
+/* gravshort_set_softenings, libgadget/gravshort-tree.c:44-50 */
+int mpg_gravshort_set_softenings(mpg_engine *eng, double MeanSeparation);
+/* FORCE_SOFTENING, libgadget/gravshort-tree.c:37-41 (returns 2.8 * GravitySoftening) */
+double mpg_force_softening(mpg_engine *eng);
+/* gravshort_fill_ntab, libgadget/gravity.c:22-51.  window_type 0 = exact (needs Asmth == 1.5), 1 = erfc.
+ * `table` = the calibrated 512 x 5 float64 table of libgadget/shortrange-kernel.c (row-major; carried as
+ * data in mp-gadget_amd/data/shortrange_force_kernels.f64). */
+int mpg_gravshort_fill_ntab(mpg_engine *eng, int window_type, double Asmth, const double *table, int nrows);
+/* gravpm_init_periodic, libgadget/gravpm.c:51-54 (-> petapm_init, petapm.c:105-223): creates the mesh and FFT plans. */
+int mpg_gravpm_init_periodic(mpg_engine *eng, double BoxSize, double Asmth, int Nmesh, double G);
+/* petapm_destroy, libgadget/petapm.c:225-232 */
+int mpg_petapm_destroy(mpg_engine *eng);
+/* init_forcetree_params, libgadget/forcetree.c:39-44 (node pool = factor * NumPart; the engine grows it on demand) */
+int mpg_init_forcetree_params(mpg_engine *eng, double TreeAllocFactor);
+
+/* ---- particle table view (host AoS) ---------------------------------------------------------- */
+/* Byte offsets into the caller's AoS record; -1 = field absent.  For struct particle_data
+ * (libgadget/partmanager.h:9-71; 160 bytes) use mpg_particle_view_reference_layout(). */
+typedef struct mpg_particle_view {
+    void *base;        /* &P[0] */
+    int64_t n;         /* PartManager->NumPart */
+    int64_t stride;    /* sizeof(struct particle_data) */
+    int32_t off_pos;   /* double[3]  Pos */
+    int32_t off_mass;  /* float      Mass */
+    int32_t off_flags; /* uint8 holding the bit-fields of partmanager.h:17-21: bit 0 IsGarbage, bit 1 Swallowed */
+    int32_t off_type;  /* uint8 Type (partmanager.h:30) */
+    int32_t off_accel; /* double[3]  FullTreeGravAccel */
+    int32_t off_gravpm;    /* double[3]  GravPM */
+    int32_t off_potential; /* double     Potential */
+    int32_t off_hsml;      /* double     Hsml */
+    int32_t off_vel;       /* double[3]  Vel */
+    int32_t off_pi;        /* int32      PI (slot index) */
+} mpg_particle_view;
+/* Fill the offsets for the reference's struct particle_data (partmanager.h:9-71, offsets verified in SURVEY 8(a)). */
+void mpg_particle_view_reference_layout(mpg_particle_view *v, void *P, int64_t NumPart);
+
+/* ---- host (drop-in) entry points ------------------------------------------------------------- */
+/* gravpm_force, libgadget/gravpm.c:61-119: zero GravPM, CIC deposit, r2c, Green's function, 4 x (transfer, c2r,
+ * CIC readout).  Writes P[i].GravPM[3] (=) and P[i].Potential (+=, as readout_potential does). */
+int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P);
+/* force_tree_full, libgadget/forcetree.c:110-128: tree of all particles with moments.  `mask` as ALLMASK etc.
+ * (forcetree.h:22-27); particles whose type bit is clear are left out. */
+int mpg_force_tree_full(mpg_engine *eng, const mpg_particle_view *P, double BoxSize);
+/* force_tree_rebuild_mask, libgadget/forcetree.c:151-166 */
+int mpg_force_tree_rebuild_mask(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, int mask);
+/* force_tree_free, libgadget/forcetree.c:1403-1413 */
+int mpg_force_tree_free(mpg_engine *eng);
+/* grav_short_tree, libgadget/gravshort-tree.c:96-154.  ActiveParticle == NULL means all particles
+ * (timestep.c:77-84).  AccelStore may be NULL.  When the tree holds all particles (full_particle_tree_flag)
+ * P[i].FullTreeGravAccel and P[i].Potential are updated as grav_short_postprocess does (gravshort.h:47-67).
+ * After the call TreeUseBH > 1 is reset to 0 (gravshort-tree.c:148-151). */
+int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                        double (*AccelStore)[3], double rho0);
+
+/* ---- device-resident entry points (inputs and outputs stay in HBM) ---------------------------- */
+/* Bind device arrays in the caller's particle order: pos[n][3] f64, mass[n] f32, type[n] u8 (NULL = all type 1).
+ * The arrays must stay valid until the next bind. */
+int mpg_dev_bind_particles(mpg_engine *eng, int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type,
+                           double BoxSize);
+/* gravpm_force on bound particles: d_gravpm[n][3] (=), d_potential[n] (+=; may be NULL). */
+int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential);
+/* force_tree_full / force_tree_rebuild_mask on bound particles. */
+int mpg_dev_force_tree_build(mpg_engine *eng, int mask);
+/* grav_short_tree on bound particles.  d_oldacc[n] = |FullTreeGravAccel + GravPM| / G (grav_get_abs_accel,
+ * gravshort.h:70-80) or NULL to have it computed from d_prev_accel[n][3] + d_gravpm[n][3].
+ * d_active: int32 target indices or NULL (all).  d_accel[n][3] receives G * Acc for every target;
+ * d_potential[n] (may be NULL) receives the post-processed potential. */
+int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm,
+                            const int *d_active, int64_t nactive, double *d_accel, double *d_potential, double rho0);
+
+/* ---- introspection (tests, bench roofline accounting) ----------------------------------------- */
+typedef struct mpg_tree_stats {
+    int64_t NumParticles; /* particles in the tree */
+    int64_t numnodes;     /* live nodes */
+    int64_t numleaves;
+    int32_t maxlevel;
+    double root_mass, root_cofm[3], root_hmax;
+} mpg_tree_stats;
+int mpg_tree_get_stats(mpg_engine *eng, mpg_tree_stats *st);
+/* Copy the node table to host arrays (each may be NULL): level[i], center[i][3], len[i], cofm[i][3], mass[i],
+ * hmax[i], sibling[i] (-1 = none), pstart[i], pcount[i] (0 for internal nodes).  Nodes are in depth-first
+ * pre-order, children in octant order x | y<<1 | z<<2 (forcetree.c:278-284). */
+int mpg_tree_export(mpg_engine *eng, int32_t *level, double *center, double *len, double *cofm, double *mass, double *hmax,
+                    int32_t *sibling, int32_t *pstart, int32_t *pcount);
+/* Tree-order permutation: order[k] = caller index of the k-th particle in tree order (n entries). */
+int mpg_tree_export_order(mpg_engine *eng, int32_t *order);
+/* Walk counters of the last grav_short_tree: [0] particle-particle interactions (= the reference's Ninteractions,
+ * treewalk.c:904-912), [1] nodes visited, [2] nodes used unopened, [3] targets. */
+int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[4]);
+/* Per-phase device times (ms, HIP events on the engine stream) of the last call of each phase. */
+typedef struct mpg_phase_times {
+    float pm_deposit, pm_fft, pm_transfer, pm_readout, pm_total;
+    float tree_keys, tree_sort, tree_nodes, tree_moments, tree_total;
+    float walk;
+    int32_t walk_launches;
+} mpg_phase_times;
+int mpg_get_phase_times(mpg_engine *eng, mpg_phase_times *t);
+/* Enable (1) / disable (0) event timing + walk counters (counters cost a few % in the walk kernel). */
+int mpg_set_instrumentation(mpg_engine *eng, int timing, int counters);
+/* Tuning knob of the walk kernel: the node phase keeps running while at least `thresh` lanes of a wave are
+ * still searching for work (1, 8, 16, 24, 32 or 48; default 8).  Results do not depend on it. */
+int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPGADGET_HIP_H */

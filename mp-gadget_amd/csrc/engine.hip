@@ -1,0 +1,654 @@
+// engine.hip -- C-ABI (include/mpgadget_hip.h) and host-side orchestration of the gfx950 TreePM engine.
+//
+// Host side mirrors the reference's call sequence: gravpm_force (gravpm.c:61-119), force_tree_full
+// (forcetree.c:110-128), grav_short_tree (gravshort-tree.c:96-154) with fill / reduce / postprocess of
+// gravshort.h:47-96.  Every entry point catches mpg::Error and returns non-zero (the reference has no
+// return codes here; the in-tree shim maps failures to endrun()).  There is no CPU fallback anywhere:
+// without a HIP device mpg_engine_create fails.
+#include "../../include/mpgadget_hip.h"
+#include "grav_walk.h"
+#include "mpg_common.h"
+#include "pm.h"
+#include "tree_build.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace mpg;
+
+static thread_local std::string g_err;
+
+struct mpg_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // module state (static variables of gravshort-tree.c:30-32, gravity.c:20, forcetree.c:30-37)
+    mpg_gravshort_tree_params treepar{0.002, 0.175, 0.9, 2, 6.0, 1.0 / 30.};
+    double GravitySoftening = 0;
+    double TreeAllocFactor = 0.9;
+    bool have_tab = false;
+    double tab_dx = 0.02935420743639786;
+    DevBuf<float> tab_force, tab_pot;
+    // subsystems
+    PMesh pm;
+    TreeBuilder tree;
+    bool tree_allocated = false;
+    bool full_particle_tree = false;
+    int tree_mask = 63;
+    EventTimer timer;
+    bool count = false;
+    int walk_thresh = 8;
+    DevBuf<unsigned long long> counters;
+    int64_t last_targets = 0;
+    // bound device particles (caller order)
+    int64_t n = 0;
+    const double *d_pos = nullptr;
+    const float *d_mass = nullptr;
+    const uint8_t *d_type = nullptr;
+    double box = 0;
+    // staging for the host (AoS) path
+    DevBuf<double> s_pos, s_accel, s_gravpm, s_pot, s_prev, s_old;
+    DevBuf<float> s_mass;
+    DevBuf<uint8_t> s_type;
+    DevBuf<int> s_active;
+    std::vector<double> h_d;
+    std::vector<float> h_f;
+    std::vector<uint8_t> h_b;
+};
+
+#define API_BEGIN try {
+#define API_END                      \
+    }                                \
+    catch(const std::exception &e) { \
+        g_err = e.what();            \
+        return 1;                    \
+    }                                \
+    g_err.clear();                   \
+    return 0;
+
+extern "C" {
+
+const char *mpg_last_error(void) { return g_err.c_str(); }
+const char *mpg_version(void) { return "mpgadget_hip 0.1 (gfx950; TreePM gravity: PM + tree + short-range walk)"; }
+
+int mpg_engine_create(mpg_engine **out, int device)
+{
+    API_BEGIN
+    MPG_CHECK(out != nullptr, "mpg_engine_create: null output pointer");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if(e != hipSuccess || ndev <= 0)
+        fail(__FILE__, __LINE__, "mpg_engine_create: no HIP device available (this engine has no CPU path)");
+    MPG_CHECK(device >= 0 && device < ndev, "mpg_engine_create: bad device index");
+    MPG_HIP(hipSetDevice(device));
+    mpg_engine *eng = new mpg_engine();
+    eng->device = device;
+    MPG_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+    eng->own_stream = true;
+    eng->counters.reserve(4);
+    *out = eng;
+    API_END
+}
+
+void mpg_engine_destroy(mpg_engine *eng)
+{
+    if(!eng)
+        return;
+    (void)hipSetDevice(eng->device);
+    (void)hipStreamSynchronize(eng->stream);
+    eng->pm.destroy();
+    if(eng->own_stream && eng->stream)
+        (void)hipStreamDestroy(eng->stream);
+    delete eng;
+}
+
+int mpg_engine_set_stream(mpg_engine *eng, void *hip_stream)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    if(eng->own_stream && eng->stream) {
+        MPG_HIP(hipStreamSynchronize(eng->stream));
+        MPG_HIP(hipStreamDestroy(eng->stream));
+    }
+    if(hip_stream) {
+        eng->stream = (hipStream_t)hip_stream;
+        eng->own_stream = false;
+    }
+    else {
+        MPG_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+        eng->own_stream = true;
+    }
+    API_END
+}
+
+void *mpg_engine_get_stream(mpg_engine *eng) { return eng ? (void *)eng->stream : nullptr; }
+
+int mpg_engine_synchronize(mpg_engine *eng)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    API_END
+}
+
+int mpg_set_gravshort_treepar(mpg_engine *eng, const mpg_gravshort_tree_params *par)
+{
+    API_BEGIN
+    MPG_CHECK(eng && par, "null argument");
+    eng->treepar = *par;
+    API_END
+}
+
+int mpg_get_gravshort_treepar(mpg_engine *eng, mpg_gravshort_tree_params *par)
+{
+    API_BEGIN
+    MPG_CHECK(eng && par, "null argument");
+    *par = eng->treepar;
+    API_END
+}
+
+int mpg_gravshort_set_softenings(mpg_engine *eng, double MeanSeparation)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->GravitySoftening = eng->treepar.FractionalGravitySoftening * MeanSeparation; // gravshort-tree.c:47
+    API_END
+}
+
+double mpg_force_softening(mpg_engine *eng) { return eng ? 2.8 * eng->GravitySoftening : 0.0; } // gravshort-tree.c:37-41
+
+int mpg_gravshort_fill_ntab(mpg_engine *eng, int window_type, double Asmth, const double *table, int nrows)
+{
+    API_BEGIN
+    MPG_CHECK(eng && table, "null argument");
+    MPG_CHECK(nrows == NTAB, "gravshort_fill_ntab: the short-range table must have 512 rows");
+    MPG_CHECK(window_type == 0 || window_type == 1, "gravshort_fill_ntab: unknown ShortRangeForceWindowType");
+    if(window_type == 0 && Asmth != 1.5) // gravity.c:25-29
+        fail(__FILE__, __LINE__, "The short range force window is calibrated for Asmth = 1.5, but running with " + std::to_string(Asmth));
+    std::vector<float> f(NTAB), p(NTAB);
+    for(int i = 0; i < NTAB; i++) {
+        const double u = table[5 * i + 0] * 0.5 / Asmth;
+        if(window_type == 0) {
+            f[i] = (float)table[5 * i + 2];
+            p[i] = (float)table[5 * i + 1];
+        }
+        else {
+            f[i] = (float)(erfc(u) + 2.0 * u / sqrt(M_PI) * exp(-u * u));
+            p[i] = (float)erfc(u);
+        }
+    }
+    eng->tab_dx = table[5 * 1 + 0];
+    eng->tab_force.reserve(NTAB);
+    eng->tab_pot.reserve(NTAB);
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_HIP(hipMemcpy(eng->tab_force.p, f.data(), NTAB * sizeof(float), hipMemcpyHostToDevice));
+    MPG_HIP(hipMemcpy(eng->tab_pot.p, p.data(), NTAB * sizeof(float), hipMemcpyHostToDevice));
+    eng->have_tab = true;
+    API_END
+}
+
+int mpg_gravpm_init_periodic(mpg_engine *eng, double BoxSize, double Asmth, int Nmesh, double G)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->pm.init(BoxSize, Asmth, Nmesh, G, eng->stream);
+    API_END
+}
+
+int mpg_petapm_destroy(mpg_engine *eng)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->pm.destroy();
+    API_END
+}
+
+int mpg_init_forcetree_params(mpg_engine *eng, double TreeAllocFactor)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->TreeAllocFactor = TreeAllocFactor;
+    API_END
+}
+
+void mpg_particle_view_reference_layout(mpg_particle_view *v, void *P, int64_t NumPart)
+{
+    // struct particle_data, partmanager.h:9-71 (160 bytes; offsets as measured in SURVEY 8(a))
+    v->base = P;
+    v->n = NumPart;
+    v->stride = 160;
+    v->off_pos = 0;
+    v->off_mass = 28;
+    v->off_pi = 32;
+    v->off_flags = 36;
+    v->off_type = 39;
+    v->off_vel = 40;
+    v->off_accel = 64;
+    v->off_gravpm = 88;
+    v->off_hsml = 120;
+    v->off_potential = 152;
+}
+
+/* ------------------------------ device-resident path ------------------------------ */
+
+int mpg_dev_bind_particles(mpg_engine *eng, int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, double BoxSize)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_CHECK(n >= 0 && (n == 0 || (d_pos && d_mass)), "mpg_dev_bind_particles: null particle arrays");
+    MPG_CHECK(BoxSize > 0, "mpg_dev_bind_particles: BoxSize must be positive");
+    eng->n = n;
+    eng->d_pos = d_pos;
+    eng->d_mass = d_mass;
+    eng->d_type = d_type;
+    eng->box = BoxSize;
+    API_END
+}
+
+int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_gravpm, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->pm.have_plans, "gravpm_force called before gravpm_init_periodic");
+    MPG_CHECK(eng->pm.box == eng->box, "gravpm_force: BoxSize of the mesh differs from the bound particles");
+    eng->pm.force(eng->n, eng->d_pos, eng->d_mass, nullptr, d_gravpm, d_potential, eng->stream, &eng->timer);
+    API_END
+}
+
+int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
+    eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+    if(eng->timer.enabled)
+        eng->timer.t.tree_total = eng->timer.t.tree_keys + eng->timer.t.tree_sort + eng->timer.t.tree_nodes + eng->timer.t.tree_moments;
+    eng->tree_allocated = true;
+    eng->tree_mask = mask;
+    // full_particle_tree_flag (forcetree.c:127,164-165): all particle types are in the tree
+    eng->full_particle_tree = (eng->tree.npart == eng->n);
+    API_END
+}
+
+static GravParams make_gp(mpg_engine *eng, double rho0)
+{
+    GravParams gp{};
+    MPG_CHECK(eng->pm.nmesh > 0, "grav_short_tree needs gravpm_init_periodic first (cell size, Asmth, G)");
+    MPG_CHECK(eng->have_tab, "grav_short_tree called before gravshort_fill_ntab");
+    const double cellsize = eng->tree.box / eng->pm.nmesh;   // gravshort-tree.c:101
+    gp.box = eng->tree.box;
+    gp.invbox = 1.0 / gp.box;
+    gp.rcut = eng->treepar.Rcut * eng->pm.Asmth * cellsize;  // :102
+    gp.rcut2 = gp.rcut * gp.rcut;
+    gp.h = 2.8 * eng->GravitySoftening;
+    MPG_CHECK(gp.h > 0, "grav_short_tree called before gravshort_set_softenings");
+    gp.hinv = 1.0 / gp.h;
+    gp.h3inv = 1.0 / gp.h / gp.h / gp.h;
+    gp.inv_cell_dx = 1.0 / (cellsize * eng->tab_dx);
+    gp.errtol = eng->treepar.ErrTolForceAcc;
+    gp.use_bh = eng->treepar.TreeUseBH != 0;
+    // gravshort-tree.c:266-270
+    gp.bhangle2 = eng->treepar.BHOpeningAngle * eng->treepar.BHOpeningAngle;
+    if(eng->treepar.TreeUseBH == 0)
+        gp.bhangle2 = eng->treepar.MaxBHOpeningAngle * eng->treepar.MaxBHOpeningAngle;
+    gp.G = eng->pm.G;
+    gp.cbrtrho0 = pow(rho0, 1.0 / 3);
+    gp.full_tree = eng->full_particle_tree;
+    return gp;
+}
+
+int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm,
+                            const int *d_active, int64_t nactive, double *d_accel, double *d_potential, double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_accel, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->tree_allocated && eng->tree.has_moments, "Gravtree called before tree moments computed!"); // gravshort-tree.c:113-114
+    const GravParams gp = make_gp(eng, rho0);
+    WalkIO io;
+    io.targets = d_active;
+    if(d_active)
+        io.ntargets = nactive;
+    else {
+        // ActiveParticle == NULL: all particles (timestep.c:77-84).  When the tree holds them all, walk in tree order.
+        MPG_CHECK(eng->tree.npart == eng->n, "grav_short_tree with ActiveParticle == NULL needs a tree of all particles "
+                                              "(pass the active list for masked trees)");
+        io.ntargets = eng->tree.npart;
+    }
+    io.pos = eng->d_pos;
+    io.mass = eng->d_mass;
+    io.oldacc = d_oldacc;
+    io.prev_accel = d_prev_accel;
+    io.gravpm = d_gravpm;
+    io.accel = d_accel;
+    io.potential = eng->full_particle_tree ? d_potential : nullptr;
+    io.tab_force = eng->tab_force.p;
+    io.tab_pot = eng->tab_pot.p;
+    io.counters = eng->counters.p;
+    if(eng->count)
+        MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 4 * sizeof(unsigned long long), eng->stream));
+    eng->timer.start(eng->stream);
+    launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->walk_thresh, eng->stream);
+    eng->timer.lap(eng->stream, &eng->timer.t.walk);
+    eng->timer.t.walk_launches = 1;
+    eng->last_targets = io.ntargets;
+    // TreeUseBH > 1: Barnes-Hut on the first walk only (gravshort-tree.c:148-151)
+    if(eng->treepar.TreeUseBH > 1)
+        eng->treepar.TreeUseBH = 0;
+    API_END
+}
+
+/* ------------------------------ host (AoS) path ------------------------------ */
+
+static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
+{
+    MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
+    MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
+    const int64_t n = P->n;
+    eng->h_d.resize(3 * (size_t)n + 1);
+    eng->h_f.resize((size_t)n + 1);
+    eng->h_b.resize((size_t)n + 1);
+    const char *b = (const char *)P->base;
+    for(int64_t i = 0; i < n; i++) {
+        const char *rec = b + i * P->stride;
+        const double *pp = (const double *)(rec + P->off_pos);
+        eng->h_d[3 * i + 0] = pp[0];
+        eng->h_d[3 * i + 1] = pp[1];
+        eng->h_d[3 * i + 2] = pp[2];
+        eng->h_f[i] = *(const float *)(rec + P->off_mass);
+        uint8_t ty = P->off_type >= 0 ? (*(const uint8_t *)(rec + P->off_type) & 7) : 1;
+        // garbage / swallowed-BH particles never enter the tree (forcetree.c:806): give them type 7 (no mask bit)
+        if(P->off_flags >= 0) {
+            const uint8_t fl = *(const uint8_t *)(rec + P->off_flags);
+            if((fl & 1) || ((fl & 2) && ty == 5))
+                ty = 7;
+        }
+        eng->h_b[i] = ty;
+    }
+    eng->s_pos.reserve(3 * (size_t)n + 1);
+    eng->s_mass.reserve((size_t)n + 1);
+    eng->s_type.reserve((size_t)n + 1);
+    MPG_HIP(hipMemcpyAsync(eng->s_pos.p, eng->h_d.data(), 3 * n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(eng->s_mass.p, eng->h_f.data(), n * sizeof(float), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(eng->s_type.p, eng->h_b.data(), n * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    eng->n = n;
+    eng->d_pos = eng->s_pos.p;
+    eng->d_mass = eng->s_mass.p;
+    eng->d_type = eng->s_type.p;
+    eng->box = BoxSize;
+}
+
+int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->pm.have_plans, "gravpm_force called before gravpm_init_periodic");
+    MPG_CHECK(P->off_gravpm >= 0, "particle view needs GravPM");
+    stage_particles(eng, P, eng->pm.box);
+    const int64_t n = P->n;
+    eng->s_gravpm.reserve(3 * (size_t)n + 1);
+    const bool wantpot = P->off_potential >= 0;
+    std::vector<double> hp;
+    if(wantpot) {
+        // readout_potential accumulates into P.Potential (gravpm.c:499-501), which is NOT zeroed first
+        eng->s_pot.reserve((size_t)n + 1);
+        hp.resize(n);
+        for(int64_t i = 0; i < n; i++)
+            hp[i] = *(const double *)((const char *)P->base + i * P->stride + P->off_potential);
+        MPG_HIP(hipMemcpyAsync(eng->s_pot.p, hp.data(), n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    }
+    eng->pm.force(n, eng->d_pos, eng->d_mass, nullptr, eng->s_gravpm.p, wantpot ? eng->s_pot.p : nullptr, eng->stream, &eng->timer);
+    std::vector<double> hg(3 * (size_t)n);
+    MPG_HIP(hipMemcpyAsync(hg.data(), eng->s_gravpm.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    if(wantpot)
+        MPG_HIP(hipMemcpyAsync(hp.data(), eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    char *b = (char *)P->base;
+    for(int64_t i = 0; i < n; i++) {
+        double *g = (double *)(b + i * P->stride + P->off_gravpm);
+        g[0] = hg[3 * i + 0];
+        g[1] = hg[3 * i + 1];
+        g[2] = hg[3 * i + 2];
+        if(wantpot)
+            *(double *)(b + i * P->stride + P->off_potential) = hp[i];
+    }
+    API_END
+}
+
+int mpg_force_tree_rebuild_mask(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, int mask)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    stage_particles(eng, P, BoxSize);
+    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, BoxSize, eng->stream, &eng->timer);
+    eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+    eng->tree_allocated = true;
+    eng->tree_mask = mask;
+    eng->full_particle_tree = (eng->tree.npart == eng->n) || mask == 63;
+    API_END
+}
+
+int mpg_force_tree_full(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
+{
+    return mpg_force_tree_rebuild_mask(eng, P, BoxSize, 63 /* ALLMASK, forcetree.h:22 */);
+}
+
+int mpg_force_tree_free(mpg_engine *eng)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->tree_allocated = false;
+    eng->full_particle_tree = false;
+    eng->tree.has_moments = false;
+    API_END
+}
+
+int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                        double (*AccelStore)[3], double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->tree_allocated && eng->tree.has_moments, "Gravtree called before tree moments computed!");
+    MPG_CHECK(P->n == eng->n, "grav_short_tree: particle table changed size since the tree was built");
+    MPG_CHECK(P->off_accel >= 0 && P->off_gravpm >= 0, "particle view needs FullTreeGravAccel and GravPM");
+    const int64_t n = P->n;
+    const char *b = (const char *)P->base;
+    // fill: OldAcc = |FullTreeGravAccel + GravPM| / G (grav_short_copy, gravshort.h:82-86)
+    std::vector<double> old(n > 0 ? n : 1);
+    const double G = eng->pm.G;
+    for(int64_t i = 0; i < n; i++) {
+        const double *a = (const double *)(b + i * P->stride + P->off_accel);
+        const double *g = (const double *)(b + i * P->stride + P->off_gravpm);
+        double s = 0;
+        for(int j = 0; j < 3; j++) {
+            const double ax = a[j] + g[j];
+            s += ax * ax;
+        }
+        old[i] = sqrt(s) / G;
+    }
+    eng->s_old.reserve((size_t)n + 1);
+    eng->s_accel.reserve(3 * (size_t)n + 1);
+    eng->s_pot.reserve((size_t)n + 1);
+    MPG_HIP(hipMemcpyAsync(eng->s_old.p, old.data(), n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    const bool full = eng->full_particle_tree;
+    const bool wantpot = full && P->off_potential >= 0;
+    MPG_HIP(hipMemsetAsync(eng->s_accel.p, 0, 3 * n * sizeof(double), eng->stream));
+    int rc = mpg_dev_grav_short_tree(eng, eng->s_old.p, nullptr, nullptr, d_act, NumActiveParticle, eng->s_accel.p,
+                                     wantpot ? eng->s_pot.p : nullptr, rho0);
+    if(rc)
+        throw Error(g_err);
+    std::vector<double> ha(3 * (size_t)n + 1), hp(n > 0 ? n : 1);
+    MPG_HIP(hipMemcpyAsync(ha.data(), eng->s_accel.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    if(wantpot)
+        MPG_HIP(hipMemcpyAsync(hp.data(), eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    const int64_t nt = ActiveParticle ? NumActiveParticle : n;
+    char *wb = (char *)P->base;
+    for(int64_t k = 0; k < nt; k++) {
+        const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+        if(AccelStore) {
+            AccelStore[i][0] = ha[3 * i + 0];
+            AccelStore[i][1] = ha[3 * i + 1];
+            AccelStore[i][2] = ha[3 * i + 2];
+        }
+        if(full) { // gravshort.h:54-66
+            double *a = (double *)(wb + i * P->stride + P->off_accel);
+            a[0] = ha[3 * i + 0];
+            a[1] = ha[3 * i + 1];
+            a[2] = ha[3 * i + 2];
+            if(wantpot)
+                *(double *)(wb + i * P->stride + P->off_potential) = hp[i];
+        }
+    }
+    API_END
+}
+
+/* ------------------------------ introspection ------------------------------ */
+
+int mpg_tree_get_stats(mpg_engine *eng, mpg_tree_stats *st)
+{
+    API_BEGIN
+    MPG_CHECK(eng && st, "null argument");
+    MPG_CHECK(eng->tree_allocated, "no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    const TreeBuilder &t = eng->tree;
+    st->NumParticles = t.npart;
+    st->numnodes = t.nnodes;
+    st->maxlevel = t.maxlevel;
+    std::vector<NodeLink> lk(t.nnodes);
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    MPG_HIP(hipMemcpy(lk.data(), t.link.p, t.nnodes * sizeof(NodeLink), hipMemcpyDeviceToHost));
+    int64_t nl = 0;
+    for(auto &l : lk)
+        nl += l.pcount > 0;
+    st->numleaves = nl;
+    Src4 root{};
+    if(t.has_moments)
+        MPG_HIP(hipMemcpy(&root, t.src.p + t.npart, sizeof(Src4), hipMemcpyDeviceToHost));
+    st->root_mass = root.m;
+    st->root_cofm[0] = root.x;
+    st->root_cofm[1] = root.y;
+    st->root_cofm[2] = root.z;
+    st->root_hmax = 0;
+    if(t.has_hmax)
+        MPG_HIP(hipMemcpy(&st->root_hmax, t.hmax.p, sizeof(double), hipMemcpyDeviceToHost));
+    API_END
+}
+
+int mpg_tree_export(mpg_engine *eng, int32_t *level, double *center, double *len, double *cofm, double *mass, double *hmax,
+                    int32_t *sibling, int32_t *pstart, int32_t *pcount)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_CHECK(eng->tree_allocated, "no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    const TreeBuilder &t = eng->tree;
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    std::vector<NodeLink> lk(t.nnodes);
+    std::vector<NodeGeo> g(t.nnodes);
+    std::vector<Src4> m(t.nnodes);
+    MPG_HIP(hipMemcpy(lk.data(), t.link.p, t.nnodes * sizeof(NodeLink), hipMemcpyDeviceToHost));
+    MPG_HIP(hipMemcpy(g.data(), t.geo.p, t.nnodes * sizeof(NodeGeo), hipMemcpyDeviceToHost));
+    if(t.has_moments)
+        MPG_HIP(hipMemcpy(m.data(), t.src.p + t.npart, t.nnodes * sizeof(Src4), hipMemcpyDeviceToHost));
+    std::vector<double> hm;
+    if(hmax && t.has_hmax) {
+        hm.resize(t.nnodes);
+        MPG_HIP(hipMemcpy(hm.data(), t.hmax.p, t.nnodes * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    for(int64_t j = 0; j < t.nnodes; j++) {
+        if(level)
+            level[j] = lk[j].level;
+        if(sibling)
+            sibling[j] = lk[j].sibling;
+        if(pstart)
+            pstart[j] = lk[j].pstart;
+        if(pcount)
+            pcount[j] = lk[j].pcount;
+        if(center) {
+            center[3 * j + 0] = g[j].cx;
+            center[3 * j + 1] = g[j].cy;
+            center[3 * j + 2] = g[j].cz;
+        }
+        if(len)
+            len[j] = g[j].len;
+        if(cofm) {
+            cofm[3 * j + 0] = m[j].x;
+            cofm[3 * j + 1] = m[j].y;
+            cofm[3 * j + 2] = m[j].z;
+        }
+        if(mass)
+            mass[j] = m[j].m;
+        if(hmax)
+            hmax[j] = hm.empty() ? 0.0 : hm[j];
+    }
+    API_END
+}
+
+int mpg_tree_export_order(mpg_engine *eng, int32_t *order)
+{
+    API_BEGIN
+    MPG_CHECK(eng && order, "null argument");
+    MPG_CHECK(eng->tree_allocated, "no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    MPG_HIP(hipMemcpy(order, eng->tree.idx_b.p, eng->tree.npart * sizeof(int32_t), hipMemcpyDeviceToHost));
+    API_END
+}
+
+int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[4])
+{
+    API_BEGIN
+    MPG_CHECK(eng && counters, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    unsigned long long c[4] = {0, 0, 0, 0};
+    MPG_HIP(hipMemcpy(c, eng->counters.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    counters[0] = (int64_t)c[0];
+    counters[1] = (int64_t)c[1];
+    counters[2] = (int64_t)c[2];
+    counters[3] = eng->last_targets;
+    API_END
+}
+
+int mpg_get_phase_times(mpg_engine *eng, mpg_phase_times *t)
+{
+    API_BEGIN
+    MPG_CHECK(eng && t, "null argument");
+    *t = eng->timer.t;
+    API_END
+}
+
+int mpg_set_instrumentation(mpg_engine *eng, int timing, int counters)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->timer.enabled = timing != 0;
+    eng->count = counters != 0;
+    API_END
+}
+
+/* tuning knob used by bench/tests: minimum number of walking lanes that keeps the node phase going */
+int mpg_set_walk_threshold(mpg_engine *eng, int thresh)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->walk_thresh = thresh;
+    API_END
+}
+
+} // extern "C"

@@ -1,0 +1,105 @@
+// mpg_common.h -- shared declarations of the gfx950 engine (internal; the public surface is include/mpgadget_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace mpg {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+[[noreturn]] inline void fail(const char *file, int line, const std::string &msg)
+{
+    char buf[64];
+    snprintf(buf, sizeof(buf), " [%s:%d]", file, line);
+    throw Error(msg + buf);
+}
+
+#define MPG_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if(_e != hipSuccess)                                                                            \
+            ::mpg::fail(__FILE__, __LINE__, std::string("HIP error: ") + hipGetErrorString(_e) + " in " #expr); \
+    } while(0)
+
+#define MPG_CHECK(cond, msg)                            \
+    do {                                                \
+        if(!(cond))                                     \
+            ::mpg::fail(__FILE__, __LINE__, (msg));     \
+    } while(0)
+
+// Growable device buffer (hipMalloc is slow: buffers are kept and only ever grown).
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n)
+    {
+        if(n <= cap)
+            return;
+        release();
+        size_t want = n + n / 16 + 64;
+        MPG_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void release()
+    {
+        if(p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+constexpr int MAXLEVEL = 21;      // octree levels below the root carried in a 63-bit key
+constexpr int NMAXCHILD = 8;      // particles per leaf, forcetree.h:13
+constexpr int NTAB = 512;         // rows of the short-range window table, gravity.c:16
+
+// 32-byte source record: a particle (x,y,z,mass) or a node's moments (cofm,mass).
+struct alignas(32) Src4 {
+    double x, y, z, m;
+};
+// Node geometry (geometric centre and side length), 32 bytes.
+struct alignas(32) NodeGeo {
+    double cx, cy, cz, len;
+};
+// Node links, 16 bytes.  Nodes are stored in depth-first pre-order: an internal node's first child is node+1.
+struct alignas(16) NodeLink {
+    int sibling; // next node when this one is skipped or used (-1: end of walk); NODE.sibling of forcetree.h:39
+    int pstart;  // first particle (tree order) below this node
+    int pcount;  // >0: leaf with that many particles (NodeChild.noccupied); 0: internal node
+    int level;   // depth (root = 0)
+};
+
+struct TreeView {
+    int64_t npart = 0;       // particles in the tree (tree order [0,npart))
+    int64_t nnodes = 0;
+    const Src4 *src = nullptr;     // [npart + nnodes]: particles then node moments
+    const NodeGeo *geo = nullptr;  // [nnodes]
+    const NodeLink *link = nullptr;// [nnodes]
+    const double *hmax = nullptr;  // [nnodes] or null
+    const int *order = nullptr;    // [npart] tree order -> caller index
+    double box = 0;
+};
+
+struct GravParams {
+    double box, invbox;
+    double rcut, rcut2;
+    double h, hinv, h3inv; // FORCE_SOFTENING and powers
+    double inv_cell_dx;    // 1 / (cellsize * table dx)
+    double errtol;         // ErrTolForceAcc
+    double bhangle2;       // opening angle squared in effect for this walk
+    double G;
+    double cbrtrho0;
+    int use_bh;            // TreeUseBH != 0
+    int full_tree;
+};
+
+} // namespace mpg

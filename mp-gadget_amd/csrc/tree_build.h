@@ -1,0 +1,79 @@
+// tree_build.h -- device oct-tree (see tree_build.hip)
+#pragma once
+#include "mpg_common.h"
+#include "../../include/mpgadget_hip.h"
+
+namespace mpg {
+
+// HIP-event stopwatch on the engine stream; fills mpg_phase_times fields.
+struct EventTimer {
+    mpg_phase_times t{};
+    bool enabled = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void init()
+    {
+        if(!e0) {
+            MPG_HIP(hipEventCreate(&e0));
+            MPG_HIP(hipEventCreate(&e1));
+        }
+    }
+    void start(hipStream_t st)
+    {
+        if(!enabled)
+            return;
+        init();
+        MPG_HIP(hipEventRecord(e0, st));
+    }
+    // store elapsed since the previous start/lap into *dst, then restart
+    void lap(hipStream_t st, float *dst)
+    {
+        if(!enabled)
+            return;
+        MPG_HIP(hipEventRecord(e1, st));
+        MPG_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        MPG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *dst = ms;
+        MPG_HIP(hipEventRecord(e0, st));
+    }
+    ~EventTimer()
+    {
+        if(e0)
+            (void)hipEventDestroy(e0);
+        if(e1)
+            (void)hipEventDestroy(e1);
+    }
+};
+
+struct TreeBuilder {
+    // inputs of the last build
+    int64_t ncaller = 0; // particles offered
+    int64_t npart = 0;   // particles in the tree (mask)
+    int64_t nnodes = 0;
+    int maxlevel = 0;
+    double box = 0;
+    bool has_moments = false, has_hmax = false;
+
+    DevBuf<uint64_t> keys_a, keys_b;
+    DevBuf<uint32_t> idx_a, idx_b; // idx_b: tree order -> caller index
+    DevBuf<uint8_t> leaflevel;
+    DevBuf<uint32_t> cnt, base;
+    DevBuf<int64_t> flags;
+    DevBuf<char> tmp;
+    DevBuf<Src4> src;
+    DevBuf<NodeGeo> geo;
+    DevBuf<NodeLink> link;
+    DevBuf<double> hmax;
+
+    // force_tree_build (forcetree.c:196-270) without moments
+    void build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box, hipStream_t st,
+               EventTimer *tm);
+    // force_tree_calc_moments (forcetree.c:170-183).  d_hsml_gasbh_treeorder: per tree-order particle, Hsml of
+    // gas/BH particles that are not hydro-active, negative otherwise; NULL = no hmax.
+    void calc_moments(const double *d_hsml_gasbh_treeorder, hipStream_t st, EventTimer *tm);
+    // hmax only (tree built without moments, force_tree_rebuild_mask + update_tree_hmax_father + calc_moments)
+    void calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st);
+    TreeView view() const;
+};
+
+} // namespace mpg

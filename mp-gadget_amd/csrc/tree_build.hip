@@ -1,0 +1,438 @@
+// tree_build.hip -- GPU construction of the reference's bucket oct-tree (libgadget/forcetree.c) for gfx950.
+//
+// The reference inserts particles one by one (forcetree.c:481-520) and merges per-thread sub-trees
+// (:526-650).  The resulting topology is canonical: a cell is an internal node iff it
+// holds more than NMAXCHILD=8 particles, children are the geometric octants (x | y<<1 | z<<2,
+// forcetree.c:278-284) with centre = parent centre +- len/4 and len/2 (:302-320), empty children are
+// pruned when moments are computed (:1032-1049), root len = 1.001*BoxSize centred on BoxSize/2 (:662-664).
+// This file builds exactly that node set without insertion:
+//   1. k_keys       per particle: 21-level octant path, obtained by replaying the reference's own
+//                   floating-point descent (Pos > centre; centre +- 0.25*len; len *= 0.5) so that every
+//                   octant decision is bit-identical to get_subnode();
+//   2. rocPRIM radix sort of (key, index);
+//   3. k_leaflevel  per sorted particle: depth of its leaf = the shallowest cell around it with <= 8
+//                   particles, from the common-prefix lengths with its +-8 neighbours;
+//   4. scan         depth-first pre-order node numbering: a leaf head emits the internal nodes that start
+//                   at it (levels common+1 .. leaf-1) followed by the leaf;
+//   5. k_fill_nodes geometry, particle ranges and `sibling` (= first node after the sub-tree);
+//   6. k_leaf_moments / k_internal_moments (bottom-up by level): mass, centre of mass, hmax
+//                   (forcetree.c:947-966, :985-1104).
+// Node numbering and in-leaf particle order differ from the reference (they also differ between two
+// reference runs with different thread counts); the node *set*, geometry and moments are the same.
+#include "tree_build.h"
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+namespace mpg {
+
+__device__ __forceinline__ int cpl_levels(uint64_t a, uint64_t b)
+{
+    // number of leading 3-bit octant digits two 63-bit keys share (bit 63 is always clear)
+    const uint64_t x = a ^ b;
+    const int lz = x ? __clzll((long long)x) : 64;
+    const int l = (lz - 1) / 3;
+    return l > MAXLEVEL ? MAXLEVEL : l;
+}
+
+__global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restrict__ pos, const uint8_t *__restrict__ type, int mask,
+                                              double box, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                                              unsigned long long *__restrict__ nexcluded)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const double x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
+    double cx = box / 2., cy = box / 2., cz = box / 2.;
+    double len = box * 1.001;
+    uint64_t key = 0;
+#pragma unroll 1
+    for(int l = 0; l < MAXLEVEL; l++) {
+        const double q = 0.25 * len;
+        const int bx = x > cx, by = y > cy, bz = z > cz;
+        key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+        cx += bx ? q : -q;
+        cy += by ? q : -q;
+        cz += bz ? q : -q;
+        len *= 0.5;
+    }
+    const int ty = type ? (type[i] & 7) : 1;
+    const bool in = ((1 << ty) & mask) != 0;
+    if(!in) {
+        key = ~0ull;
+        atomicAdd(nexcluded, 1ull);
+    }
+    keys[i] = key;
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_gather_src(int64_t n, const uint32_t *__restrict__ order, const double *__restrict__ pos,
+                                                    const float *__restrict__ mass, Src4 *__restrict__ src)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const int64_t i = order[k];
+    Src4 s;
+    s.x = pos[3 * i + 0];
+    s.y = pos[3 * i + 1];
+    s.z = pos[3 * i + 2];
+    s.m = (double)mass[i];
+    src[k] = s;
+}
+
+// flags[0]: error (too many coincident particles), flags[1]: max leaf level
+__global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__restrict__ keys, uint8_t *__restrict__ leaflevel,
+                                                   uint32_t *__restrict__ cnt, int *__restrict__ flags)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const uint64_t ki = keys[i];
+    int cl[9], cr[9];
+    cl[0] = cr[0] = MAXLEVEL + 1;
+#pragma unroll
+    for(int a = 1; a <= 8; a++) {
+        cl[a] = (i - a >= 0) ? cpl_levels(ki, keys[i - a]) : -1;
+        cr[a] = (i + a < n) ? cpl_levels(ki, keys[i + a]) : -1;
+    }
+    int best = -1;
+#pragma unroll
+    for(int a = 0; a <= 8; a++) {
+        const int m = cl[a] < cr[8 - a] ? cl[a] : cr[8 - a];
+        best = m > best ? m : best;
+    }
+    int L = best + 1; // shallowest level whose cell holds <= 8 particles
+    if(L > MAXLEVEL) {
+        flags[0] = 1;
+        L = MAXLEVEL;
+    }
+    leaflevel[i] = (uint8_t)L;
+    const int c = (i == 0) ? -1 : cl[1];
+    const bool head = (i == 0) || (c < L);
+    cnt[i] = head ? (uint32_t)(L - c) : 0u;
+    if(head)
+        atomicMax(&flags[1], L);
+}
+
+__global__ void __launch_bounds__(256) k_fill_nodes(int64_t n, const uint64_t *__restrict__ keys, const uint8_t *__restrict__ leaflevel,
+                                                    const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base, double box,
+                                                    NodeGeo *__restrict__ geo, NodeLink *__restrict__ link)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n || cnt[i] == 0)
+        return;
+    const uint64_t ki = keys[i];
+    const int L = leaflevel[i];
+    const int first = L - (int)cnt[i] + 1; // shallowest new level
+    // size of the leaf: particles up to the next head
+    int pc = 1;
+    while(i + pc < n && cnt[i + pc] == 0)
+        pc++;
+    double cx = box / 2., cy = box / 2., cz = box / 2.;
+    double len = box * 1.001;
+    for(int l = 0; l <= L; l++) {
+        if(l >= first) {
+            const int64_t j = (int64_t)base[i] + (l - first);
+            geo[j] = NodeGeo{cx, cy, cz, len};
+            NodeLink lk;
+            lk.level = l;
+            lk.pstart = (int)i;
+            int64_t e;
+            if(l == L) {
+                lk.pcount = pc;
+                e = i + pc;
+            }
+            else {
+                lk.pcount = 0;
+                // first particle after i that leaves this level-l cell: keys are sorted, binary search
+                const int shift = 3 * (MAXLEVEL - l);
+                const uint64_t pref = (l == 0) ? 0 : (ki >> shift);
+                int64_t lo = i + pc, hi = n; // everything in the leaf shares the prefix
+                while(lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    const uint64_t km = keys[mid];
+                    const bool same = (l == 0) ? true : ((km >> shift) == pref);
+                    if(same)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                e = lo;
+            }
+            lk.sibling = (e < n) ? (int)base[e] : -1;
+            link[j] = lk;
+        }
+        if(l < L) {
+            const int d = (int)((ki >> (3 * (MAXLEVEL - 1 - l))) & 7);
+            const double q = 0.25 * len;
+            cx += (d & 1) ? q : -q;
+            cy += (d & 2) ? q : -q;
+            cz += (d & 4) ? q : -q;
+            len *= 0.5;
+        }
+    }
+}
+
+// Leaf moments: add_particle_moment_to_node + force_update_particle_node (forcetree.c:947-966, :985-1004).
+// hsml/hact are in TREE order; hmax only counts gas/BH particles that are NOT hydro-active.
+__global__ void __launch_bounds__(256) k_leaf_moments(int64_t nnodes, int64_t npart, const NodeLink *__restrict__ link,
+                                                      const NodeGeo *__restrict__ geo, Src4 *__restrict__ src,
+                                                      const double *__restrict__ hsml_gasbh, double *__restrict__ hmax)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount == 0)
+        return;
+    double m = 0, sx = 0, sy = 0, sz = 0, hm = 0;
+    const NodeGeo g = geo[j];
+    for(int k = 0; k < lk.pcount; k++) {
+        const Src4 p = src[lk.pstart + k];
+        m += p.m;
+        sx += p.m * p.x;
+        sy += p.m * p.y;
+        sz += p.m * p.z;
+        if(hsml_gasbh) {
+            const double h = hsml_gasbh[lk.pstart + k]; // < 0: particle does not contribute (not gas/BH, or active)
+            if(h >= 0) {
+                hm = fmax(hm, fabs(p.x - g.cx) + h - g.len / 2.);
+                hm = fmax(hm, fabs(p.y - g.cy) + h - g.len / 2.);
+                hm = fmax(hm, fabs(p.z - g.cz) + h - g.len / 2.);
+            }
+        }
+    }
+    Src4 o;
+    if(m > 0) {
+        o.x = sx / m;
+        o.y = sy / m;
+        o.z = sz / m;
+    }
+    else {
+        o.x = g.cx;
+        o.y = g.cy;
+        o.z = g.cz;
+    }
+    o.m = m;
+    src[npart + j] = o;
+    if(hmax)
+        hmax[j] = hm;
+}
+
+// Internal moments of one level: force_update_node_recursive (forcetree.c:1081-1101): children in octant
+// order, mass-weighted centre of mass of the children's centres of mass, max of hmax.
+__global__ void __launch_bounds__(256) k_internal_moments(int64_t nnodes, int64_t npart, int level, const NodeLink *__restrict__ link,
+                                                          Src4 *__restrict__ src, double *__restrict__ hmax)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount != 0 || lk.level != level)
+        return;
+    double m = 0, sx = 0, sy = 0, sz = 0, hm = 0;
+    int c = (int)j + 1;
+    do {
+        const Src4 s = src[npart + c];
+        m += s.m;
+        sx += s.m * s.x;
+        sy += s.m * s.y;
+        sz += s.m * s.z;
+        if(hmax)
+            hm = fmax(hm, hmax[c]);
+        c = link[c].sibling;
+    } while(c != lk.sibling);
+    Src4 o;
+    o.m = m;
+    if(m > 0) {
+        o.x = sx / m;
+        o.y = sy / m;
+        o.z = sz / m;
+    }
+    else {
+        o.x = sx;
+        o.y = sy;
+        o.z = sz;
+    }
+    src[npart + j] = o;
+    if(hmax)
+        hmax[j] = hm;
+}
+
+__global__ void __launch_bounds__(256) k_only_hmax_leaf(int64_t nnodes, const NodeLink *__restrict__ link, const NodeGeo *__restrict__ geo,
+                                                        const Src4 *__restrict__ src, const double *__restrict__ hsml_gasbh,
+                                                        double *__restrict__ hmax)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount == 0)
+        return;
+    const NodeGeo g = geo[j];
+    double hm = 0;
+    for(int k = 0; k < lk.pcount; k++) {
+        const double h = hsml_gasbh[lk.pstart + k];
+        if(h >= 0) {
+            const Src4 p = src[lk.pstart + k];
+            hm = fmax(hm, fabs(p.x - g.cx) + h - g.len / 2.);
+            hm = fmax(hm, fabs(p.y - g.cy) + h - g.len / 2.);
+            hm = fmax(hm, fabs(p.z - g.cz) + h - g.len / 2.);
+        }
+    }
+    hmax[j] = hm;
+}
+
+__global__ void __launch_bounds__(256) k_only_hmax_internal(int64_t nnodes, int level, const NodeLink *__restrict__ link,
+                                                            double *__restrict__ hmax)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount != 0 || lk.level != level)
+        return;
+    double hm = 0;
+    int c = (int)j + 1;
+    do {
+        hm = fmax(hm, hmax[c]);
+        c = link[c].sibling;
+    } while(c != lk.sibling);
+    hmax[j] = hm;
+}
+
+static inline int nblk(int64_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box,
+                        hipStream_t st, EventTimer *tm)
+{
+    MPG_CHECK(n < (int64_t)1 << 31, "tree build: more than 2^31 particles on one GPU");
+    this->box = box;
+    this->ncaller = n;
+    has_moments = false;
+    has_hmax = false;
+    if(tm)
+        tm->start(st);
+    keys_a.reserve(n + 1);
+    keys_b.reserve(n + 1);
+    idx_a.reserve(n + 1);
+    idx_b.reserve(n + 1);
+    flags.reserve(8);
+    MPG_HIP(hipMemsetAsync(flags.p, 0, 8 * sizeof(int64_t), st));
+    unsigned long long *d_nexcl = (unsigned long long *)(flags.p + 4);
+    int *d_flags = (int *)flags.p;
+    if(n > 0)
+        hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_type, mask, box, keys_a.p, idx_a.p, d_nexcl);
+    if(tm)
+        tm->lap(st, &tm->t.tree_keys);
+    // --- sort
+    size_t tmpbytes = 0;
+    if(n > 0) {
+        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)n, 0, 64, st));
+        tmp.reserve(tmpbytes + 16);
+        MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)n, 0, 64, st));
+    }
+    unsigned long long nexcl = 0;
+    MPG_HIP(hipMemcpyAsync(&nexcl, d_nexcl, sizeof(nexcl), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipStreamSynchronize(st));
+    npart = n - (int64_t)nexcl;
+    if(tm)
+        tm->lap(st, &tm->t.tree_sort);
+    // --- leaf levels, node numbering
+    leaflevel.reserve(npart + 1);
+    cnt.reserve(npart + 1);
+    base.reserve(npart + 1);
+    int hflags[2] = {0, 0};
+    uint32_t lastbase = 0, lastcnt = 0;
+    if(npart > 0) {
+        hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags);
+        size_t sb = 0;
+        MPG_HIP(rocprim::exclusive_scan(nullptr, sb, cnt.p, base.p, 0u, (size_t)npart, rocprim::plus<uint32_t>(), st));
+        tmp.reserve(sb + 16);
+        MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, sb, cnt.p, base.p, 0u, (size_t)npart, rocprim::plus<uint32_t>(), st));
+        MPG_HIP(hipMemcpyAsync(hflags, d_flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(&lastbase, base.p + (npart - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(&lastcnt, cnt.p + (npart - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipStreamSynchronize(st));
+        MPG_CHECK(hflags[0] == 0, "tree build: more than 8 particles share one 2^-21 cell (coincident particles; the reference "
+                                  "aborts here too, forcetree.c:393-412)");
+        nnodes = (int64_t)lastbase + lastcnt;
+        maxlevel = hflags[1];
+    }
+    else {
+        // empty tree: a lone root leaf with no particles (forcetree.c:657-678)
+        nnodes = 1;
+        maxlevel = 0;
+    }
+    src.reserve(npart + nnodes + 1);
+    geo.reserve(nnodes + 1);
+    link.reserve(nnodes + 1);
+    if(npart > 0) {
+        hipLaunchKernelGGL(k_gather_src, dim3(nblk(npart)), dim3(256), 0, st, npart, idx_b.p, d_pos, d_mass, src.p);
+        hipLaunchKernelGGL(k_fill_nodes, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, base.p, box, geo.p,
+                           link.p);
+    }
+    else {
+        NodeGeo g{box / 2., box / 2., box / 2., box * 1.001};
+        NodeLink l{-1, 0, 0, 0};
+        Src4 s{box / 2., box / 2., box / 2., 0.0};
+        MPG_HIP(hipMemcpyAsync(geo.p, &g, sizeof(g), hipMemcpyHostToDevice, st));
+        MPG_HIP(hipMemcpyAsync(link.p, &l, sizeof(l), hipMemcpyHostToDevice, st));
+        MPG_HIP(hipMemcpyAsync(src.p, &s, sizeof(s), hipMemcpyHostToDevice, st));
+        MPG_HIP(hipStreamSynchronize(st));
+    }
+    if(tm)
+        tm->lap(st, &tm->t.tree_nodes);
+}
+
+void TreeBuilder::calc_moments(const double *d_hsml_gasbh_treeorder, hipStream_t st, EventTimer *tm)
+{
+    if(tm)
+        tm->start(st);
+    double *hm = nullptr;
+    if(d_hsml_gasbh_treeorder) {
+        hmax.reserve(nnodes + 1);
+        hm = hmax.p;
+    }
+    if(npart > 0) {
+        hipLaunchKernelGGL(k_leaf_moments, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, link.p, geo.p, src.p,
+                           d_hsml_gasbh_treeorder, hm);
+        for(int l = maxlevel - 1; l >= 0; l--)
+            hipLaunchKernelGGL(k_internal_moments, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, l, link.p, src.p, hm);
+    }
+    has_moments = true;
+    has_hmax = hm != nullptr;
+    if(tm)
+        tm->lap(st, &tm->t.tree_moments);
+}
+
+void TreeBuilder::calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st)
+{
+    hmax.reserve(nnodes + 1);
+    if(npart > 0) {
+        hipLaunchKernelGGL(k_only_hmax_leaf, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, link.p, geo.p, src.p, d_hsml_gasbh_treeorder,
+                           hmax.p);
+        for(int l = maxlevel - 1; l >= 0; l--)
+            hipLaunchKernelGGL(k_only_hmax_internal, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, l, link.p, hmax.p);
+    }
+    else
+        MPG_HIP(hipMemsetAsync(hmax.p, 0, sizeof(double), st));
+    has_hmax = true;
+}
+
+TreeView TreeBuilder::view() const
+{
+    TreeView v;
+    v.npart = npart;
+    v.nnodes = nnodes;
+    v.src = src.p;
+    v.geo = geo.p;
+    v.link = link.p;
+    v.hmax = has_hmax ? hmax.p : nullptr;
+    v.order = (const int *)idx_b.p;
+    v.box = box;
+    return v;
+}
+
+} // namespace mpg

@@ -1,0 +1,278 @@
+"""Host-side mirror of the reference's force-step interface over the C-ABI library (ctypes).
+
+The reference is C; on a machine with the reference toolchain the C-ABI of include/mpgadget_hip.h is bound
+by the in-tree shim of INTEGRATION.md.  This module is the same binding for Python callers (tests, bench):
+method names, argument meaning and error behaviour follow the reference entry points
+
+    gravpm_init_periodic / gravpm_force          libgadget/gravpm.c:51-119
+    force_tree_full / force_tree_rebuild_mask    libgadget/forcetree.c:110-166
+    grav_short_tree                              libgadget/gravshort-tree.c:96-154
+    set_gravshort_treepar / gravshort_set_softenings / gravshort_fill_ntab / FORCE_SOFTENING
+
+Errors raise EngineError (the reference calls endrun()).  There is no CPU fallback: if the HIP library is
+missing or no GPU is present, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpgadget_hip.so")
+TABLE_PATH = os.path.join(_HERE, "data", "shortrange_force_kernels.f64")
+
+# struct particle_data, libgadget/partmanager.h:9-71 (160 bytes)
+PARTICLE_DTYPE = np.dtype({
+    "names": ["Pos", "TopLeaf", "Mass", "PI", "Flags", "TimeBinHydro", "TimeBinGravity", "Type", "Vel",
+              "FullTreeGravAccel", "GravPM", "Ti_drift", "Hsml", "DtHsml", "ID", "GrNr", "Potential"],
+    "formats": [("<f8", 3), "<i4", "<f4", "<i4", "u1", "u1", "u1", "u1", ("<f8", 3), ("<f8", 3), ("<f8", 3), "<i8", "<f8",
+                "<f8", "<u8", "<i8", "<f8"],
+    "offsets": [0, 24, 28, 32, 36, 37, 38, 39, 40, 64, 88, 112, 120, 128, 136, 144, 152],
+    "itemsize": 160})
+
+SHORTRANGE_FORCE_WINDOW_TYPE_EXACT = 0   # gravity.h:24-27
+SHORTRANGE_FORCE_WINDOW_TYPE_ERFC = 1
+ALLMASK, GASMASK, DMMASK, NUMASK, STARMASK, BHMASK = 63, 1, 2, 4, 16, 32   # forcetree.h:22-27
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class TreeParams(C.Structure):
+    """struct gravshort_tree_params, gravity.h:9-22"""
+    _fields_ = [("ErrTolForceAcc", C.c_double), ("BHOpeningAngle", C.c_double), ("MaxBHOpeningAngle", C.c_double),
+                ("TreeUseBH", C.c_int), ("Rcut", C.c_double), ("FractionalGravitySoftening", C.c_double)]
+
+
+class ParticleView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("n", C.c_int64), ("stride", C.c_int64), ("off_pos", C.c_int32),
+                ("off_mass", C.c_int32), ("off_flags", C.c_int32), ("off_type", C.c_int32), ("off_accel", C.c_int32),
+                ("off_gravpm", C.c_int32), ("off_potential", C.c_int32), ("off_hsml", C.c_int32), ("off_vel", C.c_int32),
+                ("off_pi", C.c_int32)]
+
+
+class TreeStats(C.Structure):
+    _fields_ = [("NumParticles", C.c_int64), ("numnodes", C.c_int64), ("numleaves", C.c_int64), ("maxlevel", C.c_int32),
+                ("root_mass", C.c_double), ("root_cofm", C.c_double * 3), ("root_hmax", C.c_double)]
+
+
+class PhaseTimes(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("pm_deposit", "pm_fft", "pm_transfer", "pm_readout", "pm_total", "tree_keys",
+                                         "tree_sort", "tree_nodes", "tree_moments", "tree_total", "walk")] + \
+               [("walk_launches", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError("HIP engine library %s is missing: run `python __graft_entry__.py` (build()) first; "
+                          "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.mpg_last_error.restype = C.c_char_p
+    L.mpg_version.restype = C.c_char_p
+    L.mpg_force_softening.restype = C.c_double
+    L.mpg_force_softening.argtypes = [C.c_void_p]
+    L.mpg_engine_get_stream.restype = C.c_void_p
+    L.mpg_engine_get_stream.argtypes = [C.c_void_p]
+    L.mpg_engine_destroy.argtypes = [C.c_void_p]
+    L.mpg_engine_destroy.restype = None
+    _lib = L
+    return L
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor / raw int / None."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One engine per GPU (= per MPI rank in the reference's terms)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.mpg_engine_create(C.byref(h), int(device))
+        if rc:
+            raise EngineError(self.lib.mpg_last_error().decode())
+        self.h = h
+        self.device = device
+        self._table = None
+        self._keep = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _ck(self, rc):
+        if rc:
+            raise EngineError(self.lib.mpg_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mpg_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def version(self):
+        return self.lib.mpg_version().decode()
+
+    def synchronize(self):
+        self._ck(self.lib.mpg_engine_synchronize(self.h))
+
+    def set_stream(self, raw_stream):
+        self._ck(self.lib.mpg_engine_set_stream(self.h, C.c_void_p(raw_stream)))
+
+    def get_stream(self):
+        return self.lib.mpg_engine_get_stream(self.h)
+
+    def set_instrumentation(self, timing=True, counters=False):
+        self._ck(self.lib.mpg_set_instrumentation(self.h, int(timing), int(counters)))
+
+    def set_walk_threshold(self, thresh):
+        self._ck(self.lib.mpg_set_walk_threshold(self.h, int(thresh)))
+
+    # ------------------------------------------------------------------ module parameters
+    def set_gravshort_treepar(self, ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2,
+                              Rcut=6.0, FractionalGravitySoftening=1. / 30.):
+        p = TreeParams(ErrTolForceAcc, BHOpeningAngle, MaxBHOpeningAngle, TreeUseBH, Rcut, FractionalGravitySoftening)
+        self._ck(self.lib.mpg_set_gravshort_treepar(self.h, C.byref(p)))
+
+    def get_gravshort_treepar(self):
+        p = TreeParams()
+        self._ck(self.lib.mpg_get_gravshort_treepar(self.h, C.byref(p)))
+        return p
+
+    def gravshort_set_softenings(self, MeanSeparation):
+        self._ck(self.lib.mpg_gravshort_set_softenings(self.h, C.c_double(MeanSeparation)))
+
+    def FORCE_SOFTENING(self):
+        return self.lib.mpg_force_softening(self.h)
+
+    def gravshort_fill_ntab(self, ShortRangeForceWindowType=SHORTRANGE_FORCE_WINDOW_TYPE_EXACT, Asmth=1.5):
+        if self._table is None:
+            self._table = np.fromfile(TABLE_PATH, dtype="<f8")
+            if self._table.size != 512 * 5:
+                raise EngineError("corrupt short-range table " + TABLE_PATH)
+        self._ck(self.lib.mpg_gravshort_fill_ntab(self.h, int(ShortRangeForceWindowType), C.c_double(Asmth),
+                                                  self._table.ctypes.data_as(C.c_void_p), 512))
+
+    def gravpm_init_periodic(self, BoxSize, Asmth, Nmesh, G):
+        self._ck(self.lib.mpg_gravpm_init_periodic(self.h, C.c_double(BoxSize), C.c_double(Asmth), int(Nmesh), C.c_double(G)))
+
+    def petapm_destroy(self):
+        self._ck(self.lib.mpg_petapm_destroy(self.h))
+
+    def init_forcetree_params(self, TreeAllocFactor):
+        self._ck(self.lib.mpg_init_forcetree_params(self.h, C.c_double(TreeAllocFactor)))
+
+    # ------------------------------------------------------------------ host (AoS, drop-in) path
+    def _view(self, P):
+        if P.dtype != PARTICLE_DTYPE or not P.flags["C_CONTIGUOUS"]:
+            raise EngineError("P must be a contiguous array of PARTICLE_DTYPE (struct particle_data)")
+        v = ParticleView()
+        self.lib.mpg_particle_view_reference_layout(C.byref(v), C.c_void_p(P.ctypes.data), C.c_int64(len(P)))
+        return v
+
+    def gravpm_force(self, P):
+        v = self._view(P)
+        self._ck(self.lib.mpg_gravpm_force(self.h, C.byref(v)))
+
+    def force_tree_full(self, P, BoxSize):
+        v = self._view(P)
+        self._ck(self.lib.mpg_force_tree_full(self.h, C.byref(v), C.c_double(BoxSize)))
+
+    def force_tree_rebuild_mask(self, P, BoxSize, mask):
+        v = self._view(P)
+        self._ck(self.lib.mpg_force_tree_rebuild_mask(self.h, C.byref(v), C.c_double(BoxSize), int(mask)))
+
+    def force_tree_free(self):
+        self._ck(self.lib.mpg_force_tree_free(self.h))
+
+    def grav_short_tree(self, P, ActiveParticle=None, AccelStore=None, rho0=0.0):
+        v = self._view(P)
+        act = None
+        nact = 0
+        if ActiveParticle is not None:
+            act = np.ascontiguousarray(ActiveParticle, np.int32)
+            nact = len(act)
+        if AccelStore is not None and (AccelStore.dtype != np.float64 or AccelStore.shape != (len(P), 3)
+                                       or not AccelStore.flags["C_CONTIGUOUS"]):
+            raise EngineError("AccelStore must be a contiguous float64 [NumPart,3] array")
+        self._ck(self.lib.mpg_grav_short_tree(self.h, C.byref(v), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                              C.c_int64(nact),
+                                              None if AccelStore is None else AccelStore.ctypes.data_as(C.c_void_p),
+                                              C.c_double(rho0)))
+
+    # ------------------------------------------------------------------ device-resident path (torch tensors on this GPU)
+    def dev_bind_particles(self, pos, mass, BoxSize, type=None):
+        """pos [n,3] float64, mass [n] float32, type [n] uint8 or None: CUDA(HIP) tensors, contiguous."""
+        n = pos.shape[0]
+        self._keep["bind"] = (pos, mass, type)
+        self._ck(self.lib.mpg_dev_bind_particles(self.h, C.c_int64(n), _ptr(pos), _ptr(mass), _ptr(type), C.c_double(BoxSize)))
+
+    def dev_gravpm_force(self, gravpm, potential=None):
+        self._ck(self.lib.mpg_dev_gravpm_force(self.h, _ptr(gravpm), _ptr(potential)))
+
+    def dev_force_tree_build(self, mask=ALLMASK):
+        self._ck(self.lib.mpg_dev_force_tree_build(self.h, int(mask)))
+
+    def dev_grav_short_tree(self, accel, oldacc=None, prev_accel=None, gravpm=None, active=None, potential=None, rho0=0.0):
+        nact = 0 if active is None else active.shape[0]
+        self._ck(self.lib.mpg_dev_grav_short_tree(self.h, _ptr(oldacc), _ptr(prev_accel), _ptr(gravpm), _ptr(active),
+                                                  C.c_int64(nact), _ptr(accel), _ptr(potential), C.c_double(rho0)))
+
+    # ------------------------------------------------------------------ introspection
+    def tree_stats(self):
+        st = TreeStats()
+        self._ck(self.lib.mpg_tree_get_stats(self.h, C.byref(st)))
+        return st
+
+    def tree_export(self):
+        st = self.tree_stats()
+        n = st.numnodes
+        d = dict(level=np.zeros(n, np.int32), center=np.zeros((n, 3)), len=np.zeros(n), cofm=np.zeros((n, 3)),
+                 mass=np.zeros(n), hmax=np.zeros(n), sibling=np.zeros(n, np.int32), pstart=np.zeros(n, np.int32),
+                 pcount=np.zeros(n, np.int32))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._ck(self.lib.mpg_tree_export(self.h, p(d["level"]), p(d["center"]), p(d["len"]), p(d["cofm"]), p(d["mass"]),
+                                          p(d["hmax"]), p(d["sibling"]), p(d["pstart"]), p(d["pcount"])))
+        order = np.zeros(st.NumParticles, np.int32)
+        self._ck(self.lib.mpg_tree_export_order(self.h, order.ctypes.data_as(C.c_void_p)))
+        d["order"] = order
+        return d
+
+    def walk_counters(self):
+        c = (C.c_int64 * 4)()
+        self._ck(self.lib.mpg_walk_get_counters(self.h, c))
+        return dict(pp=c[0], nodes_visited=c[1], nodes_used=c[2], targets=c[3])
+
+    def phase_times(self):
+        t = PhaseTimes()
+        self._ck(self.lib.mpg_get_phase_times(self.h, C.byref(t)))
+        return t.as_dict()
+
+
+def make_particles(pos, mass, type=1):
+    """Build a struct particle_data table (PARTICLE_DTYPE) from positions and masses (test/bench helper)."""
+    P = np.zeros(len(pos), dtype=PARTICLE_DTYPE)
+    P["Pos"] = pos
+    P["Mass"] = mass
+    P["Type"] = type
+    P["ID"] = np.arange(len(pos), dtype=np.uint64)
+    return P

@@ -1,0 +1,36 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module("mp-gadget_amd")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The strict-IEEE CPU oracle (test infrastructure)."""
+    from oracle import oracle as O
+    o = O.Oracle(fast=False)
+    o.fill_ntab(0, 1.5)
+    return o
+
+
+@pytest.fixture(scope="session")
+def engine(pkg):
+    """One HIP engine on cuda:0 for the whole session.  Fails (does not skip) if the library or GPU is missing."""
+    e = pkg.Engine(0)
+    e.gravshort_fill_ntab(0, 1.5)
+    yield e
+    e.close()
