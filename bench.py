@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-updates/s of one TreePM gravity force step on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over the synchronised particle set, all particles active (a PM step of
+run.c:522-548): gravpm_force (CIC deposit, 5 FFTs, transfers, readout) + force_tree_full (tree build + moments)
++ grav_short_tree (short-range walk with the relative opening criterion, OldAcc from the previous step).
+Inputs are resident in HBM when the timed region starts.
+
+N = 1 : 256^3 dark-matter particles, Nmesh = 512 (BASELINE.json configs[1]), S-grid synthetic ICs.
+N > 1 : weak scaling, ~256^3 particles per GPU (n = 320 / 400 / 512 per dimension for N = 2 / 4 / 8, Nmesh = 2n).
+        Every rank holds the particle set; targets are sharded over ranks as contiguous tree-order (Morton) ranges
+        and the accelerations are exchanged with one RCCL all-gather per step.
+
+One JSON line is printed by rank 0 (contract of the task statement), with `roofline` for the dominant kernel
+(the short-range walk; HIP events on the engine stream inside the timed region) and `cpu_baseline` (the oracle
+built with the reference's compiler flags, timed on the host cores of this box on a bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+G = 43.0071
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=0, help="particles per dimension (default: 256 per GPU, weak scaling)")
+    ap.add_argument("--ic", default="s_grid", choices=["s_grid", "s_zel", "s_clust"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="targets walked by the CPU baseline")
+    ap.add_argument("--thresh", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    pkg = importlib.import_module("mp-gadget_amd")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / 16)) * 16)
+    nmesh = 2 * n
+    gen = getattr(pkg.ics, args.ic)
+    pos, mass, box = gen(n)
+    N = len(pos)
+    d_pos = torch.from_numpy(pos).to(dev)
+    d_mass = torch.from_numpy(mass).to(dev)
+    del pos
+
+    eng = pkg.Engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_walk_threshold(args.thresh)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,
+                              FractionalGravitySoftening=1. / 30.)
+    eng.gravshort_set_softenings(box / n)
+    eng.dev_bind_particles(d_pos, d_mass, box)
+
+    gravpm = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    acc = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    prev = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    pot = torch.zeros(N, dtype=torch.float64, device=dev)
+    # target shard of this rank: a contiguous range of tree slots
+    lo, hi = pkg.shard.slot_range(N, rank, world)
+    chunk = pkg.shard.chunk_size(N, world)
+    if world > 1:
+        gbuf = torch.zeros(world * chunk, 3, dtype=torch.float64, device=dev)
+        sbuf = torch.zeros(chunk, 3, dtype=torch.float64, device=dev)
+
+    def step():
+        nonlocal acc, prev
+        eng.dev_gravpm_force(gravpm, pot)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        if world == 1:
+            eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+        else:
+            optr = eng.dev_tree_order_ptr()
+            eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=optr + 4 * lo, nactive=hi - lo)
+            order = _as_tensor(torch, optr, N, dev)
+            pkg.shard.exchange_results(acc, order, rank, world, sbuf, gbuf)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.walk_events_collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    walk_ms, walk_launches = eng.walk_events_collect()
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    elapsed = float(dt.item())
+
+    # ---- untimed diagnostic pass: phase times and interaction counters of one more step (same inputs)
+    eng.set_instrumentation(True, True)
+    step()
+    sync()
+    ph = eng.phase_times()
+    cnt = eng.walk_counters()
+    eng.set_instrumentation(False, False)
+    eng.walk_events_collect()
+
+    out = None
+    if rank == 0:
+        value = N * args.steps / elapsed
+        n_act = cnt["targets"]
+        b_alg = n_act * 64 + cnt["pp"] * 28 + cnt["nodes_visited"] * 72   # B_walk
+        walk_avg_ms = walk_ms / max(walk_launches, 1)
+        achieved = b_alg / (walk_avg_ms * 1e-3) / 1e9
+        flops = (cnt["pp"] + cnt["nodes_used"]) * 38.0
+        out = {
+            "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
+            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
+                                   "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
+                       "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
+                       "targets sharded over %d GPUs (tree-order ranges), all-gather of accelerations" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_grav_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
+                         "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
+                         "note": "algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 (SURVEY 8(d)); reuse through L1/L2/LDS makes "
+                                 "this exceed HBM traffic; the kernel is fp64-VALU bound: %.1f TFLOP/s fp64-equivalent "
+                                 "(38 flop per interaction) of 78.6 peak" % (flops / (walk_avg_ms * 1e-3) / 1e12)},
+            "phases_ms": {k: round(v, 3) for k, v in ph.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
+                                               args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    return out
+
+
+def _as_tensor(torch, ptr, n, dev):
+    """Zero-copy int32 view of engine-owned device memory (the tree-order permutation)."""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), True), "version": 2}
+    return torch.as_tensor(h, device=dev)
+
+
+def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
+    """The CPU "port": oracle built with the reference's flags (-O3 -ffast-math -fopenmp), all host cores.
+    Bounded sample: full tree build (single thread, like one reference rank) + the short-range walk for `sample`
+    targets scaled to N; the PM part (about 10 % of a reference step) is left out, which favours the CPU."""
+    from oracle import oracle as O
+    orc = O.Oracle(fast=True)
+    orc.fill_ntab(0, 1.5)
+    N = len(pos)
+    t0 = time.perf_counter()
+    tr = orc.tree(pos, mass, box, father=False)
+    t_tree = time.perf_counter() - t0
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    old = np.sqrt((aold_vec ** 2).sum(1)) / G
+    sample = min(sample, N)
+    act = np.arange(sample, dtype=np.int32)
+    tr.grav_short_tree(par, oldacc=old, active=act[:4096])   # warm-up
+    t0 = time.perf_counter()
+    tr.grav_short_tree(par, oldacc=old, active=act)
+    t_walk = time.perf_counter() - t0
+    t_full = t_tree + t_walk * N / sample
+    return {"value": N / t_full, "unit": "particles/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "oracle (gcc -O3 -ffast-math -fopenmp): tree build of all %d particles (%.1f s, 1 thread) + short-range walk "
+                      "of %d targets (%.1f s, %d threads) scaled to N; PM excluded" % (N, t_tree, sample, t_walk, orc.num_threads())}
+
+
+if __name__ == "__main__":
+    main()

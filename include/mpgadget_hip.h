@@ -159,6 +159,12 @@ typedef struct mpg_phase_times {
 int mpg_get_phase_times(mpg_engine *eng, mpg_phase_times *t);
 /* Enable (1) / disable (0) event timing + walk counters (counters cost a few % in the walk kernel). */
 int mpg_set_instrumentation(mpg_engine *eng, int timing, int counters);
+/* HIP events are recorded (without synchronising) on the engine stream around every walk-kernel launch.  This call
+ * synchronises the stream, returns the summed duration (ms) and number of launches since the last collect. */
+int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
+/* Device pointer to the tree-order permutation (int32 [NumParticles]: tree slot -> caller index) of the current tree;
+ * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
+const int *mpg_dev_tree_order(mpg_engine *eng);
 /* Tuning knob of the walk kernel: the node phase keeps running while at least `thresh` lanes of a wave are
  * still searching for work (1, 8, 16, 24, 32 or 48; default 8).  Results do not depend on it. */
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh);

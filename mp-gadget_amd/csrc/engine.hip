@@ -40,6 +40,8 @@ struct mpg_engine {
     int walk_thresh = 8;
     DevBuf<unsigned long long> counters;
     int64_t last_targets = 0;
+    // un-synchronised HIP event pairs around every walk launch (collected by mpg_walk_events_collect)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> walk_events, free_events;
     // bound device particles (caller order)
     int64_t n = 0;
     const double *d_pos = nullptr;
@@ -332,7 +334,23 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     if(eng->count)
         MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 4 * sizeof(unsigned long long), eng->stream));
     eng->timer.start(eng->stream);
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if(!eng->free_events.empty()) {
+        ev = eng->free_events.back();
+        eng->free_events.pop_back();
+    }
+    else {
+        MPG_HIP(hipEventCreate(&ev.first));
+        MPG_HIP(hipEventCreate(&ev.second));
+    }
+    MPG_HIP(hipEventRecord(ev.first, eng->stream));
     launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->walk_thresh, eng->stream);
+    MPG_HIP(hipEventRecord(ev.second, eng->stream));
+    eng->walk_events.push_back(ev);
+    if(eng->walk_events.size() > 4096) { // nobody is collecting: recycle the oldest
+        eng->free_events.push_back(eng->walk_events.front());
+        eng->walk_events.erase(eng->walk_events.begin());
+    }
     eng->timer.lap(eng->stream, &eng->timer.t.walk);
     eng->timer.t.walk_launches = 1;
     eng->last_targets = io.ntargets;
@@ -641,6 +659,30 @@ int mpg_set_instrumentation(mpg_engine *eng, int timing, int counters)
     eng->count = counters != 0;
     API_END
 }
+
+int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count)
+{
+    API_BEGIN
+    MPG_CHECK(eng && total_ms && count, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    double tot = 0;
+    int c = 0;
+    for(auto &ev : eng->walk_events) {
+        float ms = 0;
+        MPG_HIP(hipEventSynchronize(ev.second));
+        MPG_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+        c++;
+        eng->free_events.push_back(ev);
+    }
+    eng->walk_events.clear();
+    *total_ms = tot;
+    *count = c;
+    API_END
+}
+
+const int *mpg_dev_tree_order(mpg_engine *eng) { return (eng && eng->tree_allocated) ? (const int *)eng->tree.idx_b.p : nullptr; }
 
 /* tuning knob used by bench/tests: minimum number of walking lanes that keeps the node phase going */
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh)

@@ -86,6 +86,8 @@ def load_library():
     L.mpg_engine_get_stream.argtypes = [C.c_void_p]
     L.mpg_engine_destroy.argtypes = [C.c_void_p]
     L.mpg_engine_destroy.restype = None
+    L.mpg_dev_tree_order.restype = C.c_void_p
+    L.mpg_dev_tree_order.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -232,8 +234,15 @@ class Engine:
     def dev_force_tree_build(self, mask=ALLMASK):
         self._ck(self.lib.mpg_dev_force_tree_build(self.h, int(mask)))
 
-    def dev_grav_short_tree(self, accel, oldacc=None, prev_accel=None, gravpm=None, active=None, potential=None, rho0=0.0):
-        nact = 0 if active is None else active.shape[0]
+    def dev_grav_short_tree(self, accel, oldacc=None, prev_accel=None, gravpm=None, active=None, potential=None, rho0=0.0,
+                            nactive=None):
+        """active: int32 device tensor of caller indices, or a raw device pointer (int) with `nactive` entries."""
+        if active is None:
+            nact = 0
+        elif nactive is not None:
+            nact = int(nactive)
+        else:
+            nact = active.shape[0]
         self._ck(self.lib.mpg_dev_grav_short_tree(self.h, _ptr(oldacc), _ptr(prev_accel), _ptr(gravpm), _ptr(active),
                                                   C.c_int64(nact), _ptr(accel), _ptr(potential), C.c_double(rho0)))
 
@@ -261,6 +270,17 @@ class Engine:
         c = (C.c_int64 * 4)()
         self._ck(self.lib.mpg_walk_get_counters(self.h, c))
         return dict(pp=c[0], nodes_visited=c[1], nodes_used=c[2], targets=c[3])
+
+    def walk_events_collect(self):
+        """(total_ms, launches) of the walk kernel since the last collect, from HIP events on the engine stream."""
+        tot = C.c_double()
+        cnt = C.c_int()
+        self._ck(self.lib.mpg_walk_events_collect(self.h, C.byref(tot), C.byref(cnt)))
+        return tot.value, cnt.value
+
+    def dev_tree_order_ptr(self):
+        """Raw device pointer (int) of the tree-order permutation, int32 [NumParticles]."""
+        return self.lib.mpg_dev_tree_order(self.h)
 
     def phase_times(self):
         t = PhaseTimes()

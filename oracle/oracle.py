@@ -280,9 +280,9 @@ def gravpm_force(pos, mass, box, nmesh, Asmth=1.5, G=43.0071, want_potential=Tru
     out = np.zeros((len(pos), 3))
     potential = None
     if want_potential:
-        potential = pm_readout(np.fft.irfftn(pot_k, s=(nmesh,) * 3) * n3, pos, box, nmesh)
+        potential = pm_readout(np.fft.irfftn(pot_k, s=(nmesh,) * 3, axes=(0, 1, 2)) * n3, pos, box, nmesh)
     for d in range(3):
         # (re, im) <- (-im*fac, re*fac)  == multiply by i*fac   (gravpm.c:476-489)
         fk = pot_k * (1j * diffs[d])
-        out[:, d] = pm_readout(np.fft.irfftn(fk, s=(nmesh,) * 3) * n3, pos, box, nmesh)
+        out[:, d] = pm_readout(np.fft.irfftn(fk, s=(nmesh,) * 3, axes=(0, 1, 2)) * n3, pos, box, nmesh)
     return out, potential

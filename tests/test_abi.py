@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/*.h declares (no compute calls)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms += re.findall(r"\b(mpg_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(syms))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.engine.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_version_and_error_string(pkg):
+    L = pkg.engine.load_library()
+    assert b"gfx950" in L.mpg_version()
+    assert L.mpg_last_error() is not None
+
+
+def test_reference_particle_layout(pkg):
+    """struct particle_data is 160 bytes with the offsets of partmanager.h:9-71."""
+    dt = pkg.PARTICLE_DTYPE
+    assert dt.itemsize == 160
+    off = {k: dt.fields[k][1] for k in dt.names}
+    assert off["Pos"] == 0 and off["TopLeaf"] == 24 and off["Mass"] == 28 and off["PI"] == 32 and off["Type"] == 39
+    assert off["Vel"] == 40 and off["FullTreeGravAccel"] == 64 and off["GravPM"] == 88 and off["Ti_drift"] == 112
+    assert off["Hsml"] == 120 and off["DtHsml"] == 128 and off["ID"] == 136 and off["GrNr"] == 144 and off["Potential"] == 152
+    v = pkg.engine.ParticleView()
+    P = np.zeros(3, dtype=dt)
+    pkg.engine.load_library().mpg_particle_view_reference_layout(C.byref(v), C.c_void_p(P.ctypes.data), C.c_int64(3))
+    assert (v.stride, v.off_pos, v.off_mass, v.off_type, v.off_accel, v.off_gravpm, v.off_potential, v.off_hsml) == \
+        (160, 0, 28, 39, 64, 88, 152, 120)
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a GPU the engine must fail loudly, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.EngineError, match="no HIP device"):
+        pkg.Engine(0)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under mp-gadget_amd/ may reference it."""
+    for path in glob.glob(os.path.join(ROOT, "mp-gadget_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".h", ".cpp")):
+            txt = open(path).read()
+            for needle in ("import oracle", "from oracle", "liboracle", "oracle/"):
+                assert needle not in txt, (path, needle)

@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: synthetic IC generators and the target-sharding exchange (gloo, world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sgrid_is_deterministic_and_inside_box(pkg):
+    a, m, box = pkg.ics.s_grid(8)
+    b, _, _ = pkg.ics.s_grid(8)
+    assert np.array_equal(a, b) and a.shape == (512, 3) and m.dtype == np.float32
+    assert a.min() >= 0 and a.max() < box
+    # first draws of xorshift64 seed 1234567 (SURVEY App. C.5 recipe)
+    v = 1234567
+    M = (1 << 64) - 1
+    us = []
+    for _ in range(3):
+        v ^= (v << 13) & M
+        v ^= v >> 7
+        v ^= (v << 17) & M
+        us.append((v >> 11) * 2.0 ** -53)
+    sp = box / 8
+    assert np.allclose(a[0], np.fmod((0.5 + 0.3 * (np.array(us) - 0.5)) * sp + box, box), rtol=0, atol=1e-9)
+
+
+def test_blocked_xorshift_equals_sequential(pkg):
+    n = 70000
+    a = pkg.ics.xorshift64_uniform(n)
+    v = 1234567
+    M = (1 << 64) - 1
+    for i in range(n):
+        v ^= (v << 13) & M
+        v ^= v >> 7
+        v ^= (v << 17) & M
+        if i % 9973 == 0 or i == n - 1:
+            assert a[i] == (v >> 11) * 2.0 ** -53
+
+
+def test_szel_and_sclust(pkg):
+    p, m, box = pkg.ics.s_zel(16)
+    assert p.shape == (4096, 3) and p.min() > 0 and p.max() <= box
+    q, _, b2 = pkg.ics.s_clust(8)
+    assert q.shape == (512, 3) and q.min() >= 0 and q.max() <= b2
+
+
+def test_slot_ranges_partition(pkg):
+    for n in (0, 1, 7, 1000, 4097):
+        for w in (1, 2, 3, 8):
+            r = [pkg.shard.slot_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(h - l for l, h in r) <= pkg.shard.chunk_size(n, w)
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mp-gadget_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    order = torch.randperm(n, generator=g).to(torch.int32)          # same on every rank
+    truth = torch.randn(n, 3, dtype=torch.float64, generator=g)     # what a single rank would compute
+    lo, hi = pkg.shard.slot_range(n, rank, world)
+    vals = torch.full((n, 3), float("nan"), dtype=torch.float64)
+    mine = order[lo:hi].long()
+    vals[mine] = truth[mine]                                        # this rank "walked" only its own targets
+    pkg.shard.exchange_results(vals, order, rank, world)
+    q.put((rank, bool(torch.equal(vals, truth))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 64])
+def test_exchange_results_world2_gloo(n):
+    """N>1 path on CPU: two gloo ranks each own half of the tree-order slots; after the all-gather both hold the
+    single-rank answer bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

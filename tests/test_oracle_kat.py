@@ -1,0 +1,152 @@
+"""Pin the CPU oracle against the reference's own known answers.
+
+ * outputs of the unmodified reference objects on the S-grid set (mean |FullTreeGravAccel| after the
+   second walk, Ninteractions/N) -- 6 printed digits;
+ * libgadget/tests/test_gravity.c: PM + tree vs direct summation over 27 images (max < 3 ErrTol, mean < 0.8 ErrTol,
+   :146-160) on the "close" and "random" sets, and the regular-grid net-force bounds (:259-260);
+ * libgadget/tests/test_forcetree.c: structural invariants of the tree (:33-171, :208);
+ * oracle/_ref (reference leaf files built in place): the window table values.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = 43.0071
+
+
+def two_walks(orc, pos, mass, box, n, nmesh, gravpm=None, rcut=6.0, bh_second=False):
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G, TreeRcut=rcut)
+    gp = np.zeros_like(pos) if gravpm is None else gravpm
+    par.TreeUseBH = 1
+    a1, _, c1, _ = tr.grav_short_tree(par, oldacc=np.sqrt((gp ** 2).sum(1)) / G)
+    par.TreeUseBH = 1 if bh_second else 0
+    a2, _, c2, _ = tr.grav_short_tree(par, oldacc=np.sqrt(((a1 + gp) ** 2).sum(1)) / G)
+    return a2, c2, tr
+
+
+@pytest.mark.parametrize("n,nmesh,mean_a,nint", [(32, 64, 1.67498e-05, 1333.8), (64, 192, 1.43708e-05, 512.0)])
+def test_survey_probe_known_answers(pkg, orc, n, nmesh, mean_a, nint):
+    pos, mass, box = pkg.ics.s_grid(n)
+    a2, c2, _ = two_walks(orc, pos, mass, box, n, nmesh)
+    assert abs(np.abs(a2).mean() / mean_a - 1) < 5e-6          # 6 printed digits
+    assert abs(c2[0] / len(pos) - nint) < 0.06                 # printed to 0.1
+
+
+def _test_gravity_sets(kind):
+    n = 16
+    N = n ** 3
+    i = np.arange(N)
+    if kind == "flat":      # test_gravity.c:236-242
+        pos = np.stack([(8.0 / n) * (i // n // n), (8.0 / n) * ((i // n) % n), (8.0 / n) * (i % n)], 1).astype(np.float64)
+    elif kind == "close":   # test_gravity.c:270-276
+        pos = np.stack([4. + (i // n // n) / 5000., 4. + ((i // n) % n) / 5000., 4. + (i % n) / 5000.], 1)
+    else:                   # three populations, test_gravity.c:283-305 (numpy MT19937 instead of gsl's draw order)
+        rng = np.random.RandomState(0)
+        pos = np.empty((N, 3))
+        pos[:N // 4] = 8.0 * rng.random_sample((N // 4, 3))
+        pos[N // 4:3 * N // 4] = 4.0 + 1.0 * np.exp((rng.random_sample((N // 2, 3)) - 0.5) ** 2)
+        pos[3 * N // 4:] = 0.8 + 0.25 * np.exp((rng.random_sample((N - 3 * N // 4, 3)) - 0.5) ** 2)
+    return pos, np.ones(N, np.float32), 8.0, n
+
+
+@pytest.mark.parametrize("kind", ["close", "random"])
+def test_reference_force_accuracy_vs_direct_sum(orc, kind):
+    """do_force_test + check_against_force_direct of test_gravity.c:162-219,146-160 (Nmesh 48, Asmth 1.5, Rcut 7, BH twice)."""
+    pos, mass, box, n = _test_gravity_sets(kind)
+    nmesh, err = 48, 0.002
+    gpm, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    a2, _, _ = two_walks(orc, pos, mass, box, n, nmesh, gravpm=gpm, rcut=7.0, bh_second=True)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    direct = orc.force_direct(pos, mass, box, par.h, G)
+    meanacc = np.abs(direct).mean()
+    relerr = np.abs(direct - (gpm + a2)) / meanacc
+    assert relerr.max() < 3 * err, relerr.max()
+    assert relerr.mean() < 0.8 * err, relerr.mean()
+
+
+def test_reference_flat_grid_net_force(orc):
+    """test_force_flat, test_gravity.c:224-262: homogeneous grid, |GravPM + tree| max < 0.015, mean < 0.005."""
+    pos, mass, box, n = _test_gravity_sets("flat")
+    gpm, _ = O.gravpm_force(pos, mass, box, 48, 1.5, G)
+    a2, _, _ = two_walks(orc, pos, mass, box, n, 48, gravpm=gpm, rcut=7.0, bh_second=True)
+    tot = np.abs(gpm + a2)
+    assert tot.max() < 0.015 and tot.mean() < 0.005
+
+
+def test_forcetree_invariants(pkg, orc):
+    """check_tree / check_moments of test_forcetree.c:33-171: leaves own each particle once, child geometry halves,
+    node masses are the sums of their particles, root mass = N."""
+    pos, mass, box = pkg.ics.s_clust(12, box=8.0, seed=3)
+    tr = orc.tree(pos, mass, box)
+    d = tr.export()
+    fn = d["firstnode"]
+    live = d["live"].astype(bool)
+    leaf = live & (d["childtype"] == 0)
+    # every particle in exactly one live leaf, and Father points to it
+    seen = np.zeros(len(pos), int)
+    father = tr.father()
+    for j in np.nonzero(leaf)[0]:
+        for k in range(d["noccupied"][j]):
+            p = d["suns"][j, k]
+            seen[p] += 1
+            assert father[p] == j + fn
+            assert np.all(np.abs(pos[p] - d["center"][j]) <= d["len"][j] / 2 * (1 + 1e-12))
+    assert np.all(seen == 1)
+    # children: len halves, centre offset len/4
+    internal = live & (d["childtype"] == 1)
+    for j in np.nonzero(internal)[0]:
+        assert d["mass"][j] > 8           # an internal node holds more than NMAXCHILD particles (unit masses)
+        msum = 0
+        for c in d["suns"][j]:
+            if c < 0:
+                continue
+            cj = c - fn
+            assert abs(d["len"][cj] / d["len"][j] - 0.5) < 1e-14
+            assert np.allclose(np.abs(d["center"][cj] - d["center"][j]), d["len"][j] / 4, rtol=1e-12)
+            msum += d["mass"][cj]
+        assert abs(msum - d["mass"][j]) < 1e-9
+    assert abs(d["mass"][0] - len(pos)) < 1e-9
+    assert np.allclose(d["cofm"][0], pos.mean(0), rtol=1e-12)
+
+
+def test_pair_vs_open_tree(pkg, orc):
+    """runtests.c:131-150: grav_short_pair vs the fully opened tree agree (sphere vs cube cutoff => small differences)."""
+    n, nmesh = 12, 24
+    pos, mass, box = pkg.ics.s_grid(n)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 1
+    par.BHOpeningAngle = 0.0   # everything opened
+    a_open, _, _, _ = tr.grav_short_tree(par, oldacc=np.zeros(len(pos)))
+    a_pair = orc.grav_short_pair(pos, mass, box, par, par.Rcut)
+    err = np.abs(a_open - a_pair).max() / np.abs(a_pair).mean()
+    assert err < 0.1     # runtests.c:149
+
+
+def test_window_table_matches_reference_leaf_build(orc):
+    """oracle/_ref/libref_leaf.so is the reference's own shortrange-kernel.c compiled in place: the carried data file
+    must be bit-identical to it."""
+    path = os.path.join(os.path.dirname(O.__file__), "_ref", "libref_leaf.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    L = C.CDLL(path, mode=os.RTLD_LAZY)   # densitykernel.c's error path references endrun(): bind lazily
+    tab = (C.c_double * (512 * 5)).in_dll(L, "shortrange_force_kernels")
+    ref = np.ctypeslib.as_array(tab).reshape(512, 5)
+    assert np.array_equal(ref, orc.table)
+    f, p = orc.get_ntab()
+    assert np.array_equal(f, ref[:, 2].astype(np.float32)) and np.array_equal(p, ref[:, 1].astype(np.float32))
+
+
+def test_pm_oracle_point_mass_pair():
+    """Two particles: the PM force is antisymmetric and pulls them together (sign convention of gravpm.c:476-489)."""
+    box, nmesh = 100.0, 32
+    pos = np.array([[40.0, 50.0, 50.0], [60.0, 50.0, 50.0]])
+    gpm, pot = O.gravpm_force(pos, np.ones(2, np.float32), box, nmesh, 1.5, G)
+    assert gpm[0, 0] > 0 and gpm[1, 0] < 0
+    assert np.allclose(gpm[0], -gpm[1], atol=1e-12 * np.abs(gpm).max())
+    assert np.all(pot < 0) or np.allclose(pot[0], pot[1])
