@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
+    ap.add_argument("--variant", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,6 +73,7 @@ def main():
     eng = pkg.Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_walk_threshold(args.thresh)
+    eng.set_walk_variant(args.variant)
     eng.gravshort_fill_ntab(0, 1.5)
     eng.gravpm_init_periodic(box, 1.5, nmesh, G)
     eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,

@@ -147,8 +147,9 @@ int mpg_tree_export(mpg_engine *eng, int32_t *level, double *center, double *len
 /* Tree-order permutation: order[k] = caller index of the k-th particle in tree order (n entries). */
 int mpg_tree_export_order(mpg_engine *eng, int32_t *order);
 /* Walk counters of the last grav_short_tree: [0] particle-particle interactions (= the reference's Ninteractions,
- * treewalk.c:904-912), [1] nodes visited, [2] nodes used unopened, [3] targets. */
-int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[4]);
+ * treewalk.c:904-912), [1] nodes visited, [2] nodes used unopened, [3] targets, [4..7] phase statistics of the
+ * cooperative kernel: phase-A group steps, nodes consumed by them (of 8 tested each), phase-B lane-steps issued, of which active; [8],[9] wave clock cycles spent in phase A / phase B (summed over waves). */
+int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[10]);
 /* Per-phase device times (ms, HIP events on the engine stream) of the last call of each phase. */
 typedef struct mpg_phase_times {
     float pm_deposit, pm_fft, pm_transfer, pm_readout, pm_total;
@@ -165,9 +166,14 @@ int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
 /* Device pointer to the tree-order permutation (int32 [NumParticles]: tree slot -> caller index) of the current tree;
  * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
 const int *mpg_dev_tree_order(mpg_engine *eng);
-/* Tuning knob of the walk kernel: the node phase keeps running while at least `thresh` lanes of a wave are
- * still searching for work (1, 8, 16, 24, 32 or 48; default 8).  Results do not depend on it. */
+/* Tuning knobs of the walk; results do not depend on any of them.
+ *   variant   0 = auto (default): time kernels 1 and 4 once on a large walk and keep the faster (re-tuned every 64 walks);
+ *             1 = lane-per-target while-while kernel (grav_walk.hip); 4 = group-cooperative list kernel (grav_walk_coop.hip)
+ *   threshold (kernel 1) the node phase keeps running while at least that many lanes of a wave still search (default 16)
+ *   list capacity (kernel 4) interaction-list entries per target before a group drains its lists (default 512) */
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
+int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
+int mpg_set_walk_variant(mpg_engine *eng, int variant);
 
 #ifdef __cplusplus
 }

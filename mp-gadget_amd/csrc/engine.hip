@@ -11,6 +11,7 @@
 #include "pm.h"
 #include "tree_build.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,7 +38,13 @@ struct mpg_engine {
     int tree_mask = 63;
     EventTimer timer;
     bool count = false;
-    int walk_thresh = 8;
+    int walk_thresh = 16;
+    // 1: lane-per-target while-while kernel (grav_walk.hip); 4: group-cooperative list kernel (grav_walk_coop.hip);
+    // 0: time both on the next walk and keep the faster one (the particle distribution decides: profiles/)
+    int walk_variant = 0;
+    int walk_choice = 0; // variant picked by the auto-tuner (0 = not tuned yet)
+    int walks_since_tune = 0;
+    WalkScratch w3;
     DevBuf<unsigned long long> counters;
     int64_t last_targets = 0;
     // un-synchronised HIP event pairs around every walk launch (collected by mpg_walk_events_collect)
@@ -87,7 +94,7 @@ int mpg_engine_create(mpg_engine **out, int device)
     eng->device = device;
     MPG_HIP(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
     eng->own_stream = true;
-    eng->counters.reserve(4);
+    eng->counters.reserve(16);
     *out = eng;
     API_END
 }
@@ -129,7 +136,9 @@ int mpg_engine_synchronize(mpg_engine *eng)
 {
     API_BEGIN
     MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipSetDevice(eng->device));
     MPG_HIP(hipStreamSynchronize(eng->stream));
+    MPG_CHECK(walk_coop_error(eng->w3, eng->stream) == 0, "short-range walk aborted by its loop guard (corrupt tree?)");
     API_END
 }
 
@@ -299,7 +308,7 @@ static GravParams make_gp(mpg_engine *eng, double rho0)
         gp.bhangle2 = eng->treepar.MaxBHOpeningAngle * eng->treepar.MaxBHOpeningAngle;
     gp.G = eng->pm.G;
     gp.cbrtrho0 = pow(rho0, 1.0 / 3);
-    gp.full_tree = eng->full_particle_tree;
+    gp.full_tree = eng->full_particle_tree ? 1 : 0;
     return gp;
 }
 
@@ -332,7 +341,7 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     io.tab_pot = eng->tab_pot.p;
     io.counters = eng->counters.p;
     if(eng->count)
-        MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 4 * sizeof(unsigned long long), eng->stream));
+        MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 16 * sizeof(unsigned long long), eng->stream));
     eng->timer.start(eng->stream);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if(!eng->free_events.empty()) {
@@ -344,7 +353,53 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         MPG_HIP(hipEventCreate(&ev.second));
     }
     MPG_HIP(hipEventRecord(ev.first, eng->stream));
-    launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->walk_thresh, eng->stream);
+    // hoisting the minimum-image wrap out of the pair loop is valid when every source range shares the image of its
+    // node: Rcut + 1.5 * (largest leaf side) < Box/2, and Rcut well below Box/4 (see grav_walk_coop.hip)
+    const double maxleaf = 1.001 * gp.box / (double)(1 << eng->tree.minleaflevel);
+    const bool fastwrap = !getenv("MPG_NO_FASTWRAP") && (gp.rcut + 1.5 * maxleaf < 0.49 * gp.box) && (gp.rcut < 0.2 * gp.box);
+    auto run_variant = [&](int v) {
+        if(v == 1)
+            launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->walk_thresh, eng->stream);
+        else
+            launch_grav_walk_coop(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->w3, eng->stream);
+    };
+    int variant = eng->walk_variant;
+    if(variant == 0) {
+        // auto: both kernels compute the same interaction sets; time each once and keep the faster.  Re-tuned every 64
+        // walks, and only on walks large enough for the timing to mean something.
+        if(eng->walk_choice == 0 || (eng->walks_since_tune >= 64 && io.ntargets >= 65536)) {
+            if(io.ntargets < 65536)
+                variant = 1;
+            else {
+                float t1 = 0, t4 = 0;
+                hipEvent_t a, b, c;
+                MPG_HIP(hipEventCreate(&a));
+                MPG_HIP(hipEventCreate(&b));
+                MPG_HIP(hipEventCreate(&c));
+                MPG_HIP(hipEventRecord(a, eng->stream));
+                run_variant(1);
+                MPG_HIP(hipEventRecord(b, eng->stream));
+                run_variant(4);
+                MPG_HIP(hipEventRecord(c, eng->stream));
+                MPG_HIP(hipEventSynchronize(c));
+                MPG_HIP(hipEventElapsedTime(&t1, a, b));
+                MPG_HIP(hipEventElapsedTime(&t4, b, c));
+                (void)hipEventDestroy(a);
+                (void)hipEventDestroy(b);
+                (void)hipEventDestroy(c);
+                eng->walk_choice = (t4 < t1) ? 4 : 1;
+                eng->walks_since_tune = 0;
+                if(walk_coop_error(eng->w3, eng->stream) != 0)
+                    eng->walk_choice = 1;
+                variant = -1; // results are already in place (the second run overwrote the first with equal values)
+            }
+        }
+        else
+            variant = eng->walk_choice;
+        eng->walks_since_tune++;
+    }
+    if(variant > 0)
+        run_variant(variant);
     MPG_HIP(hipEventRecord(ev.second, eng->stream));
     eng->walk_events.push_back(ev);
     if(eng->walk_events.size() > 4096) { // nobody is collecting: recycle the oldest
@@ -628,18 +683,20 @@ int mpg_tree_export_order(mpg_engine *eng, int32_t *order)
     API_END
 }
 
-int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[4])
+int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[10])
 {
     API_BEGIN
     MPG_CHECK(eng && counters, "null argument");
     MPG_HIP(hipSetDevice(eng->device));
     MPG_HIP(hipStreamSynchronize(eng->stream));
-    unsigned long long c[4] = {0, 0, 0, 0};
-    MPG_HIP(hipMemcpy(c, eng->counters.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long c[16] = {0};
+    MPG_HIP(hipMemcpy(c, eng->counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     counters[0] = (int64_t)c[0];
     counters[1] = (int64_t)c[1];
     counters[2] = (int64_t)c[2];
     counters[3] = eng->last_targets;
+    for(int k = 0; k < 6; k++)
+        counters[4 + k] = (int64_t)c[3 + k];
     API_END
 }
 
@@ -690,6 +747,23 @@ int mpg_set_walk_threshold(mpg_engine *eng, int thresh)
     API_BEGIN
     MPG_CHECK(eng, "null engine");
     eng->walk_thresh = thresh;
+    API_END
+}
+
+int mpg_set_walk_list_capacity(mpg_engine *eng, int cap)
+{
+    API_BEGIN
+    MPG_CHECK(eng && cap >= 16 && cap <= 65536, "walk list capacity must be in [16, 65536]");
+    eng->w3.cap = cap;
+    API_END
+}
+
+int mpg_set_walk_variant(mpg_engine *eng, int variant)
+{
+    API_BEGIN
+    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4), "walk variant must be 0 (auto), 1 or 4");
+    eng->walk_variant = variant;
+    eng->walk_choice = 0;
     API_END
 }
 

@@ -16,9 +16,23 @@ struct WalkIO {
     double *potential = nullptr;       // caller order [n] or null
     const float *tab_force = nullptr;  // [NTAB] shortrange_table           (gravity.c:20)
     const float *tab_pot = nullptr;    // [NTAB] shortrange_table_potential
-    unsigned long long *counters = nullptr; // [3] pp interactions, nodes visited, nodes used (COUNT builds only)
+    unsigned long long *counters = nullptr; // [8] pp interactions, nodes visited, nodes used, burst statistics (COUNT builds only)
 };
 
 void launch_grav_walk(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, int thresh, hipStream_t st);
+
+// group-cooperative list-form walk (grav_walk_coop.hip): the default.  Persistent kernel; every group of 8 lanes owns
+// one target and keeps its interaction lists in a per-wave scratch area.
+struct WalkScratch {
+    DevBuf<int2> list;      // [resident waves][8 groups][cap]
+    DevBuf<unsigned> ctr;   // [16] scratch words; [8] = device error flag (runaway-loop guard)
+    int cap = 512;          // list entries per target before the group drains its lists
+    int num_cu = 0;
+};
+// fastwrap: the minimum-image wrap may be hoisted out of the pair loop (decided by the caller from Rcut, Box, leaf sizes)
+void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap,
+                           WalkScratch &ws, hipStream_t st);
+// returns the device error flag of the last cooperative walk (0 = ok); synchronises the stream
+unsigned walk_coop_error(WalkScratch &ws, hipStream_t st);
 
 } // namespace mpg

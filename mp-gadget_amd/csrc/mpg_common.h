@@ -78,6 +78,14 @@ struct alignas(16) NodeLink {
     int level;   // depth (root = 0)
 };
 
+// Node links of the level-ordered ("children contiguous") copy of the tree used by the cooperative walk.
+struct alignas(16) NodeLinkB {
+    int firstchild; // level-order index of the first child (-1 for a leaf); the children are firstchild .. firstchild+nchild-1
+    int nchild;     // 1..8 occupied octants (0 for a leaf)
+    int pstart;     // first particle (tree order) below this node
+    int pcount;     // >0: leaf with that many particles; 0: internal node
+};
+
 struct TreeView {
     int64_t npart = 0;       // particles in the tree (tree order [0,npart))
     int64_t nnodes = 0;
@@ -86,6 +94,11 @@ struct TreeView {
     const NodeLink *link = nullptr;// [nnodes]
     const double *hmax = nullptr;  // [nnodes] or null
     const int *order = nullptr;    // [npart] tree order -> caller index
+    // level-ordered copy (root = 0, the children of a node are contiguous): geometry, moments, links, hmax
+    const NodeGeo *geoB = nullptr;
+    const Src4 *momB = nullptr;
+    const NodeLinkB *linkB = nullptr;
+    const double *hmaxB = nullptr;
     double box = 0;
 };
 

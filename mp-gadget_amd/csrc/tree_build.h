@@ -51,6 +51,7 @@ struct TreeBuilder {
     int64_t npart = 0;   // particles in the tree (mask)
     int64_t nnodes = 0;
     int maxlevel = 0;
+    int minleaflevel = 0; // depth of the shallowest leaf (largest leaf side = 1.001 Box / 2^minleaflevel)
     double box = 0;
     bool has_moments = false, has_hmax = false;
 
@@ -64,6 +65,13 @@ struct TreeBuilder {
     DevBuf<NodeGeo> geo;
     DevBuf<NodeLink> link;
     DevBuf<double> hmax;
+    // level-ordered copy for the cooperative walk (children of a node contiguous)
+    DevBuf<uint32_t> lvl_a, lvl_b, nid_a, nid_b, bfs_of_dfs;
+    DevBuf<NodeGeo> geoB;
+    DevBuf<Src4> momB;
+    DevBuf<NodeLinkB> linkB;
+    DevBuf<double> hmaxB;
+    bool has_bfs = false;
 
     // force_tree_build (forcetree.c:196-270) without moments
     void build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box, hipStream_t st,
@@ -73,6 +81,8 @@ struct TreeBuilder {
     void calc_moments(const double *d_hsml_gasbh_treeorder, hipStream_t st, EventTimer *tm);
     // hmax only (tree built without moments, force_tree_rebuild_mask + update_tree_hmax_father + calc_moments)
     void calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st);
+    // build / refresh the level-ordered copy from the depth-first arrays (after moments and/or hmax are known)
+    void make_level_order(hipStream_t st);
     TreeView view() const;
 };
 

@@ -111,8 +111,10 @@ __global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__
     const int c = (i == 0) ? -1 : cl[1];
     const bool head = (i == 0) || (c < L);
     cnt[i] = head ? (uint32_t)(L - c) : 0u;
-    if(head)
+    if(head) {
         atomicMax(&flags[1], L);
+        atomicMax(&flags[2], MAXLEVEL - L); // -> shallowest leaf level
+    }
 }
 
 __global__ void __launch_bounds__(256) k_fill_nodes(int64_t n, const uint64_t *__restrict__ keys, const uint8_t *__restrict__ leaflevel,
@@ -302,7 +304,84 @@ __global__ void __launch_bounds__(256) k_only_hmax_internal(int64_t nnodes, int 
     hmax[j] = hm;
 }
 
+__global__ void __launch_bounds__(256) k_node_levels(int64_t nnodes, const NodeLink *__restrict__ link, uint32_t *__restrict__ lvl,
+                                                     uint32_t *__restrict__ nid)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    lvl[j] = (uint32_t)link[j].level;
+    nid[j] = (uint32_t)j;
+}
+
+__global__ void __launch_bounds__(256) k_invert_perm(int64_t n, const uint32_t *__restrict__ dfs_of_bfs, uint32_t *__restrict__ bfs_of_dfs)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    bfs_of_dfs[dfs_of_bfs[i]] = (uint32_t)i;
+}
+
+// level-ordered copy: a stable sort of the depth-first nodes by level keeps key order inside a level, so the children of
+// a node (consecutive keys one level down) become contiguous.  Children are counted along the sibling chain.
+__global__ void __launch_bounds__(256) k_build_level_order(int64_t nnodes, int64_t npart, const uint32_t *__restrict__ dfs_of_bfs,
+                                                           const uint32_t *__restrict__ bfs_of_dfs, const NodeGeo *__restrict__ geo,
+                                                           const NodeLink *__restrict__ link, const Src4 *__restrict__ src,
+                                                           const double *__restrict__ hmax, NodeGeo *__restrict__ geoB,
+                                                           Src4 *__restrict__ momB, NodeLinkB *__restrict__ linkB, double *__restrict__ hmaxB)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nnodes)
+        return;
+    const int64_t j = dfs_of_bfs[i];
+    const NodeLink lk = link[j];
+    geoB[i] = geo[j];
+    momB[i] = src[npart + j];
+    NodeLinkB o;
+    o.pstart = lk.pstart;
+    o.pcount = lk.pcount;
+    o.firstchild = -1;
+    o.nchild = 0;
+    if(lk.pcount == 0 && j + 1 < nnodes) {
+        o.firstchild = (int)bfs_of_dfs[j + 1];
+        int c = (int)j + 1, n = 0;
+        do {
+            n++;
+            c = link[c].sibling;
+        } while(c != lk.sibling && n < 8);
+        o.nchild = n;
+    }
+    linkB[i] = o;
+    if(hmaxB)
+        hmaxB[i] = hmax ? hmax[j] : 0.0;
+}
+
 static inline int nblk(int64_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+void TreeBuilder::make_level_order(hipStream_t st)
+{
+    const int64_t M = nnodes;
+    lvl_a.reserve(M + 1);
+    lvl_b.reserve(M + 1);
+    nid_a.reserve(M + 1);
+    nid_b.reserve(M + 1);
+    bfs_of_dfs.reserve(M + 1);
+    geoB.reserve(M + 16);
+    momB.reserve(M + 16);
+    linkB.reserve(M + 16);
+    if(has_hmax)
+        hmaxB.reserve(M + 16);
+    hipLaunchKernelGGL(k_node_levels, dim3(nblk(M)), dim3(256), 0, st, M, link.p, lvl_a.p, nid_a.p);
+    size_t tb = 0;
+    MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb, lvl_a.p, lvl_b.p, nid_a.p, nid_b.p, (size_t)M, 0, 5, st));
+    tmp.reserve(tb + 16);
+    MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, lvl_a.p, lvl_b.p, nid_a.p, nid_b.p, (size_t)M, 0, 5, st));
+    hipLaunchKernelGGL(k_invert_perm, dim3(nblk(M)), dim3(256), 0, st, M, nid_b.p, bfs_of_dfs.p);
+    hipLaunchKernelGGL(k_build_level_order, dim3(nblk(M)), dim3(256), 0, st, M, npart, nid_b.p, bfs_of_dfs.p, geo.p, link.p, src.p,
+                       has_hmax ? hmax.p : (const double *)nullptr, geoB.p, momB.p, linkB.p, has_hmax ? hmaxB.p : (double *)nullptr);
+    MPG_HIP(hipGetLastError());
+    has_bfs = true;
+}
 
 void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box,
                         hipStream_t st, EventTimer *tm)
@@ -312,6 +391,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     this->ncaller = n;
     has_moments = false;
     has_hmax = false;
+    has_bfs = false;
     if(tm)
         tm->start(st);
     keys_a.reserve(n + 1);
@@ -343,7 +423,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     leaflevel.reserve(npart + 1);
     cnt.reserve(npart + 1);
     base.reserve(npart + 1);
-    int hflags[2] = {0, 0};
+    int hflags[3] = {0, 0, 0};
     uint32_t lastbase = 0, lastcnt = 0;
     if(npart > 0) {
         hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags);
@@ -359,15 +439,18 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
                                   "aborts here too, forcetree.c:393-412)");
         nnodes = (int64_t)lastbase + lastcnt;
         maxlevel = hflags[1];
+        minleaflevel = MAXLEVEL - hflags[2];
     }
     else {
         // empty tree: a lone root leaf with no particles (forcetree.c:657-678)
         nnodes = 1;
         maxlevel = 0;
+        minleaflevel = 0;
     }
-    src.reserve(npart + nnodes + 1);
-    geo.reserve(nnodes + 1);
-    link.reserve(nnodes + 1);
+    // padding records behind each array: the cooperative walk reads nodes no .. no+7 (those past the end are ignored)
+    src.reserve(npart + nnodes + 16);
+    geo.reserve(nnodes + 16);
+    link.reserve(nnodes + 16);
     if(npart > 0) {
         hipLaunchKernelGGL(k_gather_src, dim3(nblk(npart)), dim3(256), 0, st, npart, idx_b.p, d_pos, d_mass, src.p);
         hipLaunchKernelGGL(k_fill_nodes, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, base.p, box, geo.p,
@@ -403,6 +486,7 @@ void TreeBuilder::calc_moments(const double *d_hsml_gasbh_treeorder, hipStream_t
     }
     has_moments = true;
     has_hmax = hm != nullptr;
+    make_level_order(st);
     if(tm)
         tm->lap(st, &tm->t.tree_moments);
 }
@@ -431,6 +515,12 @@ TreeView TreeBuilder::view() const
     v.link = link.p;
     v.hmax = has_hmax ? hmax.p : nullptr;
     v.order = (const int *)idx_b.p;
+    if(has_bfs) {
+        v.geoB = geoB.p;
+        v.momB = momB.p;
+        v.linkB = linkB.p;
+        v.hmaxB = has_hmax ? hmaxB.p : nullptr;
+    }
     v.box = box;
     return v;
 }

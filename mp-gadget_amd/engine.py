@@ -146,6 +146,12 @@ class Engine:
     def set_instrumentation(self, timing=True, counters=False):
         self._ck(self.lib.mpg_set_instrumentation(self.h, int(timing), int(counters)))
 
+    def set_walk_variant(self, variant):
+        self._ck(self.lib.mpg_set_walk_variant(self.h, int(variant)))
+
+    def set_walk_list_capacity(self, cap):
+        self._ck(self.lib.mpg_set_walk_list_capacity(self.h, int(cap)))
+
     def set_walk_threshold(self, thresh):
         self._ck(self.lib.mpg_set_walk_threshold(self.h, int(thresh)))
 
@@ -267,9 +273,10 @@ class Engine:
         return d
 
     def walk_counters(self):
-        c = (C.c_int64 * 4)()
+        c = (C.c_int64 * 10)()
         self._ck(self.lib.mpg_walk_get_counters(self.h, c))
-        return dict(pp=c[0], nodes_visited=c[1], nodes_used=c[2], targets=c[3])
+        return dict(pp=c[0], nodes_visited=c[1], nodes_used=c[2], targets=c[3], node_steps=c[4], node_lanes=c[5],
+                    int_steps=c[6], int_lanes=c[7], cycles_a=c[8], cycles_b=c[9])
 
     def walk_events_collect(self):
         """(total_ms, launches) of the walk kernel since the last collect, from HIP events on the engine stream."""
