@@ -130,6 +130,84 @@ int mpg_dev_force_tree_build(mpg_engine *eng, int mask);
 int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm,
                             const int *d_active, int64_t nactive, double *d_accel, double *d_potential, double rho0);
 
+/* ---- SPH: density (with the smoothing-length iteration) and hydro force ----------------------------- */
+/* struct density_params, libgadget/density.h:10-25 (same fields, same order; DensityKernelType is the enum value
+ * 1 cubic / 2 quintic / 4 quartic of densitykernel.h:17-21). */
+typedef struct mpg_density_params {
+    double DensityResolutionEta;
+    double MaxNumNgbDeviation;
+    double BlackHoleNgbFactor;
+    double BlackHoleMaxAccretionRadius;
+    int DensityKernelType;
+    double MinGasHsmlFractional;
+} mpg_density_params;
+/* struct hydro_params, libgadget/hydra.c:26-34 */
+typedef struct mpg_hydro_params {
+    int DensityIndependentSphOn;
+    double DensityContrastLimit;
+    double ArtBulkViscConst;
+} mpg_hydro_params;
+/* set_densitypar (density.c:22-27) / the hydro_params of set_hydro_params (hydra.c:36-48) */
+int mpg_set_densitypar(mpg_engine *eng, const mpg_density_params *dp);
+int mpg_set_hydropar(mpg_engine *eng, const mpg_hydro_params *hp);
+/* GetNumNgb (density.c:53-59) for the current parameters */
+double mpg_get_numngb(mpg_engine *eng);
+
+/* Time-dependent scalars the reference derives from DriftKickTimes / Cosmology before the loops:
+ * kick_factor_data (density.h:34-39, filled by init_kick_factor_data density.c:115-132), the per-bin density drift
+ * factors of hydra.c:178-186, dloga_from_dti(Ti_Current - Ti_kick[bin]) used by SPH_EntVarPred (density.c:75),
+ * get_dloga_for_bin (hydra.c:271,463), and atime / hubble_function(atime) (hydra.c:219-223).  Index = time bin, 0..46. */
+typedef struct mpg_sph_times {
+    double FgravkickB;
+    double gravkicks[47];
+    double hydrokicks[47];
+    double drifts[47];
+    double dloga_kick[47];
+    double dloga_bin[47];
+    double atime, hubble;
+} mpg_sph_times;
+
+/* Device arrays of the particle table in caller order (n = bound particles).  SPH slot fields (SphP[P[i].PI].X,
+ * slotsmanager.h:93-129) are indexed by PARTICLE here; entries of non-gas particles are ignored.  NULL = absent/zero
+ * for the optional inputs (gacc, gpm, hydroacc_in, tb_*, dtentropy_in) and optional outputs (dthsml, gradrho). */
+typedef struct mpg_sph_arrays {
+    double *hsml;                 /* in/out  P.Hsml */
+    double *dthsml;               /* out     P.DtHsml */
+    const double *vel;            /* [n][3]  P.Vel */
+    const double *gacc;           /* [n][3]  P.FullTreeGravAccel */
+    const double *gpm;            /* [n][3]  P.GravPM */
+    const double *hydroacc_in;    /* [n][3]  SphP.HydroAccel (previous step, for the velocity prediction) */
+    const uint8_t *tb_hydro;      /* P.TimeBinHydro */
+    const uint8_t *tb_grav;       /* P.TimeBinGravity */
+    const double *entropy;        /* SphP.Entropy */
+    const double *dtentropy_in;   /* SphP.DtEntropy (previous step, for the entropy prediction) */
+    double *density;              /* out SphP.Density (BHP.Density for type 5 targets) */
+    double *egywtdensity;         /* out SphP.EgyWtDensity */
+    double *dhsmlegyfac;          /* out SphP.DhsmlEgyDensityFactor */
+    double *divvel;               /* out SphP.DivVel */
+    double *curlvel;              /* out SphP.CurlVel */
+    double *gradrho;              /* out [n][3] or NULL */
+    double *hydroacc_out;         /* out [n][3] SphP.HydroAccel */
+    double *dtentropy_out;        /* out SphP.DtEntropy */
+    double *maxsignalvel;         /* out SphP.MaxSignalVel */
+} mpg_sph_arrays;
+
+/* force_tree_rebuild_mask without moments (forcetree.c:151-166) on the bound particles; with_moments != 0 also runs
+ * force_tree_calc_moments (needed by set_init_hsml). */
+int mpg_dev_force_tree_rebuild_mask(mpg_engine *eng, int mask, int with_moments);
+/* set_init_hsml, libgadget/density.c:691-749 (tree with moments, mask GASMASK+BHMASK in the reference) */
+int mpg_dev_set_init_hsml(mpg_engine *eng, const mpg_sph_arrays *A, double MeanGasSeparation);
+/* density, libgadget/density.c:234-355.  d_active NULL = all particles.  Targets: gas and (non-swallowed) black holes. */
+int mpg_dev_density(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive,
+                    int update_hsml, int DoEgyDensity, int BlackHoleOn);
+/* force_tree_calc_moments after density (run.c:477): propagates the leaf hmax of the final Hsml up the gas tree */
+int mpg_dev_force_tree_calc_hmax(mpg_engine *eng);
+/* hydro_force, libgadget/hydra.c:153-245 (needs density() and the hmax moments of the same tree) */
+int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive);
+/* statistics of the last SPH call: [0] density iterations, [1] targets summed over iterations,
+ * [2] successful distance tests / hydro pairs evaluated, [3] candidates distance-tested */
+int mpg_sph_get_stats(mpg_engine *eng, int64_t stats[4]);
+
 /* ---- introspection (tests, bench roofline accounting) ----------------------------------------- */
 typedef struct mpg_tree_stats {
     int64_t NumParticles; /* particles in the tree */

@@ -9,6 +9,7 @@
 #include "grav_walk.h"
 #include "mpg_common.h"
 #include "pm.h"
+#include "sph.h"
 #include "tree_build.h"
 #include <cmath>
 #include <cstdlib>
@@ -49,6 +50,10 @@ struct mpg_engine {
     int64_t last_targets = 0;
     // un-synchronised HIP event pairs around every walk launch (collected by mpg_walk_events_collect)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> walk_events, free_events;
+    // SPH module state (static variables of density.c:20, hydra.c:26-34)
+    mpg_density_params denspar{1.0, 2.0, 2.0, 99999., 2 /* quintic */, 0.006};
+    mpg_hydro_params hydropar{1, 100.0, 0.75};
+    SphEngine sph;
     // bound device particles (caller order)
     int64_t n = 0;
     const double *d_pos = nullptr;
@@ -587,6 +592,131 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                 *(double *)(wb + i * P->stride + P->off_potential) = hp[i];
         }
     }
+    API_END
+}
+
+/* ------------------------------ SPH ------------------------------ */
+
+int mpg_set_densitypar(mpg_engine *eng, const mpg_density_params *dp)
+{
+    API_BEGIN
+    MPG_CHECK(eng && dp, "null argument");
+    MPG_CHECK(dp->DensityKernelType == 1 || dp->DensityKernelType == 2 || dp->DensityKernelType == 4, "Density Kernel type is unknown");
+    eng->denspar = *dp;
+    API_END
+}
+
+int mpg_set_hydropar(mpg_engine *eng, const mpg_hydro_params *hp)
+{
+    API_BEGIN
+    MPG_CHECK(eng && hp, "null argument");
+    eng->hydropar = *hp;
+    API_END
+}
+
+double mpg_get_numngb(mpg_engine *eng) { return eng ? sph_desnumngb(eng->denspar) : 0.0; }
+
+static SphView make_sph_view(mpg_engine *eng, const mpg_sph_arrays *A)
+{
+    MPG_CHECK(A, "null SPH arrays");
+    MPG_CHECK(A->hsml && A->vel && A->entropy && A->density && A->dhsmlegyfac && A->divvel && A->curlvel,
+              "SPH arrays: hsml, vel, entropy, density, dhsmlegyfac, divvel, curlvel are required");
+    SphView v{};
+    v.pos = eng->d_pos;
+    v.mass = eng->d_mass;
+    v.type = eng->d_type;
+    v.hsml = A->hsml;
+    v.dthsml = A->dthsml;
+    v.vel = A->vel;
+    v.gacc = A->gacc;
+    v.gpm = A->gpm;
+    v.hydroacc_in = A->hydroacc_in;
+    v.tb_hydro = A->tb_hydro;
+    v.tb_grav = A->tb_grav;
+    v.entropy = A->entropy;
+    v.dtentropy_in = A->dtentropy_in;
+    v.density = A->density;
+    v.egywtdensity = A->egywtdensity;
+    v.dhsmlegyfac = A->dhsmlegyfac;
+    v.divvel = A->divvel;
+    v.curlvel = A->curlvel;
+    v.gradrho = A->gradrho;
+    v.hydroacc_out = A->hydroacc_out;
+    v.dtentropy_out = A->dtentropy_out;
+    v.maxsignalvel = A->maxsignalvel;
+    return v;
+}
+
+int mpg_dev_force_tree_rebuild_mask(mpg_engine *eng, int mask, int with_moments)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
+    if(with_moments)
+        eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+    eng->tree_allocated = true;
+    eng->tree_mask = mask;
+    eng->full_particle_tree = (mask == 63) || (eng->tree.npart == eng->n);
+    eng->sph.hmax_pending = false;
+    API_END
+}
+
+int mpg_dev_set_init_hsml(mpg_engine *eng, const mpg_sph_arrays *A, double MeanGasSeparation)
+{
+    API_BEGIN
+    MPG_CHECK(eng && eng->tree_allocated, "set_init_hsml: no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    const SphView v = make_sph_view(eng, A);
+    eng->sph.set_init_hsml(eng->tree, v, eng->denspar, MeanGasSeparation, eng->stream);
+    API_END
+}
+
+int mpg_dev_density(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive,
+                    int update_hsml, int DoEgyDensity, int BlackHoleOn)
+{
+    API_BEGIN
+    MPG_CHECK(eng && T, "null argument");
+    MPG_CHECK(eng->tree_allocated, "density: no tree (force_tree_rebuild_mask first)");
+    MPG_CHECK((eng->tree_mask & 1) != 0, "density: the tree does not contain gas (GASMASK)"); // treewalk.c:942-943
+    MPG_CHECK(!DoEgyDensity || A->egywtdensity, "density: DoEgyDensity needs the egywtdensity array");
+    MPG_HIP(hipSetDevice(eng->device));
+    const SphView v = make_sph_view(eng, A);
+    eng->sph.density(eng->tree, v, *T, eng->denspar, 2.8 * eng->GravitySoftening, d_active, nactive, eng->n, update_hsml, DoEgyDensity,
+                     BlackHoleOn, eng->stream);
+    API_END
+}
+
+int mpg_dev_force_tree_calc_hmax(mpg_engine *eng)
+{
+    API_BEGIN
+    MPG_CHECK(eng && eng->tree_allocated, "force_tree_calc_moments: no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->sph.calc_hmax(eng->tree, eng->stream);
+    API_END
+}
+
+int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive)
+{
+    API_BEGIN
+    MPG_CHECK(eng && T, "null argument");
+    MPG_CHECK(eng->tree_allocated, "hydro_force: no tree");
+    MPG_CHECK(A->hydroacc_out && A->dtentropy_out && A->maxsignalvel, "hydro_force: output arrays are required");
+    MPG_CHECK(!eng->hydropar.DensityIndependentSphOn || A->egywtdensity, "hydro_force: pressure-entropy SPH needs egywtdensity");
+    MPG_HIP(hipSetDevice(eng->device));
+    const SphView v = make_sph_view(eng, A);
+    eng->sph.hydro_force(eng->tree, v, *T, eng->denspar, eng->hydropar, d_active, nactive, eng->n, eng->stream);
+    API_END
+}
+
+int mpg_sph_get_stats(mpg_engine *eng, int64_t stats[4])
+{
+    API_BEGIN
+    MPG_CHECK(eng && stats, "null argument");
+    stats[0] = eng->sph.last_iterations;
+    stats[1] = eng->sph.last_targets;
+    stats[2] = eng->sph.last_interactions;
+    stats[3] = eng->sph.last_candidates;
     API_END
 }
 

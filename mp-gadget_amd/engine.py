@@ -66,6 +66,35 @@ class PhaseTimes(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class DensityParams(C.Structure):
+    """struct density_params, density.h:10-25"""
+    _fields_ = [("DensityResolutionEta", C.c_double), ("MaxNumNgbDeviation", C.c_double), ("BlackHoleNgbFactor", C.c_double),
+                ("BlackHoleMaxAccretionRadius", C.c_double), ("DensityKernelType", C.c_int), ("MinGasHsmlFractional", C.c_double)]
+
+
+class HydroParams(C.Structure):
+    """struct hydro_params, hydra.c:26-34"""
+    _fields_ = [("DensityIndependentSphOn", C.c_int), ("DensityContrastLimit", C.c_double), ("ArtBulkViscConst", C.c_double)]
+
+
+class SphTimes(C.Structure):
+    """Time-dependent scalars of the SPH loops (kick_factor_data density.h:34-39, drifts hydra.c:178-186, dloga per bin)."""
+    _fields_ = [("FgravkickB", C.c_double), ("gravkicks", C.c_double * 47), ("hydrokicks", C.c_double * 47),
+                ("drifts", C.c_double * 47), ("dloga_kick", C.c_double * 47), ("dloga_bin", C.c_double * 47),
+                ("atime", C.c_double), ("hubble", C.c_double)]
+
+
+SPH_ARRAY_FIELDS = ("hsml", "dthsml", "vel", "gacc", "gpm", "hydroacc_in", "tb_hydro", "tb_grav", "entropy", "dtentropy_in",
+                    "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel", "gradrho", "hydroacc_out", "dtentropy_out",
+                    "maxsignalvel")
+
+
+class SphArraysC(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in SPH_ARRAY_FIELDS]
+
+
+DENSITY_KERNEL_CUBIC_SPLINE, DENSITY_KERNEL_QUINTIC_SPLINE, DENSITY_KERNEL_QUARTIC_SPLINE = 1, 2, 4   # densitykernel.h:17-21
+
 _lib = None
 
 
@@ -87,6 +116,8 @@ def load_library():
     L.mpg_engine_destroy.argtypes = [C.c_void_p]
     L.mpg_engine_destroy.restype = None
     L.mpg_dev_tree_order.restype = C.c_void_p
+    L.mpg_get_numngb.restype = C.c_double
+    L.mpg_get_numngb.argtypes = [C.c_void_p]
     L.mpg_dev_tree_order.argtypes = [C.c_void_p]
     _lib = L
     return L
@@ -251,6 +282,56 @@ class Engine:
             nact = active.shape[0]
         self._ck(self.lib.mpg_dev_grav_short_tree(self.h, _ptr(oldacc), _ptr(prev_accel), _ptr(gravpm), _ptr(active),
                                                   C.c_int64(nact), _ptr(accel), _ptr(potential), C.c_double(rho0)))
+
+    # ------------------------------------------------------------------ SPH (device-resident)
+    def set_densitypar(self, DensityResolutionEta=1.0, MaxNumNgbDeviation=2.0, BlackHoleNgbFactor=2.0,
+                       BlackHoleMaxAccretionRadius=99999., DensityKernelType=DENSITY_KERNEL_QUINTIC_SPLINE,
+                       MinGasHsmlFractional=0.006):
+        p = DensityParams(DensityResolutionEta, MaxNumNgbDeviation, BlackHoleNgbFactor, BlackHoleMaxAccretionRadius,
+                          DensityKernelType, MinGasHsmlFractional)
+        self._ck(self.lib.mpg_set_densitypar(self.h, C.byref(p)))
+
+    def set_hydropar(self, DensityIndependentSphOn=1, DensityContrastLimit=100.0, ArtBulkViscConst=0.75):
+        p = HydroParams(DensityIndependentSphOn, DensityContrastLimit, ArtBulkViscConst)
+        self._ck(self.lib.mpg_set_hydropar(self.h, C.byref(p)))
+
+    def GetNumNgb(self):
+        return self.lib.mpg_get_numngb(self.h)
+
+    @staticmethod
+    def _sph_arrays(arrays):
+        """arrays: dict name -> device tensor (torch) / raw pointer / None for the fields of mpg_sph_arrays."""
+        a = SphArraysC()
+        for k in SPH_ARRAY_FIELDS:
+            t = arrays.get(k)
+            setattr(a, k, None if t is None else (t if isinstance(t, int) else t.data_ptr()))
+        return a
+
+    def dev_force_tree_rebuild_mask(self, mask, with_moments=False):
+        self._ck(self.lib.mpg_dev_force_tree_rebuild_mask(self.h, int(mask), int(bool(with_moments))))
+
+    def dev_set_init_hsml(self, arrays, MeanGasSeparation):
+        a = self._sph_arrays(arrays)
+        self._ck(self.lib.mpg_dev_set_init_hsml(self.h, C.byref(a), C.c_double(MeanGasSeparation)))
+
+    def dev_density(self, arrays, times, active=None, update_hsml=1, DoEgyDensity=0, BlackHoleOn=0):
+        a = self._sph_arrays(arrays)
+        nact = 0 if active is None else active.shape[0]
+        self._ck(self.lib.mpg_dev_density(self.h, C.byref(a), C.byref(times), _ptr(active), C.c_int64(nact), int(update_hsml),
+                                          int(DoEgyDensity), int(BlackHoleOn)))
+
+    def dev_force_tree_calc_hmax(self):
+        self._ck(self.lib.mpg_dev_force_tree_calc_hmax(self.h))
+
+    def dev_hydro_force(self, arrays, times, active=None):
+        a = self._sph_arrays(arrays)
+        nact = 0 if active is None else active.shape[0]
+        self._ck(self.lib.mpg_dev_hydro_force(self.h, C.byref(a), C.byref(times), _ptr(active), C.c_int64(nact)))
+
+    def sph_stats(self):
+        c = (C.c_int64 * 4)()
+        self._ck(self.lib.mpg_sph_get_stats(self.h, c))
+        return dict(iterations=c[0], targets=c[1], interactions=c[2], candidates=c[3])
 
     # ------------------------------------------------------------------ introspection
     def tree_stats(self):

@@ -129,7 +129,7 @@ def s_zel(n, box=None, seed=181170, rms_disp=0.5, index=-2.0):
     dk[0, 0, 0] = 0
     psi = []
     for K in (KX, KY, KZ):
-        psi.append(np.fft.irfftn(1j * K / k2 * dk, s=(n, n, n)))
+        psi.append(np.fft.irfftn(1j * K / k2 * dk, s=(n, n, n), axes=(0, 1, 2)))
     psi = np.stack(psi, axis=-1).reshape(-1, 3)
     psi *= rms_disp / np.sqrt(np.mean(psi ** 2))
     idx = np.arange(n ** 3, dtype=np.int64)

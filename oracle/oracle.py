@@ -286,3 +286,132 @@ def gravpm_force(pos, mass, box, nmesh, Asmth=1.5, G=43.0071, want_potential=Tru
         fk = pot_k * (1j * diffs[d])
         out[:, d] = pm_readout(np.fft.irfftn(fk, s=(nmesh,) * 3, axes=(0, 1, 2)) * n3, pos, box, nmesh)
     return out, potential
+
+
+# ------------------------------------------------------------------------------------------
+# SPH oracle (sph_oracle.c): densitykernel.c / density.c / hydra.c restated
+# ------------------------------------------------------------------------------------------
+TIMEBINS = 46
+
+
+class DensityParams(C.Structure):
+    """struct density_params, density.h:10-25"""
+    _fields_ = [("DensityResolutionEta", C.c_double), ("MaxNumNgbDeviation", C.c_double), ("BlackHoleNgbFactor", C.c_double),
+                ("BlackHoleMaxAccretionRadius", C.c_double), ("DensityKernelType", C.c_int), ("MinGasHsmlFractional", C.c_double)]
+
+
+class HydroParams(C.Structure):
+    """struct hydro_params, hydra.c:26-34"""
+    _fields_ = [("DensityIndependentSphOn", C.c_int), ("DensityContrastLimit", C.c_double), ("ArtBulkViscConst", C.c_double)]
+
+
+class SphTimes(C.Structure):
+    _fields_ = [("FgravkickB", C.c_double), ("gravkicks", C.c_double * (TIMEBINS + 1)), ("hydrokicks", C.c_double * (TIMEBINS + 1)),
+                ("drifts", C.c_double * (TIMEBINS + 1)), ("dloga_kick", C.c_double * (TIMEBINS + 1)),
+                ("dloga_bin", C.c_double * (TIMEBINS + 1)), ("atime", C.c_double), ("hubble", C.c_double)]
+
+
+class _SphArraysC(C.Structure):
+    _fields_ = [("n", C.c_int64)] + [(k, C.c_void_p) for k in (
+        "pos", "mass", "type", "hsml", "dthsml", "vel", "gacc", "gpm", "hydroacc_in", "tb_hydro", "tb_grav", "entropy",
+        "dtentropy_in", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel", "numngb", "gradrho", "hydroacc_out",
+        "dtentropy_out", "maxsignalvel", "entvarpred")]
+
+
+class SphArrays:
+    """Particle table for the SPH oracle in caller order; arrays are numpy (owned here)."""
+
+    def __init__(self, pos, mass, type=None, hsml=None, vel=None, entropy=None, want_gradrho=False):
+        n = len(pos)
+        self.n = n
+        f8 = np.float64
+        self.pos = np.ascontiguousarray(pos, f8)
+        self.mass = np.ascontiguousarray(mass, np.float32)
+        self.type = np.zeros(n, np.int32) if type is None else np.ascontiguousarray(type, np.int32)
+        self.hsml = np.zeros(n, f8) if hsml is None else np.ascontiguousarray(hsml, f8).copy()
+        self.vel = np.zeros((n, 3), f8) if vel is None else np.ascontiguousarray(vel, f8)
+        self.gacc = np.zeros((n, 3), f8)
+        self.gpm = np.zeros((n, 3), f8)
+        self.hydroacc_in = np.zeros((n, 3), f8)
+        self.tb_hydro = np.zeros(n, np.uint8)
+        self.tb_grav = np.zeros(n, np.uint8)
+        self.entropy = np.ones(n, f8) if entropy is None else np.ascontiguousarray(entropy, f8)
+        self.dtentropy_in = np.zeros(n, f8)
+        for k in ("dthsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel", "numngb", "dtentropy_out",
+                  "maxsignalvel", "entvarpred"):
+            setattr(self, k, np.zeros(n, f8))
+        self.hydroacc_out = np.zeros((n, 3), f8)
+        self.gradrho = np.zeros((n, 3), f8) if want_gradrho else None
+
+    def c(self):
+        s = _SphArraysC()
+        s.n = self.n
+        for k, _ in _SphArraysC._fields_[1:]:
+            a = getattr(self, k)
+            setattr(s, k, None if a is None else a.ctypes.data)
+        return s
+
+
+def sph_times(atime=1.0, hubble=0.1, **kw):
+    t = SphTimes()
+    t.atime = atime
+    t.hubble = hubble
+    for k, v in kw.items():
+        if isinstance(v, (int, float)):
+            setattr(t, k, v)
+        else:
+            arr = getattr(t, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+    return t
+
+
+def _sph_bind(L):
+    if getattr(L, "_sph_bound", False):
+        return
+    L.os_density.restype = C.c_int
+    L.os_density.argtypes = [C.c_void_p, C.POINTER(DensityParams), C.POINTER(_SphArraysC), C.POINTER(SphTimes), C.c_int64,
+                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.os_set_init_hsml.argtypes = [C.c_void_p, C.POINTER(DensityParams), C.POINTER(_SphArraysC), C.c_double]
+    L.os_hydro_force.argtypes = [C.c_void_p, C.POINTER(DensityParams), C.POINTER(HydroParams), C.POINTER(_SphArraysC),
+                                 C.POINTER(SphTimes), C.c_int64, C.c_void_p, C.c_void_p]
+    L.os_set_softening.argtypes = [C.c_double]
+    L.os_kernel_desnumngb.restype = C.c_double
+    L.os_kernel_desnumngb.argtypes = [C.c_int, C.c_double]
+    L.os_kernel_index.argtypes = [C.c_int]
+    L._sph_bound = True
+
+
+def sph_density(orc, tree, dp, arrays, times, active=None, update_hsml=1, DoEgyDensity=0, BlackHoleOn=0):
+    """density() of density.c:234-355 on an OracleTree built WITHOUT moments (father array needed).
+    Returns stats [iterations, targets summed, successful distance tests, candidates]."""
+    _sph_bind(orc.lib)
+    st = np.zeros(4, np.int64)
+    act = None if active is None else np.ascontiguousarray(active, np.int32)
+    ca = arrays.c()
+    rc = orc.lib.os_density(tree.h, C.byref(dp), C.byref(ca), C.byref(times), 0 if act is None else len(act), _vp(act),
+                            update_hsml, DoEgyDensity, BlackHoleOn, _vp(st))
+    if rc != 0:
+        raise RuntimeError("failed to converge density (MAXITER)")
+    return st
+
+
+def sph_set_init_hsml(orc, tree, dp, arrays, mean_gas_separation):
+    _sph_bind(orc.lib)
+    ca = arrays.c()
+    orc.lib.os_set_init_hsml(tree.h, C.byref(dp), C.byref(ca), mean_gas_separation)
+
+
+def sph_hydro_force(orc, tree, dp, hp, arrays, times, active=None):
+    """hydro_force() of hydra.c:153-245; `tree` must have had calc_moments() run after the density loop (hmax)."""
+    _sph_bind(orc.lib)
+    st = np.zeros(2, np.int64)
+    act = None if active is None else np.ascontiguousarray(active, np.int32)
+    ca = arrays.c()
+    orc.lib.os_hydro_force(tree.h, C.byref(dp), C.byref(hp), C.byref(ca), C.byref(times), 0 if act is None else len(act), _vp(act), _vp(st))
+    return st
+
+
+def sph_set_softening(orc, force_softening):
+    _sph_bind(orc.lib)
+    orc.lib.os_set_softening(force_softening)

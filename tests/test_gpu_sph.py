@@ -1,0 +1,197 @@
+"""GPU parity tests of the SPH path: HIP density / hmax / hydro kernels (through the C-ABI, device-resident arrays) vs the
+CPU oracle on the same inputs.
+
+Tolerances: the Hsml iteration takes the same branch sequence on both sides, so |dH|/H <= 1e-12 is
+expected; Density, DivVel, CurlVel, HydroAccel relative <= 1e-10 (the device evaluates the kernel polynomials by
+multiplication, the reference by pow(): ulp-level differences); fallback bound |dH/H| < MaxNumNgbDeviation/DesNumNgb
+(test_density.c:144) is asserted as well.  Iteration counts and neighbour counters must be EQUAL.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_oracle_sph import density_test_set
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_arrays(torch, pos, mass, typ, hsml, vel, entropy, extra=None):
+    dev = "cuda"
+    n = len(pos)
+    f8 = torch.float64
+    a = dict(hsml=torch.from_numpy(hsml.copy()).to(dev), dthsml=torch.zeros(n, dtype=f8, device=dev),
+             vel=torch.from_numpy(np.ascontiguousarray(vel)).to(dev), entropy=torch.from_numpy(np.ascontiguousarray(entropy)).to(dev),
+             density=torch.zeros(n, dtype=f8, device=dev), egywtdensity=torch.zeros(n, dtype=f8, device=dev),
+             dhsmlegyfac=torch.zeros(n, dtype=f8, device=dev), divvel=torch.zeros(n, dtype=f8, device=dev),
+             curlvel=torch.zeros(n, dtype=f8, device=dev), gradrho=torch.zeros(n, 3, dtype=f8, device=dev),
+             hydroacc_out=torch.zeros(n, 3, dtype=f8, device=dev), dtentropy_out=torch.zeros(n, dtype=f8, device=dev),
+             maxsignalvel=torch.zeros(n, dtype=f8, device=dev))
+    for k, v in (extra or {}).items():
+        a[k] = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    keep = dict(pos=torch.from_numpy(pos).to(dev), mass=torch.from_numpy(mass).to(dev), type=torch.from_numpy(typ.astype(np.uint8)).to(dev))
+    return a, keep
+
+
+def make_times(pkg, **kw):
+    t = pkg.SphTimes()
+    t.atime = kw.pop("atime", 1.0)
+    t.hubble = kw.pop("hubble", 0.1)
+    for k, v in kw.items():
+        if isinstance(v, (int, float)):
+            setattr(t, k, v)
+        else:
+            arr = getattr(t, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+    return t
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("kind", ["flat", "close"])
+def test_reference_density_known_answer_on_gpu(pkg, orc, kind):
+    """The reference's own test (test_density.c:55-150): set_init_hsml + density, cubic spline; mean Hsml known answer."""
+    import torch
+    pos, mass, typ, box = density_test_set(kind)
+    N = len(pos)
+    eng = pkg.Engine(0)
+    eng.set_gravshort_treepar(FractionalGravitySoftening=1.0)
+    eng.gravshort_set_softenings(1.0)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_CUBIC_SPLINE, 0.006)
+    a, keep = gpu_arrays(torch, pos, mass, typ, np.zeros(N), np.full((N, 3), 1.5), np.ones(N))
+    eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK + pkg.engine.BHMASK, with_moments=True)
+    eng.dev_set_init_hsml(a, box)
+    eng.synchronize()          # dev_* calls are asynchronous on the engine stream
+    h0 = a["hsml"].cpu().numpy()
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    t = make_times(pkg)
+    eng.dev_density(a, t)
+    st = eng.sph_stats()
+    expected = {"flat": 0.501747, "close": 0.131726}[kind]
+    h = a["hsml"].cpu().numpy()
+    assert abs(h.mean() - expected) < 1e-4
+    # oracle on the same inputs
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 1, 0.006)
+    O.sph_set_softening(orc, 2.8)
+    A = O.SphArrays(pos, mass, type=typ, vel=np.full((N, 3), 1.5))
+    tr = orc.tree(pos, mass, box, type=typ, mask=1 + 32, moments=True)
+    O.sph_set_init_hsml(orc, tr, dp, A, box)
+    assert np.abs(h0 / A.hsml - 1).max() <= 1e-13
+    tr2 = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    so = O.sph_density(orc, tr2, dp, A, O.sph_times())
+    assert (st["iterations"], st["targets"], st["interactions"], st["candidates"]) == tuple(so)
+    assert np.abs(h / A.hsml - 1).max() <= 1e-12
+    gas = typ == 0
+    assert rel(a["density"].cpu().numpy()[gas], A.density[gas]) <= 1e-10
+    assert rel(a["dhsmlegyfac"].cpu().numpy()[gas], A.dhsmlegyfac[gas]) <= 1e-10
+    eng.close()
+
+
+@pytest.mark.parametrize("pe", [0, 1])
+def test_density_hmax_hydro_parity(pkg, orc, pe):
+    """density -> hmax moments -> hydro_force (run.c:466-489) with non-trivial velocities, entropies, kick / drift factors
+    and two hydro time bins; quintic spline; density-entropy (pe=0) and pressure-entropy (pe=1) SPH."""
+    import torch
+    n = 20
+    pos, mass, box = pkg.ics.s_zel(n, box=8.0)
+    N = len(pos)
+    rng = np.random.RandomState(3)
+    typ = np.zeros(N, np.int32)
+    typ[rng.choice(N, N // 5, replace=False)] = 1            # dark matter mixed in: not in the gas tree
+    vel = rng.standard_normal((N, 3))
+    ent = 1.0 + 0.5 * rng.random_sample(N)
+    tbh = rng.randint(0, 2, N).astype(np.uint8) * 3
+    extra = dict(gacc=rng.standard_normal((N, 3)) * 0.1, gpm=rng.standard_normal((N, 3)) * 0.1,
+                 hydroacc_in=rng.standard_normal((N, 3)) * 0.1, dtentropy_in=rng.standard_normal(N) * 0.01, tb_hydro=tbh, tb_grav=tbh)
+    kicks = [0.0] * 47
+    kicks[3] = 0.02
+    tk = dict(atime=0.5, hubble=0.3, FgravkickB=0.01, gravkicks=kicks, hydrokicks=kicks, drifts=[0.0, 0, 0, 0.015] + [0.0] * 43,
+              dloga_kick=[0.0, 0, 0, 0.02] + [0.0] * 43, dloga_bin=[0.01, 0, 0, 0.04] + [0.0] * 43)
+    h0 = np.full(N, 2.5 * box / n)
+    eng = pkg.Engine(0)
+    eng.set_gravshort_treepar()
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(pe, 100.0, 0.75)
+    a, keep = gpu_arrays(torch, pos, mass, typ, h0, vel, ent, extra)
+    eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    t = make_times(pkg, **tk)
+    eng.dev_density(a, t, DoEgyDensity=pe)
+    sd = eng.sph_stats()
+    eng.dev_force_tree_calc_hmax()
+    eng.dev_hydro_force(a, t)
+    sh = eng.sph_stats()
+    eng.synchronize()
+    # oracle
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 2, 0.006)
+    O.sph_set_softening(orc, 2.8 * (box / n) / 30.)
+    A = O.SphArrays(pos, mass, type=typ, hsml=h0, vel=vel, entropy=ent, want_gradrho=True)
+    A.gacc[:], A.gpm[:], A.hydroacc_in[:], A.dtentropy_in[:] = extra["gacc"], extra["gpm"], extra["hydroacc_in"], extra["dtentropy_in"]
+    A.tb_hydro[:] = tbh
+    A.tb_grav[:] = tbh
+    to = O.sph_times(**tk)
+    tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    so = O.sph_density(orc, tr, dp, A, to, DoEgyDensity=pe)
+    tr.calc_moments()
+    ho = O.sph_hydro_force(orc, tr, dp, O.HydroParams(pe, 100.0, 0.75), A, to)
+    gas = typ == 0
+    g = lambda k: a[k].cpu().numpy()
+    assert (sd["iterations"], sd["targets"], sd["interactions"], sd["candidates"]) == tuple(so)
+    assert np.abs(g("hsml")[gas] / A.hsml[gas] - 1).max() <= 1e-12
+    for k in ("density", "divvel", "curlvel", "dhsmlegyfac", "dthsml") + (("egywtdensity",) if pe else ()):
+        assert rel(g(k)[gas], getattr(A, k)[gas]) <= 1e-10, k
+    assert rel(g("gradrho")[gas], A.gradrho[gas]) <= 1e-10
+    assert abs(eng.tree_stats().root_hmax / tr.export()["hmax"][0] - 1) <= 1e-12
+    assert (sh["candidates"], sh["interactions"]) == tuple(ho)
+    assert rel(g("hydroacc_out")[gas], A.hydroacc_out[gas]) <= 1e-10
+    assert rel(g("dtentropy_out")[gas], A.dtentropy_out[gas]) <= 1e-10
+    assert rel(g("maxsignalvel")[gas], A.maxsignalvel[gas]) <= 1e-12
+    # untouched entries of non-gas particles
+    assert np.all(g("hydroacc_out")[~gas] == 0) and np.all(g("density")[~gas] == 0)
+    eng.close()
+
+
+def test_density_active_subset_and_errors(pkg, orc):
+    import torch
+    n = 16
+    pos, mass, box = pkg.ics.s_grid(n, box=8.0)
+    N = len(pos)
+    typ = np.zeros(N, np.int32)
+    vel = np.zeros((N, 3))
+    h0 = np.full(N, 2.0 * box / n)
+    eng = pkg.Engine(0)
+    eng.set_gravshort_treepar()
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUARTIC_SPLINE, 0.006)
+    a, keep = gpu_arrays(torch, pos, mass, typ, h0, vel, np.ones(N))
+    eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
+    with pytest.raises(pkg.EngineError, match="no tree|rebuild"):
+        eng.force_tree_free()
+        eng.dev_density(a, make_times(pkg))
+    eng.dev_force_tree_rebuild_mask(pkg.engine.DMMASK)
+    with pytest.raises(pkg.EngineError, match="does not contain gas"):
+        eng.dev_density(a, make_times(pkg))
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    with pytest.raises(pkg.EngineError, match="before hmax"):
+        eng.dev_hydro_force(a, make_times(pkg))
+    act = np.sort(np.random.RandomState(1).choice(N, 500, replace=False)).astype(np.int32)
+    dact = torch.from_numpy(act).cuda()
+    eng.dev_density(a, make_times(pkg), active=dact)
+    eng.synchronize()
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 4, 0.006)
+    O.sph_set_softening(orc, 2.8 * (box / n) / 30.)
+    A = O.SphArrays(pos, mass, type=typ, hsml=h0, vel=vel)
+    tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    O.sph_density(orc, tr, dp, A, O.sph_times(), active=act)
+    h = a["hsml"].cpu().numpy()
+    assert np.abs(h / A.hsml - 1).max() <= 1e-12
+    inactive = np.setdiff1d(np.arange(N), act)
+    assert np.array_equal(h[inactive], h0[inactive])
+    assert rel(a["density"].cpu().numpy()[act], A.density[act]) <= 1e-10
+    eng.close()
