@@ -37,12 +37,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=0, help="particles per dimension (default: 256 per GPU, weak scaling)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=int(os.environ.get("MPG_BENCH_N", "0")),
+                    help="particles per dimension (default: 256 per GPU, weak scaling)")
     ap.add_argument("--ic", default="s_grid", choices=["s_grid", "s_zel", "s_clust"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro"],
+                    help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
+                         "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,12 +59,22 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("MPG_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("MPG_DIST_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU in tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "hydro":
+        if world != 1:
+            raise SystemExit("--workload hydro is single-GPU in this round")
+        return hydro_bench(pkg, torch, args, dev)
     n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / 16)) * 16)
     nmesh = 2 * n
     gen = getattr(pkg.ics, args.ic)
@@ -172,12 +186,84 @@ def main():
     return out
 
 
+def hydro_bench(pkg, torch, args, dev):
+    """BASELINE.json configs[2]: 2 x n^3 (dark matter + gas), density-entropy SPH: one force step =
+    gravpm_force + force_tree_full + grav_short_tree (all particles) + force_tree_rebuild_mask(GAS) + density
+    + force_tree_calc_moments (hmax) + hydro_force  (run.c:466-548)."""
+    n = args.n or 128
+    nmesh = 2 * n
+    posd, _, box = pkg.ics.s_zel(n)
+    sp = box / n
+    ob, om = 0.045, 0.3                                   # gas / DM offsets of genic/main.c:61-63
+    posg = np.mod(posd - 0.5 * (om - ob) / om * sp, box)
+    posd = np.mod(posd + 0.5 * ob / om * sp, box)
+    posg[posg <= 0] += box
+    posd[posd <= 0] += box
+    pos = np.concatenate([posg, posd])
+    N = len(pos)
+    mass = np.concatenate([np.full(n ** 3, ob / om, np.float32), np.full(n ** 3, 1 - ob / om, np.float32)])
+    typ = np.concatenate([np.zeros(n ** 3, np.uint8), np.ones(n ** 3, np.uint8)])
+    f8 = torch.float64
+    d_pos, d_mass, d_type = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
+    eng = pkg.Engine(dev.index or 0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_walk_variant(args.variant)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(TreeUseBH=2)
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(0, 100.0, 0.75)
+    eng.dev_bind_particles(d_pos, d_mass, box, type=d_type)
+    z1 = lambda: torch.zeros(N, dtype=f8, device=dev)
+    z3 = lambda: torch.zeros(N, 3, dtype=f8, device=dev)
+    a = dict(hsml=z1(), dthsml=z1(), vel=z3(), entropy=torch.ones(N, dtype=f8, device=dev), density=z1(), egywtdensity=z1(),
+             dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(), hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
+    gravpm, acc, prev, pot = z3(), z3(), z3(), z1()
+    t = pkg.SphTimes()
+    t.atime, t.hubble = 0.1, 0.1
+    for i in range(47):
+        t.dloga_bin[i] = 0.01
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK + pkg.engine.BHMASK, with_moments=True)
+    eng.dev_set_init_hsml(a, box / n)
+    iters = []
+
+    def step():
+        nonlocal acc, prev
+        eng.dev_gravpm_force(gravpm, pot)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+        eng.dev_density(a, t)
+        iters.append(eng.sph_stats()["iterations"])
+        eng.dev_force_tree_calc_hmax()
+        eng.dev_hydro_force(a, t)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "2x%d^3 DM+gas TreePM + density-entropy SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, nmesh),
+                      "particles": N, "density_iterations": iters[-args.steps:]}}
+    print(json.dumps(out), flush=True)
+    eng.close()
+    return out
+
+
 def _as_tensor(torch, ptr, n, dev):
     """Zero-copy int32 view of engine-owned device memory (the tree-order permutation)."""
     class _Holder:
         pass
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), True), "version": 2}
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(h, device=dev)
 
 

@@ -35,7 +35,14 @@ def exchange_results(values, order, rank, world, sbuf=None, gbuf=None, group=Non
     if gbuf is None:
         gbuf = torch.zeros((world * chunk,) + tuple(values.shape[1:]), dtype=values.dtype, device=values.device)
     sbuf[:hi - lo] = values[order[lo:hi].long()]
-    dist.all_gather_into_tensor(gbuf, sbuf, group=group)
+    try:
+        dist.all_gather_into_tensor(gbuf, sbuf, group=group)
+    except (RuntimeError, NotImplementedError):
+        # backends without the flat form (gloo on device tensors): gather a list and copy
+        parts = [torch.empty_like(sbuf) for _ in range(world)]
+        dist.all_gather(parts, sbuf, group=group)
+        for r in range(world):
+            gbuf[r * chunk:(r + 1) * chunk] = parts[r]
     for r in range(world):
         rlo, rhi = slot_range(n, r, world)
         values[order[rlo:rhi].long()] = gbuf[r * chunk:r * chunk + (rhi - rlo)]

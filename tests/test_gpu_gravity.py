@@ -277,6 +277,25 @@ def test_load_order_torch_first():
     assert out.returncode == 0 and "gfx950" in out.stdout, out.stderr[-2000:]
 
 
+def test_two_ranks_match_one(tmp_path):
+    """N > 1 path with the real kernels: two ranks (gloo, sharing this GPU) each walk half of the tree-order slots and
+    all-gather; rank 0 must end with exactly the single-rank accelerations (same tree, same per-target arithmetic)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "tools", "mgpu_check.py"), one, "40"], capture_output=True, text=True,
+                        timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29577", os.path.join(root, "tools", "mgpu_check.py"), two, "40"], capture_output=True,
+                        text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a1, a2 = np.load(one), np.load(two)
+    assert np.array_equal(a1, a2)
+
+
 # ------------------------------------------------------------------------------- full size (BASELINE.json configs[1])
 def test_full_size_256_properties(pkg, orc):
     """256^3, Nmesh 512 on the device-resident path: size-independent properties + a sampled oracle comparison.

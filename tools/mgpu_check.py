@@ -1,0 +1,52 @@
+"""Run one sharded TreePM force step under torch.distributed and save rank 0's accelerations (used by
+tests/test_gpu_gravity.py::test_two_ranks_match_one).  Launch with torch.distributed.run; MPG_DIST_BACKEND=gloo lets the
+ranks share one GPU."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("mp-gadget_amd")
+import torch
+import torch.distributed as dist
+sys.path.insert(0, ROOT)
+import bench
+
+out = sys.argv[1]
+n = int(sys.argv[2])
+rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+lr = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(lr)
+dev = torch.device("cuda", lr)
+if world > 1:
+    dist.init_process_group(os.environ.get("MPG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+G = 43.0071
+pos, mass, box = pkg.ics.s_zel(n)
+N = len(pos)
+d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
+eng = pkg.Engine(lr)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.gravshort_fill_ntab(0, 1.5)
+eng.gravpm_init_periodic(box, 1.5, 2 * n, G)
+eng.set_gravshort_treepar(TreeUseBH=0)
+eng.gravshort_set_softenings(box / n)
+eng.dev_bind_particles(d_pos, d_mass, box)
+gravpm = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+acc = torch.zeros_like(gravpm)
+old = torch.full((N,), 1e-7, dtype=torch.float64, device=dev)
+eng.dev_gravpm_force(gravpm, None)
+eng.dev_force_tree_build()
+lo, hi = pkg.shard.slot_range(N, rank, world)
+if world == 1:
+    eng.dev_grav_short_tree(acc, oldacc=old)
+else:
+    optr = eng.dev_tree_order_ptr()
+    eng.dev_grav_short_tree(acc, oldacc=old, active=optr + 4 * lo, nactive=hi - lo)
+    order = bench._as_tensor(torch, optr, N, dev)
+    pkg.shard.exchange_results(acc, order, rank, world)
+torch.cuda.synchronize()
+if rank == 0:
+    np.save(out, acc.cpu().numpy())
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+eng.close()
