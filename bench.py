@@ -157,6 +157,12 @@ def main():
         walk_avg_ms = walk_ms / max(walk_launches, 1)
         achieved = b_alg / (walk_avg_ms * 1e-3) / 1e9
         flops = (cnt["pp"] + cnt["nodes_used"]) * 38.0
+        traffic, traffic_note = None, "no PMC summary committed for this configuration"
+        tpath = os.path.join(ROOT, "profiles", "walk_traffic.json")
+        if os.path.exists(tpath) and N == 256 ** 3 and args.ic == "s_grid":
+            tj = json.load(open(tpath))
+            traffic = tj["hbm_bytes_per_launch"]
+            traffic_note = "bytes per launch of %s from %s" % (tj["kernel"], tj["method"])
         out = {
             "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,7 +173,7 @@ def main():
                        "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
                        "targets sharded over %d GPUs (tree-order ranges), all-gather of accelerations" % world},
             "roofline": {"bound": "hbm", "kernel": "k_grav_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
                          "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
                          "note": "algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 (SURVEY 8(d)); reuse through L1/L2/LDS makes "

@@ -363,8 +363,12 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     const double maxleaf = 1.001 * gp.box / (double)(1 << eng->tree.minleaflevel);
     const bool fastwrap = !getenv("MPG_NO_FASTWRAP") && (gp.rcut + 1.5 * maxleaf < 0.49 * gp.box) && (gp.rcut < 0.2 * gp.box);
     auto run_variant = [&](int v) {
+        if(v != 1)
+            eng->tree.ensure_level_order(eng->stream); // variants 4 and 5 walk the level-ordered copy of the tree
         if(v == 1)
-            launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->walk_thresh, eng->stream);
+            launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
+        else if(v == 5)
+            launch_grav_walk_shared(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->w3, eng->stream);
         else
             launch_grav_walk_coop(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->w3, eng->stream);
     };
@@ -381,6 +385,7 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
                 MPG_HIP(hipEventCreate(&a));
                 MPG_HIP(hipEventCreate(&b));
                 MPG_HIP(hipEventCreate(&c));
+                run_variant(4); // untimed: first use allocates the list scratch area
                 MPG_HIP(hipEventRecord(a, eng->stream));
                 run_variant(1);
                 MPG_HIP(hipEventRecord(b, eng->stream));
@@ -891,7 +896,7 @@ int mpg_set_walk_list_capacity(mpg_engine *eng, int cap)
 int mpg_set_walk_variant(mpg_engine *eng, int variant)
 {
     API_BEGIN
-    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4), "walk variant must be 0 (auto), 1 or 4");
+    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4 || variant == 5), "walk variant must be 0 (auto), 1, 4 or 5");
     eng->walk_variant = variant;
     eng->walk_choice = 0;
     API_END

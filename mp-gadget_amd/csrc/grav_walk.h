@@ -19,7 +19,8 @@ struct WalkIO {
     unsigned long long *counters = nullptr; // [8] pp interactions, nodes visited, nodes used, burst statistics (COUNT builds only)
 };
 
-void launch_grav_walk(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, int thresh, hipStream_t st);
+void launch_grav_walk(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,
+                      hipStream_t st);
 
 // group-cooperative list-form walk (grav_walk_coop.hip): the default.  Persistent kernel; every group of 8 lanes owns
 // one target and keeps its interaction lists in a per-wave scratch area.
@@ -32,6 +33,9 @@ struct WalkScratch {
 // fastwrap: the minimum-image wrap may be hoisted out of the pair loop (decided by the caller from Rcut, Box, leaf sizes)
 void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap,
                            WalkScratch &ws, hipStream_t st);
+// shared-traversal walk (grav_walk_shared.hip): the 8 targets of a wave share one tree traversal
+void launch_grav_walk_shared(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, WalkScratch &ws,
+                             hipStream_t st);
 // returns the device error flag of the last cooperative walk (0 = ok); synchronises the stream
 unsigned walk_coop_error(WalkScratch &ws, hipStream_t st);
 

@@ -36,22 +36,27 @@ struct WTab {
     double a, b; // T[t], T[t+1]
 };
 
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    // v_rsq_f64 + one cubic Newton step -> full double precision; x > 0
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
 template <bool POT>
-__device__ __forceinline__ void interact(const Src4 s, const double px, const double py, const double pz, const GravParams &gp,
+__device__ __forceinline__ void interact(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
                                          const WTab *__restrict__ wf, const WTab *__restrict__ wp, double &ax, double &ay, double &az,
                                          double &pot)
 {
     // apply_accn_to_output, gravshort-tree.c:158-193
-    const double dx = nearest_img(s.x - px, gp.box, gp.invbox);
-    const double dy = nearest_img(s.y - py, gp.box, gp.invbox);
-    const double dz = nearest_img(s.z - pz, gp.box, gp.invbox);
     const double r2 = dx * dx + dy * dy + dz * dz;
-    const double rinv = (r2 > 0) ? rsqrt(r2) : 0.0;
-    const double r = r2 * rinv;
-    const double ti = r * gp.inv_cell_dx; // r / cellsize / dx, gravity.c:57-58
-    if(ti >= (double)(NTAB - 1))
-        return; // tabindex >= NTAB-1: no contribution (gravity.c:60-61)
-    double fac, facpot;
+    const double rinv = rsqrt_nr(fmax(r2, 1e-300));
+    const double r = r2 * rinv;                   // exactly 0 for the self interaction
+    const double ti = r * gp.inv_cell_dx;         // r / cellsize / dx, gravity.c:57-58
+    const bool inrange = ti < (double)(NTAB - 1); // tabindex >= NTAB-1: no contribution (gravity.c:60-61)
+    double fac = s.m * rinv * rinv * rinv;
+    double facpot = -s.m * rinv;
     if(r2 < gp.h * gp.h) {
         const double u = r / gp.h;
         double wpk;
@@ -65,25 +70,25 @@ __device__ __forceinline__ void interact(const Src4 s, const double px, const do
         }
         facpot = s.m / gp.h * wpk;
     }
-    else {
-        fac = s.m * rinv * rinv * rinv;
-        facpot = -s.m * rinv;
-    }
-    const int t = (int)ti;
-    const double w1 = ti - (double)t, w0 = (double)(t + 1) - ti;
+    const double tcl = inrange ? ti : 0.0;
+    const int t = (int)tcl;
+    // (t + 1 - i) and (i - t) of gravity.c:63 are both exact, so 1 - (i - t) is the same number as (t + 1 - i)
+    const double w1 = tcl - (double)t, w0 = 1.0 - w1;
     const WTab f = wf[t];
-    fac *= w0 * f.a + w1 * f.b;
-    ax += dx * fac;
-    ay += dy * fac;
-    az += dz * fac;
+    const double wgt = inrange ? (w0 * f.a + w1 * f.b) : 0.0;
+    fac *= wgt;
+    ax = fma(dx, fac, ax);
+    ay = fma(dy, fac, ay);
+    az = fma(dz, fac, az);
     if(POT) {
         const WTab p = wp[t];
-        pot += facpot * (w0 * p.a + w1 * p.b);
+        const double wpot = inrange ? (w0 * p.a + w1 * p.b) : 0.0;
+        pot = fma(facpot, wpot, pot);
     }
 }
 
-template <bool POT, bool COUNT, int THRESH>
-__global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const GravParams gp, const WalkIO io)
+template <bool POT, bool COUNT, bool FASTWRAP, int THRESH>
+__global__ void __launch_bounds__(256, 6) k_grav_walk(const TreeView tv, const GravParams gp, const WalkIO io)
 {
     __shared__ WTab s_wf[NTAB];
     __shared__ WTab s_wp[POT ? NTAB : 1];
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const Grav
     const int64_t npart = tv.npart;
     int no = valid ? 0 : -1;
     int ps = 0, pc = 0;
+    double spx = px, spy = py, spz = pz; // target shifted to the periodic image of the pending range (FASTWRAP)
     double ax = 0, ay = 0, az = 0, pot = 0;
     unsigned n_pp = 0, n_vis = 0, n_used = 0;
 
@@ -151,13 +157,23 @@ __global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const Grav
                 const NodeLink lk = tv.link[no];
                 if(COUNT)
                     n_vis++;
-                const double dx = nearest_img(mom.x - px, gp.box, gp.invbox);
-                const double dy = nearest_img(mom.y - py, gp.box, gp.invbox);
-                const double dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
+                // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
+                const double kx = rint((g.cx - px) * gp.invbox), ky = rint((g.cy - py) * gp.invbox), kz = rint((g.cz - pz) * gp.invbox);
+                double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
+                const double cdx = fabs(g.cx - qx), cdy = fabs(g.cy - qy), cdz = fabs(g.cz - qz);
+                double dx = mom.x - qx, dy = mom.y - qy, dz = mom.z - qz;
+                if(!FASTWRAP || g.len * 4.0 > gp.box) {
+                    // (top levels only when FASTWRAP) centre of mass and geometric centre may sit on different periodic
+                    // images: take NEAREST(cofm - pos) exactly as gravshort-tree.c:299-300 does
+                    const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
+                    qx = fma(jx, gp.box, px);
+                    qy = fma(jy, gp.box, py);
+                    qz = fma(jz, gp.box, pz);
+                    dx = fma(-jx, gp.box, mom.x - px);
+                    dy = fma(-jy, gp.box, mom.y - py);
+                    dz = fma(-jz, gp.box, mom.z - pz);
+                }
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                const double cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
-                const double cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
-                const double cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
                 // shall_we_discard_node, gravshort-tree.c:198-215
                 const double eff = gp.rcut + 0.5 * g.len;
                 const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
@@ -174,6 +190,9 @@ __global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const Grav
                         // node used unopened: its moments are a 1-element source range
                         ps = (int)(npart + no);
                         pc = 1;
+                        spx = qx;
+                        spy = qy;
+                        spz = qz;
                         no = lk.sibling;
                         if(COUNT)
                             n_used++;
@@ -181,6 +200,9 @@ __global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const Grav
                     else if(lk.pcount > 0) {
                         ps = lk.pstart;
                         pc = lk.pcount;
+                        spx = qx;
+                        spy = qy;
+                        spz = qz;
                         no = lk.sibling;
                         if(COUNT)
                             n_pp += lk.pcount;
@@ -198,8 +220,21 @@ __global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const Grav
             const bool has = k < pc;
             if(__ballot(has) == 0)
                 break;
-            if(has)
-                interact<POT>(tv.src[ps + k], px, py, pz, gp, s_wf, s_wp, ax, ay, az, pot);
+            if(has) {
+                const Src4 sc = tv.src[ps + k];
+                double dx, dy, dz;
+                if(FASTWRAP) {
+                    dx = sc.x - spx;
+                    dy = sc.y - spy;
+                    dz = sc.z - spz;
+                }
+                else {
+                    dx = nearest_img(sc.x - px, gp.box, gp.invbox);
+                    dy = nearest_img(sc.y - py, gp.box, gp.invbox);
+                    dz = nearest_img(sc.z - pz, gp.box, gp.invbox);
+                }
+                interact<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
+            }
         }
         pc = 0;
     }
@@ -233,7 +268,7 @@ __global__ void __launch_bounds__(256) k_grav_walk(const TreeView tv, const Grav
     }
 }
 
-template <bool POT, bool COUNT> static void launch_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, int thresh, hipStream_t st)
+template <bool POT, bool COUNT, bool FASTWRAP> static void launch_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, int thresh, hipStream_t st)
 {
     const int64_t nb = (io.ntargets + 255) / 256;
     if(nb == 0)
@@ -242,30 +277,39 @@ template <bool POT, bool COUNT> static void launch_t(const TreeView &tv, const G
     const unsigned per = (unsigned)((nb + 7) / 8);
     dim3 grid(per * 8), block(256);
     switch(thresh) {
-    case 1: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, 1>), grid, block, 0, st, tv, gp, io); break;
-    case 8: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, 8>), grid, block, 0, st, tv, gp, io); break;
-    case 16: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, 16>), grid, block, 0, st, tv, gp, io); break;
-    case 32: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, 32>), grid, block, 0, st, tv, gp, io); break;
-    case 48: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, 48>), grid, block, 0, st, tv, gp, io); break;
-    default: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, 24>), grid, block, 0, st, tv, gp, io); break;
+    case 1: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, FASTWRAP, 1>), grid, block, 0, st, tv, gp, io); break;
+    case 8: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, FASTWRAP, 8>), grid, block, 0, st, tv, gp, io); break;
+    case 16: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, FASTWRAP, 16>), grid, block, 0, st, tv, gp, io); break;
+    case 32: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, FASTWRAP, 32>), grid, block, 0, st, tv, gp, io); break;
+    case 48: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, FASTWRAP, 48>), grid, block, 0, st, tv, gp, io); break;
+    default: hipLaunchKernelGGL((k_grav_walk<POT, COUNT, FASTWRAP, 24>), grid, block, 0, st, tv, gp, io); break;
     }
     MPG_HIP(hipGetLastError());
 }
 
-void launch_grav_walk(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, int thresh, hipStream_t st)
+void launch_grav_walk(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,
+                      hipStream_t st)
 {
+#define MPG_W1(P, C)                                          \
+    do {                                                      \
+        if(fastwrap)                                          \
+            launch_t<P, C, true>(tv, gp, io, thresh, st);     \
+        else                                                  \
+            launch_t<P, C, false>(tv, gp, io, thresh, st);    \
+    } while(0)
     if(want_pot) {
         if(count)
-            launch_t<true, true>(tv, gp, io, thresh, st);
+            MPG_W1(true, true);
         else
-            launch_t<true, false>(tv, gp, io, thresh, st);
+            MPG_W1(true, false);
     }
     else {
         if(count)
-            launch_t<false, true>(tv, gp, io, thresh, st);
+            MPG_W1(false, true);
         else
-            launch_t<false, false>(tv, gp, io, thresh, st);
+            MPG_W1(false, false);
     }
+#undef MPG_W1
 }
 
 } // namespace mpg

@@ -83,6 +83,7 @@ struct TreeBuilder {
     void calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st);
     // build / refresh the level-ordered copy from the depth-first arrays (after moments and/or hmax are known)
     void make_level_order(hipStream_t st);
+    void ensure_level_order(hipStream_t st);
     TreeView view() const;
 };
 

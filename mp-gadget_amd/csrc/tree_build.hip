@@ -358,6 +358,12 @@ __global__ void __launch_bounds__(256) k_build_level_order(int64_t nnodes, int64
 
 static inline int nblk(int64_t n, int b = 256) { return (int)((n + b - 1) / b); }
 
+void TreeBuilder::ensure_level_order(hipStream_t st)
+{
+    if(!has_bfs)
+        make_level_order(st);
+}
+
 void TreeBuilder::make_level_order(hipStream_t st)
 {
     const int64_t M = nnodes;
@@ -486,7 +492,7 @@ void TreeBuilder::calc_moments(const double *d_hsml_gasbh_treeorder, hipStream_t
     }
     has_moments = true;
     has_hmax = hm != nullptr;
-    make_level_order(st);
+    has_bfs = false; // the level-ordered copy is made on demand (ensure_level_order) by the kernels that walk it
     if(tm)
         tm->lap(st, &tm->t.tree_moments);
 }

@@ -18,7 +18,7 @@ eng.set_gravshort_treepar(TreeUseBH=0); eng.gravshort_set_softenings(box / n)
 P = pkg.make_particles(pos, mass)
 P["FullTreeGravAccel"][:, 0] = 1e-6 * G
 eng.force_tree_full(P, box)
-for variant in (1, 4):
+for variant in (1, 4, 5):
     eng.set_walk_variant(variant)
     store = np.zeros((len(pos), 3))
     P["FullTreeGravAccel"] = 0; P["FullTreeGravAccel"][:, 0] = 1e-6 * G
