@@ -204,6 +204,14 @@ int mpg_dev_density(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_time
 int mpg_dev_force_tree_calc_hmax(mpg_engine *eng);
 /* hydro_force, libgadget/hydra.c:153-245 (needs density() and the hmax moments of the same tree) */
 int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive);
+/* Host-pointer forms of the four calls above: `P` supplies Pos / Mass / Type / flags (the reference AoS table), `A` holds HOST
+ * arrays in particle order (the in-tree shim gathers SphP[P[i].PI].X into them).  Inputs are copied to HBM,
+ * outputs copied back; the gas tree is (re)built inside, as force_tree_rebuild_mask does in run.c:466. */
+int mpg_set_init_hsml(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, double MeanGasSeparation);
+int mpg_density(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, const mpg_sph_times *T,
+                const int *ActiveParticle, int64_t NumActiveParticle, int update_hsml, int DoEgyDensity, int BlackHoleOn);
+int mpg_hydro_force(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T,
+                    const int *ActiveParticle, int64_t NumActiveParticle);
 /* statistics of the last SPH call: [0] density iterations, [1] targets summed over iterations,
  * [2] successful distance tests / hydro pairs evaluated, [3] candidates distance-tested */
 int mpg_sph_get_stats(mpg_engine *eng, int64_t stats[4]);

@@ -60,6 +60,9 @@ struct mpg_engine {
     const float *d_mass = nullptr;
     const uint8_t *d_type = nullptr;
     double box = 0;
+    // staging for the host SPH path: one device buffer per mpg_sph_arrays field
+    DevBuf<double> h_sph[19];
+    DevBuf<uint8_t> h_sph_u8[2];
     // staging for the host (AoS) path
     DevBuf<double> s_pos, s_accel, s_gravpm, s_pot, s_prev, s_old;
     DevBuf<float> s_mass;
@@ -711,6 +714,124 @@ int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_
     MPG_HIP(hipSetDevice(eng->device));
     const SphView v = make_sph_view(eng, A);
     eng->sph.hydro_force(eng->tree, v, *T, eng->denspar, eng->hydropar, d_active, nactive, eng->n, eng->stream);
+    API_END
+}
+
+/* host-pointer SPH path: stage every array of mpg_sph_arrays in HBM (doubles: hsml, dthsml, vel[3], gacc[3], gpm[3],
+ * hydroacc_in[3], entropy, dtentropy_in, density, egywtdensity, dhsmlegyfac, divvel, curlvel, gradrho[3], hydroacc_out[3],
+ * dtentropy_out, maxsignalvel; bytes: tb_hydro, tb_grav) */
+namespace {
+struct SphField {
+    int idx;      // slot in h_sph (or h_sph_u8 when width == 0)
+    int width;    // doubles per particle; 0 = uint8
+    bool in, out; // copied to / from the device
+};
+// order = field order of mpg_sph_arrays
+const SphField SPH_FIELDS[19] = {{0, 1, true, true},  {1, 1, false, true}, {2, 3, true, false},  {3, 3, true, false}, {4, 3, true, false},
+                                 {5, 3, true, false}, {0, 0, true, false}, {1, 0, true, false},  {6, 1, true, false}, {7, 1, true, false},
+                                 {8, 1, true, true},  {9, 1, true, true},  {10, 1, true, true},  {11, 1, true, true}, {12, 1, true, true},
+                                 {13, 3, false, true}, {14, 3, false, true}, {15, 1, false, true}, {16, 1, false, true}};
+
+void stage_sph(mpg_engine *eng, const mpg_sph_arrays *host, mpg_sph_arrays *dev, int64_t n)
+{
+    void *const *hp = (void *const *)host;
+    void **dp = (void **)dev;
+    for(int f = 0; f < 19; f++) {
+        dp[f] = nullptr;
+        if(!hp[f])
+            continue;
+        const SphField &F = SPH_FIELDS[f];
+        if(F.width == 0) {
+            eng->h_sph_u8[F.idx].reserve((size_t)n + 1);
+            dp[f] = eng->h_sph_u8[F.idx].p;
+            MPG_HIP(hipMemcpyAsync(dp[f], hp[f], (size_t)n, hipMemcpyHostToDevice, eng->stream));
+        }
+        else {
+            eng->h_sph[F.idx].reserve((size_t)n * F.width + 1);
+            dp[f] = eng->h_sph[F.idx].p;
+            if(F.in)
+                MPG_HIP(hipMemcpyAsync(dp[f], hp[f], (size_t)n * F.width * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+            else
+                MPG_HIP(hipMemsetAsync(dp[f], 0, (size_t)n * F.width * sizeof(double), eng->stream));
+        }
+    }
+}
+
+void unstage_sph(mpg_engine *eng, const mpg_sph_arrays *host, const mpg_sph_arrays *dev, int64_t n, bool hydro)
+{
+    void *const *hp = (void *const *)host;
+    void *const *dp = (void *const *)dev;
+    for(int f = 0; f < 19; f++) {
+        const SphField &F = SPH_FIELDS[f];
+        if(!hp[f] || !F.out || F.width == 0)
+            continue;
+        const bool hydro_field = (f >= 16);          // hydroacc_out, dtentropy_out, maxsignalvel
+        if(hydro != hydro_field)
+            continue;
+        MPG_HIP(hipMemcpyAsync(hp[f], dp[f], (size_t)n * F.width * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    }
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+}
+} // namespace
+
+int mpg_set_init_hsml(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, double MeanGasSeparation)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && A, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    stage_particles(eng, P, BoxSize);
+    mpg_sph_arrays d;
+    stage_sph(eng, A, &d, P->n);
+    // the reference calls it on the GAS+BH tree with moments (init.c:485-511, test_density.c:86-87)
+    if(mpg_dev_force_tree_rebuild_mask(eng, 1 + 32, 1) || mpg_dev_set_init_hsml(eng, &d, MeanGasSeparation))
+        throw Error(g_err);
+    MPG_HIP(hipMemcpyAsync(A->hsml, d.hsml, P->n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    API_END
+}
+
+int mpg_density(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, const mpg_sph_times *T,
+                const int *ActiveParticle, int64_t NumActiveParticle, int update_hsml, int DoEgyDensity, int BlackHoleOn)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && A && T, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    stage_particles(eng, P, BoxSize);
+    mpg_sph_arrays d;
+    stage_sph(eng, A, &d, P->n);
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    if(mpg_dev_force_tree_rebuild_mask(eng, 1 /* GASMASK */, 0) ||
+       mpg_dev_density(eng, &d, T, d_act, NumActiveParticle, update_hsml, DoEgyDensity, BlackHoleOn) ||
+       (update_hsml && mpg_dev_force_tree_calc_hmax(eng)))
+        throw Error(g_err);
+    unstage_sph(eng, A, &d, P->n, false);
+    API_END
+}
+
+int mpg_hydro_force(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T,
+                    const int *ActiveParticle, int64_t NumActiveParticle)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && A && T, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->tree_allocated && eng->tree.has_hmax, "Hydro called before hmax computed"); // hydra.c:172-173
+    MPG_CHECK(P->n == eng->n, "hydro_force: particle table changed size since density()");
+    mpg_sph_arrays d;
+    stage_sph(eng, A, &d, P->n);
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    if(mpg_dev_hydro_force(eng, &d, T, d_act, NumActiveParticle))
+        throw Error(g_err);
+    unstage_sph(eng, A, &d, P->n, true);
     API_END
 }
 

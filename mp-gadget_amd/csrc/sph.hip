@@ -358,15 +358,25 @@ __global__ void __launch_bounds__(256) k_density_init(int64_t nact, const int *_
                                                       double box, int *__restrict__ queue, unsigned *__restrict__ nqueue)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if(k >= nact)
-        return;
-    const int i = active ? active[k] : (int)k;
-    C.Right[i] = box; // density.c:277-285
-    C.NumNgb[i] = 0;
-    C.Left[i] = 0;
-    const int ty = A.type ? (A.type[i] & 7) : 0;
-    if(ty == 0 || ty == 5) // density_haswork, density.c:521-530
-        queue[atomicAdd(nqueue, 1u)] = i;
+    const bool inb = k < nact;
+    const int i = inb ? (active ? active[k] : (int)k) : 0;
+    if(inb) {
+        C.Right[i] = box; // density.c:277-285
+        C.NumNgb[i] = 0;
+        C.Left[i] = 0;
+    }
+    const int ty = (inb && A.type) ? (A.type[i] & 7) : 0;
+    const bool work = inb && (ty == 0 || ty == 5); // density_haswork, density.c:521-530
+    // wave-aggregated append: one atomic per wave (same-address atomics serialise)
+    const unsigned long long m = __ballot(work);
+    unsigned basepos = 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    if(work && lane == leader)
+        basepos = atomicAdd(nqueue, (unsigned)__popcll(m));
+    basepos = __shfl(basepos, leader < 0 ? 0 : leader);
+    if(work)
+        queue[basepos + __popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 // hsml of the gas particles of the tree in tree order (negative: does not contribute), for force_tree hmax

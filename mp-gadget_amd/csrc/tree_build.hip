@@ -81,39 +81,61 @@ __global__ void __launch_bounds__(256) k_gather_src(int64_t n, const uint32_t *_
     src[k] = s;
 }
 
-// flags[0]: error (too many coincident particles), flags[1]: max leaf level
+// flags[0]: error (too many coincident particles), flags[1]: max leaf level, flags[2]: MAXLEVEL - min leaf level
+// Each block stages its 256 keys plus an 8-key halo on either side in LDS (one coalesced read instead of 17 per thread).
 __global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__restrict__ keys, uint8_t *__restrict__ leaflevel,
                                                    uint32_t *__restrict__ cnt, int *__restrict__ flags)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= n)
-        return;
-    const uint64_t ki = keys[i];
-    int cl[9], cr[9];
-    cl[0] = cr[0] = MAXLEVEL + 1;
+    __shared__ uint64_t sk[256 + 16];
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t i = base + threadIdx.x;
+    for(int t = threadIdx.x; t < 256 + 16; t += 256) {
+        const int64_t j = base - 8 + t;
+        sk[t] = (j >= 0 && j < n) ? keys[j] : 0;
+    }
+    __syncthreads();
+    const bool inb = i < n;
+    int L = 0;
+    bool head = false;
+    if(inb) {
+        const int c0 = threadIdx.x + 8;
+        const uint64_t ki = sk[c0];
+        int cl[9], cr[9];
+        cl[0] = cr[0] = MAXLEVEL + 1;
 #pragma unroll
-    for(int a = 1; a <= 8; a++) {
-        cl[a] = (i - a >= 0) ? cpl_levels(ki, keys[i - a]) : -1;
-        cr[a] = (i + a < n) ? cpl_levels(ki, keys[i + a]) : -1;
-    }
-    int best = -1;
+        for(int a = 1; a <= 8; a++) {
+            cl[a] = (i - a >= 0) ? cpl_levels(ki, sk[c0 - a]) : -1;
+            cr[a] = (i + a < n) ? cpl_levels(ki, sk[c0 + a]) : -1;
+        }
+        int best = -1;
 #pragma unroll
-    for(int a = 0; a <= 8; a++) {
-        const int m = cl[a] < cr[8 - a] ? cl[a] : cr[8 - a];
-        best = m > best ? m : best;
+        for(int a = 0; a <= 8; a++) {
+            const int m = cl[a] < cr[8 - a] ? cl[a] : cr[8 - a];
+            best = m > best ? m : best;
+        }
+        L = best + 1; // shallowest level whose cell holds <= 8 particles
+        if(L > MAXLEVEL) {
+            flags[0] = 1;
+            L = MAXLEVEL;
+        }
+        leaflevel[i] = (uint8_t)L;
+        const int c = (i == 0) ? -1 : cl[1];
+        head = (i == 0) || (c < L);
+        cnt[i] = head ? (uint32_t)(L - c) : 0u;
     }
-    int L = best + 1; // shallowest level whose cell holds <= 8 particles
-    if(L > MAXLEVEL) {
-        flags[0] = 1;
-        L = MAXLEVEL;
+    // one atomic per wave for the level extrema
+    int lmax = head ? L : 0, lmin = head ? (MAXLEVEL - L) : 0;
+    for(int off = 32; off > 0; off >>= 1) {
+        lmax = max(lmax, __shfl_down(lmax, off));
+        lmin = max(lmin, __shfl_down(lmin, off));
     }
-    leaflevel[i] = (uint8_t)L;
-    const int c = (i == 0) ? -1 : cl[1];
-    const bool head = (i == 0) || (c < L);
-    cnt[i] = head ? (uint32_t)(L - c) : 0u;
-    if(head) {
-        atomicMax(&flags[1], L);
-        atomicMax(&flags[2], MAXLEVEL - L); // -> shallowest leaf level
+    // same-address atomics serialise at ~90 per microsecond on MI355X: only issue one when it would change the value
+    // (the plain read may be stale-low, which costs an unnecessary atomic, never a missed update)
+    if((threadIdx.x & 63) == 0) {
+        if(lmax > __builtin_nontemporal_load(&flags[1]))
+            atomicMax(&flags[1], lmax);
+        if(lmin > __builtin_nontemporal_load(&flags[2]))
+            atomicMax(&flags[2], lmin); // -> shallowest leaf level
     }
 }
 

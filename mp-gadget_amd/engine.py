@@ -328,6 +328,39 @@ class Engine:
         nact = 0 if active is None else active.shape[0]
         self._ck(self.lib.mpg_dev_hydro_force(self.h, C.byref(a), C.byref(times), _ptr(active), C.c_int64(nact)))
 
+    # host-pointer SPH path: `arrays` maps field names of mpg_sph_arrays to contiguous numpy arrays in particle order
+    @staticmethod
+    def _sph_host_arrays(arrays):
+        a = SphArraysC()
+        for k in SPH_ARRAY_FIELDS:
+            t = arrays.get(k)
+            if t is not None:
+                want = np.uint8 if k.startswith("tb_") else np.float64
+                if t.dtype != want or not t.flags["C_CONTIGUOUS"]:
+                    raise EngineError("SPH host array %s must be contiguous %s" % (k, want.__name__))
+            setattr(a, k, None if t is None else t.ctypes.data)
+        return a
+
+    def set_init_hsml(self, P, BoxSize, arrays, MeanGasSeparation):
+        v = self._view(P)
+        a = self._sph_host_arrays(arrays)
+        self._ck(self.lib.mpg_set_init_hsml(self.h, C.byref(v), C.c_double(BoxSize), C.byref(a), C.c_double(MeanGasSeparation)))
+
+    def density(self, P, BoxSize, arrays, times, ActiveParticle=None, update_hsml=1, DoEgyDensity=0, BlackHoleOn=0):
+        v = self._view(P)
+        a = self._sph_host_arrays(arrays)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        self._ck(self.lib.mpg_density(self.h, C.byref(v), C.c_double(BoxSize), C.byref(a), C.byref(times),
+                                      None if act is None else act.ctypes.data_as(C.c_void_p), C.c_int64(0 if act is None else len(act)),
+                                      int(update_hsml), int(DoEgyDensity), int(BlackHoleOn)))
+
+    def hydro_force(self, P, arrays, times, ActiveParticle=None):
+        v = self._view(P)
+        a = self._sph_host_arrays(arrays)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        self._ck(self.lib.mpg_hydro_force(self.h, C.byref(v), C.byref(a), C.byref(times),
+                                          None if act is None else act.ctypes.data_as(C.c_void_p), C.c_int64(0 if act is None else len(act))))
+
     def sph_stats(self):
         c = (C.c_int64 * 4)()
         self._ck(self.lib.mpg_sph_get_stats(self.h, c))

@@ -195,3 +195,42 @@ def test_density_active_subset_and_errors(pkg, orc):
     assert np.array_equal(h[inactive], h0[inactive])
     assert rel(a["density"].cpu().numpy()[act], A.density[act]) <= 1e-10
     eng.close()
+
+
+def test_host_pointer_sph_path(pkg, orc):
+    """Drop-in (host pointer) forms: set_init_hsml -> density -> hydro_force on struct particle_data + SoA SPH arrays."""
+    n = 14
+    pos, mass, box = pkg.ics.s_zel(n, box=8.0)
+    N = len(pos)
+    rng = np.random.RandomState(5)
+    vel = rng.standard_normal((N, 3))
+    ent = 1.0 + 0.5 * rng.random_sample(N)
+    P = pkg.make_particles(pos, mass, type=0)
+    eng = pkg.Engine(0)
+    eng.set_gravshort_treepar()
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(0, 100.0, 0.75)
+    z = lambda *s: np.zeros(s)
+    a = dict(hsml=z(N), dthsml=z(N), vel=vel.copy(), entropy=ent.copy(), density=z(N), egywtdensity=z(N), dhsmlegyfac=z(N), divvel=z(N),
+             curlvel=z(N), hydroacc_out=z(N, 3), dtentropy_out=z(N), maxsignalvel=z(N))
+    t = make_times(pkg, atime=0.5, hubble=0.3, dloga_bin=[0.01] * 47)
+    eng.set_init_hsml(P, box, a, box / n)
+    h_init = a["hsml"].copy()
+    eng.density(P, box, a, t)
+    eng.hydro_force(P, a, t)
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 2, 0.006)
+    O.sph_set_softening(orc, 2.8 * (box / n) / 30.)
+    A = O.SphArrays(pos, mass, vel=vel, entropy=ent)
+    tr = orc.tree(pos, mass, box, type=A.type, mask=1 + 32, moments=True)
+    O.sph_set_init_hsml(orc, tr, dp, A, box / n)
+    assert np.abs(h_init / A.hsml - 1).max() <= 1e-13
+    tr2 = orc.tree(pos, mass, box, type=A.type, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    to = O.sph_times(atime=0.5, hubble=0.3, dloga_bin=[0.01] * 47)
+    O.sph_density(orc, tr2, dp, A, to)
+    tr2.calc_moments()
+    O.sph_hydro_force(orc, tr2, dp, O.HydroParams(0, 100.0, 0.75), A, to)
+    assert np.abs(a["hsml"] / A.hsml - 1).max() <= 1e-12
+    assert rel(a["density"], A.density) <= 1e-10 and rel(a["hydroacc_out"], A.hydroacc_out) <= 1e-10
+    assert rel(a["dtentropy_out"], A.dtentropy_out) <= 1e-10 and rel(a["maxsignalvel"], A.maxsignalvel) <= 1e-12
+    eng.close()
