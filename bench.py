@@ -157,12 +157,15 @@ def main():
         walk_avg_ms = walk_ms / max(walk_launches, 1)
         achieved = b_alg / (walk_avg_ms * 1e-3) / 1e9
         flops = (cnt["pp"] + cnt["nodes_used"]) * 38.0
+        variant, list_cap, list_ovf = eng.walk_choice()
+        kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 5: "k_grav_walk_shared", 6: "k_walk_lists + k_walk_eval"}.get(variant, "?")
         traffic, traffic_note = None, "no PMC summary committed for this configuration"
         tpath = os.path.join(ROOT, "profiles", "walk_traffic.json")
         if os.path.exists(tpath) and N == 256 ** 3 and args.ic == "s_grid":
-            tj = json.load(open(tpath))
-            traffic = tj["hbm_bytes_per_launch"]
-            traffic_note = "bytes per launch of %s from %s" % (tj["kernel"], tj["method"])
+            tj = json.load(open(tpath)).get("variants", {}).get(str(variant))
+            if tj:
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_note = "bytes per walk (%s) from %s" % (tj["kernel"], tj["method"])
         out = {
             "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,13 +175,15 @@ def main():
                                    "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
                        "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
                        "targets sharded over %d GPUs (tree-order ranges), all-gather of accelerations" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_grav_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernels, "walk_variant": variant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
                          "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
-                         "note": "algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 (SURVEY 8(d)); reuse through L1/L2/LDS makes "
-                                 "this exceed HBM traffic; the kernel is fp64-VALU bound: %.1f TFLOP/s fp64-equivalent "
-                                 "(38 flop per interaction) of 78.6 peak" % (flops / (walk_avg_ms * 1e-3) / 1e12)},
+                         "note": "one launch = one short-range walk over all targets (variant 6: list-construction + evaluation "
+                                 "kernel pairs over slices of 2^21 targets); algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 "
+                                 "(SURVEY 8(d)); reuse through L1/L2/LDS makes this exceed HBM traffic; the walk is bound by fp64 "
+                                 "VALU issue and the vector-memory pipe, not HBM: %.1f TFLOP/s fp64-equivalent (38 flop per "
+                                 "interaction) of 78.6 peak" % (flops / (walk_avg_ms * 1e-3) / 1e12)},
             "phases_ms": {k: round(v, 3) for k, v in ph.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -253,13 +253,19 @@ int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
  * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
 const int *mpg_dev_tree_order(mpg_engine *eng);
 /* Tuning knobs of the walk; results do not depend on any of them.
- *   variant   0 = auto (default): time kernels 1 and 4 once on a large walk and keep the faster (re-tuned every 64 walks);
- *             1 = lane-per-target while-while kernel (grav_walk.hip); 4 = group-cooperative list kernel (grav_walk_coop.hip)
+ *   variant   0 = auto (default): time kernels 1, 4 and 6 once on a large walk and keep the fastest (re-tuned every 64 walks);
+ *             1 = lane-per-target while-while kernel (grav_walk.hip); 4 = group-cooperative list kernel (grav_walk_coop.hip);
+ *             5 = shared-traversal kernel (grav_walk_shared.hip, experimental);
+ *             6 = two kernels, list construction then evaluation (grav_walk_split.hip)
  *   threshold (kernel 1) the node phase keeps running while at least that many lanes of a wave still search (default 16)
- *   list capacity (kernel 4) interaction-list entries per target before a group drains its lists (default 512) */
+ *   list capacity (kernels 4, 6) interaction-list entries per target (default 512): kernel 4 drains its lists when they are
+ *             full; kernel 6 hands targets with longer lists to kernel 1 and doubles its capacity when > 2 % of them do */
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
 int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
 int mpg_set_walk_variant(mpg_engine *eng, int variant);
+/* kernel in use (the explicit variant, or the auto-tuner's pick; 0 = not tuned yet), kernel 6's current list capacity and
+ * the number of targets its last walk handed to the fallback kernel (either output may be NULL) */
+int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsigned *last_overflow);
 
 #ifdef __cplusplus
 }

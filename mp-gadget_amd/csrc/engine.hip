@@ -370,6 +370,8 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
             eng->tree.ensure_level_order(eng->stream); // variants 4 and 5 walk the level-ordered copy of the tree
         if(v == 1)
             launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
+        else if(v == 6)
+            launch_grav_walk_split(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->w3, eng->stream);
         else if(v == 5)
             launch_grav_walk_shared(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->w3, eng->stream);
         else
@@ -377,30 +379,37 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     };
     int variant = eng->walk_variant;
     if(variant == 0) {
-        // auto: both kernels compute the same interaction sets; time each once and keep the faster.  Re-tuned every 64
+        // auto: all kernels compute the same interaction sets; time kernels 1, 4 and 6 once and keep the fastest.  Re-tuned every 64
         // walks, and only on walks large enough for the timing to mean something.
         if(eng->walk_choice == 0 || (eng->walks_since_tune >= 64 && io.ntargets >= 65536)) {
             if(io.ntargets < 65536)
                 variant = 1;
             else {
-                float t1 = 0, t4 = 0;
-                hipEvent_t a, b, c;
-                MPG_HIP(hipEventCreate(&a));
-                MPG_HIP(hipEventCreate(&b));
-                MPG_HIP(hipEventCreate(&c));
-                run_variant(4); // untimed: first use allocates the list scratch area
-                MPG_HIP(hipEventRecord(a, eng->stream));
-                run_variant(1);
-                MPG_HIP(hipEventRecord(b, eng->stream));
+                // untimed runs first: first use allocates the list areas, and kernel 6 adapts its list capacity
                 run_variant(4);
-                MPG_HIP(hipEventRecord(c, eng->stream));
-                MPG_HIP(hipEventSynchronize(c));
-                MPG_HIP(hipEventElapsedTime(&t1, a, b));
-                MPG_HIP(hipEventElapsedTime(&t4, b, c));
-                (void)hipEventDestroy(a);
-                (void)hipEventDestroy(b);
-                (void)hipEventDestroy(c);
-                eng->walk_choice = (t4 < t1) ? 4 : 1;
+                run_variant(6);
+                run_variant(6);
+                const int cand[3] = {1, 4, 6};
+                hipEvent_t ev4[4];
+                for(auto &e : ev4)
+                    MPG_HIP(hipEventCreate(&e));
+                MPG_HIP(hipEventRecord(ev4[0], eng->stream));
+                for(int i = 0; i < 3; i++) {
+                    run_variant(cand[i]);
+                    MPG_HIP(hipEventRecord(ev4[i + 1], eng->stream));
+                }
+                MPG_HIP(hipEventSynchronize(ev4[3]));
+                float best = 0;
+                for(int i = 0; i < 3; i++) {
+                    float t = 0;
+                    MPG_HIP(hipEventElapsedTime(&t, ev4[i], ev4[i + 1]));
+                    if(i == 0 || t < best) {
+                        best = t;
+                        eng->walk_choice = cand[i];
+                    }
+                }
+                for(auto &e : ev4)
+                    (void)hipEventDestroy(e);
                 eng->walks_since_tune = 0;
                 if(walk_coop_error(eng->w3, eng->stream) != 0)
                     eng->walk_choice = 1;
@@ -1011,13 +1020,26 @@ int mpg_set_walk_list_capacity(mpg_engine *eng, int cap)
     API_BEGIN
     MPG_CHECK(eng && cap >= 16 && cap <= 65536, "walk list capacity must be in [16, 65536]");
     eng->w3.cap = cap;
+    eng->w3.split_cap = (cap + 7) / 8 * 8;
+    API_END
+}
+
+int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsigned *last_overflow)
+{
+    API_BEGIN
+    MPG_CHECK(eng && variant, "null argument");
+    *variant = eng->walk_variant ? eng->walk_variant : eng->walk_choice;
+    if(list_capacity)
+        *list_capacity = eng->w3.split_cap;
+    if(last_overflow)
+        *last_overflow = eng->w3.split_last_overflow;
     API_END
 }
 
 int mpg_set_walk_variant(mpg_engine *eng, int variant)
 {
     API_BEGIN
-    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4 || variant == 5), "walk variant must be 0 (auto), 1, 4 or 5");
+    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4 || variant == 5 || variant == 6), "walk variant must be 0 (auto), 1, 4, 5 or 6");
     eng->walk_variant = variant;
     eng->walk_choice = 0;
     API_END

@@ -29,6 +29,14 @@ struct WalkScratch {
     DevBuf<unsigned> ctr;   // [16] scratch words; [8] = device error flag (runaway-loop guard)
     int cap = 512;          // list entries per target before the group drains its lists
     int num_cu = 0;
+    // two-kernel walk (grav_walk_split.hip)
+    DevBuf<unsigned> split_lists; // [slice/8][cap*8] interleaved per-target lists
+    DevBuf<int2> split_counts;    // [slice] {leaf entries | wrapped << 30, node entries} or {-1, 0}: overflowed
+    DevBuf<int> split_ovf;        // caller indices of overflowed targets
+    int split_cap = 512;          // list entries per target (multiple of 8)
+    int split_slice = 1 << 21;    // most targets per list-construction / evaluation kernel pair
+    size_t split_bytes = 4ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes
+    unsigned split_last_overflow = 0, split_last_maxlen = 0;
 };
 // fastwrap: the minimum-image wrap may be hoisted out of the pair loop (decided by the caller from Rcut, Box, leaf sizes)
 void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap,
@@ -36,6 +44,9 @@ void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkI
 // shared-traversal walk (grav_walk_shared.hip): the 8 targets of a wave share one tree traversal
 void launch_grav_walk_shared(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, WalkScratch &ws,
                              hipStream_t st);
+// two-kernel walk (grav_walk_split.hip): list construction, then evaluation; overflowing targets fall back to launch_grav_walk
+void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,
+                            WalkScratch &ws, hipStream_t st);
 // returns the device error flag of the last cooperative walk (0 = ok); synchronises the stream
 unsigned walk_coop_error(WalkScratch &ws, hipStream_t st);
 

@@ -1,0 +1,586 @@
+// grav_walk_split.hip -- short-range gravity walk as two kernels: list construction, then evaluation (variant 6).
+//
+// Per-target semantics are the reference's (force_treeev_shortrange, gravshort-tree.c:253-379): every node a target
+// visits is discarded, used unopened or opened by exactly the reference's tests for THAT target.  The reference itself
+// separates the two activities -- it collects the particles of opened leaves in `ngblist` and evaluates them afterwards
+// (gravshort-tree.c:346-374) -- and so does this file, at kernel granularity:
+//
+//   k_walk_lists   8 lanes per target walk the level-ordered tree exactly as phase A of grav_walk_coop.hip does (LIFO of
+//                  child ranges in LDS, the 8 lanes test the <= 8 children of one opened node per step) and write, per
+//                  target, the opened leaves (4-byte entries: first particle << 3 | count-1) and the nodes used unopened
+//                  (4-byte level-order indices) to HBM.  No force arithmetic, no window tables.  (A lane-per-target
+//                  depth-first list builder was measured too: 64 lanes gathering 80-byte node records from 64 different
+//                  nodes is bound by the vector-memory pipe and is 15 % - 2.5x slower than this cooperative form.)
+//   k_walk_eval    8 lanes per target stream the target's lists: for a leaf entry lane s evaluates source s (one
+//                  coalesced 256-byte read per group), node entries are taken 8 at a time.  No traversal state: the
+//                  kernel is a pure fp64 pair loop fed by sequential list reads.
+//
+// List layout: the 8 targets of a wave ("chunk") interleave their lists in blocks of 8 entries, so that one wave-wide
+// read or write of "the next 8 entries of every group" is one contiguous 256-byte segment:
+//     index(chunk, g, e) = chunk * cap * 8 + (e >> 3) * 64 + g * 8 + (e & 7)
+// Leaf entries grow up from e = 0, node entries down from e = cap-1.  A target whose lists would exceed `cap` is put on
+// an overflow list and handled afterwards by the lane-per-target kernel (grav_walk.hip), so `cap` bounds memory, not
+// correctness.  Targets are processed in slices of `slice` targets so the list area stays bounded (cap * 4 B each).
+//
+// Periodic wrap: with FASTWRAP (box large against Rcut and the leaves) a source range shares the periodic image of its
+// node; k_walk_lists records per target whether ANY of its entries lies on a wrapped image.  Targets without (all but a
+// surface layer Rcut thick) evaluate with plain differences, which is bit-identical to NEAREST() there; the others take
+// NEAREST() per pair as partmanager.h:99 does.
+#include "grav_walk.h"
+
+namespace mpg {
+
+namespace {
+
+#ifndef MPG_EVAL_BLOCKS
+#define MPG_EVAL_BLOCKS 6 // resident 256-thread blocks per CU the evaluation kernel is compiled for (80 VGPRs)
+#endif
+
+struct WTabD {
+    double a, b;
+};
+
+constexpr int STK = 160; // pending child ranges per group (LIFO): <= 7 per tree level + 8, 21 levels
+
+
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    // v_rsq_f64 + one cubic Newton step -> full double precision; x > 0
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+// Softened branch of apply_accn_to_output, gravshort-tree.c:168-185 (Gadget-2 spline, constants as truncated there).
+// Rare (the self interaction, close encounters).  Its constants live in constant memory and are fetched inside the branch
+// (the empty asm keeps hipcc from hoisting the fetches out of the pair loop, where they would occupy ~30 registers), and
+// the divisions are v_rcp_f64 + Newton steps (<= 1 ulp from the quotient) instead of the 40-instruction IEEE expansion.
+__constant__ double SPLINE_C[13] = {10.666666666667, 32.0, 38.4,  -2.8, 5.333333333333, 6.4, 9.6,
+                                    21.333333333333, 48.0, 0.066666666667, -3.2, -16.0, 2.133333333333};
+
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+
+__device__ __forceinline__ void softened_pair(const double r, const double m, const double hinv, const double h3inv, double &fac, double &facpot)
+{
+    const double *c = SPLINE_C;
+    asm volatile("" : "+s"(c));
+    const double u = r * hinv;
+    double wpk;
+    if(u < 0.5) {
+        fac = m * h3inv * (c[0] + u * u * (c[1] * u - c[2]));
+        wpk = c[3] + u * u * (c[4] + u * u * (c[5] * u - c[6]));
+    }
+    else {
+        const double iu = rcp_nr(u);
+        fac = m * h3inv * (c[7] - c[8] * u + c[2] * u * u - c[0] * u * u * u - c[9] * (iu * iu * iu));
+        wpk = c[10] + c[9] * iu + u * u * (c[0] + u * (c[11] + u * (c[6] - c[12] * u)));
+    }
+    facpot = m * hinv * wpk;
+}
+
+template <bool POT>
+__device__ __forceinline__ void pair_force(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
+                                           const WTabD *__restrict__ wf, const WTabD *__restrict__ wp, double &ax, double &ay,
+                                           double &az, double &pot)
+{
+    // apply_accn_to_output, gravshort-tree.c:158-193
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double rinv = rsqrt_nr(fmax(r2, 1e-180)); // the clamp keeps m * rinv^3 finite for r = 0
+    const double r = r2 * rinv; // exactly 0 for the self interaction
+    // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
+    // the table's last row, which holds zeros, with weight exactly 1
+    const double tcl = fmin(r * gp.inv_cell_dx, (double)(NTAB - 1));
+    double fac = s.m * rinv * rinv * rinv;
+    double facpot = -s.m * rinv;
+    if(r2 < gp.h * gp.h) // rare (the self interaction, close encounters): kept out of line so that its divisions and
+        softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot); // constants do not occupy registers in the pair loop
+    const int t = (int)tcl;
+    // (t + 1 - i) and (i - t) of gravity.c:63 are both exact, so 1 - (i - t) is the same number as (t + 1 - i)
+    const double w1 = tcl - (double)t, w0 = 1.0 - w1;
+    const WTabD f = wf[t];
+    fac *= w0 * f.a + w1 * f.b;
+    ax = fma(dx, fac, ax);
+    ay = fma(dy, fac, ay);
+    az = fma(dz, fac, az);
+    if(POT) {
+        const WTabD p = wp[t];
+        pot = fma(facpot, w0 * p.a + w1 * p.b, pot);
+    }
+}
+
+__device__ __forceinline__ double nearest_img(double d, double box, double invbox) { return fma(-rint(d * invbox), box, d); }
+
+// chunks of 8 targets (one per 8-lane group) of the slice; XCD x (= blockIdx % 8, where the hardware places this block) owns
+// a contiguous part of the tree-ordered targets and its waves take chunks round-robin, so that each private L2 serves one
+// region of the tree and concurrently running waves work on neighbouring targets
+struct ChunkIter {
+    unsigned lo, hi, first, stride;
+    __device__ ChunkIter(unsigned nchunks)
+    {
+        const unsigned xcd = blockIdx.x & 7;
+        const unsigned waves_per_block = blockDim.x >> 6;
+        first = (blockIdx.x >> 3) * waves_per_block + (threadIdx.x >> 6);
+        stride = (gridDim.x >> 3) * waves_per_block;
+        lo = (unsigned)(((uint64_t)nchunks * xcd) >> 3);
+        hi = (unsigned)(((uint64_t)nchunks * (xcd + 1)) >> 3);
+    }
+};
+
+// ctl words: [0] number of overflowed targets, [1] error flag (loop guard / stack), [2] longest list seen
+// counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] group steps [4] children tested
+template <bool COUNT, bool FASTWRAP>
+__global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
+                                                     int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
+                                                     unsigned *__restrict__ ctl, int *__restrict__ ovf)
+{
+    __shared__ unsigned s_stack[4 * 8 * STK];
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, s = lane & 7;
+    const int gshift = grp * 8;
+    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * STK; // pending child ranges of this group: (first << 4) | count
+    const unsigned nchunks = (unsigned)((nslots + 7) / 8);
+    const ChunkIter it(nchunks);
+    const unsigned long long guard_max = 64ull * (unsigned long long)(tv.nnodes + 1024);
+    const unsigned below = (1u << s) - 1u;
+    unsigned n_pp = 0, n_vis = 0, n_used = 0, st_a = 0, st_al = 0;
+
+    for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
+        const int64_t rel = (int64_t)chunk * 8 + grp;
+        const bool valid = rel < nslots;
+        const int64_t slot = slot0 + rel;
+        int ci = -1;
+        double px = 0, py = 0, pz = 0, aold = 0;
+        if(valid) {
+            ci = io.targets ? io.targets[slot] : tv.order[slot];
+            px = io.pos[3 * (int64_t)ci + 0];
+            py = io.pos[3 * (int64_t)ci + 1];
+            pz = io.pos[3 * (int64_t)ci + 2];
+            double old = 0;
+            if(io.oldacc)
+                old = io.oldacc[ci];
+            else if(io.prev_accel) { // grav_get_abs_accel, gravshort.h:70-80
+                double s2 = 0;
+                for(int j = 0; j < 3; j++) {
+                    const double a = io.prev_accel[3 * (int64_t)ci + j] + (io.gravpm ? io.gravpm[3 * (int64_t)ci + j] : 0.0);
+                    s2 += a * a;
+                }
+                old = sqrt(s2) / gp.G;
+            }
+            aold = gp.errtol * old;
+        }
+        unsigned *__restrict__ L = lists + (size_t)chunk * (size_t)cap * 8 + gshift;
+        int sp = 0; // stack pointer (group-uniform)
+        if(valid) {
+            if(s == 0)
+                stack[0] = (0u << 4) | 1u; // the root
+            sp = 1;
+        }
+        int nleaf = 0, nnode = 0; // entries in the two lists (group-uniform)
+        bool wrapped = false, overflow = false;
+        unsigned c_pp = 0, c_vis = 0, c_used = 0;
+        unsigned long long guard = 0;
+        for(;;) {
+            if(sp > 0 && nleaf + nnode + 8 > cap) { // the next step might not fit: hand the target to the fallback kernel
+                overflow = true;
+                sp = 0;
+            }
+            const bool can = sp > 0;
+            if(__ballot(can) == 0)
+                break;
+            if(++guard > guard_max || __ballot(can && sp + 8 > STK) != 0) {
+                if(lane == 0)
+                    atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
+                return;
+            }
+            const unsigned range = can ? stack[sp - 1] : 0u;
+            const int first = (int)(range >> 4), nch = (int)(range & 15u);
+            int act = 0; // 0 nothing, 1 leaf opened (list), 2 node used unopened (list), 3 internal node opened (push)
+            unsigned pushval = 0, entry = 0;
+            bool wr = false;
+            if(can && s < nch) {
+                const int my = first + s;
+                const NodeGeo g = tv.geoB[my];
+                const Src4 mom = tv.momB[my];
+                const NodeLinkB lk = tv.linkB[my];
+                // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
+                const double kx = rint((g.cx - px) * gp.invbox);
+                const double ky = rint((g.cy - py) * gp.invbox);
+                const double kz = rint((g.cz - pz) * gp.invbox);
+                double dx, dy, dz, cdx, cdy, cdz;
+                if(FASTWRAP) {
+                    const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
+                    cdx = fabs(g.cx - qx);
+                    cdy = fabs(g.cy - qy);
+                    cdz = fabs(g.cz - qz);
+                    dx = mom.x - qx;
+                    dy = mom.y - qy;
+                    dz = mom.z - qz;
+                    wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
+                    if(g.len * 4.0 > gp.box) {
+                        // top levels only: centre of mass and geometric centre may sit on different periodic
+                        // images; take NEAREST(cofm - pos) exactly as gravshort-tree.c:299-300 does
+                        const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox),
+                                     jz = rint((mom.z - pz) * gp.invbox);
+                        dx = fma(-jx, gp.box, mom.x - px);
+                        dy = fma(-jy, gp.box, mom.y - py);
+                        dz = fma(-jz, gp.box, mom.z - pz);
+                        wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
+                    }
+                }
+                else {
+                    cdx = fabs(fma(-kx, gp.box, g.cx - px));
+                    cdy = fabs(fma(-ky, gp.box, g.cy - py));
+                    cdz = fabs(fma(-kz, gp.box, g.cz - pz));
+                    dx = nearest_img(mom.x - px, gp.box, gp.invbox);
+                    dy = nearest_img(mom.y - py, gp.box, gp.invbox);
+                    dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
+                }
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                // shall_we_discard_node, gravshort-tree.c:198-215
+                const double eff = fma(0.5, g.len, gp.rcut);
+                const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
+                if(!discard) {
+                    // shall_we_open_node, gravshort-tree.c:220-241
+                    const double l2 = g.len * g.len;
+                    const double inside = 0.6 * g.len;
+                    const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) ||
+                                      (cdx < inside && cdy < inside && cdz < inside);
+                    if(!open) {
+                        act = 2; // node used unopened: its moments are a 1-element source
+                        entry = (unsigned)my;
+                    }
+                    else if(lk.pcount > 0) {
+                        act = 1;
+                        entry = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+                    }
+                    else if(lk.nchild > 0) {
+                        act = 3;
+                        pushval = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
+                    }
+                }
+                if(COUNT) {
+                    c_vis++;
+                    if(act == 2)
+                        c_used++;
+                    if(act == 1)
+                        c_pp += lk.pcount;
+                }
+            }
+            const unsigned gm_leaf = (unsigned)((__ballot(act == 1) >> gshift) & 0xffull);
+            const unsigned gm_node = (unsigned)((__ballot(act == 2) >> gshift) & 0xffull);
+            const unsigned gm_push = (unsigned)((__ballot(act == 3) >> gshift) & 0xffull);
+            const unsigned gm_wrap = (unsigned)((__ballot(wr && (act == 1 || act == 2)) >> gshift) & 0xffull);
+            if(act == 1) {
+                const int e = nleaf + __popc(gm_leaf & below);
+                L[((e >> 3) << 6) + (e & 7)] = entry;
+            }
+            if(act == 2) {
+                const int e = cap - 1 - (nnode + __popc(gm_node & below));
+                L[((e >> 3) << 6) + (e & 7)] = entry;
+            }
+            if(act == 3)
+                stack[sp - 1 + __popc(gm_push & below)] = pushval;
+            if(can) {
+                nleaf += __popc(gm_leaf);
+                nnode += __popc(gm_node);
+                sp += __popc(gm_push) - 1;
+                wrapped = wrapped || (gm_wrap != 0);
+                if(COUNT && s == 0) {
+                    st_a++;
+                    st_al += nch;
+                }
+            }
+        }
+        if(valid && s == 0) {
+            if(overflow) {
+                counts[rel] = make_int2(-1, 0);
+                ovf[atomicAdd(&ctl[0], 1u)] = ci;
+            }
+            else {
+                counts[rel] = make_int2(nleaf | (wrapped ? (1 << 30) : 0), nnode);
+                if((unsigned)(nleaf + nnode) > ctl[2])
+                    atomicMax(&ctl[2], (unsigned)(nleaf + nnode));
+            }
+        }
+        if(COUNT && !overflow) { // an overflowed target is walked again, and counted, by the fallback kernel
+            n_pp += c_pp;
+            n_vis += c_vis;
+            n_used += c_used;
+        }
+    }
+    if(COUNT) {
+        unsigned long long c0 = n_pp, c1 = n_vis, c2 = n_used, c3 = st_a, c4 = st_al;
+        for(int off = 32; off > 0; off >>= 1) {
+            c0 += __shfl_down(c0, off);
+            c1 += __shfl_down(c1, off);
+            c2 += __shfl_down(c2, off);
+            c3 += __shfl_down(c3, off);
+            c4 += __shfl_down(c4, off);
+        }
+        if(lane == 0) {
+            atomicAdd(&io.counters[0], c0);
+            atomicAdd(&io.counters[1], c1);
+            atomicAdd(&io.counters[2], c2);
+            atomicAdd(&io.counters[3], c3);
+            atomicAdd(&io.counters[4], c4);
+        }
+    }
+}
+
+// The two list loops of one group (8 lanes, lane s <-> source s of a leaf entry / entry r0 + s of the node list).
+// WRAP: take NEAREST() per pair (partmanager.h:99); otherwise plain differences (bit-identical where no image is wrapped).
+//
+// Leaf entries are fetched 8 per group at a time (one coalesced 256-byte read per wave), two batches ahead; sources are
+// requested two pair evaluations ahead of their use.  The scheduling barriers and the empty asm keep hipcc from
+// interleaving or sinking the (independent) pair evaluations, which would triple the live registers.  A lane without a
+// source (short leaf, list exhausted) reads a zero-mass padding record behind the tree's source array instead: its pair
+// evaluates to exactly zero, so the accumulators are updated unconditionally (a conditional update makes hipcc keep a
+// renamed copy of the four accumulators per unrolled stage).
+template <bool POT, bool WRAP>
+__device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
+                                           const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
+                                           const double py, const double pz, const WTabD *__restrict__ s_wf, const WTabD *__restrict__ s_wp,
+                                           double &ax, double &ay, double &az, double &pot)
+{
+    const unsigned empty = (zero_src << 3) | 7u; // a full "leaf" of zero-mass padding records
+#define MPG_LOAD(ENT, J, SV)                                                                \
+    {                                                                                       \
+        const unsigned ej_ = (unsigned)__shfl((int)(ENT), gshift + (J));                    \
+        SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
+    }
+#define MPG_EVAL(SV)                                                              \
+    {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        double dx_ = SV.x - px, dy_ = SV.y - py, dz_ = SV.z - pz;                 \
+        if(WRAP) {                                                                \
+            dx_ = nearest_img(dx_, gp.box, gp.invbox);                            \
+            dy_ = nearest_img(dy_, gp.box, gp.invbox);                            \
+            dz_ = nearest_img(dz_, gp.box, gp.invbox);                            \
+        }                                                                         \
+        pair_force<POT>(SV, dx_, dy_, dz_, gp, s_wf, s_wp, ax, ay, az, pot);      \
+        asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(pot));               \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    }
+    {
+        // two source buffers (A, B) used alternately: while one pair is evaluated the other buffer's load is in flight.  The
+        // stage loop is deliberately not unrolled beyond that: every unrolled stage carries its own copy of the (rare)
+        // softened branch, and those copies are what drives register pressure and code size.
+        unsigned ent = (s < nleaf) ? L[s] : empty;
+        unsigned ent_n = (8 + s < nleaf) ? L[64 + s] : empty;
+        Src4 A, B;
+        MPG_LOAD(ent, 0, A);
+        for(int e0 = 0;; e0 += 8) {
+            if(__ballot(e0 < nleaf) == 0)
+                break;
+            const unsigned ent_nn = (e0 + 16 + s < nleaf) ? L[(((e0 + 16) >> 3) << 6) + s] : empty;
+#pragma unroll 1
+            for(int j = 0; j < 8; j += 2) {
+                MPG_LOAD(ent, j + 1, B);
+                MPG_EVAL(A);
+                const unsigned en = (j + 2 < 8) ? ent : ent_n;
+                MPG_LOAD(en, (j + 2) & 7, A);
+                MPG_EVAL(B);
+            }
+            ent = ent_n;
+            ent_n = ent_nn;
+        }
+    }
+    // ---- node entries (level-order indices): lane s takes entry r0 + s; entries two batches ahead, moments one
+    if(__ballot(nnode > 0) != 0) {
+        constexpr unsigned NONE = 0xffffffffu;
+        const int top = ((cap - 8) >> 3) << 6;
+        unsigned ne = (s < nnode) ? L[top + (7 - s)] : NONE;
+        unsigned ne_n = (8 + s < nnode) ? L[top - 64 + (7 - s)] : NONE;
+        Src4 sc = *(ne != NONE ? &tv.momB[ne] : &tv.src[zero_src]);
+        for(int r0 = 0;; r0 += 8) {
+            if(__ballot(r0 < nnode) == 0)
+                break;
+            ne = ne_n;
+            ne_n = (r0 + 16 + s < nnode) ? L[top - (((r0 + 16) >> 3) << 6) + (7 - s)] : NONE;
+            const Src4 sc_n = *(ne != NONE ? &tv.momB[ne] : &tv.src[zero_src]);
+            MPG_EVAL(sc);
+            sc = sc_n;
+        }
+    }
+#undef MPG_LOAD
+#undef MPG_EVAL
+}
+
+template <bool POT, bool FASTWRAP>
+__global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
+                                                    const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
+{
+    __shared__ WTabD s_wf[NTAB];
+    __shared__ WTabD s_wp[POT ? NTAB : 1];
+    for(int i = threadIdx.x; i < NTAB - 1; i += blockDim.x) {
+        s_wf[i] = WTabD{(double)io.tab_force[i], (double)io.tab_force[i + 1]};
+        if(POT)
+            s_wp[i] = WTabD{(double)io.tab_pot[i], (double)io.tab_pot[i + 1]};
+    }
+    if(threadIdx.x == 0) {
+        s_wf[NTAB - 1] = WTabD{0, 0};
+        if(POT)
+            s_wp[NTAB - 1] = WTabD{0, 0};
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, s = lane & 7;
+    const int gshift = grp * 8;
+    const unsigned nchunks = (unsigned)((nslots + 7) / 8);
+    const ChunkIter it(nchunks);
+    const unsigned zero_src = (unsigned)(tv.npart + tv.nnodes); // zero-mass padding records (TreeBuilder::build)
+
+    for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
+        const int64_t rel = (int64_t)chunk * 8 + grp;
+        bool valid = rel < nslots;
+        const int64_t slot = slot0 + rel;
+        int ci = -1;
+        double px = 0, py = 0, pz = 0;
+        int nleaf = 0, nnode = 0;
+        bool wrapped = false;
+        if(valid) {
+            const int2 c = counts[rel];
+            if(c.x < 0)
+                valid = false; // overflowed: left to the fallback kernel
+            else {
+                nleaf = c.x & 0x3fffffff;
+                wrapped = (c.x >> 30) & 1;
+                nnode = c.y;
+                ci = io.targets ? io.targets[slot] : tv.order[slot];
+                px = io.pos[3 * (int64_t)ci + 0];
+                py = io.pos[3 * (int64_t)ci + 1];
+                pz = io.pos[3 * (int64_t)ci + 2];
+            }
+        }
+        const unsigned *__restrict__ L = lists + (size_t)chunk * (size_t)cap * 8 + gshift;
+        double ax = 0, ay = 0, az = 0, pot = 0;
+        if(!FASTWRAP || __ballot(wrapped) != 0) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
+            eval_lists<POT, true>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wf, s_wp, ax, ay, az, pot);
+        else
+            eval_lists<POT, false>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wf, s_wp, ax, ay, az, pot);
+        // reduce the partial sums over the 8 lanes of the group
+        for(int off = 1; off < 8; off <<= 1) {
+            ax += __shfl_xor(ax, off);
+            ay += __shfl_xor(ay, off);
+            az += __shfl_xor(az, off);
+            if(POT)
+                pot += __shfl_xor(pot, off);
+        }
+        if(valid && s == 0) {
+            // grav_short_reduce (assign) + grav_short_postprocess, gravshort.h:47-67,88-96
+            io.accel[3 * (int64_t)ci + 0] = ax * gp.G;
+            io.accel[3 * (int64_t)ci + 1] = ay * gp.G;
+            io.accel[3 * (int64_t)ci + 2] = az * gp.G;
+            if(POT && io.potential) {
+                const double m = (double)io.mass[ci];
+                double p = pot;
+                p += m / (gp.h / 2.8);
+                p -= 2.8372975 * pow(m, 2.0 / 3) * gp.cbrtrho0;
+                p *= gp.G;
+                io.potential[ci] = p;
+            }
+        }
+    }
+}
+
+int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks)
+{
+    if(ws.num_cu == 0) {
+        int dev = 0;
+        MPG_HIP(hipGetDevice(&dev));
+        MPG_HIP(hipDeviceGetAttribute(&ws.num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int occ = 0;
+    MPG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
+    if(occ < 1)
+        occ = 1;
+    if(occ > 8)
+        occ = 8;
+    int64_t nblocks = (int64_t)ws.num_cu * occ;
+    const int64_t need = (nchunks + 3) / 4;
+    if(nblocks > need)
+        nblocks = need;
+    return (int)((nblocks + 7) / 8 * 8);
+}
+
+template <bool POT, bool COUNT, bool FASTWRAP>
+void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
+{
+    auto kl = k_walk_lists<COUNT, FASTWRAP>;
+    auto ke = k_walk_eval<POT, FASTWRAP>;
+    const int cap = ws.split_cap;
+    // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
+    int64_t slice = (int64_t)(ws.split_bytes / ((size_t)cap * sizeof(unsigned))) / 2048 * 2048;
+    if(slice < 65536)
+        slice = 65536;
+    if(slice > ws.split_slice)
+        slice = ws.split_slice;
+    const int64_t nmax = io.ntargets < slice ? io.ntargets : slice;
+    ws.split_lists.reserve((size_t)((nmax + 7) / 8) * 8 * (size_t)cap);
+    ws.split_counts.reserve((size_t)nmax + 8);
+    ws.split_ovf.reserve((size_t)io.ntargets);
+    for(int64_t s0 = 0; s0 < io.ntargets; s0 += slice) {
+        const int64_t ns = (io.ntargets - s0 < slice) ? io.ntargets - s0 : slice;
+        const int64_t nchunks = (ns + 7) / 8;
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks)), dim3(256), 0, st, tv, gp, io, ws.split_lists.p,
+                           ws.split_counts.p, cap, s0, ns, ws.ctr.p, ws.split_ovf.p);
+        hipLaunchKernelGGL(ke, dim3((unsigned)grid_blocks(ws, (const void *)ke, nchunks)), dim3(256), 0, st, tv, gp, io, ws.split_lists.p,
+                           ws.split_counts.p, cap, s0, ns);
+    }
+    MPG_HIP(hipGetLastError());
+}
+
+} // namespace
+
+void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,
+                            WalkScratch &ws, hipStream_t st)
+{
+    if(io.ntargets == 0)
+        return;
+    MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
+    ws.ctr.reserve(16);
+    MPG_HIP(hipMemsetAsync(ws.ctr.p, 0, 16 * sizeof(unsigned), st));
+#define MPG_WS(P, C)                                        \
+    do {                                                    \
+        if(fastwrap)                                        \
+            launch_split_t<P, C, true>(tv, gp, io, ws, st); \
+        else                                                \
+            launch_split_t<P, C, false>(tv, gp, io, ws, st);\
+    } while(0)
+    if(want_pot) {
+        if(count)
+            MPG_WS(true, true);
+        else
+            MPG_WS(true, false);
+    }
+    else {
+        if(count)
+            MPG_WS(false, true);
+        else
+            MPG_WS(false, false);
+    }
+#undef MPG_WS
+    // targets whose lists did not fit: walk them with the lane-per-target kernel
+    unsigned ctl[4] = {0, 0, 0, 0};
+    MPG_HIP(hipMemcpyAsync(ctl, ws.ctr.p, sizeof(ctl), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipStreamSynchronize(st));
+    MPG_CHECK(ctl[1] == 0, "short-range walk (list construction) aborted by its loop guard (corrupt tree?)");
+    ws.split_last_overflow = ctl[0];
+    ws.split_last_maxlen = ctl[2];
+    if(ctl[0] > 0) {
+        WalkIO io2 = io;
+        io2.targets = ws.split_ovf.p;
+        io2.ntargets = ctl[0];
+        launch_grav_walk(tv, gp, io2, want_pot, count, fastwrap, thresh, st);
+        if((int64_t)ctl[0] * 50 > io.ntargets && ws.split_cap < 8192)
+            ws.split_cap *= 2; // more than 2 % of the targets overflowed: give the next walk longer lists
+    }
+}
+
+} // namespace mpg

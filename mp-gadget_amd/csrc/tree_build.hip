@@ -479,6 +479,8 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     src.reserve(npart + nnodes + 16);
     geo.reserve(nnodes + 16);
     link.reserve(nnodes + 16);
+    // the padding records of the source array are zero-mass sources at the origin (grav_walk_split.hip points idle lanes at them)
+    MPG_HIP(hipMemsetAsync(src.p + npart + nnodes, 0, 16 * sizeof(Src4), st));
     if(npart > 0) {
         hipLaunchKernelGGL(k_gather_src, dim3(nblk(npart)), dim3(256), 0, st, npart, idx_b.p, d_pos, d_mass, src.p);
         hipLaunchKernelGGL(k_fill_nodes, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, base.p, box, geo.p,

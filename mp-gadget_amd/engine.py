@@ -180,6 +180,12 @@ class Engine:
     def set_walk_variant(self, variant):
         self._ck(self.lib.mpg_set_walk_variant(self.h, int(variant)))
 
+    def walk_choice(self):
+        """(kernel in use, kernel 6 list capacity, targets its last walk handed to the fallback kernel)"""
+        v, cap, ovf = C.c_int(0), C.c_int(0), C.c_uint(0)
+        self._ck(self.lib.mpg_get_walk_choice(self.h, C.byref(v), C.byref(cap), C.byref(ovf)))
+        return v.value, cap.value, ovf.value
+
     def set_walk_list_capacity(self, cap):
         self._ck(self.lib.mpg_set_walk_list_capacity(self.h, int(cap)))
 

@@ -166,6 +166,42 @@ def test_walk_parity(pkg, engine, orc, ic, n, nmesh):
     engine.set_instrumentation(False, False)
 
 
+@pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (5, 512), (6, 512), (6, 40)])
+@pytest.mark.parametrize("ic,n,nmesh", [("s_grid", 24, 48), ("s_clust", 20, 40), ("s_zel", 24, 48)])
+def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
+    """Every walk kernel (lane-per-target 1, group-cooperative 4, shared traversal 5, two-kernel list/evaluate 6) takes the
+    reference's decisions per target: equal counters and accelerations against the oracle.  The small list capacities force
+    kernel 4 to drain its lists mid-walk and kernel 6 to send overflowing targets to its fallback."""
+    if ic == "s_clust":
+        pos, mass, box = pkg.ics.s_clust(n, box=8.0, seed=3)
+    else:
+        pos, mass, box = getattr(pkg.ics, ic)(n)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    gpm_o, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    old = np.sqrt((gpm_o ** 2).sum(1)) / G
+    a_ref, p_ref, c_ref, _ = tr.grav_short_tree(par, oldacc=old, want_pot=True)
+    P = pkg.make_particles(pos, mass)
+    P["GravPM"] = gpm_o
+    P["FullTreeGravAccel"] = 0.0
+    try:
+        engine.set_walk_variant(variant)
+        engine.set_walk_list_capacity(cap)
+        engine.set_instrumentation(False, True)
+        engine.force_tree_full(P, box)
+        engine.grav_short_tree(P)
+        c = engine.walk_counters()
+    finally:
+        engine.set_walk_variant(0)
+        engine.set_walk_list_capacity(512)
+        engine.set_instrumentation(False, False)
+    assert (c["pp"], c["nodes_visited"], c["nodes_used"]) == tuple(c_ref)
+    assert_accel_parity(P["FullTreeGravAccel"], a_ref)
+    assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
+
+
 @pytest.mark.parametrize("name", ["grav_sgrid16", "grav_sclust12"])
 def test_golden_vectors(pkg, engine, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))

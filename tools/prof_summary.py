@@ -11,6 +11,7 @@ root = sys.argv[1]
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
     for pre in ("void ", "mpg::"):
         name = name.replace(pre, "")
@@ -47,25 +48,46 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 # MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
 # wide (16 B/lane) coalesced read stream -> doubled.  Collected in separate --pmc passes (tools/prof.sh).
 import json
-vals = {}
-for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
-        tot = defaultdict(float)
-        n = defaultdict(set)
-        for r in csv.DictReader(open(f)):
-            targs = [a.strip() for a in r["Kernel_Name"].split("<")[-1].split(">")[0].split(",")]
-            if r["Counter_Name"] == name and "k_grav_walk" in r["Kernel_Name"] and len(targs) > 1 and targs[1] == "false":
-                k = short(r["Kernel_Name"])
-                tot[k] += float(r["Counter_Value"])
-                n[k].add(r["Dispatch_Id"])
-        for k in tot:
-            vals.setdefault(k, {})[name] = tot[k] / len(n[k])
-for k, v in vals.items():
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        out = {"kernel": k, "fetch_bytes_per_launch": 2 * 1024 * v["FETCH_SIZE"], "write_bytes_per_launch": 1024 * v["WRITE_SIZE"],
-               "hbm_bytes_per_launch": 2 * 1024 * v["FETCH_SIZE"] + 1024 * v["WRITE_SIZE"],
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled "
-                         "(gfx950 correction for 16 B/lane reads, MI355X_MICROARCH.md section HBM)"}
-        print("== walk traffic:", json.dumps(out))
-        with open(os.path.join(root, "walk_traffic_%s.json" % k.split("<")[0]), "w") as fo:
-            json.dump(out, fo, indent=1)
+WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists<", "k_walk_eval<")}
+METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled "
+          "(gfx950 correction for 16 B/lane reads, MI355X_MICROARCH.md section HBM); summed over the dispatches of one walk")
+
+
+def is_count_build(kname):
+    # the COUNT template flag (instrumented untimed pass) is the 2nd parameter of k_grav_walk*, the 1st of k_walk_lists
+    targs = [a.strip() for a in kname.split("<")[-1].split(">")[0].split(",")]
+    if "k_walk_lists<" in kname:
+        return targs[0] == "true"
+    if "k_walk_eval<" in kname:
+        return False
+    return len(targs) > 1 and targs[1] == "true"
+
+
+variants = {}
+for var, pats in WALK_KERNELS.items():
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    walks = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+    for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+            ndisp = defaultdict(set)
+            for r in csv.DictReader(open(f)):
+                kn = r["Kernel_Name"]
+                if r["Counter_Name"] != name or not any(p_ in kn for p_ in pats) or is_count_build(kn):
+                    continue
+                if var == "1" and "k_grav_walk_" in kn:
+                    continue
+                tot[name] += float(r["Counter_Value"])
+                ndisp[[p_ for p_ in pats if p_ in kn][0]].add(r["Dispatch_Id"])
+            if ndisp:
+                # dispatches of the first kernel of the group per walk: 1 for kernels 1 and 4, ceil(N / 2^21) slices for 6
+                per_walk = int(os.environ.get("MPG_SLICES_PER_WALK", "8")) if var == "6" else 1
+                walks[name] += len(ndisp[pats[0]]) / per_walk
+    if walks["FETCH_SIZE"] and walks["WRITE_SIZE"]:
+        fb = 2 * 1024 * tot["FETCH_SIZE"] / walks["FETCH_SIZE"]
+        wb = 1024 * tot["WRITE_SIZE"] / walks["WRITE_SIZE"]
+        variants[var] = {"kernel": " + ".join(p_.rstrip("<") for p_ in pats), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                         "hbm_bytes_per_launch": fb + wb, "walks_profiled": walks["FETCH_SIZE"], "method": METHOD}
+if variants:
+    print("== walk traffic:", json.dumps(variants))
+    with open(os.path.join(root, "walk_traffic.json"), "w") as fo:
+        json.dump({"variants": variants}, fo, indent=1)

@@ -24,13 +24,17 @@ eng.set_walk_variant(1); eng.set_walk_threshold(16)
 eng.dev_grav_short_tree(acc, prev_accel=torch.zeros_like(acc), gravpm=gpm, potential=pot)   # BH-free first pass gives OldAcc
 prev = acc.clone()
 ref = None
-for variant, thr in ((1, 16), (4, 512), (5, 512)):
+VARIANTS = [int(v) for v in os.environ.get('MPG_VARIANTS', '1,4,6').split(',')]
+for variant, thr in [(v, 16 if v == 1 else 512) for v in VARIANTS]:
     eng.set_walk_variant(variant); eng.set_walk_threshold(16); eng.set_walk_list_capacity(thr)
     eng.set_instrumentation(False, True)
     eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gpm, potential=pot)
     eng.synchronize()
     c = eng.walk_counters()
     eng.set_instrumentation(False, False)
+    for _ in range(3):   # let adaptive list capacities settle
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gpm, potential=pot)
+    eng.synchronize()
     eng.walk_events_collect()
     for _ in range(3):
         eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gpm, potential=pot)
@@ -40,7 +44,7 @@ for variant, thr in ((1, 16), (4, 512), (5, 512)):
         ref = a.copy()
     d = np.sqrt(((a - ref) ** 2).sum(1)) / np.sqrt((ref ** 2).sum(1))
     s = ""
-    if variant in (4, 5) and c["node_steps"]:
+    if variant in (4, 5) and c["node_steps"] and c["int_steps"]:
         s = "A: %.1f steps/target, %.2f nodes/step; B: %.1f steps/target, lane util %.2f" % (c["node_steps"] / N, c["node_lanes"] / c["node_steps"], c["int_steps"] / 8.0 / N, c["int_lanes"] / c["int_steps"])
         s += "  cycles/step A %.0f B %.0f" % (c["cycles_a"] / max(c["node_steps"], 1) * 8, c["cycles_b"] / max(c["int_steps"] / 8, 1) * 8)
         s += "  tree ms %s" % {k: round(v, 2) for k, v in eng.phase_times().items() if k.startswith("tree")}
