@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--mgpu", choices=["slab", "replicated"], default="slab", help="N > 1: PM / target decomposition")
     ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro"],
                     help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
                          "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
@@ -85,7 +86,7 @@ def main():
     del pos
 
     eng = pkg.Engine(local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.use_torch_stream()
     eng.set_walk_threshold(args.thresh)
     eng.set_walk_variant(args.variant)
     eng.gravshort_fill_ntab(0, 1.5)
@@ -99,25 +100,44 @@ def main():
     acc = torch.zeros(N, 3, dtype=torch.float64, device=dev)
     prev = torch.zeros(N, 3, dtype=torch.float64, device=dev)
     pot = torch.zeros(N, dtype=torch.float64, device=dev)
-    # target shard of this rank: a contiguous range of tree slots
-    lo, hi = pkg.shard.slot_range(N, rank, world)
-    chunk = pkg.shard.chunk_size(N, world)
-    if world > 1:
+    # N > 1: "slab" = x-slab PM (two all-to-all transposes per step) with the particles of the slab as
+    # PM-readout and walk targets; "replicated" = every rank does the whole PM, targets are contiguous tree-slot ranges
+    pm_ms = [0.0, 0]
+    if world > 1 and args.mgpu == "slab":
+        spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
+        tex = pkg.pm_slab.TargetExchange(world, dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    elif world > 1:
+        lo, hi = pkg.shard.slot_range(N, rank, world)
+        chunk = pkg.shard.chunk_size(N, world)
         gbuf = torch.zeros(world * chunk, 3, dtype=torch.float64, device=dev)
         sbuf = torch.zeros(chunk, 3, dtype=torch.float64, device=dev)
 
     def step():
         nonlocal acc, prev
-        eng.dev_gravpm_force(gravpm, pot)
-        eng.dev_force_tree_build()
-        prev, acc = acc, prev
         if world == 1:
+            eng.dev_gravpm_force(gravpm, pot)
+            eng.dev_force_tree_build()
+            prev, acc = acc, prev
             eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+        elif args.mgpu == "slab":
+            eng.dev_force_tree_build()
+            tg = spm.targets(d_pos, eng.dev_tree_order(N, dev))
+            ev0.record()
+            spm.force(tg, gravpm, pot)
+            ev1.record()
+            prev, acc = acc, prev
+            eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=tg)
+            tex.exchange(acc, tg)
+            pm_ms[0] += ev0.elapsed_time(ev1)   # both events are complete: exchange() synchronised on the target counts
+            pm_ms[1] += 1
         else:
+            eng.dev_gravpm_force(gravpm, pot)
+            eng.dev_force_tree_build()
+            prev, acc = acc, prev
             optr = eng.dev_tree_order_ptr()
             eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=optr + 4 * lo, nactive=hi - lo)
-            order = _as_tensor(torch, optr, N, dev)
-            pkg.shard.exchange_results(acc, order, rank, world, sbuf, gbuf)
+            pkg.shard.exchange_results(acc, eng.dev_tree_order(N, dev), rank, world, sbuf, gbuf)
 
     def sync():
         torch.cuda.synchronize()
@@ -174,7 +194,9 @@ def main():
             "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
                                    "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
                        "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
-                       "targets sharded over %d GPUs (tree-order ranges), all-gather of accelerations" % world},
+                       ("%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
+                        "replicated, one all-gather of accelerations" % world if args.mgpu == "slab" else
+                        "targets sharded over %d GPUs (tree-order ranges), PM and tree replicated, all-gather of accelerations" % world)},
             "roofline": {"bound": "hbm", "kernel": kernels, "walk_variant": variant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
@@ -186,6 +208,8 @@ def main():
                                  "interaction) of 78.6 peak" % (flops / (walk_avg_ms * 1e-3) / 1e12)},
             "phases_ms": {k: round(v, 3) for k, v in ph.items()},
         }
+        if pm_ms[1]:
+            out["phases_ms"]["pm_slab_total_incl_collectives"] = round(pm_ms[0] / pm_ms[1], 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
                                                args.cpu_sample)
@@ -217,7 +241,7 @@ def hydro_bench(pkg, torch, args, dev):
     f8 = torch.float64
     d_pos, d_mass, d_type = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
     eng = pkg.Engine(dev.index or 0)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.use_torch_stream()
     eng.set_walk_variant(args.variant)
     eng.gravshort_fill_ntab(0, 1.5)
     eng.gravpm_init_periodic(box, 1.5, nmesh, G)
@@ -267,15 +291,6 @@ def hydro_bench(pkg, torch, args, dev):
     print(json.dumps(out), flush=True)
     eng.close()
     return out
-
-
-def _as_tensor(torch, ptr, n, dev):
-    """Zero-copy int32 view of engine-owned device memory (the tree-order permutation)."""
-    class _Holder:
-        pass
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(h, device=dev)
 
 
 def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):

@@ -252,6 +252,29 @@ int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
 /* Device pointer to the tree-order permutation (int32 [NumParticles]: tree slot -> caller index) of the current tree;
  * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
 const int *mpg_dev_tree_order(mpg_engine *eng);
+/* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
+ * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
+ * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:
+ *
+ *   mpg_dev_pm_slab_init(rank, world)        after mpg_gravpm_init_periodic; Nmesh % world == 0.  Outputs the number of complex
+ *                                            values per peer block (P * Py * (Nmesh/2+1)) and the doubles of one mesh plane.
+ *   mpg_dev_pm_slab_forward_a(sendA)         deposit the bound particles onto this rank's planes, 2-D r2c, pack:
+ *                                            sendA[world][cplx_per_peer] complex      -> all-to-all -> recvA
+ *   mpg_dev_pm_slab_forward_b(recvA, sendB)  1-D c2c along x, potential_transfer, 4 x (force_transfer, inverse 1-D c2c):
+ *                                            sendB[world][4 * cplx_per_peer] complex  -> all-to-all -> recvB
+ *   mpg_dev_pm_slab_inverse_c(recvB, ghost_send)  2-D c2r of Potential, ForceX, ForceY, ForceZ; ghost_send[4][plane] = this
+ *                                            rank's first planes                      -> rank r sends them to rank r-1
+ *   mpg_dev_pm_slab_readout(ghost_recv, targets, n, GravPM, Potential)   readout_force_* / readout_potential (gravpm.c:499-510)
+ *                                            for the listed particles, whose base cell must lie in this rank's slab.
+ * Every rank binds the same particle set (mpg_dev_bind_particles); a particle's CIC cloud is deposited by the owners of the
+ * planes it touches, so no region exchange is needed.  world == 1 reproduces mpg_dev_gravpm_force to FFT round-off. */
+int mpg_dev_pm_slab_init(mpg_engine *eng, int rank, int world, int64_t *cplx_per_peer, int64_t *plane_doubles);
+int mpg_dev_pm_slab_forward_a(mpg_engine *eng, double *sendA);
+int mpg_dev_pm_slab_forward_b(mpg_engine *eng, double *recvA, double *sendB);
+int mpg_dev_pm_slab_inverse_c(mpg_engine *eng, const double *recvB, double *ghost_send);
+int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int *d_targets, int64_t ntargets, double *d_gravpm,
+                            double *d_potential);
+
 /* Tuning knobs of the walk; results do not depend on any of them.
  *   variant   0 = auto (default): time kernels 1, 4 and 6 once on a large walk and keep the fastest (re-tuned every 64 walks);
  *             1 = lane-per-target while-while kernel (grav_walk.hip); 4 = group-cooperative list kernel (grav_walk_coop.hip);

@@ -7,4 +7,5 @@ or through the `mpgadget_amd()` helper of the repo-root conftest / bench.
 from . import ics  # noqa: F401
 from . import engine  # noqa: F401
 from . import shard  # noqa: F401
+from . import pm_slab  # noqa: F401
 from .engine import Engine, EngineError, PARTICLE_DTYPE, make_particles, SphTimes  # noqa: F401

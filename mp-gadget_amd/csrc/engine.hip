@@ -277,6 +277,57 @@ int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential)
     API_END
 }
 
+int mpg_dev_pm_slab_init(mpg_engine *eng, int rank, int world, int64_t *cplx_per_peer, int64_t *plane_doubles)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->pm.slab_init(rank, world);
+    if(cplx_per_peer)
+        *cplx_per_peer = (int64_t)eng->pm.slab_cplx_per_peer();
+    if(plane_doubles)
+        *plane_doubles = (int64_t)eng->pm.nmesh * eng->pm.nmesh;
+    API_END
+}
+
+int mpg_dev_pm_slab_forward_a(mpg_engine *eng, double *sendA)
+{
+    API_BEGIN
+    MPG_CHECK(eng && sendA, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->pm.box == eng->box, "gravpm_force: BoxSize of the mesh differs from the bound particles");
+    eng->pm.slab_forward_a(eng->n, eng->d_pos, eng->d_mass, sendA, eng->stream);
+    API_END
+}
+
+int mpg_dev_pm_slab_forward_b(mpg_engine *eng, double *recvA, double *sendB)
+{
+    API_BEGIN
+    MPG_CHECK(eng && recvA && sendB, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->pm.slab_forward_b(recvA, sendB, eng->stream);
+    API_END
+}
+
+int mpg_dev_pm_slab_inverse_c(mpg_engine *eng, const double *recvB, double *ghost_send)
+{
+    API_BEGIN
+    MPG_CHECK(eng && recvB && ghost_send, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->pm.slab_inverse_c(recvB, ghost_send, eng->stream);
+    API_END
+}
+
+int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int *d_targets, int64_t ntargets, double *d_gravpm,
+                            double *d_potential)
+{
+    API_BEGIN
+    MPG_CHECK(eng && ghost_recv && d_gravpm && (d_targets || ntargets == 0), "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->pm.slab_readout(ghost_recv, d_targets, ntargets, eng->d_pos, d_gravpm, d_potential, eng->stream);
+    API_END
+}
+
 int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
 {
     API_BEGIN

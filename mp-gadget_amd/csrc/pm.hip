@@ -74,18 +74,19 @@ __device__ __forceinline__ double sinc_unnormed(double x)
 
 // potential_transfer, gravpm.c:383-454, swept as pm_apply_transfer_function does (petapm.c:1092-1132).
 // Layout here: [kx][ky][kz], kz in [0, N/2].  k index -> signed mode: petapm_mesh_to_k, petapm.c:81-84.
-__global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, double asmth2, double pot_factor, const double *__restrict__ invsinc2,
-                                                            double2 *__restrict__ cplx)
+// ny rows of ky starting at y0 are held (ny = nmesh, y0 = 0 on one GPU; a ky-slab in the slab-decomposed form).
+__global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, int ny, int y0, double asmth2, double pot_factor,
+                                                            const double *__restrict__ invsinc2, double2 *__restrict__ cplx)
 {
     const int nz = nmesh / 2 + 1;
-    const size_t total = (size_t)nmesh * nmesh * nz;
+    const size_t total = (size_t)nmesh * ny * nz;
     const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(ip >= total)
         return;
     const int iz = (int)(ip % nz);
     const size_t t = ip / nz;
-    const int iy = (int)(t % nmesh);
-    const int ix = (int)(t / nmesh);
+    const int iy = y0 + (int)(t % ny);
+    const int ix = (int)(t / ny);
     const int kx = ix <= nmesh / 2 ? ix : ix - nmesh;
     const int ky = iy <= nmesh / 2 ? iy : iy - nmesh;
     const int kz = iz;
@@ -108,27 +109,29 @@ __global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, double as
 
 // force_transfer for one axis, gravpm.c:476-498: (re, im) <- (-im*fac, re*fac), fac = -diff_kernel(k 2pi/N) N/Box.
 // axis < 0: plain copy (the Potential pass has no transfer function, gravpm.c:32-39).
-__global__ void __launch_bounds__(256) k_force_transfer(int nmesh, int axis, const double *__restrict__ difffac,
-                                                        const double2 *__restrict__ src, double2 *__restrict__ dst)
+// The destination element of source (ix, row, iz) is dst[(ix * xmul + xoff) * ny * nz + row * nz + iz]: xmul = 1, xoff = 0 on one
+// GPU; (4, function) in the slab form, which interleaves the four functions so that each all-to-all block stays contiguous.
+__global__ void __launch_bounds__(256) k_force_transfer(int nmesh, int ny, int y0, int axis, const double *__restrict__ difffac,
+                                                        const double2 *__restrict__ src, double2 *__restrict__ dst, int xmul, int xoff)
 {
     const int nz = nmesh / 2 + 1;
-    const size_t total = (size_t)nmesh * nmesh * nz;
+    const size_t total = (size_t)nmesh * ny * nz;
     const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(ip >= total)
         return;
     double2 v = src[ip];
+    const size_t rowsz = (size_t)ny * nz;
+    const int ix = (int)(ip / rowsz);
     if(axis >= 0) {
         const int iz = (int)(ip % nz);
-        const size_t t = ip / nz;
-        const int iy = (int)(t % nmesh);
-        const int ix = (int)(t / nmesh);
+        const int iy = y0 + (int)((ip / nz) % ny);
         const int ii = axis == 0 ? ix : (axis == 1 ? iy : iz);
         const double fac = difffac[ii];
         const double t0 = -v.y * fac, t1 = v.x * fac;
         v.x = t0;
         v.y = t1;
     }
-    dst[ip] = v;
+    dst[((size_t)ix * xmul + xoff) * rowsz + (ip - (size_t)ix * rowsz)] = v;
 }
 
 // readout_potential / readout_force_{x,y,z} through pm_iterate_one (gravpm.c:499-510).
@@ -214,6 +217,7 @@ void PMesh::destroy()
         (void)hipfftDestroy(plan_c2r);
         have_plans = false;
     }
+    slab_destroy();
     real.release();
     rho_k.release();
     work_k.release();
@@ -224,6 +228,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
                   hipStream_t st, EventTimer *tm)
 {
     MPG_CHECK(have_plans, "gravpm_force called before gravpm_init_periodic");
+    MPG_CHECK(!slab.ready, "gravpm_force: the mesh is in its slab-decomposed form (use the pm_slab calls)");
     const size_t nreal = (size_t)nmesh * nmesh * nmesh;
     const size_t ncplx = (size_t)nmesh * nmesh * (nmesh / 2 + 1);
     MPG_FFT(hipfftSetStream(plan_r2c, st));
@@ -244,7 +249,8 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
     }
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
-    hipLaunchKernelGGL(k_potential_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, asmth2, pot_factor, invsinc2.p, (double2 *)rho_k.p);
+    hipLaunchKernelGGL(k_potential_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, asmth2, pot_factor, invsinc2.p,
+                       (double2 *)rho_k.p);
     if(tm) {
         tm->lap(st, &t);
         t_tr += t;
@@ -254,8 +260,8 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         const int axis = f - 1;
         if(f == 0 && !d_potential)
             continue;
-        hipLaunchKernelGGL(k_force_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, axis, difffac.p, (const double2 *)rho_k.p,
-                           (double2 *)work_k.p);
+        hipLaunchKernelGGL(k_force_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, axis, difffac.p, (const double2 *)rho_k.p,
+                           (double2 *)work_k.p, 1, 0);
         if(tm) {
             tm->lap(st, &t);
             t_tr += t;
@@ -283,6 +289,262 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         tm->t.pm_readout = t_ro;
         tm->t.pm_total = tm->t.pm_deposit + t_fft + t_tr + t_ro;
     }
+}
+
+// ================================================================================================ slab-decomposed form
+// Reference: petapm.c lays the mesh out in 2-D pencils over all ranks and moves particles' "region" meshes to them and back
+// (petapm.c:584-885); PFFT transposes between the three 1-D transform stages.  With <= 8 GPUs on one node a 1-D (slab)
+// decomposition needs one transpose per 3-D transform and keeps every message large (xGMI is point-to-point: 7 peers x one
+// contiguous block each).  Every rank holds all particle positions, so instead of exchanging region
+// meshes each rank deposits, straight into its own planes, the part of every particle's CIC cloud that falls on them, and
+// reads forces back for the particles whose base cell lies in its slab (one ghost plane from the next rank).
+//
+//   forward_a : deposit -> 2-D r2c over (y,z) of the P own planes -> pack by destination ky-slab     [sendA]
+//   all-to-all (caller)                                                                               [recvA = [x][ky local][kz]]
+//   forward_b : 1-D c2c along x (stride Py*Nz) -> potential transfer -> 4 x (force transfer -> inverse 1-D c2c -> strided copy),
+//               interleaved as [x][function][ky local][kz] so that the block for rank d (its x-planes) is contiguous  [sendB]
+//   all-to-all (caller)                                                                               [recvB]
+//   inverse_c : unpack to [x local][ky][kz] -> 2-D c2r -> 4 real slabs; first planes out as ghosts    [ghost_send]
+//   neighbour exchange (caller) -> readout.
+// hipFFT transforms are unnormalised like PFFT's; the three 1-D stages compose to the same 3-D DFT.
+
+__global__ void __launch_bounds__(256) k_cic_deposit_slab(int64_t n, const double *__restrict__ pos, const float *__restrict__ mass,
+                                                          double cellsize, int nmesh, int x0, int P, double *__restrict__ slab)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const double tx = pos[3 * i + 0] / cellsize;
+    const double fx = floor(tx);
+    const int ix = (int)fx;
+    const int p0 = wrap(ix, nmesh) - x0, p1 = wrap(ix + 1, nmesh) - x0; // planes relative to the slab
+    const bool in0 = p0 >= 0 && p0 < P, in1 = p1 >= 0 && p1 < P;
+    if(!in0 && !in1)
+        return;
+    const double rx = tx - fx;
+    int ic[2];
+    double res[2];
+#pragma unroll
+    for(int k = 0; k < 2; k++) {
+        const double tmp = pos[3 * i + 1 + k] / cellsize;
+        const double fl = floor(tmp);
+        ic[k] = (int)fl;
+        res[k] = tmp - fl;
+    }
+    const double m = (double)mass[i];
+#pragma unroll
+    for(int c = 0; c < 8; c++) {
+        const int offx = c & 1; // same corner order and weight product order as k_cic_deposit
+        if(offx ? !in1 : !in0)
+            continue;
+        double w = offx ? rx : (1 - rx);
+        size_t lin = (size_t)(offx ? p1 : p0);
+#pragma unroll
+        for(int k = 0; k < 2; k++) {
+            const int off = (c >> (k + 1)) & 1;
+            lin = lin * (size_t)nmesh + (size_t)wrap(ic[k] + off, nmesh);
+            w *= off ? res[k] : (1 - res[k]);
+        }
+        unsafeAtomicAdd(&slab[lin], w * m);
+    }
+}
+
+// C[xl][y][z] -> sendA[d][xl][yl][z], d = y / Py
+__global__ void __launch_bounds__(256) k_slab_pack_a(int nmesh, int P, int Py, const double2 *__restrict__ C, double2 *__restrict__ sendA)
+{
+    const int nz = nmesh / 2 + 1;
+    const size_t total = (size_t)P * nmesh * nz;
+    const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int iz = (int)(ip % nz);
+    const size_t t = ip / nz;
+    const int y = (int)(t % nmesh);
+    const int xl = (int)(t / nmesh);
+    const int d = y / Py, yl = y - d * Py;
+    sendA[(((size_t)d * P + xl) * Py + yl) * nz + iz] = C[ip];
+}
+
+// recvB[s][xl][f][yl][z] -> C[xl][y = s Py + yl][z] for one function f
+__global__ void __launch_bounds__(256) k_slab_unpack_b(int nmesh, int P, int Py, int f, const double2 *__restrict__ recvB, double2 *__restrict__ C)
+{
+    const int nz = nmesh / 2 + 1;
+    const size_t total = (size_t)P * nmesh * nz;
+    const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int iz = (int)(ip % nz);
+    const size_t t = ip / nz;
+    const int y = (int)(t % nmesh);
+    const int xl = (int)(t / nmesh);
+    const int s = y / Py, yl = y - s * Py;
+    C[ip] = recvB[((((size_t)s * P + xl) * 4 + f) * Py + yl) * nz + iz];
+}
+
+// readout for a list of targets whose base cell lies in the slab; plane P of the slab is the ghost (first plane of the next rank)
+__global__ void __launch_bounds__(256) k_cic_readout_slab(int64_t nt, const int *__restrict__ targets, const double *__restrict__ pos,
+                                                          double cellsize, int nmesh, int x0, int P, const double *__restrict__ slab, int comp,
+                                                          double *__restrict__ out, unsigned *__restrict__ err)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nt)
+        return;
+    const int64_t i = targets[t];
+    const double tx = pos[3 * i + 0] / cellsize;
+    const double fx = floor(tx);
+    const int px = wrap((int)fx, nmesh) - x0;
+    if(px < 0 || px >= P) { // the caller's target list is not this rank's slab
+        atomicExch(err, 1u);
+        return;
+    }
+    const double rx = tx - fx;
+    int ic[2];
+    double res[2];
+#pragma unroll
+    for(int k = 0; k < 2; k++) {
+        const double tmp = pos[3 * i + 1 + k] / cellsize;
+        const double fl = floor(tmp);
+        ic[k] = (int)fl;
+        res[k] = tmp - fl;
+    }
+    double acc = 0;
+#pragma unroll
+    for(int c = 0; c < 8; c++) {
+        const int offx = c & 1;
+        double w = offx ? rx : (1 - rx);
+        size_t lin = (size_t)(px + offx);
+#pragma unroll
+        for(int k = 0; k < 2; k++) {
+            const int off = (c >> (k + 1)) & 1;
+            lin = lin * (size_t)nmesh + (size_t)wrap(ic[k] + off, nmesh);
+            w *= off ? res[k] : (1 - res[k]);
+        }
+        acc += w * slab[lin];
+    }
+    if(comp < 3)
+        out[3 * i + comp] = acc;
+    else
+        out[i] += acc;
+}
+
+void PMesh::slab_destroy()
+{
+    if(slab.ready) {
+        (void)hipfftDestroy(slab.p2d_r2c);
+        (void)hipfftDestroy(slab.p2d_c2r);
+        (void)hipfftDestroy(slab.p1d_fwd);
+        slab.ready = false;
+    }
+    for(auto &b : slab.realF)
+        b.release();
+    slab.C.release();
+    slab.rho_k.release();
+}
+
+void PMesh::slab_init(int rank, int world)
+{
+    MPG_CHECK(have_plans, "pm_slab_init called before gravpm_init_periodic");
+    MPG_CHECK(world >= 1 && rank >= 0 && rank < world, "pm_slab_init: bad rank / world");
+    MPG_CHECK(nmesh % world == 0, "pm_slab_init: Nmesh must be a multiple of the number of GPUs");
+    slab_destroy();
+    slab.rank = rank;
+    slab.world = world;
+    slab.P = slab.Py = nmesh / world;
+    const int nz = nmesh / 2 + 1;
+    const size_t S = (size_t)slab.Py * nz;
+    for(auto &b : slab.realF)
+        b.reserve((size_t)(slab.P + 1) * nmesh * nmesh);
+    slab.C.reserve(2 * (size_t)slab.P * nmesh * nz);
+    slab.rho_k.reserve(2 * (size_t)nmesh * S);
+    // the single-GPU buffers are not needed in this form
+    real.release();
+    rho_k.release();
+    work_k.release();
+    int n2[2] = {nmesh, nmesh};
+    MPG_FFT(hipfftPlanMany(&slab.p2d_r2c, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, slab.P));
+    MPG_FFT(hipfftPlanMany(&slab.p2d_c2r, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, slab.P));
+    int n1[1] = {nmesh};
+    int emb[1] = {nmesh};
+    MPG_FFT(hipfftPlanMany(&slab.p1d_fwd, 1, n1, emb, (int)S, 1, emb, (int)S, 1, HIPFFT_Z2Z, (int)S));
+    slab.ready = true;
+}
+
+void PMesh::slab_forward_a(int64_t n, const double *d_pos, const float *d_mass, double *sendA, hipStream_t st)
+{
+    MPG_CHECK(slab.ready, "pm_slab: not initialised");
+    const int nz = nmesh / 2 + 1;
+    const size_t nreal = (size_t)slab.P * nmesh * nmesh;
+    MPG_FFT(hipfftSetStream(slab.p2d_r2c, st));
+    MPG_HIP(hipMemsetAsync(slab.realF[0].p, 0, nreal * sizeof(double), st));
+    if(n > 0)
+        hipLaunchKernelGGL(k_cic_deposit_slab, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, cellsize, nmesh, slab.rank * slab.P, slab.P,
+                           slab.realF[0].p);
+    MPG_FFT(hipfftExecD2Z(slab.p2d_r2c, slab.realF[0].p, (hipfftDoubleComplex *)slab.C.p));
+    hipLaunchKernelGGL(k_slab_pack_a, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, (const double2 *)slab.C.p,
+                       (double2 *)sendA);
+    MPG_HIP(hipGetLastError());
+}
+
+void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
+{
+    MPG_CHECK(slab.ready, "pm_slab: not initialised");
+    const int nz = nmesh / 2 + 1;
+    const size_t ncplx = (size_t)nmesh * slab.Py * nz;
+    const int y0 = slab.rank * slab.Py;
+    MPG_FFT(hipfftSetStream(slab.p1d_fwd, st));
+    MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)recvA, (hipfftDoubleComplex *)recvA, HIPFFT_FORWARD));
+    const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
+    const double pot_factor = -G / (M_PI * box);
+    MPG_HIP(hipMemcpyAsync(slab.rho_k.p, recvA, ncplx * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_potential_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, asmth2, pot_factor, invsinc2.p,
+                       (double2 *)slab.rho_k.p);
+    const size_t S = (size_t)slab.Py * nz;
+    for(int f = 0; f < 4; f++) {
+        // recvA serves as the work array [x][ky local][kz] of this function; the result is interleaved into sendB[x][f][..]
+        hipLaunchKernelGGL(k_force_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, f - 1, difffac.p, (const double2 *)slab.rho_k.p,
+                           (double2 *)recvA, 1, 0);
+        MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)recvA, (hipfftDoubleComplex *)recvA, HIPFFT_BACKWARD));
+        MPG_HIP(hipMemcpy2DAsync((double2 *)sendB + (size_t)f * S, 4 * S * sizeof(double2), recvA, S * sizeof(double2), S * sizeof(double2),
+                                 (size_t)nmesh, hipMemcpyDeviceToDevice, st));
+    }
+    MPG_HIP(hipGetLastError());
+}
+
+void PMesh::slab_inverse_c(const double *recvB, double *ghost_send, hipStream_t st)
+{
+    MPG_CHECK(slab.ready, "pm_slab: not initialised");
+    const int nz = nmesh / 2 + 1;
+    const size_t plane = (size_t)nmesh * nmesh;
+    MPG_FFT(hipfftSetStream(slab.p2d_c2r, st));
+    for(int f = 0; f < 4; f++) {
+        hipLaunchKernelGGL(k_slab_unpack_b, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, f,
+                           (const double2 *)recvB, (double2 *)slab.C.p);
+        MPG_FFT(hipfftExecZ2D(slab.p2d_c2r, (hipfftDoubleComplex *)slab.C.p, slab.realF[f].p));
+        MPG_HIP(hipMemcpyAsync(ghost_send + f * plane, slab.realF[f].p, plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    MPG_HIP(hipGetLastError());
+}
+
+void PMesh::slab_readout(const double *ghost_recv, const int *targets, int64_t nt, const double *d_pos, double *d_gravpm, double *d_potential,
+                         hipStream_t st)
+{
+    MPG_CHECK(slab.ready, "pm_slab: not initialised");
+    const size_t plane = (size_t)nmesh * nmesh;
+    DevBuf<unsigned> &flag = slab_err;
+    flag.reserve(1);
+    MPG_HIP(hipMemsetAsync(flag.p, 0, sizeof(unsigned), st));
+    for(int f = 0; f < 4; f++) {
+        MPG_HIP(hipMemcpyAsync(slab.realF[f].p + (size_t)slab.P * plane, ghost_recv + f * plane, plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if(nt == 0 || (f == 0 && !d_potential))
+            continue;
+        hipLaunchKernelGGL(k_cic_readout_slab, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, slab.rank * slab.P, slab.P,
+                           slab.realF[f].p, f == 0 ? 3 : f - 1, f == 0 ? d_potential : d_gravpm, flag.p);
+    }
+    MPG_HIP(hipGetLastError());
+    unsigned e = 0;
+    MPG_HIP(hipMemcpyAsync(&e, flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipStreamSynchronize(st));
+    MPG_CHECK(e == 0, "pm_slab_readout: a target's base cell is outside this rank's slab");
 }
 
 } // namespace mpg

@@ -171,6 +171,17 @@ class Engine:
     def set_stream(self, raw_stream):
         self._ck(self.lib.mpg_engine_set_stream(self.h, C.c_void_p(raw_stream)))
 
+    def use_torch_stream(self, device=None):
+        """Run the engine and torch (collectives, index ops on the engine's outputs) on ONE stream: a new torch stream is
+        made current and handed to the engine.  (torch's default stream is the null stream, whose handle is 0, which
+        mpg_engine_set_stream takes as "own non-blocking stream" - work on the two would then be unordered.)"""
+        import torch
+        torch.cuda.synchronize()   # work already queued on the previous stream (uploads, fills) is done before the switch
+        self._torch_stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(self._torch_stream)
+        self.set_stream(self._torch_stream.cuda_stream)
+        return self._torch_stream
+
     def get_stream(self):
         return self.lib.mpg_engine_get_stream(self.h)
 
@@ -273,6 +284,25 @@ class Engine:
 
     def dev_gravpm_force(self, gravpm, potential=None):
         self._ck(self.lib.mpg_dev_gravpm_force(self.h, _ptr(gravpm), _ptr(potential)))
+
+    # slab-decomposed PM over several GPUs: local stages (the collectives between them are in pm_slab.py)
+    def dev_pm_slab_init(self, rank, world):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.mpg_dev_pm_slab_init(self.h, int(rank), int(world), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def dev_pm_slab_forward_a(self, sendA):
+        self._ck(self.lib.mpg_dev_pm_slab_forward_a(self.h, _ptr(sendA)))
+
+    def dev_pm_slab_forward_b(self, recvA, sendB):
+        self._ck(self.lib.mpg_dev_pm_slab_forward_b(self.h, _ptr(recvA), _ptr(sendB)))
+
+    def dev_pm_slab_inverse_c(self, recvB, ghost_send):
+        self._ck(self.lib.mpg_dev_pm_slab_inverse_c(self.h, _ptr(recvB), _ptr(ghost_send)))
+
+    def dev_pm_slab_readout(self, ghost_recv, targets, gravpm, potential=None):
+        self._ck(self.lib.mpg_dev_pm_slab_readout(self.h, _ptr(ghost_recv), _ptr(targets), C.c_int64(targets.shape[0]), _ptr(gravpm),
+                                                  _ptr(potential)))
 
     def dev_force_tree_build(self, mask=ALLMASK):
         self._ck(self.lib.mpg_dev_force_tree_build(self.h, int(mask)))
@@ -404,6 +434,16 @@ class Engine:
         cnt = C.c_int()
         self._ck(self.lib.mpg_walk_events_collect(self.h, C.byref(tot), C.byref(cnt)))
         return tot.value, cnt.value
+
+    def dev_tree_order(self, n, device):
+        """Zero-copy int32 torch view of the engine-owned tree-order permutation (tree slot -> caller index)."""
+        import torch
+
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(self.dev_tree_order_ptr()), False), "version": 2}
+        return torch.as_tensor(h, device=device)
 
     def dev_tree_order_ptr(self):
         """Raw device pointer (int) of the tree-order permutation, int32 [NumParticles]."""

@@ -1,0 +1,135 @@
+"""Long-range PM and target sharding over the GPUs of one node (one process per GPU, torch.distributed / RCCL).
+
+The reference decomposes the mesh into 2-D pencils over all MPI ranks, ships each rank's "region" meshes to the pencils
+and back (petapm.c:584-885) and lets PFFT transpose between the 1-D transform stages.  Here:
+
+* every rank binds the same particle set; rank r owns the x-planes [r P, (r+1) P), P = Nmesh / world, of the mesh;
+* a particle's CIC cloud is deposited by the owner(s) of the planes it touches, so there is no region exchange;
+* one 3-D transform = local 2-D transforms, ONE all-to-all transpose, local 1-D transforms; the four inverse transforms
+  (Potential, ForceX, ForceY, ForceZ) share one all-to-all; one neighbour plane per function is passed around the ring;
+* the targets of rank r - for the PM readout and for the short-range walk alike - are the particles whose base mesh
+  cell lies in its slab, listed in tree (Morton) order; their accelerations are all-gathered once per step.
+
+xGMI is point-to-point: each all-to-all is 7 contiguous blocks of Nmesh^3 / world^2 complex values per rank (134 MB at
+Nmesh 1024 on 8 GPUs, x4 for the inverse), large enough to run every link at its streaming rate.
+
+This module holds the collectives and the index logic only (torch tensors as buffers); all arithmetic is in the engine.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _all_to_all(recv, send, world, group=None):
+    """recv[s-th block] <- rank s's send[my block].  RCCL all_to_all_single; backends without it (gloo, used by the
+    CPU-launched tests that put two ranks on one GPU) gather everything and slice."""
+    if world == 1:
+        recv.copy_(send)
+        return
+    try:
+        dist.all_to_all_single(recv, send, group=group)
+        return
+    except (RuntimeError, NotImplementedError):
+        pass
+    rank = dist.get_rank(group)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    blk = send.numel() // world
+    for s in range(world):
+        recv.view(-1)[s * blk:(s + 1) * blk] = parts[s].view(-1)[rank * blk:(rank + 1) * blk]
+
+
+def _ring_prev(recv, send, rank, world, group=None):
+    """recv <- send of rank (rank + 1) % world (every rank passes its first planes to the previous rank)."""
+    if world == 1:
+        recv.copy_(send)
+        return
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)   # 4 planes per rank: small; one collective instead of paired send/recv
+    recv.copy_(parts[(rank + 1) % world])
+
+
+def slab_of_cells(pos_x, cellsize, nmesh, world):
+    """Owner rank of each particle: the slab holding its base cell floor(x / cellsize) (wrapped), as the engine computes it."""
+    ix = torch.floor(pos_x / cellsize).to(torch.int64)
+    ix = torch.where(ix >= nmesh, ix - nmesh, ix)
+    ix = torch.where(ix < 0, ix + nmesh, ix)
+    return ix // (nmesh // world)
+
+
+class SlabPM:
+    """gravpm_force (gravpm.c:61-119) over `world` GPUs.  `eng` must have gravpm_init_periodic and dev_bind_particles done."""
+
+    def __init__(self, eng, box, nmesh, rank, world, device, group=None):
+        if nmesh % world:
+            raise ValueError("Nmesh must be a multiple of the number of GPUs")
+        self.eng, self.rank, self.world, self.group = eng, rank, world, group
+        self.box, self.nmesh, self.cellsize = box, nmesh, box / nmesh
+        per_peer, plane = eng.dev_pm_slab_init(rank, world)
+        f64 = dict(dtype=torch.float64, device=device)
+        self.sendA = torch.empty(2 * per_peer * world, **f64)
+        self.recvA = torch.empty_like(self.sendA)
+        self.sendB = torch.empty(2 * 4 * per_peer * world, **f64)
+        self.recvB = torch.empty_like(self.sendB)
+        self.ghost_send = torch.empty(4 * plane, **f64)
+        self.ghost_recv = torch.empty_like(self.ghost_send)
+
+    def targets(self, pos, order):
+        """Caller indices (int32, tree order) of the particles whose base cell lies in this rank's slab.
+        pos: [N,3] device tensor; order: [N] int32 tree slot -> caller index (engine.dev_tree_order)."""
+        o = order.long()
+        owner = slab_of_cells(pos[:, 0][o], self.cellsize, self.nmesh, self.world)
+        return order[owner == self.rank].contiguous()
+
+    def force(self, targets, gravpm, potential=None):
+        """GravPM (assigned) and Potential (incremented) for `targets`; rows of other particles are left untouched."""
+        e = self.eng
+        e.dev_pm_slab_forward_a(self.sendA)
+        _all_to_all(self.recvA, self.sendA, self.world, self.group)
+        e.dev_pm_slab_forward_b(self.recvA, self.sendB)
+        _all_to_all(self.recvB, self.sendB, self.world, self.group)
+        e.dev_pm_slab_inverse_c(self.recvB, self.ghost_send)
+        _ring_prev(self.ghost_recv, self.ghost_send, self.rank, self.world, self.group)
+        e.dev_pm_slab_readout(self.ghost_recv, targets, gravpm, potential)
+
+
+class TargetExchange:
+    """All-gather of per-target results (one per step): every rank contributes the rows of its own targets."""
+
+    def __init__(self, world, device, group=None):
+        self.world, self.device, self.group = world, device, group
+        self.cap = 0
+
+    def _reserve(self, nmax, width):
+        if nmax > self.cap or getattr(self, "width", None) != width:
+            self.cap = int(nmax * 1.05) + 1024
+            self.width = width
+            f64 = dict(dtype=torch.float64, device=self.device)
+            self.sv = torch.zeros(self.cap, width, **f64)
+            self.gv = torch.zeros(self.world * self.cap, width, **f64)
+            self.si = torch.zeros(self.cap, dtype=torch.int32, device=self.device)
+            self.gi = torch.zeros(self.world * self.cap, dtype=torch.int32, device=self.device)
+
+    def exchange(self, values, targets):
+        """values: [N, k] caller order, rows `targets` fresh on this rank.  On return every row holds its owner's result."""
+        if self.world == 1:
+            return values
+        nt = torch.tensor([targets.shape[0]], dtype=torch.int64, device=self.device)
+        counts = [torch.zeros_like(nt) for _ in range(self.world)]
+        dist.all_gather(counts, nt, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        self._reserve(max(counts), values.shape[1])
+        n = targets.shape[0]
+        self.sv[:n] = values[targets.long()]
+        self.si[:n] = targets
+        for g, s in ((self.gv, self.sv), (self.gi, self.si)):
+            try:
+                dist.all_gather_into_tensor(g, s, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                parts = [torch.empty_like(s) for _ in range(self.world)]
+                dist.all_gather(parts, s, group=self.group)
+                for r in range(self.world):
+                    g[r * self.cap:(r + 1) * self.cap] = parts[r]
+        for r in range(self.world):
+            c = counts[r]
+            values[self.gi[r * self.cap:r * self.cap + c].long()] = self.gv[r * self.cap:r * self.cap + c]
+        return values

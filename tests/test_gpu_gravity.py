@@ -313,26 +313,39 @@ def test_load_order_torch_first():
     assert out.returncode == 0 and "gfx950" in out.stdout, out.stderr[-2000:]
 
 
-def test_two_ranks_match_one(tmp_path):
-    """N > 1 path with the real kernels: two ranks (gloo, sharing this GPU) each walk half of the tree-order slots and
-    all-gather; rank 0 must end with exactly the single-rank accelerations (same tree, same per-target arithmetic)."""
+def _run_mgpu(tmp_path, name, nproc, mode, port):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
-    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    r1 = subprocess.run([sys.executable, os.path.join(root, "tools", "mgpu_check.py"), one, "40"], capture_output=True, text=True,
-                        timeout=600, env=env)
-    assert r1.returncode == 0, r1.stderr[-2000:]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29577", os.path.join(root, "tools", "mgpu_check.py"), two, "40"], capture_output=True,
-                        text=True, timeout=900, env=env)
-    assert r2.returncode == 0, r2.stderr[-2000:]
-    a1, a2 = np.load(one), np.load(two)
-    assert np.array_equal(a1, a2)
+    out = str(tmp_path / name)
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode)
+    script = os.path.join(root, "tools", "mgpu_check.py")
+    if nproc == 1:
+        cmd = [sys.executable, script, out, "40"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, out, "40"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
 
 
-# ------------------------------------------------------------------------------- full size (BASELINE.json configs[1])
+def test_two_ranks_match_one(tmp_path):
+    """N > 1 paths with the real kernels; two ranks (gloo, sharing this GPU).
+    replicated: each rank walks half of the tree-order slots, one all-gather -> exactly the single-rank accelerations.
+    slab: x-slab PM (two all-to-all transposes + ghost planes) and x-slab targets -> the same accelerations (the walk's
+    per-target arithmetic does not depend on the sharding) and GravPM / Potential to FFT round-off."""
+    one = _run_mgpu(tmp_path, "one.npy", 1, "single", 0)
+    rep = _run_mgpu(tmp_path, "rep.npy", 2, "replicated", 29577)
+    assert np.array_equal(one[:, 0:3], rep[:, 0:3])
+    for name, nproc, mode, port in (("slab1.npy", 1, "slab1", 0), ("slab2.npy", 2, "slab", 29578), ("slab4.npy", 4, "slab", 29579)):
+        sl = _run_mgpu(tmp_path, name, nproc, mode, port)
+        assert np.array_equal(one[:, 0:3], sl[:, 0:3]), name
+        gpm = np.abs(one[:, 3:6]).mean()
+        assert np.abs(sl[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * gpm, name
+        assert np.abs(sl[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
+
+
 def test_full_size_256_properties(pkg, orc):
     """256^3, Nmesh 512 on the device-resident path: size-independent properties + a sampled oracle comparison.
       * S-grid opens every node, so the short-range force is a pure pair sum; pairs are antisymmetric except where

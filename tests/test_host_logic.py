@@ -92,3 +92,60 @@ def test_exchange_results_world2_gloo(n):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _slab_worker(rank, world, port, q):
+    """Collectives and index logic of the slab-decomposed PM on CPU tensors (gloo): the all-to-all transpose of a toy
+    [x][y] array, the ring pass of ghost planes, slab ownership of particles and the per-target all-gather."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mp-gadget_amd")
+    S = pkg.pm_slab
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    # transpose: rank r holds rows x in [r P, (r+1) P) of A[x][y]; after the all-to-all it holds columns y in its range, x slowest
+    M, P = 8, 8 // world
+    A = torch.arange(M * M, dtype=torch.float64).reshape(M, M)
+    mine = A[rank * P:(rank + 1) * P]                                    # [P][M]
+    send = torch.stack([mine[:, d * P:(d + 1) * P] for d in range(world)]).contiguous()   # [d][xl][yl]
+    recv = torch.empty_like(send)
+    S._all_to_all(recv.view(-1), send.view(-1), world)
+    ok &= bool(torch.equal(recv.reshape(M, P), A[:, rank * P:(rank + 1) * P]))
+    # ghost planes go to the previous rank
+    g = torch.full((4,), float(rank), dtype=torch.float64)
+    gr = torch.empty_like(g)
+    S._ring_prev(gr, g, rank, world)
+    ok &= bool((gr == float((rank + 1) % world)).all())
+    # slab ownership incl. x == box (wraps to cell 0) and the per-target exchange
+    nmesh, box = 16, 4.0
+    gen = torch.Generator().manual_seed(3)
+    n = 1000
+    pos = torch.rand(n, 3, dtype=torch.float64, generator=gen) * box
+    pos[0, 0] = box
+    owner = S.slab_of_cells(pos[:, 0], box / nmesh, nmesh, world)
+    ok &= int(owner[0]) == 0 and int(owner.min()) >= 0 and int(owner.max()) < world
+    order = torch.randperm(n, generator=gen).to(torch.int32)
+    tg = order[owner[order.long()] == rank].contiguous()
+    truth = torch.randn(n, 3, dtype=torch.float64, generator=gen)
+    vals = torch.full((n, 3), float("nan"), dtype=torch.float64)
+    vals[tg.long()] = truth[tg.long()]
+    S.TargetExchange(world, torch.device("cpu")).exchange(vals, tg)
+    ok &= bool(torch.equal(vals, truth))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_pm_collectives_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_slab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

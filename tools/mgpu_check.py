@@ -9,7 +9,6 @@ pkg = importlib.import_module("mp-gadget_amd")
 import torch
 import torch.distributed as dist
 sys.path.insert(0, ROOT)
-import bench
 
 out = sys.argv[1]
 n = int(sys.argv[2])
@@ -24,7 +23,7 @@ pos, mass, box = pkg.ics.s_zel(n)
 N = len(pos)
 d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
 eng = pkg.Engine(lr)
-eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.use_torch_stream()
 eng.gravshort_fill_ntab(0, 1.5)
 eng.gravpm_init_periodic(box, 1.5, 2 * n, G)
 eng.set_gravshort_treepar(TreeUseBH=0)
@@ -33,19 +32,33 @@ eng.dev_bind_particles(d_pos, d_mass, box)
 gravpm = torch.zeros(N, 3, dtype=torch.float64, device=dev)
 acc = torch.zeros_like(gravpm)
 old = torch.full((N,), 1e-7, dtype=torch.float64, device=dev)
-eng.dev_gravpm_force(gravpm, None)
-eng.dev_force_tree_build()
-lo, hi = pkg.shard.slot_range(N, rank, world)
-if world == 1:
+mode = os.environ.get("MPG_MGPU_MODE", "slab")
+pot = torch.zeros(N, dtype=torch.float64, device=dev)
+if world == 1 and mode != "slab1":
+    eng.dev_gravpm_force(gravpm, pot)
+    eng.dev_force_tree_build()
     eng.dev_grav_short_tree(acc, oldacc=old)
-else:
+elif mode == "replicated":
+    eng.dev_gravpm_force(gravpm, pot)
+    eng.dev_force_tree_build()
+    lo, hi = pkg.shard.slot_range(N, rank, world)
     optr = eng.dev_tree_order_ptr()
     eng.dev_grav_short_tree(acc, oldacc=old, active=optr + 4 * lo, nactive=hi - lo)
-    order = bench._as_tensor(torch, optr, N, dev)
-    pkg.shard.exchange_results(acc, order, rank, world)
+    pkg.shard.exchange_results(acc, eng.dev_tree_order(N, dev), rank, world)
+else:
+    # slab-decomposed PM; PM readout and walk targets = the particles of this rank's x-slab
+    eng.dev_force_tree_build()
+    spm = pkg.pm_slab.SlabPM(eng, box, 2 * n, rank, world, dev)
+    tg = spm.targets(d_pos, eng.dev_tree_order(N, dev))
+    spm.force(tg, gravpm, pot)
+    eng.dev_grav_short_tree(acc, oldacc=old, active=tg)
+    ex = pkg.pm_slab.TargetExchange(world, dev)
+    both = torch.cat([acc, gravpm, pot[:, None]], dim=1)
+    ex.exchange(both, tg)
+    acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
 torch.cuda.synchronize()
 if rank == 0:
-    np.save(out, acc.cpu().numpy())
+    np.save(out, np.concatenate([acc.cpu().numpy(), gravpm.cpu().numpy(), pot.cpu().numpy()[:, None]], axis=1))
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()

@@ -16,7 +16,7 @@ dev = "cuda"
 f8 = torch.float64
 d_pos, d_mass, d_type = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
 eng = pkg.Engine(0)
-eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.use_torch_stream()
 eng.set_gravshort_treepar(); eng.gravshort_set_softenings(box / n)
 eng.set_densitypar(1.0, 2.0, 2.0, 99999., 2, 0.006); eng.set_hydropar(0, 100.0, 0.75)
 eng.dev_bind_particles(d_pos, d_mass, box, type=d_type)
