@@ -60,6 +60,7 @@ struct TreeBuilder {
     DevBuf<uint8_t> leaflevel;
     DevBuf<uint32_t> cnt, base;
     DevBuf<int64_t> flags;
+    DevBuf<int> wave_ext; // per-wave leaf-level extrema of k_leaflevel
     DevBuf<char> tmp;
     DevBuf<Src4> src;
     DevBuf<NodeGeo> geo;

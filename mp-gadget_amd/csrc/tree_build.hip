@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) k_gather_src(int64_t n, const uint32_t *_
 // flags[0]: error (too many coincident particles), flags[1]: max leaf level, flags[2]: MAXLEVEL - min leaf level
 // Each block stages its 256 keys plus an 8-key halo on either side in LDS (one coalesced read instead of 17 per thread).
 __global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__restrict__ keys, uint8_t *__restrict__ leaflevel,
-                                                   uint32_t *__restrict__ cnt, int *__restrict__ flags)
+                                                   uint32_t *__restrict__ cnt, int *__restrict__ flags, int *__restrict__ wave_ext)
 {
     __shared__ uint64_t sk[256 + 16];
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -123,19 +123,33 @@ __global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__
         head = (i == 0) || (c < L);
         cnt[i] = head ? (uint32_t)(L - c) : 0u;
     }
-    // one atomic per wave for the level extrema
+    // level extrema: one word per wave, reduced by k_level_extrema.  (Same-address traffic from every wave - atomics at ~90
+    // per microsecond, or 2 x 262144 uncached reads of one word to avoid them - cost this kernel 2-4 ms at 256^3.)
     int lmax = head ? L : 0, lmin = head ? (MAXLEVEL - L) : 0;
     for(int off = 32; off > 0; off >>= 1) {
         lmax = max(lmax, __shfl_down(lmax, off));
         lmin = max(lmin, __shfl_down(lmin, off));
     }
-    // same-address atomics serialise at ~90 per microsecond on MI355X: only issue one when it would change the value
-    // (the plain read may be stale-low, which costs an unnecessary atomic, never a missed update)
+    if((threadIdx.x & 63) == 0)
+        wave_ext[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = lmax | (lmin << 8);
+}
+
+// flags[1] = deepest leaf level, flags[2] = MAXLEVEL - shallowest leaf level
+__global__ void __launch_bounds__(256) k_level_extrema(int64_t nwaves, const int *__restrict__ wave_ext, int *__restrict__ flags)
+{
+    int lmax = 0, lmin = 0;
+    for(int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwaves; w += (int64_t)gridDim.x * blockDim.x) {
+        const int v = wave_ext[w];
+        lmax = max(lmax, v & 255);
+        lmin = max(lmin, v >> 8);
+    }
+    for(int off = 32; off > 0; off >>= 1) {
+        lmax = max(lmax, __shfl_down(lmax, off));
+        lmin = max(lmin, __shfl_down(lmin, off));
+    }
     if((threadIdx.x & 63) == 0) {
-        if(lmax > __builtin_nontemporal_load(&flags[1]))
-            atomicMax(&flags[1], lmax);
-        if(lmin > __builtin_nontemporal_load(&flags[2]))
-            atomicMax(&flags[2], lmin); // -> shallowest leaf level
+        atomicMax(&flags[1], lmax);
+        atomicMax(&flags[2], lmin);
     }
 }
 
@@ -454,7 +468,10 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     int hflags[3] = {0, 0, 0};
     uint32_t lastbase = 0, lastcnt = 0;
     if(npart > 0) {
-        hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags);
+        const int64_t nwaves = (int64_t)nblk(npart) * 4;
+        wave_ext.reserve((size_t)nwaves);
+        hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags, wave_ext.p);
+        hipLaunchKernelGGL(k_level_extrema, dim3(64), dim3(256), 0, st, nwaves, wave_ext.p, d_flags);
         size_t sb = 0;
         MPG_HIP(rocprim::exclusive_scan(nullptr, sb, cnt.p, base.p, 0u, (size_t)npart, rocprim::plus<uint32_t>(), st));
         tmp.reserve(sb + 16);
