@@ -46,6 +46,7 @@ double sph_desnumngb(const mpg_density_params &P);
 struct SphEngine {
     DevBuf<double> left, right, numngb, entvarpred, hsml_tree;
     DevBuf<int> queue_a, queue_b, slot_of;
+    DevBuf<uint8_t> active_flags;
     DevBuf<Aux4> aux;
     DevBuf<HydroSrc> hsrc;
     DevBuf<unsigned> ctr;
@@ -53,6 +54,7 @@ struct SphEngine {
     bool hmax_pending = false;
     int64_t last_iterations = 0, last_targets = 0, last_interactions = 0, last_candidates = 0;
 
+    const uint8_t *mark_active(const int *d_active, int64_t nactive, int64_t n, hipStream_t st);
     // density(), density.c:234-355
     void density(TreeBuilder &tree, const SphView &A, const mpg_sph_times &T, const mpg_density_params &P, double force_softening,
                  const int *d_active, int64_t nactive, int64_t n, int update_hsml, int DoEgyDensity, int BlackHoleOn, hipStream_t st);

@@ -171,20 +171,176 @@ __device__ __forceinline__ bool cull_node(const NodeGeo &g, double hm, double hs
     return r2 > dist * dist;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Group-cooperative neighbour search (both SPH loops).  A wave is 8 groups of 8 lanes; a group owns ONE target and walks
+// the level-ordered copy of the tree (children of a node contiguous): one step pops a child range from the group's LIFO in
+// LDS, the 8 lanes cull the <= 8 children (treewalk.c:1015-1042) with one coalesced read each, internal survivors push their
+// own child range, and the surviving leaves are evaluated at once, lane s <-> particle s of the leaf (one coalesced read
+// per group).  The visited set is the reference's; only the order of the sums differs.  (The first form, one lane per
+// target walking the depth-first arrays, spent its time in dependent, uncoalesced 48-byte node reads: 27 ms per density
+// pass over 2.1 M targets against the figures in DESIGN.md section 3.4.)
+constexpr int SPH_STK = 160; // pending child ranges per group: <= 7 per level + 8, 21 levels
+
+struct DensAcc {
+    double EgyRho = 0, DhsmlEgy = 0, Rho = 0, DhsmlDensity = 0, Ngb = 0, Div = 0, Rot0 = 0, Rot1 = 0, Rot2 = 0, G0 = 0, G1 = 0, G2 = 0;
+};
+
+// Candidate handling is split in two so that the expensive part runs with full lanes: every candidate of an opened leaf
+// gets the distance test (treewalk.c:1218-1232; cheap, ~1/3 pass), the survivors are compacted into a small per-group
+// buffer in LDS, and the kernel evaluation (density_ngbiter / hydro_ngbiter) is run 8 survivors at a time.
+constexpr int SPH_CBUF = 24; // survivor slots per group: evaluation triggers when any group of the wave holds >= 16
+
+// distance test of density: returns whether the kernel evaluation is needed; counts the reference's "ninteractions"
+__device__ __forceinline__ bool density_test(const Src4 s, const double px, const double py, const double pz, const double h2, const double HH,
+                                             const double box, unsigned &n_int)
+{
+    // the distance vector points to 'other': I.Pos - P[other].Pos (treewalk.c:1218-1225)
+    const double d0 = nearest_img(px - s.x, box, 1.0 / box);
+    const double d1 = nearest_img(py - s.y, box, 1.0 / box);
+    const double d2 = nearest_img(pz - s.z, box, 1.0 / box);
+    const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+    if(r2 > h2)
+        return false;
+    n_int++;
+    return r2 < HH;
+}
+
+// density_ngbiter for one neighbour inside the kernel, density.c:451-518
+__device__ __forceinline__ void density_eval(const Src4 s, const Aux4 o, const double px, const double py, const double pz, const DKernel &kern,
+                                             const double kvol, const double *ivel, const DensityCtl &C, const double box, DensAcc &a)
+{
+    const double d0 = nearest_img(px - s.x, box, 1.0 / box);
+    const double d1 = nearest_img(py - s.y, box, 1.0 / box);
+    const double d2 = nearest_img(pz - s.z, box, 1.0 / box);
+    const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const double r = sqrt(r2);
+    const double u = r * kern.Hinv;
+    const double wk = kernel_wk(kern, C.ktype, u);
+    a.Ngb += wk * kvol;
+    const double dwk = kernel_dwk(kern, C.ktype, u);
+    const double mass_j = s.m;
+    a.Rho += mass_j * wk;
+    const double density_dW = -(NUMDIMS * kern.Hinv * wk + u * dwk);
+    a.DhsmlDensity += mass_j * density_dW;
+    if(C.DoEgyDensity) {
+        a.EgyRho += mass_j * o.w * wk;
+        a.DhsmlEgy += mass_j * o.w * density_dW;
+    }
+    if(r > 0) {
+        const double fac = mass_j * dwk / r;
+        const double dv0 = ivel[0] - o.x, dv1 = ivel[1] - o.y, dv2 = ivel[2] - o.z;
+        a.Div += -fac * (d0 * dv0 + d1 * dv1 + d2 * dv2);
+        a.Rot0 += fac * (dv1 * d2 - d1 * dv2); // crossproduct(dv, dist), densitykernel.h:63-76
+        a.Rot1 += fac * (dv2 * d0 - d2 * dv0);
+        a.Rot2 += fac * (dv0 * d1 - d0 * dv1);
+        a.G0 += fac * d0;
+        a.G1 += fac * d1;
+        a.G2 += fac * d2;
+    }
+}
+
+// appends this lane's survivor (if any) to the group's buffer; returns the new (group-uniform) fill level
+__device__ __forceinline__ int cbuf_push(int *cbuf, int cnt, const bool keep, const int sidx, const int s, const int gshift)
+{
+    const unsigned gm = (unsigned)((__ballot(keep) >> gshift) & 0xffull);
+    if(keep)
+        cbuf[cnt + __popc(gm & ((1u << s) - 1u))] = sidx;
+    return cnt + __popc(gm);
+}
+
+// after the first 8 survivors were evaluated: move the rest to the front
+__device__ __forceinline__ int cbuf_pop8(int *cbuf, int cnt, const int s)
+{
+    const int rest = cnt - 8;
+    int v0 = 0, v1 = 0;
+    if(s < rest)
+        v0 = cbuf[8 + s];
+    if(8 + s < rest)
+        v1 = cbuf[16 + s];
+    if(s < rest)
+        cbuf[s] = v0;
+    if(8 + s < rest)
+        cbuf[8 + s] = v1;
+    return rest;
+}
+
+__device__ __forceinline__ double group_sum(double v)
+{
+    for(int off = 1; off < 8; off <<= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+// One cooperative walk step shared by both loops: pops a child range, culls, pushes; returns in (leaf_ps, leaf_pc) the leaf
+// this lane opened (pc = 0: none) and the group's mask of lanes that opened one.  SYM: symmetric search radius
+// max(node hmax, Hsml) (hydro); otherwise Hsml (density).
+template <bool SYM>
+__device__ __forceinline__ unsigned walk_step(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
+                                              const double hsml, const double px, const double py, const double pz, int &leaf_ps, int &leaf_pc,
+                                              bool &overflow)
+{
+    const bool can = valid_more;
+    const unsigned range = can ? stack[sp - 1] : 0u;
+    const int first = (int)(range >> 4), nch = (int)(range & 15u);
+    int act = 0;
+    unsigned pushval = 0;
+    leaf_pc = 0;
+    leaf_ps = 0;
+    if(can && s < nch) {
+        const int my = first + s;
+        const NodeGeo g = tv.geoB[my];
+        const NodeLinkB lk = tv.linkB[my];
+        const double hm = SYM ? tv.hmaxB[my] : 0.0;
+        if(!cull_node(g, hm, hsml, px, py, pz, tv.box, 1.0 / tv.box)) {
+            if(lk.pcount > 0) {
+                act = 1;
+                leaf_ps = lk.pstart;
+                leaf_pc = lk.pcount;
+            }
+            else if(lk.nchild > 0) {
+                act = 3;
+                pushval = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
+            }
+        }
+    }
+    const unsigned gm_leaf = (unsigned)((__ballot(act == 1) >> gshift) & 0xffull);
+    const unsigned gm_push = (unsigned)((__ballot(act == 3) >> gshift) & 0xffull);
+    const unsigned below = (1u << s) - 1u;
+    if(can && sp - 1 + __popc(gm_push) > SPH_STK)
+        overflow = true;
+    else if(act == 3)
+        stack[sp - 1 + __popc(gm_push & below)] = pushval;
+    if(can)
+        sp += __popc(gm_push) - 1;
+    return can ? gm_leaf : 0u;
+}
+
 // One density pass over the current queue: treewalk_visit_nolist_ngbiter + density_ngbiter + density_reduce +
 // density_postprocess + density_check_neighbours.  Targets that are not done are appended to `redo`.
 __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_density_params P,
                                                  const DensityCtl C, const Aux4 *__restrict__ aux, const int *__restrict__ queue,
                                                  int64_t nqueue, int *__restrict__ redo, unsigned *__restrict__ nredo,
-                                                 unsigned long long *__restrict__ stats)
+                                                 unsigned long long *__restrict__ stats, unsigned *__restrict__ err)
 {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long n_int = 0, n_cand = 0;
-    if(q < nqueue) {
-        const int i = queue[q];
-        const int ty = A.type ? (A.type[i] & 7) : 0;
-        const double px = A.pos[3 * (int64_t)i], py = A.pos[3 * (int64_t)i + 1], pz = A.pos[3 * (int64_t)i + 2];
-        double ivel[3];
+    __shared__ unsigned s_stack[4 * 8 * SPH_STK];
+    __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
+    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
+    int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
+    int cnt = 0; // survivors waiting in cbuf (group-uniform)
+    const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
+    const bool valid = q < nqueue;
+    unsigned n_int = 0, n_cand = 0;
+    int i = 0, ty = 0;
+    double px = 0, py = 0, pz = 0, hsml = 0;
+    double ivel[3] = {0, 0, 0};
+    if(valid) {
+        i = queue[q];
+        ty = A.type ? (A.type[i] & 7) : 0;
+        px = A.pos[3 * (int64_t)i];
+        py = A.pos[3 * (int64_t)i + 1];
+        pz = A.pos[3 * (int64_t)i + 2];
         if(ty != 0) { // density_copy, density.c:357-372
             ivel[0] = A.vel[3 * (int64_t)i];
             ivel[1] = A.vel[3 * (int64_t)i + 1];
@@ -192,65 +348,74 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         }
         else
             vel_pred(A, T, i, ivel);
-        const double hsml = A.hsml[i];
-        const DKernel kern = kernel_init(hsml, C.ktype);
-        const double kvol = NORM_COEFF * p3(kern.H);
-        const double h2 = hsml * hsml;
-        double EgyRho = 0, DhsmlEgy = 0, Rho = 0, DhsmlDensity = 0, Ngb = 0, Div = 0, Rot0 = 0, Rot1 = 0, Rot2 = 0, G0 = 0, G1 = 0, G2 = 0;
-        int no = 0;
-        while(no >= 0) {
-            const NodeGeo g = tv.geo[no];
-            const NodeLink lk = tv.link[no];
-            if(cull_node(g, 0.0, hsml, px, py, pz, tv.box, 1.0 / tv.box)) {
-                no = lk.sibling;
-                continue;
+        hsml = A.hsml[i];
+    }
+    const DKernel kern = kernel_init(valid ? hsml : 1.0, C.ktype);
+    const double kvol = NORM_COEFF * p3(kern.H);
+    const double h2 = hsml * hsml;
+    DensAcc a;
+    int sp = 0;
+    if(valid) {
+        if(s == 0)
+            stack[0] = (0u << 4) | 1u; // the root
+        sp = 1;
+    }
+    bool overflow = false;
+    for(;;) {
+        if(__ballot(sp > 0) == 0)
+            break;
+        int lps, lpc;
+        unsigned rem = walk_step<false>(tv, stack, sp, sp > 0, s, gshift, hsml, px, py, pz, lps, lpc, overflow);
+        if(__ballot(overflow) != 0)
+            break;
+        while(__ballot(rem != 0) != 0) {
+            const int b = rem ? (__ffs(rem) - 1) : 0;
+            const int ps = __shfl(lps, gshift + b), pc = __shfl(lpc, gshift + b);
+            bool keep = false;
+            if(rem != 0 && s < pc) {
+                n_cand++;
+                keep = density_test(tv.src[ps + s], px, py, pz, h2, kern.HH, tv.box, n_int);
             }
-            if(lk.pcount > 0) {
-                for(int k = 0; k < lk.pcount; k++) {
-                    const int sidx = lk.pstart + k;
-                    const Src4 s = tv.src[sidx];
-                    n_cand++;
-                    // the distance vector points to 'other': I.Pos - P[other].Pos (treewalk.c:1218-1225)
-                    const double d0 = nearest_img(px - s.x, tv.box, 1.0 / tv.box);
-                    const double d1 = nearest_img(py - s.y, tv.box, 1.0 / tv.box);
-                    const double d2 = nearest_img(pz - s.z, tv.box, 1.0 / tv.box);
-                    const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
-                    if(r2 > h2)
-                        continue;
-                    n_int++;
-                    if(r2 < kern.HH) { // density_ngbiter, density.c:451-518
-                        const double r = sqrt(r2);
-                        const double u = r * kern.Hinv;
-                        const double wk = kernel_wk(kern, C.ktype, u);
-                        Ngb += wk * kvol;
-                        const double dwk = kernel_dwk(kern, C.ktype, u);
-                        const double mass_j = s.m;
-                        Rho += mass_j * wk;
-                        const double density_dW = -(NUMDIMS * kern.Hinv * wk + u * dwk);
-                        DhsmlDensity += mass_j * density_dW;
-                        const Aux4 a = aux[sidx];
-                        if(C.DoEgyDensity) {
-                            EgyRho += mass_j * a.w * wk;
-                            DhsmlEgy += mass_j * a.w * density_dW;
-                        }
-                        if(r > 0) {
-                            const double fac = mass_j * dwk / r;
-                            const double dv0 = ivel[0] - a.x, dv1 = ivel[1] - a.y, dv2 = ivel[2] - a.z;
-                            Div += -fac * (d0 * dv0 + d1 * dv1 + d2 * dv2);
-                            Rot0 += fac * (dv1 * d2 - d1 * dv2); // crossproduct(dv, dist), densitykernel.h:63-76
-                            Rot1 += fac * (dv2 * d0 - d2 * dv0);
-                            Rot2 += fac * (dv0 * d1 - d0 * dv1);
-                            G0 += fac * d0;
-                            G1 += fac * d1;
-                            G2 += fac * d2;
-                        }
-                    }
+            cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
+            rem &= rem - 1;
+            if(__ballot(cnt >= 16) != 0) {
+                if(cnt >= 8) {
+                    const int sidx = cbuf[s];
+                    density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
+                    cnt = cbuf_pop8(cbuf, cnt, s);
                 }
-                no = lk.sibling;
-                continue;
             }
-            no = no + 1;
         }
+    }
+    if(__ballot(overflow) != 0) {
+        if(lane == 0)
+            atomicExch(err, 1u);
+        return;
+    }
+    while(__ballot(cnt > 0) != 0) { // drain the survivor buffers
+        if(s < cnt) {
+            const int sidx = cbuf[s];
+            density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
+        }
+        cnt = cnt > 8 ? cbuf_pop8(cbuf, cnt, s) : 0;
+    }
+    // sum over the 8 lanes of the group
+    a.EgyRho = group_sum(a.EgyRho);
+    a.DhsmlEgy = group_sum(a.DhsmlEgy);
+    a.Rho = group_sum(a.Rho);
+    a.DhsmlDensity = group_sum(a.DhsmlDensity);
+    a.Ngb = group_sum(a.Ngb);
+    a.Div = group_sum(a.Div);
+    a.Rot0 = group_sum(a.Rot0);
+    a.Rot1 = group_sum(a.Rot1);
+    a.Rot2 = group_sum(a.Rot2);
+    a.G0 = group_sum(a.G0);
+    a.G1 = group_sum(a.G1);
+    a.G2 = group_sum(a.G2);
+    bool notdone = false;
+    if(valid && s == 0) {
+        const double EgyRho = a.EgyRho, DhsmlEgy = a.DhsmlEgy, Rho = a.Rho, DhsmlDensity = a.DhsmlDensity, Ngb = a.Ngb, Div = a.Div;
+        const double Rot0 = a.Rot0, Rot1 = a.Rot1, Rot2 = a.Rot2, G0 = a.G0, G1 = a.G1, G2 = a.G2;
         // ---- density_reduce (PRIMARY: assign), density.c:374-409
         C.NumNgb[i] = Ngb;
         double dhsmlfac = DhsmlDensity;
@@ -316,8 +481,7 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                     newh = C.MinGasHsml;
             }
             A.hsml[i] = newh;
-            if(!done)
-                redo[atomicAdd(nredo, 1u)] = i;
+            notdone = !done;
         }
         if(ty == 0) {
             if(C.DoEgyDensity) {
@@ -343,30 +507,58 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                 A.dthsml[i] = (1.0 / NUMDIMS) * divvel * newh;
         }
     }
-    // statistics: successful distance tests (the reference's ninteractions) and candidates tested
-    for(int off = 32; off > 0; off >>= 1) {
-        n_int += __shfl_down(n_int, off);
-        n_cand += __shfl_down(n_cand, off);
+    // wave-aggregated append of the unfinished targets (one atomic per wave)
+    {
+        const unsigned long long m = __ballot(notdone);
+        if(m != 0) {
+            unsigned basepos = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if(lane == leader)
+                basepos = atomicAdd(nredo, (unsigned)__popcll(m));
+            basepos = __shfl(basepos, leader);
+            if(notdone)
+                redo[basepos + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
     }
-    if((threadIdx.x & 63) == 0 && stats) {
-        atomicAdd(&stats[0], n_int);
-        atomicAdd(&stats[1], n_cand);
+    // statistics: successful distance tests (the reference's ninteractions) and candidates tested
+    unsigned long long c_int = n_int, c_cand = n_cand;
+    for(int off = 32; off > 0; off >>= 1) {
+        c_int += __shfl_down(c_int, off);
+        c_cand += __shfl_down(c_cand, off);
+    }
+    if(lane == 0 && stats) {
+        atomicAdd(&stats[0], c_int);
+        atomicAdd(&stats[1], c_cand);
     }
 }
 
-__global__ void __launch_bounds__(256) k_density_init(int64_t nact, const int *__restrict__ active, const SphView A, const DensityCtl C,
-                                                      double box, int *__restrict__ queue, unsigned *__restrict__ nqueue)
+// marks the active particles (caller indices) in a byte map
+__global__ void __launch_bounds__(256) k_mark_active(int64_t nact, const int *__restrict__ active, uint8_t *__restrict__ flags)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inb = k < nact;
-    const int i = inb ? (active ? active[k] : (int)k) : 0;
-    if(inb) {
-        C.Right[i] = box; // density.c:277-285
+    if(k < nact)
+        flags[active[k]] = 1;
+}
+
+// Work queue of a loop in TREE ORDER (consecutive entries are neighbours in space, so the 8 targets of a wave walk the same
+// nodes and leaves): the active gas / black-hole particles of the tree.  INIT: also the per-target initialisation of
+// density() (density.c:277-285).  flags == null: every particle is active.
+template <bool INIT>
+__global__ void __launch_bounds__(256) k_queue_treeorder(int64_t npart, const int *__restrict__ order, const uint8_t *__restrict__ flags,
+                                                         const SphView A, const DensityCtl C, double box, bool gas_only,
+                                                         int *__restrict__ queue, unsigned *__restrict__ nqueue)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = k < npart;
+    const int i = inb ? order[k] : 0;
+    const bool act = inb && (!flags || flags[i]);
+    if(INIT && act) {
+        C.Right[i] = box;
         C.NumNgb[i] = 0;
         C.Left[i] = 0;
     }
-    const int ty = (inb && A.type) ? (A.type[i] & 7) : 0;
-    const bool work = inb && (ty == 0 || ty == 5); // density_haswork, density.c:521-530
+    const int ty = (act && A.type) ? (A.type[i] & 7) : 0;
+    const bool work = act && (ty == 0 || (!gas_only && ty == 5)); // density_haswork (density.c:521-530) / hydro_haswork
     // wave-aggregated append: one atomic per wave (same-address atomics serialise)
     const unsigned long long m = __ballot(work);
     unsigned basepos = 0;
@@ -476,131 +668,202 @@ __global__ void __launch_bounds__(256) k_hydro_prepare(int64_t npart, const int 
     hs[k] = o;
 }
 
-__global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_hydro_params HP,
-                                               const HydroCtl C, const HydroSrc *__restrict__ hs, const int *__restrict__ slot_of,
-                                               const int *__restrict__ targets, int64_t ntargets, unsigned long long *__restrict__ stats)
+// the target-side constants of hydro_ngbiter
+struct HydroTarget {
+    double px, py, pz, IMass, IDensity, IEgyRho, IF1, soundspeed_i, p_over_rho2_i;
+    HydroSrc me;
+};
+struct HydroAcc {
+    double Acc0 = 0, Acc1 = 0, Acc2 = 0, DtEntropy = 0, MaxSignalVel = 0;
+};
+
+// symmetric distance test (treewalk.c:1218-1232) and the pair condition of hydro_ngbiter (hydra.c:330-338): is this a pair?
+__device__ __forceinline__ bool hydro_test(const Src4 s, const double hsml_j, const HydroTarget &t, const DKernel &kernel_i, const HydroCtl &C,
+                                           const double box)
 {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long n_cand = 0, n_pair = 0;
-    if(q < ntargets) {
-        const int i = targets ? targets[q] : tv.order[q];
-        const int ty = A.type ? (A.type[i] & 7) : 0;
-        if(ty == 0) { // hydro_haswork
-            const int myslot = slot_of[i];
-            const HydroSrc me = hs[myslot];
-            const double px = A.pos[3 * (int64_t)i], py = A.pos[3 * (int64_t)i + 1], pz = A.pos[3 * (int64_t)i + 2];
-            // hydro_copy, hydra.c:247-277
-            const double IMass = (double)A.mass[i];
-            const double IDensity = A.density[i];
-            const double IEgyRho = A.egywtdensity ? A.egywtdensity[i] : 0.0;
-            const double eomdensity_i = HP.DensityIndependentSphOn ? IEgyRho : IDensity;
-            // the target's own pressure: PressurePred[PI] = predicted from the drifted EOM density (hydra.c:206-212)
-            const double IPressure = me.pressure;
-            const double soundspeed_c = sqrt(SPH_GAMMA * IPressure / eomdensity_i);
-            const double IF1 = fabs(A.divvel[i]) / (fabs(A.divvel[i]) + A.curlvel[i] + 0.0001 * soundspeed_c / me.hsml / C.fac_mu);
-            double soundspeed_i, p_over_rho2_i;
-            if(HP.DensityIndependentSphOn) {
-                soundspeed_i = sqrt(SPH_GAMMA * IPressure / IEgyRho);
-                p_over_rho2_i = IPressure / (IEgyRho * IEgyRho);
-            }
-            else {
-                soundspeed_i = sqrt(SPH_GAMMA * IPressure / IDensity);
-                p_over_rho2_i = IPressure / (IDensity * IDensity);
-            }
-            const DKernel kernel_i = kernel_init(me.hsml, C.ktype);
-            double Acc0 = 0, Acc1 = 0, Acc2 = 0, DtEntropy = 0, MaxSignalVel = soundspeed_i;
-            int no = 0;
-            while(no >= 0) {
-                const NodeGeo g = tv.geo[no];
-                const NodeLink lk = tv.link[no];
-                if(cull_node(g, tv.hmax[no], me.hsml, px, py, pz, tv.box, 1.0 / tv.box)) {
-                    no = lk.sibling;
-                    continue;
-                }
-                if(lk.pcount > 0) {
-                    for(int k = 0; k < lk.pcount; k++) {
-                        const int sidx = lk.pstart + k;
-                        const Src4 s = tv.src[sidx];
-                        const HydroSrc o = hs[sidx];
-                        n_cand++;
-                        const double hh = fmax(o.hsml, me.hsml);
-                        const double d0 = nearest_img(px - s.x, tv.box, 1.0 / tv.box);
-                        const double d1 = nearest_img(py - s.y, tv.box, 1.0 / tv.box);
-                        const double d2 = nearest_img(pz - s.z, tv.box, 1.0 / tv.box);
-                        const double rsq = d0 * d0 + d1 * d1 + d2 * d2;
-                        if(rsq > hh * hh)
-                            continue;
-                        const DKernel kernel_j = kernel_init(o.hsml, C.ktype);
-                        if(rsq <= 0 || !(rsq < kernel_i.HH || rsq < kernel_j.HH))
-                            continue;
-                        n_pair++;
-                        const double r = sqrt(rsq);
-                        const double p_over_rho2_j = o.pressure / (o.eomdensity * o.eomdensity);
-                        const double soundspeed_j = o.soundspeed;
-                        double vsig = soundspeed_i + soundspeed_j;
-                        if(vsig > MaxSignalVel)
-                            MaxSignalVel = vsig;
-                        const double dv0 = me.vx - o.vx, dv1 = me.vy - o.vy, dv2 = me.vz - o.vz;
-                        const double vdotr = d0 * dv0 + d1 * dv1 + d2 * dv2;
-                        const double vdotr2 = vdotr + C.hubble_a2 * rsq;
-                        const double dwk_i = kernel_dwk(kernel_i, C.ktype, r * kernel_i.Hinv);
-                        const double dwk_j = kernel_dwk(kernel_j, C.ktype, r * kernel_j.Hinv);
-                        double visc = 0;
-                        if(vdotr2 < 0) { // Gadget-2 eqs. 13-14, hydra.c:435-462
-                            const double mu_ij = C.fac_mu * vdotr2 / r;
-                            const double rho_ij = 0.5 * (IDensity + o.density);
-                            double vs = soundspeed_i + soundspeed_j;
-                            vs -= 3 * mu_ij;
-                            if(vs > MaxSignalVel)
-                                MaxSignalVel = vs;
-                            visc = 0.25 * HP.ArtBulkViscConst * vs * (-mu_ij) / rho_ij * (IF1 + o.f2);
-                            const double dloga = 2 * fmax(me.dloga, o.dloga);
-                            if(dloga > 0 && (dwk_i + dwk_j) < 0) {
-                                if((IMass + s.m) > 0)
-                                    visc = fmin(visc, 0.5 * C.fac_vsic_fix * vdotr2 / (0.5 * (IMass + s.m) * (dwk_i + dwk_j) * r * dloga));
-                            }
-                        }
-                        const double hfc_visc = 0.5 * s.m * visc * (dwk_i + dwk_j) / r;
-                        double hfc = hfc_visc;
-                        double rr1 = 1, rr2 = 1;
-                        if(HP.DensityIndependentSphOn) {
-                            rr1 = 0, rr2 = 0;
-                            hfc += s.m * (dwk_i * p_over_rho2_i * o.entvarpred / me.entvarpred + dwk_j * p_over_rho2_j * me.entvarpred / o.entvarpred) / r;
-                            if(HP.DensityContrastLimit >= 0) {
-                                rr1 = IEgyRho / IDensity;
-                                rr2 = o.eomdensity / o.density;
-                                if(HP.DensityContrastLimit > 0) {
-                                    rr1 = fmin(rr1, HP.DensityContrastLimit);
-                                    rr2 = fmin(rr2, HP.DensityContrastLimit);
-                                }
-                            }
-                        }
-                        hfc += s.m * (p_over_rho2_i * me.dhsml * dwk_i * rr1 + p_over_rho2_j * o.dhsml * dwk_j * rr2) / r;
-                        Acc0 += -hfc * d0;
-                        Acc1 += -hfc * d1;
-                        Acc2 += -hfc * d2;
-                        DtEntropy += 0.5 * hfc_visc * vdotr2;
-                    }
-                    no = lk.sibling;
-                    continue;
-                }
-                no = no + 1;
-            }
-            // hydro_reduce (assign) + hydro_postprocess, hydra.c:279-294, 514-528
-            A.hydroacc_out[3 * (int64_t)i] = Acc0;
-            A.hydroacc_out[3 * (int64_t)i + 1] = Acc1;
-            A.hydroacc_out[3 * (int64_t)i + 2] = Acc2;
-            A.maxsignalvel[i] = MaxSignalVel;
-            A.dtentropy_out[i] = DtEntropy * (SPH_GAMMA_MINUS1 / (C.hubble_a2 * pow(IDensity, SPH_GAMMA_MINUS1)));
+    const double hh = fmax(hsml_j, t.me.hsml);
+    const double d0 = nearest_img(t.px - s.x, box, 1.0 / box);
+    const double d1 = nearest_img(t.py - s.y, box, 1.0 / box);
+    const double d2 = nearest_img(t.pz - s.z, box, 1.0 / box);
+    const double rsq = d0 * d0 + d1 * d1 + d2 * d2;
+    if(rsq > hh * hh)
+        return false;
+    const double HHj = hsml_j * hsml_j; // kernel_init(hsml_j).HH
+    return !(rsq <= 0 || !(rsq < kernel_i.HH || rsq < HHj));
+}
+
+// hydro_ngbiter for one pair, hydra.c:296-512
+__device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, const HydroTarget &t, const DKernel &kernel_i, const HydroCtl &C,
+                                           const mpg_hydro_params &HP, const double box, HydroAcc &a)
+{
+    const HydroSrc &me = t.me;
+    const double d0 = nearest_img(t.px - s.x, box, 1.0 / box);
+    const double d1 = nearest_img(t.py - s.y, box, 1.0 / box);
+    const double d2 = nearest_img(t.pz - s.z, box, 1.0 / box);
+    const double rsq = d0 * d0 + d1 * d1 + d2 * d2;
+    const DKernel kernel_j = kernel_init(o.hsml, C.ktype);
+    const double r = sqrt(rsq);
+    const double p_over_rho2_j = o.pressure / (o.eomdensity * o.eomdensity);
+    const double soundspeed_j = o.soundspeed;
+    const double vsig = t.soundspeed_i + soundspeed_j;
+    if(vsig > a.MaxSignalVel)
+        a.MaxSignalVel = vsig;
+    const double dv0 = me.vx - o.vx, dv1 = me.vy - o.vy, dv2 = me.vz - o.vz;
+    const double vdotr = d0 * dv0 + d1 * dv1 + d2 * dv2;
+    const double vdotr2 = vdotr + C.hubble_a2 * rsq;
+    const double dwk_i = kernel_dwk(kernel_i, C.ktype, r * kernel_i.Hinv);
+    const double dwk_j = kernel_dwk(kernel_j, C.ktype, r * kernel_j.Hinv);
+    double visc = 0;
+    if(vdotr2 < 0) { // Gadget-2 eqs. 13-14, hydra.c:435-462
+        const double mu_ij = C.fac_mu * vdotr2 / r;
+        const double rho_ij = 0.5 * (t.IDensity + o.density);
+        double vs = t.soundspeed_i + soundspeed_j;
+        vs -= 3 * mu_ij;
+        if(vs > a.MaxSignalVel)
+            a.MaxSignalVel = vs;
+        visc = 0.25 * HP.ArtBulkViscConst * vs * (-mu_ij) / rho_ij * (t.IF1 + o.f2);
+        const double dloga = 2 * fmax(me.dloga, o.dloga);
+        if(dloga > 0 && (dwk_i + dwk_j) < 0) {
+            if((t.IMass + s.m) > 0)
+                visc = fmin(visc, 0.5 * C.fac_vsic_fix * vdotr2 / (0.5 * (t.IMass + s.m) * (dwk_i + dwk_j) * r * dloga));
         }
     }
-    for(int off = 32; off > 0; off >>= 1) {
-        n_cand += __shfl_down(n_cand, off);
-        n_pair += __shfl_down(n_pair, off);
+    const double hfc_visc = 0.5 * s.m * visc * (dwk_i + dwk_j) / r;
+    double hfc = hfc_visc;
+    double rr1 = 1, rr2 = 1;
+    if(HP.DensityIndependentSphOn) {
+        rr1 = 0, rr2 = 0;
+        hfc += s.m * (dwk_i * t.p_over_rho2_i * o.entvarpred / me.entvarpred + dwk_j * p_over_rho2_j * me.entvarpred / o.entvarpred) / r;
+        if(HP.DensityContrastLimit >= 0) {
+            rr1 = t.IEgyRho / t.IDensity;
+            rr2 = o.eomdensity / o.density;
+            if(HP.DensityContrastLimit > 0) {
+                rr1 = fmin(rr1, HP.DensityContrastLimit);
+                rr2 = fmin(rr2, HP.DensityContrastLimit);
+            }
+        }
     }
-    if((threadIdx.x & 63) == 0 && stats) {
-        atomicAdd(&stats[0], n_cand);
-        atomicAdd(&stats[1], n_pair);
+    hfc += s.m * (t.p_over_rho2_i * me.dhsml * dwk_i * rr1 + p_over_rho2_j * o.dhsml * dwk_j * rr2) / r;
+    a.Acc0 += -hfc * d0;
+    a.Acc1 += -hfc * d1;
+    a.Acc2 += -hfc * d2;
+    a.DtEntropy += 0.5 * hfc_visc * vdotr2;
+}
+
+// hydro_force loop: group-cooperative walk with the symmetric cull (see k_density)
+__global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_hydro_params HP,
+                                               const HydroCtl C, const HydroSrc *__restrict__ hs, const int *__restrict__ slot_of,
+                                               const int *__restrict__ targets, int64_t ntargets, unsigned long long *__restrict__ stats,
+                                               unsigned *__restrict__ err)
+{
+    __shared__ unsigned s_stack[4 * 8 * SPH_STK];
+    __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
+    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
+    int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
+    int cnt = 0; // survivors waiting in cbuf (group-uniform)
+    const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
+    const bool valid = q < ntargets; // the queue holds gas particles only (hydro_haswork)
+    unsigned n_cand = 0, n_pair = 0;
+    int i = 0;
+    HydroTarget t{};
+    t.me.hsml = 1.0;
+    if(valid) {
+        i = targets[q];
+        t.me = hs[slot_of[i]];
+        t.px = A.pos[3 * (int64_t)i];
+        t.py = A.pos[3 * (int64_t)i + 1];
+        t.pz = A.pos[3 * (int64_t)i + 2];
+        // hydro_copy, hydra.c:247-277
+        t.IMass = (double)A.mass[i];
+        t.IDensity = A.density[i];
+        t.IEgyRho = A.egywtdensity ? A.egywtdensity[i] : 0.0;
+        const double eomdensity_i = HP.DensityIndependentSphOn ? t.IEgyRho : t.IDensity;
+        // the target's own pressure: PressurePred[PI] = predicted from the drifted EOM density (hydra.c:206-212)
+        const double IPressure = t.me.pressure;
+        const double soundspeed_c = sqrt(SPH_GAMMA * IPressure / eomdensity_i);
+        t.IF1 = fabs(A.divvel[i]) / (fabs(A.divvel[i]) + A.curlvel[i] + 0.0001 * soundspeed_c / t.me.hsml / C.fac_mu);
+        if(HP.DensityIndependentSphOn) {
+            t.soundspeed_i = sqrt(SPH_GAMMA * IPressure / t.IEgyRho);
+            t.p_over_rho2_i = IPressure / (t.IEgyRho * t.IEgyRho);
+        }
+        else {
+            t.soundspeed_i = sqrt(SPH_GAMMA * IPressure / t.IDensity);
+            t.p_over_rho2_i = IPressure / (t.IDensity * t.IDensity);
+        }
+    }
+    const DKernel kernel_i = kernel_init(t.me.hsml, C.ktype);
+    HydroAcc a;
+    a.MaxSignalVel = t.soundspeed_i;
+    int sp = 0;
+    if(valid) {
+        if(s == 0)
+            stack[0] = (0u << 4) | 1u; // the root
+        sp = 1;
+    }
+    bool overflow = false;
+    for(;;) {
+        if(__ballot(sp > 0) == 0)
+            break;
+        int lps, lpc;
+        unsigned rem = walk_step<true>(tv, stack, sp, sp > 0, s, gshift, t.me.hsml, t.px, t.py, t.pz, lps, lpc, overflow);
+        if(__ballot(overflow) != 0)
+            break;
+        while(__ballot(rem != 0) != 0) {
+            const int b = rem ? (__ffs(rem) - 1) : 0;
+            const int ps = __shfl(lps, gshift + b), pc = __shfl(lpc, gshift + b);
+            bool keep = false;
+            if(rem != 0 && s < pc) {
+                n_cand++;
+                keep = hydro_test(tv.src[ps + s], hs[ps + s].hsml, t, kernel_i, C, tv.box);
+                n_pair += keep ? 1u : 0u;
+            }
+            cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
+            rem &= rem - 1;
+            if(__ballot(cnt >= 16) != 0) {
+                if(cnt >= 8) {
+                    const int sidx = cbuf[s];
+                    hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
+                    cnt = cbuf_pop8(cbuf, cnt, s);
+                }
+            }
+        }
+    }
+    if(__ballot(overflow) != 0) {
+        if(lane == 0)
+            atomicExch(err, 1u);
+        return;
+    }
+    while(__ballot(cnt > 0) != 0) { // drain the survivor buffers
+        if(s < cnt) {
+            const int sidx = cbuf[s];
+            hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
+        }
+        cnt = cnt > 8 ? cbuf_pop8(cbuf, cnt, s) : 0;
+    }
+    a.Acc0 = group_sum(a.Acc0);
+    a.Acc1 = group_sum(a.Acc1);
+    a.Acc2 = group_sum(a.Acc2);
+    a.DtEntropy = group_sum(a.DtEntropy);
+    for(int off = 1; off < 8; off <<= 1)
+        a.MaxSignalVel = fmax(a.MaxSignalVel, __shfl_xor(a.MaxSignalVel, off));
+    if(valid && s == 0) {
+        // hydro_reduce (assign) + hydro_postprocess, hydra.c:279-294, 514-528
+        A.hydroacc_out[3 * (int64_t)i] = a.Acc0;
+        A.hydroacc_out[3 * (int64_t)i + 1] = a.Acc1;
+        A.hydroacc_out[3 * (int64_t)i + 2] = a.Acc2;
+        A.maxsignalvel[i] = a.MaxSignalVel;
+        A.dtentropy_out[i] = a.DtEntropy * (SPH_GAMMA_MINUS1 / (C.hubble_a2 * pow(t.IDensity, SPH_GAMMA_MINUS1)));
+    }
+    unsigned long long c_cand = n_cand, c_pair = n_pair;
+    for(int off = 32; off > 0; off >>= 1) {
+        c_cand += __shfl_down(c_cand, off);
+        c_pair += __shfl_down(c_pair, off);
+    }
+    if(lane == 0 && stats) {
+        atomicAdd(&stats[0], c_cand);
+        atomicAdd(&stats[1], c_pair);
     }
 }
 
@@ -630,6 +893,7 @@ double sph_desnumngb(const mpg_density_params &P)
 void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times &T, const mpg_density_params &P, double force_softening,
                         const int *d_active, int64_t nactive, int64_t n, int update_hsml, int DoEgyDensity, int BlackHoleOn, hipStream_t st)
 {
+    tree.ensure_level_order(st); // the cooperative walk uses the level-ordered copy of the tree
     const TreeView tv = tree.view();
     MPG_CHECK(tv.npart > 0 || n == 0, "density: the tree holds no gas particles");
     const int64_t nact = d_active ? nactive : n;
@@ -637,8 +901,8 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
     right.reserve(n + 1);
     numngb.reserve(n + 1);
     entvarpred.reserve(n + 1);
-    queue_a.reserve(nact + 1);
-    queue_b.reserve(nact + 1);
+    queue_a.reserve(tv.npart + 1);
+    queue_b.reserve(tv.npart + 1);
     aux.reserve(tv.npart + 1);
     ctr.reserve(8);
     stats.reserve(8);
@@ -657,8 +921,10 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
     MPG_HIP(hipMemsetAsync(stats.p, 0, 8 * sizeof(unsigned long long), st));
     if(tv.npart > 0)
         hipLaunchKernelGGL(k_sph_predict, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, A, T, aux.p, entvarpred.p);
-    if(nact > 0)
-        hipLaunchKernelGGL(k_density_init, dim3(nblk(nact)), dim3(256), 0, st, nact, d_active, A, C, tv.box, queue_a.p, ctr.p);
+    const uint8_t *flags = mark_active(d_active, nact, n, st);
+    if(tv.npart > 0 && nact > 0)
+        hipLaunchKernelGGL(k_queue_treeorder<true>, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, flags, A, C, tv.box, false,
+                           queue_a.p, ctr.p);
     unsigned nq = 0;
     MPG_HIP(hipMemcpyAsync(&nq, ctr.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipStreamSynchronize(st));
@@ -669,14 +935,16 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
         last_iterations++;
         last_targets += nq;
         MPG_HIP(hipMemsetAsync(ctr.p + 1, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(k_density, dim3(nblk(nq)), dim3(256), 0, st, tv, A, T, P, C, aux.p, qa, (int64_t)nq, qb, ctr.p + 1, stats.p);
+        hipLaunchKernelGGL(k_density, dim3(nblk(nq, 32)), dim3(256), 0, st, tv, A, T, P, C, aux.p, qa, (int64_t)nq, qb, ctr.p + 1, stats.p,
+                           ctr.p + 7);
         MPG_HIP(hipGetLastError());
         if(!update_hsml)
             break;
-        unsigned nr = 0;
-        MPG_HIP(hipMemcpyAsync(&nr, ctr.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        unsigned nr[7] = {0, 0, 0, 0, 0, 0, 0};
+        MPG_HIP(hipMemcpyAsync(nr, ctr.p + 1, sizeof(nr), hipMemcpyDeviceToHost, st));
         MPG_HIP(hipStreamSynchronize(st));
-        nq = nr;
+        MPG_CHECK(nr[6] == 0, "density: neighbour-search stack overflow (tree deeper than the walk supports)");
+        nq = nr[0];
         int *t = qa;
         qa = qb;
         qb = t;
@@ -690,10 +958,24 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
         hmax_pending = true;
     }
     unsigned long long hs[2] = {0, 0};
+    unsigned e = 0;
     MPG_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipMemcpyAsync(&e, ctr.p + 7, sizeof(e), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipStreamSynchronize(st));
+    MPG_CHECK(e == 0, "density: neighbour-search stack overflow (tree deeper than the walk supports)");
     last_interactions = (int64_t)hs[0];
     last_candidates = (int64_t)hs[1];
+}
+
+const uint8_t *SphEngine::mark_active(const int *d_active, int64_t nactive, int64_t n, hipStream_t st)
+{
+    if(!d_active)
+        return nullptr;
+    active_flags.reserve(n + 1);
+    MPG_HIP(hipMemsetAsync(active_flags.p, 0, (size_t)n, st));
+    if(nactive > 0)
+        hipLaunchKernelGGL(k_mark_active, dim3(nblk(nactive)), dim3(256), 0, st, nactive, d_active, active_flags.p);
+    return active_flags.p;
 }
 
 void SphEngine::set_init_hsml(TreeBuilder &tree, const SphView &A, const mpg_density_params &P, double MeanGasSeparation, hipStream_t st)
@@ -715,8 +997,9 @@ void SphEngine::calc_hmax(TreeBuilder &tree, hipStream_t st)
 void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_times &T, const mpg_density_params &P, const mpg_hydro_params &HP,
                             const int *d_active, int64_t nactive, int64_t n, hipStream_t st)
 {
+    tree.ensure_level_order(st);
     const TreeView tv = tree.view();
-    MPG_CHECK(tree.has_hmax && tv.hmax, "Hydro called before hmax computed"); // hydra.c:172-173
+    MPG_CHECK(tree.has_hmax && tv.hmax && tv.hmaxB, "Hydro called before hmax computed"); // hydra.c:172-173
     MPG_CHECK(entvarpred.p != nullptr, "hydro_force needs the predicted entropies of density()");
     hsrc.reserve(tv.npart + 1);
     slot_of.reserve(n + 1);
@@ -732,13 +1015,28 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
         hipLaunchKernelGGL(k_slot_of, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, slot_of.p);
         hipLaunchKernelGGL(k_hydro_prepare, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, A, T, HP, entvarpred.p, C.fac_mu, hsrc.p);
     }
-    const int64_t nt = d_active ? nactive : tv.npart;
+    // work queue: the active gas particles in tree order
+    queue_a.reserve(tv.npart + 1);
+    ctr.reserve(8);
+    MPG_HIP(hipMemsetAsync(ctr.p, 0, 8 * sizeof(unsigned), st));
+    const uint8_t *flags = mark_active(d_active, nactive, n, st);
+    unsigned nt = 0;
+    if(tv.npart > 0 && (!d_active || nactive > 0)) {
+        hipLaunchKernelGGL(k_queue_treeorder<false>, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, flags, A, DensityCtl{}, tv.box, true,
+                           queue_a.p, ctr.p);
+        MPG_HIP(hipMemcpyAsync(&nt, ctr.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipStreamSynchronize(st));
+    }
     if(nt > 0)
-        hipLaunchKernelGGL(k_hydro, dim3(nblk(nt)), dim3(256), 0, st, tv, A, T, HP, C, hsrc.p, slot_of.p, d_active, nt, stats.p);
+        hipLaunchKernelGGL(k_hydro, dim3(nblk(nt, 32)), dim3(256), 0, st, tv, A, T, HP, C, hsrc.p, slot_of.p, queue_a.p, (int64_t)nt, stats.p,
+                           ctr.p + 7);
     MPG_HIP(hipGetLastError());
     unsigned long long hs[2] = {0, 0};
+    unsigned e = 0;
     MPG_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipMemcpyAsync(&e, ctr.p + 7, sizeof(e), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipStreamSynchronize(st));
+    MPG_CHECK(e == 0, "hydro_force: neighbour-search stack overflow (tree deeper than the walk supports)");
     last_candidates = (int64_t)hs[0];
     last_interactions = (int64_t)hs[1];
 }

@@ -392,6 +392,14 @@ __global__ void __launch_bounds__(256) k_build_level_order(int64_t nnodes, int64
         hmaxB[i] = hmax ? hmax[j] : 0.0;
 }
 
+__global__ void __launch_bounds__(256) k_permute_hmax(int64_t nnodes, const uint32_t *__restrict__ dfs_of_bfs, const double *__restrict__ hmax,
+                                                      double *__restrict__ hmaxB)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < nnodes)
+        hmaxB[i] = hmax[dfs_of_bfs[i]];
+}
+
 static inline int nblk(int64_t n, int b = 256) { return (int)((n + b - 1) / b); }
 
 void TreeBuilder::ensure_level_order(hipStream_t st)
@@ -550,6 +558,10 @@ void TreeBuilder::calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st
     else
         MPG_HIP(hipMemsetAsync(hmax.p, 0, sizeof(double), st));
     has_hmax = true;
+    if(has_bfs) { // keep the level-ordered copy in step
+        hmaxB.reserve(nnodes + 16);
+        hipLaunchKernelGGL(k_permute_hmax, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, nid_b.p, hmax.p, hmaxB.p);
+    }
 }
 
 TreeView TreeBuilder::view() const
