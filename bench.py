@@ -283,11 +283,44 @@ def hydro_bench(pkg, torch, args, dev):
         step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # ---- untimed diagnostic pass: per-phase times (events on the engine's stream) and the SPH kernels against SURVEY 8(d)'s bytes
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+    ev[0].record()
+    eng.dev_gravpm_force(gravpm, pot)
+    eng.dev_force_tree_build()
+    eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+    ev[1].record()
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    ev[2].record()
+    eng.dev_density(a, t)
+    sd = eng.sph_stats()
+    ev[3].record()
+    eng.dev_force_tree_calc_hmax()
+    ev[4].record()
+    eng.dev_hydro_force(a, t)
+    sh = eng.sph_stats()
+    ev[5].record()
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    ngas = n ** 3
+    b_dens = sd["targets"] * 128 + sd["candidates"] * 28 + sd["interactions"] * 32
+    b_hyd = ngas * 176 + sh["candidates"] * 36 + sh["interactions"] * 100
+
+    def roof(kernel, b, t_ms, note):
+        ach = b / (t_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": b, "avg_launch_ms": t_ms, "note": note}
     out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "2x%d^3 DM+gas TreePM + density-entropy SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, nmesh),
-                      "particles": N, "density_iterations": iters[-args.steps:]}}
+                      "particles": N, "density_iterations": iters[-args.steps:]},
+           "roofline": roof("k_density", b_dens, ms[2], "one density pass incl. queue set-up and predictions; B_dens = N_tgt*128 + N_cand*28 + "
+                            "N_ngb*32 (SURVEY 8(d)): %d targets, %d candidates, %d neighbours" % (sd["targets"], sd["candidates"], sd["interactions"])),
+           "roofline_hydro": roof("k_hydro", b_hyd, ms[4], "B_hyd = N_tgt*176 + N_cand*36 + N_pair*100: %d candidates, %d pairs"
+                                  % (sh["candidates"], sh["interactions"])),
+           "phases_ms": {"gravity_pm_tree_walk": round(ms[0], 3), "gas_tree": round(ms[1], 3), "density": round(ms[2], 3),
+                         "hmax": round(ms[3], 3), "hydro": round(ms[4], 3)}}
     print(json.dumps(out), flush=True)
     eng.close()
     return out

@@ -284,6 +284,9 @@ int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int
  *   list capacity (kernels 4, 6) interaction-list entries per target (default 512): kernel 4 drains its lists when they are
  *             full; kernel 6 hands targets with longer lists to kernel 1 and doubles its capacity when > 2 % of them do */
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
+/* kernel 6: overlap != 0 builds the lists of slice k+1 on a second stream while slice k is evaluated (default on);
+ * chunks_per_wave = 0 uses persistent grids, > 0 that many 8-target chunks per wave (default 2) */
+int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave);
 int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
 int mpg_set_walk_variant(mpg_engine *eng, int variant);
 /* kernel in use (the explicit variant, or the auto-tuner's pick; 0 = not tuned yet), kernel 6's current list capacity and

@@ -1058,6 +1058,15 @@ int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count)
 const int *mpg_dev_tree_order(mpg_engine *eng) { return (eng && eng->tree_allocated) ? (const int *)eng->tree.idx_b.p : nullptr; }
 
 /* tuning knob used by bench/tests: minimum number of walking lanes that keeps the node phase going */
+int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave)
+{
+    API_BEGIN
+    MPG_CHECK(eng && chunks_per_wave >= 0 && chunks_per_wave <= 1024, "bad argument");
+    eng->w3.split_overlap = overlap != 0;
+    eng->w3.split_chunks_per_wave = chunks_per_wave;
+    API_END
+}
+
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh)
 {
     API_BEGIN

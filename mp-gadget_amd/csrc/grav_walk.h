@@ -37,6 +37,10 @@ struct WalkScratch {
     int split_slice = 1 << 21;    // most targets per list-construction / evaluation kernel pair
     size_t split_bytes = 4ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes
     unsigned split_last_overflow = 0, split_last_maxlen = 0;
+    bool split_overlap = true;        // build the lists of slice k+1 (second stream) while slice k is evaluated
+    int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)
+    hipStream_t split_stream = nullptr;
+    hipEvent_t ev_lists[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_begin = nullptr;
 };
 // fastwrap: the minimum-image wrap may be hoisted out of the pair loop (decided by the caller from Rcut, Box, leaf sizes)
 void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap,

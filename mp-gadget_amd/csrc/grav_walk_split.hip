@@ -27,6 +27,7 @@
 // surface layer Rcut thick) evaluate with plain differences, which is bit-identical to NEAREST() there; the others take
 // NEAREST() per pair as partmanager.h:99 does.
 #include "grav_walk.h"
+#include <cstdlib>
 
 namespace mpg {
 
@@ -489,23 +490,31 @@ __global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeVi
     }
 }
 
-int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks)
+// Grid of a kernel over `nchunks` chunks of 8 targets.  chunks_per_wave == 0: persistent (one block per resident slot, every wave
+// loops over many chunks); otherwise every wave takes about that many chunks, so that blocks of the list-construction kernel
+// of one slice and of the evaluation kernel of the previous slice, launched on two streams, share the CUs.
+int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_per_wave)
 {
     if(ws.num_cu == 0) {
         int dev = 0;
         MPG_HIP(hipGetDevice(&dev));
         MPG_HIP(hipDeviceGetAttribute(&ws.num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    int occ = 0;
-    MPG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
-    if(occ < 1)
-        occ = 1;
-    if(occ > 8)
-        occ = 8;
-    int64_t nblocks = (int64_t)ws.num_cu * occ;
     const int64_t need = (nchunks + 3) / 4;
-    if(nblocks > need)
-        nblocks = need;
+    int64_t nblocks;
+    if(chunks_per_wave > 0)
+        nblocks = (need + chunks_per_wave - 1) / chunks_per_wave;
+    else {
+        int occ = 0;
+        MPG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0));
+        if(occ < 1)
+            occ = 1;
+        if(occ > 8)
+            occ = 8;
+        nblocks = (int64_t)ws.num_cu * occ;
+        if(nblocks > need)
+            nblocks = need;
+    }
     return (int)((nblocks + 7) / 8 * 8);
 }
 
@@ -521,17 +530,48 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         slice = 65536;
     if(slice > ws.split_slice)
         slice = ws.split_slice;
+    if(const char *e = getenv("MPG_SPLIT_SLICE")) // experiment knob
+        slice = atoll(e);
     const int64_t nmax = io.ntargets < slice ? io.ntargets : slice;
-    ws.split_lists.reserve((size_t)((nmax + 7) / 8) * 8 * (size_t)cap);
-    ws.split_counts.reserve((size_t)nmax + 8);
+    const int64_t nslices = (io.ntargets + slice - 1) / slice;
+    const bool overlap = ws.split_overlap && nslices > 1;
+    const size_t lists_sz = (size_t)((nmax + 7) / 8) * 8 * (size_t)cap, counts_sz = (size_t)nmax + 8;
+    ws.split_lists.reserve(lists_sz * (overlap ? 2 : 1));
+    ws.split_counts.reserve(counts_sz * (overlap ? 2 : 1));
     ws.split_ovf.reserve((size_t)io.ntargets);
-    for(int64_t s0 = 0; s0 < io.ntargets; s0 += slice) {
+    if(overlap && !ws.split_stream) {
+        MPG_HIP(hipStreamCreateWithFlags(&ws.split_stream, hipStreamNonBlocking));
+        for(int k = 0; k < 2; k++) {
+            MPG_HIP(hipEventCreateWithFlags(&ws.ev_lists[k], hipEventDisableTiming));
+            MPG_HIP(hipEventCreateWithFlags(&ws.ev_eval[k], hipEventDisableTiming));
+        }
+        MPG_HIP(hipEventCreateWithFlags(&ws.ev_begin, hipEventDisableTiming));
+    }
+    const int cpw = ws.split_chunks_per_wave;
+    hipStream_t sl = overlap ? ws.split_stream : st; // list construction runs one slice ahead of the evaluation
+    if(overlap) {
+        MPG_HIP(hipEventRecord(ws.ev_begin, st)); // tree, counters and the control words are ready
+        MPG_HIP(hipStreamWaitEvent(sl, ws.ev_begin, 0));
+    }
+    int64_t i = 0;
+    for(int64_t s0 = 0; s0 < io.ntargets; s0 += slice, i++) {
         const int64_t ns = (io.ntargets - s0 < slice) ? io.ntargets - s0 : slice;
         const int64_t nchunks = (ns + 7) / 8;
-        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks)), dim3(256), 0, st, tv, gp, io, ws.split_lists.p,
-                           ws.split_counts.p, cap, s0, ns, ws.ctr.p, ws.split_ovf.p);
-        hipLaunchKernelGGL(ke, dim3((unsigned)grid_blocks(ws, (const void *)ke, nchunks)), dim3(256), 0, st, tv, gp, io, ws.split_lists.p,
-                           ws.split_counts.p, cap, s0, ns);
+        const int b = overlap ? (int)(i & 1) : 0;
+        unsigned *lists = ws.split_lists.p + (size_t)b * lists_sz;
+        int2 *counts = ws.split_counts.p + (size_t)b * counts_sz;
+        if(overlap && i >= 2)
+            MPG_HIP(hipStreamWaitEvent(sl, ws.ev_eval[b], 0)); // the evaluation that read this buffer two slices ago is done
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks, cpw)), dim3(256), 0, sl, tv, gp, io, lists, counts, cap, s0,
+                           ns, ws.ctr.p, ws.split_ovf.p);
+        if(overlap) {
+            MPG_HIP(hipEventRecord(ws.ev_lists[b], sl));
+            MPG_HIP(hipStreamWaitEvent(st, ws.ev_lists[b], 0));
+        }
+        hipLaunchKernelGGL(ke, dim3((unsigned)grid_blocks(ws, (const void *)ke, nchunks, cpw)), dim3(256), 0, st, tv, gp, io, lists, counts, cap, s0,
+                           ns);
+        if(overlap)
+            MPG_HIP(hipEventRecord(ws.ev_eval[b], st));
     }
     MPG_HIP(hipGetLastError());
 }

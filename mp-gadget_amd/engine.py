@@ -200,6 +200,9 @@ class Engine:
     def set_walk_list_capacity(self, cap):
         self._ck(self.lib.mpg_set_walk_list_capacity(self.h, int(cap)))
 
+    def set_walk_split_mode(self, overlap=True, chunks_per_wave=2):
+        self._ck(self.lib.mpg_set_walk_split_mode(self.h, int(bool(overlap)), int(chunks_per_wave)))
+
     def set_walk_threshold(self, thresh):
         self._ck(self.lib.mpg_set_walk_threshold(self.h, int(thresh)))
 

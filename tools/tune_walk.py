@@ -20,6 +20,9 @@ eng.dev_bind_particles(dpos, dmass, box)
 gpm = torch.zeros(N, 3, dtype=torch.float64, device="cuda"); acc = torch.zeros_like(gpm); pot = torch.zeros(N, dtype=torch.float64, device="cuda")
 eng.dev_gravpm_force(gpm, pot)
 eng.dev_force_tree_build()
+if 'MPG_SPLIT_MODE' in os.environ:
+    ov, cpw = os.environ['MPG_SPLIT_MODE'].split(',')
+    eng.set_walk_split_mode(int(ov), int(cpw))
 eng.set_walk_variant(1); eng.set_walk_threshold(16)
 eng.dev_grav_short_tree(acc, prev_accel=torch.zeros_like(acc), gravpm=gpm, potential=pot)   # BH-free first pass gives OldAcc
 prev = acc.clone()
