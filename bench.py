@@ -145,6 +145,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()          # set-up, not a step: first-use allocations, FFT plans, the walk auto-tuner's trial runs (engine.hip)
     for _ in range(args.warmup):
         step()
     sync()
