@@ -15,10 +15,63 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
 
 using namespace mpg;
 
 static thread_local std::string g_err;
+
+
+// ---- host-side staging helpers of the AoS (host pointer) path -------------------------------------------------------------
+// Pinned, growable host buffer: transfers from / to pageable std::vector memory run at a fraction of the PCIe rate.
+template <typename T> struct HostBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n)
+    {
+        if(n <= cap)
+            return;
+        release();
+        const size_t want = n + n / 16 + 64;
+        MPG_HIP(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+    }
+    void release()
+    {
+        if(p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~HostBuf() { release(); }
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+};
+
+// f(lo, hi) over [0, n) on up to 32 host threads: packing 160-byte records into arrays (and back) is memory-bound and one
+// thread moves ~2 GB/s of them; the reference's callers have the cores of the rank idle while the GPU works anyway.
+template <class F> static void parallel_for(int64_t n, F f)
+{
+    unsigned T = std::thread::hardware_concurrency();
+    if(T > 32)
+        T = 32;
+    if(T < 2 || n < 131072) {
+        f((int64_t)0, n);
+        return;
+    }
+    const int64_t chunk = (n + T - 1) / T;
+    std::vector<std::thread> th;
+    th.reserve(T);
+    for(unsigned t = 0; t < T; t++) {
+        const int64_t lo = (int64_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if(lo >= hi)
+            break;
+        th.emplace_back([=] { f(lo, hi); });
+    }
+    for(auto &x : th)
+        x.join();
+}
 
 struct mpg_engine {
     int device = 0;
@@ -68,9 +121,9 @@ struct mpg_engine {
     DevBuf<float> s_mass;
     DevBuf<uint8_t> s_type;
     DevBuf<int> s_active;
-    std::vector<double> h_d;
-    std::vector<float> h_f;
-    std::vector<uint8_t> h_b;
+    HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
+    HostBuf<float> h_f;
+    HostBuf<uint8_t> h_b;
 };
 
 #define API_BEGIN try {
@@ -495,32 +548,38 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
     MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
     MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
     const int64_t n = P->n;
-    eng->h_d.resize(3 * (size_t)n + 1);
-    eng->h_f.resize((size_t)n + 1);
-    eng->h_b.resize((size_t)n + 1);
+    eng->h_d.reserve(3 * (size_t)n + 1);
+    eng->h_f.reserve((size_t)n + 1);
+    eng->h_b.reserve((size_t)n + 1);
     const char *b = (const char *)P->base;
-    for(int64_t i = 0; i < n; i++) {
-        const char *rec = b + i * P->stride;
-        const double *pp = (const double *)(rec + P->off_pos);
-        eng->h_d[3 * i + 0] = pp[0];
-        eng->h_d[3 * i + 1] = pp[1];
-        eng->h_d[3 * i + 2] = pp[2];
-        eng->h_f[i] = *(const float *)(rec + P->off_mass);
-        uint8_t ty = P->off_type >= 0 ? (*(const uint8_t *)(rec + P->off_type) & 7) : 1;
-        // garbage / swallowed-BH particles never enter the tree (forcetree.c:806): give them type 7 (no mask bit)
-        if(P->off_flags >= 0) {
-            const uint8_t fl = *(const uint8_t *)(rec + P->off_flags);
-            if((fl & 1) || ((fl & 2) && ty == 5))
-                ty = 7;
+    double *hd = eng->h_d.p;
+    float *hf = eng->h_f.p;
+    uint8_t *hb = eng->h_b.p;
+    const mpg_particle_view V = *P;
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++) {
+            const char *rec = b + i * V.stride;
+            const double *pp = (const double *)(rec + V.off_pos);
+            hd[3 * i + 0] = pp[0];
+            hd[3 * i + 1] = pp[1];
+            hd[3 * i + 2] = pp[2];
+            hf[i] = *(const float *)(rec + V.off_mass);
+            uint8_t ty = V.off_type >= 0 ? (*(const uint8_t *)(rec + V.off_type) & 7) : 1;
+            // garbage / swallowed-BH particles never enter the tree (forcetree.c:806): give them type 7 (no mask bit)
+            if(V.off_flags >= 0) {
+                const uint8_t fl = *(const uint8_t *)(rec + V.off_flags);
+                if((fl & 1) || ((fl & 2) && ty == 5))
+                    ty = 7;
+            }
+            hb[i] = ty;
         }
-        eng->h_b[i] = ty;
-    }
+    });
     eng->s_pos.reserve(3 * (size_t)n + 1);
     eng->s_mass.reserve((size_t)n + 1);
     eng->s_type.reserve((size_t)n + 1);
-    MPG_HIP(hipMemcpyAsync(eng->s_pos.p, eng->h_d.data(), 3 * n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
-    MPG_HIP(hipMemcpyAsync(eng->s_mass.p, eng->h_f.data(), n * sizeof(float), hipMemcpyHostToDevice, eng->stream));
-    MPG_HIP(hipMemcpyAsync(eng->s_type.p, eng->h_b.data(), n * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(eng->s_pos.p, eng->h_d.p, 3 * n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(eng->s_mass.p, eng->h_f.p, n * sizeof(float), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(eng->s_type.p, eng->h_b.p, n * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
     MPG_HIP(hipStreamSynchronize(eng->stream));
     eng->n = n;
     eng->d_pos = eng->s_pos.p;
@@ -540,30 +599,35 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     const int64_t n = P->n;
     eng->s_gravpm.reserve(3 * (size_t)n + 1);
     const bool wantpot = P->off_potential >= 0;
-    std::vector<double> hp;
+    char *b = (char *)P->base;
+    const mpg_particle_view V = *P;
+    eng->h_d2.reserve(3 * (size_t)n + 1);
+    eng->h_d3.reserve((size_t)n + 1);
+    double *hg = eng->h_d2.p, *hp = eng->h_d3.p;
     if(wantpot) {
         // readout_potential accumulates into P.Potential (gravpm.c:499-501), which is NOT zeroed first
         eng->s_pot.reserve((size_t)n + 1);
-        hp.resize(n);
-        for(int64_t i = 0; i < n; i++)
-            hp[i] = *(const double *)((const char *)P->base + i * P->stride + P->off_potential);
-        MPG_HIP(hipMemcpyAsync(eng->s_pot.p, hp.data(), n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+        parallel_for(n, [=](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++)
+                hp[i] = *(const double *)(b + i * V.stride + V.off_potential);
+        });
+        MPG_HIP(hipMemcpyAsync(eng->s_pot.p, hp, n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     }
     eng->pm.force(n, eng->d_pos, eng->d_mass, nullptr, eng->s_gravpm.p, wantpot ? eng->s_pot.p : nullptr, eng->stream, &eng->timer);
-    std::vector<double> hg(3 * (size_t)n);
-    MPG_HIP(hipMemcpyAsync(hg.data(), eng->s_gravpm.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipMemcpyAsync(hg, eng->s_gravpm.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
     if(wantpot)
-        MPG_HIP(hipMemcpyAsync(hp.data(), eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+        MPG_HIP(hipMemcpyAsync(hp, eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
     MPG_HIP(hipStreamSynchronize(eng->stream));
-    char *b = (char *)P->base;
-    for(int64_t i = 0; i < n; i++) {
-        double *g = (double *)(b + i * P->stride + P->off_gravpm);
-        g[0] = hg[3 * i + 0];
-        g[1] = hg[3 * i + 1];
-        g[2] = hg[3 * i + 2];
-        if(wantpot)
-            *(double *)(b + i * P->stride + P->off_potential) = hp[i];
-    }
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++) {
+            double *g = (double *)(b + i * V.stride + V.off_gravpm);
+            g[0] = hg[3 * i + 0];
+            g[1] = hg[3 * i + 1];
+            g[2] = hg[3 * i + 2];
+            if(wantpot)
+                *(double *)(b + i * V.stride + V.off_potential) = hp[i];
+        }
+    });
     API_END
 }
 
@@ -608,22 +672,26 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     const int64_t n = P->n;
     const char *b = (const char *)P->base;
     // fill: OldAcc = |FullTreeGravAccel + GravPM| / G (grav_short_copy, gravshort.h:82-86)
-    std::vector<double> old(n > 0 ? n : 1);
+    eng->h_d3.reserve((size_t)n + 1);
+    double *old = eng->h_d3.p;
     const double G = eng->pm.G;
-    for(int64_t i = 0; i < n; i++) {
-        const double *a = (const double *)(b + i * P->stride + P->off_accel);
-        const double *g = (const double *)(b + i * P->stride + P->off_gravpm);
-        double s = 0;
-        for(int j = 0; j < 3; j++) {
-            const double ax = a[j] + g[j];
-            s += ax * ax;
+    const mpg_particle_view V = *P;
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++) {
+            const double *a = (const double *)(b + i * V.stride + V.off_accel);
+            const double *g = (const double *)(b + i * V.stride + V.off_gravpm);
+            double s2 = 0;
+            for(int j = 0; j < 3; j++) {
+                const double ax = a[j] + g[j];
+                s2 += ax * ax;
+            }
+            old[i] = sqrt(s2) / G;
         }
-        old[i] = sqrt(s) / G;
-    }
+    });
     eng->s_old.reserve((size_t)n + 1);
     eng->s_accel.reserve(3 * (size_t)n + 1);
     eng->s_pot.reserve((size_t)n + 1);
-    MPG_HIP(hipMemcpyAsync(eng->s_old.p, old.data(), n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(eng->s_old.p, old, n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     const int *d_act = nullptr;
     if(ActiveParticle) {
         eng->s_active.reserve((size_t)NumActiveParticle + 1);
@@ -637,29 +705,32 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                                      wantpot ? eng->s_pot.p : nullptr, rho0);
     if(rc)
         throw Error(g_err);
-    std::vector<double> ha(3 * (size_t)n + 1), hp(n > 0 ? n : 1);
-    MPG_HIP(hipMemcpyAsync(ha.data(), eng->s_accel.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    eng->h_d2.reserve(3 * (size_t)n + 1);
+    double *ha = eng->h_d2.p, *hp = eng->h_d3.p; // (OldAcc has been uploaded: its staging buffer is free again)
+    MPG_HIP(hipMemcpyAsync(ha, eng->s_accel.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
     if(wantpot)
-        MPG_HIP(hipMemcpyAsync(hp.data(), eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+        MPG_HIP(hipMemcpyAsync(hp, eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
     MPG_HIP(hipStreamSynchronize(eng->stream));
     const int64_t nt = ActiveParticle ? NumActiveParticle : n;
     char *wb = (char *)P->base;
-    for(int64_t k = 0; k < nt; k++) {
-        const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
-        if(AccelStore) {
-            AccelStore[i][0] = ha[3 * i + 0];
-            AccelStore[i][1] = ha[3 * i + 1];
-            AccelStore[i][2] = ha[3 * i + 2];
+    parallel_for(nt, [=](int64_t lo, int64_t hi) {
+        for(int64_t k = lo; k < hi; k++) {
+            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            if(AccelStore) {
+                AccelStore[i][0] = ha[3 * i + 0];
+                AccelStore[i][1] = ha[3 * i + 1];
+                AccelStore[i][2] = ha[3 * i + 2];
+            }
+            if(full) { // gravshort.h:54-66
+                double *a = (double *)(wb + i * V.stride + V.off_accel);
+                a[0] = ha[3 * i + 0];
+                a[1] = ha[3 * i + 1];
+                a[2] = ha[3 * i + 2];
+                if(wantpot)
+                    *(double *)(wb + i * V.stride + V.off_potential) = hp[i];
+            }
         }
-        if(full) { // gravshort.h:54-66
-            double *a = (double *)(wb + i * P->stride + P->off_accel);
-            a[0] = ha[3 * i + 0];
-            a[1] = ha[3 * i + 1];
-            a[2] = ha[3 * i + 2];
-            if(wantpot)
-                *(double *)(wb + i * P->stride + P->off_potential) = hp[i];
-        }
-    }
+    });
     API_END
 }
 
