@@ -248,6 +248,18 @@ __device__ __forceinline__ int cbuf_push(int *cbuf, int cnt, const bool keep, co
     return cnt + __popc(gm);
 }
 
+// The walk and the leaf work are separated in time so that the 8 groups of a wave stay in step: phase A walks (walk_step) and
+// only records the opened leaves in a per-group list in LDS; phase B lets every group take its next leaf per iteration.
+// (Interleaving them made every group wait while one group tested the leaves it had just opened.)
+constexpr int SPH_LCAP = 120; // leaf entries per group; phase A pauses when a group may not fit 8 more
+
+__device__ __forceinline__ int llist_push(unsigned *llist, int nl, const unsigned gm_leaf, const int lps, const int lpc, const int s)
+{
+    if(lpc > 0)
+        llist[nl + __popc(gm_leaf & ((1u << s) - 1u))] = ((unsigned)lps << 4) | (unsigned)lpc;
+    return nl + __popc(gm_leaf);
+}
+
 // after the first 8 survivors were evaluated: move the rest to the front
 __device__ __forceinline__ int cbuf_pop8(int *cbuf, int cnt, const int s)
 {
@@ -324,10 +336,12 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
 {
     __shared__ unsigned s_stack[4 * 8 * SPH_STK];
     __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
+    __shared__ unsigned s_llist[4 * 8 * SPH_LCAP];
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
     int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
+    unsigned *llist = s_llist + ((threadIdx.x >> 6) * 8 + grp) * SPH_LCAP;
     int cnt = 0; // survivors waiting in cbuf (group-uniform)
     const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
     const bool valid = q < nqueue;
@@ -362,22 +376,33 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
     }
     bool overflow = false;
     for(;;) {
-        if(__ballot(sp > 0) == 0)
-            break;
-        int lps, lpc;
-        unsigned rem = walk_step<false>(tv, stack, sp, sp > 0, s, gshift, hsml, px, py, pz, lps, lpc, overflow);
+        // ---- phase A: walk; opened leaves go to the group's list
+        int nl = 0;
+        for(;;) {
+            const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
+            if(__ballot(go) == 0)
+                break;
+            int lps, lpc;
+            const unsigned gm = walk_step<false>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, lps, lpc, overflow);
+            nl = llist_push(llist, nl, gm, lps, lpc, s);
+            if(__ballot(overflow) != 0)
+                break;
+        }
         if(__ballot(overflow) != 0)
             break;
-        while(__ballot(rem != 0) != 0) {
-            const int b = rem ? (__ffs(rem) - 1) : 0;
-            const int ps = __shfl(lps, gshift + b), pc = __shfl(lpc, gshift + b);
+        // ---- phase B: every group takes its next leaf; lane s <-> particle s
+        for(int it = 0;; it++) {
+            const bool has = it < nl;
+            if(__ballot(has) == 0)
+                break;
+            const unsigned e = has ? llist[it] : 0u;
+            const int ps = (int)(e >> 4), pc = (int)(e & 15u);
             bool keep = false;
-            if(rem != 0 && s < pc) {
+            if(s < pc) {
                 n_cand++;
                 keep = density_test(tv.src[ps + s], px, py, pz, h2, kern.HH, tv.box, n_int);
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
-            rem &= rem - 1;
             if(__ballot(cnt >= 16) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[s];
@@ -386,6 +411,8 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                 }
             }
         }
+        if(__ballot(sp > 0) == 0)
+            break;
     }
     if(__ballot(overflow) != 0) {
         if(lane == 0)
@@ -758,10 +785,12 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
 {
     __shared__ unsigned s_stack[4 * 8 * SPH_STK];
     __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
+    __shared__ unsigned s_llist[4 * 8 * SPH_LCAP];
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
     int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
+    unsigned *llist = s_llist + ((threadIdx.x >> 6) * 8 + grp) * SPH_LCAP;
     int cnt = 0; // survivors waiting in cbuf (group-uniform)
     const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
     const bool valid = q < ntargets; // the queue holds gas particles only (hydro_haswork)
@@ -804,23 +833,34 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
     }
     bool overflow = false;
     for(;;) {
-        if(__ballot(sp > 0) == 0)
-            break;
-        int lps, lpc;
-        unsigned rem = walk_step<true>(tv, stack, sp, sp > 0, s, gshift, t.me.hsml, t.px, t.py, t.pz, lps, lpc, overflow);
+        // ---- phase A: walk; opened leaves go to the group's list
+        int nl = 0;
+        for(;;) {
+            const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
+            if(__ballot(go) == 0)
+                break;
+            int lps, lpc;
+            const unsigned gm = walk_step<true>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, lps, lpc, overflow);
+            nl = llist_push(llist, nl, gm, lps, lpc, s);
+            if(__ballot(overflow) != 0)
+                break;
+        }
         if(__ballot(overflow) != 0)
             break;
-        while(__ballot(rem != 0) != 0) {
-            const int b = rem ? (__ffs(rem) - 1) : 0;
-            const int ps = __shfl(lps, gshift + b), pc = __shfl(lpc, gshift + b);
+        // ---- phase B: every group takes its next leaf; lane s <-> particle s
+        for(int it = 0;; it++) {
+            const bool has = it < nl;
+            if(__ballot(has) == 0)
+                break;
+            const unsigned e = has ? llist[it] : 0u;
+            const int ps = (int)(e >> 4), pc = (int)(e & 15u);
             bool keep = false;
-            if(rem != 0 && s < pc) {
+            if(s < pc) {
                 n_cand++;
                 keep = hydro_test(tv.src[ps + s], hs[ps + s].hsml, t, kernel_i, C, tv.box);
                 n_pair += keep ? 1u : 0u;
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
-            rem &= rem - 1;
             if(__ballot(cnt >= 16) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[s];
@@ -829,6 +869,8 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
                 }
             }
         }
+        if(__ballot(sp > 0) == 0)
+            break;
     }
     if(__ballot(overflow) != 0) {
         if(lane == 0)
