@@ -185,6 +185,10 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
         bool wrapped = false, overflow = false;
         unsigned c_pp = 0, c_vis = 0, c_used = 0;
         unsigned long long guard = 0;
+        // One step per iteration, written without divergent control flow (the first form, an `act` code set in nested
+        // branches, cost ~25 register moves and three extra exec-mask regions per step): every lane computes the tests for
+        // "its" child (idle lanes recompute the root, a broadcast read), the outcomes are booleans, and only the three kinds
+        // of stores are predicated.
         for(;;) {
             if(sp > 0 && nleaf + nnode + 8 > cap) { // the next step might not fit: hand the target to the fallback kernel
                 overflow = true;
@@ -199,99 +203,83 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
                 return;
             }
             const unsigned range = can ? stack[sp - 1] : 0u;
-            const int first = (int)(range >> 4), nch = (int)(range & 15u);
-            int act = 0; // 0 nothing, 1 leaf opened (list), 2 node used unopened (list), 3 internal node opened (push)
-            unsigned pushval = 0, entry = 0;
+            const int nch = (int)(range & 15u);
+            const bool mine = s < nch; // false for every lane of a group that is not walking
+            const int my = mine ? (int)(range >> 4) + s : 0;
+            const NodeGeo g = tv.geoB[my];
+            const Src4 mom = tv.momB[my];
+            const NodeLinkB lk = tv.linkB[my];
+            // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
+            const double kx = rint((g.cx - px) * gp.invbox);
+            const double ky = rint((g.cy - py) * gp.invbox);
+            const double kz = rint((g.cz - pz) * gp.invbox);
+            double dx, dy, dz, cdx, cdy, cdz;
             bool wr = false;
-            if(can && s < nch) {
-                const int my = first + s;
-                const NodeGeo g = tv.geoB[my];
-                const Src4 mom = tv.momB[my];
-                const NodeLinkB lk = tv.linkB[my];
-                // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
-                const double kx = rint((g.cx - px) * gp.invbox);
-                const double ky = rint((g.cy - py) * gp.invbox);
-                const double kz = rint((g.cz - pz) * gp.invbox);
-                double dx, dy, dz, cdx, cdy, cdz;
-                if(FASTWRAP) {
-                    const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
-                    cdx = fabs(g.cx - qx);
-                    cdy = fabs(g.cy - qy);
-                    cdz = fabs(g.cz - qz);
-                    dx = mom.x - qx;
-                    dy = mom.y - qy;
-                    dz = mom.z - qz;
-                    wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
-                    if(g.len * 4.0 > gp.box) {
-                        // top levels only: centre of mass and geometric centre may sit on different periodic
-                        // images; take NEAREST(cofm - pos) exactly as gravshort-tree.c:299-300 does
-                        const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox),
-                                     jz = rint((mom.z - pz) * gp.invbox);
-                        dx = fma(-jx, gp.box, mom.x - px);
-                        dy = fma(-jy, gp.box, mom.y - py);
-                        dz = fma(-jz, gp.box, mom.z - pz);
-                        wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
-                    }
-                }
-                else {
-                    cdx = fabs(fma(-kx, gp.box, g.cx - px));
-                    cdy = fabs(fma(-ky, gp.box, g.cy - py));
-                    cdz = fabs(fma(-kz, gp.box, g.cz - pz));
-                    dx = nearest_img(mom.x - px, gp.box, gp.invbox);
-                    dy = nearest_img(mom.y - py, gp.box, gp.invbox);
-                    dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
-                }
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                // shall_we_discard_node, gravshort-tree.c:198-215
-                const double eff = fma(0.5, g.len, gp.rcut);
-                const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
-                if(!discard) {
-                    // shall_we_open_node, gravshort-tree.c:220-241
-                    const double l2 = g.len * g.len;
-                    const double inside = 0.6 * g.len;
-                    const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) ||
-                                      (cdx < inside && cdy < inside && cdz < inside);
-                    if(!open) {
-                        act = 2; // node used unopened: its moments are a 1-element source
-                        entry = (unsigned)my;
-                    }
-                    else if(lk.pcount > 0) {
-                        act = 1;
-                        entry = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-                    }
-                    else if(lk.nchild > 0) {
-                        act = 3;
-                        pushval = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
-                    }
-                }
-                if(COUNT) {
-                    c_vis++;
-                    if(act == 2)
-                        c_used++;
-                    if(act == 1)
-                        c_pp += lk.pcount;
+            if(FASTWRAP) {
+                const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
+                cdx = fabs(g.cx - qx);
+                cdy = fabs(g.cy - qy);
+                cdz = fabs(g.cz - qz);
+                dx = mom.x - qx;
+                dy = mom.y - qy;
+                dz = mom.z - qz;
+                wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
+                if(g.len * 4.0 > gp.box) {
+                    // top levels only: centre of mass and geometric centre may sit on different periodic
+                    // images; take NEAREST(cofm - pos) exactly as gravshort-tree.c:299-300 does
+                    const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox),
+                                 jz = rint((mom.z - pz) * gp.invbox);
+                    dx = fma(-jx, gp.box, mom.x - px);
+                    dy = fma(-jy, gp.box, mom.y - py);
+                    dz = fma(-jz, gp.box, mom.z - pz);
+                    wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
                 }
             }
-            const unsigned gm_leaf = (unsigned)((__ballot(act == 1) >> gshift) & 0xffull);
-            const unsigned gm_node = (unsigned)((__ballot(act == 2) >> gshift) & 0xffull);
-            const unsigned gm_push = (unsigned)((__ballot(act == 3) >> gshift) & 0xffull);
-            const unsigned gm_wrap = (unsigned)((__ballot(wr && (act == 1 || act == 2)) >> gshift) & 0xffull);
-            if(act == 1) {
+            else {
+                cdx = fabs(fma(-kx, gp.box, g.cx - px));
+                cdy = fabs(fma(-ky, gp.box, g.cy - py));
+                cdz = fabs(fma(-kz, gp.box, g.cz - pz));
+                dx = nearest_img(mom.x - px, gp.box, gp.invbox);
+                dy = nearest_img(mom.y - py, gp.box, gp.invbox);
+                dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
+            }
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            // shall_we_discard_node, gravshort-tree.c:198-215
+            const double eff = fma(0.5, g.len, gp.rcut);
+            const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
+            // shall_we_open_node, gravshort-tree.c:220-241
+            const double l2 = g.len * g.len;
+            const double inside = 0.6 * g.len;
+            const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) ||
+                              (cdx < inside && cdy < inside && cdz < inside);
+            const bool keep = mine && !discard;
+            const bool b_node = keep && !open;                                   // used unopened: a 1-element source
+            const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
+            const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
+            const unsigned gm_leaf = (unsigned)((__ballot(b_leaf) >> gshift) & 0xffull);
+            const unsigned gm_node = (unsigned)((__ballot(b_node) >> gshift) & 0xffull);
+            const unsigned gm_push = (unsigned)((__ballot(b_push) >> gshift) & 0xffull);
+            const unsigned gm_wrap = (unsigned)((__ballot(wr && (b_leaf || b_node)) >> gshift) & 0xffull);
+            if(b_leaf) {
                 const int e = nleaf + __popc(gm_leaf & below);
-                L[((e >> 3) << 6) + (e & 7)] = entry;
+                L[((e >> 3) << 6) + (e & 7)] = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
             }
-            if(act == 2) {
+            if(b_node) {
                 const int e = cap - 1 - (nnode + __popc(gm_node & below));
-                L[((e >> 3) << 6) + (e & 7)] = entry;
+                L[((e >> 3) << 6) + (e & 7)] = (unsigned)my;
             }
-            if(act == 3)
-                stack[sp - 1 + __popc(gm_push & below)] = pushval;
-            if(can) {
-                nleaf += __popc(gm_leaf);
-                nnode += __popc(gm_node);
-                sp += __popc(gm_push) - 1;
-                wrapped = wrapped || (gm_wrap != 0);
-                if(COUNT && s == 0) {
+            if(b_push)
+                stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
+            // (all masks are zero for a group that is not walking)
+            nleaf += __popc(gm_leaf);
+            nnode += __popc(gm_node);
+            sp += __popc(gm_push) - (can ? 1 : 0);
+            wrapped = wrapped || (gm_wrap != 0);
+            if(COUNT) {
+                c_vis += mine ? 1u : 0u;
+                c_used += b_node ? 1u : 0u;
+                c_pp += b_leaf ? (unsigned)lk.pcount : 0u;
+                if(can && s == 0) {
                     st_a++;
                     st_al += nch;
                 }
