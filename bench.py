@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--mgpu", choices=["slab", "replicated"], default="slab", help="N > 1: PM / target decomposition")
-    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro"],
+    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate"],
                     help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
                          "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
     args = ap.parse_args()
@@ -72,6 +72,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "integrate":
+        if world != 1:
+            raise SystemExit("--workload integrate is single-GPU")
+        return integrate_bench(pkg, torch, args, dev)
     if args.workload == "hydro":
         if world != 1:
             raise SystemExit("--workload hydro is single-GPU in this round")
@@ -218,6 +222,63 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    eng.close()
+    return out
+
+
+def integrate_bench(pkg, torch, args, dev):
+    """the streaming loops between force steps on device-resident arrays - apply_PM_half_kick,
+    apply_half_kick (gravity + hydro kick), drift_all_particles - for 2 x n^3 particles (half gas).  One step = the three
+    loops once.  Pure HBM streaming: the roofline is bytes moved / time against the HBM peak."""
+    n = args.n or 256
+    N = 2 * n ** 3
+    g = torch.Generator(device=dev).manual_seed(1)
+    f8 = torch.float64
+    box = 1000.0 * n
+    r3 = lambda s: torch.randn(N, 3, dtype=f8, device=dev, generator=g) * s
+    pos = torch.rand(N, 3, dtype=f8, device=dev, generator=g) * box
+    pos.clamp_(min=1e-9)
+    vel, gpm, gacc, hacc = r3(100.0), r3(1.0), r3(1.0), r3(1.0)
+    typ = torch.cat([torch.zeros(N // 2, dtype=torch.uint8, device=dev), torch.ones(N // 2, dtype=torch.uint8, device=dev)])
+    flags = torch.zeros(N, dtype=torch.uint8, device=dev)
+    tb = torch.randint(0, 4, (N,), dtype=torch.uint8, device=dev, generator=g)
+    hsml = torch.full((N,), box / n, dtype=f8, device=dev)
+    dthsml = torch.zeros(N, dtype=f8, device=dev)
+    ent = torch.ones(N, dtype=f8, device=dev)
+    dte = torch.zeros(N, dtype=f8, device=dev)
+    K = pkg.KickFactors()
+    for b in range(4):
+        K.gravkick[b], K.hydrokick[b], K.dt_entr[b], K.bin_active[b] = 1e-3, 1e-3, 1e-3, 1
+    K.atime, K.MaxGasVel = 0.5, 3e5
+    eng = pkg.Engine(dev.index or 0)
+    eng.use_torch_stream()
+
+    def step():
+        eng.dev_apply_pm_half_kick(vel, gpm, 1e-3, flags=flags)
+        eng.dev_apply_half_kick(vel, gacc, K, type=typ, flags=flags, tb_grav=tb, tb_hydro=tb, hydroaccel=hacc, entropy=ent, dtentropy=dte)
+        eng.dev_drift_all_particles(pos, vel, 1e-3, box, (0.0, 0.0, 0.0), type=typ, flags=flags, hsml=hsml, dthsml=dthsml)
+
+    for _ in range(args.warmup + 1):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # bytes per particle: PM kick 24+24+1 read, 24 written; half kick 24+24+1+1+2 read (+24+16 gas), 24 (+8) written;
+    # drift 24+24+1+1 read (+16 gas), 24 (+8) written
+    b_alg = N * (49 + 24 + 52 + 24 + 50 + 24) + (N // 2) * (40 + 8 + 16 + 8)
+    ach = b_alg * args.steps / el / 1e9
+    out = {"metric": "particle-updates/sec (PM half kick + half kick + drift)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "time integration of 2x%d^3 particles (half gas) on device-resident arrays" % n, "particles": N},
+           "roofline": {"bound": "hbm", "kernel": "k_pm_half_kick + k_half_kick + k_drift", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_alg,
+                        "avg_launch_ms": 1e3 * el / args.steps,
+                        "note": "three launches per step; each call also reads back an error word (one stream synchronisation per call)"}}
+    print(json.dumps(out), flush=True)
     eng.close()
     return out
 

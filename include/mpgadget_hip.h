@@ -252,6 +252,33 @@ int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
 /* Device pointer to the tree-order permutation (int32 [NumParticles]: tree slot -> caller index) of the current tree;
  * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
 const int *mpg_dev_tree_order(mpg_engine *eng);
+/* ---- time integration on device-resident arrays: the streaming loops the reference runs between force
+ * steps.  Arrays are in particle order with n entries; flags[i] is the bit-field byte of struct particle_data (bit 0 IsGarbage,
+ * bit 1 Swallowed; may be NULL).  Results are bit-identical to the reference's loops (no FMA contraction).
+ * Not carried: black-hole repositioning (drift.c:33-55) and the dynamic-friction / drag kicks of type 5 (timestep.c:1003-1010). */
+#define MPG_TIMEBINS 46 /* timebinmgr.h:8 */
+typedef struct {
+    double gravkick[MPG_TIMEBINS + 1];  /* get_exact_gravkick_factor(Ti_kick[bin], Ti_kick[bin] + dti/2); 0 for inactive bins */
+    double hydrokick[MPG_TIMEBINS + 1]; /* get_exact_hydrokick_factor, same interval (timestep.c:878-890) */
+    double dt_entr[MPG_TIMEBINS + 1];   /* dloga_from_dti(dti_from_timebin(bin) / 2, Ti_Current)  (timestep.c:917) */
+    unsigned char bin_active[MPG_TIMEBINS + 1]; /* is_timebin_active(bin, Ti_Current) */
+    double atime, MaxGasVel;            /* TimestepParams.MaxGasVel (timestep.c:1026) */
+} mpg_kick_factors;
+/* drift_all_particles (drift.c:84-102): Pos += Vel * ddrift + random_shift, wrapped into (0, BoxSize]; gas Hsml += DtHsml *
+ * ddrift, capped at BoxSize/2.  Returns non-zero (the reference's endrun(5)) for Hsml <= 0 or a non-finite position.
+ * d_type, d_flags, d_hsml, d_dthsml may be NULL (then no smoothing lengths are drifted). */
+int mpg_dev_drift_all_particles(mpg_engine *eng, int64_t n, double *d_pos, const double *d_vel, const unsigned char *d_type,
+                                const unsigned char *d_flags, double *d_hsml, const double *d_dthsml, double ddrift, double BoxSize,
+                                const double random_shift[3]);
+/* apply_PM_half_kick (timestep.c:964-985): Vel += GravPM * Fgravkick */
+int mpg_dev_apply_pm_half_kick(mpg_engine *eng, int64_t n, double *d_vel, const double *d_gravpm, const unsigned char *d_flags, double Fgravkick);
+/* apply_half_kick (timestep.c:873-929): short-range gravity kick of the particles in active gravity bins and the hydro kick
+ * (velocity, gas velocity limit, entropy) of gas.  d_active == NULL: all n particles.  d_tb_grav / d_tb_hydro NULL: bin 0. */
+int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int64_t nactive, double *d_vel, const double *d_gravaccel,
+                            const unsigned char *d_type, const unsigned char *d_flags, const unsigned char *d_tb_grav,
+                            const unsigned char *d_tb_hydro, const double *d_hydroaccel, double *d_entropy, const double *d_dtentropy,
+                            const mpg_kick_factors *K);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

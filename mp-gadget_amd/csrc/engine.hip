@@ -10,6 +10,7 @@
 #include "mpg_common.h"
 #include "pm.h"
 #include "sph.h"
+#include "timestep.h"
 #include "tree_build.h"
 #include <cmath>
 #include <cstdlib>
@@ -121,6 +122,7 @@ struct mpg_engine {
     DevBuf<float> s_mass;
     DevBuf<uint8_t> s_type;
     DevBuf<int> s_active;
+    DevBuf<unsigned> ts_flag;
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
     HostBuf<uint8_t> h_b;
@@ -538,6 +540,56 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     // TreeUseBH > 1: Barnes-Hut on the first walk only (gravshort-tree.c:148-151)
     if(eng->treepar.TreeUseBH > 1)
         eng->treepar.TreeUseBH = 0;
+    API_END
+}
+
+/* ------------------------------ time integration (device-resident arrays) ------------------------------ */
+static unsigned read_flag(mpg_engine *eng, unsigned *d)
+{
+    unsigned e = 0;
+    MPG_HIP(hipMemcpyAsync(&e, d, sizeof(e), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    return e;
+}
+
+int mpg_dev_drift_all_particles(mpg_engine *eng, int64_t n, double *d_pos, const double *d_vel, const unsigned char *d_type,
+                                const unsigned char *d_flags, double *d_hsml, const double *d_dthsml, double ddrift, double BoxSize,
+                                const double random_shift[3])
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_pos && d_vel && random_shift && n >= 0, "null argument");
+    MPG_CHECK(!d_hsml || (d_dthsml && d_type), "drift: Hsml needs DtHsml and Type");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->ts_flag.reserve(4);
+    MPG_HIP(hipMemsetAsync(eng->ts_flag.p, 0, sizeof(unsigned), eng->stream));
+    launch_drift(n, d_pos, d_vel, d_type, d_flags, d_hsml, d_dthsml, ddrift, BoxSize, random_shift, eng->ts_flag.p, eng->stream);
+    MPG_CHECK(read_flag(eng, eng->ts_flag.p) == 0, "drift: a particle has Hsml <= 0 or a non-finite position (drift.c:62-75)");
+    API_END
+}
+
+int mpg_dev_apply_pm_half_kick(mpg_engine *eng, int64_t n, double *d_vel, const double *d_gravpm, const unsigned char *d_flags, double Fgravkick)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_vel && d_gravpm && n >= 0, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    launch_pm_half_kick(n, d_vel, d_gravpm, d_flags, Fgravkick, eng->stream);
+    API_END
+}
+
+int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int64_t nactive, double *d_vel, const double *d_gravaccel,
+                            const unsigned char *d_type, const unsigned char *d_flags, const unsigned char *d_tb_grav,
+                            const unsigned char *d_tb_hydro, const double *d_hydroaccel, double *d_entropy, const double *d_dtentropy,
+                            const mpg_kick_factors *K)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_vel && d_gravaccel && K && n >= 0, "null argument");
+    MPG_CHECK(!d_type || (d_hydroaccel && d_entropy && d_dtentropy), "half kick: gas needs HydroAccel, Entropy and DtEntropy");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->ts_flag.reserve(4);
+    MPG_HIP(hipMemsetAsync(eng->ts_flag.p, 0, sizeof(unsigned), eng->stream));
+    launch_half_kick(n, d_active, nactive, d_vel, d_gravaccel, d_type, d_flags, d_tb_grav, d_tb_hydro, d_hydroaccel, d_entropy, d_dtentropy, *K,
+                     eng->ts_flag.p, eng->stream);
+    MPG_CHECK(read_flag(eng, eng->ts_flag.p) == 0, "half kick: a particle has an unexpected time bin (timestep.c:900-901)");
     API_END
 }
 

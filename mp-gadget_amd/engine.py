@@ -132,6 +132,15 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+TIMEBINS = 46
+
+
+class KickFactors(C.Structure):
+    """mpg_kick_factors (include/mpgadget_hip.h)"""
+    _fields_ = [("gravkick", C.c_double * (TIMEBINS + 1)), ("hydrokick", C.c_double * (TIMEBINS + 1)), ("dt_entr", C.c_double * (TIMEBINS + 1)),
+                ("bin_active", C.c_ubyte * (TIMEBINS + 1)), ("atime", C.c_double), ("MaxGasVel", C.c_double)]
+
+
 class Engine:
     """One engine per GPU (= per MPI rank in the reference's terms)."""
 
@@ -287,6 +296,21 @@ class Engine:
 
     def dev_gravpm_force(self, gravpm, potential=None):
         self._ck(self.lib.mpg_dev_gravpm_force(self.h, _ptr(gravpm), _ptr(potential)))
+
+    # time integration on device-resident arrays (drift.c / timestep.c loops)
+    def dev_drift_all_particles(self, pos, vel, ddrift, BoxSize, random_shift=(0.0, 0.0, 0.0), type=None, flags=None, hsml=None, dthsml=None):
+        sh = (C.c_double * 3)(*random_shift)
+        self._ck(self.lib.mpg_dev_drift_all_particles(self.h, C.c_int64(pos.shape[0]), _ptr(pos), _ptr(vel), _ptr(type), _ptr(flags),
+                                                      _ptr(hsml), _ptr(dthsml), C.c_double(ddrift), C.c_double(BoxSize), sh))
+
+    def dev_apply_pm_half_kick(self, vel, gravpm, Fgravkick, flags=None):
+        self._ck(self.lib.mpg_dev_apply_pm_half_kick(self.h, C.c_int64(vel.shape[0]), _ptr(vel), _ptr(gravpm), _ptr(flags), C.c_double(Fgravkick)))
+
+    def dev_apply_half_kick(self, vel, gravaccel, K, active=None, type=None, flags=None, tb_grav=None, tb_hydro=None, hydroaccel=None,
+                            entropy=None, dtentropy=None):
+        self._ck(self.lib.mpg_dev_apply_half_kick(self.h, C.c_int64(vel.shape[0]), _ptr(active), C.c_int64(0 if active is None else active.shape[0]),
+                                                  _ptr(vel), _ptr(gravaccel), _ptr(type), _ptr(flags), _ptr(tb_grav), _ptr(tb_hydro),
+                                                  _ptr(hydroaccel), _ptr(entropy), _ptr(dtentropy), C.byref(K)))
 
     # slab-decomposed PM over several GPUs: local stages (the collectives between them are in pm_slab.py)
     def dev_pm_slab_init(self, rank, world):

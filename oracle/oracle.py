@@ -415,3 +415,43 @@ def sph_hydro_force(orc, tree, dp, hp, arrays, times, active=None):
 def sph_set_softening(orc, force_softening):
     _sph_bind(orc.lib)
     orc.lib.os_set_softening(force_softening)
+
+
+# ------------------------------------------------------------------ time integration (oracle/timestep_oracle.c)
+TIMEBINS = 46
+
+
+class KickFactors(C.Structure):
+    """ots_kick_factors"""
+    _fields_ = [("gravkick", C.c_double * (TIMEBINS + 1)), ("hydrokick", C.c_double * (TIMEBINS + 1)), ("dt_entr", C.c_double * (TIMEBINS + 1)),
+                ("bin_active", C.c_ubyte * (TIMEBINS + 1)), ("atime", C.c_double), ("MaxGasVel", C.c_double)]
+
+
+def _u8(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def drift_all_particles(orc, pos, vel, ddrift, box, random_shift=(0., 0., 0.), type=None, flags=None, hsml=None, dthsml=None):
+    """drift.c:84-102 on plain arrays (pos, hsml are updated in place).  Returns the reference's endrun code (0 = ok)."""
+    L = orc.lib
+    L.ots_drift_all_particles.restype = C.c_int
+    L.ots_drift_all_particles.argtypes = [C.c_int64, _dp, _dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                          C.POINTER(C.c_double)]
+    sh = (C.c_double * 3)(*random_shift)
+    return L.ots_drift_all_particles(len(pos), pos, vel, _u8(type), _u8(flags), _u8(hsml), _u8(dthsml), ddrift, box, sh)
+
+
+def apply_pm_half_kick(orc, vel, gravpm, F, flags=None):
+    L = orc.lib
+    L.ots_apply_pm_half_kick.restype = None
+    L.ots_apply_pm_half_kick.argtypes = [C.c_int64, _dp, _dp, C.c_void_p, C.c_double]
+    L.ots_apply_pm_half_kick(len(vel), vel, gravpm, _u8(flags), F)
+
+
+def apply_half_kick(orc, vel, gravaccel, K, active=None, type=None, flags=None, tb_grav=None, tb_hydro=None, hydroaccel=None, entropy=None,
+                    dtentropy=None):
+    L = orc.lib
+    L.ots_apply_half_kick.restype = C.c_int
+    L.ots_apply_half_kick.argtypes = [C.c_int64, C.c_void_p, C.c_int64, _dp, _dp] + [C.c_void_p] * 7 + [C.POINTER(KickFactors)]
+    return L.ots_apply_half_kick(len(vel), _u8(active), 0 if active is None else len(active), vel, gravaccel, _u8(type), _u8(flags),
+                                 _u8(tb_grav), _u8(tb_hydro), _u8(hydroaccel), _u8(entropy), _u8(dtentropy), C.byref(K))
