@@ -44,7 +44,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--mgpu", choices=["slab", "replicated"], default="slab", help="N > 1: PM / target decomposition")
+    ap.add_argument("--mgpu", choices=["domain", "slab", "replicated"], default="domain",
+                    help="N > 1: domain = particles distributed (x-slab domains, ghost import, slab PM); slab = particles replicated, "
+                         "slab PM and slab targets; replicated = everything but the walk targets replicated")
     ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate"],
                     help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
                          "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
@@ -107,7 +109,18 @@ def main():
     # N > 1: "slab" = x-slab PM (two all-to-all transposes per step) with the particles of the slab as
     # PM-readout and walk targets; "replicated" = every rank does the whole PM, targets are contiguous tree-slot ranges
     pm_ms = [0.0, 0]
-    if world > 1 and args.mgpu == "slab":
+    if world > 1 and args.mgpu == "domain":
+        rcut = 6.0 * 1.5 * box / nmesh                       # Rcut * Asmth * cell size (gravshort-tree.c:102)
+        dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut)
+        own = dom.select_own(d_pos)
+        own_pos, own_mass = d_pos[own].contiguous(), d_mass[own].contiguous()
+        n_own = int(own.shape[0])
+        del d_pos, d_mass, own, gravpm, acc, prev, pot      # from here on this rank holds its own particles and their ghosts only
+        torch.cuda.empty_cache()
+        spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        loc = {}                                             # arrays over [own | ghosts], sized on first use
+    elif world > 1 and args.mgpu == "slab":
         spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
         tex = pkg.pm_slab.TargetExchange(world, dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -117,8 +130,31 @@ def main():
         gbuf = torch.zeros(world * chunk, 3, dtype=torch.float64, device=dev)
         sbuf = torch.zeros(chunk, 3, dtype=torch.float64, device=dev)
 
+    def step_domain():
+        lpos, lmass = dom.import_ghosts(own_pos, own_mass)
+        nl = int(lpos.shape[0])
+        if loc.get("n", -1) < nl:
+            z3 = lambda: torch.zeros(int(nl * 1.02) + 1024, 3, dtype=torch.float64, device=dev)
+            loc.update(n=int(nl * 1.02) + 1024, acc=z3(), prev=z3(), gravpm=z3(), pot=torch.zeros(int(nl * 1.02) + 1024, dtype=torch.float64, device=dev))
+        loc["pos"], loc["mass"] = lpos, lmass               # keep the bound arrays alive
+        eng.dev_bind_particles(lpos, lmass, box)
+        eng.dev_force_tree_build()
+        dom.set_global_top(n_own)
+        tg = dom.own_targets(n_own, nl)
+        ev0.record()
+        spm.force(tg, loc["gravpm"], loc["pot"])
+        ev1.record()
+        loc["prev"], loc["acc"] = loc["acc"], loc["prev"]
+        eng.dev_grav_short_tree(loc["acc"], prev_accel=loc["prev"], gravpm=loc["gravpm"], potential=loc["pot"], active=tg)
+        loc["ghost_fraction"] = nl / n_own - 1
+        eng.synchronize()
+        pm_ms[0] += ev0.elapsed_time(ev1)
+        pm_ms[1] += 1
+
     def step():
         nonlocal acc, prev
+        if world > 1 and args.mgpu == "domain":
+            return step_domain()
         if world == 1:
             eng.dev_gravpm_force(gravpm, pot)
             eng.dev_force_tree_build()
@@ -199,7 +235,10 @@ def main():
             "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
                                    "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
                        "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
-                       ("%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
+                       ("%d GPUs: particles distributed in x-slab domains, ghosts imported in whole tree-cell columns within Rcut "
+                        "(one personalised exchange per step), top of the tree from an all-reduce, x-slab PM (2 all-to-all "
+                        "transposes + ghost planes per step); nothing replicated or all-gathered" % world if args.mgpu == "domain" else
+                        "%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
                         "replicated, one all-gather of accelerations" % world if args.mgpu == "slab" else
                         "targets sharded over %d GPUs (tree-order ranges), PM and tree replicated, all-gather of accelerations" % world)},
             "roofline": {"bound": "hbm", "kernel": kernels, "walk_variant": variant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -215,6 +254,8 @@ def main():
         }
         if pm_ms[1]:
             out["phases_ms"]["pm_slab_total_incl_collectives"] = round(pm_ms[0] / pm_ms[1], 3)
+        if world > 1 and args.mgpu == "domain":
+            out["config"]["ghost_fraction_rank0"] = round(loc["ghost_fraction"], 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
                                                args.cpu_sample)

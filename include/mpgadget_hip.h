@@ -296,6 +296,18 @@ int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int
  * Every rank binds the same particle set (mpg_dev_bind_particles); a particle's CIC cloud is deposited by the owners of the
  * planes it touches, so no region exchange is needed.  world == 1 reproduces mpg_dev_gravpm_force to FFT round-off. */
 int mpg_dev_pm_slab_init(mpg_engine *eng, int rank, int world, int64_t *cplx_per_peer, int64_t *plane_doubles);
+
+/* ---- particles distributed over ranks (the reference: Peano-Hilbert domains, a replicated top-tree whose leaves carry the
+ * moments of remote sub-trees, forcetree.c:1106-1290; here: x-slab domains, ghosts imported in whole columns of level-La
+ * cells).  The bound particle set is [own particles | ghosts]; the tree built from it equals the global tree at levels >= La;
+ * the nodes above get their moments from sums over all ranks:
+ *   mpg_dev_tree_top_partial(La, n_own, out)  out[8^(La-1)][4] = (sum m, sum m x, sum m y, sum m z) of the OWN particles
+ *                                             (caller index < n_own) per level-(La-1) cell, cells numbered by octant path
+ *   -> all-reduce over ranks; coarser levels by summing 8 children
+ *   mpg_dev_tree_top_set(La, sums)            sums[(8^La - 1)/7][4]: levels 0 .. La-1 concatenated; sets the moments of
+ *                                             every local node above level La (error if such a node is a leaf) */
+int mpg_dev_tree_top_partial(mpg_engine *eng, int La, int64_t n_own, double *d_out);
+int mpg_dev_tree_top_set(mpg_engine *eng, int La, const double *d_sums);
 int mpg_dev_pm_slab_forward_a(mpg_engine *eng, double *sendA);
 int mpg_dev_pm_slab_forward_b(mpg_engine *eng, double *recvA, double *sendB);
 int mpg_dev_pm_slab_inverse_c(mpg_engine *eng, const double *recvB, double *ghost_send);

@@ -332,6 +332,26 @@ int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential)
     API_END
 }
 
+int mpg_dev_tree_top_partial(mpg_engine *eng, int La, int64_t n_own, double *d_out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_out, "null argument");
+    MPG_CHECK(eng->tree_allocated, "no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->tree.top_partial(La, n_own, d_out, eng->stream);
+    API_END
+}
+
+int mpg_dev_tree_top_set(mpg_engine *eng, int La, const double *d_sums)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_sums, "null argument");
+    MPG_CHECK(eng->tree_allocated, "no tree");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->tree.top_set(La, d_sums, eng->stream);
+    API_END
+}
+
 int mpg_dev_pm_slab_init(mpg_engine *eng, int rank, int world, int64_t *cplx_per_peer, int64_t *plane_doubles)
 {
     API_BEGIN

@@ -84,6 +84,9 @@ struct TreeBuilder {
     void calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st);
     // build / refresh the level-ordered copy from the depth-first arrays (after moments and/or hmax are known)
     void make_level_order(hipStream_t st);
+    // domain-decomposed runs: own-particle sums of the level-(La-1) cells / moments of the nodes above level La from global sums
+    void top_partial(int La, int64_t n_own, double *d_out, hipStream_t st);
+    void top_set(int La, const double *d_sums, hipStream_t st);
     void ensure_level_order(hipStream_t st);
     TreeView view() const;
 };

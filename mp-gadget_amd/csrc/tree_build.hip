@@ -564,6 +564,98 @@ void TreeBuilder::calc_hmax(const double *d_hsml_gasbh_treeorder, hipStream_t st
     }
 }
 
+// ---- domain-decomposed runs: the top of the tree from global sums ------------------------------------
+// With particles distributed over ranks, the local tree holds the rank's own particles plus ghosts in whole columns of
+// level-La cells, so cells at levels >= La are complete and equal to the global tree's; cells above (levels < La) also
+// hold remote particles.  Their moments come from sums over ALL ranks: top_partial() adds (m, m x, m y, m z) of the rank's
+// OWN particles (caller index < n_own) into the cells of level La-1; the caller all-reduces and builds the coarser levels;
+// top_set() writes the moments of every local node above level La from those sums.
+__global__ void __launch_bounds__(256) k_top_partial(int64_t npart, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ order,
+                                                     const Src4 *__restrict__ src, int64_t n_own, int shift, double *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool own = k < npart && (int64_t)order[k] < n_own;
+    const unsigned long long cell = own ? (unsigned long long)(keys[k] >> shift) : ~0ull;
+    Src4 p{0, 0, 0, 0};
+    if(own)
+        p = src[k];
+    double v[4] = {p.m, p.m * p.x, p.m * p.y, p.m * p.z};
+    // sorted keys: the lanes of a wave mostly share one cell -> one atomic per wave and component (same-address atomics
+    // serialise at ~90 per microsecond); mixed waves fall back to per-lane atomics
+    const unsigned long long c0 = __shfl(cell, 0);
+    if(__ballot(cell != c0) == 0) {
+        if(c0 == ~0ull)
+            return;
+#pragma unroll
+        for(int j = 0; j < 4; j++) {
+            double t = v[j];
+            for(int off = 32; off > 0; off >>= 1)
+                t += __shfl_down(t, off);
+            if((threadIdx.x & 63) == 0)
+                unsafeAtomicAdd(&out[4 * c0 + j], t);
+        }
+    }
+    else if(own) {
+#pragma unroll
+        for(int j = 0; j < 4; j++)
+            unsafeAtomicAdd(&out[4 * cell + j], v[j]);
+    }
+}
+
+// sums[]: levels 0 .. La-1 concatenated (level l starts at (8^l - 1) / 7 cells), 4 doubles per cell
+__global__ void __launch_bounds__(256) k_top_set(int64_t nnodes, int64_t npart, int La, const NodeLink *__restrict__ link,
+                                                 const uint64_t *__restrict__ keys, const double *__restrict__ sums, Src4 *__restrict__ src,
+                                                 int *__restrict__ flag)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.level >= La)
+        return;
+    if(lk.pcount > 0) { // a leaf above the decomposition level: its particle set may be incomplete on this rank
+        atomicExch(flag, 1);
+        return;
+    }
+    const unsigned long long cell = lk.level == 0 ? 0ull : (unsigned long long)(keys[lk.pstart] >> (3 * (MAXLEVEL - lk.level)));
+    unsigned long long base = 0, p8 = 1;
+    for(int l = 0; l < lk.level; l++) {
+        base += p8;
+        p8 *= 8;
+    }
+    const double *q = sums + 4 * (base + cell);
+    Src4 o;
+    o.m = q[0];
+    o.x = q[1] / q[0];
+    o.y = q[2] / q[0];
+    o.z = q[3] / q[0];
+    src[npart + j] = o;
+}
+
+void TreeBuilder::top_partial(int La, int64_t n_own, double *d_out, hipStream_t st)
+{
+    MPG_CHECK(La >= 1 && La <= 8, "decomposition level must be in [1, 8]");
+    const size_t ncell = (size_t)1 << (3 * (La - 1));
+    MPG_HIP(hipMemsetAsync(d_out, 0, ncell * 4 * sizeof(double), st));
+    if(npart > 0)
+        hipLaunchKernelGGL(k_top_partial, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, idx_b.p, src.p, n_own, 3 * (MAXLEVEL - (La - 1)),
+                           d_out);
+    MPG_HIP(hipGetLastError());
+}
+
+void TreeBuilder::top_set(int La, const double *d_sums, hipStream_t st)
+{
+    MPG_CHECK(La >= 1 && La <= 8 && has_moments, "top_set: needs a tree with moments and a level in [1, 8]");
+    int *d_flag = (int *)flags.p;
+    MPG_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_top_set, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, La, link.p, keys_b.p, d_sums, src.p, d_flag);
+    int f = 0;
+    MPG_HIP(hipMemcpyAsync(&f, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipStreamSynchronize(st));
+    MPG_CHECK(f == 0, "domain decomposition: a cell above the decomposition level holds <= 8 local particles (use a coarser level)");
+    has_bfs = false; // the level-ordered copy must pick up the new moments
+}
+
 TreeView TreeBuilder::view() const
 {
     TreeView v;

@@ -1,0 +1,152 @@
+"""Particles distributed over the GPUs of a node: x-slab domains with ghost import (one process per GPU, torch.distributed).
+
+The reference gives every rank a set of Peano-Hilbert key ranges, builds a replicated "top-tree" whose leaves carry the
+moments of the remote sub-trees, and ships walk targets to the ranks that own the nodes they open
+(domain.c, forcetree.c:1106-1290, treewalk.c:325-793).  Here:
+
+* rank r OWNS the particles whose base PM-mesh cell lies in its x-slab (the same slabs as pm_slab.py); they are its targets
+  for the PM readout and for the short-range walk;
+* before every force step it IMPORTS, from the ranks that own them, the particles in the columns of level-La tree cells that
+  overlap its slab widened by Rcut on either side (whole columns, so every tree cell at level >= La that one of its targets
+  can reach is complete and identical to the global tree's cell; cells that are missing locally lie entirely more than
+  Rcut away and would be discarded by the walk on geometry alone);
+* the nodes above level La also contain remote particles: their moments come from sums over all ranks
+  (engine.dev_tree_top_partial -> all-reduce -> engine.dev_tree_top_set), the counterpart of the reference's top-tree;
+* nothing is all-gathered: per step one personalised exchange of ghost particles (32 B each, a surface layer) and one
+  all-reduce of (8^La - 1)/7 * 4 doubles.
+
+This module holds the index logic and the collectives; all arithmetic on particles is in the engine."""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import pm_slab
+
+
+def tree_column(x, box, La):
+    """x-index of the level-La tree cell of each position: the reference's own floating-point descent
+    (forcetree.c:get_subnode via the engine's k_keys: Pos > centre; centre +- len/4; len /= 2), so that ownership of a column
+    agrees with the tree bit for bit."""
+    cx = torch.full_like(x, box / 2.)
+    ln = box * 1.001
+    col = torch.zeros_like(x, dtype=torch.int64)
+    for _ in range(La):
+        q = 0.25 * ln
+        b = x > cx
+        cx = torch.where(b, cx + q, cx - q)
+        col = col * 2 + b.to(torch.int64)
+        ln *= 0.5
+    return col
+
+
+def needed_columns(box, nmesh, world, La, margin):
+    """[world, 2^La] bool: the columns of level-La cells rank s needs = those overlapping its slab widened by `margin`
+    (periodic).  Column k covers [root_lo + k w, root_lo + (k+1) w), root = the tree's root cell (1.001 Box wide)."""
+    ncol = 1 << La
+    w = 1.001 * box / ncol
+    root_lo = box / 2. - 0.5 * 1.001 * box
+    need = torch.zeros(world, ncol, dtype=torch.bool)
+    slab = box / world
+    for s in range(world):
+        a, b = s * slab - margin, (s + 1) * slab + margin
+        pieces = []
+        if b - a >= box:
+            pieces = [(0.0, box)]
+        elif a < 0:
+            pieces = [(a + box, box), (0.0, b)]
+        elif b > box:
+            pieces = [(a, box), (0.0, b - box)]
+        else:
+            pieces = [(a, b)]
+        for lo, hi in pieces:
+            k0 = max(0, int(math.floor((lo - root_lo) / w)) - 0)
+            k1 = min(ncol - 1, int(math.floor((hi - root_lo) / w)))
+            need[s, k0:k1 + 1] = True
+    return need
+
+
+def _exchange_rows(send, counts, world, group=None):
+    """Personalised exchange: `send` holds the rows for rank 0, 1, ... back to back (counts[d] rows each); returns the rows
+    received from all ranks, in rank order.  RCCL all_to_all_single with uneven splits; backends without it (gloo) gather."""
+    dev = send.device
+    cnt = torch.tensor(counts, dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt, group=group)
+    allc = torch.stack(allc).cpu()                       # allc[s][d] = rows rank s sends to rank d
+    rank = dist.get_rank(group)
+    recv_counts = [int(allc[s][rank]) for s in range(world)]
+    out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
+    try:
+        dist.all_to_all_single(out, send, recv_counts, list(counts), group=group)
+        return out
+    except (RuntimeError, NotImplementedError):
+        pass
+    nmax = int(allc.sum(1).max())
+    pad = torch.zeros((nmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
+    pad[:send.shape[0]] = send
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    o = 0
+    for s in range(world):
+        off = int(allc[s][:rank].sum())
+        c = recv_counts[s]
+        out[o:o + c] = parts[s][off:off + c]
+        o += c
+    return out
+
+
+class SlabDomain:
+    """Ownership, ghost import and the global top of the tree for one rank.  `rcut` is the short-range cut-off radius in
+    length units (Rcut * Asmth * cell size, gravshort-tree.c:102)."""
+
+    def __init__(self, eng, box, nmesh, rank, world, device, rcut, La=None, group=None):
+        self.eng, self.box, self.nmesh, self.rank, self.world, self.dev, self.group = eng, box, nmesh, rank, world, device, group
+        self.cellsize = box / nmesh
+        if La is None:   # column width in [rcut, 2 rcut): little over-import, few cells above the decomposition level
+            La = int(math.floor(math.log2(1.001 * box / rcut)))
+        self.La = max(1, min(7, La))
+        self.margin = max(rcut, 2 * self.cellsize) + 0.01 * self.cellsize   # > Rcut: the walk's discard test is strict
+        self.need = needed_columns(box, nmesh, world, self.La, self.margin).to(device)
+        self.ntop_fine = 8 ** (self.La - 1)
+        self.partial = torch.zeros(self.ntop_fine * 4, dtype=torch.float64, device=device)
+
+    def select_own(self, pos):
+        """Indices of the particles this rank owns (base PM cell in its slab)."""
+        owner = pm_slab.slab_of_cells(pos[:, 0], self.cellsize, self.nmesh, self.world)
+        return torch.nonzero(owner == self.rank).squeeze(1)
+
+    def import_ghosts(self, own_pos, own_mass):
+        """Returns (pos, mass) of [own | ghosts]: the particle set this rank builds its tree and its PM slab from."""
+        if self.world == 1:
+            return own_pos, own_mass
+        col = tree_column(own_pos[:, 0], self.box, self.La)
+        rows, counts = [], []
+        for d in range(self.world):
+            if d == self.rank:
+                counts.append(0)
+                continue
+            idx = torch.nonzero(self.need[d][col]).squeeze(1)
+            counts.append(int(idx.shape[0]))
+            rows.append(torch.cat([own_pos[idx], own_mass[idx].to(torch.float64)[:, None]], dim=1))
+        send = torch.cat(rows) if rows else torch.zeros(0, 4, dtype=torch.float64, device=self.dev)
+        got = _exchange_rows(send, counts, self.world, self.group)
+        pos = torch.cat([own_pos, got[:, 0:3]]).contiguous()
+        mass = torch.cat([own_mass, got[:, 3].to(torch.float32)]).contiguous()
+        return pos, mass
+
+    def set_global_top(self, n_own):
+        """Moments of the tree nodes above level La from the sums over all ranks (call after dev_force_tree_build)."""
+        self.eng.dev_tree_top_partial(self.La, n_own, self.partial)
+        if self.world > 1:
+            dist.all_reduce(self.partial, group=self.group)
+        levels = [self.partial.view(self.ntop_fine, 4)]
+        for _ in range(self.La - 1):                       # a parent's 8 children are consecutive (octant-path numbering)
+            levels.append(levels[-1].view(-1, 8, 4).sum(1))
+        sums = torch.cat(levels[::-1]).contiguous()        # level 0 first
+        self.eng.dev_tree_top_set(self.La, sums)
+
+    def own_targets(self, n_own, n_local):
+        """Own particles in tree order (int32 caller indices into the [own | ghosts] arrays)."""
+        order = self.eng.dev_tree_order(n_local, self.dev)
+        return order[order < n_own].contiguous()

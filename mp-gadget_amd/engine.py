@@ -312,6 +312,12 @@ class Engine:
                                                   _ptr(vel), _ptr(gravaccel), _ptr(type), _ptr(flags), _ptr(tb_grav), _ptr(tb_hydro),
                                                   _ptr(hydroaccel), _ptr(entropy), _ptr(dtentropy), C.byref(K)))
 
+    def dev_tree_top_partial(self, La, n_own, out):
+        self._ck(self.lib.mpg_dev_tree_top_partial(self.h, int(La), C.c_int64(n_own), _ptr(out)))
+
+    def dev_tree_top_set(self, La, sums):
+        self._ck(self.lib.mpg_dev_tree_top_set(self.h, int(La), _ptr(sums)))
+
     # slab-decomposed PM over several GPUs: local stages (the collectives between them are in pm_slab.py)
     def dev_pm_slab_init(self, rank, world):
         a, b = C.c_int64(0), C.c_int64(0)

@@ -344,6 +344,13 @@ def test_two_ranks_match_one(tmp_path):
         gpm = np.abs(one[:, 3:6]).mean()
         assert np.abs(sl[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * gpm, name
         assert np.abs(sl[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
+    # particles distributed over the ranks (ghost import, global top of the tree): same decisions except where a node's moments,
+    # now summed in a different order, sit within an ulp of an opening threshold -> the usual parity bounds
+    for name, nproc, port in (("dom1.npy", 1, 0), ("dom2.npy", 2, 29580), ("dom4.npy", 4, 29581)):
+        dm = _run_mgpu(tmp_path, name, nproc, "domain", port)
+        assert_accel_parity(dm[:, 0:3], one[:, 0:3])
+        assert np.abs(dm[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * np.abs(one[:, 3:6]).mean(), name
+        assert np.abs(dm[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
 
 
 def test_full_size_256_properties(pkg, orc):

@@ -149,3 +149,55 @@ def test_slab_pm_collectives_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_tree_columns_and_needed_sets(pkg):
+    """Index logic of the distributed-particle mode: tree_column replays the octree descent (root cell 1.001 Box around Box/2);
+    every rank's needed columns cover its slab widened by the margin, periodically."""
+    D = pkg.domain
+    box, La = 8.0, 3
+    x = torch.tensor([1e-9, 0.9959, 0.9961, 3.999, 4.001, 7.99, 8.0], dtype=torch.float64)
+    w, lo = 1.001 * box / 8, box / 2 - 0.5 * 1.001 * box
+    ref = torch.floor((x - lo) / w).to(torch.int64)
+    assert torch.equal(D.tree_column(x, box, La), ref)
+    need = D.needed_columns(box, 64, 4, La, margin=0.7)
+    assert need.shape == (4, 8)
+    for s in range(4):
+        for xx in np.linspace(s * 2.0 - 0.7, (s + 1) * 2.0 + 0.7, 50):
+            xx = float(np.mod(xx, box))
+            assert bool(need[s, int(np.floor((xx - lo) / w))]), (s, xx)
+    assert bool(need[0, 7]) and bool(need[3, 0])            # periodic neighbours across the box edge
+    assert not bool(need[0, 3]) and not bool(need[2, 0])
+
+
+def _domain_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mp-gadget_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # personalised exchange with uneven counts: rank r sends (d + 1 + r) rows tagged (r, d) to rank d
+    rows, counts = [], []
+    for d in range(world):
+        c = 0 if d == rank else d + 1 + rank
+        counts.append(c)
+        rows.append(torch.full((c, 4), float(10 * rank + d), dtype=torch.float64))
+    got = pkg.domain._exchange_rows(torch.cat(rows), counts, world)
+    exp = torch.cat([torch.full((0 if s == rank else rank + 1 + s, 4), float(10 * s + rank), dtype=torch.float64) for s in range(world)])
+    q.put((rank, bool(torch.equal(got, exp))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ghost_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_domain_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -45,6 +45,29 @@ elif mode == "replicated":
     optr = eng.dev_tree_order_ptr()
     eng.dev_grav_short_tree(acc, oldacc=old, active=optr + 4 * lo, nactive=hi - lo)
     pkg.shard.exchange_results(acc, eng.dev_tree_order(N, dev), rank, world)
+elif mode.startswith("domain"):
+    # particles distributed: own = x-slab particles, ghosts imported in whole tree-cell columns, global top of the tree
+    rcut = 6.0 * 1.5 * box / (2 * n)
+    dom = pkg.domain.SlabDomain(eng, box, 2 * n, rank, world, dev, rcut)
+    own = dom.select_own(d_pos)
+    n_own = own.shape[0]
+    lpos, lmass = dom.import_ghosts(d_pos[own].contiguous(), d_mass[own].contiguous())
+    nl = lpos.shape[0]
+    eng.dev_bind_particles(lpos, lmass, box)
+    eng.dev_force_tree_build()
+    dom.set_global_top(n_own)
+    spm = pkg.pm_slab.SlabPM(eng, box, 2 * n, rank, world, dev)
+    tg = dom.own_targets(n_own, nl)
+    f8 = dict(dtype=torch.float64, device=dev)
+    gl, al, pl = torch.zeros(nl, 3, **f8), torch.zeros(nl, 3, **f8), torch.zeros(nl, **f8)
+    spm.force(tg, gl, pl)
+    eng.dev_grav_short_tree(al, oldacc=torch.full((nl,), 1e-7, **f8), active=tg)
+    both = torch.zeros(N, 7, **f8)
+    both[own] = torch.cat([al[:n_own], gl[:n_own], pl[:n_own, None]], dim=1)
+    pkg.pm_slab.TargetExchange(world, dev).exchange(both, own.to(torch.int32))
+    acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
+    if rank == 0:
+        print("domain: La %d, own %d, local %d (ghost fraction %.2f)" % (dom.La, n_own, nl, nl / n_own - 1), flush=True)
 else:
     # slab-decomposed PM; PM readout and walk targets = the particles of this rank's x-slab
     eng.dev_force_tree_build()
