@@ -82,7 +82,8 @@ def main():
         if world != 1:
             raise SystemExit("--workload hydro is single-GPU in this round")
         return hydro_bench(pkg, torch, args, dev)
-    n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / 16)) * 16)
+    # weak scaling: about 256^3 particles per GPU; Nmesh = 2 n must be a multiple of the number of GPUs (x-slab PM)
+    n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / (8 * world))) * 8 * world)
     nmesh = 2 * n
     gen = getattr(pkg.ics, args.ic)
     pos, mass, box = gen(n)
