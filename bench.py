@@ -80,7 +80,7 @@ def main():
         return integrate_bench(pkg, torch, args, dev)
     if args.workload == "hydro":
         if world != 1:
-            raise SystemExit("--workload hydro is single-GPU in this round")
+            return hydro_bench_domain(pkg, torch, dist, args, dev, rank, world)
         return hydro_bench(pkg, torch, args, dev)
     # weak scaling: about 256^3 particles per GPU; Nmesh = 2 n must be a multiple of the number of GPUs (x-slab PM)
     n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / (8 * world))) * 8 * world)
@@ -331,17 +331,8 @@ def hydro_bench(pkg, torch, args, dev):
     + force_tree_calc_moments (hmax) + hydro_force  (run.c:466-548)."""
     n = args.n or 128
     nmesh = 2 * n
-    posd, _, box = pkg.ics.s_zel(n)
-    sp = box / n
-    ob, om = 0.045, 0.3                                   # gas / DM offsets of genic/main.c:61-63
-    posg = np.mod(posd - 0.5 * (om - ob) / om * sp, box)
-    posd = np.mod(posd + 0.5 * ob / om * sp, box)
-    posg[posg <= 0] += box
-    posd[posd <= 0] += box
-    pos = np.concatenate([posg, posd])
+    pos, mass, typ, box = hydro_ics(pkg, n)
     N = len(pos)
-    mass = np.concatenate([np.full(n ** 3, ob / om, np.float32), np.full(n ** 3, 1 - ob / om, np.float32)])
-    typ = np.concatenate([np.zeros(n ** 3, np.uint8), np.ones(n ** 3, np.uint8)])
     f8 = torch.float64
     d_pos, d_mass, d_type = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
     eng = pkg.Engine(dev.index or 0)
@@ -426,6 +417,114 @@ def hydro_bench(pkg, torch, args, dev):
            "phases_ms": {"gravity_pm_tree_walk": round(ms[0], 3), "gas_tree": round(ms[1], 3), "density": round(ms[2], 3),
                          "hmax": round(ms[3], 3), "hydro": round(ms[4], 3)}}
     print(json.dumps(out), flush=True)
+    eng.close()
+    return out
+
+
+def hydro_ics(pkg, n):
+    """2 x n^3 particles: gas and dark matter offset from a Zel'dovich-displaced grid (genic/main.c:61-63)."""
+    posd, _, box = pkg.ics.s_zel(n)
+    sp = box / n
+    ob, om = 0.045, 0.3
+    posg = np.mod(posd - 0.5 * (om - ob) / om * sp, box)
+    posd = np.mod(posd + 0.5 * ob / om * sp, box)
+    posg[posg <= 0] += box
+    posd[posd <= 0] += box
+    pos = np.concatenate([posg, posd])
+    mass = np.concatenate([np.full(n ** 3, ob / om, np.float32), np.full(n ** 3, 1 - ob / om, np.float32)])
+    typ = np.concatenate([np.zeros(n ** 3, np.uint8), np.ones(n ** 3, np.uint8)])
+    return pos, mass, typ, box
+
+
+def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
+    """configs[2] weak-scaled over GPUs with the particles distributed: x-slab domains, ghosts within
+    max(Rcut, largest Hsml), gravity as in the DM-only bench, then gas tree -> density (own gas) -> the ghosts' SPH fields from
+    their owners -> hmax -> hydro_force (own gas)."""
+    n = args.n or {2: 160, 4: 200, 8: 256}.get(world, int(round(128 * world ** (1. / 3) / (4 * world))) * 4 * world)
+    nmesh = 2 * n
+    pos, mass, typ, box = hydro_ics(pkg, n)
+    N = len(pos)
+    f8 = dict(dtype=torch.float64, device=dev)
+    eng = pkg.Engine(dev.index or 0)
+    eng.use_torch_stream()
+    eng.set_walk_variant(args.variant)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(TreeUseBH=2)
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(0, 100.0, 0.75)
+    rcut = 6.0 * 1.5 * box / nmesh
+    dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut, margin=6.0 * box / n)
+    g_pos = torch.from_numpy(pos).to(dev)
+    own = dom.select_own(g_pos)
+    n_own = int(own.shape[0])
+    o_pos, o_mass, o_typ = g_pos[own].contiguous(), torch.from_numpy(mass).to(dev)[own].contiguous(), torch.from_numpy(typ).to(dev)[own].contiguous()
+    del g_pos
+    o_vel, o_ent = torch.zeros(n_own, 3, **f8), torch.ones(n_own, **f8)
+    o_hsml = torch.full((n_own,), 2.0 * box / n, **f8)          # first pass converges it (untimed set-up step)
+    o_prev = torch.zeros(n_own, 3, **f8)
+    spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
+    t = pkg.SphTimes()
+    t.atime, t.hubble = 0.1, 0.1
+    for i in range(47):
+        t.dloga_bin[i] = 0.01
+    FIELDS = ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel")
+    keep = {}
+
+    def step():
+        nonlocal o_hsml, o_prev
+        lpos, lmass, ltyp, lvel, lent, lhsml = dom.import_ghosts(o_pos, o_mass, (o_typ, o_vel, o_ent, o_hsml))
+        nl = int(lpos.shape[0])
+        z1, z3 = (lambda: torch.zeros(nl, **f8)), (lambda: torch.zeros(nl, 3, **f8))
+        gravpm, acc, prev, pot = z3(), z3(), z3(), z1()
+        prev[:n_own] = o_prev
+        eng.dev_bind_particles(lpos, lmass, box, type=ltyp)
+        eng.dev_force_tree_build()
+        dom.set_global_top(n_own)
+        tg = dom.own_targets(n_own, nl)
+        spm.force(tg, gravpm, pot)
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=tg)
+        a = dict(hsml=lhsml, dthsml=z1(), vel=lvel, entropy=lent, density=z1(), egywtdensity=z1(), dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(),
+                 hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
+        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+        act = torch.nonzero(ltyp[:n_own] == 0).squeeze(1).to(torch.int32).contiguous()
+        eng.dev_density(a, t, active=act)
+        dom.check_hsml_margin(a["hsml"][:n_own])
+        for k in FIELDS:
+            a[k][n_own:] = dom.ghost_update(a[k][:n_own].contiguous())
+        eng.dev_force_tree_calc_hmax()
+        eng.dev_hydro_force(a, t, active=act)
+        eng.synchronize()
+        o_hsml, o_prev = a["hsml"][:n_own].clone(), acc[:n_own].clone()
+        keep.update(arrays=(lpos, lmass, ltyp, a, acc), ghost_fraction=nl / n_own - 1, it=eng.sph_stats()["iterations"])
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup + 1):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], **f8)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    el = float(dt.item())
+    out = None
+    if rank == 0:
+        out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "2x%d^3 DM+gas TreePM + density-entropy SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, nmesh),
+                          "particles": N, "parallelism": "%d GPUs: particles distributed in x-slab domains with ghost import" % world,
+                          "ghost_fraction_rank0": round(keep["ghost_fraction"], 3), "density_iterations_last": keep["it"]}}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
     eng.close()
     return out
 

@@ -52,6 +52,7 @@ struct SphEngine {
     DevBuf<unsigned> ctr;
     DevBuf<unsigned long long> stats;
     bool hmax_pending = false;
+    SphView hsml_view{}; // the caller's arrays at the last density(): calc_hmax gathers Hsml from them
     int64_t last_iterations = 0, last_targets = 0, last_interactions = 0, last_candidates = 0;
 
     const uint8_t *mark_active(const int *d_active, int64_t nactive, int64_t n, hipStream_t st);

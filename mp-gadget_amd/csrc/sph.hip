@@ -995,8 +995,9 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
     }
     if(update_hsml && tv.npart > 0) {
         // update_tree_hmax_father for every finished particle (density.c:551-553) == leaf hmax from the final Hsml
-        hsml_tree.reserve(tv.npart + 1);
-        hipLaunchKernelGGL(k_hsml_treeorder, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, A, hsml_tree.p);
+        // (gathered in calc_hmax, from the array as it is then: with distributed particles the smoothing lengths of the ghost
+        // particles are refreshed from their owners between density() and the hmax pass)
+        hsml_view = A;
         hmax_pending = true;
     }
     unsigned long long hs[2] = {0, 0};
@@ -1032,6 +1033,10 @@ void SphEngine::set_init_hsml(TreeBuilder &tree, const SphView &A, const mpg_den
 void SphEngine::calc_hmax(TreeBuilder &tree, hipStream_t st)
 {
     MPG_CHECK(hmax_pending, "force_tree_calc_moments for hmax called before density()");
+    const TreeView tv = tree.view();
+    hsml_tree.reserve(tv.npart + 1);
+    if(tv.npart > 0)
+        hipLaunchKernelGGL(k_hsml_treeorder, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, hsml_view, hsml_tree.p);
     tree.calc_hmax(hsml_tree.p, st);
     hmax_pending = false;
 }

@@ -66,14 +66,21 @@ def needed_columns(box, nmesh, world, La, margin):
     return need
 
 
-def _exchange_rows(send, counts, world, group=None):
-    """Personalised exchange: `send` holds the rows for rank 0, 1, ... back to back (counts[d] rows each); returns the rows
-    received from all ranks, in rank order.  RCCL all_to_all_single with uneven splits; backends without it (gloo) gather."""
-    dev = send.device
-    cnt = torch.tensor(counts, dtype=torch.int64, device=dev)
+def _count_matrix(counts, world, device, group=None):
+    """allc[s][d] = rows rank s sends to rank d (host tensor)"""
+    cnt = torch.tensor(counts, dtype=torch.int64, device=device)
     allc = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(allc, cnt, group=group)
-    allc = torch.stack(allc).cpu()                       # allc[s][d] = rows rank s sends to rank d
+    return torch.stack(allc).cpu()
+
+
+def _exchange_rows(send, counts, world, group=None, allc=None):
+    """Personalised exchange: `send` holds the rows for rank 0, 1, ... back to back (counts[d] rows each); returns the rows
+    received from all ranks, in rank order.  RCCL all_to_all_single with uneven splits; backends without it (gloo) gather.
+    `allc`: the count matrix of _count_matrix when the caller already has it (several fields, same lists)."""
+    dev = send.device
+    if allc is None:
+        allc = _count_matrix(counts, world, dev, group)
     rank = dist.get_rank(group)
     recv_counts = [int(allc[s][rank]) for s in range(world)]
     out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
@@ -100,13 +107,14 @@ class SlabDomain:
     """Ownership, ghost import and the global top of the tree for one rank.  `rcut` is the short-range cut-off radius in
     length units (Rcut * Asmth * cell size, gravshort-tree.c:102)."""
 
-    def __init__(self, eng, box, nmesh, rank, world, device, rcut, La=None, group=None):
+    def __init__(self, eng, box, nmesh, rank, world, device, rcut, La=None, group=None, margin=None):
         self.eng, self.box, self.nmesh, self.rank, self.world, self.dev, self.group = eng, box, nmesh, rank, world, device, group
         self.cellsize = box / nmesh
         if La is None:   # column width in [rcut, 2 rcut): little over-import, few cells above the decomposition level
             La = int(math.floor(math.log2(1.001 * box / rcut)))
         self.La = max(1, min(7, La))
-        self.margin = max(rcut, 2 * self.cellsize) + 0.01 * self.cellsize   # > Rcut: the walk's discard test is strict
+        # > Rcut: the walk's discard test is strict.  SPH needs margin >= the largest smoothing length (check_hsml_margin).
+        self.margin = max(rcut, 2 * self.cellsize, margin or 0.0) + 0.01 * self.cellsize
         self.need = needed_columns(box, nmesh, world, self.La, self.margin).to(device)
         self.ntop_fine = 8 ** (self.La - 1)
         self.partial = torch.zeros(self.ntop_fine * 4, dtype=torch.float64, device=device)
@@ -116,24 +124,45 @@ class SlabDomain:
         owner = pm_slab.slab_of_cells(pos[:, 0], self.cellsize, self.nmesh, self.world)
         return torch.nonzero(owner == self.rank).squeeze(1)
 
-    def import_ghosts(self, own_pos, own_mass):
-        """Returns (pos, mass) of [own | ghosts]: the particle set this rank builds its tree and its PM slab from."""
+    def import_ghosts(self, own_pos, own_mass, fields=()):
+        """Returns (pos, mass, *fields) of [own | ghosts]: the particle set this rank builds its trees and its PM slab from.
+        `fields`: further per-particle tensors ([n_own] or [n_own, k]) to carry along.  The send lists are kept so that
+        ghost_update() can refresh per-particle data of the same ghosts later in the step."""
         if self.world == 1:
-            return own_pos, own_mass
+            self.send_idx, self.send_counts = None, None
+            return (own_pos, own_mass) + tuple(fields)
         col = tree_column(own_pos[:, 0], self.box, self.La)
-        rows, counts = [], []
+        idxs, counts = [], []
         for d in range(self.world):
             if d == self.rank:
                 counts.append(0)
                 continue
             idx = torch.nonzero(self.need[d][col]).squeeze(1)
             counts.append(int(idx.shape[0]))
-            rows.append(torch.cat([own_pos[idx], own_mass[idx].to(torch.float64)[:, None]], dim=1))
-        send = torch.cat(rows) if rows else torch.zeros(0, 4, dtype=torch.float64, device=self.dev)
-        got = _exchange_rows(send, counts, self.world, self.group)
-        pos = torch.cat([own_pos, got[:, 0:3]]).contiguous()
-        mass = torch.cat([own_mass, got[:, 3].to(torch.float32)]).contiguous()
-        return pos, mass
+            idxs.append(idx)
+        self.send_idx = torch.cat(idxs) if idxs else torch.zeros(0, dtype=torch.int64, device=self.dev)
+        self.send_counts = counts
+        self.count_matrix = _count_matrix(counts, self.world, self.dev, self.group)
+        out = [self.ghost_update(t) for t in (own_pos, own_mass) + tuple(fields)]
+        return tuple(torch.cat([t, g]).contiguous() for t, g in zip((own_pos, own_mass) + tuple(fields), out))
+
+    def ghost_update(self, own_t):
+        """Rows of `own_t` ([n_own] or [n_own, k], any dtype) for this rank's ghosts, fetched from their owners, in ghost order."""
+        if self.world == 1:
+            return own_t[:0]
+        t = own_t[self.send_idx]
+        flat = t.reshape(t.shape[0], -1).to(torch.float64)
+        got = _exchange_rows(flat.contiguous(), self.send_counts, self.world, self.group, self.count_matrix)
+        return got.reshape((got.shape[0],) + tuple(own_t.shape[1:])).to(own_t.dtype)
+
+    def check_hsml_margin(self, own_hsml):
+        """The SPH loops on the distributed set need every neighbour within max(Hsml_i, Hsml_j) of an own gas particle to be
+        local: the largest smoothing length of any rank must not exceed the import margin."""
+        h = own_hsml.max().reshape(1) if own_hsml.numel() else torch.zeros(1, dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+        if float(h.item()) > self.margin:
+            raise RuntimeError("largest smoothing length %g exceeds the ghost margin %g" % (float(h.item()), self.margin))
 
     def set_global_top(self, n_own):
         """Moments of the tree nodes above level La from the sums over all ranks (call after dev_force_tree_build)."""

@@ -1,0 +1,91 @@
+"""One density -> hmax -> hydro_force pass with the particles distributed over ranks (x-slab domains, ghost import), saving rank
+0's view of the global results; world == 1 without MPG_MGPU_MODE=domain is the plain single-GPU pass.  Used by
+tests/test_gpu_sph.py::test_sph_ranks_match_one.  MPG_DIST_BACKEND=gloo lets the ranks share one GPU."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("mp-gadget_amd")
+import torch
+import torch.distributed as dist
+
+out, n = sys.argv[1], int(sys.argv[2])
+rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+lr = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(lr)
+dev = torch.device("cuda", lr)
+if world > 1:
+    dist.init_process_group(os.environ.get("MPG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+mode = os.environ.get("MPG_MGPU_MODE", "single")
+pos, mass, box = pkg.ics.s_zel(n, box=8.0)
+N = len(pos)
+rng = np.random.RandomState(3)
+typ = np.zeros(N, np.uint8)
+typ[rng.choice(N, N // 4, replace=False)] = 1                 # dark matter mixed in
+vel = rng.standard_normal((N, 3))
+ent = 1.0 + 0.5 * rng.random_sample(N)
+f8 = dict(dtype=torch.float64, device=dev)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+g_pos, g_mass, g_typ, g_vel, g_ent = T(pos), T(mass), T(typ), T(vel), T(ent)
+g_hsml = torch.full((N,), 2.2 * box / n, **f8)
+eng = pkg.Engine(lr)
+eng.use_torch_stream()
+eng.set_gravshort_treepar()
+eng.gravshort_set_softenings(box / n)
+eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+eng.set_hydropar(0, 100.0, 0.75)
+t = pkg.SphTimes()
+t.atime, t.hubble = 0.5, 0.3
+for i in range(47):
+    t.dloga_bin[i] = 0.01
+FIELDS = ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel")
+
+
+def arrays(m, hsml, v, e):
+    z1 = lambda: torch.zeros(m, **f8)
+    return dict(hsml=hsml, dthsml=z1(), vel=v, entropy=e, density=z1(), egywtdensity=z1(), dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(),
+                hydroacc_out=torch.zeros(m, 3, **f8), dtentropy_out=z1(), maxsignalvel=z1())
+
+
+if mode == "single":
+    a = arrays(N, g_hsml.clone(), g_vel, g_ent)
+    eng.dev_bind_particles(g_pos, g_mass, box, type=g_typ)
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    eng.dev_density(a, t)
+    eng.dev_force_tree_calc_hmax()
+    eng.dev_hydro_force(a, t)
+    res = {k: a[k] for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel")}
+else:
+    nmesh = 2 * n
+    dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut=6.0 * 1.5 * box / nmesh, margin=6.0 * box / n)
+    own = dom.select_own(g_pos)
+    n_own = own.shape[0]
+    lpos, lmass, ltyp, lvel, lent, lhsml = dom.import_ghosts(g_pos[own].contiguous(), g_mass[own].contiguous(),
+                                                            (g_typ[own].contiguous(), g_vel[own].contiguous(), g_ent[own].contiguous(), g_hsml[own].contiguous()))
+    nl = lpos.shape[0]
+    a = arrays(nl, lhsml, lvel, lent)
+    eng.dev_bind_particles(lpos, lmass, box, type=ltyp)
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    act = torch.nonzero(ltyp[:n_own] == 0).squeeze(1).to(torch.int32).contiguous()    # own gas particles
+    eng.dev_density(a, t, active=act)
+    dom.check_hsml_margin(a["hsml"][:n_own])
+    for k in FIELDS:                                            # the ghosts' new smoothing lengths, densities, ... from their owners
+        a[k][n_own:] = dom.ghost_update(a[k][:n_own].contiguous())
+    eng.dev_force_tree_calc_hmax()
+    eng.dev_hydro_force(a, t, active=act)
+    res = {}
+    ex = pkg.pm_slab.TargetExchange(world, dev)
+    for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel"):
+        full = torch.zeros((N,) + tuple(a[k].shape[1:]), **f8)
+        full[own] = a[k][:n_own]
+        ex.exchange(full.reshape(N, -1), own.to(torch.int32))
+        res[k] = full
+    if rank == 0:
+        print("hydro domain: La %d own %d local %d" % (dom.La, n_own, nl), flush=True)
+torch.cuda.synchronize()
+if rank == 0:
+    np.savez(out, typ=typ, **{k: v.cpu().numpy() for k, v in res.items()})
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+eng.close()
