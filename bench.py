@@ -32,6 +32,18 @@ G = 43.0071
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def emit(out):
+    """The ONE JSON line, as the last thing on stdout: RCCL prints a version banner through C stdio, which sits in libc's buffer
+    until exit when stdout is a pipe - flush it first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,8 +78,12 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MPG_FORCE_MGPU=1: run the multi-GPU code path (collectives included) in a one-rank group - a single-GPU box can then
+    # exercise exactly what the ranks of an N-GPU run execute
+    multi = world > 1 or bool(os.environ.get("MPG_FORCE_MGPU"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("MPG_DIST_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU in tests
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -78,8 +94,10 @@ def main():
         if world != 1:
             raise SystemExit("--workload integrate is single-GPU")
         return integrate_bench(pkg, torch, args, dev)
+    if multi and world == 1:
+        pkg.pm_slab.FORCE_COLLECTIVES = True
     if args.workload == "hydro":
-        if world != 1:
+        if multi:
             return hydro_bench_domain(pkg, torch, dist, args, dev, rank, world)
         return hydro_bench(pkg, torch, args, dev)
     # weak scaling: about 256^3 particles per GPU; Nmesh = 2 n must be a multiple of the number of GPUs (x-slab PM)
@@ -110,7 +128,7 @@ def main():
     # N > 1: "slab" = x-slab PM (two all-to-all transposes per step) with the particles of the slab as
     # PM-readout and walk targets; "replicated" = every rank does the whole PM, targets are contiguous tree-slot ranges
     pm_ms = [0.0, 0]
-    if world > 1 and args.mgpu == "domain":
+    if multi and args.mgpu == "domain":
         rcut = 6.0 * 1.5 * box / nmesh                       # Rcut * Asmth * cell size (gravshort-tree.c:102)
         dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut)
         own = dom.select_own(d_pos)
@@ -121,11 +139,11 @@ def main():
         spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         loc = {}                                             # arrays over [own | ghosts], sized on first use
-    elif world > 1 and args.mgpu == "slab":
+    elif multi and args.mgpu == "slab":
         spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
         tex = pkg.pm_slab.TargetExchange(world, dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    elif world > 1:
+    elif multi:
         lo, hi = pkg.shard.slot_range(N, rank, world)
         chunk = pkg.shard.chunk_size(N, world)
         gbuf = torch.zeros(world * chunk, 3, dtype=torch.float64, device=dev)
@@ -154,9 +172,9 @@ def main():
 
     def step():
         nonlocal acc, prev
-        if world > 1 and args.mgpu == "domain":
+        if multi and args.mgpu == "domain":
             return step_domain()
-        if world == 1:
+        if not multi:
             eng.dev_gravpm_force(gravpm, pot)
             eng.dev_force_tree_build()
             prev, acc = acc, prev
@@ -182,7 +200,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -198,7 +216,7 @@ def main():
     t1 = time.perf_counter()
     walk_ms, walk_launches = eng.walk_events_collect()
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     elapsed = float(dt.item())
 
@@ -255,16 +273,17 @@ def main():
         }
         if pm_ms[1]:
             out["phases_ms"]["pm_slab_total_incl_collectives"] = round(pm_ms[0] / pm_ms[1], 3)
-        if world > 1 and args.mgpu == "domain":
+        if multi and args.mgpu == "domain":
             out["config"]["ghost_fraction_rank0"] = round(loc["ghost_fraction"], 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
                                                args.cpu_sample)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if out is not None:
+        emit(out)
     return out
 
 
@@ -320,8 +339,8 @@ def integrate_bench(pkg, torch, args, dev):
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_alg,
                         "avg_launch_ms": 1e3 * el / args.steps,
                         "note": "three launches per step; each call also reads back an error word (one stream synchronisation per call)"}}
-    print(json.dumps(out), flush=True)
     eng.close()
+    emit(out)
     return out
 
 
@@ -416,8 +435,8 @@ def hydro_bench(pkg, torch, args, dev):
                                   % (sh["candidates"], sh["interactions"])),
            "phases_ms": {"gravity_pm_tree_walk": round(ms[0], 3), "gas_tree": round(ms[1], 3), "density": round(ms[2], 3),
                          "hmax": round(ms[3], 3), "hydro": round(ms[4], 3)}}
-    print(json.dumps(out), flush=True)
     eng.close()
+    emit(out)
     return out
 
 
@@ -522,10 +541,11 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
                "config": {"workload": "2x%d^3 DM+gas TreePM + density-entropy SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, nmesh),
                           "particles": N, "parallelism": "%d GPUs: particles distributed in x-slab domains with ghost import" % world,
                           "ghost_fraction_rank0": round(keep["ghost_fraction"], 3), "density_iterations_last": keep["it"]}}
-        print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
+    if out is not None:
+        emit(out)
     return out
 
 

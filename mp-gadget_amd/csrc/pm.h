@@ -35,7 +35,8 @@ struct PMesh {
         hipfftHandle p2d_r2c{}, p2d_c2r{}, p1d_fwd{};
         DevBuf<double> realF[4]; // Potential, ForceX, ForceY, ForceZ: (P + 1) planes of Nmesh^2 each, the last is the ghost plane
         DevBuf<double> C;        // 2 * P * Nmesh * (Nmesh/2+1): the slab after / before the 2-D transforms
-        DevBuf<double> rho_k;    // 2 * Nmesh * Py * (Nmesh/2+1): potential in Fourier space, layout [kx][ky local][kz]
+        DevBuf<double> rho_k;    // 2 * Nmesh * Py * (Nmesh/2+1): potential in Fourier space, layout [ky local][kz][kx]
+        DevBuf<double> work;     // same size: per-function work array
     } slab;
     DevBuf<unsigned> slab_err;
     size_t slab_cplx_per_peer() const { return (size_t)slab.P * slab.Py * (nmesh / 2 + 1); }

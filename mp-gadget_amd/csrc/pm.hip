@@ -75,6 +75,8 @@ __device__ __forceinline__ double sinc_unnormed(double x)
 // potential_transfer, gravpm.c:383-454, swept as pm_apply_transfer_function does (petapm.c:1092-1132).
 // Layout here: [kx][ky][kz], kz in [0, N/2].  k index -> signed mode: petapm_mesh_to_k, petapm.c:81-84.
 // ny rows of ky starting at y0 are held (ny = nmesh, y0 = 0 on one GPU; a ky-slab in the slab-decomposed form).
+// XLAST: the array is [ky local][kz][kx] (kx fastest: the slab form after its transpose) instead of [kx][ky local][kz].
+template <bool XLAST>
 __global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, int ny, int y0, double asmth2, double pot_factor,
                                                             const double *__restrict__ invsinc2, double2 *__restrict__ cplx)
 {
@@ -83,10 +85,19 @@ __global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, int ny, i
     const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(ip >= total)
         return;
-    const int iz = (int)(ip % nz);
-    const size_t t = ip / nz;
-    const int iy = y0 + (int)(t % ny);
-    const int ix = (int)(t / ny);
+    int ix, iy, iz;
+    if(XLAST) {
+        ix = (int)(ip % nmesh);
+        const size_t j = ip / nmesh;
+        iz = (int)(j % nz);
+        iy = y0 + (int)(j / nz);
+    }
+    else {
+        iz = (int)(ip % nz);
+        const size_t t = ip / nz;
+        iy = y0 + (int)(t % ny);
+        ix = (int)(t / ny);
+    }
     const int kx = ix <= nmesh / 2 ? ix : ix - nmesh;
     const int ky = iy <= nmesh / 2 ? iy : iy - nmesh;
     const int kz = iz;
@@ -111,6 +122,7 @@ __global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, int ny, i
 // axis < 0: plain copy (the Potential pass has no transfer function, gravpm.c:32-39).
 // The destination element of source (ix, row, iz) is dst[(ix * xmul + xoff) * ny * nz + row * nz + iz]: xmul = 1, xoff = 0 on one
 // GPU; (4, function) in the slab form, which interleaves the four functions so that each all-to-all block stays contiguous.
+template <bool XLAST>
 __global__ void __launch_bounds__(256) k_force_transfer(int nmesh, int ny, int y0, int axis, const double *__restrict__ difffac,
                                                         const double2 *__restrict__ src, double2 *__restrict__ dst, int xmul, int xoff)
 {
@@ -121,6 +133,19 @@ __global__ void __launch_bounds__(256) k_force_transfer(int nmesh, int ny, int y
         return;
     double2 v = src[ip];
     const size_t rowsz = (size_t)ny * nz;
+    if(XLAST) { // same layout in and out
+        if(axis >= 0) {
+            const int ix = (int)(ip % nmesh);
+            const size_t j = ip / nmesh;
+            const int iz = (int)(j % nz), iy = y0 + (int)(j / nz);
+            const double fac = difffac[axis == 0 ? ix : (axis == 1 ? iy : iz)];
+            const double t0 = -v.y * fac, t1 = v.x * fac;
+            v.x = t0;
+            v.y = t1;
+        }
+        dst[ip] = v;
+        return;
+    }
     const int ix = (int)(ip / rowsz);
     if(axis >= 0) {
         const int iz = (int)(ip % nz);
@@ -249,7 +274,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
     }
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
-    hipLaunchKernelGGL(k_potential_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, asmth2, pot_factor, invsinc2.p,
+    hipLaunchKernelGGL(k_potential_transfer<false>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, asmth2, pot_factor, invsinc2.p,
                        (double2 *)rho_k.p);
     if(tm) {
         tm->lap(st, &t);
@@ -260,8 +285,8 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         const int axis = f - 1;
         if(f == 0 && !d_potential)
             continue;
-        hipLaunchKernelGGL(k_force_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, axis, difffac.p, (const double2 *)rho_k.p,
-                           (double2 *)work_k.p, 1, 0);
+        hipLaunchKernelGGL(k_force_transfer<false>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, axis, difffac.p,
+                           (const double2 *)rho_k.p, (double2 *)work_k.p, 1, 0);
         if(tm) {
             tm->lap(st, &t);
             t_tr += t;
@@ -301,8 +326,9 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
 //
 //   forward_a : deposit -> 2-D r2c over (y,z) of the P own planes -> pack by destination ky-slab     [sendA]
 //   all-to-all (caller)                                                                               [recvA = [x][ky local][kz]]
-//   forward_b : 1-D c2c along x (stride Py*Nz) -> potential transfer -> 4 x (force transfer -> inverse 1-D c2c -> strided copy),
-//               interleaved as [x][function][ky local][kz] so that the block for rank d (its x-planes) is contiguous  [sendB]
+//   forward_b : tiled transpose to [ky local][kz][kx] -> 1-D c2c along x (contiguous rows) -> potential transfer -> 4 x (force
+//               transfer -> inverse 1-D c2c -> tiled transpose back), interleaved as [x][function][ky local][kz] so that the
+//               block for rank d (its x-planes) is contiguous                                              [sendB]
 //   all-to-all (caller)                                                                               [recvB]
 //   inverse_c : unpack to [x local][ky][kz] -> 2-D c2r -> 4 real slabs; first planes out as ghosts    [ghost_send]
 //   neighbour exchange (caller) -> readout.
@@ -427,6 +453,30 @@ __global__ void __launch_bounds__(256) k_cic_readout_slab(int64_t nt, const int 
         out[i] += acc;
 }
 
+// out[c * out_ld + r] = in[r * in_ld + c] for r < rows, c < cols (complex doubles), through a 32 x 32 LDS tile so that both the
+// reads and the writes are coalesced.  The 1-D transforms along x then run on contiguous rows: rocFFT's strided plan for the
+// same transform (stride Py*Nz, batch Py*Nz) measured 2.06 ms against 0.4 ms + 0.5 ms for transpose + contiguous transform.
+__global__ void __launch_bounds__(256) k_transpose(int rows, int cols, const double2 *__restrict__ in, size_t in_ld, double2 *__restrict__ out,
+                                                   size_t out_ld)
+{
+    __shared__ double2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for(int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        if(r < rows && c < cols)
+            tile[ty + k][tx] = in[(size_t)r * in_ld + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for(int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;
+        if(r < rows && c < cols)
+            out[(size_t)c * out_ld + r] = tile[tx][ty + k];
+    }
+}
+
 void PMesh::slab_destroy()
 {
     if(slab.ready) {
@@ -439,6 +489,7 @@ void PMesh::slab_destroy()
         b.release();
     slab.C.release();
     slab.rho_k.release();
+    slab.work.release();
 }
 
 void PMesh::slab_init(int rank, int world)
@@ -465,7 +516,8 @@ void PMesh::slab_init(int rank, int world)
     MPG_FFT(hipfftPlanMany(&slab.p2d_c2r, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, slab.P));
     int n1[1] = {nmesh};
     int emb[1] = {nmesh};
-    MPG_FFT(hipfftPlanMany(&slab.p1d_fwd, 1, n1, emb, (int)S, 1, emb, (int)S, 1, HIPFFT_Z2Z, (int)S));
+    MPG_FFT(hipfftPlanMany(&slab.p1d_fwd, 1, n1, emb, 1, nmesh, emb, 1, nmesh, HIPFFT_Z2Z, (int)S)); // contiguous rows of kx
+    slab.work.reserve(2 * (size_t)nmesh * S);
     slab.ready = true;
 }
 
@@ -491,21 +543,23 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
     const int nz = nmesh / 2 + 1;
     const size_t ncplx = (size_t)nmesh * slab.Py * nz;
     const int y0 = slab.rank * slab.Py;
+    const size_t S = (size_t)slab.Py * nz;
     MPG_FFT(hipfftSetStream(slab.p1d_fwd, st));
-    MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)recvA, (hipfftDoubleComplex *)recvA, HIPFFT_FORWARD));
+    // [x][j] -> [j][x], j = (ky local, kz): the transforms along x run on contiguous rows
+    const dim3 tgrid_f((unsigned)((S + 31) / 32), (unsigned)((nmesh + 31) / 32)), tgrid_b((unsigned)((nmesh + 31) / 32), (unsigned)((S + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, tgrid_f, dim3(256), 0, st, nmesh, (int)S, (const double2 *)recvA, S, (double2 *)slab.rho_k.p, (size_t)nmesh);
+    MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.rho_k.p, (hipfftDoubleComplex *)slab.rho_k.p, HIPFFT_FORWARD));
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
-    MPG_HIP(hipMemcpyAsync(slab.rho_k.p, recvA, ncplx * sizeof(double2), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_potential_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, asmth2, pot_factor, invsinc2.p,
+    hipLaunchKernelGGL(k_potential_transfer<true>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, asmth2, pot_factor, invsinc2.p,
                        (double2 *)slab.rho_k.p);
-    const size_t S = (size_t)slab.Py * nz;
     for(int f = 0; f < 4; f++) {
-        // recvA serves as the work array [x][ky local][kz] of this function; the result is interleaved into sendB[x][f][..]
-        hipLaunchKernelGGL(k_force_transfer, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, f - 1, difffac.p, (const double2 *)slab.rho_k.p,
-                           (double2 *)recvA, 1, 0);
-        MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)recvA, (hipfftDoubleComplex *)recvA, HIPFFT_BACKWARD));
-        MPG_HIP(hipMemcpy2DAsync((double2 *)sendB + (size_t)f * S, 4 * S * sizeof(double2), recvA, S * sizeof(double2), S * sizeof(double2),
-                                 (size_t)nmesh, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_force_transfer<true>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, f - 1, difffac.p,
+                           (const double2 *)slab.rho_k.p, (double2 *)slab.work.p, 1, 0);
+        MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.work.p, (hipfftDoubleComplex *)slab.work.p, HIPFFT_BACKWARD));
+        // [j][x] -> sendB[x][f][j]: the block for rank d (its x-planes, all four functions) is contiguous
+        hipLaunchKernelGGL(k_transpose, tgrid_b, dim3(256), 0, st, (int)S, nmesh, (const double2 *)slab.work.p, (size_t)nmesh,
+                           (double2 *)sendB + (size_t)f * S, 4 * S);
     }
     MPG_HIP(hipGetLastError());
 }

@@ -128,7 +128,7 @@ class SlabDomain:
         """Returns (pos, mass, *fields) of [own | ghosts]: the particle set this rank builds its trees and its PM slab from.
         `fields`: further per-particle tensors ([n_own] or [n_own, k]) to carry along.  The send lists are kept so that
         ghost_update() can refresh per-particle data of the same ghosts later in the step."""
-        if self.world == 1:
+        if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
             self.send_idx, self.send_counts = None, None
             return (own_pos, own_mass) + tuple(fields)
         col = tree_column(own_pos[:, 0], self.box, self.La)
@@ -148,10 +148,13 @@ class SlabDomain:
 
     def ghost_update(self, own_t):
         """Rows of `own_t` ([n_own] or [n_own, k], any dtype) for this rank's ghosts, fetched from their owners, in ghost order."""
-        if self.world == 1:
+        if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
             return own_t[:0]
         t = own_t[self.send_idx]
-        flat = t.reshape(t.shape[0], -1).to(torch.float64)
+        width = 1
+        for d in own_t.shape[1:]:
+            width *= int(d)
+        flat = t.reshape(t.shape[0], width).to(torch.float64)   # (explicit width: a rank may have no ghosts to send)
         got = _exchange_rows(flat.contiguous(), self.send_counts, self.world, self.group, self.count_matrix)
         return got.reshape((got.shape[0],) + tuple(own_t.shape[1:])).to(own_t.dtype)
 
@@ -159,7 +162,7 @@ class SlabDomain:
         """The SPH loops on the distributed set need every neighbour within max(Hsml_i, Hsml_j) of an own gas particle to be
         local: the largest smoothing length of any rank must not exceed the import margin."""
         h = own_hsml.max().reshape(1) if own_hsml.numel() else torch.zeros(1, dtype=torch.float64, device=self.dev)
-        if self.world > 1:
+        if self.world > 1 or pm_slab.FORCE_COLLECTIVES:
             dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
         if float(h.item()) > self.margin:
             raise RuntimeError("largest smoothing length %g exceeds the ghost margin %g" % (float(h.item()), self.margin))
@@ -167,7 +170,7 @@ class SlabDomain:
     def set_global_top(self, n_own):
         """Moments of the tree nodes above level La from the sums over all ranks (call after dev_force_tree_build)."""
         self.eng.dev_tree_top_partial(self.La, n_own, self.partial)
-        if self.world > 1:
+        if self.world > 1 or pm_slab.FORCE_COLLECTIVES:
             dist.all_reduce(self.partial, group=self.group)
         levels = [self.partial.view(self.ntop_fine, 4)]
         for _ in range(self.La - 1):                       # a parent's 8 children are consecutive (octant-path numbering)

@@ -15,14 +15,19 @@ Nmesh 1024 on 8 GPUs, x4 for the inverse), large enough to run every link at its
 
 This module holds the collectives and the index logic only (torch tensors as buffers); all arithmetic is in the engine.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# MPG_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (lets a single-GPU box exercise the RCCL code path)
+FORCE_COLLECTIVES = bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
 
 
 def _all_to_all(recv, send, world, group=None):
     """recv[s-th block] <- rank s's send[my block].  RCCL all_to_all_single; backends without it (gloo, used by the
     CPU-launched tests that put two ranks on one GPU) gather everything and slice."""
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         recv.copy_(send)
         return
     try:
@@ -40,7 +45,7 @@ def _all_to_all(recv, send, world, group=None):
 
 def _ring_prev(recv, send, rank, world, group=None):
     """recv <- send of rank (rank + 1) % world (every rank passes its first planes to the previous rank)."""
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         recv.copy_(send)
         return
     parts = [torch.empty_like(send) for _ in range(world)]
@@ -111,7 +116,7 @@ class TargetExchange:
 
     def exchange(self, values, targets):
         """values: [N, k] caller order, rows `targets` fresh on this rank.  On return every row holds its owner's result."""
-        if self.world == 1:
+        if self.world == 1 and not FORCE_COLLECTIVES:
             return values
         nt = torch.tensor([targets.shape[0]], dtype=torch.int64, device=self.device)
         counts = [torch.zeros_like(nt) for _ in range(self.world)]

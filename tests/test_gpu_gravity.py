@@ -313,12 +313,12 @@ def test_load_order_torch_first():
     assert out.returncode == 0 and "gfx950" in out.stdout, out.stderr[-2000:]
 
 
-def _run_mgpu(tmp_path, name, nproc, mode, port):
+def _run_mgpu(tmp_path, name, nproc, mode, port, ic="s_zel"):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / name)
-    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode)
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode, MPG_MGPU_IC=ic)
     script = os.path.join(root, "tools", "mgpu_check.py")
     if nproc == 1:
         cmd = [sys.executable, script, out, "40"]
@@ -351,6 +351,16 @@ def test_two_ranks_match_one(tmp_path):
         assert_accel_parity(dm[:, 0:3], one[:, 0:3])
         assert np.abs(dm[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * np.abs(one[:, 3:6]).mean(), name
         assert np.abs(dm[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
+
+
+def test_distributed_particles_clustered(tmp_path):
+    """The distributed-particle path on a strongly clustered set (deep tree, thousands of nodes used unopened per target, very
+    unequal slabs): 2 and 4 ranks against one GPU."""
+    one = _run_mgpu(tmp_path, "c1.npy", 1, "single", 0, ic="s_clust")
+    for name, nproc, port in (("cd2.npy", 2, 29584), ("cd4.npy", 4, 29585)):
+        dm = _run_mgpu(tmp_path, name, nproc, "domain", port, ic="s_clust")
+        assert_accel_parity(dm[:, 0:3], one[:, 0:3])
+        assert np.abs(dm[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * np.abs(one[:, 3:6]).mean(), name
 
 
 def test_full_size_256_properties(pkg, orc):

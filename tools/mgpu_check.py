@@ -16,10 +16,14 @@ rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE"
 lr = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
 torch.cuda.set_device(lr)
 dev = torch.device("cuda", lr)
-if world > 1:
+grouped = world > 1 or bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
+if grouped:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29555")
     dist.init_process_group(os.environ.get("MPG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 G = 43.0071
-pos, mass, box = pkg.ics.s_zel(n)
+ic = os.environ.get("MPG_MGPU_IC", "s_zel")
+pos, mass, box = pkg.ics.s_clust(n, seed=5) if ic == "s_clust" else getattr(pkg.ics, ic)(n)
 N = len(pos)
 d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
 eng = pkg.Engine(lr)
@@ -82,7 +86,7 @@ else:
 torch.cuda.synchronize()
 if rank == 0:
     np.save(out, np.concatenate([acc.cpu().numpy(), gravpm.cpu().numpy(), pot.cpu().numpy()[:, None]], axis=1))
-if world > 1:
+if grouped:
     dist.barrier()
     dist.destroy_process_group()
 eng.close()

@@ -14,7 +14,10 @@ rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE"
 lr = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
 torch.cuda.set_device(lr)
 dev = torch.device("cuda", lr)
-if world > 1:
+grouped = world > 1 or bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
+if grouped:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29555")
     dist.init_process_group(os.environ.get("MPG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 mode = os.environ.get("MPG_MGPU_MODE", "single")
 pos, mass, box = pkg.ics.s_zel(n, box=8.0)
@@ -85,7 +88,7 @@ else:
 torch.cuda.synchronize()
 if rank == 0:
     np.savez(out, typ=typ, **{k: v.cpu().numpy() for k, v in res.items()})
-if world > 1:
+if grouped:
     dist.barrier()
     dist.destroy_process_group()
 eng.close()
