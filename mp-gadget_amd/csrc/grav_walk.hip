@@ -23,6 +23,7 @@
 // The kernel is bounded by fp64 VALU issue, not by HBM; MFMA is not applicable (pairwise
 // 1/r^2 with a per-pair table lookup is not a contraction).
 #include "grav_walk.h"
+#include "grav_pair.h"
 
 namespace mpg {
 
@@ -30,61 +31,6 @@ __device__ __forceinline__ double nearest_img(double x, double box, double invbo
 {
     // NEAREST(x, Box) of partmanager.h:99 for |x| <= Box: x - Box*rint(x/Box) (x -+ Box is exact there).
     return x - box * rint(x * invbox);
-}
-
-struct WTab {
-    double a, b; // T[t], T[t+1]
-};
-
-__device__ __forceinline__ double rsqrt_nr(double x)
-{
-    // v_rsq_f64 + one cubic Newton step -> full double precision; x > 0
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-(x * y), y, 1.0);
-    return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-
-template <bool POT>
-__device__ __forceinline__ void interact(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
-                                         const WTab *__restrict__ wf, const WTab *__restrict__ wp, double &ax, double &ay, double &az,
-                                         double &pot)
-{
-    // apply_accn_to_output, gravshort-tree.c:158-193
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double rinv = rsqrt_nr(fmax(r2, 1e-300));
-    const double r = r2 * rinv;                   // exactly 0 for the self interaction
-    const double ti = r * gp.inv_cell_dx;         // r / cellsize / dx, gravity.c:57-58
-    const bool inrange = ti < (double)(NTAB - 1); // tabindex >= NTAB-1: no contribution (gravity.c:60-61)
-    double fac = s.m * rinv * rinv * rinv;
-    double facpot = -s.m * rinv;
-    if(r2 < gp.h * gp.h) {
-        const double u = r / gp.h;
-        double wpk;
-        if(u < 0.5) {
-            fac = s.m * gp.h3inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
-            wpk = -2.8 + u * u * (5.333333333333 + u * u * (6.4 * u - 9.6));
-        }
-        else {
-            fac = s.m * gp.h3inv * (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
-            wpk = -3.2 + 0.066666666667 / u + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
-        }
-        facpot = s.m / gp.h * wpk;
-    }
-    const double tcl = inrange ? ti : 0.0;
-    const int t = (int)tcl;
-    // (t + 1 - i) and (i - t) of gravity.c:63 are both exact, so 1 - (i - t) is the same number as (t + 1 - i)
-    const double w1 = tcl - (double)t, w0 = 1.0 - w1;
-    const WTab f = wf[t];
-    const double wgt = inrange ? (w0 * f.a + w1 * f.b) : 0.0;
-    fac *= wgt;
-    ax = fma(dx, fac, ax);
-    ay = fma(dy, fac, ay);
-    az = fma(dz, fac, az);
-    if(POT) {
-        const WTab p = wp[t];
-        const double wpot = inrange ? (w0 * p.a + w1 * p.b) : 0.0;
-        pot = fma(facpot, wpot, pot);
-    }
 }
 
 template <bool POT, bool COUNT, bool FASTWRAP, int THRESH>
@@ -233,7 +179,7 @@ __global__ void __launch_bounds__(256, 6) k_grav_walk(const TreeView tv, const G
                     dy = nearest_img(sc.y - py, gp.box, gp.invbox);
                     dz = nearest_img(sc.z - pz, gp.box, gp.invbox);
                 }
-                interact<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
+                pair_force<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
             }
         }
         pc = 0;

@@ -26,65 +26,11 @@
 // of their node (FASTWRAP, decided on the host); for the unwrapped image (all pairs away from the box faces) the
 // arithmetic is bit-identical to the per-pair NEAREST of partmanager.h:99.
 #include "grav_walk.h"
+#include "grav_pair.h"
 
 namespace mpg {
 
-struct WTabD {
-    double a, b;
-};
-
 constexpr int STK = 160; // pending child ranges per group (LIFO): <= 7 per tree level + 8, 21 levels
-
-__device__ __forceinline__ double rsqrt_nr(double x)
-{
-    // v_rsq_f64 + one cubic Newton step -> full double precision; x > 0
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-(x * y), y, 1.0);
-    return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-
-template <bool POT>
-__device__ __forceinline__ void pair_force(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
-                                           const WTabD *__restrict__ wf, const float2 *__restrict__ wp, double &ax, double &ay,
-                                           double &az, double &pot)
-{
-    // apply_accn_to_output, gravshort-tree.c:158-193
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double rinv = rsqrt_nr(fmax(r2, 1e-300));
-    const double r = r2 * rinv;                   // exactly 0 for the self interaction
-    const double ti = r * gp.inv_cell_dx;         // r / cellsize / dx, gravity.c:57-58
-    const bool inrange = ti < (double)(NTAB - 1); // tabindex >= NTAB-1 contributes nothing (gravity.c:60-61)
-    double fac = s.m * rinv * rinv * rinv;
-    double facpot = -s.m * rinv;
-    if(r2 < gp.h * gp.h) {
-        const double u = r / gp.h;
-        double wpk;
-        if(u < 0.5) {
-            fac = s.m * gp.h3inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
-            wpk = -2.8 + u * u * (5.333333333333 + u * u * (6.4 * u - 9.6));
-        }
-        else {
-            fac = s.m * gp.h3inv * (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
-            wpk = -3.2 + 0.066666666667 / u + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
-        }
-        facpot = s.m / gp.h * wpk;
-    }
-    const double tcl = inrange ? ti : 0.0;
-    const int t = (int)tcl;
-    // (t + 1 - i) and (i - t) of gravity.c:63 are both exact, so 1 - (i - t) is the same number as (t + 1 - i)
-    const double w1 = tcl - (double)t, w0 = 1.0 - w1;
-    const WTabD f = wf[t];
-    const double wgt = inrange ? (w0 * f.a + w1 * f.b) : 0.0;
-    fac *= wgt;
-    ax = fma(dx, fac, ax);
-    ay = fma(dy, fac, ay);
-    az = fma(dz, fac, az);
-    if(POT) {
-        const float2 p = wp[t];
-        const double wpot = inrange ? (w0 * (double)p.x + w1 * (double)p.y) : 0.0;
-        pot = fma(facpot, wpot, pot);
-    }
-}
 
 __device__ __forceinline__ void image_shift(const int code, const GravParams &gp, const double px, const double py, const double pz,
                                             double &spx, double &spy, double &spz)
@@ -100,16 +46,16 @@ template <bool POT, bool COUNT, bool FASTWRAP>
 __global__ void __launch_bounds__(256, 3) k_grav_walk_coop(const TreeView tv, const GravParams gp, const WalkIO io, int2 *__restrict__ scratch,
                                                         const int cap, unsigned *__restrict__ err)
 {
-    __shared__ WTabD s_wf[NTAB];
+    __shared__ WTab s_wf[NTAB];
     __shared__ float2 s_wp[POT ? NTAB : 1];
     __shared__ unsigned s_stack[4 * 8 * STK];
     for(int i = threadIdx.x; i < NTAB - 1; i += blockDim.x) {
-        s_wf[i] = WTabD{(double)io.tab_force[i], (double)io.tab_force[i + 1]};
+        s_wf[i] = WTab{(double)io.tab_force[i], (double)io.tab_force[i + 1]};
         if(POT)
             s_wp[i] = make_float2(io.tab_pot[i], io.tab_pot[i + 1]);
     }
     if(threadIdx.x == 0) {
-        s_wf[NTAB - 1] = WTabD{0, 0};
+        s_wf[NTAB - 1] = WTab{0, 0};
         if(POT)
             s_wp[NTAB - 1] = make_float2(0.f, 0.f);
     }
@@ -121,7 +67,6 @@ __global__ void __launch_bounds__(256, 3) k_grav_walk_coop(const TreeView tv, co
     const int64_t gwave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int2 *__restrict__ list = scratch + (gwave * 8 + grp) * (int64_t)cap; // leaf entries grow up from 0, node entries down from cap-1
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * STK;            // pending child ranges of this group: (first << 4) | count
-    const int64_t npart = tv.npart;
 
     // chunks of 8 targets (one per group); XCD x (= blockIdx % 8, where the hardware places this block) owns a contiguous
     // part of the tree-ordered targets and its waves take chunks round-robin, so each private L2 serves one region of the tree

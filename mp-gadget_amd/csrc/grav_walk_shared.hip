@@ -18,63 +18,11 @@
 // The lists live in a per-wave scratch area and are read with wave-uniform addresses.  Kernel is persistent; the waves of
 // one XCD take chunks of 8 tree-ordered targets round-robin from that XCD's contiguous part of the target range.
 #include "grav_walk.h"
+#include "grav_pair.h"
 
 namespace mpg {
 
-struct WTabD {
-    double a, b;
-};
-
 constexpr int STK5 = 192; // pending child ranges per wave
-
-__device__ __forceinline__ double rsqrt_nr5(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-(x * y), y, 1.0);
-    return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-
-template <bool POT>
-__device__ __forceinline__ void pair_force5(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
-                                            const WTabD *__restrict__ wf, const float2 *__restrict__ wp, double &ax, double &ay,
-                                            double &az, double &pot)
-{
-    // apply_accn_to_output, gravshort-tree.c:158-193
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    const double rinv = rsqrt_nr5(fmax(r2, 1e-300));
-    const double r = r2 * rinv;
-    const double ti = r * gp.inv_cell_dx;
-    const bool inrange = ti < (double)(NTAB - 1);
-    double fac = s.m * rinv * rinv * rinv;
-    double facpot = -s.m * rinv;
-    if(r2 < gp.h * gp.h) {
-        const double u = r / gp.h;
-        double wpk;
-        if(u < 0.5) {
-            fac = s.m * gp.h3inv * (10.666666666667 + u * u * (32.0 * u - 38.4));
-            wpk = -2.8 + u * u * (5.333333333333 + u * u * (6.4 * u - 9.6));
-        }
-        else {
-            fac = s.m * gp.h3inv * (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
-            wpk = -3.2 + 0.066666666667 / u + u * u * (10.666666666667 + u * (-16.0 + u * (9.6 - 2.133333333333 * u)));
-        }
-        facpot = s.m / gp.h * wpk;
-    }
-    const double tcl = inrange ? ti : 0.0;
-    const int t = (int)tcl;
-    const double w1 = tcl - (double)t, w0 = 1.0 - w1;
-    const WTabD f = wf[t];
-    const double wgt = inrange ? (w0 * f.a + w1 * f.b) : 0.0;
-    fac *= wgt;
-    ax = fma(dx, fac, ax);
-    ay = fma(dy, fac, ay);
-    az = fma(dz, fac, az);
-    if(POT) {
-        const float2 p = wp[t];
-        const double wpot = inrange ? (w0 * (double)p.x + w1 * (double)p.y) : 0.0;
-        pot = fma(facpot, wpot, pot);
-    }
-}
 
 // ballot bit index = lane = g*8 + s: view the 64 bits as an 8x8 matrix (row g, column s) and extract column s as a byte
 __device__ __forceinline__ unsigned column_mask(unsigned long long b, int s)
@@ -89,16 +37,16 @@ template <bool POT, bool COUNT>
 __global__ void __launch_bounds__(256) k_grav_walk_shared(const TreeView tv, const GravParams gp, const WalkIO io, int2 *__restrict__ scratch,
                                                           const int cap, unsigned *__restrict__ err)
 {
-    __shared__ WTabD s_wf[NTAB];
+    __shared__ WTab s_wf[NTAB];
     __shared__ float2 s_wp[POT ? NTAB : 1];
     __shared__ uint2 s_stack[4 * STK5];
     for(int i = threadIdx.x; i < NTAB - 1; i += blockDim.x) {
-        s_wf[i] = WTabD{(double)io.tab_force[i], (double)io.tab_force[i + 1]};
+        s_wf[i] = WTab{(double)io.tab_force[i], (double)io.tab_force[i + 1]};
         if(POT)
             s_wp[i] = make_float2(io.tab_pot[i], io.tab_pot[i + 1]);
     }
     if(threadIdx.x == 0) {
-        s_wf[NTAB - 1] = WTabD{0, 0};
+        s_wf[NTAB - 1] = WTab{0, 0};
         if(POT)
             s_wp[NTAB - 1] = make_float2(0.f, 0.f);
     }
@@ -111,7 +59,6 @@ __global__ void __launch_bounds__(256) k_grav_walk_shared(const TreeView tv, con
     // per-wave lists (wave-uniform addresses): leaf entries grow up from 0, node entries down from cap-1
     int2 *__restrict__ list = scratch + gwave * (int64_t)cap;
     uint2 *stack = s_stack + wib * STK5;
-    const int64_t npart = tv.npart;
 
     const unsigned nchunks = (unsigned)((io.ntargets + 7) / 8);
     const unsigned xcd = blockIdx.x & 7;
@@ -262,7 +209,7 @@ __global__ void __launch_bounds__(256) k_grav_walk_shared(const TreeView tv, con
                     dx = fma(-rint(dx * gp.invbox), gp.box, dx);
                     dy = fma(-rint(dy * gp.invbox), gp.box, dy);
                     dz = fma(-rint(dz * gp.invbox), gp.box, dz);
-                    pair_force5<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
+                    pair_force<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
                 }
             }
             // ------------------------------------------------------------------ phase B2: node entries, 8 per step
@@ -290,7 +237,7 @@ __global__ void __launch_bounds__(256) k_grav_walk_shared(const TreeView tv, con
                     dx = fma(-rint(dx * gp.invbox), gp.box, dx);
                     dy = fma(-rint(dy * gp.invbox), gp.box, dy);
                     dz = fma(-rint(dz * gp.invbox), gp.box, dz);
-                    pair_force5<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
+                    pair_force<POT>(sc, dx, dy, dz, gp, s_wf, s_wp, ax, ay, az, pot);
                 }
             }
             guard = 0;
