@@ -60,3 +60,54 @@ def test_drift_error_codes(pkg, engine):
     vel[3, 1] = np.inf
     with pytest.raises(pkg.EngineError, match="non-finite"):
         engine.dev_drift_all_particles(dev(torch, pos), dev(torch, vel), 1.0, box)
+
+
+def test_three_force_kick_drift_steps_track_the_oracle(pkg, engine, orc):
+    """End to end across steps, everything device-resident: (PM + tree build + short-range walk) -> PM kick + short-range kick ->
+    drift, three times, against the same sequence on the CPU oracle.  The forces agree to ~1e-13 and the kicks / drifts are
+    bit-exact, so the trajectories stay together far below the force accuracy."""
+    import torch
+    n, nmesh, G = 16, 32, 43.0071
+    pos, mass, box = pkg.ics.s_zel(n)
+    N = len(pos)
+    dt = 2e-4 * box / np.sqrt(G)                                  # moves particles by a few per cent of the spacing per step
+    rng = np.random.RandomState(4)
+    vel = rng.standard_normal((N, 3)) * 0.02 * box / n / dt
+    eng = engine
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(TreeUseBH=0)
+    eng.gravshort_set_softenings(box / n)
+    f8 = dict(dtype=torch.float64, device="cuda")
+    d_pos, d_mass, d_vel = dev(torch, pos), dev(torch, mass), dev(torch, vel)
+    d_gpm, d_acc, d_prev, d_pot = torch.zeros(N, 3, **f8), torch.zeros(N, 3, **f8), torch.zeros(N, 3, **f8), torch.zeros(N, **f8)
+    Kd, Ko = pkg.KickFactors(), O.KickFactors()
+    for K in (Kd, Ko):
+        K.gravkick[0], K.bin_active[0], K.atime, K.MaxGasVel = dt, 1, 1.0, 1e30
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    o_pos, o_vel, o_prev = pos.copy(), vel.copy(), np.zeros((N, 3))
+    for step in range(3):
+        # device
+        eng.dev_bind_particles(d_pos, d_mass, box)
+        eng.dev_gravpm_force(d_gpm, None)
+        eng.dev_force_tree_build()
+        d_prev, d_acc = d_acc, d_prev
+        eng.dev_grav_short_tree(d_acc, prev_accel=d_prev, gravpm=d_gpm)
+        eng.dev_apply_pm_half_kick(d_vel, d_gpm, dt)
+        eng.dev_apply_half_kick(d_vel, d_acc, Kd)
+        eng.dev_drift_all_particles(d_pos, d_vel, dt, box)
+        eng.synchronize()
+        # oracle
+        gpm, _ = O.gravpm_force(o_pos, mass, box, nmesh, 1.5, G)
+        tr = orc.tree(o_pos, mass, box)
+        acc, _, _, _ = tr.grav_short_tree(par, oldacc=np.sqrt(((o_prev + gpm) ** 2).sum(1)) / G)
+        O.apply_pm_half_kick(orc, o_vel, gpm, dt)
+        assert O.apply_half_kick(orc, o_vel, acc, Ko) == 0
+        assert O.drift_all_particles(orc, o_pos, o_vel, dt, box) == 0
+        o_prev = acc
+        dp = np.abs(np.mod(d_pos.cpu().numpy() - o_pos + box / 2, box) - box / 2).max()
+        dv = np.abs(d_vel.cpu().numpy() - o_vel).max() / np.abs(o_vel).max()
+        assert dp <= 1e-11 * box / n and dv <= 1e-10, (step, dp, dv)
+    moved = np.abs(np.mod(o_pos - pos + box / 2, box) - box / 2).max()
+    assert moved > 0.02 * box / n                                   # the particles did move: the tree of step 3 is not the tree of step 1
