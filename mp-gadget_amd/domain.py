@@ -158,6 +158,32 @@ class SlabDomain:
         got = _exchange_rows(flat.contiguous(), self.send_counts, self.world, self.group, self.count_matrix)
         return got.reshape((got.shape[0],) + tuple(own_t.shape[1:])).to(own_t.dtype)
 
+    def migrate(self, own_pos, fields=()):
+        """After a drift: particles whose base PM cell has left this rank's slab go to their new owner, with all the per-particle
+        tensors in `fields` ([n_own] or [n_own, k]; the reference: domain_exchange, exchange.c).  Returns (pos, *fields) of the
+        new own set: the particles that stayed, in their old order, followed by the arrivals in rank order."""
+        if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
+            return (own_pos,) + tuple(fields)
+        owner = pm_slab.slab_of_cells(own_pos[:, 0], self.cellsize, self.nmesh, self.world)
+        stay = torch.nonzero(owner == self.rank).squeeze(1)
+        idxs, counts = [], []
+        for d in range(self.world):
+            idx = torch.nonzero(owner == d).squeeze(1) if d != self.rank else stay[:0]
+            idxs.append(idx)
+            counts.append(int(idx.shape[0]))
+        send_idx = torch.cat(idxs)
+        allc = _count_matrix(counts, self.world, self.dev, self.group)
+        out = []
+        for t in (own_pos,) + tuple(fields):
+            width = 1
+            for dd in t.shape[1:]:
+                width *= int(dd)
+            flat = t[send_idx].reshape(send_idx.shape[0], width).to(torch.float64).contiguous()
+            got = _exchange_rows(flat, counts, self.world, self.group, allc)
+            got = got.reshape((got.shape[0],) + tuple(t.shape[1:])).to(t.dtype)
+            out.append(torch.cat([t[stay], got]).contiguous())
+        return tuple(out)
+
     def check_hsml_margin(self, own_hsml):
         """The SPH loops on the distributed set need every neighbour within max(Hsml_i, Hsml_j) of an own gas particle to be
         local: the largest smoothing length of any rank must not exceed the import margin."""

@@ -111,3 +111,32 @@ def test_three_force_kick_drift_steps_track_the_oracle(pkg, engine, orc):
         assert dp <= 1e-11 * box / n and dv <= 1e-10, (step, dp, dv)
     moved = np.abs(np.mod(o_pos - pos + box / 2, box) - box / 2).max()
     assert moved > 0.02 * box / n                                   # the particles did move: the tree of step 3 is not the tree of step 1
+
+
+def test_distributed_evolution_matches_one_gpu(tmp_path):
+    """A complete distributed loop - ghost import, tree with the global top, slab PM, walk, kicks, drift, particle migration - for
+    three steps on 2 and 4 ranks (sharing this GPU over gloo) against the same three steps on one GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(name, nproc, mode, port):
+        out = str(tmp_path / name)
+        env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode)
+        script = os.path.join(root, "tools", "mgpu_evolve_check.py")
+        cmd = [sys.executable, script, out, "24"] if nproc == 1 else \
+              [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, out, "24"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return np.load(out)
+
+    one = run("one.npy", 1, "single", 0)
+    for name, nproc, port in (("e2.npy", 2, 29595), ("e4.npy", 4, 29596)):
+        d = run(name, nproc, "domain", port)
+        dp = np.abs(d[:, 0:3] - one[:, 0:3])
+        dp = np.minimum(dp, np.abs(dp - np.abs(one[:, 0:3]).max()))       # (a particle sitting on the periodic seam)
+        assert np.median(dp) <= 1e-12 * np.abs(one[:, 0:3]).max(), name
+        assert np.abs(d[:, 3:6] - one[:, 3:6]).max() <= 1e-9 * np.abs(one[:, 3:6]).max(), name
+        assert np.abs(d[:, 6:9] - one[:, 6:9]).max() <= 2 * 0.002 * np.abs(one[:, 6:9]).mean(), name

@@ -201,3 +201,47 @@ def test_ghost_exchange_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _migrate_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    pkg = importlib.import_module("mp-gadget_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    box, nmesh = 8.0, 32
+    dom = pkg.domain.SlabDomain(None, box, nmesh, rank, world, torch.device("cpu"), rcut=1.0)
+    g = torch.Generator().manual_seed(11)
+    pos = torch.rand(3000, 3, dtype=torch.float64, generator=g) * box      # the same global set on every rank
+    ids = torch.arange(3000, dtype=torch.float64)
+    own = dom.select_own(pos)
+    p, i = pos[own].clone(), ids[own].clone()
+    p[:, 0] = torch.remainder(p[:, 0] + 1.7, box)                          # a "drift" that carries many particles across slab faces
+    p2, i2 = dom.migrate(p, (i,))
+    owner = pkg.pm_slab.slab_of_cells(p2[:, 0], box / nmesh, nmesh, world)
+    ok = bool((owner == rank).all())
+    # global check: every id exactly once, carried with its own position
+    cnt = torch.zeros(3000, dtype=torch.float64)
+    cnt[i2.long()] += 1
+    dist.all_reduce(cnt)
+    ok &= bool((cnt == 1).all())
+    exp = pos[i2.long()].clone()
+    exp[:, 0] = torch.remainder(exp[:, 0] + 1.7, box)
+    ok &= bool(torch.equal(exp, p2))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_particle_migration_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_migrate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

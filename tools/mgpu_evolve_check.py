@@ -1,0 +1,93 @@
+"""Three force / kick / drift steps with the particles distributed over ranks (x-slab domains, ghost import every step, migration
+after every drift), saving rank 0's gather of the final state by particle id; world == 1 without MPG_MGPU_MODE=domain runs the
+same steps on one GPU.  Used by tests/test_gpu_timestep.py::test_distributed_evolution_matches_one_gpu."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("mp-gadget_amd")
+import torch
+import torch.distributed as dist
+
+out, n = sys.argv[1], int(sys.argv[2])
+rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+lr = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(lr)
+dev = torch.device("cuda", lr)
+grouped = world > 1 or bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
+if grouped:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29556")
+    dist.init_process_group(os.environ.get("MPG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+mode = os.environ.get("MPG_MGPU_MODE", "single")
+G = 43.0071
+nmesh = 2 * n
+pos, mass, box = pkg.ics.s_zel(n)
+N = len(pos)
+dt = 2e-4 * box / np.sqrt(G)
+vel = np.random.RandomState(4).standard_normal((N, 3)) * 0.02 * box / n / dt
+f8 = dict(dtype=torch.float64, device=dev)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+eng = pkg.Engine(lr)
+eng.use_torch_stream()
+eng.gravshort_fill_ntab(0, 1.5)
+eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+eng.set_gravshort_treepar(TreeUseBH=0)
+eng.gravshort_set_softenings(box / n)
+K = pkg.KickFactors()
+K.gravkick[0], K.bin_active[0], K.atime, K.MaxGasVel = dt, 1, 1.0, 1e30
+if mode == "single":
+    d_pos, d_mass, d_vel = T(pos), T(mass), T(vel)
+    acc, prev, gpm = torch.zeros(N, 3, **f8), torch.zeros(N, 3, **f8), torch.zeros(N, 3, **f8)
+    for step in range(3):
+        eng.dev_bind_particles(d_pos, d_mass, box)
+        eng.dev_gravpm_force(gpm, None)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gpm)
+        eng.dev_apply_pm_half_kick(d_vel, gpm, dt)
+        eng.dev_apply_half_kick(d_vel, acc, K)
+        eng.dev_drift_all_particles(d_pos, d_vel, dt, box)
+    final = torch.cat([d_pos, d_vel, acc], dim=1)
+else:
+    dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut=6.0 * 1.5 * box / nmesh)
+    spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
+    g_pos = T(pos)
+    own = dom.select_own(g_pos)
+    o_id = own.to(torch.float64)
+    o_pos, o_mass, o_vel = g_pos[own].contiguous(), T(mass)[own].contiguous(), T(vel)[own].contiguous()
+    o_acc = torch.zeros(own.shape[0], 3, **f8)
+    for step in range(3):
+        n_own = o_pos.shape[0]
+        lpos, lmass = dom.import_ghosts(o_pos, o_mass)
+        nl = lpos.shape[0]
+        eng.dev_bind_particles(lpos, lmass, box)
+        eng.dev_force_tree_build()
+        dom.set_global_top(n_own)
+        tg = dom.own_targets(n_own, nl)
+        gpm, acc, prev = torch.zeros(nl, 3, **f8), torch.zeros(nl, 3, **f8), torch.zeros(nl, 3, **f8)
+        prev[:n_own] = o_acc
+        spm.force(tg, gpm, None)
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gpm, active=tg)
+        o_acc = acc[:n_own].contiguous()
+        o_gpm = gpm[:n_own].contiguous()
+        eng.dev_apply_pm_half_kick(o_vel, o_gpm, dt)
+        eng.dev_apply_half_kick(o_vel, o_acc, K)
+        eng.dev_drift_all_particles(o_pos, o_vel, dt, box)
+        eng.synchronize()
+        o_pos, o_mass, o_vel, o_acc, o_id = dom.migrate(o_pos, (o_mass, o_vel, o_acc, o_id))
+    final = torch.zeros(N, 9, **f8)
+    ids = o_id.long()
+    final[ids] = torch.cat([o_pos, o_vel, o_acc], dim=1)
+    pkg.pm_slab.TargetExchange(world, dev).exchange(final, ids.to(torch.int32))
+    cnt = torch.tensor([o_pos.shape[0]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(cnt)
+    assert int(cnt.item()) == N, "particles lost or duplicated in migration"
+torch.cuda.synchronize()
+if rank == 0:
+    np.save(out, final.cpu().numpy())
+if grouped:
+    dist.barrier()
+    dist.destroy_process_group()
+eng.close()
