@@ -279,6 +279,11 @@ int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int
                             const unsigned char *d_tb_hydro, const double *d_hydroaccel, double *d_entropy, const double *d_dtentropy,
                             const mpg_kick_factors *K);
 
+/* get_timestep_gravity_dloga (timestep.c:1039-1074) for every particle: dloga = H * sqrt(2 ErrTolIntAccuracy a (FORCE_SOFTENING/2.8)
+ * / |a_phys|), a_phys = (FullTreeGravAccel + GravPM) / a^2.  Uses the softening set by mpg_gravshort_set_softenings. */
+int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_gravaccel, const double *d_gravpm, double atime, double hubble,
+                                   double ErrTolIntAccuracy, double *d_dloga);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

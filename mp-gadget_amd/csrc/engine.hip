@@ -613,6 +613,17 @@ int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int
     API_END
 }
 
+int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_gravaccel, const double *d_gravpm, double atime, double hubble,
+                                   double ErrTolIntAccuracy, double *d_dloga)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_gravaccel && d_gravpm && d_dloga && n >= 0, "null argument");
+    MPG_CHECK(eng->GravitySoftening > 0, "timestep: gravshort_set_softenings has not been called");
+    MPG_HIP(hipSetDevice(eng->device));
+    launch_timestep_gravity(n, d_gravaccel, d_gravpm, atime, hubble, ErrTolIntAccuracy, 2.8 * eng->GravitySoftening, d_dloga, eng->stream);
+    API_END
+}
+
 /* ------------------------------ host (AoS) path ------------------------------ */
 
 static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)

@@ -10,4 +10,6 @@ void launch_pm_half_kick(int64_t n, double *vel, const double *gravpm, const uin
 void launch_half_kick(int64_t n, const int *active, int64_t nactive, double *vel, const double *gacc, const uint8_t *type, const uint8_t *flags,
                       const uint8_t *tbg, const uint8_t *tbh, const double *hacc, double *entropy, const double *dtentropy,
                       const mpg_kick_factors &K, unsigned *err, hipStream_t st);
+void launch_timestep_gravity(int64_t n, const double *gacc, const double *gpm, double atime, double hubble, double errtol, double soft,
+                             double *dloga, hipStream_t st);
 } // namespace mpg

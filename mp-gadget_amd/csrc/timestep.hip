@@ -119,7 +119,37 @@ __global__ void __launch_bounds__(256) k_half_kick(int64_t n, const int *__restr
         vel[3 * i + j] = v[j];
 }
 
+// get_timestep_gravity_dloga, timestep.c:1039-1074
+__global__ void __launch_bounds__(256) k_timestep_gravity(int64_t n, const double *__restrict__ gacc, const double *__restrict__ gpm, double atime,
+                                                          double hubble, double errtol, double soft, double *__restrict__ dloga)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const double a2inv = 1 / (atime * atime);
+    double ax = a2inv * gacc[3 * i + 0];
+    double ay = a2inv * gacc[3 * i + 1];
+    double az = a2inv * gacc[3 * i + 2];
+    ay += a2inv * gpm[3 * i + 1];
+    ax += a2inv * gpm[3 * i + 0];
+    az += a2inv * gpm[3 * i + 2];
+    double ac2 = ax * ax + ay * ay + az * az;
+    if(ac2 == 0)
+        ac2 = 1.0e-60;
+    const double ac = sqrt(ac2);
+    const double dt = sqrt(2 * errtol * atime * (soft / 2.8) / ac);
+    dloga[i] = dt * hubble;
+}
+
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+void launch_timestep_gravity(int64_t n, const double *gacc, const double *gpm, double atime, double hubble, double errtol, double soft,
+                             double *dloga, hipStream_t st)
+{
+    if(n > 0)
+        hipLaunchKernelGGL(k_timestep_gravity, dim3(nblk(n)), dim3(256), 0, st, n, gacc, gpm, atime, hubble, errtol, soft, dloga);
+    MPG_HIP(hipGetLastError());
+}
 
 void launch_drift(int64_t n, double *pos, const double *vel, const uint8_t *type, const uint8_t *flags, double *hsml, const double *dthsml,
                   double ddrift, double box, const double shift[3], unsigned *err, hipStream_t st)

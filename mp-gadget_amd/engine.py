@@ -312,6 +312,10 @@ class Engine:
                                                   _ptr(vel), _ptr(gravaccel), _ptr(type), _ptr(flags), _ptr(tb_grav), _ptr(tb_hydro),
                                                   _ptr(hydroaccel), _ptr(entropy), _ptr(dtentropy), C.byref(K)))
 
+    def dev_timestep_gravity_dloga(self, gravaccel, gravpm, atime, hubble, ErrTolIntAccuracy, dloga):
+        self._ck(self.lib.mpg_dev_timestep_gravity_dloga(self.h, C.c_int64(gravaccel.shape[0]), _ptr(gravaccel), _ptr(gravpm), C.c_double(atime),
+                                                         C.c_double(hubble), C.c_double(ErrTolIntAccuracy), _ptr(dloga)))
+
     def dev_tree_top_partial(self, La, n_own, out):
         self._ck(self.lib.mpg_dev_tree_top_partial(self.h, int(La), C.c_int64(n_own), _ptr(out)))
 

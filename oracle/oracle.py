@@ -455,3 +455,13 @@ def apply_half_kick(orc, vel, gravaccel, K, active=None, type=None, flags=None, 
     L.ots_apply_half_kick.argtypes = [C.c_int64, C.c_void_p, C.c_int64, _dp, _dp] + [C.c_void_p] * 7 + [C.POINTER(KickFactors)]
     return L.ots_apply_half_kick(len(vel), _u8(active), 0 if active is None else len(active), vel, gravaccel, _u8(type), _u8(flags),
                                  _u8(tb_grav), _u8(tb_hydro), _u8(hydroaccel), _u8(entropy), _u8(dtentropy), C.byref(K))
+
+
+def timestep_gravity_dloga(orc, gravaccel, gravpm, atime, hubble, ErrTolIntAccuracy, force_softening):
+    """timestep.c:1039-1074; force_softening = FORCE_SOFTENING() = 2.8 * GravitySoftening"""
+    L = orc.lib
+    L.ots_timestep_gravity_dloga.restype = None
+    L.ots_timestep_gravity_dloga.argtypes = [C.c_int64, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
+    out = np.zeros(len(gravaccel))
+    L.ots_timestep_gravity_dloga(len(gravaccel), gravaccel, gravpm, atime, hubble, ErrTolIntAccuracy, force_softening, out)
+    return out

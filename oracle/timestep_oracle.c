@@ -104,3 +104,25 @@ int ots_apply_half_kick(int64_t n, const int *active, int64_t nactive, double *v
     }
     return rc;
 }
+
+/* get_timestep_gravity_dloga, timestep.c:1039-1074 (grav_acceleration2 + the gravity time-step criterion): dloga per particle */
+void ots_timestep_gravity_dloga(int64_t n, const double *gravaccel, const double *gravpm, double atime, double hubble,
+                                double ErrTolIntAccuracy, double force_softening, double *dloga)
+{
+    for(int64_t i = 0; i < n; i++) {
+        const double a2inv = 1 / (atime * atime);
+        double ax = a2inv * gravaccel[3 * i + 0];
+        double ay = a2inv * gravaccel[3 * i + 1];
+        double az = a2inv * gravaccel[3 * i + 2];
+        ay += a2inv * gravpm[3 * i + 1];
+        ax += a2inv * gravpm[3 * i + 0];
+        az += a2inv * gravpm[3 * i + 2];
+        double ac2 = ax * ax + ay * ay + az * az; /* this is now the physical acceleration */
+        if(ac2 == 0)
+            ac2 = 1.0e-60;
+        const double ac = sqrt(ac2);
+        /* mind the factor 2.8 difference between gravity and softening used here. */
+        const double dt = sqrt(2 * ErrTolIntAccuracy * atime * (force_softening / 2.8) / ac);
+        dloga[i] = dt * hubble; /* d a / a = dt * H */
+    }
+}

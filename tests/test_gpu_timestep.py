@@ -140,3 +140,18 @@ def test_distributed_evolution_matches_one_gpu(tmp_path):
         assert np.median(dp) <= 1e-12 * np.abs(one[:, 0:3]).max(), name
         assert np.abs(d[:, 3:6] - one[:, 3:6]).max() <= 1e-9 * np.abs(one[:, 3:6]).max(), name
         assert np.abs(d[:, 6:9] - one[:, 6:9]).max() <= 2 * 0.002 * np.abs(one[:, 6:9]).mean(), name
+
+
+def test_timestep_gravity_dloga(pkg, engine, orc):
+    import torch
+    rng = np.random.RandomState(2)
+    n = 50001
+    acc, gpm = rng.standard_normal((n, 3)) * 1e-3, rng.standard_normal((n, 3)) * 1e-4
+    acc[7], gpm[7] = 0.0, 0.0                                     # zero acceleration: the 1e-60 guard (timestep.c:1054-1055)
+    engine.set_gravshort_treepar()
+    engine.gravshort_set_softenings(0.5)                          # GravitySoftening = 0.5 / 30; FORCE_SOFTENING = 2.8 times that
+    out = torch.zeros(n, dtype=torch.float64, device="cuda")
+    engine.dev_timestep_gravity_dloga(dev(torch, acc), dev(torch, gpm), 0.25, 0.7, 0.025, out)
+    engine.synchronize()
+    ref = O.timestep_gravity_dloga(orc, acc, gpm, 0.25, 0.7, 0.025, 2.8 * 0.5 / 30.)
+    assert np.abs(out.cpu().numpy() / ref - 1).max() <= 4e-16
