@@ -510,8 +510,8 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
         act = torch.nonzero(ltyp[:n_own] == 0).squeeze(1).to(torch.int32).contiguous()
         eng.dev_density(a, t, active=act)
         dom.check_hsml_margin(a["hsml"][:n_own])
-        for k in FIELDS:
-            a[k][n_own:] = dom.ghost_update(a[k][:n_own].contiguous())
+        for k, g in zip(FIELDS, dom.ghost_update_many([a[k][:n_own] for k in FIELDS])):
+            a[k][n_own:] = g
         eng.dev_force_tree_calc_hmax()
         eng.dev_hydro_force(a, t, active=act)
         eng.synchronize()

@@ -103,6 +103,29 @@ def _exchange_rows(send, counts, world, group=None, allc=None):
     return out
 
 
+def _pack_rows(tensors, idx):
+    """Rows `idx` of several per-particle tensors ([n] or [n, k], any dtype) side by side in one float64 buffer."""
+    cols = []
+    for t in tensors:
+        w = 1
+        for d in t.shape[1:]:
+            w *= int(d)
+        cols.append(t[idx].reshape(idx.shape[0], w).to(torch.float64))
+    return torch.cat(cols, dim=1).contiguous() if len(cols) > 1 else cols[0].contiguous()
+
+
+def _unpack_rows(buf, like):
+    """Inverse of _pack_rows for the received buffer: one tensor per entry of `like` (shape[1:] and dtype taken from it)."""
+    out, c = [], 0
+    for t in like:
+        w = 1
+        for d in t.shape[1:]:
+            w *= int(d)
+        out.append(buf[:, c:c + w].reshape((buf.shape[0],) + tuple(t.shape[1:])).to(t.dtype))
+        c += w
+    return out
+
+
 class SlabDomain:
     """Ownership, ghost import and the global top of the tree for one rank.  `rcut` is the short-range cut-off radius in
     length units (Rcut * Asmth * cell size, gravshort-tree.c:102)."""
@@ -143,20 +166,23 @@ class SlabDomain:
         self.send_idx = torch.cat(idxs) if idxs else torch.zeros(0, dtype=torch.int64, device=self.dev)
         self.send_counts = counts
         self.count_matrix = _count_matrix(counts, self.world, self.dev, self.group)
-        out = [self.ghost_update(t) for t in (own_pos, own_mass) + tuple(fields)]
-        return tuple(torch.cat([t, g]).contiguous() for t, g in zip((own_pos, own_mass) + tuple(fields), out))
+        own = (own_pos, own_mass) + tuple(fields)                 # one message per peer carries all fields
+        got = _exchange_rows(_pack_rows(own, self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
+        return tuple(torch.cat([t, g]).contiguous() for t, g in zip(own, _unpack_rows(got, own)))
 
     def ghost_update(self, own_t):
         """Rows of `own_t` ([n_own] or [n_own, k], any dtype) for this rank's ghosts, fetched from their owners, in ghost order."""
         if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
             return own_t[:0]
-        t = own_t[self.send_idx]
-        width = 1
-        for d in own_t.shape[1:]:
-            width *= int(d)
-        flat = t.reshape(t.shape[0], width).to(torch.float64)   # (explicit width: a rank may have no ghosts to send)
-        got = _exchange_rows(flat.contiguous(), self.send_counts, self.world, self.group, self.count_matrix)
-        return got.reshape((got.shape[0],) + tuple(own_t.shape[1:])).to(own_t.dtype)
+        got = _exchange_rows(_pack_rows((own_t,), self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
+        return _unpack_rows(got, (own_t,))[0]
+
+    def ghost_update_many(self, own_tensors):
+        """ghost_update for several tensors with one message per peer; returns the list of ghost rows."""
+        if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
+            return [t[:0] for t in own_tensors]
+        got = _exchange_rows(_pack_rows(tuple(own_tensors), self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
+        return _unpack_rows(got, tuple(own_tensors))
 
     def migrate(self, own_pos, fields=()):
         """After a drift: particles whose base PM cell has left this rank's slab go to their new owner, with all the per-particle
@@ -173,16 +199,9 @@ class SlabDomain:
             counts.append(int(idx.shape[0]))
         send_idx = torch.cat(idxs)
         allc = _count_matrix(counts, self.world, self.dev, self.group)
-        out = []
-        for t in (own_pos,) + tuple(fields):
-            width = 1
-            for dd in t.shape[1:]:
-                width *= int(dd)
-            flat = t[send_idx].reshape(send_idx.shape[0], width).to(torch.float64).contiguous()
-            got = _exchange_rows(flat, counts, self.world, self.group, allc)
-            got = got.reshape((got.shape[0],) + tuple(t.shape[1:])).to(t.dtype)
-            out.append(torch.cat([t[stay], got]).contiguous())
-        return tuple(out)
+        own = (own_pos,) + tuple(fields)
+        got = _unpack_rows(_exchange_rows(_pack_rows(own, send_idx), counts, self.world, self.group, allc), own)
+        return tuple(torch.cat([t[stay], g]).contiguous() for t, g in zip(own, got))
 
     def check_hsml_margin(self, own_hsml):
         """The SPH loops on the distributed set need every neighbour within max(Hsml_i, Hsml_j) of an own gas particle to be
