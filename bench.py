@@ -104,12 +104,26 @@ def main():
     n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / (8 * world))) * 8 * world)
     nmesh = 2 * n
     gen = getattr(pkg.ics, args.ic)
-    pos, mass, box = gen(n)
-    N = len(pos)
+    slabwise = multi and args.mgpu == "domain" and args.ic == "s_grid" and world > 1 and n % world == 0
+    if slabwise:
+        # every rank generates only the grid planes its slab can own: its n/world planes and one more on either side (the
+        # +-0.15 spacing jitter moves no particle further); the union over ranks is exactly s_grid(n)
+        lo, hi = rank * (n // world), (rank + 1) * (n // world)
+        parts = [pkg.ics.s_grid_planes(n, max(lo - 1, 0), min(hi + 1, n))]
+        if lo == 0:
+            parts.append(pkg.ics.s_grid_planes(n, n - 1, n))
+        if hi == n:
+            parts.append(pkg.ics.s_grid_planes(n, 0, 1))
+        pos = np.concatenate([p[0] for p in parts])
+        mass = np.concatenate([p[1] for p in parts])
+        box = parts[0][2]
+        N = n ** 3
+    else:
+        pos, mass, box = gen(n)
+        N = len(pos)
     d_pos = torch.from_numpy(pos).to(dev)
     d_mass = torch.from_numpy(mass).to(dev)
     del pos
-
     eng = pkg.Engine(local_rank)
     eng.use_torch_stream()
     eng.set_walk_threshold(args.thresh)
@@ -121,10 +135,11 @@ def main():
     eng.gravshort_set_softenings(box / n)
     eng.dev_bind_particles(d_pos, d_mass, box)
 
-    gravpm = torch.zeros(N, 3, dtype=torch.float64, device=dev)
-    acc = torch.zeros(N, 3, dtype=torch.float64, device=dev)
-    prev = torch.zeros(N, 3, dtype=torch.float64, device=dev)
-    pot = torch.zeros(N, dtype=torch.float64, device=dev)
+    NB = int(d_pos.shape[0])    # particles bound at set-up (all of them, except in the slab-wise domain mode)
+    gravpm = torch.zeros(NB, 3, dtype=torch.float64, device=dev)
+    acc = torch.zeros(NB, 3, dtype=torch.float64, device=dev)
+    prev = torch.zeros(NB, 3, dtype=torch.float64, device=dev)
+    pot = torch.zeros(NB, dtype=torch.float64, device=dev)
     # N > 1: "slab" = x-slab PM (two all-to-all transposes per step) with the particles of the slab as
     # PM-readout and walk targets; "replicated" = every rank does the whole PM, targets are contiguous tree-slot ranges
     pm_ms = [0.0, 0]
@@ -134,6 +149,9 @@ def main():
         own = dom.select_own(d_pos)
         own_pos, own_mass = d_pos[own].contiguous(), d_mass[own].contiguous()
         n_own = int(own.shape[0])
+        tot = torch.tensor([n_own], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        assert int(tot.item()) == N, "the ranks' own sets do not add up to the particle set (%d of %d)" % (int(tot.item()), N)
         del d_pos, d_mass, own, gravpm, acc, prev, pot      # from here on this rank holds its own particles and their ghosts only
         torch.cuda.empty_cache()
         spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)

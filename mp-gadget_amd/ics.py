@@ -13,9 +13,12 @@ import numpy as np
 _MASK = (1 << 64) - 1
 
 
-def xorshift64_uniform(count, seed=1234567):
+def xorshift64_uniform(count, seed=1234567, skip=0):
     """u = (s >> 11) * 2^-53 with s ^= s<<13; s ^= s>>7; s ^= s<<17 (64-bit), vectorised by jumping:
-    the stream is strictly sequential, so generate it with a small blocked python loop over numpy uint64."""
+    the stream is strictly sequential, so generate it with a small blocked python loop over numpy uint64.
+    skip: number of draws of the stream to jump over first (GF(2) jump, O(64^2 log skip))."""
+    if skip:
+        seed = _apply_gf2(_xorshift_jump_matrix(int(skip)), int(seed))
     out = np.empty(count, dtype=np.float64)
     s = np.uint64(seed)
     # sequential recurrence; ~1e7 draws/s is not reachable in pure python, so use the linear (GF(2)) structure:
@@ -82,6 +85,20 @@ def _apply_gf2(M, v):
         v >>= 1
         b += 1
     return r
+
+
+def s_grid_planes(n, ix0, ix1, box=None, seed=1234567, amp=0.3):
+    """The particles of s_grid(n) with grid index ix in [ix0, ix1) (a contiguous range of the particle numbering), without
+    generating the others: lets every rank of a multi-GPU run build only its own slab of a large set."""
+    if box is None:
+        box = 64000.0 * n / 64
+    sp = box / n
+    i0, i1 = ix0 * n * n, ix1 * n * n
+    u = xorshift64_uniform(3 * (i1 - i0), seed, skip=3 * i0).reshape(i1 - i0, 3)
+    idx = np.arange(i0, i1, dtype=np.int64)
+    ijk = np.stack([idx // (n * n), (idx // n) % n, idx % n], axis=1).astype(np.float64)
+    pos = np.fmod((ijk + 0.5 + amp * (u - 0.5)) * sp + box, box)
+    return pos, np.ones(i1 - i0, dtype=np.float32), box
 
 
 def s_grid(n, box=None, seed=1234567, amp=0.3):

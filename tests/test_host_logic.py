@@ -245,3 +245,11 @@ def test_particle_migration_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_sgrid_planes_equal_slices_of_the_full_set(pkg):
+    n = 24
+    full, _, box = pkg.ics.s_grid(n)
+    for a, b in ((0, 5), (7, 19), (23, 24)):
+        part, m, box2 = pkg.ics.s_grid_planes(n, a, b)
+        assert box2 == box and np.array_equal(part, full[a * n * n:b * n * n]) and len(m) == len(part)
