@@ -292,12 +292,15 @@ int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_g
  *                                            values per peer block (P * Py * (Nmesh/2+1)) and the doubles of one mesh plane.
  *   mpg_dev_pm_slab_forward_a(sendA)         deposit the bound particles onto this rank's planes, 2-D r2c, pack:
  *                                            sendA[world][cplx_per_peer] complex      -> all-to-all -> recvA
- *   mpg_dev_pm_slab_forward_b(recvA, sendB)  1-D c2c along x, potential_transfer, 4 x (force_transfer, inverse 1-D c2c):
- *                                            sendB[world][4 * cplx_per_peer] complex  -> all-to-all -> recvB
- *   mpg_dev_pm_slab_inverse_c(recvB, ghost_send)  2-D c2r of Potential, ForceX, ForceY, ForceZ; ghost_send[4][plane] = this
- *                                            rank's first planes                      -> rank r sends them to rank r-1
- *   mpg_dev_pm_slab_readout(ghost_recv, targets, n, GravPM, Potential)   readout_force_* / readout_potential (gravpm.c:499-510)
- *                                            for the listed particles, whose base cell must lie in this rank's slab.
+ *   mpg_dev_pm_slab_forward_b(recvA, sendB)  1-D c2c along x, potential_transfer, inverse 1-D c2c of the potential:
+ *                                            sendB[world][cplx_per_peer] complex      -> all-to-all -> recvB
+ *   mpg_dev_pm_slab_inverse_c(recvB, ghost_send)  2-D c2r: the potential on this rank's planes; ghost_send[5][plane] = its first 3
+ *                                            planes (for the previous rank) and its last 2 (for the next rank)
+ *   mpg_dev_pm_slab_readout(ghost_recv, targets, n, GravPM, Potential)   ghost_recv[5][plane] = the next rank's first 3 planes, then
+ *                                            the previous rank's last 2.  Forces = 4-point differences of the potential (the
+ *                                            real-space form of force_transfer, gravpm.c:456-489), then readout_force_* /
+ *                                            readout_potential (gravpm.c:499-510) for the listed particles, whose base cell must
+ *                                            lie in this rank's slab.
  * Every rank binds the same particle set (mpg_dev_bind_particles); a particle's CIC cloud is deposited by the owners of the
  * planes it touches, so no region exchange is needed.  world == 1 reproduces mpg_dev_gravpm_force to FFT round-off. */
 int mpg_dev_pm_slab_init(mpg_engine *eng, int rank, int world, int64_t *cplx_per_peer, int64_t *plane_doubles);

@@ -264,6 +264,8 @@ int mpg_gravshort_fill_ntab(mpg_engine *eng, int window_type, double Asmth, cons
 int mpg_gravpm_init_periodic(mpg_engine *eng, double BoxSize, double Asmth, int Nmesh, double G)
 {
     API_BEGIN
+    if(eng)
+        eng->pm.kspace_force = getenv("MPG_PM_KSPACE_FORCE") != nullptr;
     MPG_CHECK(eng, "null engine");
     MPG_HIP(hipSetDevice(eng->device));
     eng->pm.init(BoxSize, Asmth, Nmesh, G, eng->stream);

@@ -11,6 +11,7 @@ struct PMesh {
     double box = 0, Asmth = 0, G = 0, cellsize = 0;
     int nmesh = 0;
     bool have_plans = false;
+    bool kspace_force = false; // true: forces by four inverse transforms as the reference does; false: by differencing the potential (pm.hip)
     hipfftHandle plan_r2c{}, plan_c2r{};
     DevBuf<double> real;    // Nmesh^3
     DevBuf<double> rho_k;   // 2 * Nmesh^2 (Nmesh/2+1): potential in Fourier space after the transfer
@@ -33,7 +34,8 @@ struct PMesh {
         int rank = 0, world = 1, P = 0, Py = 0;
         bool ready = false;
         hipfftHandle p2d_r2c{}, p2d_c2r{}, p1d_fwd{};
-        DevBuf<double> realF[4]; // Potential, ForceX, ForceY, ForceZ: (P + 1) planes of Nmesh^2 each, the last is the ghost plane
+        DevBuf<double> phi;      // the potential: planes -2 .. P+2 of Nmesh^2 each (2 + 3 ghost planes around the slab)
+        DevBuf<double> force;    // one force component on planes 0 .. P (and the density slab before the forward transform)
         DevBuf<double> C;        // 2 * P * Nmesh * (Nmesh/2+1): the slab after / before the 2-D transforms
         DevBuf<double> rho_k;    // 2 * Nmesh * Py * (Nmesh/2+1): potential in Fourier space, layout [ky local][kz][kx]
         DevBuf<double> work;     // same size: per-function work array
@@ -44,12 +46,12 @@ struct PMesh {
     void slab_destroy();
     // deposit the particles whose CIC cloud touches this rank's planes, 2-D r2c, pack for the transpose: sendA[world][P][Py][Nz]
     void slab_forward_a(int64_t n, const double *d_pos, const float *d_mass, double *sendA, hipStream_t st);
-    // recvA[Nmesh][Py][Nz] (x slowest): 1-D transform along x, potential transfer; then per function the force transfer and
-    // the inverse 1-D transform straight into sendB[Nmesh][4][Py][Nz]
+    // recvA[Nmesh][Py][Nz] (x slowest): 1-D transform along x, potential transfer, inverse 1-D transform -> sendB[Nmesh][Py][Nz]
     void slab_forward_b(double *recvA, double *sendB, hipStream_t st);
-    // recvB[world][P][4][Py][Nz] -> 4 real slabs (2-D c2r); ghost_send[4][Nmesh^2] = first plane of each
+    // recvB[world][P][Py][Nz] -> the potential slab (2-D c2r); ghost_send[5][Nmesh^2] = its first 3 and last 2 planes
     void slab_inverse_c(const double *recvB, double *ghost_send, hipStream_t st);
-    // ghost_recv[4][Nmesh^2] = first planes of the next rank; CIC readout for `nt` targets (caller indices) that lie in the slab
+    // ghost_recv[5][Nmesh^2] = the next rank's first 3 planes, then the previous rank's last 2; forces by differencing the
+    // potential, CIC readout for `nt` targets (caller indices) that lie in the slab
     void slab_readout(const double *ghost_recv, const int *targets, int64_t nt, const double *d_pos, double *d_gravpm, double *d_potential,
                       hipStream_t st);
 };

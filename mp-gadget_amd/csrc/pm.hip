@@ -196,6 +196,61 @@ __global__ void __launch_bounds__(256) k_cic_readout(int64_t n, const double *__
         out[i] += acc;
 }
 
+// Force component along `axis` from the potential mesh by the 4-point central difference
+//     F = -[ 2/3 (phi[+1] - phi[-1]) - 1/12 (phi[+2] - phi[-2]) ] N / Box          (periodic)
+// This IS the reference's force_transfer (gravpm.c:456-489): its Fourier-space factor i * (-diff_kernel(w)) N/Box,
+// diff_kernel(w) = (8 sin w - sin 2w) / 6 ("the same as GADGET-2 but in fourier space: c1 = 2/3, c2 = 1/12"), is the symbol of
+// exactly this stencil, so differencing the potential in real space replaces three of the four inverse transforms (and their
+// transfer sweeps) by three streaming passes; the results differ from the Fourier-space form by rounding only.
+// nplanes / plane0: the x-planes held (all of them on one GPU); for axis 0 in the slab form, planes -2..-1 and P..P+1 are the
+// ghost planes stored around the slab (see slab_gradient).
+__global__ void __launch_bounds__(256) k_gradient_axis(int nmesh, int nplanes, int axis, double scale, const double *__restrict__ phi,
+                                                       double *__restrict__ out, int xghost)
+{
+    const size_t total = (size_t)nplanes * nmesh * nmesh;
+    const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int iz = (int)(ip % nmesh);
+    const size_t t = ip / nmesh;
+    const int iy = (int)(t % nmesh);
+    const int ix = (int)(t / nmesh);
+    const size_t plane = (size_t)nmesh * nmesh;
+    // phi is stored with `xghost` ghost planes below plane 0 (0 on one GPU, where x wraps periodically instead)
+    const double *c = phi + ((size_t)(ix + xghost) * nmesh + iy) * nmesh + iz;
+    double p1, m1, p2, m2;
+    if(axis == 0) {
+        if(xghost) {
+            p1 = c[plane];
+            m1 = c[-(ptrdiff_t)plane];
+            p2 = c[2 * plane];
+            m2 = c[-2 * (ptrdiff_t)plane];
+        }
+        else {
+            const size_t row = (size_t)iy * nmesh + iz;
+            p1 = phi[(size_t)wrap(ix + 1, nmesh) * plane + row];
+            m1 = phi[(size_t)wrap(ix - 1, nmesh) * plane + row];
+            p2 = phi[(size_t)wrap(ix + 2, nmesh) * plane + row];
+            m2 = phi[(size_t)wrap(ix - 2, nmesh) * plane + row];
+        }
+    }
+    else if(axis == 1) {
+        const double *r = c - (size_t)iy * nmesh;
+        p1 = r[(size_t)wrap(iy + 1, nmesh) * nmesh];
+        m1 = r[(size_t)wrap(iy - 1, nmesh) * nmesh];
+        p2 = r[(size_t)wrap(iy + 2, nmesh) * nmesh];
+        m2 = r[(size_t)wrap(iy - 2, nmesh) * nmesh];
+    }
+    else {
+        const double *r = c - iz;
+        p1 = r[wrap(iz + 1, nmesh)];
+        m1 = r[wrap(iz - 1, nmesh)];
+        p2 = r[wrap(iz + 2, nmesh)];
+        m2 = r[wrap(iz - 2, nmesh)];
+    }
+    out[ip] = -((2.0 / 3.0) * (p1 - m1) - (1.0 / 12.0) * (p2 - m2)) * scale;
+}
+
 static inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
 void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream_t st)
@@ -280,8 +335,37 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         tm->lap(st, &t);
         t_tr += t;
     }
-    // functions[] = Potential, ForceX, ForceY, ForceZ (gravpm.c:32-39)
-    for(int f = 0; f < 4; f++) {
+    // functions[] = Potential, ForceX, ForceY, ForceZ (gravpm.c:32-39).  Default: one inverse transform (the potential), the
+    // forces by differencing it in real space (k_gradient_axis: the same operator as force_transfer); kspace_force restores
+    // the reference's four inverse transforms.
+    if(!kspace_force) {
+        MPG_FFT(hipfftExecZ2D(plan_c2r, (hipfftDoubleComplex *)rho_k.p, real.p)); // rho_k is consumed: it is not needed again
+        if(tm) {
+            tm->lap(st, &t);
+            t_fft += t;
+        }
+        if(n > 0 && d_potential)
+            hipLaunchKernelGGL(k_cic_readout, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, real.p, 3, d_potential);
+        if(tm) {
+            tm->lap(st, &t);
+            t_ro += t;
+        }
+        for(int axis = 0; axis < 3; axis++) {
+            hipLaunchKernelGGL(k_gradient_axis, dim3(nblk(nreal)), dim3(256), 0, st, nmesh, nmesh, axis, (double)nmesh / box, real.p, work_k.p, 0);
+            if(tm) {
+                tm->lap(st, &t);
+                t_tr += t;
+            }
+            if(n > 0)
+                hipLaunchKernelGGL(k_cic_readout, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, work_k.p, axis, d_gravpm);
+            if(tm) {
+                tm->lap(st, &t);
+                t_ro += t;
+            }
+        }
+    }
+    else
+        for(int f = 0; f < 4; f++) {
         const int axis = f - 1;
         if(f == 0 && !d_potential)
             continue;
@@ -326,12 +410,11 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
 //
 //   forward_a : deposit -> 2-D r2c over (y,z) of the P own planes -> pack by destination ky-slab     [sendA]
 //   all-to-all (caller)                                                                               [recvA = [x][ky local][kz]]
-//   forward_b : tiled transpose to [ky local][kz][kx] -> 1-D c2c along x (contiguous rows) -> potential transfer -> 4 x (force
-//               transfer -> inverse 1-D c2c -> tiled transpose back), interleaved as [x][function][ky local][kz] so that the
-//               block for rank d (its x-planes) is contiguous                                              [sendB]
+//   forward_b : tiled transpose to [ky local][kz][kx] -> 1-D c2c along x (contiguous rows) -> potential transfer -> inverse 1-D
+//               c2c -> tiled transpose back to [x][ky local][kz] (the block for rank d, its x-planes, is contiguous)  [sendB]
 //   all-to-all (caller)                                                                               [recvB]
-//   inverse_c : unpack to [x local][ky][kz] -> 2-D c2r -> 4 real slabs; first planes out as ghosts    [ghost_send]
-//   neighbour exchange (caller) -> readout.
+//   inverse_c : unpack to [x local][ky][kz] -> 2-D c2r -> the potential slab; its first 3 / last 2 planes out as ghosts [ghost_send]
+//   neighbour exchange (caller) -> readout: forces by differencing the potential (k_gradient_axis), CIC readout.
 // hipFFT transforms are unnormalised like PFFT's; the three 1-D stages compose to the same 3-D DFT.
 
 __global__ void __launch_bounds__(256) k_cic_deposit_slab(int64_t n, const double *__restrict__ pos, const float *__restrict__ mass,
@@ -391,8 +474,8 @@ __global__ void __launch_bounds__(256) k_slab_pack_a(int nmesh, int P, int Py, c
     sendA[(((size_t)d * P + xl) * Py + yl) * nz + iz] = C[ip];
 }
 
-// recvB[s][xl][f][yl][z] -> C[xl][y = s Py + yl][z] for one function f
-__global__ void __launch_bounds__(256) k_slab_unpack_b(int nmesh, int P, int Py, int f, const double2 *__restrict__ recvB, double2 *__restrict__ C)
+// recvB[s][xl][yl][z] -> C[xl][y = s Py + yl][z]
+__global__ void __launch_bounds__(256) k_slab_unpack_b(int nmesh, int P, int Py, const double2 *__restrict__ recvB, double2 *__restrict__ C)
 {
     const int nz = nmesh / 2 + 1;
     const size_t total = (size_t)P * nmesh * nz;
@@ -404,7 +487,7 @@ __global__ void __launch_bounds__(256) k_slab_unpack_b(int nmesh, int P, int Py,
     const int y = (int)(t % nmesh);
     const int xl = (int)(t / nmesh);
     const int s = y / Py, yl = y - s * Py;
-    C[ip] = recvB[((((size_t)s * P + xl) * 4 + f) * Py + yl) * nz + iz];
+    C[ip] = recvB[(((size_t)s * P + xl) * Py + yl) * nz + iz];
 }
 
 // readout for a list of targets whose base cell lies in the slab; plane P of the slab is the ghost (first plane of the next rank)
@@ -485,8 +568,8 @@ void PMesh::slab_destroy()
         (void)hipfftDestroy(slab.p1d_fwd);
         slab.ready = false;
     }
-    for(auto &b : slab.realF)
-        b.release();
+    slab.phi.release();
+    slab.force.release();
     slab.C.release();
     slab.rho_k.release();
     slab.work.release();
@@ -503,8 +586,9 @@ void PMesh::slab_init(int rank, int world)
     slab.P = slab.Py = nmesh / world;
     const int nz = nmesh / 2 + 1;
     const size_t S = (size_t)slab.Py * nz;
-    for(auto &b : slab.realF)
-        b.reserve((size_t)(slab.P + 1) * nmesh * nmesh);
+    MPG_CHECK(slab.P >= 3, "pm_slab_init: at least 3 mesh planes per GPU are needed");
+    slab.phi.reserve((size_t)(slab.P + 5) * nmesh * nmesh);
+    slab.force.reserve((size_t)(slab.P + 1) * nmesh * nmesh);
     slab.C.reserve(2 * (size_t)slab.P * nmesh * nz);
     slab.rho_k.reserve(2 * (size_t)nmesh * S);
     // the single-GPU buffers are not needed in this form
@@ -527,11 +611,11 @@ void PMesh::slab_forward_a(int64_t n, const double *d_pos, const float *d_mass, 
     const int nz = nmesh / 2 + 1;
     const size_t nreal = (size_t)slab.P * nmesh * nmesh;
     MPG_FFT(hipfftSetStream(slab.p2d_r2c, st));
-    MPG_HIP(hipMemsetAsync(slab.realF[0].p, 0, nreal * sizeof(double), st));
+    MPG_HIP(hipMemsetAsync(slab.force.p, 0, nreal * sizeof(double), st)); // (the force buffer doubles as the density slab)
     if(n > 0)
         hipLaunchKernelGGL(k_cic_deposit_slab, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, cellsize, nmesh, slab.rank * slab.P, slab.P,
-                           slab.realF[0].p);
-    MPG_FFT(hipfftExecD2Z(slab.p2d_r2c, slab.realF[0].p, (hipfftDoubleComplex *)slab.C.p));
+                           slab.force.p);
+    MPG_FFT(hipfftExecD2Z(slab.p2d_r2c, slab.force.p, (hipfftDoubleComplex *)slab.C.p));
     hipLaunchKernelGGL(k_slab_pack_a, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, (const double2 *)slab.C.p,
                        (double2 *)sendA);
     MPG_HIP(hipGetLastError());
@@ -553,14 +637,11 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
     const double pot_factor = -G / (M_PI * box);
     hipLaunchKernelGGL(k_potential_transfer<true>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, asmth2, pot_factor, invsinc2.p,
                        (double2 *)slab.rho_k.p);
-    for(int f = 0; f < 4; f++) {
-        hipLaunchKernelGGL(k_force_transfer<true>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, f - 1, difffac.p,
-                           (const double2 *)slab.rho_k.p, (double2 *)slab.work.p, 1, 0);
-        MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.work.p, (hipfftDoubleComplex *)slab.work.p, HIPFFT_BACKWARD));
-        // [j][x] -> sendB[x][f][j]: the block for rank d (its x-planes, all four functions) is contiguous
-        hipLaunchKernelGGL(k_transpose, tgrid_b, dim3(256), 0, st, (int)S, nmesh, (const double2 *)slab.work.p, (size_t)nmesh,
-                           (double2 *)sendB + (size_t)f * S, 4 * S);
-    }
+    // only the potential is transformed back: the forces are its real-space differences (k_gradient_axis), which also cuts
+    // the inverse all-to-all to a quarter
+    MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.rho_k.p, (hipfftDoubleComplex *)slab.rho_k.p, HIPFFT_BACKWARD));
+    // [j][x] -> sendB[x][j]: the block for rank d (its x-planes) is contiguous
+    hipLaunchKernelGGL(k_transpose, tgrid_b, dim3(256), 0, st, (int)S, nmesh, (const double2 *)slab.rho_k.p, (size_t)nmesh, (double2 *)sendB, S);
     MPG_HIP(hipGetLastError());
 }
 
@@ -570,12 +651,13 @@ void PMesh::slab_inverse_c(const double *recvB, double *ghost_send, hipStream_t 
     const int nz = nmesh / 2 + 1;
     const size_t plane = (size_t)nmesh * nmesh;
     MPG_FFT(hipfftSetStream(slab.p2d_c2r, st));
-    for(int f = 0; f < 4; f++) {
-        hipLaunchKernelGGL(k_slab_unpack_b, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, f,
-                           (const double2 *)recvB, (double2 *)slab.C.p);
-        MPG_FFT(hipfftExecZ2D(slab.p2d_c2r, (hipfftDoubleComplex *)slab.C.p, slab.realF[f].p));
-        MPG_HIP(hipMemcpyAsync(ghost_send + f * plane, slab.realF[f].p, plane * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
+    hipLaunchKernelGGL(k_slab_unpack_b, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, (const double2 *)recvB,
+                       (double2 *)slab.C.p);
+    double *phi0 = slab.phi.p + 2 * plane; // plane 0 of the slab; planes -2, -1 and P .. P+2 are ghosts
+    MPG_FFT(hipfftExecZ2D(slab.p2d_c2r, (hipfftDoubleComplex *)slab.C.p, phi0));
+    // ghosts the neighbours need: the first 3 planes go to the previous rank, the last 2 to the next
+    MPG_HIP(hipMemcpyAsync(ghost_send, phi0, 3 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MPG_HIP(hipMemcpyAsync(ghost_send + 3 * plane, phi0 + (size_t)(slab.P - 2) * plane, 2 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
     MPG_HIP(hipGetLastError());
 }
 
@@ -587,12 +669,20 @@ void PMesh::slab_readout(const double *ghost_recv, const int *targets, int64_t n
     DevBuf<unsigned> &flag = slab_err;
     flag.reserve(1);
     MPG_HIP(hipMemsetAsync(flag.p, 0, sizeof(unsigned), st));
-    for(int f = 0; f < 4; f++) {
-        MPG_HIP(hipMemcpyAsync(slab.realF[f].p + (size_t)slab.P * plane, ghost_recv + f * plane, plane * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if(nt == 0 || (f == 0 && !d_potential))
-            continue;
-        hipLaunchKernelGGL(k_cic_readout_slab, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, slab.rank * slab.P, slab.P,
-                           slab.realF[f].p, f == 0 ? 3 : f - 1, f == 0 ? d_potential : d_gravpm, flag.p);
+    double *phi0 = slab.phi.p + 2 * plane;
+    // ghost_recv: planes P, P+1, P+2 (the next rank's first three), then planes -2, -1 (the previous rank's last two)
+    MPG_HIP(hipMemcpyAsync(phi0 + (size_t)slab.P * plane, ghost_recv, 3 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MPG_HIP(hipMemcpyAsync(slab.phi.p, ghost_recv + 3 * plane, 2 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const int x0 = slab.rank * slab.P;
+    if(nt > 0 && d_potential)
+        hipLaunchKernelGGL(k_cic_readout_slab, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, x0, slab.P, phi0, 3, d_potential,
+                           flag.p);
+    const size_t ncell = (size_t)(slab.P + 1) * plane; // planes 0 .. P: the CIC readout reaches one plane beyond the slab
+    for(int axis = 0; axis < 3 && nt > 0; axis++) {
+        hipLaunchKernelGGL(k_gradient_axis, dim3(nblk(ncell)), dim3(256), 0, st, nmesh, slab.P + 1, axis, (double)nmesh / box, slab.phi.p,
+                           slab.force.p, 2);
+        hipLaunchKernelGGL(k_cic_readout_slab, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, x0, slab.P, slab.force.p, axis,
+                           d_gravpm, flag.p);
     }
     MPG_HIP(hipGetLastError());
     unsigned e = 0;

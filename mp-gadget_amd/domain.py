@@ -66,43 +66,6 @@ def needed_columns(box, nmesh, world, La, margin):
     return need
 
 
-def _count_matrix(counts, world, device, group=None):
-    """allc[s][d] = rows rank s sends to rank d (host tensor)"""
-    cnt = torch.tensor(counts, dtype=torch.int64, device=device)
-    allc = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(allc, cnt, group=group)
-    return torch.stack(allc).cpu()
-
-
-def _exchange_rows(send, counts, world, group=None, allc=None):
-    """Personalised exchange: `send` holds the rows for rank 0, 1, ... back to back (counts[d] rows each); returns the rows
-    received from all ranks, in rank order.  RCCL all_to_all_single with uneven splits; backends without it (gloo) gather.
-    `allc`: the count matrix of _count_matrix when the caller already has it (several fields, same lists)."""
-    dev = send.device
-    if allc is None:
-        allc = _count_matrix(counts, world, dev, group)
-    rank = dist.get_rank(group)
-    recv_counts = [int(allc[s][rank]) for s in range(world)]
-    out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
-    try:
-        dist.all_to_all_single(out, send, recv_counts, list(counts), group=group)
-        return out
-    except (RuntimeError, NotImplementedError):
-        pass
-    nmax = int(allc.sum(1).max())
-    pad = torch.zeros((nmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
-    pad[:send.shape[0]] = send
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    o = 0
-    for s in range(world):
-        off = int(allc[s][:rank].sum())
-        c = recv_counts[s]
-        out[o:o + c] = parts[s][off:off + c]
-        o += c
-    return out
-
-
 def _pack_rows(tensors, idx):
     """Rows `idx` of several per-particle tensors ([n] or [n, k], any dtype) side by side in one float64 buffer."""
     cols = []
@@ -165,23 +128,23 @@ class SlabDomain:
             idxs.append(idx)
         self.send_idx = torch.cat(idxs) if idxs else torch.zeros(0, dtype=torch.int64, device=self.dev)
         self.send_counts = counts
-        self.count_matrix = _count_matrix(counts, self.world, self.dev, self.group)
+        self.count_matrix = pm_slab.count_matrix(counts, self.world, self.dev, self.group)
         own = (own_pos, own_mass) + tuple(fields)                 # one message per peer carries all fields
-        got = _exchange_rows(_pack_rows(own, self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
+        got = pm_slab.exchange_rows(_pack_rows(own, self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
         return tuple(torch.cat([t, g]).contiguous() for t, g in zip(own, _unpack_rows(got, own)))
 
     def ghost_update(self, own_t):
         """Rows of `own_t` ([n_own] or [n_own, k], any dtype) for this rank's ghosts, fetched from their owners, in ghost order."""
         if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
             return own_t[:0]
-        got = _exchange_rows(_pack_rows((own_t,), self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
+        got = pm_slab.exchange_rows(_pack_rows((own_t,), self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
         return _unpack_rows(got, (own_t,))[0]
 
     def ghost_update_many(self, own_tensors):
         """ghost_update for several tensors with one message per peer; returns the list of ghost rows."""
         if self.world == 1 and not pm_slab.FORCE_COLLECTIVES:
             return [t[:0] for t in own_tensors]
-        got = _exchange_rows(_pack_rows(tuple(own_tensors), self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
+        got = pm_slab.exchange_rows(_pack_rows(tuple(own_tensors), self.send_idx), self.send_counts, self.world, self.group, self.count_matrix)
         return _unpack_rows(got, tuple(own_tensors))
 
     def migrate(self, own_pos, fields=()):
@@ -198,9 +161,9 @@ class SlabDomain:
             idxs.append(idx)
             counts.append(int(idx.shape[0]))
         send_idx = torch.cat(idxs)
-        allc = _count_matrix(counts, self.world, self.dev, self.group)
+        allc = pm_slab.count_matrix(counts, self.world, self.dev, self.group)
         own = (own_pos,) + tuple(fields)
-        got = _unpack_rows(_exchange_rows(_pack_rows(own, send_idx), counts, self.world, self.group, allc), own)
+        got = _unpack_rows(pm_slab.exchange_rows(_pack_rows(own, send_idx), counts, self.world, self.group, allc), own)
         return tuple(torch.cat([t[stay], g]).contiguous() for t, g in zip(own, got))
 
     def check_hsml_margin(self, own_hsml):

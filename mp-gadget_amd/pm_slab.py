@@ -6,12 +6,13 @@ and back (petapm.c:584-885) and lets PFFT transpose between the 1-D transform st
 * every rank binds the same particle set; rank r owns the x-planes [r P, (r+1) P), P = Nmesh / world, of the mesh;
 * a particle's CIC cloud is deposited by the owner(s) of the planes it touches, so there is no region exchange;
 * one 3-D transform = local 2-D transforms, ONE all-to-all transpose, local 1-D transforms; the four inverse transforms
-  (Potential, ForceX, ForceY, ForceZ) share one all-to-all; one neighbour plane per function is passed around the ring;
+  only the potential is transformed back (the forces are its 4-point differences, the real-space form of the reference's
+  Fourier-space force transfer), so there are TWO all-to-alls per PM step; five potential planes go to the neighbours;
 * the targets of rank r - for the PM readout and for the short-range walk alike - are the particles whose base mesh
   cell lies in its slab, listed in tree (Morton) order; their accelerations are all-gathered once per step.
 
 xGMI is point-to-point: each all-to-all is 7 contiguous blocks of Nmesh^3 / world^2 complex values per rank (134 MB at
-Nmesh 1024 on 8 GPUs, x4 for the inverse), large enough to run every link at its streaming rate.
+Nmesh 1024 on 8 GPUs), large enough to run every link at its streaming rate.
 
 This module holds the collectives and the index logic only (torch tensors as buffers); all arithmetic is in the engine.
 """
@@ -43,14 +44,42 @@ def _all_to_all(recv, send, world, group=None):
         recv.view(-1)[s * blk:(s + 1) * blk] = parts[s].view(-1)[rank * blk:(rank + 1) * blk]
 
 
-def _ring_prev(recv, send, rank, world, group=None):
-    """recv <- send of rank (rank + 1) % world (every rank passes its first planes to the previous rank)."""
-    if world == 1 and not FORCE_COLLECTIVES:
-        recv.copy_(send)
-        return
-    parts = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(parts, send, group=group)   # 4 planes per rank: small; one collective instead of paired send/recv
-    recv.copy_(parts[(rank + 1) % world])
+def count_matrix(counts, world, device, group=None):
+    """allc[s][d] = rows rank s sends to rank d (host tensor)"""
+    cnt = torch.tensor(counts, dtype=torch.int64, device=device)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt, group=group)
+    return torch.stack(allc).cpu()
+
+
+def exchange_rows(send, counts, world, group=None, allc=None):
+    """Personalised exchange: `send` holds the rows for rank 0, 1, ... back to back (counts[d] rows each); returns the rows
+    received from all ranks, in rank order.  RCCL all_to_all_single with uneven splits; backends without it (gloo) gather.
+    `allc`: the count matrix of count_matrix when the caller already has it (several fields, same lists)."""
+    dev = send.device
+    if allc is None:
+        allc = count_matrix(counts, world, dev, group)
+    rank = dist.get_rank(group)
+    recv_counts = [int(allc[s][rank]) for s in range(world)]
+    out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
+    try:
+        dist.all_to_all_single(out, send, recv_counts, list(counts), group=group)
+        return out
+    except (RuntimeError, NotImplementedError):
+        pass
+    nmax = int(allc.sum(1).max())
+    pad = torch.zeros((nmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
+    pad[:send.shape[0]] = send
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    o = 0
+    for s in range(world):
+        off = int(allc[s][:rank].sum())
+        c = recv_counts[s]
+        out[o:o + c] = parts[s][off:off + c]
+        o += c
+    return out
+
 
 
 def slab_of_cells(pos_x, cellsize, nmesh, world):
@@ -73,10 +102,11 @@ class SlabPM:
         f64 = dict(dtype=torch.float64, device=device)
         self.sendA = torch.empty(2 * per_peer * world, **f64)
         self.recvA = torch.empty_like(self.sendA)
-        self.sendB = torch.empty(2 * 4 * per_peer * world, **f64)
+        self.sendB = torch.empty(2 * per_peer * world, **f64)     # the inverse transpose carries the potential only
         self.recvB = torch.empty_like(self.sendB)
-        self.ghost_send = torch.empty(4 * plane, **f64)
+        self.ghost_send = torch.empty(5, plane, **f64)            # first 3 planes (-> previous rank), last 2 (-> next rank)
         self.ghost_recv = torch.empty_like(self.ghost_send)
+        self.device = device
 
     def targets(self, pos, order):
         """Caller indices (int32, tree order) of the particles whose base cell lies in this rank's slab.
@@ -93,8 +123,38 @@ class SlabPM:
         e.dev_pm_slab_forward_b(self.recvA, self.sendB)
         _all_to_all(self.recvB, self.sendB, self.world, self.group)
         e.dev_pm_slab_inverse_c(self.recvB, self.ghost_send)
-        _ring_prev(self.ghost_recv, self.ghost_send, self.rank, self.world, self.group)
+        self._ghost_planes()
         e.dev_pm_slab_readout(self.ghost_recv, targets, gravpm, potential)
+
+    def _ghost_planes(self):
+        """ghost_recv <- [first 3 planes of rank+1 | last 2 planes of rank-1] (periodic): the force stencil reaches two planes
+        either way and the CIC readout one plane up.  One personalised exchange (both neighbours may be the same rank, or this
+        rank itself)."""
+        w, r = self.world, self.rank
+        if w == 1 and not FORCE_COLLECTIVES:
+            self.ghost_recv.copy_(self.ghost_send)
+            return
+        prev, nxt = (r - 1) % w, (r + 1) % w
+        # rows for each destination in rank order; within one destination: planes it uses as its upper ghosts first (our first 3),
+        # then those it uses as its lower ghosts (our last 2)
+        rows, counts = [], [0] * w
+        for d in range(w):
+            if d == prev:
+                rows.append(self.ghost_send[0:3])
+                counts[d] += 3
+            if d == nxt:
+                rows.append(self.ghost_send[3:5])
+                counts[d] += 2
+        got = exchange_rows(torch.cat(rows).contiguous(), counts, w, self.group)
+        # received in source-rank order; from a source that is both our next and our previous rank: its first 3, then its last 2
+        o = 0
+        for s_ in range(w):
+            if s_ == nxt:
+                self.ghost_recv[0:3] = got[o:o + 3]
+                o += 3
+            if s_ == prev:
+                self.ghost_recv[3:5] = got[o:o + 2]
+                o += 2
 
 
 class TargetExchange:

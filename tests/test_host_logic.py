@@ -113,11 +113,17 @@ def _slab_worker(rank, world, port, q):
     recv = torch.empty_like(send)
     S._all_to_all(recv.view(-1), send.view(-1), world)
     ok &= bool(torch.equal(recv.reshape(M, P), A[:, rank * P:(rank + 1) * P]))
-    # ghost planes go to the previous rank
-    g = torch.full((4,), float(rank), dtype=torch.float64)
-    gr = torch.empty_like(g)
-    S._ring_prev(gr, g, rank, world)
-    ok &= bool((gr == float((rank + 1) % world)).all())
+    # ghost planes of the potential: first 3 planes to the previous rank, last 2 to the next (the same rank when world == 2)
+    class _E:   # the exchange only needs the buffers
+        pass
+    spm = S.SlabPM.__new__(S.SlabPM)
+    spm.world, spm.rank, spm.group = world, rank, None
+    spm.ghost_send = torch.stack([torch.full((6,), 10.0 * rank + k, dtype=torch.float64) for k in range(5)])
+    spm.ghost_recv = torch.zeros_like(spm.ghost_send)
+    spm._ghost_planes()
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    exp = [10.0 * nxt + 0, 10.0 * nxt + 1, 10.0 * nxt + 2, 10.0 * prv + 3, 10.0 * prv + 4]
+    ok &= bool(torch.equal(spm.ghost_recv[:, 0], torch.tensor(exp, dtype=torch.float64)))
     # slab ownership incl. x == box (wraps to cell 0) and the per-target exchange
     nmesh, box = 16, 4.0
     gen = torch.Generator().manual_seed(3)
@@ -183,7 +189,7 @@ def _domain_worker(rank, world, port, q):
         c = 0 if d == rank else d + 1 + rank
         counts.append(c)
         rows.append(torch.full((c, 4), float(10 * rank + d), dtype=torch.float64))
-    got = pkg.domain._exchange_rows(torch.cat(rows), counts, world)
+    got = pkg.pm_slab.exchange_rows(torch.cat(rows), counts, world)
     exp = torch.cat([torch.full((0 if s == rank else rank + 1 + s, 4), float(10 * s + rank), dtype=torch.float64) for s in range(world)])
     q.put((rank, bool(torch.equal(got, exp))))
     dist.barrier()
