@@ -252,6 +252,15 @@ int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
 /* Device pointer to the tree-order permutation (int32 [NumParticles]: tree slot -> caller index) of the current tree;
  * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
 const int *mpg_dev_tree_order(mpg_engine *eng);
+/* grav_short_pair (gravshort-pair.c:21-57): the exact pair-wise short-range force over all particles within Rcut * Asmth * cell
+ * size of each target (a sphere, not the tree walk's cube), same softening spline and window; runtests.c:131 checks the tree force
+ * against it.  Needs a tree (any walk order); results as for grav_short_tree: FullTreeGravAccel and Potential when the tree holds
+ * every particle. */
+int mpg_grav_short_pair(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle, double Rcut,
+                        double rho0);
+int mpg_dev_grav_short_pair(mpg_engine *eng, const int *d_active, int64_t nactive, double Rcut, double *d_accel, double *d_potential,
+                            double rho0);
+
 /* ---- time integration on device-resident arrays: the streaming loops the reference runs between force
  * steps.  Arrays are in particle order with n entries; flags[i] is the bit-field byte of struct particle_data (bit 0 IsGarbage,
  * bit 1 Swallowed; may be NULL).  Results are bit-identical to the reference's loops (no FMA contraction).

@@ -565,6 +565,38 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     API_END
 }
 
+static unsigned read_flag(mpg_engine *eng, unsigned *d);
+
+int mpg_dev_grav_short_pair(mpg_engine *eng, const int *d_active, int64_t nactive, double Rcut, double *d_accel, double *d_potential, double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_accel, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->tree_allocated, "grav_short_pair: no tree");
+    const GravParams gp = make_gp(eng, rho0);
+    WalkIO io;
+    io.targets = d_active;
+    if(d_active)
+        io.ntargets = nactive;
+    else {
+        MPG_CHECK(eng->tree.npart == eng->n, "grav_short_pair with ActiveParticle == NULL needs a tree of all particles");
+        io.ntargets = eng->tree.npart;
+    }
+    io.pos = eng->d_pos;
+    io.mass = eng->d_mass;
+    io.accel = d_accel;
+    io.potential = eng->full_particle_tree ? d_potential : nullptr;
+    io.tab_force = eng->tab_force.p;
+    io.tab_pot = eng->tab_pot.p;
+    eng->tree.ensure_level_order(eng->stream);
+    eng->ts_flag.reserve(4);
+    MPG_HIP(hipMemsetAsync(eng->ts_flag.p, 0, sizeof(unsigned), eng->stream));
+    const double rcut_abs = Rcut * eng->pm.Asmth * (eng->tree.box / eng->pm.nmesh); // gravshort-pair.c:27-28
+    launch_grav_short_pair(eng->tree.view(), gp, io, rcut_abs, io.potential != nullptr, eng->ts_flag.p, eng->stream);
+    MPG_CHECK(read_flag(eng, eng->ts_flag.p) == 0, "grav_short_pair: neighbour-search stack overflow");
+    API_END
+}
+
 /* ------------------------------ time integration (device-resident arrays) ------------------------------ */
 static unsigned read_flag(mpg_engine *eng, unsigned *d)
 {
@@ -816,6 +848,54 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
             }
         }
     });
+    API_END
+}
+
+int mpg_grav_short_pair(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle, double Rcut, double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_CHECK(eng->tree_allocated, "grav_short_pair: no tree");
+    MPG_CHECK(P->n == eng->n, "grav_short_pair: particle table changed size since the tree was built");
+    MPG_CHECK(P->off_accel >= 0, "particle view needs FullTreeGravAccel");
+    const int64_t n = P->n;
+    eng->s_accel.reserve(3 * (size_t)n + 1);
+    eng->s_pot.reserve((size_t)n + 1);
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    const bool full = eng->full_particle_tree;
+    const bool wantpot = full && P->off_potential >= 0;
+    MPG_HIP(hipMemsetAsync(eng->s_accel.p, 0, 3 * n * sizeof(double), eng->stream));
+    if(mpg_dev_grav_short_pair(eng, d_act, NumActiveParticle, Rcut, eng->s_accel.p, wantpot ? eng->s_pot.p : nullptr, rho0))
+        throw Error(g_err);
+    eng->h_d2.reserve(3 * (size_t)n + 1);
+    eng->h_d3.reserve((size_t)n + 1);
+    double *ha = eng->h_d2.p, *hp = eng->h_d3.p;
+    MPG_HIP(hipMemcpyAsync(ha, eng->s_accel.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    if(wantpot)
+        MPG_HIP(hipMemcpyAsync(hp, eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    if(full) { // the pair-wise result reaches the caller only through P (gravshort.h:54-66): priv.Accel is freed on return
+        const int64_t nt = ActiveParticle ? NumActiveParticle : n;
+        char *wb = (char *)P->base;
+        const mpg_particle_view V = *P;
+        parallel_for(nt, [=](int64_t lo, int64_t hi) {
+            for(int64_t k = lo; k < hi; k++) {
+                const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+                double *a = (double *)(wb + i * V.stride + V.off_accel);
+                a[0] = ha[3 * i + 0];
+                a[1] = ha[3 * i + 1];
+                a[2] = ha[3 * i + 2];
+                if(wantpot)
+                    *(double *)(wb + i * V.stride + V.off_potential) = hp[i];
+            }
+        });
+    }
     API_END
 }
 

@@ -51,6 +51,9 @@ void launch_grav_walk_shared(const TreeView &tv, const GravParams &gp, const Wal
 // two-kernel walk (grav_walk_split.hip): list construction, then evaluation; overflowing targets fall back to launch_grav_walk
 void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,
                             WalkScratch &ws, hipStream_t st);
+// grav_short_pair (grav_pair_walk.hip): exact pair-wise short-range force within the sphere of radius rcut_abs
+void launch_grav_short_pair(const TreeView &tv, const GravParams &gp, const WalkIO &io, double rcut_abs, bool want_pot, unsigned *d_err,
+                            hipStream_t st);
 // returns the device error flag of the last cooperative walk (0 = ok); synchronises the stream
 unsigned walk_coop_error(WalkScratch &ws, hipStream_t st);
 

@@ -297,6 +297,17 @@ class Engine:
     def dev_gravpm_force(self, gravpm, potential=None):
         self._ck(self.lib.mpg_dev_gravpm_force(self.h, _ptr(gravpm), _ptr(potential)))
 
+    def dev_grav_short_pair(self, accel, Rcut, active=None, potential=None, rho0=0.0):
+        """grav_short_pair (gravshort-pair.c:21-57) on device-resident arrays"""
+        self._ck(self.lib.mpg_dev_grav_short_pair(self.h, _ptr(active), C.c_int64(0 if active is None else active.shape[0]), C.c_double(Rcut),
+                                                  _ptr(accel), _ptr(potential), C.c_double(rho0)))
+
+    def grav_short_pair(self, P, Rcut, ActiveParticle=None, rho0=0.0):
+        v = self._view(P)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        self._ck(self.lib.mpg_grav_short_pair(self.h, C.byref(v), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                              C.c_int64(0 if act is None else len(act)), C.c_double(Rcut), C.c_double(rho0)))
+
     # time integration on device-resident arrays (drift.c / timestep.c loops; SURVEY 8(f) row 1)
     def dev_drift_all_particles(self, pos, vel, ddrift, BoxSize, random_shift=(0.0, 0.0, 0.0), type=None, flags=None, hsml=None, dthsml=None):
         sh = (C.c_double * 3)(*random_shift)

@@ -402,3 +402,35 @@ def test_full_size_256_properties(pkg, orc):
     ao, _, co, _ = tr.grav_short_tree(par, oldacc=np.full(N, 1e-7), active=act)
     assert_accel_parity(a[act], ao[act])
     eng.close()
+
+
+@pytest.mark.parametrize("ic,n", [("s_grid", 20), ("s_clust", 16)])
+def test_grav_short_pair(pkg, engine, orc, ic, n):
+    """grav_short_pair (gravshort-pair.c): the exact pair-wise short-range force within the Rcut sphere, against the oracle's
+    O(N^2) restatement; and, as runtests.c:131-176 does with it, the tree force against the pair-wise force."""
+    nmesh = 2 * n
+    pos, mass, box = (pkg.ics.s_clust(n, box=8.0, seed=2) if ic == "s_clust" else pkg.ics.s_grid(n))
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    P = pkg.make_particles(pos, mass)
+    P["GravPM"] = 0.0
+    engine.force_tree_full(P, box)
+    engine.grav_short_pair(P, 6.0)
+    a_pair = P["FullTreeGravAccel"].copy()
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    a_ref = orc.grav_short_pair(pos, mass, box, par, 6.0 * 1.5 * box / nmesh)
+    assert_accel_parity(a_pair, a_ref)
+    # active subset through the device entry point
+    import torch
+    act = np.sort(np.random.RandomState(0).choice(len(pos), 300, replace=False)).astype(np.int32)
+    d_acc = torch.zeros(len(pos), 3, dtype=torch.float64, device="cuda")
+    engine.dev_grav_short_pair(d_acc, 6.0, active=torch.from_numpy(act).cuda())
+    engine.synchronize()
+    got = d_acc.cpu().numpy()
+    assert_accel_parity(got[act], a_ref[act])
+    assert np.all(np.delete(got, act, axis=0) == 0)
+    # tree force vs pair-wise force, as runtests.c:131-176 compares them: they differ by the tree's node approximations
+    # (ErrTolForceAcc 0.002) and by the window's tail between the Rcut sphere and the cube the walk accepts
+    P["FullTreeGravAccel"] = a_pair
+    engine.grav_short_tree(P)
+    rel = np.sqrt(((P["FullTreeGravAccel"] - a_pair) ** 2).sum(1)) / np.sqrt((a_pair ** 2).sum(1)).mean()
+    assert rel.mean() < 2.5 * 0.002 and rel.max() < 50 * 0.002, (rel.mean(), rel.max())
