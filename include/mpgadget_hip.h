@@ -107,6 +107,11 @@ int mpg_force_tree_full(mpg_engine *eng, const mpg_particle_view *P, double BoxS
 int mpg_force_tree_rebuild_mask(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, int mask);
 /* force_tree_free, libgadget/forcetree.c:1403-1413 */
 int mpg_force_tree_free(mpg_engine *eng);
+/* force_tree_active_moments (forcetree.c:129-148): a tree of the active particles only (ActiveParticle == NULL: all), with
+ * moments; HybridNuTracer != 0 leaves neutrinos (type 2) out.  A walk over it takes the same active list as its targets. */
+int mpg_force_tree_active_moments(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const int *ActiveParticle,
+                                  int64_t NumActiveParticle, int HybridNuTracer);
+int mpg_dev_force_tree_active_moments(mpg_engine *eng, const int *d_active, int64_t nactive, int HybridNuTracer);
 /* grav_short_tree, libgadget/gravshort-tree.c:96-154.  ActiveParticle == NULL means all particles
  * (timestep.c:77-84).  AccelStore may be NULL.  When the tree holds all particles (full_particle_tree_flag)
  * P[i].FullTreeGravAccel and P[i].Potential are updated as grav_short_postprocess does (gravshort.h:47-67).

@@ -123,6 +123,7 @@ struct mpg_engine {
     DevBuf<uint8_t> s_type;
     DevBuf<int> s_active;
     DevBuf<unsigned> ts_flag;
+    DevBuf<uint8_t> tree_incl; // particles included in an active-particle tree
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
     HostBuf<uint8_t> h_b;
@@ -963,6 +964,55 @@ int mpg_dev_force_tree_rebuild_mask(mpg_engine *eng, int mask, int with_moments)
     eng->tree_mask = mask;
     eng->full_particle_tree = (mask == 63) || (eng->tree.npart == eng->n);
     eng->sph.hmax_pending = false;
+    API_END
+}
+
+__global__ void __launch_bounds__(256) k_mark_included(int64_t nact, const int *__restrict__ active, uint8_t *__restrict__ flags)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < nact)
+        flags[active[k]] = 1;
+}
+
+int mpg_dev_force_tree_active_moments(mpg_engine *eng, const int *d_active, int64_t nactive, int HybridNuTracer)
+{
+    API_BEGIN
+    MPG_CHECK(eng && (d_active || nactive == 0), "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int mask = HybridNuTracer ? (1 + 2 + 16 + 32) : 63; // GASMASK + DMMASK + STARMASK + BHMASK, or ALLMASK (forcetree.c:139-141)
+    const uint8_t *incl = nullptr;
+    if(d_active) {
+        eng->tree_incl.reserve((size_t)eng->n + 1);
+        MPG_HIP(hipMemsetAsync(eng->tree_incl.p, 0, (size_t)eng->n, eng->stream));
+        if(nactive > 0)
+            hipLaunchKernelGGL(k_mark_included, dim3((unsigned)((nactive + 255) / 256)), dim3(256), 0, eng->stream, nactive, d_active,
+                               eng->tree_incl.p);
+        incl = eng->tree_incl.p;
+    }
+    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer, incl);
+    eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+    eng->tree_allocated = true;
+    eng->tree_mask = mask;
+    eng->full_particle_tree = !d_active && eng->tree.npart == eng->n; // forcetree.c:146-147
+    eng->sph.hmax_pending = false;
+    API_END
+}
+
+int mpg_force_tree_active_moments(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const int *ActiveParticle,
+                                  int64_t NumActiveParticle, int HybridNuTracer)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    stage_particles(eng, P, BoxSize);
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    if(mpg_dev_force_tree_active_moments(eng, d_act, NumActiveParticle, HybridNuTracer))
+        throw Error(g_err);
     API_END
 }
 

@@ -76,7 +76,7 @@ struct TreeBuilder {
 
     // force_tree_build (forcetree.c:196-270) without moments
     void build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box, hipStream_t st,
-               EventTimer *tm);
+               EventTimer *tm, const uint8_t *d_include = nullptr);
     // force_tree_calc_moments (forcetree.c:170-183).  d_hsml_gasbh_treeorder: per tree-order particle, Hsml of
     // gas/BH particles that are not hydro-active, negative otherwise; NULL = no hmax.
     void calc_moments(const double *d_hsml_gasbh_treeorder, hipStream_t st, EventTimer *tm);

@@ -35,9 +35,10 @@ __device__ __forceinline__ int cpl_levels(uint64_t a, uint64_t b)
     return l > MAXLEVEL ? MAXLEVEL : l;
 }
 
+// include: optional byte per particle, 0 = leave out (the active-particle trees of force_tree_active_moments)
 __global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restrict__ pos, const uint8_t *__restrict__ type, int mask,
-                                              double box, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
-                                              unsigned long long *__restrict__ nexcluded)
+                                              const uint8_t *__restrict__ include, double box, uint64_t *__restrict__ keys,
+                                              uint32_t *__restrict__ idx, unsigned long long *__restrict__ nexcluded)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restric
         len *= 0.5;
     }
     const int ty = type ? (type[i] & 7) : 1;
-    const bool in = ((1 << ty) & mask) != 0;
+    const bool in = (((1 << ty) & mask) != 0) && (!include || include[i]);
     if(!in) {
         key = ~0ull;
         atomicAdd(nexcluded, 1ull);
@@ -434,7 +435,7 @@ void TreeBuilder::make_level_order(hipStream_t st)
 }
 
 void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box,
-                        hipStream_t st, EventTimer *tm)
+                        hipStream_t st, EventTimer *tm, const uint8_t *d_include)
 {
     MPG_CHECK(n < (int64_t)1 << 31, "tree build: more than 2^31 particles on one GPU");
     this->box = box;
@@ -453,7 +454,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     unsigned long long *d_nexcl = (unsigned long long *)(flags.p + 4);
     int *d_flags = (int *)flags.p;
     if(n > 0)
-        hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_type, mask, box, keys_a.p, idx_a.p, d_nexcl);
+        hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_type, mask, d_include, box, keys_a.p, idx_a.p, d_nexcl);
     if(tm)
         tm->lap(st, &tm->t.tree_keys);
     // --- sort

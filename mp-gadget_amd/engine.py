@@ -272,6 +272,16 @@ class Engine:
     def force_tree_free(self):
         self._ck(self.lib.mpg_force_tree_free(self.h))
 
+    def force_tree_active_moments(self, P, BoxSize, ActiveParticle=None, HybridNuTracer=0):
+        v = self._view(P)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        self._ck(self.lib.mpg_force_tree_active_moments(self.h, C.byref(v), C.c_double(BoxSize), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                                        C.c_int64(0 if act is None else len(act)), int(HybridNuTracer)))
+
+    def dev_force_tree_active_moments(self, active=None, HybridNuTracer=0):
+        self._ck(self.lib.mpg_dev_force_tree_active_moments(self.h, _ptr(active), C.c_int64(0 if active is None else active.shape[0]),
+                                                            int(HybridNuTracer)))
+
     def grav_short_tree(self, P, ActiveParticle=None, AccelStore=None, rho0=0.0):
         v = self._view(P)
         act = None

@@ -434,3 +434,40 @@ def test_grav_short_pair(pkg, engine, orc, ic, n):
     engine.grav_short_tree(P)
     rel = np.sqrt(((P["FullTreeGravAccel"] - a_pair) ** 2).sum(1)) / np.sqrt((a_pair ** 2).sum(1)).mean()
     assert rel.mean() < 2.5 * 0.002 and rel.max() < 50 * 0.002, (rel.mean(), rel.max())
+
+
+def test_force_tree_active_moments(pkg, engine, orc):
+    """force_tree_active_moments (forcetree.c:129-148): a tree of the active particles only (the hierarchical-gravity level loop
+    re-enters tree build + walk per time bin with such trees).  Tree and walk equal the oracle's on the sub-set."""
+    n, nmesh = 20, 40
+    pos, mass, box = pkg.ics.s_zel(n)
+    N = len(pos)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    act = np.sort(np.random.RandomState(7).choice(N, N // 3, replace=False)).astype(np.int32)
+    P = pkg.make_particles(pos, mass)
+    rng = np.random.RandomState(8)
+    P["GravPM"] = rng.standard_normal((N, 3)) * 1e-3
+    P["FullTreeGravAccel"] = rng.standard_normal((N, 3)) * 1e-3
+    before = P["FullTreeGravAccel"].copy()
+    engine.force_tree_active_moments(P, box, act)
+    st = engine.tree_stats()
+    tr = orc.tree(pos[act], mass[act], box)
+    assert st.NumParticles == len(act) and st.numnodes == int(tr.export()["live"].sum())   # (the oracle also counts empty child slots)
+    assert abs(st.root_mass - mass[act].astype(np.float64).sum()) <= 1e-9 * len(act)
+    store = np.zeros((N, 3))
+    engine.set_instrumentation(False, True)
+    engine.grav_short_tree(P, ActiveParticle=act, AccelStore=store)
+    c = engine.walk_counters()
+    engine.set_instrumentation(False, False)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    old = np.sqrt(((before + P["GravPM"]) ** 2).sum(1)) / G
+    a_ref, _, c_ref, _ = tr.grav_short_tree(par, oldacc=old[act])
+    assert (c["pp"], c["nodes_visited"], c["nodes_used"]) == tuple(c_ref)
+    assert_accel_parity(store[act], a_ref)
+    assert np.array_equal(P["FullTreeGravAccel"], before)            # not a full particle tree: P is left alone (gravshort.h:54-66)
+    assert np.all(np.delete(store, act, axis=0) == 0)
+    # ActiveParticle == NULL: the full tree, flagged as such
+    engine.force_tree_active_moments(P, box, None)
+    engine.grav_short_tree(P)
+    assert not np.array_equal(P["FullTreeGravAccel"], before)
