@@ -169,6 +169,13 @@ void mpg_engine_destroy(mpg_engine *eng)
         return;
     (void)hipSetDevice(eng->device);
     (void)hipStreamSynchronize(eng->stream);
+    if(eng->w3.split_stream)
+        (void)hipStreamSynchronize(eng->w3.split_stream);
+    for(auto &v : {&eng->walk_events, &eng->free_events})
+        for(auto &e : *v) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     eng->pm.destroy();
     if(eng->own_stream && eng->stream)
         (void)hipStreamDestroy(eng->stream);

@@ -41,6 +41,14 @@ struct WalkScratch {
     int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)
     hipStream_t split_stream = nullptr;
     hipEvent_t ev_lists[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_begin = nullptr;
+    ~WalkScratch()
+    {
+        for(hipEvent_t e : {ev_lists[0], ev_lists[1], ev_eval[0], ev_eval[1], ev_begin})
+            if(e)
+                (void)hipEventDestroy(e);
+        if(split_stream)
+            (void)hipStreamDestroy(split_stream);
+    }
 };
 // fastwrap: the minimum-image wrap may be hoisted out of the pair loop (decided by the caller from Rcut, Box, leaf sizes)
 void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap,
