@@ -336,7 +336,7 @@ int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential)
     API_BEGIN
     MPG_CHECK(eng && d_gravpm, "null argument");
     MPG_HIP(hipSetDevice(eng->device));
-    MPG_CHECK(eng->pm.have_plans, "gravpm_force called before gravpm_init_periodic");
+    MPG_CHECK(eng->pm.nmesh > 0, "gravpm_force called before gravpm_init_periodic");
     MPG_CHECK(eng->pm.box == eng->box, "gravpm_force: BoxSize of the mesh differs from the bound particles");
     eng->pm.force(eng->n, eng->d_pos, eng->d_mass, nullptr, d_gravpm, d_potential, eng->stream, &eng->timer);
     API_END
@@ -718,7 +718,7 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     API_BEGIN
     MPG_CHECK(eng && P, "null argument");
     MPG_HIP(hipSetDevice(eng->device));
-    MPG_CHECK(eng->pm.have_plans, "gravpm_force called before gravpm_init_periodic");
+    MPG_CHECK(eng->pm.nmesh > 0, "gravpm_force called before gravpm_init_periodic");
     MPG_CHECK(P->off_gravpm >= 0, "particle view needs GravPM");
     stage_particles(eng, P, eng->pm.box);
     const int64_t n = P->n;

@@ -20,6 +20,7 @@ struct PMesh {
 
     // gravpm_init_periodic -> petapm_init (gravpm.c:51-54, petapm.c:105-223)
     void init(double BoxSize, double Asmth, int Nmesh, double G, hipStream_t st);
+    void ensure_single(); // meshes + 3-D plans of the single-GPU form, made on first use
     // petapm_destroy (petapm.c:225-232)
     void destroy();
     // gravpm_force (gravpm.c:61-119): d_gravpm[n][3] is assigned, d_potential[n] (may be null) is incremented

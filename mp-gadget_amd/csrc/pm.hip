@@ -262,11 +262,7 @@ void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream
     nmesh = Nmesh_;
     G = G_;
     cellsize = box / nmesh; // petapm.c:112
-    const size_t nreal = (size_t)nmesh * nmesh * nmesh;
-    const size_t ncplx = (size_t)nmesh * nmesh * (nmesh / 2 + 1);
-    real.reserve(nreal);
-    rho_k.reserve(2 * ncplx);
-    work_k.reserve(2 * ncplx);
+    // the meshes and the 3-D plans are made by the first gravpm_force (ensure_single): the slab-decomposed form never needs them
     // per-index tables: 1/sinc^2(pi k / N) (gravpm.c:412-418) and the differencing factor (gravpm.c:482)
     std::vector<double> is2(nmesh), dff(nmesh);
     for(int i = 0; i < nmesh; i++) {
@@ -282,6 +278,17 @@ void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream
     MPG_HIP(hipMemcpyAsync(invsinc2.p, is2.data(), nmesh * sizeof(double), hipMemcpyHostToDevice, st));
     MPG_HIP(hipMemcpyAsync(difffac.p, dff.data(), nmesh * sizeof(double), hipMemcpyHostToDevice, st));
     MPG_HIP(hipStreamSynchronize(st));
+}
+
+void PMesh::ensure_single()
+{
+    if(have_plans)
+        return;
+    const size_t nreal = (size_t)nmesh * nmesh * nmesh;
+    const size_t ncplx = (size_t)nmesh * nmesh * (nmesh / 2 + 1);
+    real.reserve(nreal);
+    rho_k.reserve(2 * ncplx);
+    work_k.reserve(2 * ncplx);
     MPG_FFT(hipfftCreate(&plan_r2c));
     MPG_FFT(hipfftCreate(&plan_c2r));
     size_t ws1 = 0, ws2 = 0;
@@ -307,8 +314,9 @@ void PMesh::destroy()
 void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_active, double *d_gravpm, double *d_potential,
                   hipStream_t st, EventTimer *tm)
 {
-    MPG_CHECK(have_plans, "gravpm_force called before gravpm_init_periodic");
+    MPG_CHECK(nmesh > 0, "gravpm_force called before gravpm_init_periodic");
     MPG_CHECK(!slab.ready, "gravpm_force: the mesh is in its slab-decomposed form (use the pm_slab calls)");
+    ensure_single();
     const size_t nreal = (size_t)nmesh * nmesh * nmesh;
     const size_t ncplx = (size_t)nmesh * nmesh * (nmesh / 2 + 1);
     MPG_FFT(hipfftSetStream(plan_r2c, st));
@@ -577,7 +585,7 @@ void PMesh::slab_destroy()
 
 void PMesh::slab_init(int rank, int world)
 {
-    MPG_CHECK(have_plans, "pm_slab_init called before gravpm_init_periodic");
+    MPG_CHECK(nmesh > 0, "pm_slab_init called before gravpm_init_periodic");
     MPG_CHECK(world >= 1 && rank >= 0 && rank < world, "pm_slab_init: bad rank / world");
     MPG_CHECK(nmesh % world == 0, "pm_slab_init: Nmesh must be a multiple of the number of GPUs");
     slab_destroy();
@@ -591,7 +599,12 @@ void PMesh::slab_init(int rank, int world)
     slab.force.reserve((size_t)(slab.P + 1) * nmesh * nmesh);
     slab.C.reserve(2 * (size_t)slab.P * nmesh * nz);
     slab.rho_k.reserve(2 * (size_t)nmesh * S);
-    // the single-GPU buffers are not needed in this form
+    // the single-GPU meshes and plans are not needed in this form
+    if(have_plans) {
+        (void)hipfftDestroy(plan_r2c);
+        (void)hipfftDestroy(plan_c2r);
+        have_plans = false;
+    }
     real.release();
     rho_k.release();
     work_k.release();
