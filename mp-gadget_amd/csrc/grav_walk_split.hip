@@ -37,10 +37,6 @@ namespace {
 #define MPG_EVAL_BLOCKS 6 // resident 256-thread blocks per CU the evaluation kernel is compiled for (80 VGPRs)
 #endif
 
-struct WTabD {
-    double a, b;
-};
-
 constexpr int STK = 160; // pending child ranges per group (LIFO): <= 7 per tree level + 8, 21 levels
 
 
@@ -86,7 +82,7 @@ __device__ __forceinline__ void softened_pair(const double r, const double m, co
 
 template <bool POT>
 __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
-                                           const WTabD *__restrict__ wf, const WTabD *__restrict__ wp, double &ax, double &ay,
+                                           const double *__restrict__ wtab, double &ax, double &ay,
                                            double &az, double &pot)
 {
     // apply_accn_to_output, gravshort-tree.c:158-193
@@ -94,24 +90,29 @@ __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const 
     const double rinv = rsqrt_nr(fmax(r2, 1e-180)); // the clamp keeps m * rinv^3 finite for r = 0
     const double r = r2 * rinv; // exactly 0 for the self interaction
     // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
-    // the table's last row, which holds zeros, with weight exactly 1
-    const double tcl = fmin(r * gp.inv_cell_dx, (double)(NTAB - 1));
-    double fac = s.m * rinv * rinv * rinv;
-    double facpot = -s.m * rinv;
+    // the table's last row, which holds zeros
+    const double ti = r * gp.inv_cell_dx;
+    const double mr = s.m * rinv;
+    double fac = mr * rinv * rinv;
+    double facpot = -mr;
     if(r2 < gp.h * gp.h) // rare (the self interaction, close encounters): kept out of line so that its divisions and
         softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot); // constants do not occupy registers in the pair loop
-    const int t = (int)tcl;
-    // (t + 1 - i) and (i - t) of gravity.c:63 are both exact, so 1 - (i - t) is the same number as (t + 1 - i)
-    const double w1 = tcl - (double)t, w0 = 1.0 - w1;
-    const WTabD f = wf[t];
-    fac *= w0 * f.a + w1 * f.b;
+    // row t holds {T[t], T[t+1] - T[t]} (the difference of two floats is exact in double): T[t] + (i - t) (T[t+1] - T[t]) is the
+    // interpolation of gravity.c:63 up to one rounding.  (i - t) = fract(i) exactly for i >= 0.
+    const int t = min((int)ti, NTAB - 1);
+    const double w1 = __builtin_amdgcn_fract(ti);
+    // one row = {force T, force dT, potential T, potential dT} (the last two only with POT): both reads are issued together
+    const double *__restrict__ row = wtab + t * (POT ? 4 : 2);
+    const double2 f = *(const double2 *)row;
+    double2 p = f;
+    if(POT)
+        p = *(const double2 *)(row + 2);
+    fac *= fma(w1, f.y, f.x);
     ax = fma(dx, fac, ax);
     ay = fma(dy, fac, ay);
     az = fma(dz, fac, az);
-    if(POT) {
-        const WTabD p = wp[t];
-        pot = fma(facpot, w0 * p.a + w1 * p.b, pot);
-    }
+    if(POT)
+        pot = fma(facpot, fma(w1, p.y, p.x), pot);
 }
 
 __device__ __forceinline__ double nearest_img(double d, double box, double invbox) { return fma(-rint(d * invbox), box, d); }
@@ -132,6 +133,146 @@ struct ChunkIter {
     }
 };
 
+// One target's walk (8 lanes), lists written to L.  MODE: 0 NEAREST() per quantity (small boxes); 1 the node's periodic image
+// k = rint((c - p)/Box) is applied to the target (FASTWRAP); 2 plain differences, for targets farther than Rcut + Box/500 from
+// every face of the box.  MODE 2 is exact: a node that is not discarded has |c - p| <= Rcut + len/2 per axis on its nearest
+// image (its centre of mass lies inside it), which for such a target is the unwrapped image; and a node that is discarded
+// with nearest-image distances is discarded with the (larger or equal) unwrapped ones.  In modes 1 and 2 the centre of mass
+// of a node can sit on another image than its centre only if Rcut + len >= Box/2 (the root and its children, two steps per
+// target): those take NEAREST() for both, exactly as gravshort-tree.c:299-300 does.
+// Returns false on an internal error (loop guard / stack), which ends the kernel.
+template <bool COUNT, int MODE>
+__device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ L, unsigned *__restrict__ stack,
+                                            const int cap, const int lane, const int s, const int gshift, const bool valid, const double px,
+                                            const double py, const double pz, const double aold, const unsigned long long guard_max,
+                                            unsigned *__restrict__ ctl, int &nleaf, int &nnode, bool &wrapped, bool &overflow, unsigned &c_pp,
+                                            unsigned &c_vis, unsigned &c_used, unsigned &st_a, unsigned &st_al)
+{
+    const unsigned below = (1u << s) - 1u;
+    int sp = 0; // stack pointer (group-uniform)
+    if(valid) {
+        if(s == 0)
+            stack[0] = (0u << 4) | 1u; // the root
+        sp = 1;
+    }
+    unsigned long long guard = 0;
+    // One step per iteration, written without divergent control flow (the first form, an `act` code set in nested
+    // branches, cost ~25 register moves and three extra exec-mask regions per step): every lane computes the tests for
+    // "its" child (idle lanes recompute the root, a broadcast read), the outcomes are booleans, and only the three kinds
+    // of stores are predicated.
+    for(;;) {
+        if(sp > 0 && nleaf + nnode + 8 > cap) { // the next step might not fit: hand the target to the fallback kernel
+            overflow = true;
+            sp = 0;
+        }
+        const bool can = sp > 0;
+        if(__ballot(can) == 0)
+            break;
+        if(++guard > guard_max || __ballot(can && sp + 8 > STK) != 0) {
+            if(lane == 0)
+                atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
+            return false;
+        }
+        const unsigned range = can ? stack[sp - 1] : 0u;
+        const int nch = (int)(range & 15u);
+        const bool mine = s < nch; // false for every lane of a group that is not walking
+        const int my = mine ? (int)(range >> 4) + s : 0;
+        const NodeGeo g = tv.geoB[my];
+        const Src4 mom = tv.momB[my];
+        const NodeLinkB lk = tv.linkB[my];
+        double dx, dy, dz, cdx, cdy, cdz;
+        bool wr = false;
+        if(MODE == 0) {
+            cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
+            cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
+            cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+            dx = nearest_img(mom.x - px, gp.box, gp.invbox);
+            dy = nearest_img(mom.y - py, gp.box, gp.invbox);
+            dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
+        }
+        else {
+            if(MODE == 1) {
+                // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
+                const double kx = rint((g.cx - px) * gp.invbox);
+                const double ky = rint((g.cy - py) * gp.invbox);
+                const double kz = rint((g.cz - pz) * gp.invbox);
+                const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
+                cdx = fabs(g.cx - qx);
+                cdy = fabs(g.cy - qy);
+                cdz = fabs(g.cz - qz);
+                dx = mom.x - qx;
+                dy = mom.y - qy;
+                dz = mom.z - qz;
+                wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
+            }
+            else {
+                cdx = fabs(g.cx - px);
+                cdy = fabs(g.cy - py);
+                cdz = fabs(g.cz - pz);
+                dx = mom.x - px;
+                dy = mom.y - py;
+                dz = mom.z - pz;
+            }
+            if(g.len + gp.rcut > 0.49 * gp.box) { // the root and its children
+                const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
+                dx = fma(-jx, gp.box, mom.x - px);
+                dy = fma(-jy, gp.box, mom.y - py);
+                dz = fma(-jz, gp.box, mom.z - pz);
+                wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
+                if(MODE == 2) {
+                    cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
+                    cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
+                    cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+                }
+            }
+        }
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        // shall_we_discard_node, gravshort-tree.c:198-215
+        const double eff = fma(0.5, g.len, gp.rcut);
+        const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
+        // shall_we_open_node, gravshort-tree.c:220-241
+        const double l2 = g.len * g.len;
+        const double inside = 0.6 * g.len;
+        const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) ||
+                          (cdx < inside && cdy < inside && cdz < inside);
+        const bool keep = mine && !discard;
+        const bool b_node = keep && !open;                                   // used unopened: a 1-element source
+        const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
+        const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
+        const unsigned gm_leaf = (unsigned)((__ballot(b_leaf) >> gshift) & 0xffull);
+        const unsigned gm_node = (unsigned)((__ballot(b_node) >> gshift) & 0xffull);
+        const unsigned gm_push = (unsigned)((__ballot(b_push) >> gshift) & 0xffull);
+        if(b_leaf) {
+            const int e = nleaf + __popc(gm_leaf & below);
+            L[((e >> 3) << 6) + (e & 7)] = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+        }
+        if(b_node) {
+            const int e = cap - 1 - (nnode + __popc(gm_node & below));
+            L[((e >> 3) << 6) + (e & 7)] = (unsigned)my;
+        }
+        if(b_push)
+            stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
+        // (all masks are zero for a group that is not walking)
+        nleaf += __popc(gm_leaf);
+        nnode += __popc(gm_node);
+        sp += __popc(gm_push) - (can ? 1 : 0);
+        if(MODE != 0) {
+            const unsigned gm_wrap = (unsigned)((__ballot(wr && (b_leaf || b_node)) >> gshift) & 0xffull);
+            wrapped = wrapped || (gm_wrap != 0);
+        }
+        if(COUNT) {
+            c_vis += mine ? 1u : 0u;
+            c_used += b_node ? 1u : 0u;
+            c_pp += b_leaf ? (unsigned)lk.pcount : 0u;
+            if(can && s == 0) {
+                st_a++;
+                st_al += nch;
+            }
+        }
+    }
+    return true;
+}
+
 // ctl words: [0] number of overflowed targets, [1] error flag (loop guard / stack), [2] longest list seen
 // counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] group steps [4] children tested
 template <bool COUNT, bool FASTWRAP>
@@ -147,7 +288,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
     const unsigned nchunks = (unsigned)((nslots + 7) / 8);
     const ChunkIter it(nchunks);
     const unsigned long long guard_max = 64ull * (unsigned long long)(tv.nnodes + 1024);
-    const unsigned below = (1u << s) - 1u;
+    const double face = gp.rcut + 0.002 * gp.box; // MODE 2 margin (the root cell is 1.001 Box wide: + Box/2000, with slack)
     unsigned n_pp = 0, n_vis = 0, n_used = 0, st_a = 0, st_al = 0;
 
     for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
@@ -175,116 +316,24 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
             aold = gp.errtol * old;
         }
         unsigned *__restrict__ L = lists + (size_t)chunk * (size_t)cap * 8 + gshift;
-        int sp = 0; // stack pointer (group-uniform)
-        if(valid) {
-            if(s == 0)
-                stack[0] = (0u << 4) | 1u; // the root
-            sp = 1;
-        }
         int nleaf = 0, nnode = 0; // entries in the two lists (group-uniform)
         bool wrapped = false, overflow = false;
         unsigned c_pp = 0, c_vis = 0, c_used = 0;
-        unsigned long long guard = 0;
-        // One step per iteration, written without divergent control flow (the first form, an `act` code set in nested
-        // branches, cost ~25 register moves and three extra exec-mask regions per step): every lane computes the tests for
-        // "its" child (idle lanes recompute the root, a broadcast read), the outcomes are booleans, and only the three kinds
-        // of stores are predicated.
-        for(;;) {
-            if(sp > 0 && nleaf + nnode + 8 > cap) { // the next step might not fit: hand the target to the fallback kernel
-                overflow = true;
-                sp = 0;
-            }
-            const bool can = sp > 0;
-            if(__ballot(can) == 0)
-                break;
-            if(++guard > guard_max || __ballot(can && sp + 8 > STK) != 0) {
-                if(lane == 0)
-                    atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
-                return;
-            }
-            const unsigned range = can ? stack[sp - 1] : 0u;
-            const int nch = (int)(range & 15u);
-            const bool mine = s < nch; // false for every lane of a group that is not walking
-            const int my = mine ? (int)(range >> 4) + s : 0;
-            const NodeGeo g = tv.geoB[my];
-            const Src4 mom = tv.momB[my];
-            const NodeLinkB lk = tv.linkB[my];
-            // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
-            const double kx = rint((g.cx - px) * gp.invbox);
-            const double ky = rint((g.cy - py) * gp.invbox);
-            const double kz = rint((g.cz - pz) * gp.invbox);
-            double dx, dy, dz, cdx, cdy, cdz;
-            bool wr = false;
-            if(FASTWRAP) {
-                const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
-                cdx = fabs(g.cx - qx);
-                cdy = fabs(g.cy - qy);
-                cdz = fabs(g.cz - qz);
-                dx = mom.x - qx;
-                dy = mom.y - qy;
-                dz = mom.z - qz;
-                wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
-                if(g.len * 4.0 > gp.box) {
-                    // top levels only: centre of mass and geometric centre may sit on different periodic
-                    // images; take NEAREST(cofm - pos) exactly as gravshort-tree.c:299-300 does
-                    const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox),
-                                 jz = rint((mom.z - pz) * gp.invbox);
-                    dx = fma(-jx, gp.box, mom.x - px);
-                    dy = fma(-jy, gp.box, mom.y - py);
-                    dz = fma(-jz, gp.box, mom.z - pz);
-                    wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
-                }
-            }
-            else {
-                cdx = fabs(fma(-kx, gp.box, g.cx - px));
-                cdy = fabs(fma(-ky, gp.box, g.cy - py));
-                cdz = fabs(fma(-kz, gp.box, g.cz - pz));
-                dx = nearest_img(mom.x - px, gp.box, gp.invbox);
-                dy = nearest_img(mom.y - py, gp.box, gp.invbox);
-                dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
-            }
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            // shall_we_discard_node, gravshort-tree.c:198-215
-            const double eff = fma(0.5, g.len, gp.rcut);
-            const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
-            // shall_we_open_node, gravshort-tree.c:220-241
-            const double l2 = g.len * g.len;
-            const double inside = 0.6 * g.len;
-            const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) ||
-                              (cdx < inside && cdy < inside && cdz < inside);
-            const bool keep = mine && !discard;
-            const bool b_node = keep && !open;                                   // used unopened: a 1-element source
-            const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
-            const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
-            const unsigned gm_leaf = (unsigned)((__ballot(b_leaf) >> gshift) & 0xffull);
-            const unsigned gm_node = (unsigned)((__ballot(b_node) >> gshift) & 0xffull);
-            const unsigned gm_push = (unsigned)((__ballot(b_push) >> gshift) & 0xffull);
-            const unsigned gm_wrap = (unsigned)((__ballot(wr && (b_leaf || b_node)) >> gshift) & 0xffull);
-            if(b_leaf) {
-                const int e = nleaf + __popc(gm_leaf & below);
-                L[((e >> 3) << 6) + (e & 7)] = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-            }
-            if(b_node) {
-                const int e = cap - 1 - (nnode + __popc(gm_node & below));
-                L[((e >> 3) << 6) + (e & 7)] = (unsigned)my;
-            }
-            if(b_push)
-                stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
-            // (all masks are zero for a group that is not walking)
-            nleaf += __popc(gm_leaf);
-            nnode += __popc(gm_node);
-            sp += __popc(gm_push) - (can ? 1 : 0);
-            wrapped = wrapped || (gm_wrap != 0);
-            if(COUNT) {
-                c_vis += mine ? 1u : 0u;
-                c_used += b_node ? 1u : 0u;
-                c_pp += b_leaf ? (unsigned)lk.pcount : 0u;
-                if(can && s == 0) {
-                    st_a++;
-                    st_al += nch;
-                }
-            }
+        bool ok;
+        if(FASTWRAP) {
+            const bool near_face = valid && (fmin(fmin(px, py), pz) < face || fmax(fmax(px, py), pz) > gp.box - face);
+            if(__ballot(near_face) == 0)
+                ok = walk_target<COUNT, 2>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
+                                           overflow, c_pp, c_vis, c_used, st_a, st_al);
+            else
+                ok = walk_target<COUNT, 1>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
+                                           overflow, c_pp, c_vis, c_used, st_a, st_al);
         }
+        else
+            ok = walk_target<COUNT, 0>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped, overflow,
+                                       c_pp, c_vis, c_used, st_a, st_al);
+        if(!ok)
+            return;
         if(valid && s == 0) {
             if(overflow) {
                 counts[rel] = make_int2(-1, 0);
@@ -333,7 +382,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
 template <bool POT, bool WRAP>
 __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
                                            const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
-                                           const double py, const double pz, const WTabD *__restrict__ s_wf, const WTabD *__restrict__ s_wp,
+                                           const double py, const double pz, const double *__restrict__ s_wtab,
                                            double &ax, double &ay, double &az, double &pot)
 {
     const unsigned empty = (zero_src << 3) | 7u; // a full "leaf" of zero-mass padding records
@@ -351,7 +400,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
             dy_ = nearest_img(dy_, gp.box, gp.invbox);                            \
             dz_ = nearest_img(dz_, gp.box, gp.invbox);                            \
         }                                                                         \
-        pair_force<POT>(SV, dx_, dy_, dz_, gp, s_wf, s_wp, ax, ay, az, pot);      \
+        pair_force<POT>(SV, dx_, dy_, dz_, gp, s_wtab, ax, ay, az, pot);           \
         asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(pot));               \
         __builtin_amdgcn_sched_barrier(0);                                        \
     }
@@ -404,17 +453,16 @@ template <bool POT, bool FASTWRAP>
 __global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
                                                     const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
 {
-    __shared__ WTabD s_wf[NTAB];
-    __shared__ WTabD s_wp[POT ? NTAB : 1];
-    for(int i = threadIdx.x; i < NTAB - 1; i += blockDim.x) {
-        s_wf[i] = WTabD{(double)io.tab_force[i], (double)io.tab_force[i + 1]};
-        if(POT)
-            s_wp[i] = WTabD{(double)io.tab_pot[i], (double)io.tab_pot[i + 1]};
-    }
-    if(threadIdx.x == 0) {
-        s_wf[NTAB - 1] = WTabD{0, 0};
-        if(POT)
-            s_wp[NTAB - 1] = WTabD{0, 0};
+    constexpr int ROW = POT ? 4 : 2;
+    __shared__ __attribute__((aligned(16))) double s_wtab[NTAB * ROW];
+    for(int i = threadIdx.x; i < NTAB; i += blockDim.x) {
+        const bool last = i == NTAB - 1; // the row the clamp lands on: zeros
+        s_wtab[i * ROW + 0] = last ? 0.0 : (double)io.tab_force[i];
+        s_wtab[i * ROW + 1] = last ? 0.0 : (double)io.tab_force[i + 1] - (double)io.tab_force[i];
+        if(POT) {
+            s_wtab[i * ROW + 2] = last ? 0.0 : (double)io.tab_pot[i];
+            s_wtab[i * ROW + 3] = last ? 0.0 : (double)io.tab_pot[i + 1] - (double)io.tab_pot[i];
+        }
     }
     __syncthreads();
 
@@ -450,9 +498,9 @@ __global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeVi
         const unsigned *__restrict__ L = lists + (size_t)chunk * (size_t)cap * 8 + gshift;
         double ax = 0, ay = 0, az = 0, pot = 0;
         if(!FASTWRAP || __ballot(wrapped) != 0) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
-            eval_lists<POT, true>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wf, s_wp, ax, ay, az, pot);
+            eval_lists<POT, true>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         else
-            eval_lists<POT, false>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wf, s_wp, ax, ay, az, pot);
+            eval_lists<POT, false>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         // reduce the partial sums over the 8 lanes of the group
         for(int off = 1; off < 8; off <<= 1) {
             ax += __shfl_xor(ax, off);
