@@ -115,6 +115,23 @@ __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const 
         pot = fma(facpot, fma(w1, p.y, p.x), pot);
 }
 
+// element i of a device array.  O32: the byte offset fits 32 bits (decided on the host), which lets the load use the
+// scalar-base + 32-bit-offset addressing mode instead of 64-bit vector address arithmetic
+template <bool O32, typename T>
+__device__ __forceinline__ T ld(const T *__restrict__ base, const unsigned i)
+{
+    if(O32)
+        return *(const T *)((const char *)base + (size_t)(unsigned)(i * (unsigned)sizeof(T)));
+    return base[i];
+}
+
+__device__ __forceinline__ void st32(unsigned *__restrict__ base, const unsigned i, const unsigned v)
+{
+    *(unsigned *)((char *)base + (size_t)(unsigned)(i * 4u)) = v; // offsets inside one chunk's list area: always < 2^32 bytes
+}
+
+__device__ __forceinline__ bool any_lane(const bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }
+
 __device__ __forceinline__ double nearest_img(double d, double box, double invbox) { return fma(-rint(d * invbox), box, d); }
 
 // chunks of 8 targets (one per 8-lane group) of the slice; XCD x (= blockIdx % 8, where the hardware places this block) owns
@@ -141,10 +158,10 @@ struct ChunkIter {
 // of a node can sit on another image than its centre only if Rcut + len >= Box/2 (the root and its children, two steps per
 // target): those take NEAREST() for both, exactly as gravshort-tree.c:299-300 does.
 // Returns false on an internal error (loop guard / stack), which ends the kernel.
-template <bool COUNT, int MODE>
-__device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ L, unsigned *__restrict__ stack,
+template <bool COUNT, int MODE, bool O32>
+__device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ stack,
                                             const int cap, const int lane, const int s, const int gshift, const bool valid, const double px,
-                                            const double py, const double pz, const double aold, const unsigned long long guard_max,
+                                            const double py, const double pz, const double aold, const unsigned guard_max,
                                             unsigned *__restrict__ ctl, int &nleaf, int &nnode, bool &wrapped, bool &overflow, unsigned &c_pp,
                                             unsigned &c_vis, unsigned &c_used, unsigned &st_a, unsigned &st_al)
 {
@@ -155,7 +172,8 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
             stack[0] = (0u << 4) | 1u; // the root
         sp = 1;
     }
-    unsigned long long guard = 0;
+    unsigned guard = 0;
+    bool err = false, wrap_lane = false;
     // One step per iteration, written without divergent control flow (the first form, an `act` code set in nested
     // branches, cost ~25 register moves and three extra exec-mask regions per step): every lane computes the tests for
     // "its" child (idle lanes recompute the root, a broadcast read), the outcomes are booleans, and only the three kinds
@@ -166,20 +184,19 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
             sp = 0;
         }
         const bool can = sp > 0;
-        if(__ballot(can) == 0)
+        if(!any_lane(can))
             break;
-        if(++guard > guard_max || __ballot(can && sp + 8 > STK) != 0) {
-            if(lane == 0)
-                atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
-            return false;
+        if(++guard > guard_max || any_lane(sp + 8 > STK)) { // (one exit for both, so that the loop keeps a single latch)
+            err = true;
+            break;
         }
         const unsigned range = can ? stack[sp - 1] : 0u;
         const int nch = (int)(range & 15u);
         const bool mine = s < nch; // false for every lane of a group that is not walking
-        const int my = mine ? (int)(range >> 4) + s : 0;
-        const NodeGeo g = tv.geoB[my];
-        const Src4 mom = tv.momB[my];
-        const NodeLinkB lk = tv.linkB[my];
+        const unsigned my = mine ? (range >> 4) + (unsigned)s : 0u;
+        const NodeGeo g = ld<O32>(tv.geoB, my);
+        const Src4 mom = ld<O32>(tv.momB, my);
+        const NodeLinkB lk = ld<O32>(tv.linkB, my);
         double dx, dy, dz, cdx, cdy, cdz;
         bool wr = false;
         if(MODE == 0) {
@@ -239,16 +256,16 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
         const bool b_node = keep && !open;                                   // used unopened: a 1-element source
         const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
         const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
-        const unsigned gm_leaf = (unsigned)((__ballot(b_leaf) >> gshift) & 0xffull);
-        const unsigned gm_node = (unsigned)((__ballot(b_node) >> gshift) & 0xffull);
-        const unsigned gm_push = (unsigned)((__ballot(b_push) >> gshift) & 0xffull);
+        const unsigned gm_leaf = (unsigned)((__builtin_amdgcn_ballot_w64(b_leaf) >> gshift) & 0xffull);
+        const unsigned gm_node = (unsigned)((__builtin_amdgcn_ballot_w64(b_node) >> gshift) & 0xffull);
+        const unsigned gm_push = (unsigned)((__builtin_amdgcn_ballot_w64(b_push) >> gshift) & 0xffull);
         if(b_leaf) {
-            const int e = nleaf + __popc(gm_leaf & below);
-            L[((e >> 3) << 6) + (e & 7)] = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+            const unsigned e = (unsigned)(nleaf + __popc(gm_leaf & below));
+            st32(Lw, ((e >> 3) << 6) + (unsigned)gshift + (e & 7u), ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1));
         }
         if(b_node) {
-            const int e = cap - 1 - (nnode + __popc(gm_node & below));
-            L[((e >> 3) << 6) + (e & 7)] = (unsigned)my;
+            const unsigned e = (unsigned)(cap - 1 - (nnode + __popc(gm_node & below)));
+            st32(Lw, ((e >> 3) << 6) + (unsigned)gshift + (e & 7u), my);
         }
         if(b_push)
             stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
@@ -256,10 +273,8 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
         nleaf += __popc(gm_leaf);
         nnode += __popc(gm_node);
         sp += __popc(gm_push) - (can ? 1 : 0);
-        if(MODE != 0) {
-            const unsigned gm_wrap = (unsigned)((__ballot(wr && (b_leaf || b_node)) >> gshift) & 0xffull);
-            wrapped = wrapped || (gm_wrap != 0);
-        }
+        if(MODE != 0)
+            wrap_lane = wrap_lane || (wr && (b_leaf || b_node));
         if(COUNT) {
             c_vis += mine ? 1u : 0u;
             c_used += b_node ? 1u : 0u;
@@ -270,12 +285,19 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
             }
         }
     }
+    if(err) {
+        if(lane == 0)
+            atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
+        return false;
+    }
+    if(MODE != 0) // an entry of this target lies on a wrapped image
+        wrapped = ((__builtin_amdgcn_ballot_w64(wrap_lane) >> gshift) & 0xffull) != 0;
     return true;
 }
 
 // ctl words: [0] number of overflowed targets, [1] error flag (loop guard / stack), [2] longest list seen
 // counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] group steps [4] children tested
-template <bool COUNT, bool FASTWRAP>
+template <bool COUNT, bool FASTWRAP, bool O32>
 __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
                                                      int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
                                                      unsigned *__restrict__ ctl, int *__restrict__ ovf)
@@ -287,7 +309,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * STK; // pending child ranges of this group: (first << 4) | count
     const unsigned nchunks = (unsigned)((nslots + 7) / 8);
     const ChunkIter it(nchunks);
-    const unsigned long long guard_max = 64ull * (unsigned long long)(tv.nnodes + 1024);
+    const unsigned guard_max = (unsigned)min((long long)(64ll * (tv.nnodes + 1024)), 0x7fffffffll);
     const double face = gp.rcut + 0.002 * gp.box; // MODE 2 margin (the root cell is 1.001 Box wide: + Box/2000, with slack)
     unsigned n_pp = 0, n_vis = 0, n_used = 0, st_a = 0, st_al = 0;
 
@@ -315,22 +337,23 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
             }
             aold = gp.errtol * old;
         }
-        unsigned *__restrict__ L = lists + (size_t)chunk * (size_t)cap * 8 + gshift;
+        // (chunk is wave-uniform: a scalar base lets the list stores use 32-bit offsets)
+        unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8;
         int nleaf = 0, nnode = 0; // entries in the two lists (group-uniform)
         bool wrapped = false, overflow = false;
         unsigned c_pp = 0, c_vis = 0, c_used = 0;
         bool ok;
         if(FASTWRAP) {
             const bool near_face = valid && (fmin(fmin(px, py), pz) < face || fmax(fmax(px, py), pz) > gp.box - face);
-            if(__ballot(near_face) == 0)
-                ok = walk_target<COUNT, 2>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
+            if(!any_lane(near_face))
+                ok = walk_target<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
                                            overflow, c_pp, c_vis, c_used, st_a, st_al);
             else
-                ok = walk_target<COUNT, 1>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
+                ok = walk_target<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
                                            overflow, c_pp, c_vis, c_used, st_a, st_al);
         }
         else
-            ok = walk_target<COUNT, 0>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped, overflow,
+            ok = walk_target<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped, overflow,
                                        c_pp, c_vis, c_used, st_a, st_al);
         if(!ok)
             return;
@@ -379,7 +402,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
 // source (short leaf, list exhausted) reads a zero-mass padding record behind the tree's source array instead: its pair
 // evaluates to exactly zero, so the accumulators are updated unconditionally (a conditional update makes hipcc keep a
 // renamed copy of the four accumulators per unrolled stage).
-template <bool POT, bool WRAP>
+template <bool POT, bool WRAP, bool O32>
 __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
                                            const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
                                            const double py, const double pz, const double *__restrict__ s_wtab,
@@ -389,7 +412,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
 #define MPG_LOAD(ENT, J, SV)                                                                \
     {                                                                                       \
         const unsigned ej_ = (unsigned)__shfl((int)(ENT), gshift + (J));                    \
-        SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
+        SV = ld<O32>(tv.src, (s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src); \
     }
 #define MPG_EVAL(SV)                                                              \
     {                                                                             \
@@ -408,14 +431,15 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // two source buffers (A, B) used alternately: while one pair is evaluated the other buffer's load is in flight.  The
         // stage loop is deliberately not unrolled beyond that: every unrolled stage carries its own copy of the (rare)
         // softened branch, and those copies are what drives register pressure and code size.
-        unsigned ent = (s < nleaf) ? L[s] : empty;
-        unsigned ent_n = (8 + s < nleaf) ? L[64 + s] : empty;
+        const unsigned ls = (unsigned)(gshift + s);
+        unsigned ent = (s < nleaf) ? ld<true>(L, ls) : empty;
+        unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, 64u + ls) : empty;
         Src4 A, B;
         MPG_LOAD(ent, 0, A);
         for(int e0 = 0;; e0 += 8) {
-            if(__ballot(e0 < nleaf) == 0)
+            if(!any_lane(e0 < nleaf))
                 break;
-            const unsigned ent_nn = (e0 + 16 + s < nleaf) ? L[(((e0 + 16) >> 3) << 6) + s] : empty;
+            const unsigned ent_nn = (e0 + 16 + s < nleaf) ? ld<true>(L, (((unsigned)(e0 + 16) >> 3) << 6) + ls) : empty;
 #pragma unroll 1
             for(int j = 0; j < 8; j += 2) {
                 MPG_LOAD(ent, j + 1, B);
@@ -429,18 +453,18 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         }
     }
     // ---- node entries (level-order indices): lane s takes entry r0 + s; entries two batches ahead, moments one
-    if(__ballot(nnode > 0) != 0) {
-        constexpr unsigned NONE = 0xffffffffu;
-        const int top = ((cap - 8) >> 3) << 6;
-        unsigned ne = (s < nnode) ? L[top + (7 - s)] : NONE;
-        unsigned ne_n = (8 + s < nnode) ? L[top - 64 + (7 - s)] : NONE;
-        Src4 sc = *(ne != NONE ? &tv.momB[ne] : &tv.src[zero_src]);
+    if(any_lane(nnode > 0)) {
+        const unsigned NONE = (unsigned)tv.nnodes; // a zero-mass padding record behind the moments (TreeBuilder::make_level_order)
+        const unsigned top = (((unsigned)(cap - 8) >> 3) << 6) + (unsigned)(gshift + 7 - s);
+        unsigned ne = (s < nnode) ? ld<true>(L, top) : NONE;
+        unsigned ne_n = (8 + s < nnode) ? ld<true>(L, top - 64u) : NONE;
+        Src4 sc = ld<O32>(tv.momB, ne);
         for(int r0 = 0;; r0 += 8) {
-            if(__ballot(r0 < nnode) == 0)
+            if(!any_lane(r0 < nnode))
                 break;
             ne = ne_n;
-            ne_n = (r0 + 16 + s < nnode) ? L[top - (((r0 + 16) >> 3) << 6) + (7 - s)] : NONE;
-            const Src4 sc_n = *(ne != NONE ? &tv.momB[ne] : &tv.src[zero_src]);
+            ne_n = (r0 + 16 + s < nnode) ? ld<true>(L, top - (((unsigned)(r0 + 16) >> 3) << 6)) : NONE;
+            const Src4 sc_n = ld<O32>(tv.momB, ne);
             MPG_EVAL(sc);
             sc = sc_n;
         }
@@ -449,7 +473,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
 #undef MPG_EVAL
 }
 
-template <bool POT, bool FASTWRAP>
+template <bool POT, bool FASTWRAP, bool O32>
 __global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
                                                     const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
 {
@@ -495,12 +519,12 @@ __global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeVi
                 pz = io.pos[3 * (int64_t)ci + 2];
             }
         }
-        const unsigned *__restrict__ L = lists + (size_t)chunk * (size_t)cap * 8 + gshift;
+        const unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8; // wave-uniform
         double ax = 0, ay = 0, az = 0, pot = 0;
-        if(!FASTWRAP || __ballot(wrapped) != 0) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
-            eval_lists<POT, true>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+        if(!FASTWRAP || any_lane(wrapped)) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
+            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         else
-            eval_lists<POT, false>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         // reduce the partial sums over the 8 lanes of the group
         for(int off = 1; off < 8; off <<= 1) {
             ax += __shfl_xor(ax, off);
@@ -554,11 +578,11 @@ int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_p
     return (int)((nblocks + 7) / 8 * 8);
 }
 
-template <bool POT, bool COUNT, bool FASTWRAP>
+template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
-    auto kl = k_walk_lists<COUNT, FASTWRAP>;
-    auto ke = k_walk_eval<POT, FASTWRAP>;
+    auto kl = k_walk_lists<COUNT, FASTWRAP, O32>;
+    auto ke = k_walk_eval<POT, FASTWRAP, O32>;
     const int cap = ws.split_cap;
     // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
     int64_t slice = (int64_t)(ws.split_bytes / ((size_t)cap * sizeof(unsigned))) / 2048 * 2048;
@@ -622,12 +646,18 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
     MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
     ws.ctr.reserve(16);
     MPG_HIP(hipMemsetAsync(ws.ctr.p, 0, 16 * sizeof(unsigned), st));
-#define MPG_WS(P, C)                                        \
-    do {                                                    \
-        if(fastwrap)                                        \
-            launch_split_t<P, C, true>(tv, gp, io, ws, st); \
-        else                                                \
-            launch_split_t<P, C, false>(tv, gp, io, ws, st);\
+    // 32-bit byte offsets into the source and node arrays (32-byte records, padding included)?
+    const bool o32 = (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
+#define MPG_WS(P, C)                                                \
+    do {                                                            \
+        if(fastwrap) {                                              \
+            if(o32)                                                 \
+                launch_split_t<P, C, true, true>(tv, gp, io, ws, st);  \
+            else                                                    \
+                launch_split_t<P, C, true, false>(tv, gp, io, ws, st); \
+        }                                                           \
+        else                                                        \
+            launch_split_t<P, C, false, false>(tv, gp, io, ws, st); \
     } while(0)
     if(want_pot) {
         if(count)

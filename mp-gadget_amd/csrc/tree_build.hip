@@ -422,6 +422,8 @@ void TreeBuilder::make_level_order(hipStream_t st)
     linkB.reserve(M + 16);
     if(has_hmax)
         hmaxB.reserve(M + 16);
+    // zero-mass padding records behind the moments (the evaluation kernel points idle lanes of its node loop at them)
+    MPG_HIP(hipMemsetAsync(momB.p + M, 0, 16 * sizeof(Src4), st));
     hipLaunchKernelGGL(k_node_levels, dim3(nblk(M)), dim3(256), 0, st, M, link.p, lvl_a.p, nid_a.p);
     size_t tb = 0;
     MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb, lvl_a.p, lvl_b.p, nid_a.p, nid_b.p, (size_t)M, 0, 5, st));
