@@ -298,6 +298,54 @@ int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int
 int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_gravaccel, const double *d_gravpm, double atime, double hubble,
                                    double ErrTolIntAccuracy, double *d_dloga);
 
+/* ---- hierarchical gravity (SplitGravityTimestepsOn, the default): the level loop of timestep.c:239-599 on
+ * device-resident arrays.  Per level it builds the tree of the particles active at that level (force_tree_active_moments),
+ * walks it for exactly those particles into a separate acceleration array (grav_short_tree with AccelStore) and applies the
+ * hierarchical half kick; the first half of a step also assigns the gravity time bins.  The integer timeline, the kick times
+ * and the kick integrals stay with the caller: it passes its sync points, its DriftKickTimes and a callback for
+ * get_exact_gravkick_factor.  Not carried here: get_PM_timestep_ti (the caller passes the PM step length it found), the hydro
+ * bins (find_hydro_timesteps), star / black-hole particles created during the step. */
+typedef struct {            /* the integer timeline: SyncPoints[i].loga (timebinmgr.c:18, 372-417); host array, nsync >= 2 */
+    int64_t nsync;
+    const double *loga;
+} mpg_timeline;
+typedef struct {            /* DriftKickTimes, timestep.h:10-27 (same fields, same order) */
+    int mintimebin, maxtimebin, mingravtimebin;
+    int64_t Ti_kick[MPG_TIMEBINS + 1];
+    int64_t Ti_lastactivedrift[MPG_TIMEBINS + 1];
+    int64_t Ti_Current;
+    int64_t PM_length, PM_start, PM_kick;
+} mpg_drift_kick_times;
+typedef double (*mpg_gravkick_fn)(void *ctx, int64_t ti0, int64_t ti1); /* get_exact_gravkick_factor(CP, ti0, ti1), timefac.c:65-68 */
+typedef struct {            /* device arrays in particle order (the particles bound with mpg_dev_bind_particles) */
+    double *d_vel;                  /* P[].Vel              [n][3] */
+    const double *d_gravpm;         /* P[].GravPM           [n][3] */
+    double *d_fulltree_accel;       /* P[].FullTreeGravAccel[n][3] */
+    double *d_potential;            /* P[].Potential        [n] (written by walks over a full tree; may be NULL) */
+    unsigned char *d_tb_grav;       /* P[].TimeBinGravity   [n] */
+    const unsigned char *d_flags;   /* bit 0 IsGarbage, bit 1 Swallowed; may be NULL */
+    double *d_stored_accel;         /* StoredGravAccel.GravAccel [n][3], or NULL: FullTreeGravAccel plays its part */
+} mpg_hiergrav_arrays;
+typedef struct {            /* TimestepParams (timestep.c:40-60) as far as this path reads them */
+    double ErrTolIntAccuracy, MinSizeTimestep;
+} mpg_timestep_params;
+/* hierarchical_gravity_and_timesteps (timestep.c:293-490).  d_active: the active list (NULL = all n particles), with
+ * NumActiveGravity of them gravitationally active.  On a PM step (Ti_Current == PM_start + PM_length) dti_max_pm is the
+ * caller's get_PM_timestep_ti and times->PM_length / PM_start are updated as the reference does.  rho0 = the mean density
+ * of grav_short_tree.  Returns in *badstepsizecount the number of particles print_bad_timebin would have reported. */
+int mpg_dev_hierarchical_gravity_and_timesteps(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *d_active, int64_t NumActiveParticle,
+                                               int64_t NumActiveGravity, mpg_drift_kick_times *times, const mpg_timeline *timeline,
+                                               const mpg_timestep_params *par, double atime, double hubble, int64_t dti_max_pm, double rho0,
+                                               int HybridNuGrav, mpg_gravkick_fn gravkick, void *gravkick_ctx, int64_t *badstepsizecount);
+/* hierarchical_gravity_accelerations (timestep.c:495-599): the second half of the step. */
+int mpg_dev_hierarchical_gravity_accelerations(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *d_active, int64_t NumActiveParticle,
+                                               int64_t NumActiveGravity, mpg_drift_kick_times *times, double rho0, int HybridNuGrav,
+                                               mpg_gravkick_fn gravkick, void *gravkick_ctx);
+/* build_active_sublist (timestep.c:1435-1478): the entries of d_active (NULL = all n) that are not garbage, whose gravity bin
+ * is <= maxtimebin and active at Ti_Current, order preserved.  d_out must hold NumActiveParticle entries. */
+int mpg_dev_build_active_sublist(mpg_engine *eng, const int *d_active, int64_t NumActiveParticle, const unsigned char *d_tb_grav,
+                                 const unsigned char *d_flags, int maxtimebin, int64_t Ti_Current, int *d_out, int64_t *n_out);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

@@ -124,6 +124,12 @@ struct mpg_engine {
     DevBuf<int> s_active;
     DevBuf<unsigned> ts_flag;
     DevBuf<uint8_t> tree_incl; // particles included in an active-particle tree
+    // hierarchical gravity (timestep.c:239-599): active sublists (ping-pong), the per-level acceleration array, scratch
+    DevBuf<int> hier_list[2], hier_val;
+    DevBuf<uint8_t> hier_keep;
+    DevBuf<double> hier_accel, hier_sp;
+    DevBuf<unsigned long long> hier_cnt;
+    DevBuf<char> hier_tmp;
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
     HostBuf<uint8_t> h_b;
@@ -663,6 +669,267 @@ int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_g
     MPG_CHECK(eng->GravitySoftening > 0, "timestep: gravshort_set_softenings has not been called");
     MPG_HIP(hipSetDevice(eng->device));
     launch_timestep_gravity(n, d_gravaccel, d_gravpm, atime, hubble, ErrTolIntAccuracy, 2.8 * eng->GravitySoftening, d_dloga, eng->stream);
+    API_END
+}
+
+/* ------------------------------ hierarchical gravity (timestep.c:239-599) ------------------------------ */
+
+} // extern "C" (helpers below have C++ linkage)
+
+static inline int64_t dti_from_timebin(int bin) { return bin > 0 ? ((int64_t)1 << bin) : 0; } // timebinmgr.h:47-50
+static inline bool is_timebin_active(int i, int64_t current) // timestep.c:143-150
+{
+    if(i <= 0 || current <= 0)
+        return true;
+    return current % dti_from_timebin(i) == 0;
+}
+
+// build_active_sublist on the device; returns the count (one small D2H copy: the reference needs the count on the host as well)
+static int64_t hier_sublist(mpg_engine *eng, const int *list, int64_t nlist, const uint8_t *tb, const uint8_t *flags, int maxtimebin,
+                            int64_t Ti_Current, int *out)
+{
+    eng->hier_val.reserve((size_t)nlist + 1);
+    eng->hier_keep.reserve((size_t)nlist + 1);
+    eng->hier_cnt.reserve(64);
+    launch_sublist_flags(list, nlist, tb, flags, maxtimebin, Ti_Current, eng->hier_val.p, eng->hier_keep.p, eng->stream);
+    compact_flagged(eng->hier_val.p, eng->hier_keep.p, nlist, out, eng->hier_cnt.p + 60, eng->hier_tmp, eng->stream);
+    unsigned long long c = 0;
+    MPG_HIP(hipMemcpyAsync(&c, eng->hier_cnt.p + 60, sizeof(c), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    return (int64_t)c;
+}
+
+// grav_short_tree_build_tree (timestep.c:281-291): tree of the listed particles, walk for them into `accel`
+static void hier_tree_and_walk(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *list, int64_t nlist, double *accel, double rho0,
+                               int HybridNuGrav)
+{
+    if(list && nlist == 0)
+        return; // nothing active on this rank: an empty tree and an empty walk
+    if(mpg_dev_force_tree_active_moments(eng, list, list ? nlist : 0, HybridNuGrav) != 0)
+        fail(__FILE__, __LINE__, mpg_last_error());
+    if(mpg_dev_grav_short_tree(eng, nullptr, A->d_fulltree_accel, A->d_gravpm, list, nlist, accel, A->d_potential, rho0) != 0)
+        fail(__FILE__, __LINE__, mpg_last_error());
+    // a tree of all particles: grav_short_postprocess also stores the result in P[].FullTreeGravAccel (gravshort.h:47-67)
+    if(eng->full_particle_tree && accel != A->d_fulltree_accel)
+        MPG_HIP(hipMemcpyAsync(A->d_fulltree_accel, accel, 3 * (size_t)eng->n * sizeof(double), hipMemcpyDeviceToDevice, eng->stream));
+}
+
+// apply_hierarchical_grav_kick, timestep.c:238-278
+static void hier_kick(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *list, int64_t nlist, const double *accel,
+                      const mpg_drift_kick_times *times, int ti, int largest_active, mpg_gravkick_fn fn, void *ctx)
+{
+    const int64_t dti = dti_from_timebin(ti);
+    double gravkick = fn(ctx, times->Ti_kick[ti], times->Ti_kick[ti] + dti / 2);
+    if(ti < largest_active) {
+        const int64_t lowerdti = dti_from_timebin(ti + 1);
+        gravkick -= fn(ctx, times->Ti_kick[ti + 1], times->Ti_kick[ti + 1] + lowerdti / 2);
+    }
+    launch_kick_list(list, nlist, A->d_vel, accel ? accel : A->d_fulltree_accel, A->d_flags, gravkick, eng->stream);
+}
+
+static int hier_largest_active(const mpg_drift_kick_times *times, int *ti_out)
+{
+    int ti, largest_active = MPG_TIMEBINS;
+    for(ti = MPG_TIMEBINS; ti >= 0; ti--)
+        if(is_timebin_active(ti, times->Ti_Current) && dti_from_timebin(ti) <= times->PM_length) {
+            largest_active = ti;
+            break;
+        }
+    if(ti_out)
+        *ti_out = ti;
+    return largest_active;
+}
+
+// timebinmgr.c:372-417 on the host
+static double host_dloga_interval(const mpg_timeline *tl, int64_t ti)
+{
+    const int64_t lastsnap = ti >> MPG_TIMEBINS;
+    if(lastsnap >= tl->nsync - 1)
+        return 0;
+    return (tl->loga[lastsnap + 1] - tl->loga[lastsnap]) / (double)(1ull << MPG_TIMEBINS);
+}
+static double host_loga_from_ti(const mpg_timeline *tl, int64_t ti)
+{
+    const int64_t lastsnap = ti >> MPG_TIMEBINS;
+    MPG_CHECK(lastsnap >= 0 && lastsnap < tl->nsync, "loga_from_ti: Ti_Current beyond the last sync point");
+    const int64_t dti = ti & (((int64_t)1 << MPG_TIMEBINS) - 1);
+    return tl->loga[lastsnap] + dti * host_dloga_interval(tl, ti);
+}
+static int64_t host_ti_from_loga(const mpg_timeline *tl, double loga)
+{
+    int64_t i;
+    for(i = 1; i < tl->nsync - 1; i++)
+        if(tl->loga[i] > loga)
+            break;
+    const double logDTime = (tl->loga[i] - tl->loga[i - 1]) / (double)(1ull << MPG_TIMEBINS);
+    int64_t ti = (i - 1) << MPG_TIMEBINS;
+    ti = (int64_t)((double)ti + (loga - tl->loga[i - 1]) / logDTime);
+    return ti;
+}
+
+extern "C" {
+
+int mpg_dev_build_active_sublist(mpg_engine *eng, const int *d_active, int64_t NumActiveParticle, const unsigned char *d_tb_grav,
+                                 const unsigned char *d_flags, int maxtimebin, int64_t Ti_Current, int *d_out, int64_t *n_out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_tb_grav && d_out && n_out && NumActiveParticle >= 0, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    *n_out = hier_sublist(eng, d_active, NumActiveParticle, d_tb_grav, d_flags, maxtimebin, Ti_Current, d_out);
+    API_END
+}
+
+int mpg_dev_hierarchical_gravity_and_timesteps(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *d_active, int64_t NumActiveParticle,
+                                               int64_t NumActiveGravity, mpg_drift_kick_times *times, const mpg_timeline *timeline,
+                                               const mpg_timestep_params *par, double atime, double hubble, int64_t dti_max_pm, double rho0,
+                                               int HybridNuGrav, mpg_gravkick_fn gravkick, void *gravkick_ctx, int64_t *badstepsizecount)
+{
+    API_BEGIN
+    MPG_CHECK(eng && A && times && timeline && par && gravkick && badstepsizecount, "null argument");
+    MPG_CHECK(A->d_vel && A->d_gravpm && A->d_fulltree_accel && A->d_tb_grav, "hierarchical gravity: Vel, GravPM, FullTreeGravAccel and TimeBinGravity are needed");
+    MPG_CHECK(timeline->nsync >= 2 && timeline->loga, "hierarchical gravity: the timeline needs at least two sync points");
+    MPG_CHECK(eng->GravitySoftening > 0, "timestep: gravshort_set_softenings has not been called");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int64_t n = eng->n;
+    const int64_t nact = d_active ? NumActiveParticle : n;
+    // is_PM_timestep, timestep.c:153-159
+    MPG_CHECK(times->Ti_Current <= times->PM_start + times->PM_length, "Passed end of PM step!");
+    const bool isPM = times->Ti_Current == times->PM_start + times->PM_length;
+    int64_t dti_max = times->PM_length;
+    if(isPM) { // timestep.c:303-309
+        dti_max = dti_max_pm;
+        times->PM_length = dti_max;
+        times->PM_start = times->PM_kick;
+    }
+    int largest_active = hier_largest_active(times, nullptr);
+    // the gravitationally active particles (timestep.c:323-328)
+    eng->hier_list[0].reserve((size_t)nact + 1);
+    eng->hier_list[1].reserve((size_t)nact + 1);
+    const int *sub = d_active;
+    int64_t nsub = nact;
+    int cur = 0; // hier_list[cur] is free
+    if(!(NumActiveGravity == NumActiveParticle || isPM)) {
+        nsub = hier_sublist(eng, d_active, nact, A->d_tb_grav, A->d_flags, largest_active, times->Ti_Current, eng->hier_list[0].p);
+        sub = eng->hier_list[0].p;
+        cur = 1;
+    }
+    // the timeline for the per-particle conversion
+    eng->hier_sp.reserve((size_t)timeline->nsync + 1);
+    MPG_HIP(hipMemcpyAsync(eng->hier_sp.p, timeline->loga, (size_t)timeline->nsync * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    HierTimeline T;
+    T.sp = eng->hier_sp.p;
+    T.nsync = (int)timeline->nsync;
+    T.loga_cur = host_loga_from_ti(timeline, times->Ti_Current);
+    T.ti0 = host_ti_from_loga(timeline, T.loga_cur);
+    T.MinSizeTimestep = par->MinSizeTimestep;
+    const double soft = 2.8 * eng->GravitySoftening; // FORCE_SOFTENING
+    // new gravity bins from the acceleration of the longest step (timestep.c:345-370)
+    eng->hier_cnt.reserve(64);
+    MPG_HIP(hipMemsetAsync(eng->hier_cnt.p, 0, 64 * sizeof(unsigned long long), eng->stream));
+    const double *topacc = A->d_stored_accel ? A->d_stored_accel : A->d_fulltree_accel;
+    launch_assign_gravity_bins(sub, nsub, topacc, A->d_gravpm, A->d_flags, atime, hubble, par->ErrTolIntAccuracy, soft, T, dti_max, largest_active,
+                               A->d_tb_grav, eng->hier_cnt.p, eng->hier_cnt.p + 48, eng->stream);
+    unsigned long long hc[49];
+    MPG_HIP(hipMemcpyAsync(hc, eng->hier_cnt.p, sizeof(hc), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    int64_t counts[MPG_TIMEBINS + 1];
+    for(int b = 0; b <= MPG_TIMEBINS; b++)
+        counts[b] = (int64_t)hc[b];
+    int64_t bad = (int64_t)hc[48];
+    // largest bin with particles (timestep.c:379-385)
+    for(int ti = largest_active; ti >= 1; ti--)
+        if(counts[ti] > 0) {
+            largest_active = ti;
+            break;
+        }
+    // push the top bin down where it holds too few particles (PM steps only, timestep.c:392-413)
+    int push_down_bin = largest_active;
+    if(isPM) {
+        for(int ti = largest_active; ti >= 1; ti--) {
+            if(counts[ti] / 3 > counts[ti - 1])
+                break;
+            push_down_bin = ti - 1;
+            counts[ti - 1] += counts[ti];
+        }
+    }
+    MPG_CHECK(push_down_bin != 0, "Bad timestep: every particle wants the shortest bin");
+    if(push_down_bin != largest_active) {
+        launch_push_down_bins(sub, nsub, push_down_bin, A->d_tb_grav, eng->stream);
+        largest_active = push_down_bin;
+    }
+    times->maxtimebin = largest_active;
+    // the kick of the topmost bin (timestep.c:417)
+    hier_kick(eng, A, sub, nsub, A->d_stored_accel, times, largest_active, largest_active, gravkick, gravkick_ctx);
+    // all lower bins (timestep.c:433-490)
+    eng->hier_accel.reserve(3 * (size_t)n + 3);
+    MPG_HIP(hipMemsetAsync(eng->hier_cnt.p + 48, 0, sizeof(unsigned long long), eng->stream));
+    const int *last = sub;
+    int64_t nlast = nsub;
+    for(int ti = largest_active - 1; ti > 0; ti--) {
+        int *subl = eng->hier_list[cur].p;
+        const int64_t ns = hier_sublist(eng, last, nlast, A->d_tb_grav, A->d_flags, ti, times->Ti_Current, subl);
+        if(ns == 0) {
+            times->mingravtimebin = ti + 1;
+            break;
+        }
+        hier_tree_and_walk(eng, A, subl, ns, eng->hier_accel.p, rho0, HybridNuGrav);
+        launch_level_gravity_bins(subl, ns, eng->hier_accel.p, A->d_gravpm, A->d_flags, atime, hubble, par->ErrTolIntAccuracy, soft, T, dti_max, ti,
+                                  A->d_tb_grav, eng->hier_cnt.p + 48, eng->stream);
+        hier_kick(eng, A, subl, ns, eng->hier_accel.p, times, ti, largest_active, gravkick, gravkick_ctx);
+        last = subl;
+        nlast = ns;
+        cur ^= 1;
+    }
+    times->mintimebin = times->mingravtimebin;
+    unsigned long long b2 = 0;
+    MPG_HIP(hipMemcpyAsync(&b2, eng->hier_cnt.p + 48, sizeof(b2), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    *badstepsizecount = bad + (int64_t)b2;
+    API_END
+}
+
+int mpg_dev_hierarchical_gravity_accelerations(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *d_active, int64_t NumActiveParticle,
+                                               int64_t NumActiveGravity, mpg_drift_kick_times *times, double rho0, int HybridNuGrav,
+                                               mpg_gravkick_fn gravkick, void *gravkick_ctx)
+{
+    API_BEGIN
+    MPG_CHECK(eng && A && times && gravkick, "null argument");
+    MPG_CHECK(A->d_vel && A->d_gravpm && A->d_fulltree_accel && A->d_tb_grav, "hierarchical gravity: Vel, GravPM, FullTreeGravAccel and TimeBinGravity are needed");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int64_t n = eng->n;
+    const int64_t nact = d_active ? NumActiveParticle : n;
+    int ti = 0;
+    const int largest_active = hier_largest_active(times, &ti);
+    eng->hier_list[0].reserve((size_t)nact + 1);
+    eng->hier_list[1].reserve((size_t)nact + 1);
+    eng->hier_accel.reserve(3 * (size_t)n + 3);
+    const int *last = d_active;
+    int64_t nlast = nact, last_grav = NumActiveGravity;
+    int cur = 0;
+    if(NumActiveGravity != NumActiveParticle) { // some particles are only hydro active (timestep.c:520-524)
+        nlast = hier_sublist(eng, d_active, nact, A->d_tb_grav, A->d_flags, ti, times->Ti_Current, eng->hier_list[0].p);
+        last = eng->hier_list[0].p;
+        last_grav = nlast;
+        cur = 1;
+    }
+    // all currently active particles: into StoredGravAccel (or, without it, a scratch array: only a full tree then leaves a
+    // result, in FullTreeGravAccel, as in the reference where grav_short_tree allocates the array itself)
+    hier_tree_and_walk(eng, A, last, nlast, A->d_stored_accel ? A->d_stored_accel : eng->hier_accel.p, rho0, HybridNuGrav);
+    hier_kick(eng, A, last, nlast, A->d_stored_accel, times, ti, largest_active, gravkick, gravkick_ctx);
+    const double *gravaccel = nullptr;
+    for(ti = largest_active - 1; ti >= times->mingravtimebin; ti--) {
+        int *subl = eng->hier_list[cur].p;
+        const int64_t ns = hier_sublist(eng, last, nlast, A->d_tb_grav, A->d_flags, ti, times->Ti_Current, subl);
+        if(ns != last_grav) { // (the same particles as one level up: the accelerations are the same, timestep.c:556-564)
+            gravaccel = eng->hier_accel.p;
+            hier_tree_and_walk(eng, A, subl, ns, eng->hier_accel.p, rho0, HybridNuGrav);
+        }
+        hier_kick(eng, A, subl, ns, gravaccel ? gravaccel : A->d_stored_accel, times, ti, largest_active, gravkick, gravkick_ctx);
+        last = subl;
+        nlast = ns;
+        last_grav = ns;
+        cur ^= 1;
+    }
     API_END
 }
 

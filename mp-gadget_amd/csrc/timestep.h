@@ -4,6 +4,26 @@
 #include "../../include/mpgadget_hip.h"
 
 namespace mpg {
+// what the per-particle timestep conversion needs of the integer timeline (timebinmgr.c): the sync points (device copy), the
+// current log a = loga_from_ti(Ti_Current) and ti0 = ti_from_loga(that), TimestepParams.MinSizeTimestep
+struct HierTimeline {
+    const double *sp;
+    int nsync;
+    double loga_cur;
+    int64_t ti0;
+    double MinSizeTimestep;
+};
+void launch_assign_gravity_bins(const int *list, int64_t nlist, const double *gacc, const double *gpm, const uint8_t *flags, double atime,
+                                double hubble, double errtol, double soft, const HierTimeline &T, int64_t dti_max, int largest_active, uint8_t *tb,
+                                unsigned long long *counts, unsigned long long *bad, hipStream_t st);
+void launch_level_gravity_bins(const int *list, int64_t nlist, const double *gacc, const double *gpm, const uint8_t *flags, double atime, double hubble,
+                               double errtol, double soft, const HierTimeline &T, int64_t dti_max, int ti, uint8_t *tb, unsigned long long *bad,
+                               hipStream_t st);
+void launch_push_down_bins(const int *list, int64_t nlist, int push_down_bin, uint8_t *tb, hipStream_t st);
+void launch_kick_list(const int *list, int64_t nlist, double *vel, const double *acc, const uint8_t *flags, double gravkick, hipStream_t st);
+void launch_sublist_flags(const int *list, int64_t nlist, const uint8_t *tb, const uint8_t *flags, int maxtimebin, int64_t Ti_Current, int *value,
+                          uint8_t *keep, hipStream_t st);
+void compact_flagged(const int *value, const uint8_t *keep, int64_t n, int *out, unsigned long long *d_count, DevBuf<char> &tmp, hipStream_t st);
 void launch_drift(int64_t n, double *pos, const double *vel, const uint8_t *type, const uint8_t *flags, double *hsml, const double *dthsml,
                   double ddrift, double box, const double shift[3], unsigned *err, hipStream_t st);
 void launch_pm_half_kick(int64_t n, double *vel, const double *gravpm, const uint8_t *flags, double F, hipStream_t st);

@@ -5,6 +5,8 @@
 //   k_drift          drift_all_particles / real_drift_particle   libgadget/drift.c:18-102
 //   k_pm_half_kick   apply_PM_half_kick                          libgadget/timestep.c:964-985
 //   k_half_kick      apply_half_kick + do_grav_short_range_kick + do_hydro_kick (gas part)   timestep.c:873-929, 988-1036
+//   k_assign_gravity_bins, k_level_gravity_bins, k_push_down_bins, k_kick_list, k_sublist_flags
+//                    the per-particle loops of the hierarchical gravity level loop             timestep.c:239-599, 1435-1478
 // The per-bin factors (get_exact_drift/gravkick/hydrokick_factor, dloga_from_dti) are computed by the caller with the
 // reference's own functions and passed in (mpg_kick_factors), as for the SPH loops.  Not carried: black-hole repositioning
 // and the dynamic-friction / drag kicks of type-5 particles (sub-grid physics, out of scope).
@@ -13,6 +15,9 @@
 // required to be bit-identical to it (tests/test_gpu_timestep.py).
 #include "mpg_common.h"
 #include "../../include/mpgadget_hip.h"
+#include "timestep.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 #pragma clang fp contract(off)
 
@@ -141,6 +146,165 @@ __global__ void __launch_bounds__(256) k_timestep_gravity(int64_t n, const doubl
     dloga[i] = dt * hubble;
 }
 
+
+// ---- hierarchical gravity (timestep.c:239-599): per-particle loops -------------------------------------------------------------
+
+// ti_from_loga, timebinmgr.c:400-417 (sp = SyncPoints[].loga, nsync >= 2)
+__device__ __forceinline__ int64_t ti_from_loga_dev(const double loga, const double *__restrict__ sp, const int nsync)
+{
+    int i;
+    for(i = 1; i < nsync - 1; i++)
+        if(sp[i] > loga)
+            break;
+    const double logDTime = (sp[i] - sp[i - 1]) / (double)(1ull << MPG_TIMEBINS);
+    int64_t ti = (int64_t)(i - 1) << MPG_TIMEBINS;
+    ti = (int64_t)((double)ti + (loga - sp[i - 1]) / logDTime); // "ti += double": converted, added, truncated
+    return ti;
+}
+
+// convert_timestep_to_ti (timestep.c:1155-1175) with dti_from_dloga (timebinmgr.c:434-440): loga_cur = loga_from_ti(Ti_Current)
+// and ti0 = ti_from_loga(loga_cur) are the same for every particle and come from the host
+__device__ __forceinline__ int64_t convert_timestep_to_ti_dev(double dloga, const int64_t dti_max, const HierTimeline &T)
+{
+    if(dti_max == 0)
+        return 0;
+    if(dloga < T.MinSizeTimestep)
+        dloga = T.MinSizeTimestep;
+    int64_t dti = ti_from_loga_dev(dloga + T.loga_cur, T.sp, T.nsync) - T.ti0;
+    if(dti > dti_max || dti < 0)
+        dti = dti_max;
+    return dti;
+}
+
+// get_timestep_gravity_dloga, timestep.c:1045-1074
+__device__ __forceinline__ double gravity_dloga_dev(const int64_t i, const double *__restrict__ gacc, const double *__restrict__ gpm,
+                                                    const double atime, const double hubble, const double errtol, const double soft)
+{
+    const double a2inv = 1 / (atime * atime);
+    double ax = a2inv * gacc[3 * i + 0];
+    double ay = a2inv * gacc[3 * i + 1];
+    double az = a2inv * gacc[3 * i + 2];
+    ay += a2inv * gpm[3 * i + 1];
+    ax += a2inv * gpm[3 * i + 0];
+    az += a2inv * gpm[3 * i + 2];
+    double ac2 = ax * ax + ay * ay + az * az;
+    if(ac2 == 0)
+        ac2 = 1.0e-60;
+    const double ac = sqrt(ac2);
+    const double dt = sqrt(2 * errtol * atime * (soft / 2.8) / ac);
+    return dt * hubble;
+}
+
+// The first loop of hierarchical_gravity_and_timesteps (timestep.c:345-370): new gravity bin of every particle of the list from
+// the stored acceleration; counts[bin] += 1; bad += 1 for dti <= 1 or > TIMEBASE (print_bad_timebin).
+__global__ void __launch_bounds__(256) k_assign_gravity_bins(const int *__restrict__ list, int64_t nlist, const double *__restrict__ gacc,
+                                                             const double *__restrict__ gpm, const uint8_t *__restrict__ flags, double atime,
+                                                             double hubble, double errtol, double soft, HierTimeline T, int64_t dti_max,
+                                                             int largest_active, uint8_t *__restrict__ tb,
+                                                             unsigned long long *__restrict__ counts, unsigned long long *__restrict__ bad)
+{
+    __shared__ unsigned s_cnt[MPG_TIMEBINS + 2];
+    for(int b = threadIdx.x; b < MPG_TIMEBINS + 2; b += blockDim.x)
+        s_cnt[b] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < nlist) {
+        const int64_t pa = list ? list[k] : k;
+        if(!(flags && (flags[pa] & 3))) {
+            const double dloga = gravity_dloga_dev(pa, gacc, gpm, atime, hubble, errtol, soft);
+            int64_t dti = convert_timestep_to_ti_dev(dloga, dti_max, T);
+            // round_down_power_of_two, timebinmgr.c:449-462 (dti >= 0 here)
+            int64_t ti_min = (int64_t)1 << MPG_TIMEBINS;
+            while(ti_min > dti)
+                ti_min >>= 1;
+            dti = ti_min;
+            if(dti <= 1 || dti > ((int64_t)1 << MPG_TIMEBINS))
+                atomicAdd(&s_cnt[MPG_TIMEBINS + 1], 1u);
+            // get_timestep_bin, timestep.c:1301-1315
+            int bin = 0;
+            if(dti > 1)
+                bin = 63 - __clzll((unsigned long long)dti);
+            if(bin > largest_active)
+                bin = largest_active;
+            atomicAdd(&s_cnt[bin], 1u);
+            tb[pa] = (uint8_t)bin;
+        }
+    }
+    __syncthreads();
+    for(int b = threadIdx.x; b < MPG_TIMEBINS + 2; b += blockDim.x)
+        if(s_cnt[b]) {
+            if(b <= MPG_TIMEBINS)
+                atomicAdd(&counts[b], (unsigned long long)s_cnt[b]);
+            else
+                atomicAdd(bad, (unsigned long long)s_cnt[b]);
+        }
+}
+
+// The loop of the lower levels (timestep.c:461-477): a particle whose step from the acceleration AT THIS LEVEL is shorter than
+// the level's goes one bin down; bad += 1 if that happens at ti == 1.
+__global__ void __launch_bounds__(256) k_level_gravity_bins(const int *__restrict__ list, int64_t nlist, const double *__restrict__ gacc,
+                                                            const double *__restrict__ gpm, const uint8_t *__restrict__ flags, double atime,
+                                                            double hubble, double errtol, double soft, HierTimeline T, int64_t dti_max, int ti,
+                                                            uint8_t *__restrict__ tb, unsigned long long *__restrict__ bad)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nlist)
+        return;
+    const int64_t pa = list ? list[k] : k;
+    if(flags && (flags[pa] & 3))
+        return;
+    const double dloga = gravity_dloga_dev(pa, gacc, gpm, atime, hubble, errtol, soft);
+    const int64_t dti = convert_timestep_to_ti_dev(dloga, dti_max, T);
+    const int64_t dti_bin = ti > 0 ? ((int64_t)1 << ti) : 0; // dti_from_timebin
+    if(dti < dti_bin) {
+        tb[pa] = (uint8_t)(ti - 1);
+        if(ti == 1)
+            atomicAdd(bad, 1ull);
+    }
+}
+
+// "Pushing down top bin" (timestep.c:404-411)
+__global__ void __launch_bounds__(256) k_push_down_bins(const int *__restrict__ list, int64_t nlist, int push_down_bin, uint8_t *__restrict__ tb)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nlist)
+        return;
+    const int64_t pa = list ? list[k] : k;
+    if(tb[pa] > push_down_bin)
+        tb[pa] = (uint8_t)push_down_bin;
+}
+
+// apply_hierarchical_grav_kick (timestep.c:238-278) + do_grav_short_range_kick (:995-1001)
+__global__ void __launch_bounds__(256) k_kick_list(const int *__restrict__ list, int64_t nlist, double *__restrict__ vel,
+                                                   const double *__restrict__ acc, const uint8_t *__restrict__ flags, double gravkick)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nlist)
+        return;
+    const int64_t pa = list ? list[k] : k;
+    if(flags && (flags[pa] & 3))
+        return;
+    for(int j = 0; j < 3; j++)
+        vel[3 * pa + j] += acc[3 * pa + j] * gravkick;
+}
+
+// build_active_sublist (timestep.c:1435-1478): keep[k] = 1 for the entries that stay; value[k] = the particle index
+__global__ void __launch_bounds__(256) k_sublist_flags(const int *__restrict__ list, int64_t nlist, const uint8_t *__restrict__ tb,
+                                                       const uint8_t *__restrict__ flags, int maxtimebin, int64_t Ti_Current,
+                                                       int *__restrict__ value, uint8_t *__restrict__ keep)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nlist)
+        return;
+    const int64_t pa = list ? list[k] : k;
+    const int bin = tb[pa];
+    bool ok = !(flags && (flags[pa] & 3)) && bin <= maxtimebin;
+    if(ok && bin > 0 && Ti_Current > 0) // is_timebin_active, timestep.c:143-150
+        ok = (Ti_Current % ((int64_t)1 << bin)) == 0;
+    value[k] = (int)pa;
+    keep[k] = ok ? 1 : 0;
+}
+
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 void launch_timestep_gravity(int64_t n, const double *gacc, const double *gpm, double atime, double hubble, double errtol, double soft,
@@ -149,6 +313,62 @@ void launch_timestep_gravity(int64_t n, const double *gacc, const double *gpm, d
     if(n > 0)
         hipLaunchKernelGGL(k_timestep_gravity, dim3(nblk(n)), dim3(256), 0, st, n, gacc, gpm, atime, hubble, errtol, soft, dloga);
     MPG_HIP(hipGetLastError());
+}
+
+
+void launch_assign_gravity_bins(const int *list, int64_t nlist, const double *gacc, const double *gpm, const uint8_t *flags, double atime,
+                                double hubble, double errtol, double soft, const HierTimeline &T, int64_t dti_max, int largest_active, uint8_t *tb,
+                                unsigned long long *counts, unsigned long long *bad, hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_assign_gravity_bins, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, gacc, gpm, flags, atime, hubble, errtol, soft, T,
+                           dti_max, largest_active, tb, counts, bad);
+    MPG_HIP(hipGetLastError());
+}
+
+void launch_level_gravity_bins(const int *list, int64_t nlist, const double *gacc, const double *gpm, const uint8_t *flags, double atime, double hubble,
+                               double errtol, double soft, const HierTimeline &T, int64_t dti_max, int ti, uint8_t *tb, unsigned long long *bad,
+                               hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_level_gravity_bins, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, gacc, gpm, flags, atime, hubble, errtol, soft, T,
+                           dti_max, ti, tb, bad);
+    MPG_HIP(hipGetLastError());
+}
+
+void launch_push_down_bins(const int *list, int64_t nlist, int push_down_bin, uint8_t *tb, hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_push_down_bins, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, push_down_bin, tb);
+    MPG_HIP(hipGetLastError());
+}
+
+void launch_kick_list(const int *list, int64_t nlist, double *vel, const double *acc, const uint8_t *flags, double gravkick, hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_kick_list, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, vel, acc, flags, gravkick);
+    MPG_HIP(hipGetLastError());
+}
+
+void launch_sublist_flags(const int *list, int64_t nlist, const uint8_t *tb, const uint8_t *flags, int maxtimebin, int64_t Ti_Current, int *value,
+                          uint8_t *keep, hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_sublist_flags, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, tb, flags, maxtimebin, Ti_Current, value, keep);
+    MPG_HIP(hipGetLastError());
+}
+
+// order-preserving compaction of value[k] with keep[k] != 0 (the merge step of build_active_sublist); *d_count receives the count
+void compact_flagged(const int *value, const uint8_t *keep, int64_t n, int *out, unsigned long long *d_count, DevBuf<char> &tmp, hipStream_t st)
+{
+    if(n <= 0) {
+        MPG_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
+        return;
+    }
+    size_t bytes = 0;
+    MPG_HIP(rocprim::select(nullptr, bytes, value, keep, out, d_count, (size_t)n, st));
+    tmp.reserve(bytes + 16);
+    MPG_HIP(rocprim::select((void *)tmp.p, bytes, value, keep, out, d_count, (size_t)n, st));
 }
 
 void launch_drift(int64_t n, double *pos, const double *vel, const uint8_t *type, const uint8_t *flags, double *hsml, const double *dthsml,

@@ -141,6 +141,31 @@ class KickFactors(C.Structure):
                 ("bin_active", C.c_ubyte * (TIMEBINS + 1)), ("atime", C.c_double), ("MaxGasVel", C.c_double)]
 
 
+class DriftKickTimes(C.Structure):
+    """mpg_drift_kick_times = DriftKickTimes of libgadget/timestep.h:10-27"""
+    _fields_ = [("mintimebin", C.c_int), ("maxtimebin", C.c_int), ("mingravtimebin", C.c_int), ("Ti_kick", C.c_int64 * (TIMEBINS + 1)),
+                ("Ti_lastactivedrift", C.c_int64 * (TIMEBINS + 1)), ("Ti_Current", C.c_int64), ("PM_length", C.c_int64),
+                ("PM_start", C.c_int64), ("PM_kick", C.c_int64)]
+
+
+class Timeline(C.Structure):
+    """mpg_timeline: the sync points of the integer timeline (timebinmgr.c)"""
+    _fields_ = [("nsync", C.c_int64), ("loga", C.POINTER(C.c_double))]
+
+
+class HierGravArrays(C.Structure):
+    """mpg_hiergrav_arrays: device arrays of the hierarchical gravity level loop"""
+    _fields_ = [("d_vel", C.c_void_p), ("d_gravpm", C.c_void_p), ("d_fulltree_accel", C.c_void_p), ("d_potential", C.c_void_p),
+                ("d_tb_grav", C.c_void_p), ("d_flags", C.c_void_p), ("d_stored_accel", C.c_void_p)]
+
+
+class TimestepParams(C.Structure):
+    _fields_ = [("ErrTolIntAccuracy", C.c_double), ("MinSizeTimestep", C.c_double)]
+
+
+GRAVKICK_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.c_int64)
+
+
 class Engine:
     """One engine per GPU (= per MPI rank in the reference's terms)."""
 
@@ -336,6 +361,43 @@ class Engine:
     def dev_timestep_gravity_dloga(self, gravaccel, gravpm, atime, hubble, ErrTolIntAccuracy, dloga):
         self._ck(self.lib.mpg_dev_timestep_gravity_dloga(self.h, C.c_int64(gravaccel.shape[0]), _ptr(gravaccel), _ptr(gravpm), C.c_double(atime),
                                                          C.c_double(hubble), C.c_double(ErrTolIntAccuracy), _ptr(dloga)))
+
+    # hierarchical gravity (timestep.c:239-599)
+    @staticmethod
+    def _hier_arrays(vel, gravpm, fulltree_accel, tb_grav, potential=None, flags=None, stored_accel=None):
+        dp = lambda t: None if t is None else t.data_ptr()
+        return HierGravArrays(dp(vel), dp(gravpm), dp(fulltree_accel), dp(potential), dp(tb_grav), dp(flags), dp(stored_accel))
+
+    def dev_build_active_sublist(self, active, tb_grav, flags, maxtimebin, Ti_Current, out):
+        n = C.c_int64(0)
+        na = active.shape[0] if active is not None else tb_grav.shape[0]
+        self._ck(self.lib.mpg_dev_build_active_sublist(self.h, _ptr(active), C.c_int64(na), _ptr(tb_grav), _ptr(flags), int(maxtimebin),
+                                                       C.c_int64(Ti_Current), _ptr(out), C.byref(n)))
+        return n.value
+
+    def dev_hierarchical_gravity_and_timesteps(self, arrays, active, num_active_gravity, times, sync_loga, ErrTolIntAccuracy, MinSizeTimestep,
+                                               atime, hubble, dti_max_pm, rho0, gravkick, HybridNuGrav=0):
+        """arrays: HierGravArrays (Engine._hier_arrays); times: DriftKickTimes (updated in place); sync_loga: the sync points' log a;
+        gravkick(ti0, ti1) -> get_exact_gravkick_factor.  Returns badstepsizecount."""
+        loga = (C.c_double * len(sync_loga))(*[float(x) for x in sync_loga])
+        tl = Timeline(len(sync_loga), C.cast(loga, C.POINTER(C.c_double)))
+        par = TimestepParams(ErrTolIntAccuracy, MinSizeTimestep)
+        fn = GRAVKICK_FN(lambda ctx, a, b: float(gravkick(a, b)))
+        bad = C.c_int64(0)
+        na = active.shape[0] if active is not None else 0
+        nag = num_active_gravity if active is not None else 0
+        self._ck(self.lib.mpg_dev_hierarchical_gravity_and_timesteps(self.h, C.byref(arrays), _ptr(active), C.c_int64(na), C.c_int64(nag),
+                                                                     C.byref(times), C.byref(tl), C.byref(par), C.c_double(atime),
+                                                                     C.c_double(hubble), C.c_int64(dti_max_pm), C.c_double(rho0),
+                                                                     int(HybridNuGrav), fn, None, C.byref(bad)))
+        return bad.value
+
+    def dev_hierarchical_gravity_accelerations(self, arrays, active, num_active_gravity, times, rho0, gravkick, HybridNuGrav=0):
+        fn = GRAVKICK_FN(lambda ctx, a, b: float(gravkick(a, b)))
+        na = active.shape[0] if active is not None else 0
+        nag = num_active_gravity if active is not None else 0
+        self._ck(self.lib.mpg_dev_hierarchical_gravity_accelerations(self.h, C.byref(arrays), _ptr(active), C.c_int64(na), C.c_int64(nag),
+                                                                     C.byref(times), C.c_double(rho0), int(HybridNuGrav), fn, None))
 
     def dev_tree_top_partial(self, La, n_own, out):
         self._ck(self.lib.mpg_dev_tree_top_partial(self.h, int(La), C.c_int64(n_own), _ptr(out)))

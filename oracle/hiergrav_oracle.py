@@ -1,0 +1,266 @@
+"""CPU restatement of the hierarchical gravity level loop -- TEST INFRASTRUCTURE ONLY (see oracle/README.md): only tests/ may import it.
+
+Follows libgadget/timestep.c:
+  apply_hierarchical_grav_kick            :238-278
+  grav_short_tree_build_tree              :281-291
+  hierarchical_gravity_and_timesteps      :293-490
+  hierarchical_gravity_accelerations      :495-599
+  get_timestep_gravity_dloga              :1045-1074   (via oracle.timestep_gravity_dloga, C)
+  convert_timestep_to_ti                  :1155-1175
+  get_timestep_bin                        :1301-1315
+  build_active_sublist                    :1435-1478
+  is_timebin_active                       :143-150
+and libgadget/timebinmgr.c: Dloga_interval_ti :372-385, loga_from_ti :388-398, ti_from_loga :400-417, dti_from_dloga :434-440,
+round_down_power_of_two :449-462; timebinmgr.h: dti_from_timebin :47-50.
+
+Trees and walks are the oracle's (oracle.Oracle.tree on the active sub-set, OracleTree.grav_short_tree).  The orchestration has no
+known-answer test in the reference (there is no test_timestep.c): parity of this layer is pinned by this restatement only.
+
+State is a dict of numpy arrays in particle order: pos[N,3], mass[N] (f32), vel[N,3], gravpm[N,3], fulltree[N,3] (FullTreeGravAccel),
+tb_grav[N] (u8), flags[N] (u8, optional), stored[N,3] or None (StoredGravAccel.GravAccel).
+`times` is a dict with the DriftKickTimes fields (timestep.h:10-27)."""
+import numpy as np
+
+from . import oracle as O
+
+TIMEBINS = 46
+TIMEBASE = 1 << TIMEBINS
+
+
+def dti_from_timebin(b):
+    return (1 << int(b)) if b > 0 else 0
+
+
+def is_timebin_active(i, current):
+    if i <= 0 or current <= 0:
+        return True
+    return current % dti_from_timebin(i) == 0
+
+
+class Timeline:
+    """SyncPoints[].loga"""
+
+    def __init__(self, loga):
+        self.loga = [float(x) for x in loga]
+        self.n = len(self.loga)
+
+    def dloga_interval_ti(self, ti):
+        lastsnap = ti >> TIMEBINS
+        if lastsnap >= self.n - 1:
+            return 0.0
+        return (self.loga[lastsnap + 1] - self.loga[lastsnap]) / float(TIMEBASE)
+
+    def loga_from_ti(self, ti):
+        lastsnap = ti >> TIMEBINS
+        dti = ti & (TIMEBASE - 1)
+        return self.loga[lastsnap] + dti * self.dloga_interval_ti(ti)
+
+    def ti_from_loga(self, loga):
+        """vectorised over `loga`"""
+        loga = np.atleast_1d(np.asarray(loga, np.float64))
+        out = np.zeros(loga.shape, np.int64)
+        for k, x in enumerate(loga):
+            i = 1
+            while i < self.n - 1:
+                if self.loga[i] > x:
+                    break
+                i += 1
+            logDTime = np.float64(self.loga[i] - self.loga[i - 1]) / np.float64(TIMEBASE)
+            ti = np.float64((i - 1) << TIMEBINS)
+            out[k] = np.int64(np.trunc(ti + np.float64(x - self.loga[i - 1]) / logDTime))
+        return out
+
+
+def convert_timestep_to_ti(dloga, dti_max, Ti_Current, tl, MinSizeTimestep):
+    if dti_max == 0:
+        return np.zeros(len(dloga), np.int64)
+    dloga = np.where(dloga < MinSizeTimestep, MinSizeTimestep, dloga)
+    loga_cur = tl.loga_from_ti(Ti_Current)
+    ti = tl.ti_from_loga(loga_cur)[0]
+    dti = tl.ti_from_loga(dloga + loga_cur) - ti
+    return np.where((dti > dti_max) | (dti < 0), dti_max, dti).astype(np.int64)
+
+
+def round_down_power_of_two(dti):
+    out = np.zeros(len(dti), np.int64)
+    for k, d in enumerate(dti):
+        ti_min = TIMEBASE
+        d = int(d)
+        sign = 1
+        if d < 0:
+            d, sign = -d, -1
+        while ti_min > d:
+            ti_min >>= 1
+        out[k] = ti_min * sign
+    return out
+
+
+def get_timestep_bin(dti):
+    out = np.zeros(len(dti), np.int64)
+    for k, d in enumerate(dti):
+        d = int(d)
+        if d <= 1:
+            continue
+        b = -1
+        while d:
+            b += 1
+            d >>= 1
+        out[k] = b
+    return out
+
+
+def build_active_sublist(S, act, maxtimebin, Ti_Current):
+    idx = np.arange(len(S["tb_grav"]), dtype=np.int64) if act is None else np.asarray(act, np.int64)
+    keep = []
+    for pi in idx:
+        b = int(S["tb_grav"][pi])
+        if S.get("flags") is not None and (S["flags"][pi] & 3):
+            continue
+        if b > maxtimebin:
+            continue
+        if not is_timebin_active(b, Ti_Current):
+            continue
+        keep.append(pi)
+    return np.array(keep, np.int32)
+
+
+def _listed(S, act):
+    idx = np.arange(len(S["tb_grav"]), dtype=np.int64) if act is None else np.asarray(act, np.int64)
+    if S.get("flags") is not None:
+        idx = idx[(S["flags"][idx] & 3) == 0]
+    return idx
+
+
+def apply_hierarchical_grav_kick(S, act, times, accel, ti, largest_active, gravkick):
+    dti = dti_from_timebin(ti)
+    gk = gravkick(times["Ti_kick"][ti], times["Ti_kick"][ti] + dti // 2)
+    if ti < largest_active:
+        lowerdti = dti_from_timebin(ti + 1)
+        gk -= gravkick(times["Ti_kick"][ti + 1], times["Ti_kick"][ti + 1] + lowerdti // 2)
+    idx = _listed(S, act)
+    a = S["fulltree"] if accel is None else accel
+    S["vel"][idx] += a[idx] * gk
+
+
+def grav_short_tree_build_tree(orc, S, act, accel_store, par, G):
+    """Tree of the listed particles (all if act is None), walk for them; results into accel_store (if given) and, for a tree of all
+    particles, into FullTreeGravAccel (grav_short_postprocess, gravshort.h:47-67)."""
+    N = len(S["tb_grav"])
+    idx = np.arange(N) if act is None else np.asarray(act, np.int64)
+    if len(idx) == 0:
+        return
+    tr = orc.tree(S["pos"][idx], S["mass"][idx], S["box"])
+    old = np.sqrt(((S["fulltree"] + S["gravpm"]) ** 2).sum(1)) / G          # grav_get_abs_accel, gravshort.h:70-80
+    a, _, _, _ = tr.grav_short_tree(par, oldacc=old[idx])
+    tr.free()
+    if accel_store is not None:
+        accel_store[idx] = a
+    if act is None:
+        S["fulltree"][idx] = a
+    if par.TreeUseBH > 1:                                                      # gravshort-tree.c:148-151
+        par.TreeUseBH = 0
+
+
+def _largest_active(times):
+    largest, ti = TIMEBINS, TIMEBINS
+    while ti >= 0:
+        if is_timebin_active(ti, times["Ti_Current"]) and dti_from_timebin(ti) <= times["PM_length"]:
+            largest = ti
+            break
+        ti -= 1
+    return largest, ti
+
+
+def _dloga(orc, S, accel, idx, atime, hubble, ErrTol, soft):
+    return O.timestep_gravity_dloga(orc, np.ascontiguousarray(accel[idx]), np.ascontiguousarray(S["gravpm"][idx]), atime, hubble, ErrTol, soft)
+
+
+def hierarchical_gravity_and_timesteps(orc, S, act, num_active_gravity, times, tl, ErrTolIntAccuracy, MinSizeTimestep, atime, hubble,
+                                       dti_max_pm, par, G, soft, gravkick):
+    N = len(S["tb_grav"])
+    nact = N if act is None else len(act)
+    nag = nact if act is None else num_active_gravity
+    assert times["Ti_Current"] <= times["PM_start"] + times["PM_length"]
+    isPM = times["Ti_Current"] == times["PM_start"] + times["PM_length"]
+    dti_max = times["PM_length"]
+    if isPM:
+        dti_max = dti_max_pm
+        times["PM_length"] = dti_max
+        times["PM_start"] = times["PM_kick"]
+    largest_active, _ = _largest_active(times)
+    if nag == nact or isPM:
+        subact = act
+    else:
+        subact = build_active_sublist(S, act, largest_active, times["Ti_Current"])
+    idx = _listed(S, subact)
+    counts = np.zeros(TIMEBINS + 1, np.int64)
+    bad = 0
+    topacc = S["stored"] if S.get("stored") is not None else S["fulltree"]
+    if len(idx):
+        dl = _dloga(orc, S, topacc, idx, atime, hubble, ErrTolIntAccuracy, soft)
+        dti = convert_timestep_to_ti(dl, dti_max, times["Ti_Current"], tl, MinSizeTimestep)
+        dti = round_down_power_of_two(dti)
+        bad += int(((dti <= 1) | (dti > TIMEBASE)).sum())
+        b = np.minimum(get_timestep_bin(dti), largest_active)
+        np.add.at(counts, b, 1)
+        S["tb_grav"][idx] = b.astype(np.uint8)
+    for ti in range(largest_active, 0, -1):
+        if counts[ti] > 0:
+            largest_active = ti
+            break
+    push_down_bin = largest_active
+    if isPM:
+        for ti in range(largest_active, 0, -1):
+            if counts[ti] // 3 > counts[ti - 1]:
+                break
+            push_down_bin = ti - 1
+            counts[ti - 1] += counts[ti]
+    assert push_down_bin != 0
+    if push_down_bin != largest_active:
+        ii = np.arange(N) if subact is None else np.asarray(subact, np.int64)
+        S["tb_grav"][ii] = np.minimum(S["tb_grav"][ii], push_down_bin)
+        largest_active = push_down_bin
+    times["maxtimebin"] = largest_active
+    apply_hierarchical_grav_kick(S, subact, times, S.get("stored"), largest_active, largest_active, gravkick)
+    lastact = subact
+    for ti in range(largest_active - 1, 0, -1):
+        sub = build_active_sublist(S, lastact, ti, times["Ti_Current"])
+        if len(sub) == 0:
+            times["mingravtimebin"] = ti + 1
+            break
+        grav = np.zeros((N, 3))
+        grav_short_tree_build_tree(orc, S, sub, grav, par, G)
+        idx = _listed(S, sub)
+        dl = _dloga(orc, S, grav, idx, atime, hubble, ErrTolIntAccuracy, soft)
+        dti = convert_timestep_to_ti(dl, dti_max, times["Ti_Current"], tl, MinSizeTimestep)
+        down = dti < dti_from_timebin(ti)
+        S["tb_grav"][idx[down]] = ti - 1
+        if ti == 1:
+            bad += int(down.sum())
+        apply_hierarchical_grav_kick(S, sub, times, grav, ti, largest_active, gravkick)
+        lastact = sub
+    times["mintimebin"] = times["mingravtimebin"]
+    return bad
+
+
+def hierarchical_gravity_accelerations(orc, S, act, num_active_gravity, times, par, G, gravkick):
+    N = len(S["tb_grav"])
+    nact = N if act is None else len(act)
+    nag = nact if act is None else num_active_gravity
+    largest_active, ti = _largest_active(times)
+    if nag == nact:
+        lastact, last_grav = act, nag
+    else:
+        lastact = build_active_sublist(S, act, ti, times["Ti_Current"])
+        last_grav = len(lastact)
+    grav_short_tree_build_tree(orc, S, lastact, S.get("stored"), par, G)
+    apply_hierarchical_grav_kick(S, lastact, times, S.get("stored"), ti, largest_active, gravkick)
+    grav = None
+    for ti in range(largest_active - 1, times["mingravtimebin"] - 1, -1):
+        sub = build_active_sublist(S, lastact, ti, times["Ti_Current"])
+        if len(sub) != last_grav:
+            grav = np.zeros((N, 3))
+            grav_short_tree_build_tree(orc, S, sub, grav, par, G)
+        tmp = grav if grav is not None else S.get("stored")
+        apply_hierarchical_grav_kick(S, sub, times, tmp, ti, largest_active, gravkick)
+        lastact, last_grav = sub, len(sub)

@@ -1,0 +1,52 @@
+"""The integer-timeline helpers of oracle/hiergrav_oracle.py against the known answers of the reference's own test
+(libgadget/tests/test_timebinmgr.c:22-43, 72-92: sync points at a = 0.1, 0.2, 0.8, 1.0) and the bin arithmetic of timestep.c."""
+import numpy as np
+
+from oracle import hiergrav_oracle as H
+
+TIMEBASE = H.TIMEBASE
+outs = [0.1, 0.2, 0.8, 1.0]
+logouts = [np.log(a) for a in outs]
+
+
+def test_conversions_known_answers():
+    tl = H.Timeline(logouts)
+    assert abs(tl.loga_from_ti(0) - logouts[0]) < 1e-6
+    assert abs(tl.loga_from_ti(TIMEBASE) - logouts[1]) < 1e-6
+    assert abs(tl.loga_from_ti(TIMEBASE - 1) - (logouts[0] + (logouts[1] - logouts[0]) * (TIMEBASE - 1) / TIMEBASE)) < 1e-6
+    assert abs(tl.loga_from_ti(TIMEBASE + 1) - (logouts[1] + (logouts[2] - logouts[1]) / TIMEBASE)) < 1e-6
+    assert abs(tl.loga_from_ti(2 * TIMEBASE) - logouts[2]) < 1e-6
+    assert tl.ti_from_loga(logouts[0])[0] == 0
+    assert tl.ti_from_loga(logouts[1])[0] == TIMEBASE
+    assert tl.ti_from_loga(logouts[2])[0] == 2 * TIMEBASE
+    midpt = (logouts[2] + logouts[1]) / 2
+    assert tl.ti_from_loga(midpt)[0] == TIMEBASE + TIMEBASE // 2
+    assert abs(tl.loga_from_ti(TIMEBASE + TIMEBASE // 2) - midpt) < 1e-6
+    assert tl.ti_from_loga(0.0)[0] == 3 * TIMEBASE                       # past the end
+    assert abs(tl.loga_from_ti(int(tl.ti_from_loga(np.log(0.1))[0])) - np.log(0.1)) < 1e-6
+
+
+def test_dloga_and_power_of_two_known_answers():
+    tl = H.Timeline(logouts)
+    ti = int(tl.ti_from_loga(np.log(0.55))[0])
+    dl = tl.dloga_interval_ti(ti)
+    assert abs(H.dti_from_timebin(0) * dl) < 1e-6                       # get_dloga_for_bin(0)
+    assert abs(H.dti_from_timebin(H.TIMEBINS) * dl - (logouts[2] - logouts[1])) < 1e-6
+    assert abs(H.dti_from_timebin(H.TIMEBINS - 2) * dl - (logouts[2] - logouts[1]) / 4) < 1e-6
+    r = H.round_down_power_of_two(np.array([TIMEBASE, TIMEBASE + 1, TIMEBASE - 1, 0, 1, 5]))
+    assert r.tolist() == [TIMEBASE, TIMEBASE, TIMEBASE // 2, 0, 1, 4]
+
+
+def test_bins_and_activity():
+    assert H.get_timestep_bin(np.array([0, 1, 2, 3, 4, 1 << 40, (1 << 40) + 5])).tolist() == [0, 0, 1, 1, 2, 40, 40]
+    assert H.is_timebin_active(0, 12345) and H.is_timebin_active(7, 0) and H.is_timebin_active(3, 16) and not H.is_timebin_active(3, 12)
+    tl = H.Timeline(logouts)
+    # convert_timestep_to_ti: capped at dti_max, floored at MinSizeTimestep, 0 when dti_max == 0
+    cur = 1 << 40
+    d = H.convert_timestep_to_ti(np.array([1e-30, 1e-3, 10.0]), 1 << 42, cur, tl, 1e-5)
+    iv = (logouts[1] - logouts[0]) / TIMEBASE
+    assert abs(int(d[0]) - 1e-5 / iv) <= 2 and abs(int(d[1]) - 1e-3 / iv) <= 2 and int(d[2]) == 1 << 42
+    assert H.convert_timestep_to_ti(np.array([1e-3]), 0, cur, tl, 0.0).tolist() == [0]
+    S = dict(tb_grav=np.array([0, 1, 2, 3, 4], np.uint8), flags=np.array([0, 0, 1, 0, 0], np.uint8))
+    assert H.build_active_sublist(S, None, 3, 8).tolist() == [0, 1, 3]
+    assert H.build_active_sublist(S, np.array([4, 3, 1]), 4, 8).tolist() == [3, 1]   # order of the input list; bin 4 inactive at 8
