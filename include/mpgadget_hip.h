@@ -346,6 +346,16 @@ int mpg_dev_hierarchical_gravity_accelerations(mpg_engine *eng, const mpg_hiergr
 int mpg_dev_build_active_sublist(mpg_engine *eng, const int *d_active, int64_t NumActiveParticle, const unsigned char *d_tb_grav,
                                  const unsigned char *d_flags, int maxtimebin, int64_t Ti_Current, int *d_out, int64_t *n_out);
 
+/* ---- particle order: Peano-Hilbert keys and the (type, key) sort the reference keeps its particles in
+ * (slots_gc_sorted after every full domain decomposition, domain.c:247).  Keys are bit-identical to the reference's. */
+/* PEANO(Pos, BoxSize), libgadget/utils/peano.h:15-21 + peano_hilbert_key, peano.c:117-140: d_keys[n] */
+int mpg_dev_peano_keys(mpg_engine *eng, int64_t n, const double *d_pos, double BoxSize, uint64_t *d_keys);
+/* the order of slots_gc_sorted (slotsmanager.c:404-452): d_perm[k] = index of the k-th particle by (Type, Key), garbage
+ * (flags bit 0) last; *n_live = the particles that are not garbage.  d_type NULL: one type.  Equal (type, key) keep their
+ * input order (the reference's qsort leaves it unspecified). */
+int mpg_dev_order_by_type_and_key(mpg_engine *eng, int64_t n, const unsigned char *d_type, const unsigned char *d_flags,
+                                  const uint64_t *d_keys, int *d_perm, int64_t *n_live);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

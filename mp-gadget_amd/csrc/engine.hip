@@ -11,6 +11,7 @@
 #include "pm.h"
 #include "sph.h"
 #include "timestep.h"
+#include "peano.h"
 #include "tree_build.h"
 #include <cmath>
 #include <cstdlib>
@@ -130,6 +131,7 @@ struct mpg_engine {
     DevBuf<double> hier_accel, hier_sp;
     DevBuf<unsigned long long> hier_cnt;
     DevBuf<char> hier_tmp;
+    PeanoScratch peano;
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
     HostBuf<uint8_t> h_b;
@@ -669,6 +671,25 @@ int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_g
     MPG_CHECK(eng->GravitySoftening > 0, "timestep: gravshort_set_softenings has not been called");
     MPG_HIP(hipSetDevice(eng->device));
     launch_timestep_gravity(n, d_gravaccel, d_gravpm, atime, hubble, ErrTolIntAccuracy, 2.8 * eng->GravitySoftening, d_dloga, eng->stream);
+    API_END
+}
+
+int mpg_dev_peano_keys(mpg_engine *eng, int64_t n, const double *d_pos, double BoxSize, uint64_t *d_keys)
+{
+    API_BEGIN
+    MPG_CHECK(eng && n >= 0 && (n == 0 || (d_pos && d_keys)) && BoxSize > 0, "peano_keys: bad argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    launch_peano_keys(n, d_pos, BoxSize, d_keys, eng->stream);
+    API_END
+}
+
+int mpg_dev_order_by_type_and_key(mpg_engine *eng, int64_t n, const unsigned char *d_type, const unsigned char *d_flags,
+                                  const uint64_t *d_keys, int *d_perm, int64_t *n_live)
+{
+    API_BEGIN
+    MPG_CHECK(eng && n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (d_keys && d_perm)) && n_live, "order_by_type_and_key: bad argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    *n_live = order_by_type_and_key(n, d_type, d_flags, d_keys, d_perm, eng->peano, eng->stream);
     API_END
 }
 

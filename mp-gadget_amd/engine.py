@@ -362,6 +362,15 @@ class Engine:
         self._ck(self.lib.mpg_dev_timestep_gravity_dloga(self.h, C.c_int64(gravaccel.shape[0]), _ptr(gravaccel), _ptr(gravpm), C.c_double(atime),
                                                          C.c_double(hubble), C.c_double(ErrTolIntAccuracy), _ptr(dloga)))
 
+    # particle order: Peano-Hilbert keys and the (type, key) sort (utils/peano.h, slotsmanager.c:404-452)
+    def dev_peano_keys(self, pos, box, keys):
+        self._ck(self.lib.mpg_dev_peano_keys(self.h, C.c_int64(pos.shape[0]), _ptr(pos), C.c_double(box), _ptr(keys)))
+
+    def dev_order_by_type_and_key(self, keys, perm, type=None, flags=None):
+        n = C.c_int64(0)
+        self._ck(self.lib.mpg_dev_order_by_type_and_key(self.h, C.c_int64(keys.shape[0]), _ptr(type), _ptr(flags), _ptr(keys), _ptr(perm), C.byref(n)))
+        return n.value
+
     # hierarchical gravity (timestep.c:239-599)
     @staticmethod
     def _hier_arrays(vel, gravpm, fulltree_accel, tb_grav, potential=None, flags=None, stored_accel=None):
