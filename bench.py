@@ -20,6 +20,7 @@ import importlib
 import json
 import os
 import sys
+import math
 import time
 
 import numpy as np
@@ -59,7 +60,7 @@ def main():
     ap.add_argument("--mgpu", choices=["domain", "slab", "replicated"], default="domain",
                     help="N > 1: domain = particles distributed (x-slab domains, ghost import, slab PM); slab = particles replicated, "
                          "slab PM and slab targets; replicated = everything but the walk targets replicated")
-    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate"],
+    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof"],
                     help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
                          "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
     args = ap.parse_args()
@@ -94,6 +95,10 @@ def main():
         if world != 1:
             raise SystemExit("--workload integrate is single-GPU")
         return integrate_bench(pkg, torch, args, dev)
+    if args.workload == "fof":
+        if world != 1:
+            raise SystemExit("--workload fof is single-GPU")
+        return fof_bench(pkg, torch, args, dev)
     if multi and world == 1:
         pkg.pm_slab.FORCE_COLLECTIVES = True
     if args.workload == "hydro":
@@ -357,6 +362,63 @@ def integrate_bench(pkg, torch, args, dev):
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_alg,
                         "avg_launch_ms": 1e3 * el / args.steps,
                         "note": "three launches per step; each call also reads back an error word (one stream synchronisation per call)"}}
+    eng.close()
+    emit(out)
+    return out
+
+
+def fof_bench(pkg, torch, args, dev):
+    """fof_fof (tree of the dark matter, primary linking, group table, P[].GrNr) on n^3 particles: a uniform
+    background (60 %) plus Gaussian clumps of 20 .. 20000 members, linking length 0.2 mean separations, FOFHaloMinLength 32.
+    One step = one fof_fof.  Reported against the HBM peak with the compulsory bytes of the passes (positions, IDs, labels, sort)."""
+    n = args.n or 256
+    N = n ** 3
+    box = 1000.0 * n
+    g = torch.Generator(device=dev).manual_seed(7)
+    f8 = torch.float64
+    nback = int(0.6 * N)
+    parts = [torch.rand(nback, 3, dtype=f8, device=dev, generator=g) * box]
+    left = N - nback
+    LL = 0.2 * box / n
+    cpu = torch.Generator().manual_seed(3)
+    while left > 0:
+        m = min(left, int(torch.exp(torch.empty(1).uniform_(math.log(20.), math.log(20000.), generator=cpu)).item()))
+        c = torch.rand(3, dtype=f8, device=dev, generator=g) * box
+        parts.append(torch.remainder(c + torch.randn(m, 3, dtype=f8, device=dev, generator=g) * (0.25 * LL * m ** (1. / 3)), box))
+        left -= m
+    pos = torch.cat(parts).contiguous()
+    pos.clamp_(min=1e-9)
+    mass = torch.ones(N, dtype=torch.float32, device=dev)
+    ids = torch.randperm(N, device=dev, generator=g).to(torch.int64)
+    vel = torch.randn(N, 3, dtype=f8, device=dev, generator=g)
+    grnr = torch.zeros(N, dtype=torch.int64, device=dev)
+    eng = pkg.Engine(dev.index or 0)
+    eng.use_torch_stream()
+    eng.dev_bind_particles(pos, mass, box)
+    ng = 0
+    for _ in range(args.warmup + 1):
+        ng = eng.dev_fof_fof(ids, LL, 32, vel=vel, grnr=grnr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ng = eng.dev_fof_fof(ids, LL, 32, vel=vel, grnr=grnr)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    in_groups = int((grnr >= 0).sum().item())
+    # compulsory bytes per particle: tree build (keys, sort, gather: ~200), link walk (32 source + 4 parent), flatten / labels (4+4+8+8+8),
+    # label sort (8 passes x 24), accumulate (4+24+24+4+8), GrNr write 8
+    b_alg = N * (200 + 36 + 32 + 192 + 64 + 8)
+    ach = b_alg * args.steps / el / 1e9
+    out = {"metric": "particles/sec through fof_fof (primary linking + group catalogue)", "value": N * args.steps / el, "unit": "particles/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "friends-of-friends groups of %d^3 dark-matter particles (60%% uniform + Gaussian clumps), LL = 0.2" % n,
+                      "particles": N, "groups": ng, "particles_in_groups": in_groups},
+           "roofline": {"bound": "hbm", "kernel": "fof_fof (tree build + k_fof_walk + sorts + k_fof_accumulate)", "achieved": ach,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_alg,
+                        "avg_launch_ms": 1e3 * el / args.steps,
+                        "note": "whole fof_fof call (about 30 launches, three host synchronisations for counts); the link walk is a "
+                                "neighbour search bound by instruction issue and latency, not by HBM"}}
     eng.close()
     emit(out)
     return out

@@ -356,6 +356,32 @@ int mpg_dev_peano_keys(mpg_engine *eng, int64_t n, const double *d_pos, double B
 int mpg_dev_order_by_type_and_key(mpg_engine *eng, int64_t n, const unsigned char *d_type, const unsigned char *d_flags,
                                   const uint64_t *d_keys, int *d_perm, int64_t *n_live);
 
+/* ---- friends-of-friends groups (libgadget/fof.c) on the bound particles: primary linking of the
+ * FOFPrimaryLinkTypes at the comoving linking length, secondary particles attached to the nearest primary one, groups of at
+ * least FOFHaloMinLength members numbered by (Length descending, MinID).  A group is labelled by its smallest particle ID.
+ * Not carried: the sub-grid group properties (Sfr, metals, black-hole masses, MaxDens / seed index) and groups that span ranks. */
+typedef struct mpg_fof_params {     /* struct FOFParams, fof.c:37-48, as far as this path reads it */
+    int FOFPrimaryLinkTypes;        /* bit mask of particle types, default 2 (dark matter) */
+    int FOFSecondaryLinkTypes;      /* default 1 + 16 + 32 (gas, stars, black holes); disjoint from the primary types */
+    double FOFHaloComovingLinkingLength; /* FOFHaloLinkingLength * mean DM separation (fof_init, fof.c:83-86) */
+    int FOFHaloMinLength;
+} mpg_fof_params;
+typedef struct mpg_fof_groups {     /* struct Group / BaseGroup, fof.h:14-49: device arrays of *ngroups entries; NULL = not wanted */
+    uint64_t *MinID;
+    int *Length, *GrNr, *LenType;   /* LenType[g][6] */
+    double *Mass, *MassType;        /* MassType[g][6] */
+    double *CM, *Vel, *Jmom;        /* [g][3] */
+    double *Imom;                   /* [g][3][3] */
+    float *FirstPos;                /* [g][3] */
+} mpg_fof_groups;
+/* fof_fof (fof.c:157-253) with StoreGrNr: d_id[n] = P[].ID, d_vel[n][3] (may be NULL: zero), d_hsml[n] (may be NULL: no radius hint
+ * for gas), d_flags (may be NULL).  d_grnr[n] (may be NULL) receives P[].GrNr (-1: in no group); *ngroups = fof.TotNgroups.
+ * Builds the tree of the primary types itself (force_tree_rebuild_mask) and leaves it in place. */
+int mpg_dev_fof_fof(mpg_engine *eng, const mpg_fof_params *par, const uint64_t *d_id, const double *d_vel, const double *d_hsml,
+                    const unsigned char *d_flags, int64_t *d_grnr, int64_t *ngroups);
+/* the group table of the last mpg_dev_fof_fof, in MinID order (the order of fof.Group) */
+int mpg_dev_fof_groups(mpg_engine *eng, const mpg_fof_groups *out);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

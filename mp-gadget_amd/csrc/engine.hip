@@ -12,6 +12,7 @@
 #include "sph.h"
 #include "timestep.h"
 #include "peano.h"
+#include "fof.h"
 #include "tree_build.h"
 #include <cmath>
 #include <cstdlib>
@@ -132,6 +133,7 @@ struct mpg_engine {
     DevBuf<unsigned long long> hier_cnt;
     DevBuf<char> hier_tmp;
     PeanoScratch peano;
+    FofEngine fof;
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
     HostBuf<uint8_t> h_b;
@@ -690,6 +692,74 @@ int mpg_dev_order_by_type_and_key(mpg_engine *eng, int64_t n, const unsigned cha
     MPG_CHECK(eng && n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (d_keys && d_perm)) && n_live, "order_by_type_and_key: bad argument");
     MPG_HIP(hipSetDevice(eng->device));
     *n_live = order_by_type_and_key(n, d_type, d_flags, d_keys, d_perm, eng->peano, eng->stream);
+    API_END
+}
+
+__global__ void __launch_bounds__(256) k_include_live(int64_t n, const uint8_t *__restrict__ flags, uint8_t *__restrict__ incl)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        incl[i] = (flags[i] & 3) ? 0 : 1; // garbage and swallowed particles are not in the tree (forcetree.c:357-365)
+}
+
+int mpg_dev_fof_fof(mpg_engine *eng, const mpg_fof_params *par, const uint64_t *d_id, const double *d_vel, const double *d_hsml,
+                    const unsigned char *d_flags, int64_t *d_grnr, int64_t *ngroups)
+{
+    API_BEGIN
+    MPG_CHECK(eng && par && ngroups && (eng->n == 0 || d_id), "fof_fof: null argument");
+    MPG_CHECK(eng->d_pos || eng->n == 0, "fof_fof: no particles bound (mpg_dev_bind_particles)");
+    MPG_CHECK(par->FOFHaloComovingLinkingLength > 0 && par->FOFHaloMinLength >= 1, "fof_fof: bad parameters");
+    MPG_CHECK((par->FOFPrimaryLinkTypes & par->FOFSecondaryLinkTypes) == 0, "fof_fof: primary and secondary link types must be disjoint");
+    MPG_HIP(hipSetDevice(eng->device));
+    // the tree of the primary linking particles, no moments (fof.c:178-180)
+    const uint8_t *incl = nullptr;
+    if(d_flags && eng->n > 0) {
+        eng->tree_incl.reserve((size_t)eng->n + 1);
+        hipLaunchKernelGGL(k_include_live, dim3((unsigned)((eng->n + 255) / 256)), dim3(256), 0, eng->stream, eng->n, d_flags, eng->tree_incl.p);
+        incl = eng->tree_incl.p;
+    }
+    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, par->FOFPrimaryLinkTypes, eng->box, eng->stream, &eng->timer, incl);
+    eng->tree_allocated = true;
+    eng->tree_mask = par->FOFPrimaryLinkTypes;
+    eng->full_particle_tree = false;
+    eng->sph.hmax_pending = false;
+    FofInput in;
+    in.n = eng->n;
+    in.pos = eng->d_pos;
+    in.vel = d_vel;
+    in.mass = eng->d_mass;
+    in.type = eng->d_type;
+    in.flags = d_flags;
+    in.id = (const unsigned long long *)d_id;
+    in.hsml = d_hsml;
+    in.box = eng->box;
+    in.LL = par->FOFHaloComovingLinkingLength;
+    in.minlen = par->FOFHaloMinLength;
+    in.secondary_mask = par->FOFSecondaryLinkTypes;
+    *ngroups = eng->fof.run(eng->tree, in, eng->stream);
+    if(d_grnr && eng->n > 0)
+        MPG_HIP(hipMemcpyAsync(d_grnr, eng->fof.p_grnr.p, (size_t)eng->n * sizeof(int64_t), hipMemcpyDeviceToDevice, eng->stream));
+    API_END
+}
+
+int mpg_dev_fof_groups(mpg_engine *eng, const mpg_fof_groups *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && out, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    FofTable t;
+    t.MinID = (unsigned long long *)out->MinID;
+    t.Length = out->Length;
+    t.GrNr = out->GrNr;
+    t.LenType = out->LenType;
+    t.Mass = out->Mass;
+    t.MassType = out->MassType;
+    t.CM = out->CM;
+    t.Vel = out->Vel;
+    t.Jmom = out->Jmom;
+    t.Imom = out->Imom;
+    t.FirstPos = out->FirstPos;
+    eng->fof.export_groups(t, eng->stream);
     API_END
 }
 

@@ -163,6 +163,17 @@ class TimestepParams(C.Structure):
     _fields_ = [("ErrTolIntAccuracy", C.c_double), ("MinSizeTimestep", C.c_double)]
 
 
+class FofParams(C.Structure):
+    """mpg_fof_params"""
+    _fields_ = [("FOFPrimaryLinkTypes", C.c_int), ("FOFSecondaryLinkTypes", C.c_int), ("FOFHaloComovingLinkingLength", C.c_double),
+                ("FOFHaloMinLength", C.c_int)]
+
+
+class FofGroupsC(C.Structure):
+    """mpg_fof_groups"""
+    _fields_ = [(k, C.c_void_p) for k in ("MinID", "Length", "GrNr", "LenType", "Mass", "MassType", "CM", "Vel", "Jmom", "Imom", "FirstPos")]
+
+
 GRAVKICK_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.c_int64)
 
 
@@ -370,6 +381,26 @@ class Engine:
         n = C.c_int64(0)
         self._ck(self.lib.mpg_dev_order_by_type_and_key(self.h, C.c_int64(keys.shape[0]), _ptr(type), _ptr(flags), _ptr(keys), _ptr(perm), C.byref(n)))
         return n.value
+
+    # friends-of-friends groups (fof.c)
+    def dev_fof_fof(self, ids, linking_length, min_length=32, vel=None, hsml=None, flags=None, grnr=None, primary=2, secondary=1 + 16 + 32):
+        """fof_fof on the bound particles; returns the number of groups.  grnr: int64 [n] device tensor for P[].GrNr (optional)."""
+        par = FofParams(int(primary), int(secondary), float(linking_length), int(min_length))
+        ng = C.c_int64(0)
+        self._ck(self.lib.mpg_dev_fof_fof(self.h, C.byref(par), _ptr(ids), _ptr(vel), _ptr(hsml), _ptr(flags), _ptr(grnr), C.byref(ng)))
+        return ng.value
+
+    def dev_fof_groups(self, ngroups, device="cuda"):
+        """The group table of the last dev_fof_fof as a dict of device tensors (MinID order)."""
+        import torch
+        mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        g = dict(MinID=mk(ngroups, torch.int64), Length=mk(ngroups, torch.int32), GrNr=mk(ngroups, torch.int32),
+                 LenType=mk((ngroups, 6), torch.int32), Mass=mk(ngroups, torch.float64), MassType=mk((ngroups, 6), torch.float64),
+                 CM=mk((ngroups, 3), torch.float64), Vel=mk((ngroups, 3), torch.float64), Jmom=mk((ngroups, 3), torch.float64),
+                 Imom=mk((ngroups, 3, 3), torch.float64), FirstPos=mk((ngroups, 3), torch.float32))
+        out = FofGroupsC(*[g[k].data_ptr() for k in ("MinID", "Length", "GrNr", "LenType", "Mass", "MassType", "CM", "Vel", "Jmom", "Imom", "FirstPos")])
+        self._ck(self.lib.mpg_dev_fof_groups(self.h, C.byref(out)))
+        return g
 
     # hierarchical gravity (timestep.c:239-599)
     @staticmethod
