@@ -1,4 +1,4 @@
-"""The Peano-Hilbert state machine generated for the device (mp-gadget_amd/csrc/peano_tables.h, made by oracle/gen_peano_tables.py)
+"""The Peano-Hilbert state machine generated for the device (mp-gadget_amd/csrc/peano_tables.h, made by tools/gen_peano_tables.py)
 against golden vectors taken from the reference function (tests/golden/peano_keys.npz, make_peano_golden.py) and, when
 oracle/_ref is present, against the reference function itself on fresh random input.  CPU only: the tables are parsed from the header."""
 import ctypes as C
