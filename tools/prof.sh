@@ -17,4 +17,5 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- pytho
 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o pmc -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
 cd $ROOT
 python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+find $OUT -name '*.csv' -size +4M -delete   # (per-dispatch traces / counter dumps of tens of MB; the stats CSV and the summary are what is kept)
 cat $OUT/summary.txt
