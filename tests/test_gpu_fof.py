@@ -106,3 +106,26 @@ def test_clumpy_set_matches_oracle(engine, orc, seed, gas):
     if gas:
         assert (Go["LenType"][:, 0] > 0).sum() >= 20 and Go["LenType"][:, 4].sum() >= 1
     compare(g, G, go, Go, box)
+
+
+def test_fof_edge_cases(engine, orc):
+    import torch
+    box, LL = 10.0, 0.5
+    # no particle of a primary type: everybody stays alone
+    pos = np.array([[1.0, 1, 1], [1.1, 1, 1], [1.2, 1, 1]])
+    typ = np.zeros(3, np.uint8)
+    ids = np.array([3, 4, 5], np.uint64)
+    g, G = run_engine(engine, pos, np.ones(3), ids, box, LL, 2, typ=typ)
+    assert len(G["MinID"]) == 0 and np.all(g == -1)
+    g, G = run_engine(engine, pos, np.ones(3), ids, box, LL, 1, typ=typ)
+    assert G["MinID"].tolist() == [3, 4, 5] and G["Length"].tolist() == [1, 1, 1] and sorted(g.tolist()) == [1, 2, 3]
+    # one particle; identical positions (a full leaf of coincident points links into one group)
+    g, G = run_engine(engine, pos[:1], np.ones(1), ids[:1], box, LL, 1)
+    assert G["MinID"].tolist() == [3] and g.tolist() == [1]
+    same = np.repeat(np.array([[2.0, 3.0, 4.0]]), 8, axis=0)
+    g, G = run_engine(engine, same, np.ones(8), np.arange(8, dtype=np.uint64) + 10, box, LL, 1)
+    assert G["Length"].tolist() == [8] and G["MinID"].tolist() == [10] and np.abs(G["CM"][0] - [2.0, 3.0, 4.0]).max() < 1e-6
+    # no particles at all
+    z = torch.zeros(0, 3, dtype=torch.float64, device="cuda")
+    engine.dev_bind_particles(z, torch.zeros(0, dtype=torch.float32, device="cuda"), box)
+    assert engine.dev_fof_fof(torch.zeros(0, dtype=torch.int64, device="cuda"), LL, 1) == 0
