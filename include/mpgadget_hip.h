@@ -382,6 +382,27 @@ int mpg_dev_fof_fof(mpg_engine *eng, const mpg_fof_params *par, const uint64_t *
 /* the group table of the last mpg_dev_fof_fof, in MinID order (the order of fof.Group) */
 int mpg_dev_fof_groups(mpg_engine *eng, const mpg_fof_groups *out);
 
+/* ---- snapshot / IC wire format: the "bigfile" blocks petaio.c reads and writes (libgadget/petaio.c:986-1120;
+ * format: depends/bigfile/src/bigfile.c).  `file` is the snapshot directory (PART_000, an MP-GenIC output), `block` a column such
+ * as "1/Position" or "Header".  dtypes are bigfile's: "f8", "f4", "i8", "u8", "i4", "u4", "u1", "S1" (little-endian).  Host IO only;
+ * files written here are read by the reference library and vice versa (tests/test_snapshot_io.py). */
+typedef struct mpg_bigblock_info {
+    char dtype[8];   /* normalised, e.g. "<f8" */
+    int nmemb;       /* values per element (3 for Position) */
+    int nfile;       /* physical files of the block */
+    int64_t size;    /* elements */
+} mpg_bigblock_info;
+int mpg_bigfile_block_info(const char *file, const char *block, mpg_bigblock_info *info);            /* big_file_open_block */
+/* big_block_read with a cast: `count` elements from element `start`, converted to want_dtype, into out */
+int mpg_bigfile_read_block(const char *file, const char *block, int64_t start, int64_t count, const char *want_dtype, void *out);
+/* big_file_create_block + big_block_write: `size` elements of `nmemb` values stored as `dtype`, split evenly over nfile files
+ * (bigfile-mpi.c:106-111); data holds src_dtype values (NULL: dtype) */
+int mpg_bigfile_write_block(const char *file, const char *block, const char *dtype, int nmemb, int nfile, int64_t size, const char *src_dtype,
+                            const void *data);
+/* big_block_get_attr / big_block_set_attr; get returns 2 when the attribute does not exist */
+int mpg_bigfile_get_attr(const char *file, const char *block, const char *name, const char *want_dtype, void *out, int nmemb);
+int mpg_bigfile_set_attr(const char *file, const char *block, const char *name, const char *dtype, const void *data, int nmemb);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

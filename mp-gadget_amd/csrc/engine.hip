@@ -13,6 +13,7 @@
 #include "timestep.h"
 #include "peano.h"
 #include "fof.h"
+#include "snapshot_io.h"
 #include "tree_build.h"
 #include <cmath>
 #include <cstdlib>
@@ -760,6 +761,62 @@ int mpg_dev_fof_groups(mpg_engine *eng, const mpg_fof_groups *out)
     t.Imom = out->Imom;
     t.FirstPos = out->FirstPos;
     eng->fof.export_groups(t, eng->stream);
+    API_END
+}
+
+/* ------------------------------ snapshot / IC wire format (host IO) ------------------------------ */
+int mpg_bigfile_block_info(const char *file, const char *block, mpg_bigblock_info *info)
+{
+    API_BEGIN
+    MPG_CHECK(info, "null argument");
+    BigBlockInfo b;
+    bigfile_block_info(file, block, &b);
+    memcpy(info->dtype, b.dtype, 8);
+    info->nmemb = b.nmemb;
+    info->nfile = b.nfile;
+    info->size = b.size;
+    API_END
+}
+
+int mpg_bigfile_read_block(const char *file, const char *block, int64_t start, int64_t count, const char *want_dtype, void *out)
+{
+    API_BEGIN
+    MPG_CHECK(out || count == 0, "null argument");
+    bigfile_read_block(file, block, start, count, want_dtype, out);
+    API_END
+}
+
+int mpg_bigfile_write_block(const char *file, const char *block, const char *dtype, int nmemb, int nfile, int64_t size, const char *src_dtype,
+                            const void *data)
+{
+    API_BEGIN
+    MPG_CHECK(data || size == 0, "null argument");
+    bigfile_write_block(file, block, dtype, nmemb, nfile, size, src_dtype, data);
+    API_END
+}
+
+int mpg_bigfile_get_attr(const char *file, const char *block, const char *name, const char *want_dtype, void *out, int nmemb)
+{
+    try {
+        MPG_CHECK(name && out, "null argument");
+        if(bigfile_get_attr(file, block, name, want_dtype, out, nmemb) != 0) {
+            g_err = std::string("bigfile: no attribute `") + name + "'";
+            return 2;
+        }
+    }
+    catch(const std::exception &e) {
+        g_err = e.what();
+        return 1;
+    }
+    g_err.clear();
+    return 0;
+}
+
+int mpg_bigfile_set_attr(const char *file, const char *block, const char *name, const char *dtype, const void *data, int nmemb)
+{
+    API_BEGIN
+    MPG_CHECK(data || nmemb == 0, "null argument");
+    bigfile_set_attr(file, block, name, dtype, data, nmemb);
     API_END
 }
 
