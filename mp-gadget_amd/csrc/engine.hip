@@ -495,6 +495,7 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     io.tab_force = eng->tab_force.p;
     io.tab_pot = eng->tab_pot.p;
     io.counters = eng->counters.p;
+    io.pack_leaves = getenv("MPG_PACK_LEAVES") ? 1 : 0; // (experiment knob, see grav_walk_split.hip: measured a wash)
     if(eng->count)
         MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 16 * sizeof(unsigned long long), eng->stream));
     eng->timer.start(eng->stream);

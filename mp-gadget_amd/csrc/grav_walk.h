@@ -17,6 +17,7 @@ struct WalkIO {
     const float *tab_force = nullptr;  // [NTAB] shortrange_table           (gravity.c:20)
     const float *tab_pot = nullptr;    // [NTAB] shortrange_table_potential
     unsigned long long *counters = nullptr; // [8] pp interactions, nodes visited, nodes used, burst statistics (COUNT builds only)
+    int pack_leaves = 0;               // split walk: pack short adjacent leaves into full list entries (0: one entry per leaf)
 };
 
 void launch_grav_walk(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,

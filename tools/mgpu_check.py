@@ -1,3 +1,4 @@
+import os
 """Run one sharded TreePM force step under torch.distributed and save rank 0's accelerations (used by
 tests/test_gpu_gravity.py::test_two_ranks_match_one).  Launch with torch.distributed.run; MPG_DIST_BACKEND=gloo lets the
 ranks share one GPU."""
@@ -27,6 +28,7 @@ pos, mass, box = pkg.ics.s_clust(n, seed=5) if ic == "s_clust" else getattr(pkg.
 N = len(pos)
 d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
 eng = pkg.Engine(lr)
+eng.set_walk_variant(int(os.environ.get("MPG_WALK_VARIANT", "6")))   # one kernel everywhere: the comparisons are of summation-order-identical results
 eng.use_torch_stream()
 eng.gravshort_fill_ntab(0, 1.5)
 eng.gravpm_init_periodic(box, 1.5, 2 * n, G)

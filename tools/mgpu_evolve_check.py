@@ -1,3 +1,4 @@
+import os
 """Three force / kick / drift steps with the particles distributed over ranks (x-slab domains, ghost import every step, migration
 after every drift), saving rank 0's gather of the final state by particle id; world == 1 without MPG_MGPU_MODE=domain runs the
 same steps on one GPU.  Used by tests/test_gpu_timestep.py::test_distributed_evolution_matches_one_gpu."""
@@ -29,6 +30,7 @@ vel = np.random.RandomState(4).standard_normal((N, 3)) * 0.02 * box / n / dt
 f8 = dict(dtype=torch.float64, device=dev)
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 eng = pkg.Engine(lr)
+eng.set_walk_variant(int(os.environ.get("MPG_WALK_VARIANT", "6")))   # one kernel everywhere: the comparisons are of summation-order-identical results
 eng.use_torch_stream()
 eng.gravshort_fill_ntab(0, 1.5)
 eng.gravpm_init_periodic(box, 1.5, nmesh, G)

@@ -1,3 +1,4 @@
+import os
 """One density -> hmax -> hydro_force pass with the particles distributed over ranks (x-slab domains, ghost import), saving rank
 0's view of the global results; world == 1 without MPG_MGPU_MODE=domain is the plain single-GPU pass.  Used by
 tests/test_gpu_sph.py::test_sph_ranks_match_one.  MPG_DIST_BACKEND=gloo lets the ranks share one GPU."""
@@ -32,6 +33,7 @@ T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 g_pos, g_mass, g_typ, g_vel, g_ent = T(pos), T(mass), T(typ), T(vel), T(ent)
 g_hsml = torch.full((N,), 2.2 * box / n, **f8)
 eng = pkg.Engine(lr)
+eng.set_walk_variant(int(os.environ.get("MPG_WALK_VARIANT", "6")))   # one kernel everywhere: the comparisons are of summation-order-identical results
 eng.use_torch_stream()
 eng.set_gravshort_treepar()
 eng.gravshort_set_softenings(box / n)
