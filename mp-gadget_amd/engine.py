@@ -178,7 +178,12 @@ GRAVKICK_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.c_int64)
 
 
 class Engine:
-    """One engine per GPU (= per MPI rank in the reference's terms)."""
+    """One engine per GPU (= per MPI rank in the reference's terms).
+
+    Stream semantics of the dev_* (device-resident) calls: they are queued on the ENGINE's stream, which is its own non-blocking
+    stream unless use_torch_stream() / set_stream() says otherwise.  Reading their outputs with torch (`.cpu()`, index ops,
+    collectives) is ordered after them only if both use one stream - call use_torch_stream() once after construction (bench.py,
+    tools/) - or after synchronize().  The host-pointer (AoS) calls synchronise before returning."""
 
     def __init__(self, device=0):
         self.lib = load_library()
