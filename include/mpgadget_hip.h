@@ -97,6 +97,12 @@ typedef struct mpg_particle_view {
 void mpg_particle_view_reference_layout(mpg_particle_view *v, void *P, int64_t NumPart);
 
 /* ---- host (drop-in) entry points ------------------------------------------------------------- */
+/* Every host entry point that needs positions packs Pos / Mass / Type of P[] and uploads them, because P may have moved or
+ * changed between calls.  A caller that knows better declares an EPOCH of its particle table: calls made with the same non-zero
+ * epoch, the same &P[0], NumPart and BoxSize as the last upload reuse it (gravpm_force -> force_tree_full -> grav_short_tree of
+ * one step, run.c:522-548).  Bump the epoch after anything that moves or reorders particles (drift, exchange, garbage collection);
+ * 0 (the default) switches the reuse off. */
+int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch);
 /* gravpm_force, libgadget/gravpm.c:61-119: zero GravPM, CIC deposit, r2c, Green's function, 4 x (transfer, c2r,
  * CIC readout).  Writes P[i].GravPM[3] (=) and P[i].Potential (+=, as readout_potential does). */
 int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P);

@@ -138,6 +138,11 @@ struct mpg_engine {
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
     HostBuf<uint8_t> h_b;
+    // host path: what is staged (mpg_set_particle_epoch) and the events of the chunked downloads
+    int64_t host_epoch = 0, staged_epoch = 0, staged_n = -1;
+    const void *staged_base = nullptr;
+    double staged_box = 0;
+    hipEvent_t chunk_ev[8] = {};
 };
 
 #define API_BEGIN try {
@@ -187,6 +192,9 @@ void mpg_engine_destroy(mpg_engine *eng)
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+    for(auto &e : eng->chunk_ev)
+        if(e)
+            (void)hipEventDestroy(e);
     eng->pm.destroy();
     if(eng->own_stream && eng->stream)
         (void)hipStreamDestroy(eng->stream);
@@ -1084,49 +1092,103 @@ int mpg_dev_hierarchical_gravity_accelerations(mpg_engine *eng, const mpg_hiergr
 
 /* ------------------------------ host (AoS) path ------------------------------ */
 
+// The host <-> device staging of the AoS path is cut into chunks so that packing / unpacking on the host threads overlaps the
+// PCIe transfers of the neighbouring chunks (pinned buffers: the copies are asynchronous).
+constexpr int HOST_CHUNKS = 8;
+static inline void chunk_range(int64_t n, int c, int64_t &lo, int64_t &hi)
+{
+    lo = n * c / HOST_CHUNKS;
+    hi = n * (c + 1) / HOST_CHUNKS;
+}
+
+} // extern "C" (a template)
+// unpack(lo, hi) runs on the host for each chunk as soon as the device -> host copies issue(lo, hi) queued for it have landed
+template <class Issue, class Unpack> static void download_chunks(mpg_engine *eng, int64_t n, Issue issue, Unpack unpack)
+{
+    for(int c = 0; c < HOST_CHUNKS; c++) {
+        int64_t lo, hi;
+        chunk_range(n, c, lo, hi);
+        if(hi > lo)
+            issue(lo, hi);
+        if(!eng->chunk_ev[c])
+            MPG_HIP(hipEventCreateWithFlags(&eng->chunk_ev[c], hipEventDisableTiming));
+        MPG_HIP(hipEventRecord(eng->chunk_ev[c], eng->stream));
+    }
+    for(int c = 0; c < HOST_CHUNKS; c++) {
+        int64_t lo, hi;
+        chunk_range(n, c, lo, hi);
+        MPG_HIP(hipEventSynchronize(eng->chunk_ev[c]));
+        if(hi > lo)
+            parallel_for(hi - lo, [=](int64_t a, int64_t b) { unpack(lo + a, lo + b); });
+    }
+}
+extern "C" {
+
 static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
 {
     MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
     MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
     const int64_t n = P->n;
+    // positions, masses and types of this very table are on the device already (mpg_set_particle_epoch)
+    if(eng->host_epoch != 0 && eng->staged_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n &&
+       eng->staged_box == BoxSize && eng->d_pos == eng->s_pos.p)
+        return;
     eng->h_d.reserve(3 * (size_t)n + 1);
     eng->h_f.reserve((size_t)n + 1);
     eng->h_b.reserve((size_t)n + 1);
+    eng->s_pos.reserve(3 * (size_t)n + 1);
+    eng->s_mass.reserve((size_t)n + 1);
+    eng->s_type.reserve((size_t)n + 1);
     const char *b = (const char *)P->base;
     double *hd = eng->h_d.p;
     float *hf = eng->h_f.p;
     uint8_t *hb = eng->h_b.p;
     const mpg_particle_view V = *P;
-    parallel_for(n, [=](int64_t lo, int64_t hi) {
-        for(int64_t i = lo; i < hi; i++) {
-            const char *rec = b + i * V.stride;
-            const double *pp = (const double *)(rec + V.off_pos);
-            hd[3 * i + 0] = pp[0];
-            hd[3 * i + 1] = pp[1];
-            hd[3 * i + 2] = pp[2];
-            hf[i] = *(const float *)(rec + V.off_mass);
-            uint8_t ty = V.off_type >= 0 ? (*(const uint8_t *)(rec + V.off_type) & 7) : 1;
-            // garbage / swallowed-BH particles never enter the tree (forcetree.c:806): give them type 7 (no mask bit)
-            if(V.off_flags >= 0) {
-                const uint8_t fl = *(const uint8_t *)(rec + V.off_flags);
-                if((fl & 1) || ((fl & 2) && ty == 5))
-                    ty = 7;
+    for(int c = 0; c < HOST_CHUNKS; c++) {
+        int64_t lo, hi;
+        chunk_range(n, c, lo, hi);
+        if(hi <= lo)
+            continue;
+        parallel_for(hi - lo, [=](int64_t a0, int64_t a1) {
+            for(int64_t i = lo + a0; i < lo + a1; i++) {
+                const char *rec = b + i * V.stride;
+                const double *pp = (const double *)(rec + V.off_pos);
+                hd[3 * i + 0] = pp[0];
+                hd[3 * i + 1] = pp[1];
+                hd[3 * i + 2] = pp[2];
+                hf[i] = *(const float *)(rec + V.off_mass);
+                uint8_t ty = V.off_type >= 0 ? (*(const uint8_t *)(rec + V.off_type) & 7) : 1;
+                // garbage / swallowed-BH particles never enter the tree (forcetree.c:806): give them type 7 (no mask bit)
+                if(V.off_flags >= 0) {
+                    const uint8_t fl = *(const uint8_t *)(rec + V.off_flags);
+                    if((fl & 1) || ((fl & 2) && ty == 5))
+                        ty = 7;
+                }
+                hb[i] = ty;
             }
-            hb[i] = ty;
-        }
-    });
-    eng->s_pos.reserve(3 * (size_t)n + 1);
-    eng->s_mass.reserve((size_t)n + 1);
-    eng->s_type.reserve((size_t)n + 1);
-    MPG_HIP(hipMemcpyAsync(eng->s_pos.p, eng->h_d.p, 3 * n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
-    MPG_HIP(hipMemcpyAsync(eng->s_mass.p, eng->h_f.p, n * sizeof(float), hipMemcpyHostToDevice, eng->stream));
-    MPG_HIP(hipMemcpyAsync(eng->s_type.p, eng->h_b.p, n * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
+        });
+        MPG_HIP(hipMemcpyAsync(eng->s_pos.p + 3 * lo, hd + 3 * lo, 3 * (hi - lo) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+        MPG_HIP(hipMemcpyAsync(eng->s_mass.p + lo, hf + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, eng->stream));
+        MPG_HIP(hipMemcpyAsync(eng->s_type.p + lo, hb + lo, (hi - lo) * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
+    }
     MPG_HIP(hipStreamSynchronize(eng->stream));
     eng->n = n;
     eng->d_pos = eng->s_pos.p;
     eng->d_mass = eng->s_mass.p;
     eng->d_type = eng->s_type.p;
     eng->box = BoxSize;
+    eng->staged_epoch = eng->host_epoch;
+    eng->staged_base = P->base;
+    eng->staged_n = n;
+    eng->staged_box = BoxSize;
+}
+
+int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->host_epoch = epoch;
+    API_END
 }
 
 int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
@@ -1155,20 +1217,25 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
         MPG_HIP(hipMemcpyAsync(eng->s_pot.p, hp, n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     }
     eng->pm.force(n, eng->d_pos, eng->d_mass, nullptr, eng->s_gravpm.p, wantpot ? eng->s_pot.p : nullptr, eng->stream, &eng->timer);
-    MPG_HIP(hipMemcpyAsync(hg, eng->s_gravpm.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
-    if(wantpot)
-        MPG_HIP(hipMemcpyAsync(hp, eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
-    MPG_HIP(hipStreamSynchronize(eng->stream));
-    parallel_for(n, [=](int64_t lo, int64_t hi) {
-        for(int64_t i = lo; i < hi; i++) {
-            double *g = (double *)(b + i * V.stride + V.off_gravpm);
-            g[0] = hg[3 * i + 0];
-            g[1] = hg[3 * i + 1];
-            g[2] = hg[3 * i + 2];
+    const double *dg = eng->s_gravpm.p, *dp = eng->s_pot.p;
+    hipStream_t st = eng->stream;
+    download_chunks(
+        eng, n,
+        [=](int64_t lo, int64_t hi) {
+            MPG_HIP(hipMemcpyAsync(hg + 3 * lo, dg + 3 * lo, 3 * (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, st));
             if(wantpot)
-                *(double *)(b + i * V.stride + V.off_potential) = hp[i];
-        }
-    });
+                MPG_HIP(hipMemcpyAsync(hp + lo, dp + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, st));
+        },
+        [=](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++) {
+                double *g = (double *)(b + i * V.stride + V.off_gravpm);
+                g[0] = hg[3 * i + 0];
+                g[1] = hg[3 * i + 1];
+                g[2] = hg[3 * i + 2];
+                if(wantpot)
+                    *(double *)(b + i * V.stride + V.off_potential) = hp[i];
+            }
+        });
     API_END
 }
 
@@ -1248,30 +1315,46 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
         throw Error(g_err);
     eng->h_d2.reserve(3 * (size_t)n + 1);
     double *ha = eng->h_d2.p, *hp = eng->h_d3.p; // (OldAcc has been uploaded: its staging buffer is free again)
-    MPG_HIP(hipMemcpyAsync(ha, eng->s_accel.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
-    if(wantpot)
-        MPG_HIP(hipMemcpyAsync(hp, eng->s_pot.p, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
-    MPG_HIP(hipStreamSynchronize(eng->stream));
-    const int64_t nt = ActiveParticle ? NumActiveParticle : n;
     char *wb = (char *)P->base;
-    parallel_for(nt, [=](int64_t lo, int64_t hi) {
-        for(int64_t k = lo; k < hi; k++) {
-            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
-            if(AccelStore) {
-                AccelStore[i][0] = ha[3 * i + 0];
-                AccelStore[i][1] = ha[3 * i + 1];
-                AccelStore[i][2] = ha[3 * i + 2];
-            }
-            if(full) { // gravshort.h:54-66
-                double *a = (double *)(wb + i * V.stride + V.off_accel);
-                a[0] = ha[3 * i + 0];
-                a[1] = ha[3 * i + 1];
-                a[2] = ha[3 * i + 2];
-                if(wantpot)
-                    *(double *)(wb + i * V.stride + V.off_potential) = hp[i];
-            }
+    auto put = [=](int64_t i) {
+        if(AccelStore) {
+            AccelStore[i][0] = ha[3 * i + 0];
+            AccelStore[i][1] = ha[3 * i + 1];
+            AccelStore[i][2] = ha[3 * i + 2];
         }
-    });
+        if(full) { // gravshort.h:54-66
+            double *a = (double *)(wb + i * V.stride + V.off_accel);
+            a[0] = ha[3 * i + 0];
+            a[1] = ha[3 * i + 1];
+            a[2] = ha[3 * i + 2];
+            if(wantpot)
+                *(double *)(wb + i * V.stride + V.off_potential) = hp[i];
+        }
+    };
+    const double *da = eng->s_accel.p, *dpot = eng->s_pot.p;
+    hipStream_t st = eng->stream;
+    if(!ActiveParticle) // all particles: unpack chunk by chunk while the later chunks are still on the bus
+        download_chunks(
+            eng, n,
+            [=](int64_t lo, int64_t hi) {
+                MPG_HIP(hipMemcpyAsync(ha + 3 * lo, da + 3 * lo, 3 * (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, st));
+                if(wantpot)
+                    MPG_HIP(hipMemcpyAsync(hp + lo, dpot + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, st));
+            },
+            [=](int64_t lo, int64_t hi) {
+                for(int64_t i = lo; i < hi; i++)
+                    put(i);
+            });
+    else {
+        MPG_HIP(hipMemcpyAsync(ha, da, 3 * n * sizeof(double), hipMemcpyDeviceToHost, st));
+        if(wantpot)
+            MPG_HIP(hipMemcpyAsync(hp, dpot, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipStreamSynchronize(st));
+        parallel_for(NumActiveParticle, [=](int64_t lo, int64_t hi) {
+            for(int64_t k = lo; k < hi; k++)
+                put(ActiveParticle[k]);
+        });
+    }
     API_END
 }
 

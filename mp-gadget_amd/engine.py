@@ -284,6 +284,11 @@ class Engine:
     def gravpm_init_periodic(self, BoxSize, Asmth, Nmesh, G):
         self._ck(self.lib.mpg_gravpm_init_periodic(self.h, C.c_double(BoxSize), C.c_double(Asmth), int(Nmesh), C.c_double(G)))
 
+    def set_particle_epoch(self, epoch):
+        """Declare the epoch of the host particle table: host calls with the same non-zero epoch, table address, size and box reuse
+        the uploaded positions (include/mpgadget_hip.h)."""
+        self._ck(self.lib.mpg_set_particle_epoch(self.h, C.c_int64(epoch)))
+
     def petapm_destroy(self):
         self._ck(self.lib.mpg_petapm_destroy(self.h))
 

@@ -471,3 +471,43 @@ def test_force_tree_active_moments(pkg, engine, orc):
     engine.force_tree_active_moments(P, box, None)
     engine.grav_short_tree(P)
     assert not np.array_equal(P["FullTreeGravAccel"], before)
+
+
+def test_host_path_particle_epoch(pkg, engine):
+    """mpg_set_particle_epoch: with the same non-zero epoch the upload of Pos / Mass / Type is reused (results identical); a new epoch
+    (or epoch 0) picks up changed positions."""
+    n, nmesh = 12, 24
+    pos, mass, box = pkg.ics.s_zel(n)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    P = pkg.make_particles(pos, mass)
+
+    start = [None]
+
+    def step():
+        if start[0] is not None:
+            P["FullTreeGravAccel"] = start[0]            # the same OldAcc for every step that is compared
+        engine.gravpm_force(P)
+        engine.force_tree_full(P, box)
+        engine.grav_short_tree(P)
+        return P["GravPM"].copy(), P["FullTreeGravAccel"].copy()
+
+    engine.set_particle_epoch(0)
+    start[0] = step()[1]
+    g0, a0 = step()
+    engine.set_particle_epoch(7)
+    g1, a1 = step()
+    same = lambda x, y: np.abs(x - y).max() <= 1e-10 * np.abs(y).max()                      # (the CIC deposit sums with atomics)
+    assert same(g1, g0) and np.abs(a1 - a0).max() <= 1e-9 * np.abs(a0).max()               # (a1 uses a0 as OldAcc: same decisions)
+    P["Pos"][:, 0] = np.mod(P["Pos"][:, 0] + 0.37 * box / n, box)                           # the table changes ...
+    engine.set_particle_epoch(7)
+    P["FullTreeGravAccel"] = start[0]
+    engine.force_tree_full(P, box)                                                          # ... but the epoch says it did not: stale upload
+    engine.grav_short_tree(P)
+    stale = P["FullTreeGravAccel"].copy()
+    assert np.abs(stale - a1).max() <= 1e-9 * np.abs(a1).max()
+    engine.set_particle_epoch(8)
+    g2, a2 = step()
+    assert not same(g2, g1) and np.abs(a2 - stale).max() > 1e-6 * np.abs(a2).max()
+    engine.set_particle_epoch(0)
+    g3, a3 = step()
+    assert same(g3, g2)

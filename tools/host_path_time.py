@@ -13,7 +13,10 @@ eng.gravshort_fill_ntab(0, 1.5)
 eng.gravpm_init_periodic(box, 1.5, 2 * n, G)
 eng.set_gravshort_treepar(TreeUseBH=2)
 eng.gravshort_set_softenings(box / n)
-for it in range(4):
+use_epoch = len(sys.argv) > 2 and sys.argv[2] == "epoch"
+for it in range(5):
+    if use_epoch:
+        eng.set_particle_epoch(it + 1)       # P is unchanged between the three calls of a step
     t0 = time.perf_counter()
     eng.gravpm_force(P)
     t1 = time.perf_counter()
