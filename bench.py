@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--mgpu", choices=["domain", "slab", "replicated"], default="domain",
                     help="N > 1: domain = particles distributed (x-slab domains, ghost import, slab PM); slab = particles replicated, "
                          "slab PM and slab targets; replicated = everything but the walk targets replicated")
+    ap.add_argument("--sph", default="auto", choices=["auto", "de", "pe"],
+                    help="hydro workload: density-entropy (BASELINE configs[2]) or pressure-entropy SPH (configs[4]); auto: de on one GPU, pe on several")
     ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof"],
                     help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
                          "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
@@ -430,6 +432,7 @@ def hydro_bench(pkg, torch, args, dev):
     + force_tree_calc_moments (hmax) + hydro_force  (run.c:466-548)."""
     n = args.n or 128
     nmesh = 2 * n
+    PE = 1 if args.sph == "pe" else 0
     pos, mass, typ, box = hydro_ics(pkg, n)
     N = len(pos)
     f8 = torch.float64
@@ -442,7 +445,7 @@ def hydro_bench(pkg, torch, args, dev):
     eng.set_gravshort_treepar(TreeUseBH=2)
     eng.gravshort_set_softenings(box / n)
     eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
-    eng.set_hydropar(0, 100.0, 0.75)
+    eng.set_hydropar(PE, 100.0, 0.75)
     eng.dev_bind_particles(d_pos, d_mass, box, type=d_type)
     z1 = lambda: torch.zeros(N, dtype=f8, device=dev)
     z3 = lambda: torch.zeros(N, 3, dtype=f8, device=dev)
@@ -464,7 +467,7 @@ def hydro_bench(pkg, torch, args, dev):
         prev, acc = acc, prev
         eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
         eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
-        eng.dev_density(a, t)
+        eng.dev_density(a, t, DoEgyDensity=PE)
         iters.append(eng.sph_stats()["iterations"])
         eng.dev_force_tree_calc_hmax()
         eng.dev_hydro_force(a, t)
@@ -486,7 +489,7 @@ def hydro_bench(pkg, torch, args, dev):
     ev[1].record()
     eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
     ev[2].record()
-    eng.dev_density(a, t)
+    eng.dev_density(a, t, DoEgyDensity=PE)
     sd = eng.sph_stats()
     ev[3].record()
     eng.dev_force_tree_calc_hmax()
@@ -507,7 +510,7 @@ def hydro_bench(pkg, torch, args, dev):
     out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "2x%d^3 DM+gas TreePM + density-entropy SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, nmesh),
+           "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
                       "particles": N, "density_iterations": iters[-args.steps:]},
            "roofline": roof("k_density", b_dens, ms[2], "one density pass incl. queue set-up and predictions; B_dens = N_tgt*128 + N_cand*28 + "
                             "N_ngb*32 (SURVEY 8(d)): %d targets, %d candidates, %d neighbours" % (sd["targets"], sd["candidates"], sd["interactions"])),
@@ -541,6 +544,7 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
     their owners -> hmax -> hydro_force (own gas)."""
     n = args.n or {2: 160, 4: 200, 8: 256}.get(world, int(round(128 * world ** (1. / 3) / (4 * world))) * 4 * world)
     nmesh = 2 * n
+    PE = 0 if args.sph == "de" else 1                        # configs[4]: pressure-entropy SPH on several GPUs
     pos, mass, typ, box = hydro_ics(pkg, n)
     N = len(pos)
     f8 = dict(dtype=torch.float64, device=dev)
@@ -552,7 +556,7 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
     eng.set_gravshort_treepar(TreeUseBH=2)
     eng.gravshort_set_softenings(box / n)
     eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
-    eng.set_hydropar(0, 100.0, 0.75)
+    eng.set_hydropar(PE, 100.0, 0.75)
     rcut = 6.0 * 1.5 * box / nmesh
     dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut, margin=6.0 * box / n)
     g_pos = torch.from_numpy(pos).to(dev)
@@ -588,7 +592,7 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
                  hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
         eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
         act = torch.nonzero(ltyp[:n_own] == 0).squeeze(1).to(torch.int32).contiguous()
-        eng.dev_density(a, t, active=act)
+        eng.dev_density(a, t, active=act, DoEgyDensity=PE)
         dom.check_hsml_margin(a["hsml"][:n_own])
         for k, g in zip(FIELDS, dom.ghost_update_many([a[k][:n_own] for k in FIELDS])):
             a[k][n_own:] = g
@@ -618,7 +622,7 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
         out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "2x%d^3 DM+gas TreePM + density-entropy SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, nmesh),
+               "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
                           "particles": N, "parallelism": "%d GPUs: particles distributed in x-slab domains with ghost import" % world,
                           "ghost_fraction_rank0": round(keep["ghost_fraction"], 3), "density_iterations_last": keep["it"]}}
     dist.barrier()
