@@ -409,6 +409,25 @@ int mpg_bigfile_write_block(const char *file, const char *block, const char *dty
 int mpg_bigfile_get_attr(const char *file, const char *block, const char *name, const char *want_dtype, void *out, int nmemb);
 int mpg_bigfile_set_attr(const char *file, const char *block, const char *name, const char *dtype, const void *data, int nmemb);
 
+/* ---- matter power spectrum of the PM density field: gravpm_force measures it on every PM step (measure_power_spectrum /
+ * powerspectrum_add_mode, gravpm.c:331-382: |delta_k|^2 with the CIC window removed once, weight 2 off the kz = 0 / Nyquist planes,
+ * Nmesh logarithmic bins) and writes powerspectrum-<a>.txt (powerspectrum_sum / powerspectrum_save, powerspectrum.c:55-122).
+ * The engine accumulates the raw sums during mpg_(dev_)gravpm_force and mpg_dev_pm_slab_forward_b; the neutrino linear-response
+ * correction (gravpm.c:307-327, 415-436) is not carried. */
+int mpg_gravpm_measure_power(mpg_engine *eng, int on);   /* default on, as in the reference */
+/* raw sums of the last PM step into caller device arrays: d_acc[2 Nmesh + 1] = Power[Nmesh], kk[Nmesh], Norm; d_modes[Nmesh].
+ * One process per GPU: sum them over the ranks (the MPI_Allreduce of powerspectrum_sum) before mpg_powerspectrum_sum. */
+int mpg_dev_gravpm_powerspectrum_raw(mpg_engine *eng, double *d_acc, int64_t *d_modes);
+/* powerspectrum_sum (powerspectrum.c:55-91) on host arrays: averages, normalises by Norm, converts to Mpc/h units with BoxSize_in_MPC
+ * and drops empty bins; kk, Power, Nmodes hold nbins entries, *nonzero of which are filled. */
+int mpg_powerspectrum_sum(int nbins, const double *acc, const int64_t *modes, double BoxSize_in_MPC, double *kk, double *Power,
+                          int64_t *Nmodes, int *nonzero);
+/* both steps for one GPU */
+int mpg_gravpm_get_powerspectrum(mpg_engine *eng, double BoxSize_in_MPC, double *kk, double *Power, int64_t *Nmodes, int *nonzero);
+/* powerspectrum_save (powerspectrum.c:93-122): OutputDir/filename-<Time>.txt with the reference's columns "k P N P(z=0)" */
+int mpg_powerspectrum_save(const char *OutputDir, const char *filename, double Time, double D1, int nonzero, const double *kk,
+                           const double *Power, const int64_t *Nmodes);
+
 /* ---- long-range PM over several GPUs, one process per GPU (petapm.c:584-885 exchanges region meshes with 2-D pencils and lets
  * PFFT transpose; here: x-slabs of Nmesh/world planes, two all-to-all transposes per PM step and one neighbour plane).  The
  * engine does the local stages; the caller (one rank per GPU) does the collectives between them on the engine's stream:

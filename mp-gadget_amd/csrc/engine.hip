@@ -773,6 +773,89 @@ int mpg_dev_fof_groups(mpg_engine *eng, const mpg_fof_groups *out)
     API_END
 }
 
+/* ------------------------------ matter power spectrum of the PM step ------------------------------ */
+int mpg_gravpm_measure_power(mpg_engine *eng, int on)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->pm.measure_power = on != 0;
+    API_END
+}
+
+int mpg_dev_gravpm_powerspectrum_raw(mpg_engine *eng, double *d_acc, int64_t *d_modes)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_acc && d_modes, "null argument");
+    MPG_CHECK(eng->pm.nmesh > 0 && eng->pm.ps_valid, "power spectrum: no PM step has been run with the measurement on");
+    MPG_HIP(hipSetDevice(eng->device));
+    const size_t nb = (size_t)eng->pm.nmesh;
+    MPG_HIP(hipMemcpyAsync(d_acc, eng->pm.ps_acc.p, (2 * nb + 1) * sizeof(double), hipMemcpyDeviceToDevice, eng->stream));
+    MPG_HIP(hipMemcpyAsync(d_modes, eng->pm.ps_modes.p, nb * sizeof(int64_t), hipMemcpyDeviceToDevice, eng->stream));
+    API_END
+}
+
+int mpg_powerspectrum_sum(int nbins, const double *acc, const int64_t *modes, double BoxSize_in_MPC, double *kk, double *Power,
+                          int64_t *Nmodes, int *nonzero)
+{
+    API_BEGIN
+    MPG_CHECK(nbins > 0 && acc && modes && kk && Power && Nmodes && nonzero, "null argument");
+    const double Norm = acc[2 * (size_t)nbins];
+    int nz = 0;
+    for(int i = 0; i < nbins; i++) { // powerspectrum.c:75-89
+        if(modes[i] == 0)
+            continue;
+        double P = acc[i] / modes[i];
+        P /= Norm;
+        double k = acc[nbins + i] / modes[i];
+        k *= 2 * M_PI / BoxSize_in_MPC;
+        P *= pow(BoxSize_in_MPC, 3.0);
+        Power[nz] = P;
+        kk[nz] = k;
+        Nmodes[nz] = modes[i];
+        nz++;
+    }
+    *nonzero = nz;
+    API_END
+}
+
+int mpg_gravpm_get_powerspectrum(mpg_engine *eng, double BoxSize_in_MPC, double *kk, double *Power, int64_t *Nmodes, int *nonzero)
+{
+    API_BEGIN
+    MPG_CHECK(eng && kk && Power && Nmodes && nonzero, "null argument");
+    MPG_CHECK(eng->pm.nmesh > 0 && eng->pm.ps_valid, "power spectrum: no PM step has been run with the measurement on");
+    MPG_HIP(hipSetDevice(eng->device));
+    const size_t nb = (size_t)eng->pm.nmesh;
+    std::vector<double> acc(2 * nb + 1);
+    std::vector<int64_t> modes(nb);
+    MPG_HIP(hipMemcpyAsync(acc.data(), eng->pm.ps_acc.p, (2 * nb + 1) * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipMemcpyAsync(modes.data(), eng->pm.ps_modes.p, nb * sizeof(int64_t), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    if(mpg_powerspectrum_sum((int)nb, acc.data(), modes.data(), BoxSize_in_MPC, kk, Power, Nmodes, nonzero) != 0)
+        throw Error(g_err);
+    API_END
+}
+
+int mpg_powerspectrum_save(const char *OutputDir, const char *filename, double Time, double D1, int nonzero, const double *kk,
+                           const double *Power, const int64_t *Nmodes)
+{
+    API_BEGIN
+    MPG_CHECK(OutputDir && filename && kk && Power && Nmodes && nonzero >= 0, "null argument");
+    char fname[4096];
+    if(Time <= 1e-4) // "avoid -0.0000.txt at high z" (powerspectrum.c:101-105)
+        snprintf(fname, sizeof(fname), "%s/%s-%0.4e.txt", OutputDir, filename, Time);
+    else
+        snprintf(fname, sizeof(fname), "%s/%s-%0.4f.txt", OutputDir, filename, Time);
+    FILE *fp = fopen(fname, "w");
+    MPG_CHECK(fp != nullptr, std::string("Could not open ") + fname + " for writing");
+    fprintf(fp, "# in Mpc/h Units \n");
+    fprintf(fp, "# D1 = %g \n", D1);
+    fprintf(fp, "# k P N P(z=0)\n");
+    for(int i = 0; i < nonzero; i++)
+        fprintf(fp, "%g %g %ld %g\n", kk[i], Power[i], (long)Nmodes[i], Power[i] / (D1 * D1));
+    fclose(fp);
+    API_END
+}
+
 /* ------------------------------ snapshot / IC wire format (host IO) ------------------------------ */
 int mpg_bigfile_block_info(const char *file, const char *block, mpg_bigblock_info *info)
 {

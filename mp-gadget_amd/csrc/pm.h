@@ -17,6 +17,12 @@ struct PMesh {
     DevBuf<double> rho_k;   // 2 * Nmesh^2 (Nmesh/2+1): potential in Fourier space after the transfer
     DevBuf<double> work_k;  // same size: per-component work array (Z2D overwrites its input)
     DevBuf<double> invsinc2, difffac;
+    // matter power spectrum of the PM density field (gravpm.c:331-382): raw sums of the last PM step
+    bool measure_power = true, ps_valid = false;
+    DevBuf<double> ps_acc;               // Power[Nmesh], kk[Nmesh], Norm
+    DevBuf<unsigned long long> ps_modes; // Nmodes[Nmesh]
+    void ps_zero(hipStream_t st);
+    size_t ps_lds_bytes() const { return (size_t)nmesh * 3 * sizeof(double); }
 
     // gravpm_init_periodic -> petapm_init (gravpm.c:51-54, petapm.c:105-223)
     void init(double BoxSize, double Asmth, int Nmesh, double G, hipStream_t st);

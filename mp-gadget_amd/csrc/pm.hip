@@ -118,6 +118,70 @@ __global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, int ny, i
     cplx[ip] = v;
 }
 
+// measure_power_spectrum + powerspectrum_add_mode, gravpm.c:331-382: per Fourier cell (before the potential transfer touches
+// it) m = |delta_k|^2 de-convolved with the CIC window once (invwindow^2), weight 2 except on the kz = 0 and Nyquist planes,
+// logarithmic bins in |k| (Nmesh bins up to sqrt(3) Nmesh / 2); the k = 0 mode is the normalisation.  acc = [Power[nbins],
+// kk[nbins], Norm], modes[nbins]; the reference's per-thread copies are per-block LDS histograms here.
+template <bool XLAST>
+__global__ void __launch_bounds__(256) k_power_spectrum(int nmesh, int ny, int y0, const double *__restrict__ invsinc2,
+                                                        const double2 *__restrict__ cplx, double *__restrict__ acc,
+                                                        unsigned long long *__restrict__ modes)
+{
+    extern __shared__ double s_ps[]; // Power[nbins], kk[nbins], then modes[nbins] (u64)
+    const int nbins = nmesh;
+    double *s_pow = s_ps, *s_kk = s_ps + nbins;
+    unsigned long long *s_n = (unsigned long long *)(s_ps + 2 * nbins);
+    for(int b = threadIdx.x; b < nbins; b += blockDim.x) {
+        s_pow[b] = 0;
+        s_kk[b] = 0;
+        s_n[b] = 0;
+    }
+    __syncthreads();
+    const int nz = nmesh / 2 + 1;
+    const size_t total = (size_t)nmesh * ny * nz;
+    const double binsperunit = (nbins - 1) / log(sqrt(3.0) * nmesh / 2.0);
+    for(size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ip < total; ip += (size_t)gridDim.x * blockDim.x) {
+        int ix, iy, iz;
+        if(XLAST) {
+            ix = (int)(ip % nmesh);
+            const size_t j = ip / nmesh;
+            iz = (int)(j % nz);
+            iy = y0 + (int)(j / nz);
+        }
+        else {
+            iz = (int)(ip % nz);
+            const size_t t = ip / nz;
+            iy = y0 + (int)(t % ny);
+            ix = (int)(t / ny);
+        }
+        const int kx = ix <= nmesh / 2 ? ix : ix - nmesh;
+        const int ky = iy <= nmesh / 2 ? iy : iy - nmesh;
+        const int kz = iz;
+        const long long k2 = (long long)kx * kx + (long long)ky * ky + (long long)kz * kz;
+        const double2 v = cplx[ip];
+        const double m = v.x * v.x + v.y * v.y;
+        if(k2 == 0) {
+            acc[2 * nbins] = m; // Norm
+            continue;
+        }
+        const int kint = (int)floor(binsperunit * log((double)k2) / 2.);
+        if(kint >= nbins)
+            continue;
+        const int w = (kz == 0 || kz == nmesh / 2) ? 1 : 2;
+        const double f = invsinc2[ix] * invsinc2[iy] * invsinc2[iz];
+        __hip_atomic_fetch_add(&s_pow[kint], w * m * f * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_kk[kint], w * sqrt((double)k2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_n[kint], (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    for(int b = threadIdx.x; b < nbins; b += blockDim.x)
+        if(s_n[b]) {
+            unsafeAtomicAdd(&acc[b], s_pow[b]);
+            unsafeAtomicAdd(&acc[nbins + b], s_kk[b]);
+            atomicAdd(&modes[b], s_n[b]);
+        }
+}
+
 // force_transfer for one axis, gravpm.c:476-498: (re, im) <- (-im*fac, re*fac), fac = -diff_kernel(k 2pi/N) N/Box.
 // axis < 0: plain copy (the Potential pass has no transfer function, gravpm.c:32-39).
 // The destination element of source (ix, row, iz) is dst[(ix * xmul + xoff) * ny * nz + row * nz + iz]: xmul = 1, xoff = 0 on one
@@ -297,6 +361,15 @@ void PMesh::ensure_single()
     have_plans = true;
 }
 
+void PMesh::ps_zero(hipStream_t st)
+{
+    ps_acc.reserve(2 * (size_t)nmesh + 8);
+    ps_modes.reserve((size_t)nmesh + 8);
+    MPG_HIP(hipMemsetAsync(ps_acc.p, 0, (2 * (size_t)nmesh + 1) * sizeof(double), st));
+    MPG_HIP(hipMemsetAsync(ps_modes.p, 0, (size_t)nmesh * sizeof(unsigned long long), st));
+    ps_valid = true;
+}
+
 void PMesh::destroy()
 {
     if(have_plans) {
@@ -337,6 +410,11 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
     }
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
+    if(measure_power) {
+        ps_zero(st);
+        hipLaunchKernelGGL(k_power_spectrum<false>, dim3(2048), dim3(256), ps_lds_bytes(), st, nmesh, nmesh, 0, invsinc2.p,
+                           (const double2 *)rho_k.p, ps_acc.p, ps_modes.p);
+    }
     hipLaunchKernelGGL(k_potential_transfer<false>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, asmth2, pot_factor, invsinc2.p,
                        (double2 *)rho_k.p);
     if(tm) {
@@ -648,6 +726,11 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
     MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.rho_k.p, (hipfftDoubleComplex *)slab.rho_k.p, HIPFFT_FORWARD));
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
+    if(measure_power) { // this rank's ky rows: the caller sums the raw accumulators over the ranks (powerspectrum_sum's Allreduce)
+        ps_zero(st);
+        hipLaunchKernelGGL(k_power_spectrum<true>, dim3(1024), dim3(256), ps_lds_bytes(), st, nmesh, slab.Py, y0, invsinc2.p,
+                           (const double2 *)slab.rho_k.p, ps_acc.p, ps_modes.p);
+    }
     hipLaunchKernelGGL(k_potential_transfer<true>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, asmth2, pot_factor, invsinc2.p,
                        (double2 *)slab.rho_k.p);
     // only the potential is transformed back: the forces are its real-space differences (k_gradient_axis), which also cuts

@@ -284,6 +284,36 @@ class Engine:
     def gravpm_init_periodic(self, BoxSize, Asmth, Nmesh, G):
         self._ck(self.lib.mpg_gravpm_init_periodic(self.h, C.c_double(BoxSize), C.c_double(Asmth), int(Nmesh), C.c_double(G)))
 
+    # matter power spectrum of the PM step (gravpm.c:331-382, powerspectrum.c)
+    def gravpm_measure_power(self, on=True):
+        self._ck(self.lib.mpg_gravpm_measure_power(self.h, int(bool(on))))
+
+    def gravpm_get_powerspectrum(self, nmesh, BoxSize_in_MPC):
+        """(kk, Power, Nmodes) of the last PM step in Mpc/h units, empty bins dropped (powerspectrum_sum)."""
+        kk, P, N = np.zeros(nmesh), np.zeros(nmesh), np.zeros(nmesh, np.int64)
+        nz = C.c_int(0)
+        self._ck(self.lib.mpg_gravpm_get_powerspectrum(self.h, C.c_double(BoxSize_in_MPC), kk.ctypes.data_as(C.c_void_p),
+                                                       P.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.byref(nz)))
+        return kk[:nz.value], P[:nz.value], N[:nz.value]
+
+    def dev_gravpm_powerspectrum_raw(self, acc, modes):
+        self._ck(self.lib.mpg_dev_gravpm_powerspectrum_raw(self.h, _ptr(acc), _ptr(modes)))
+
+    def powerspectrum_sum(self, acc, modes, BoxSize_in_MPC):
+        """powerspectrum_sum on host arrays acc[2 nbins + 1], modes[nbins] (after the sum over ranks)."""
+        acc, modes = np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(modes, np.int64)
+        nb = len(modes)
+        kk, P, N = np.zeros(nb), np.zeros(nb), np.zeros(nb, np.int64)
+        nz = C.c_int(0)
+        self._ck(self.lib.mpg_powerspectrum_sum(nb, acc.ctypes.data_as(C.c_void_p), modes.ctypes.data_as(C.c_void_p), C.c_double(BoxSize_in_MPC),
+                                                kk.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.byref(nz)))
+        return kk[:nz.value], P[:nz.value], N[:nz.value]
+
+    def powerspectrum_save(self, outdir, filename, Time, D1, kk, P, N):
+        kk, P, N = np.ascontiguousarray(kk, np.float64), np.ascontiguousarray(P, np.float64), np.ascontiguousarray(N, np.int64)
+        self._ck(self.lib.mpg_powerspectrum_save(outdir.encode(), filename.encode(), C.c_double(Time), C.c_double(D1), len(kk),
+                                                 kk.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p)))
+
     def set_particle_epoch(self, epoch):
         """Declare the epoch of the host particle table: host calls with the same non-zero epoch, table address, size and box reuse
         the uploaded positions (include/mpgadget_hip.h)."""

@@ -126,6 +126,17 @@ class SlabPM:
         self._ghost_planes()
         e.dev_pm_slab_readout(self.ghost_recv, targets, gravpm, potential)
 
+    def power_spectrum(self, BoxSize_in_MPC):
+        """(kk, Power, Nmodes) of the last force() call: the raw sums of this rank's Fourier rows, summed over the ranks
+        (the MPI_Allreduce of powerspectrum_sum, powerspectrum.c:68-72), then powerspectrum_sum."""
+        acc = torch.zeros(2 * self.nmesh + 1, dtype=torch.float64, device=self.device)
+        modes = torch.zeros(self.nmesh, dtype=torch.int64, device=self.device)
+        self.eng.dev_gravpm_powerspectrum_raw(acc, modes)
+        if self.world > 1 or FORCE_COLLECTIVES:
+            dist.all_reduce(acc, group=self.group)
+            dist.all_reduce(modes, group=self.group)
+        return self.eng.powerspectrum_sum(acc.cpu().numpy(), modes.cpu().numpy(), BoxSize_in_MPC)
+
     def _ghost_planes(self):
         """ghost_recv <- [first 3 planes of rank+1 | last 2 planes of rank-1] (periodic): the force stencil reaches two planes
         either way and the CIC readout one plane up.  One personalised exchange (both neighbours may be the same rank, or this

@@ -288,6 +288,38 @@ def gravpm_force(pos, mass, box, nmesh, Asmth=1.5, G=43.0071, want_potential=Tru
     return out, potential
 
 
+def pm_power_spectrum(pos, mass, box, nmesh, BoxSize_in_MPC):
+    """The matter power spectrum gravpm_force measures on the PM mesh: measure_power_spectrum + powerspectrum_add_mode
+    (gravpm.c:331-382) per Fourier cell, then powerspectrum_sum (powerspectrum.c:55-91).  Returns (kk, Power, Nmodes) with empty
+    bins dropped, kk in h/Mpc, Power in (Mpc/h)^3."""
+    rho_k = np.fft.rfftn(pm_cic_deposit(np.asarray(pos, np.float64), np.asarray(mass), box, nmesh))
+    kx = np.fft.fftfreq(nmesh, 1.0 / nmesh).astype(np.int64)
+    kx[nmesh // 2] = nmesh // 2
+    kz = np.arange(nmesh // 2 + 1, dtype=np.int64)
+    KX, KY, KZ = np.broadcast_arrays(kx[:, None, None], kx[None, :, None], kz[None, None, :])
+    k2 = KX * KX + KY * KY + KZ * KZ
+    f = np.ones(k2.shape)
+    for K in (KX, KY, KZ):
+        t = _sinc_unnormed(K * np.pi / nmesh)
+        f = f * (1.0 / (t * t))
+    m = rho_k.real ** 2 + rho_k.imag ** 2
+    norm = m[0, 0, 0]                                                  # the k = 0 mode
+    size = nmesh                                                       # powerspectrum_alloc(pm->ps, pm->Nmesh, ...), gravpm.c:207
+    binsperunit = (size - 1) / np.log(np.sqrt(3) * nmesh / 2.0)
+    sel = k2 > 0
+    kint = np.floor(binsperunit * np.log(k2[sel].astype(np.float64)) / 2.).astype(np.int64)
+    w = np.where((KZ[sel] == 0) | (KZ[sel] == nmesh // 2), 1, 2)
+    ok = kint < size
+    kint, w = kint[ok], w[ok]
+    power = np.bincount(kint, weights=(w * m[sel][ok] * f[sel][ok] ** 2), minlength=size)
+    kk = np.bincount(kint, weights=w * np.sqrt(k2[sel][ok].astype(np.float64)), minlength=size)
+    nmodes = np.bincount(kint, weights=w, minlength=size).astype(np.int64)
+    nz = nmodes > 0
+    P = power[nz] / nmodes[nz] / norm * BoxSize_in_MPC ** 3
+    K = kk[nz] / nmodes[nz] * 2 * np.pi / BoxSize_in_MPC
+    return K, P, nmodes[nz]
+
+
 # ------------------------------------------------------------------------------------------
 # SPH oracle (sph_oracle.c): densitykernel.c / density.c / hydra.c restated
 # ------------------------------------------------------------------------------------------

@@ -341,6 +341,8 @@ def test_two_ranks_match_one(tmp_path):
     for name, nproc, mode, port in (("slab1.npy", 1, "slab1", 0), ("slab2.npy", 2, "slab", 29578), ("slab4.npy", 4, "slab", 29579)):
         sl = _run_mgpu(tmp_path, name, nproc, mode, port)
         assert np.array_equal(one[:, 0:3], sl[:, 0:3]), name
+        ps1, psn = np.load(str(tmp_path / "one.npy") + ".ps.npy"), np.load(str(tmp_path / name) + ".ps.npy")
+        assert np.array_equal(ps1[:, 2], psn[:, 2]) and np.allclose(psn[:, :2], ps1[:, :2], rtol=1e-9), name   # P(k) summed over the ranks
         gpm = np.abs(one[:, 3:6]).mean()
         assert np.abs(sl[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * gpm, name
         assert np.abs(sl[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
@@ -511,3 +513,34 @@ def test_host_path_particle_epoch(pkg, engine):
     engine.set_particle_epoch(0)
     g3, a3 = step()
     assert same(g3, g2)
+
+
+def test_pm_power_spectrum(pkg, engine, tmp_path):
+    """The matter power spectrum measured during gravpm_force (gravpm.c:331-382, powerspectrum.c:55-122) against the numpy
+    restatement: mode counts equal, k and P(k) to rounding; the saved file has the reference's columns."""
+    import torch
+    n, nmesh = 24, 48
+    pos, mass, box = pkg.ics.s_zel(n)
+    setup_engine(engine, box, n, nmesh)
+    mpc = box / 1000.0
+    d_pos, d_mass = torch.from_numpy(pos).cuda(), torch.from_numpy(mass).cuda()
+    gpm = torch.zeros(len(pos), 3, dtype=torch.float64, device="cuda")
+    engine.dev_bind_particles(d_pos, d_mass, box)
+    engine.dev_gravpm_force(gpm, None)
+    k, P, N = engine.gravpm_get_powerspectrum(nmesh, mpc)
+    ko, Po, No = O.pm_power_spectrum(pos, mass, box, nmesh, mpc)
+    assert np.array_equal(N, No) and N.sum() == nmesh ** 3 - 1                              # every mode but k = 0, weights included
+    assert np.allclose(k, ko, rtol=1e-12) and np.allclose(P, Po, rtol=1e-9)
+    assert len(k) > 20 and np.all(np.diff(k) > 0)
+    engine.powerspectrum_save(str(tmp_path), "powerspectrum", 0.1, 0.5, k, P, N)
+    lines = open(tmp_path / "powerspectrum-0.1000.txt").read().split("\n")
+    assert lines[0] == "# in Mpc/h Units " and lines[2] == "# k P N P(z=0)"
+    row = lines[3].split()
+    assert abs(float(row[0]) / k[0] - 1) < 1e-5 and int(row[2]) == N[0] and abs(float(row[3]) / (P[0] / 0.25) - 1) < 1e-5
+    # the measurement can be switched off; the forces do not depend on it
+    g1 = gpm.cpu().numpy().copy()
+    engine.gravpm_measure_power(False)
+    engine.dev_gravpm_force(gpm, None)
+    engine.gravpm_measure_power(True)
+    engine.synchronize()
+    assert np.abs(gpm.cpu().numpy() - g1).max() <= 1e-10 * np.abs(g1).max()

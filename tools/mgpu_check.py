@@ -85,8 +85,15 @@ else:
     both = torch.cat([acc, gravpm, pot[:, None]], dim=1)
     ex.exchange(both, tg)
     acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
+# the matter power spectrum measured on the way (gravpm.c:331-382): rows of (k, P, Nmodes)
+mpc = box / 1000.0
+if world == 1 and mode != "slab1" or mode == "replicated":
+    ps = eng.gravpm_get_powerspectrum(2 * n, mpc)
+else:
+    ps = spm.power_spectrum(mpc)
 torch.cuda.synchronize()
 if rank == 0:
+    np.save(out + ".ps.npy", np.stack([ps[0], ps[1], ps[2].astype(np.float64)], axis=1))
     np.save(out, np.concatenate([acc.cpu().numpy(), gravpm.cpu().numpy(), pot.cpu().numpy()[:, None]], axis=1))
 if grouped:
     dist.barrier()
