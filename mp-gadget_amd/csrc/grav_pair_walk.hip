@@ -56,19 +56,19 @@ __global__ void __launch_bounds__(256) k_grav_short_pair(const TreeView tv, cons
         int nl = 0;
         for(;;) { // phase A: walk; opened leaves go to the group's list
             const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
-            if(__ballot(go) == 0)
+            if(ballot64(go) == 0)
                 break;
             int lps, lpc;
             const unsigned gm = walk_step<false>(tv, stack, sp, go, s, gshift, rcut_abs, px, py, pz, lps, lpc, overflow);
             nl = llist_push(llist, nl, gm, lps, lpc, s);
-            if(__ballot(overflow) != 0)
+            if(ballot64(overflow) != 0)
                 break;
         }
-        if(__ballot(overflow) != 0)
+        if(ballot64(overflow) != 0)
             break;
         for(int it = 0;; it++) { // phase B: every group takes its next leaf; lane s <-> particle s
             const bool has = it < nl;
-            if(__ballot(has) == 0)
+            if(ballot64(has) == 0)
                 break;
             const unsigned e = has ? llist[it] : 0u;
             const int ps = (int)(e >> 4), pc = (int)(e & 15u);
@@ -82,10 +82,10 @@ __global__ void __launch_bounds__(256) k_grav_short_pair(const TreeView tv, cons
                     pair_force<POT>(o, -d0, -d1, -d2, gp, s_wf, s_wp, ax, ay, az, pot);
             }
         }
-        if(__ballot(sp > 0) == 0)
+        if(ballot64(sp > 0) == 0)
             break;
     }
-    if(__ballot(overflow) != 0) {
+    if(ballot64(overflow) != 0) {
         if(lane == 0)
             atomicExch(err, 1u);
         return;

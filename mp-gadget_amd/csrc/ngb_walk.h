@@ -7,6 +7,10 @@ namespace mpg {
 
 #define FACT1 0.366025403785      // treewalk.c:19
 
+// wave-wide ballot of a predicate.  (HIP's ballot64(int) compares an integer with zero: a boolean that exists only as a lane mask is
+// first materialised as 0 / 1 in a VGPR and compared again - two vector instructions per ballot that this form does not need.)
+__device__ __forceinline__ unsigned long long ballot64(const bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 __device__ __forceinline__ double nearest_img(double x, double box, double invbox) { return x - box * rint(x * invbox); }
 
 // cull_node, treewalk.c:1015-1042 (hm = 0: asymmetric search radius Hsml; symmetric: max(node hmax, Hsml))
@@ -88,8 +92,8 @@ __device__ __forceinline__ unsigned walk_step(const TreeView &tv, unsigned *stac
             }
         }
     }
-    const unsigned gm_leaf = (unsigned)((__ballot(act == 1) >> gshift) & 0xffull);
-    const unsigned gm_push = (unsigned)((__ballot(act == 3) >> gshift) & 0xffull);
+    const unsigned gm_leaf = (unsigned)((ballot64(act == 1) >> gshift) & 0xffull);
+    const unsigned gm_push = (unsigned)((ballot64(act == 3) >> gshift) & 0xffull);
     const unsigned below = (1u << s) - 1u;
     if(can && sp - 1 + __popc(gm_push) > SPH_STK)
         overflow = true;

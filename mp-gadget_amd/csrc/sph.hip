@@ -215,7 +215,7 @@ __device__ __forceinline__ void density_eval(const Src4 s, const Aux4 o, const d
 // appends this lane's survivor (if any) to the group's buffer; returns the new (group-uniform) fill level
 __device__ __forceinline__ int cbuf_push(int *cbuf, int cnt, const bool keep, const int sidx, const int s, const int gshift)
 {
-    const unsigned gm = (unsigned)((__ballot(keep) >> gshift) & 0xffull);
+    const unsigned gm = (unsigned)((ballot64(keep) >> gshift) & 0xffull);
     if(keep)
         cbuf[cnt + __popc(gm & ((1u << s) - 1u))] = sidx;
     return cnt + __popc(gm);
@@ -293,20 +293,20 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         int nl = 0;
         for(;;) {
             const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
-            if(__ballot(go) == 0)
+            if(ballot64(go) == 0)
                 break;
             int lps, lpc;
             const unsigned gm = walk_step<false>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, lps, lpc, overflow);
             nl = llist_push(llist, nl, gm, lps, lpc, s);
-            if(__ballot(overflow) != 0)
+            if(ballot64(overflow) != 0)
                 break;
         }
-        if(__ballot(overflow) != 0)
+        if(ballot64(overflow) != 0)
             break;
         // ---- phase B: every group takes its next leaf; lane s <-> particle s
         for(int it = 0;; it++) {
             const bool has = it < nl;
-            if(__ballot(has) == 0)
+            if(ballot64(has) == 0)
                 break;
             const unsigned e = has ? llist[it] : 0u;
             const int ps = (int)(e >> 4), pc = (int)(e & 15u);
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                 keep = density_test(tv.src[ps + s], px, py, pz, h2, kern.HH, tv.box, n_int);
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
-            if(__ballot(cnt >= 16) != 0) {
+            if(ballot64(cnt >= 16) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[s];
                     density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
@@ -324,15 +324,15 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                 }
             }
         }
-        if(__ballot(sp > 0) == 0)
+        if(ballot64(sp > 0) == 0)
             break;
     }
-    if(__ballot(overflow) != 0) {
+    if(ballot64(overflow) != 0) {
         if(lane == 0)
             atomicExch(err, 1u);
         return;
     }
-    while(__ballot(cnt > 0) != 0) { // drain the survivor buffers
+    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
         if(s < cnt) {
             const int sidx = cbuf[s];
             density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
     }
     // wave-aggregated append of the unfinished targets (one atomic per wave)
     {
-        const unsigned long long m = __ballot(notdone);
+        const unsigned long long m = ballot64(notdone);
         if(m != 0) {
             unsigned basepos = 0;
             const int leader = __ffsll((long long)m) - 1;
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) k_queue_treeorder(int64_t npart, const in
     const int ty = (act && A.type) ? (A.type[i] & 7) : 0;
     const bool work = act && (ty == 0 || (!gas_only && ty == 5)); // density_haswork (density.c:521-530) / hydro_haswork
     // wave-aggregated append: one atomic per wave (same-address atomics serialise)
-    const unsigned long long m = __ballot(work);
+    const unsigned long long m = ballot64(work);
     unsigned basepos = 0;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
@@ -750,20 +750,20 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
         int nl = 0;
         for(;;) {
             const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
-            if(__ballot(go) == 0)
+            if(ballot64(go) == 0)
                 break;
             int lps, lpc;
             const unsigned gm = walk_step<true>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, lps, lpc, overflow);
             nl = llist_push(llist, nl, gm, lps, lpc, s);
-            if(__ballot(overflow) != 0)
+            if(ballot64(overflow) != 0)
                 break;
         }
-        if(__ballot(overflow) != 0)
+        if(ballot64(overflow) != 0)
             break;
         // ---- phase B: every group takes its next leaf; lane s <-> particle s
         for(int it = 0;; it++) {
             const bool has = it < nl;
-            if(__ballot(has) == 0)
+            if(ballot64(has) == 0)
                 break;
             const unsigned e = has ? llist[it] : 0u;
             const int ps = (int)(e >> 4), pc = (int)(e & 15u);
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
                 n_pair += keep ? 1u : 0u;
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
-            if(__ballot(cnt >= 16) != 0) {
+            if(ballot64(cnt >= 16) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[s];
                     hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
@@ -782,15 +782,15 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
                 }
             }
         }
-        if(__ballot(sp > 0) == 0)
+        if(ballot64(sp > 0) == 0)
             break;
     }
-    if(__ballot(overflow) != 0) {
+    if(ballot64(overflow) != 0) {
         if(lane == 0)
             atomicExch(err, 1u);
         return;
     }
-    while(__ballot(cnt > 0) != 0) { // drain the survivor buffers
+    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
         if(s < cnt) {
             const int sidx = cbuf[s];
             hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
