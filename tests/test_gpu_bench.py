@@ -42,3 +42,7 @@ def test_other_workloads():
     assert KEYS <= set(h) and "roofline_hydro" in h
     i = run_bench(["--workload", "integrate", "--size", "64", "--steps", "2", "--warmup", "1"])
     assert KEYS <= set(i) and i["roofline"]["frac"] > 0.05
+    f = run_bench(["--workload", "fof", "--size", "64", "--steps", "1", "--warmup", "0"])
+    assert KEYS <= set(f) and f["config"]["groups"] > 0 and f["config"]["particles_in_groups"] > 0
+    p = run_bench(["--workload", "hydro", "--sph", "pe", "--size", "32", "--steps", "1", "--warmup", "0"])
+    assert KEYS <= set(p) and "pressure-entropy" in p["config"]["workload"]

@@ -18,7 +18,8 @@ def clumps(total, mmin, mmax):
     return torch.cat(parts)
 sets = {"uniform": lambda: torch.rand(N, 3, dtype=f8, device=dev, generator=g) * box,
         "clumps 20..20000": lambda: clumps(N, 20, 20000),
-        "clumps 20..200": lambda: clumps(N, 20, 200)}
+        "clumps 20..200": lambda: clumps(N, 20, 200),
+        "4 clumps of 1M + uniform": lambda: torch.cat([clumps(4 << 20, 1 << 20, (1 << 20) + 1), torch.rand(N - (4 << 20), 3, dtype=f8, device=dev, generator=g) * box])}
 eng = pkg.Engine(0); eng.use_torch_stream()
 for name, mk in sets.items():
     pos = mk().contiguous(); pos.clamp_(min=1e-9)
