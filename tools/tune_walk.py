@@ -51,4 +51,6 @@ for variant, thr in [(v, 16 if v == 1 else 512) for v in VARIANTS]:
         s = "A: %.1f steps/target, %.2f nodes/step; B: %.1f steps/target, lane util %.2f" % (c["node_steps"] / N, c["node_lanes"] / c["node_steps"], c["int_steps"] / 8.0 / N, c["int_lanes"] / c["int_steps"])
         s += "  cycles/step A %.0f B %.0f" % (c["cycles_a"] / max(c["node_steps"], 1) * 8, c["cycles_b"] / max(c["int_steps"] / 8, 1) * 8)
         s += "  tree ms %s" % {k: round(v, 2) for k, v in eng.phase_times().items() if k.startswith("tree")}
+    if variant == 6:
+        print("   kernel-6 state (variant, list capacity, targets handed to the fallback):", eng.walk_choice(), "of", N, flush=True)
     print("n=%d %s variant %d thr %2d: %.2f ms  pp/N %.1f nodes/N %.1f used/N %.2f  maxrel vs v1 %.1e  %s" % (n, ic, variant, thr, ms / k, c["pp"] / N, c["nodes_visited"] / N, c["nodes_used"] / N, d.max(), s), flush=True)
