@@ -8,6 +8,9 @@
  *   grav_short_tree, gravshort_fill_ntab, gravshort_set_softenings, set_gravshort_treepar, FORCE_SOFTENING,
  *   density, hydro_force
  * to this library.  No torch / C++ types appear in any signature.
+ * Around that path: drift / kicks / gravity time bins and the hierarchical gravity level loop, Peano-Hilbert keys
+ * and the (type, key) particle order, friends-of-friends groups, the matter power spectrum of the PM step, and the snapshot / IC
+ * wire format - each section below cites what it replaces.
  *
  * Conventions
  *   - every call returns 0 on success, non-zero on failure; mpg_last_error() gives the message
