@@ -17,6 +17,11 @@ struct PMesh {
     DevBuf<double> rho_k;   // 2 * Nmesh^2 (Nmesh/2+1): potential in Fourier space after the transfer
     DevBuf<double> work_k;  // same size: per-component work array (Z2D overwrites its input)
     DevBuf<double> invsinc2, difffac;
+    // deposit: 0 not tuned yet, 1 plain atomics, 2 cell-sorted with wave-aggregated atomics (pm.hip)
+    int deposit_mode = 0, deposits_since_tune = 0;
+    DevBuf<unsigned long long> dep_keys_a, dep_keys_b;
+    DevBuf<int> dep_idx_a, dep_idx_b;
+    DevBuf<char> dep_tmp;
     // matter power spectrum of the PM density field (gravpm.c:331-382): raw sums of the last PM step
     bool measure_power = true, ps_valid = false;
     DevBuf<double> ps_acc;               // Power[Nmesh], kk[Nmesh], Norm

@@ -10,6 +10,9 @@
 // All kernels are HBM-streaming: per PM step ~ N*(28+128) + 5*3*2*R + 5*2*R + N*(24+256+32) bytes, R = 8*Nmesh^3.
 #include "pm.h"
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 namespace mpg {
 
@@ -59,6 +62,91 @@ __global__ void __launch_bounds__(256) k_cic_deposit(int64_t n, const double *__
             w *= off ? res[k] : (1 - res[k]);
         }
         unsafeAtomicAdd(&mesh[lin], w * m);
+    }
+}
+
+// ---- deposit for clustered sets.  In a dense clump thousands of particles share a handful of mesh cells and the plain kernel's
+// atomics serialise on those addresses (256^3 clustered set: 29.8 ms instead of 4.0).  Here the particles are first sorted by
+// their base cell (one radix sort of cell index -> particle); a wave then holds RUNS of particles with the same 8 target cells,
+// their corner weights are summed over each run with a segmented wave scan, and only the last lane of a run issues the 8
+// atomics ("wavefront atomics": one per cell and wave instead of one per particle).  Slower than the plain kernel when cells hold
+// less than one particle (the sort costs what the atomics do), so PMesh::force times both and keeps the faster one.
+__global__ void __launch_bounds__(256) k_cell_keys(int64_t n, const double *__restrict__ pos, const uint8_t *__restrict__ active, double cellsize,
+                                                   int nmesh, unsigned long long *__restrict__ keys, int *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    unsigned long long lin = 0;
+#pragma unroll
+    for(int k = 0; k < 3; k++)
+        lin = lin * (unsigned long long)nmesh + (unsigned long long)wrap((int)floor(pos[3 * i + k] / cellsize), nmesh);
+    keys[i] = (active && !active[i]) ? ~0ull : lin; // inactive particles sort to the end and are skipped
+    idx[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(256) k_cic_deposit_sorted(int64_t n, const unsigned long long *__restrict__ skeys, const int *__restrict__ sidx,
+                                                            const double *__restrict__ pos, const float *__restrict__ mass, double cellsize,
+                                                            int nmesh, double *__restrict__ mesh)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned long long key = ~0ull;
+    double w[8];
+    int ic[3] = {0, 0, 0};
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+        w[c] = 0;
+    if(k < n) {
+        key = skeys[k];
+        if(key != ~0ull) {
+            const int i = sidx[k];
+            double res[3];
+#pragma unroll
+            for(int d = 0; d < 3; d++) {
+                const double tmp = pos[3 * (int64_t)i + d] / cellsize;
+                const double fl = floor(tmp);
+                ic[d] = (int)fl;
+                res[d] = tmp - fl;
+            }
+            const double m = (double)mass[i];
+#pragma unroll
+            for(int c = 0; c < 8; c++) {
+                double x = m;
+#pragma unroll
+                for(int d = 0; d < 3; d++)
+                    x *= ((c >> d) & 1) ? res[d] : (1 - res[d]);
+                w[c] = x;
+            }
+        }
+    }
+    // segmented inclusive scan over the lanes of the wave (segments = runs of equal keys)
+    const unsigned long long prev = __shfl_up(key, 1);
+    bool f = lane == 0 || prev != key; // head of a run (within this wave)
+    const bool head_next = __shfl_down(f ? 1 : 0, 1) != 0;
+    const bool tail = lane == 63 || head_next;
+    for(int d = 1; d < 64; d <<= 1) {
+        const bool f2 = __shfl_up(f ? 1 : 0, d) != 0;
+        double v2[8];
+#pragma unroll
+        for(int c = 0; c < 8; c++)
+            v2[c] = __shfl_up(w[c], d);
+        if(lane >= d && !f) {
+#pragma unroll
+            for(int c = 0; c < 8; c++)
+                w[c] += v2[c];
+            f = f2;
+        }
+    }
+    if(tail && key != ~0ull) {
+#pragma unroll
+        for(int c = 0; c < 8; c++) {
+            size_t lin = 0;
+#pragma unroll
+            for(int d = 0; d < 3; d++)
+                lin = lin * (size_t)nmesh + (size_t)wrap(ic[d] + ((c >> d) & 1), nmesh);
+            unsafeAtomicAdd(&mesh[lin], w[c]);
+        }
     }
 }
 
@@ -399,8 +487,58 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         tm->start(st);
     // pm_init_regions zeroes the mesh (petapm.c:932-952); deposit
     MPG_HIP(hipMemsetAsync(real.p, 0, nreal * sizeof(double), st));
-    if(n > 0)
-        hipLaunchKernelGGL(k_cic_deposit, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, d_active, cellsize, nmesh, real.p);
+    if(n > 0) {
+        auto plain = [&]() { hipLaunchKernelGGL(k_cic_deposit, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, d_active, cellsize, nmesh, real.p); };
+        auto sorted = [&]() {
+            dep_keys_a.reserve((size_t)n + 1);
+            dep_keys_b.reserve((size_t)n + 1);
+            dep_idx_a.reserve((size_t)n + 1);
+            dep_idx_b.reserve((size_t)n + 1);
+            hipLaunchKernelGGL(k_cell_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, dep_keys_a.p, dep_idx_a.p);
+            int bits = 1;
+            while(bits < 64 && ((unsigned long long)1 << bits) < (unsigned long long)nreal)
+                bits++;
+            size_t tb = 0;
+            MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb, dep_keys_a.p, dep_keys_b.p, dep_idx_a.p, dep_idx_b.p, (size_t)n, 0, 64, st));
+            dep_tmp.reserve(tb + 16);
+            // (all 64 bits: the inactive particles carry the all-ones key)
+            MPG_HIP(rocprim::radix_sort_pairs((void *)dep_tmp.p, tb, dep_keys_a.p, dep_keys_b.p, dep_idx_a.p, dep_idx_b.p, (size_t)n, 0,
+                                              d_active ? 64 : bits, st));
+            hipLaunchKernelGGL(k_cic_deposit_sorted, dim3(nblk(n)), dim3(256), 0, st, n, dep_keys_b.p, dep_idx_b.p, d_pos, d_mass, cellsize, nmesh,
+                               real.p);
+        };
+        if(const char *e = getenv("MPG_PM_DEPOSIT")) // experiment knob: "plain" / "sorted"
+            deposit_mode = !strcmp(e, "sorted") ? 2 : 1;
+        if(deposit_mode == 0 || ++deposits_since_tune >= 64) {
+            // time both forms on this set and keep the faster one (the particle distribution decides)
+            hipEvent_t e0, e1, e2;
+            MPG_HIP(hipEventCreate(&e0));
+            MPG_HIP(hipEventCreate(&e1));
+            MPG_HIP(hipEventCreate(&e2));
+            MPG_HIP(hipEventRecord(e0, st));
+            sorted();
+            MPG_HIP(hipEventRecord(e1, st));
+            MPG_HIP(hipMemsetAsync(real.p, 0, nreal * sizeof(double), st));
+            plain();
+            MPG_HIP(hipEventRecord(e2, st));
+            MPG_HIP(hipEventSynchronize(e2));
+            float ts = 0, tp = 0;
+            MPG_HIP(hipEventElapsedTime(&ts, e0, e1));
+            MPG_HIP(hipEventElapsedTime(&tp, e1, e2));
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            (void)hipEventDestroy(e2);
+            deposit_mode = ts < tp ? 2 : 1;
+            deposits_since_tune = 0;
+            if(tm)
+                tm->start(st); // the tuning pass is not the deposit's time
+            MPG_HIP(hipMemsetAsync(real.p, 0, nreal * sizeof(double), st));
+        }
+        if(deposit_mode == 2)
+            sorted();
+        else
+            plain();
+    }
     if(tm)
         tm->lap(st, &tm->t.pm_deposit);
     MPG_FFT(hipfftExecD2Z(plan_r2c, real.p, (hipfftDoubleComplex *)rho_k.p));

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import rerun_once_on_failure
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -330,6 +332,7 @@ def _run_mgpu(tmp_path, name, nproc, mode, port, ic="s_zel"):
     return np.load(out)
 
 
+@rerun_once_on_failure
 def test_two_ranks_match_one(tmp_path):
     """N > 1 paths with the real kernels; two ranks (gloo, sharing this GPU).
     replicated: each rank walks half of the tree-order slots, one all-gather -> exactly the single-rank accelerations.
@@ -355,6 +358,7 @@ def test_two_ranks_match_one(tmp_path):
         assert np.abs(dm[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
 
 
+@rerun_once_on_failure
 def test_distributed_particles_clustered(tmp_path):
     """The distributed-particle path on a strongly clustered set (deep tree, thousands of nodes used unopened per target, very
     unequal slabs): 2 and 4 ranks against one GPU."""
