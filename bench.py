@@ -229,7 +229,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step()          # set-up, not a step: first-use allocations, FFT plans, the walk auto-tuner's trial runs (engine.hip)
+    step()          # set-up, not a step: first-use allocations, FFT plans, the list-capacity adaptation of the walk and the deposit's timing trial (engine.hip, pm.hip)
     for _ in range(args.warmup):
         step()
     sync()

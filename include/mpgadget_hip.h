@@ -483,7 +483,7 @@ int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
 int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave);
 int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
 int mpg_set_walk_variant(mpg_engine *eng, int variant);
-/* kernel in use (the explicit variant, or the auto-tuner's pick; 0 = not tuned yet), kernel 6's current list capacity and
+/* kernel in use (the explicit variant, or the default policy's pick: 6 for >= 65536 targets, else 1; 0 = no walk yet), kernel 6's current list capacity and
  * the number of targets its last walk handed to the fallback kernel (either output may be NULL) */
 int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsigned *last_overflow);
 

@@ -97,10 +97,10 @@ struct mpg_engine {
     EventTimer timer;
     bool count = false;
     int walk_thresh = 16;
-    // 1: lane-per-target while-while kernel (grav_walk.hip); 4: group-cooperative list kernel (grav_walk_coop.hip);
-    // 0: time both on the next walk and keep the faster one (the particle distribution decides: profiles/)
+    // 1: lane-per-target while-while kernel (grav_walk.hip); 4: group-cooperative list kernel (grav_walk_coop.hip); 6: two-kernel walk
+    // (grav_walk_split.hip); 0: 6 for large target sets, 1 for small ones
     int walk_variant = 0;
-    int walk_choice = 0; // variant picked by the auto-tuner (0 = not tuned yet)
+    int walk_choice = 0; // the kernel the default policy used last (0: no walk yet)
     int walks_since_tune = 0;
     WalkScratch w3;
     DevBuf<unsigned long long> counters;
@@ -521,59 +521,29 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     // node: Rcut + 1.5 * (largest leaf side) < Box/2, and Rcut well below Box/4 (see grav_walk_coop.hip)
     const double maxleaf = 1.001 * gp.box / (double)(1 << eng->tree.minleaflevel);
     const bool fastwrap = !getenv("MPG_NO_FASTWRAP") && (gp.rcut + 1.5 * maxleaf < 0.49 * gp.box) && (gp.rcut < 0.2 * gp.box);
-    auto run_variant = [&](int v) {
+    auto run_variant_io = [&](int v, const WalkIO &w) {
         if(v != 1)
             eng->tree.ensure_level_order(eng->stream); // variants 4 and 5 walk the level-ordered copy of the tree
         if(v == 1)
-            launch_grav_walk(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
+            launch_grav_walk(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
         else if(v == 6)
-            launch_grav_walk_split(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->w3, eng->stream);
+            launch_grav_walk_split(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->w3, eng->stream);
         else if(v == 5)
-            launch_grav_walk_shared(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, eng->w3, eng->stream);
+            launch_grav_walk_shared(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, eng->w3, eng->stream);
         else
-            launch_grav_walk_coop(eng->tree.view(), gp, io, io.potential != nullptr, eng->count, fastwrap, eng->w3, eng->stream);
+            launch_grav_walk_coop(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->w3, eng->stream);
     };
+    auto run_variant = [&](int v) { run_variant_io(v, io); };
     int variant = eng->walk_variant;
     if(variant == 0) {
-        // auto: all kernels compute the same interaction sets; time kernels 1, 4 and 6 once and keep the fastest.  Re-tuned every 64
-        // walks, and only on walks large enough for the timing to mean something.
-        if(eng->walk_choice == 0 || (eng->walks_since_tune >= 64 && io.ntargets >= 65536)) {
-            if(io.ntargets < 65536)
-                variant = 1;
-            else {
-                // untimed runs first: first use allocates the list areas, and kernel 6 adapts its list capacity
-                run_variant(4);
-                run_variant(6);
-                run_variant(6);
-                const int cand[3] = {1, 4, 6};
-                hipEvent_t ev4[4];
-                for(auto &e : ev4)
-                    MPG_HIP(hipEventCreate(&e));
-                MPG_HIP(hipEventRecord(ev4[0], eng->stream));
-                for(int i = 0; i < 3; i++) {
-                    run_variant(cand[i]);
-                    MPG_HIP(hipEventRecord(ev4[i + 1], eng->stream));
-                }
-                MPG_HIP(hipEventSynchronize(ev4[3]));
-                float best = 0;
-                for(int i = 0; i < 3; i++) {
-                    float t = 0;
-                    MPG_HIP(hipEventElapsedTime(&t, ev4[i], ev4[i + 1]));
-                    if(i == 0 || t < best) {
-                        best = t;
-                        eng->walk_choice = cand[i];
-                    }
-                }
-                for(auto &e : ev4)
-                    (void)hipEventDestroy(e);
-                eng->walks_since_tune = 0;
-                if(walk_coop_error(eng->w3, eng->stream) != 0)
-                    eng->walk_choice = 1;
-                variant = -1; // results are already in place (the second run overwrote the first with equal values)
-            }
-        }
-        else
-            variant = eng->walk_choice;
+        // Default: the two-kernel walk (6) with the cooperative kernel (4) for the targets whose lists overflow; the lane-per-target
+        // kernel (1) for small target sets, where launch count matters more than lane use.  (This used to be decided by timing
+        // kernels 1, 4 and 6 on the first walk and every 64th.  On the measured sets - grid, Zel'dovich, clustered, 96^3 .. 256^3 -
+        // kernel 6 now always wins, and the trial itself is unaffordable on clustered sets: 6.7 s for kernel 1 and 2 s for kernel 4
+        // against 0.18 s for kernel 6 at 256^3; timing a sample of the targets instead misjudges kernel 6, whose fixed costs -
+        // slices, two streams, the control-word read-back - weigh on a small sample.)
+        variant = io.ntargets >= 65536 ? 6 : 1;
+        eng->walk_choice = variant;
         eng->walks_since_tune++;
     }
     if(variant > 0)
