@@ -735,8 +735,11 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
             launch_grav_walk_coop(tv, gp, io2, want_pot, count, fastwrap, ws, st);
             MPG_CHECK(walk_coop_error(ws, st) == 0, "short-range walk (fallback for long lists) aborted by its loop guard");
         }
-        if((int64_t)ctl[0] * 50 > io.ntargets && ws.split_cap < 8192)
+        if((int64_t)ctl[0] * 50 > io.ntargets && ws.split_cap < 8192) {
             ws.split_cap *= 2; // more than 2 % of the targets overflowed: give the next walk longer lists
+            if((int64_t)ctl[0] * 5 > io.ntargets && ws.split_cap < 8192)
+                ws.split_cap *= 2; // ... much longer if it was more than 20 % (a clustered set: the fallback is what costs then)
+        }
     }
 }
 
