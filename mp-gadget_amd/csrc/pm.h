@@ -18,7 +18,11 @@ struct PMesh {
     DevBuf<double> work_k;  // same size: per-component work array (Z2D overwrites its input)
     DevBuf<double> invsinc2, difffac;
     // deposit: 0 not tuned yet, 1 plain atomics, 2 cell-sorted with wave-aggregated atomics (pm.hip)
-    int deposit_mode = 0, deposits_since_tune = 0;
+    struct DepositState {
+        int mode = 0, since_tune = 0;
+    } dep_single, dep_slab;
+    void deposit(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_active, double *mesh, int x0, int P, DepositState &ds,
+                 hipStream_t st, EventTimer *tm);
     DevBuf<unsigned long long> dep_keys_a, dep_keys_b;
     DevBuf<int> dep_idx_a, dep_idx_b;
     DevBuf<char> dep_tmp;

@@ -87,8 +87,9 @@ __global__ void __launch_bounds__(256) k_cell_keys(int64_t n, const double *__re
 
 __global__ void __launch_bounds__(256) k_cic_deposit_sorted(int64_t n, const unsigned long long *__restrict__ skeys, const int *__restrict__ sidx,
                                                             const double *__restrict__ pos, const float *__restrict__ mass, double cellsize,
-                                                            int nmesh, double *__restrict__ mesh)
+                                                            int nmesh, int x0, int P, double *__restrict__ mesh)
 {
+    // mesh holds the x-planes [x0, x0 + P) (all of them on one GPU: x0 = 0, P = nmesh); corners on other planes are skipped
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     unsigned long long key = ~0ull;
@@ -141,9 +142,12 @@ __global__ void __launch_bounds__(256) k_cic_deposit_sorted(int64_t n, const uns
     if(tail && key != ~0ull) {
 #pragma unroll
         for(int c = 0; c < 8; c++) {
-            size_t lin = 0;
+            const int px = wrap(ic[0] + (c & 1), nmesh) - x0;
+            if(px < 0 || px >= P)
+                continue;
+            size_t lin = (size_t)px;
 #pragma unroll
-            for(int d = 0; d < 3; d++)
+            for(int d = 1; d < 3; d++)
                 lin = lin * (size_t)nmesh + (size_t)wrap(ic[d] + ((c >> d) & 1), nmesh);
             unsafeAtomicAdd(&mesh[lin], w[c]);
         }
@@ -472,6 +476,72 @@ void PMesh::destroy()
     nmesh = 0;
 }
 
+__global__ void k_cic_deposit_slab(int64_t n, const double *__restrict__ pos, const float *__restrict__ mass, double cellsize, int nmesh, int x0,
+                                   int P, double *__restrict__ slab);
+
+// CIC deposit onto the x-planes [x0, x0 + P) of `mesh` (zeroed by the caller): plain atomics, or cell-sorted with wave-aggregated
+// atomics; the first call and every 64th time both forms on the set at hand and keep the faster one.
+void PMesh::deposit(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_active, double *mesh, int x0, int P, DepositState &ds,
+                    hipStream_t st, EventTimer *tm)
+{
+    const size_t ncell = (size_t)P * nmesh * nmesh, nreal = (size_t)nmesh * nmesh * nmesh;
+    const bool whole = x0 == 0 && P == nmesh;
+    auto plain = [&]() {
+        if(whole)
+            hipLaunchKernelGGL(k_cic_deposit, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, d_active, cellsize, nmesh, mesh);
+        else
+            hipLaunchKernelGGL(k_cic_deposit_slab, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, cellsize, nmesh, x0, P, mesh);
+    };
+    auto sorted = [&]() {
+        dep_keys_a.reserve((size_t)n + 1);
+        dep_keys_b.reserve((size_t)n + 1);
+        dep_idx_a.reserve((size_t)n + 1);
+        dep_idx_b.reserve((size_t)n + 1);
+        hipLaunchKernelGGL(k_cell_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, dep_keys_a.p, dep_idx_a.p);
+        int bits = 1;
+        while(bits < 64 && ((unsigned long long)1 << bits) < (unsigned long long)nreal)
+            bits++;
+        size_t tb = 0;
+        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb, dep_keys_a.p, dep_keys_b.p, dep_idx_a.p, dep_idx_b.p, (size_t)n, 0, 64, st));
+        dep_tmp.reserve(tb + 16);
+        // (all 64 bits when there are inactive particles: they carry the all-ones key)
+        MPG_HIP(rocprim::radix_sort_pairs((void *)dep_tmp.p, tb, dep_keys_a.p, dep_keys_b.p, dep_idx_a.p, dep_idx_b.p, (size_t)n, 0,
+                                          d_active ? 64 : bits, st));
+        hipLaunchKernelGGL(k_cic_deposit_sorted, dim3(nblk(n)), dim3(256), 0, st, n, dep_keys_b.p, dep_idx_b.p, d_pos, d_mass, cellsize, nmesh, x0, P,
+                           mesh);
+    };
+    if(const char *e = getenv("MPG_PM_DEPOSIT")) // experiment knob: "plain" / "sorted"
+        ds.mode = !strcmp(e, "sorted") ? 2 : 1;
+    if(ds.mode == 0 || ++ds.since_tune >= 64) {
+        hipEvent_t e0, e1, e2;
+        MPG_HIP(hipEventCreate(&e0));
+        MPG_HIP(hipEventCreate(&e1));
+        MPG_HIP(hipEventCreate(&e2));
+        MPG_HIP(hipEventRecord(e0, st));
+        sorted();
+        MPG_HIP(hipEventRecord(e1, st));
+        MPG_HIP(hipMemsetAsync(mesh, 0, ncell * sizeof(double), st));
+        plain();
+        MPG_HIP(hipEventRecord(e2, st));
+        MPG_HIP(hipEventSynchronize(e2));
+        float ts = 0, tp = 0;
+        MPG_HIP(hipEventElapsedTime(&ts, e0, e1));
+        MPG_HIP(hipEventElapsedTime(&tp, e1, e2));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipEventDestroy(e2);
+        ds.mode = ts < tp ? 2 : 1;
+        ds.since_tune = 0;
+        if(tm)
+            tm->start(st); // the trial is not the deposit's time
+        MPG_HIP(hipMemsetAsync(mesh, 0, ncell * sizeof(double), st));
+    }
+    if(ds.mode == 2)
+        sorted();
+    else
+        plain();
+}
+
 void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_active, double *d_gravpm, double *d_potential,
                   hipStream_t st, EventTimer *tm)
 {
@@ -487,58 +557,8 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         tm->start(st);
     // pm_init_regions zeroes the mesh (petapm.c:932-952); deposit
     MPG_HIP(hipMemsetAsync(real.p, 0, nreal * sizeof(double), st));
-    if(n > 0) {
-        auto plain = [&]() { hipLaunchKernelGGL(k_cic_deposit, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, d_active, cellsize, nmesh, real.p); };
-        auto sorted = [&]() {
-            dep_keys_a.reserve((size_t)n + 1);
-            dep_keys_b.reserve((size_t)n + 1);
-            dep_idx_a.reserve((size_t)n + 1);
-            dep_idx_b.reserve((size_t)n + 1);
-            hipLaunchKernelGGL(k_cell_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, dep_keys_a.p, dep_idx_a.p);
-            int bits = 1;
-            while(bits < 64 && ((unsigned long long)1 << bits) < (unsigned long long)nreal)
-                bits++;
-            size_t tb = 0;
-            MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb, dep_keys_a.p, dep_keys_b.p, dep_idx_a.p, dep_idx_b.p, (size_t)n, 0, 64, st));
-            dep_tmp.reserve(tb + 16);
-            // (all 64 bits: the inactive particles carry the all-ones key)
-            MPG_HIP(rocprim::radix_sort_pairs((void *)dep_tmp.p, tb, dep_keys_a.p, dep_keys_b.p, dep_idx_a.p, dep_idx_b.p, (size_t)n, 0,
-                                              d_active ? 64 : bits, st));
-            hipLaunchKernelGGL(k_cic_deposit_sorted, dim3(nblk(n)), dim3(256), 0, st, n, dep_keys_b.p, dep_idx_b.p, d_pos, d_mass, cellsize, nmesh,
-                               real.p);
-        };
-        if(const char *e = getenv("MPG_PM_DEPOSIT")) // experiment knob: "plain" / "sorted"
-            deposit_mode = !strcmp(e, "sorted") ? 2 : 1;
-        if(deposit_mode == 0 || ++deposits_since_tune >= 64) {
-            // time both forms on this set and keep the faster one (the particle distribution decides)
-            hipEvent_t e0, e1, e2;
-            MPG_HIP(hipEventCreate(&e0));
-            MPG_HIP(hipEventCreate(&e1));
-            MPG_HIP(hipEventCreate(&e2));
-            MPG_HIP(hipEventRecord(e0, st));
-            sorted();
-            MPG_HIP(hipEventRecord(e1, st));
-            MPG_HIP(hipMemsetAsync(real.p, 0, nreal * sizeof(double), st));
-            plain();
-            MPG_HIP(hipEventRecord(e2, st));
-            MPG_HIP(hipEventSynchronize(e2));
-            float ts = 0, tp = 0;
-            MPG_HIP(hipEventElapsedTime(&ts, e0, e1));
-            MPG_HIP(hipEventElapsedTime(&tp, e1, e2));
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            (void)hipEventDestroy(e2);
-            deposit_mode = ts < tp ? 2 : 1;
-            deposits_since_tune = 0;
-            if(tm)
-                tm->start(st); // the tuning pass is not the deposit's time
-            MPG_HIP(hipMemsetAsync(real.p, 0, nreal * sizeof(double), st));
-        }
-        if(deposit_mode == 2)
-            sorted();
-        else
-            plain();
-    }
+    if(n > 0)
+        deposit(n, d_pos, d_mass, d_active, real.p, 0, nmesh, dep_single, st, tm);
     if(tm)
         tm->lap(st, &tm->t.pm_deposit);
     MPG_FFT(hipfftExecD2Z(plan_r2c, real.p, (hipfftDoubleComplex *)rho_k.p));
@@ -842,8 +862,7 @@ void PMesh::slab_forward_a(int64_t n, const double *d_pos, const float *d_mass, 
     MPG_FFT(hipfftSetStream(slab.p2d_r2c, st));
     MPG_HIP(hipMemsetAsync(slab.force.p, 0, nreal * sizeof(double), st)); // (the force buffer doubles as the density slab)
     if(n > 0)
-        hipLaunchKernelGGL(k_cic_deposit_slab, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_mass, cellsize, nmesh, slab.rank * slab.P, slab.P,
-                           slab.force.p);
+        deposit(n, d_pos, d_mass, nullptr, slab.force.p, slab.rank * slab.P, slab.P, dep_slab, st, nullptr);
     MPG_FFT(hipfftExecD2Z(slab.p2d_r2c, slab.force.p, (hipfftDoubleComplex *)slab.C.p));
     hipLaunchKernelGGL(k_slab_pack_a, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, (const double2 *)slab.C.p,
                        (double2 *)sendA);
