@@ -688,7 +688,6 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
         return;
     MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
     ws.ctr.reserve(16);
-    MPG_HIP(hipMemsetAsync(ws.ctr.p, 0, 16 * sizeof(unsigned), st));
     // 32-bit byte offsets into the source and node arrays (32-byte records, padding included)?
     const bool o32 = (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
 #define MPG_WS(P, C)                                                \
@@ -702,24 +701,34 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
         else                                                        \
             launch_split_t<P, C, false, false>(tv, gp, io, ws, st); \
     } while(0)
-    if(want_pot) {
-        if(count)
-            MPG_WS(true, true);
-        else
-            MPG_WS(true, false);
-    }
-    else {
-        if(count)
-            MPG_WS(false, true);
-        else
-            MPG_WS(false, false);
+    unsigned ctl[4] = {0, 0, 0, 0};
+    for(;;) {
+        MPG_HIP(hipMemsetAsync(ws.ctr.p, 0, 16 * sizeof(unsigned), st));
+        if(want_pot) {
+            if(count)
+                MPG_WS(true, true);
+            else
+                MPG_WS(true, false);
+        }
+        else {
+            if(count)
+                MPG_WS(false, true);
+            else
+                MPG_WS(false, false);
+        }
+        MPG_HIP(hipMemcpyAsync(ctl, ws.ctr.p, sizeof(ctl), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipStreamSynchronize(st));
+        MPG_CHECK(ctl[1] == 0, "short-range walk (list construction) aborted by its loop guard (corrupt tree?)");
+        // More than a fifth of the targets did not fit their lists (the first walk of a clustered set with the initial capacity):
+        // walking them all with the fallback kernel costs seconds (256^3 clustered set: 3.3 s), a second pass of this kernel with
+        // four times the capacity a fraction of one.  (Not when the interaction counters are on: they would count twice.)
+        if(!count && (int64_t)ctl[0] * 5 > io.ntargets && ws.split_cap < 8192) {
+            ws.split_cap = ws.split_cap * 4 < 8192 ? ws.split_cap * 4 : 8192;
+            continue;
+        }
+        break;
     }
 #undef MPG_WS
-    // targets whose lists did not fit: walk them with the lane-per-target kernel
-    unsigned ctl[4] = {0, 0, 0, 0};
-    MPG_HIP(hipMemcpyAsync(ctl, ws.ctr.p, sizeof(ctl), hipMemcpyDeviceToHost, st));
-    MPG_HIP(hipStreamSynchronize(st));
-    MPG_CHECK(ctl[1] == 0, "short-range walk (list construction) aborted by its loop guard (corrupt tree?)");
     ws.split_last_overflow = ctl[0];
     ws.split_last_maxlen = ctl[2];
     if(ctl[0] > 0) {
