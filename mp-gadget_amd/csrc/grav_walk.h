@@ -36,7 +36,7 @@ struct WalkScratch {
     DevBuf<int> split_ovf;        // caller indices of overflowed targets
     int split_cap = 512;          // list entries per target (multiple of 8)
     int split_slice = 1 << 21;    // most targets per list-construction / evaluation kernel pair
-    size_t split_bytes = 4ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes
+    size_t split_bytes = 16ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes (x 2 buffers; 288 GB of HBM)
     unsigned split_last_overflow = 0, split_last_maxlen = 0;
     bool split_overlap = true;        // build the lists of slice k+1 (second stream) while slice k is evaluated
     int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)
