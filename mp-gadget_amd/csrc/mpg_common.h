@@ -1,6 +1,7 @@
 // mpg_common.h -- shared declarations of the gfx950 engine (internal; the public surface is include/mpgadget_hip.h)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -44,6 +45,13 @@ template <typename T> struct DevBuf {
         size_t want = n + n / 16 + 64;
         MPG_HIP(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
+        // debugging aid: MPG_POISON=1 fills every fresh allocation with 0xFF bytes (NaN as double, -1 as int), so that a kernel
+        // reading memory nobody wrote shows up at once instead of depending on what the allocation held before
+        static const bool poison = getenv("MPG_POISON") != nullptr;
+        if(poison) { // (the fill runs on the null stream: finish it before a kernel on another stream writes the buffer)
+            MPG_HIP(hipMemset(p, 0xff, want * sizeof(T)));
+            MPG_HIP(hipDeviceSynchronize());
+        }
     }
     void release()
     {
