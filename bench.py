@@ -300,7 +300,7 @@ def main():
             out["phases_ms"]["pm_slab_total_incl_collectives"] = round(pm_ms[0] / pm_ms[1], 3)
         if multi and args.mgpu == "domain":
             out["config"]["ghost_fraction_rank0"] = round(loc["ghost_fraction"], 3)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not multi and not args.no_cpu_baseline:    # (MPG_FORCE_MGPU frees the full arrays: no baseline leg)
             out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
                                                args.cpu_sample)
     if multi:
