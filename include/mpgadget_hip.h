@@ -357,6 +357,44 @@ int mpg_dev_build_active_sublist(mpg_engine *eng, const int *d_active, int64_t N
 
 /* ---- particle order: Peano-Hilbert keys and the (type, key) sort the reference keeps its particles in
  * (slots_gc_sorted after every full domain decomposition, domain.c:247).  Keys are bit-identical to the reference's. */
+/* ---- Peano-Hilbert domain decomposition (libgadget/domain.c) -------------------------------------------------------------
+ * The reference's domain_decompose_full (domain.c:153-258) in the pieces its MPI code is made of: the device passes over a
+ * rank's particles, the arithmetic on the top-level tree (host; no GPU needed), and - left to the caller, where the reference
+ * calls MPI - the sums, the pairwise hand-over of trees and the all-to-all of particle records (INTEGRATION.md shows the
+ * sequence; mp-gadget_amd/domain_peano.py is that caller over torch.distributed). */
+typedef struct mpg_topnode {            /* struct local_topnode_data, domain.c:60-70, + Leaf of struct topnode_data, domain.h:12-18 */
+    uint64_t StartKey;
+    int32_t Shift, Daughter, Parent, Leaf;
+    int64_t Count, Cost;
+} mpg_topnode;
+/* the rank's sample of keys for the local refinement, sorted (domain.c:1031-1083 with DomainUseGlobalSorting = 0; for the
+ * global sort the caller gathers the ranks' samples and sorts them): every SubSampleDistance-th particle, after a key sort
+ * that drops garbage if PreSort.  keys_out: HOST array of `cap` entries; d_garbage: device bytes (IsGarbage) or NULL */
+int mpg_dev_domain_sample(mpg_engine *eng, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize, int PreSort,
+                          int SubSampleDistance, uint64_t *keys_out, int64_t cap, int64_t *nsample);
+/* domain_check_for_local_refine_subsample from the sorted sample on (domain.c:1085-1180); costs NULL: 1 per sample.
+ * *failed = 1: MaxTopNodes too small (the caller enlarges TopNodeAllocFactor and retries, domain.c:182-194) */
+int mpg_domain_local_refine(const uint64_t *keys, const int64_t *costs, int64_t nsample, mpg_topnode *tree, int *size, int MaxTopNodes, int *failed);
+/* domain_toptree_truncate, domain.c:954-967 */
+int mpg_domain_toptree_truncate(mpg_topnode *tree, int *size, int64_t countlimit, int64_t costlimit);
+/* one receive step of domain_nonrecursively_combine_topTree (domain.c:1232-1247): tree B of rank ThisTask + sep merged into A */
+int mpg_domain_toptree_merge(mpg_topnode *A, int *sizeA, const mpg_topnode *B, int sizeB, int MaxTopNodes, int *failed);
+/* domain_global_refine, domain.c:1344-1395 */
+int mpg_domain_global_refine(mpg_topnode *tree, int *size, int MaxTopNodes, int64_t countlimit, int64_t costlimit, int *failed);
+/* domain_create_topleaves, domain.c:810-824: sets tree[].Leaf, fills leaf_topnode[*nleaves] */
+int mpg_domain_create_topleaves(mpg_topnode *tree, int size, int *leaf_topnode, int *nleaves);
+/* domain_assign_topleaves_balanced + domain_set_task_leafs (domain.c:610-786): reorders the leaves by (Task, Key) - leaf_topnode
+ * and tree[].Leaf are rewritten - and fills leaf_task[nleaves], StartLeaf[NTask], EndLeaf[NTask] */
+int mpg_domain_assign_topleaves_balanced(mpg_topnode *tree, int size, int *leaf_topnode, int nleaves, const int64_t *cost, int NTask,
+                                         int NsegmentPerTask, int *leaf_task, int *StartLeaf, int *EndLeaf);
+/* one pass over the rank's particles: P[].TopLeaf (domain.c:216-225, -1 for garbage) into d_topleaf, the destination task
+ * (domain_layoutfunc, domain.c:794-802) into d_task, particles per leaf (domain_compute_costs, domain.c:1398-1457, before the
+ * Allreduce) into leaf_counts[nleaves] and per destination task into task_counts[NTask] (host arrays).  leaf_task, d_topleaf,
+ * d_task, leaf_counts, task_counts may be NULL. */
+int mpg_dev_domain_topleaves(mpg_engine *eng, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize,
+                             const mpg_topnode *tree, int size, int nleaves, const int *leaf_task, int NTask, int32_t *d_topleaf,
+                             int32_t *d_task, int64_t *leaf_counts, int64_t *task_counts);
+
 /* PEANO(Pos, BoxSize), libgadget/utils/peano.h:15-21 + peano_hilbert_key, peano.c:117-140: d_keys[n] */
 int mpg_dev_peano_keys(mpg_engine *eng, int64_t n, const double *d_pos, double BoxSize, uint64_t *d_keys);
 /* the order of slots_gc_sorted (slotsmanager.c:404-452): d_perm[k] = index of the k-th particle by (Type, Key), garbage

@@ -12,6 +12,7 @@
 #include "sph.h"
 #include "timestep.h"
 #include "peano.h"
+#include "domain.h"
 #include "fof.h"
 #include "snapshot_io.h"
 #include "tree_build.h"
@@ -134,6 +135,7 @@ struct mpg_engine {
     DevBuf<unsigned long long> hier_cnt;
     DevBuf<char> hier_tmp;
     PeanoScratch peano;
+    DomainScratch domain;
     FofEngine fof;
     HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
     HostBuf<float> h_f;
@@ -672,6 +674,81 @@ int mpg_dev_order_by_type_and_key(mpg_engine *eng, int64_t n, const unsigned cha
     MPG_CHECK(eng && n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || (d_keys && d_perm)) && n_live, "order_by_type_and_key: bad argument");
     MPG_HIP(hipSetDevice(eng->device));
     *n_live = order_by_type_and_key(n, d_type, d_flags, d_keys, d_perm, eng->peano, eng->stream);
+    API_END
+}
+
+// ---- Peano-Hilbert domain decomposition (domain.hip) ------------------------------------------------------------------------
+static_assert(sizeof(mpg_topnode) == sizeof(TopNode) && offsetof(mpg_topnode, Count) == offsetof(TopNode, Count), "mpg_topnode layout");
+
+int mpg_dev_domain_sample(mpg_engine *eng, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize, int PreSort,
+                          int SubSampleDistance, uint64_t *keys_out, int64_t cap, int64_t *nsample)
+{
+    API_BEGIN
+    MPG_CHECK(eng && n >= 0 && (n == 0 || d_pos) && BoxSize > 0 && keys_out && nsample, "domain_sample: bad argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    *nsample = domain_sample(n, d_pos, d_garbage, BoxSize, PreSort, SubSampleDistance, keys_out, cap, eng->domain, eng->stream);
+    API_END
+}
+
+int mpg_domain_local_refine(const uint64_t *keys, const int64_t *costs, int64_t nsample, mpg_topnode *tree, int *size, int MaxTopNodes, int *failed)
+{
+    API_BEGIN
+    MPG_CHECK((keys || nsample == 0) && nsample >= 0 && tree && size && failed, "domain_local_refine: bad argument");
+    *failed = toptree_local_refine(keys, costs, nsample, (TopNode *)tree, size, MaxTopNodes) ? 0 : 1;
+    API_END
+}
+
+int mpg_domain_toptree_truncate(mpg_topnode *tree, int *size, int64_t countlimit, int64_t costlimit)
+{
+    API_BEGIN
+    MPG_CHECK(tree && size && *size >= 1, "domain_toptree_truncate: bad argument");
+    toptree_truncate((TopNode *)tree, size, countlimit, costlimit);
+    API_END
+}
+
+int mpg_domain_toptree_merge(mpg_topnode *A, int *sizeA, const mpg_topnode *B, int sizeB, int MaxTopNodes, int *failed)
+{
+    API_BEGIN
+    MPG_CHECK(A && sizeA && *sizeA >= 1 && (B || sizeB == 0) && sizeB >= 0 && failed, "domain_toptree_merge: bad argument");
+    *failed = toptree_merge((TopNode *)A, sizeA, (const TopNode *)B, sizeB, MaxTopNodes) ? 0 : 1;
+    API_END
+}
+
+int mpg_domain_global_refine(mpg_topnode *tree, int *size, int MaxTopNodes, int64_t countlimit, int64_t costlimit, int *failed)
+{
+    API_BEGIN
+    MPG_CHECK(tree && size && *size >= 1 && failed, "domain_global_refine: bad argument");
+    *failed = toptree_global_refine((TopNode *)tree, size, MaxTopNodes, countlimit, costlimit) ? 0 : 1;
+    API_END
+}
+
+int mpg_domain_create_topleaves(mpg_topnode *tree, int size, int *leaf_topnode, int *nleaves)
+{
+    API_BEGIN
+    MPG_CHECK(tree && size >= 1 && leaf_topnode && nleaves, "domain_create_topleaves: bad argument");
+    *nleaves = toptree_create_leaves((TopNode *)tree, size, leaf_topnode);
+    API_END
+}
+
+int mpg_domain_assign_topleaves_balanced(mpg_topnode *tree, int size, int *leaf_topnode, int nleaves, const int64_t *cost, int NTask,
+                                         int NsegmentPerTask, int *leaf_task, int *StartLeaf, int *EndLeaf)
+{
+    API_BEGIN
+    MPG_CHECK(tree && size >= 1 && leaf_topnode && nleaves >= 1 && cost && NTask >= 1 && NsegmentPerTask >= 1 && leaf_task && StartLeaf && EndLeaf,
+              "domain_assign_topleaves_balanced: bad argument");
+    toptree_assign_balanced((TopNode *)tree, size, leaf_topnode, nleaves, cost, NTask, NsegmentPerTask, leaf_task, StartLeaf, EndLeaf);
+    API_END
+}
+
+int mpg_dev_domain_topleaves(mpg_engine *eng, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize,
+                             const mpg_topnode *tree, int size, int nleaves, const int *leaf_task, int NTask, int32_t *d_topleaf,
+                             int32_t *d_task, int64_t *leaf_counts, int64_t *task_counts)
+{
+    API_BEGIN
+    MPG_CHECK(eng && n >= 0 && (n == 0 || d_pos) && BoxSize > 0 && tree && NTask >= 1, "domain_topleaves: bad argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    domain_topleaves(n, d_pos, d_garbage, BoxSize, (const TopNode *)tree, size, nleaves, leaf_task, NTask, d_topleaf, d_task, leaf_counts,
+                     task_counts, eng->domain, eng->stream);
     API_END
 }
 

@@ -1,0 +1,107 @@
+"""GPU: the Peano-Hilbert domain decomposition (libgadget/domain.c) - device passes of the C-ABI against oracle/domain_oracle.py, and
+whole decompositions + particle exchange on 1, 2 and 3 ranks (gloo, sharing this GPU) against the oracle's."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rerun_once_on_failure
+from oracle import domain_oracle as D
+from test_domain_host import keys_of, clumpy, assert_tree_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_sample_and_topleaf_passes(pkg, engine):
+    import torch
+    DP = importlib.import_module("mp-gadget_amd.domain_peano")
+    lib = engine.lib
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    box, n = 100.0, 300007
+    pos = clumpy(n, box, 3)
+    rng = np.random.RandomState(4)
+    garbage = (rng.random_sample(n) < 0.05).astype(np.uint8)
+    keys = keys_of(pos, box)
+    d_pos, d_g = torch.from_numpy(pos).cuda(), torch.from_numpy(garbage).cuda()
+    for presort, sub, g in ((0, 256, None), (0, 7, garbage), (1, 16, garbage), (1, 1, garbage), (1, 400000, None), (0, 400000, garbage)):
+        out = np.zeros(n + 2, np.uint64)
+        ns = C.c_int64(0)
+        assert lib.mpg_dev_domain_sample(engine.h, C.c_int64(n), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_g.data_ptr()) if g is not None else None,
+                                         C.c_double(box), presort, sub, P(out, C.c_uint64), C.c_int64(n + 2), C.byref(ns)) == 0, lib.mpg_last_error()
+        rk, rc = D.sample_keys(keys, g, presort, sub)
+        assert ns.value == len(rk) and np.array_equal(out[:ns.value], np.sort(rk, kind="stable")), (presort, sub)
+    # TopLeaf / Task / counts on the tree the oracle builds for 3 tasks
+    cut = [0, 90000, 200000, n]
+    ranks = [keys[a:b] for a, b in zip(cut[:-1], cut[1:])]
+    ref = D.decompose(ranks, 12, presort=0, subsample=64, garbage=[garbage[a:b] for a, b in zip(cut[:-1], cut[1:])])
+    t = ref["tree"]
+    tree = np.zeros(t.size(), DP.TOPNODE_DTYPE)
+    for k in ("StartKey", "Shift", "Daughter", "Parent", "Count", "Cost"):
+        tree[k] = getattr(t, k)
+    tree["Leaf"] = ref["Leaf"]
+    nl = len(ref["Task"])
+    leaf_task = np.array(ref["Task"], np.int32)
+    tl, ta = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")
+    lc, tc = np.zeros(nl, np.int64), np.zeros(3, np.int64)
+    assert lib.mpg_dev_domain_topleaves(engine.h, C.c_int64(n), C.c_void_p(d_pos.data_ptr()), C.c_void_p(d_g.data_ptr()), C.c_double(box), P(tree, DP.TopNode),
+                                        t.size(), nl, P(leaf_task, C.c_int), 3, C.c_void_p(tl.data_ptr()), C.c_void_p(ta.data_ptr()), P(lc, C.c_int64),
+                                        P(tc, C.c_int64)) == 0, lib.mpg_last_error()
+    want = np.concatenate(ref["TopLeaf"])
+    want[garbage != 0] = -1
+    assert np.array_equal(tl.cpu().numpy(), want)
+    assert np.array_equal(ta.cpu().numpy(), np.where(want >= 0, leaf_task[np.maximum(want, 0)], -1))
+    assert np.array_equal(lc, ref["TopLeafCount"])
+    assert np.array_equal(tc, [ref["TopLeafCount"][s:e].sum() for s, e in zip(ref["StartLeaf"], ref["EndLeaf"])])
+
+
+def _run(tmp_path, name, nproc, port, n, global_sort=1):
+    out = str(tmp_path / name)
+    script = os.path.join(ROOT, "tools", "mgpu_domain_check.py")
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MPG_GLOBAL_SORT=str(global_sort), MASTER_PORT=str(port))
+    if nproc == 1:
+        cmd = [sys.executable, script, out, str(n)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, out, str(n)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [np.load(out + ".%d.npz" % k) for k in range(nproc)]
+
+
+@rerun_once_on_failure
+def test_decomposition_and_exchange_on_ranks(tmp_path):
+    import mgpu_domain_check as T
+    n = 400000
+    pos, garbage, box = T.particle_set(n)
+    keys = keys_of(pos, box)
+    for nproc, port, gs in ((1, 0, 1), (2, 29581, 1), (3, 29582, 0)):
+        got = _run(tmp_path, "d%d" % nproc, nproc, port, n, gs)
+        cut = T.shares(n, nproc)
+        sl = [slice(int(a), int(b)) for a, b in zip(cut[:-1], cut[1:])]
+        ref = D.decompose([keys[s] for s in sl], 4 * nproc, presort=0, subsample=256, global_sort=bool(gs), garbage=[garbage[s] for s in sl])
+        task_of = np.full(n, -1, np.int64)
+        for r, s in enumerate(sl):
+            g = got[r]
+            assert int(g["policy"][0]) == 0 and float(g["alloc_factor"]) == ref["alloc_factor"]
+            assert_tree_equal(g["TopNodes"], len(g["TopNodes"]), ref["tree"], ref["Leaf"])           # every rank holds the same global tree
+            assert np.array_equal(g["leaf_task"], ref["Task"]) and np.array_equal(g["leaf_topnode"], ref["topnode"])
+            assert np.array_equal(g["StartLeaf"], ref["StartLeaf"]) and np.array_equal(g["EndLeaf"], ref["EndLeaf"])
+            assert np.array_equal(g["TopLeafCount"], ref["TopLeafCount"])
+            want = ref["TopLeaf"][r].copy()
+            want[garbage[s] != 0] = -1
+            assert np.array_equal(g["topleaf"], want)
+            task_of[s] = np.where(want >= 0, np.array(ref["Task"])[np.maximum(want, 0)], -1)
+        # after the exchange: rank r holds exactly the live particles of its leaves, grouped by source rank in source order
+        for r in range(nproc):
+            ids = got[r]["ids"]
+            assert np.array_equal(ids, np.nonzero(task_of == r)[0]), (nproc, r)
+            assert np.array_equal(got[r]["pos"], pos[ids])
+        loads = np.array([len(got[r]["ids"]) for r in range(nproc)])
+        assert loads.sum() == int((garbage == 0).sum())
+        assert loads.max() <= 1.3 * loads.mean() + 1, loads
