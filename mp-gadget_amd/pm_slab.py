@@ -25,6 +25,14 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
 
 
+def _scratch(*shape, **kw):
+    """an uninitialised work buffer; MPG_POISON=1 (the engine's debugging aid, csrc/mpg_common.h) fills it with NaN so that a read of
+    an element nobody wrote shows up in the results"""
+    if os.environ.get("MPG_POISON"):
+        return torch.full(shape, float("nan"), **kw)
+    return torch.empty(*shape, **kw)
+
+
 def _all_to_all(recv, send, world, group=None):
     """recv[s-th block] <- rank s's send[my block].  RCCL all_to_all_single; backends without it (gloo, used by the
     CPU-launched tests that put two ranks on one GPU) gather everything and slice."""
@@ -100,12 +108,12 @@ class SlabPM:
         self.box, self.nmesh, self.cellsize = box, nmesh, box / nmesh
         per_peer, plane = eng.dev_pm_slab_init(rank, world)
         f64 = dict(dtype=torch.float64, device=device)
-        self.sendA = torch.empty(2 * per_peer * world, **f64)
-        self.recvA = torch.empty_like(self.sendA)
-        self.sendB = torch.empty(2 * per_peer * world, **f64)     # the inverse transpose carries the potential only
-        self.recvB = torch.empty_like(self.sendB)
-        self.ghost_send = torch.empty(5, plane, **f64)            # first 3 planes (-> previous rank), last 2 (-> next rank)
-        self.ghost_recv = torch.empty_like(self.ghost_send)
+        self.sendA = _scratch(2 * per_peer * world, **f64)
+        self.recvA = _scratch(2 * per_peer * world, **f64)
+        self.sendB = _scratch(2 * per_peer * world, **f64)        # the inverse transpose carries the potential only
+        self.recvB = _scratch(2 * per_peer * world, **f64)
+        self.ghost_send = _scratch(5, plane, **f64)               # first 3 planes (-> previous rank), last 2 (-> next rank)
+        self.ghost_recv = _scratch(5, plane, **f64)
         self.device = device
 
     def targets(self, pos, order):
