@@ -285,7 +285,8 @@ def main():
                         "%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
                         "replicated, one all-gather of accelerations" % world if args.mgpu == "slab" else
                         "targets sharded over %d GPUs (tree-order ranges), PM and tree replicated, all-gather of accelerations" % world)},
-            "roofline": {"bound": "hbm", "kernel": kernels, "walk_variant": variant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernels, "walk_variant": variant, "list_capacity": eng.walk_choice()[1],
+                         "targets_to_fallback_kernel": eng.walk_choice()[2], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
                          "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
