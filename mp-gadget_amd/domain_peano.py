@@ -93,16 +93,39 @@ class PeanoDomain:
         dist.recv(b, src, group=self.group)
         return b.cpu().numpy().view(TOPNODE_DTYPE), n
 
-    # ---------------------------------------------------------------- the decomposition
-    def _global_toptree(self, pos, garbage, policy, maxn):
-        """domain_determine_global_toptree, domain.c:1280-1341: (tree, size) or None when out of top nodes"""
-        lib, n = self.lib, int(pos.shape[0])
+    # ---------------------------------------------------------------- the two passes over the particles (device)
+    def _sample(self, pos, garbage, policy):
+        """the rank's sorted sample of keys (mpg_dev_domain_sample)"""
+        n = int(pos.shape[0])
         cap = n // policy.SubSampleDistance + 2
         keys = np.zeros(cap, np.uint64)
         ns = C.c_int64(0)
-        _ck(lib, lib.mpg_dev_domain_sample(self.eng.h, C.c_int64(n), E._ptr(pos), E._ptr(garbage), C.c_double(self.box), policy.PreSort,
-                                           policy.SubSampleDistance, _p(keys, C.c_uint64), C.c_int64(cap), C.byref(ns)))
-        keys = keys[:ns.value]
+        _ck(self.lib, self.lib.mpg_dev_domain_sample(self.eng.h, C.c_int64(n), E._ptr(pos), E._ptr(garbage), C.c_double(self.box), policy.PreSort,
+                                                     policy.SubSampleDistance, _p(keys, C.c_uint64), C.c_int64(cap), C.byref(ns)))
+        return keys[:ns.value]
+
+    def _topleaves(self, pos, garbage, tree, size, nleaves, leaf_task):
+        """(particles per leaf, per destination task, TopLeaf and Task of every particle) of this rank (mpg_dev_domain_topleaves);
+        without leaf_task only the first"""
+        n = int(pos.shape[0])
+        counts = np.zeros(nleaves, np.int64)
+        if leaf_task is None:
+            _ck(self.lib, self.lib.mpg_dev_domain_topleaves(self.eng.h, C.c_int64(n), E._ptr(pos), E._ptr(garbage), C.c_double(self.box), _p(tree, TopNode),
+                                                            size, nleaves, None, self.world, None, None, _p(counts, C.c_int64), None))
+            return counts, None, None, None
+        topleaf = torch.zeros(n, dtype=torch.int32, device=pos.device)
+        task = torch.zeros(n, dtype=torch.int32, device=pos.device)
+        tcounts = np.zeros(self.world, np.int64)
+        _ck(self.lib, self.lib.mpg_dev_domain_topleaves(self.eng.h, C.c_int64(n), E._ptr(pos), E._ptr(garbage), C.c_double(self.box), _p(tree, TopNode), size,
+                                                        nleaves, _p(leaf_task, C.c_int), self.world, E._ptr(topleaf), E._ptr(task), _p(counts, C.c_int64),
+                                                        _p(tcounts, C.c_int64)))
+        return counts, tcounts, topleaf, task
+
+    # ---------------------------------------------------------------- the decomposition
+    def _global_toptree(self, pos, garbage, policy, maxn):
+        """domain_determine_global_toptree, domain.c:1280-1341: (tree, size) or None when out of top nodes"""
+        lib = self.lib
+        keys = self._sample(pos, garbage, policy)
         if self.global_sorting and self.world > 1:
             # mpsort_mpi (domain.c:1076-1077): the samples sorted over all ranks, every rank keeps as many as it had
             cnt = torch.tensor([len(keys)], dtype=torch.int64).to(self._cdev)
@@ -176,9 +199,7 @@ class PeanoDomain:
             _ck(lib, lib.mpg_domain_create_topleaves(_p(tree, TopNode), size, _p(leaf_topnode, C.c_int), C.byref(nl)))
             nleaves = nl.value
             # domain_balance, domain.c:481-500
-            counts = np.zeros(nleaves, np.int64)
-            _ck(lib, lib.mpg_dev_domain_topleaves(self.eng.h, C.c_int64(n), E._ptr(pos), E._ptr(garbage), C.c_double(self.box), _p(tree, TopNode), size,
-                                                  nleaves, None, self.world, None, None, _p(counts, C.c_int64), None))
+            counts = self._topleaves(pos, garbage, tree, size, nleaves, None)[0]
             if self.world > 1:
                 t = torch.from_numpy(counts).to(self._cdev)
                 dist.all_reduce(t, group=self.group)
@@ -188,12 +209,7 @@ class PeanoDomain:
             _ck(lib, lib.mpg_domain_assign_topleaves_balanced(_p(tree, TopNode), size, _p(leaf_topnode, C.c_int), nleaves, _p(counts, C.c_int64), self.world, 1,
                                                               _p(leaf_task, C.c_int), _p(start, C.c_int), _p(end, C.c_int)))
             # (counts were per leaf in key order; the assignment renumbers the leaves by (Task, Key): count again in the final order)
-            self.topleaf = torch.zeros(n, dtype=torch.int32, device=pos.device)
-            self.task = torch.zeros(n, dtype=torch.int32, device=pos.device)
-            fcounts, tcounts = np.zeros(nleaves, np.int64), np.zeros(self.world, np.int64)
-            _ck(lib, lib.mpg_dev_domain_topleaves(self.eng.h, C.c_int64(n), E._ptr(pos), E._ptr(garbage), C.c_double(self.box), _p(tree, TopNode), size,
-                                                  nleaves, _p(leaf_task, C.c_int), self.world, E._ptr(self.topleaf), E._ptr(self.task),
-                                                  _p(fcounts, C.c_int64), _p(tcounts, C.c_int64)))
+            fcounts, tcounts, self.topleaf, self.task = self._topleaves(pos, garbage, tree, size, nleaves, leaf_task)
             if self.world > 1:
                 t = torch.from_numpy(fcounts).to(self._cdev)
                 dist.all_reduce(t, group=self.group)

@@ -155,3 +155,87 @@ def test_local_refine_edge_cases():
     # an unsorted sample is an error
     bad = np.array([1 << 60, 5 << 60, (1 << 60) + 1], np.uint64)      # the third key falls into a leaf that was left behind
     assert lib.mpg_domain_local_refine(P(bad, C.c_uint64), None, C.c_int64(3), P(tree, DP.TopNode), C.byref(size), 60, C.byref(failed)) != 0
+
+
+# ---- N > 1 on CPU: the collective choreography of mp-gadget_amd/domain_peano.py with two gloo ranks ------------------------------
+# The two passes over the particles need the GPU; here they are replaced by host stand-ins built from the oracle (test-side
+# only), so that everything else - sample all-gather, sums, pairwise tree hand-over, broadcast, count all-reduce, the
+# C-ABI host functions and the all-to-all of particle rows - runs as in a multi-GPU job.
+def _domain_worker(rank, world, port, n, global_sort, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import mgpu_domain_check as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    box = 100.0
+
+    class HostPasses(DP.PeanoDomain):
+        def _sample(self, pos, garbage, policy):
+            k, _ = D.sample_keys(keys_of(pos.numpy(), box), None if garbage is None else garbage.numpy(), policy.PreSort, policy.SubSampleDistance)
+            return np.sort(k, kind="stable")
+
+        def _topleaves(self, pos, garbage, tree, size, nleaves, leaf_task):
+            t = D.TopTree()
+            t.resize(size)
+            for f in ("StartKey", "Shift", "Daughter"):
+                getattr(t, f)[:] = [int(v) for v in tree[f][:size]]
+            tl = D.topleaf_of_keys(t, [int(v) for v in tree["Leaf"][:size]], keys_of(pos.numpy(), box))
+            if garbage is not None:
+                tl[garbage.numpy() != 0] = -1
+            counts = np.bincount(tl[tl >= 0], minlength=nleaves).astype(np.int64)
+            if leaf_task is None:
+                return counts, None, None, None
+            task = np.where(tl >= 0, leaf_task[np.maximum(tl, 0)], -1)
+            tc = np.bincount(task[task >= 0], minlength=self.world).astype(np.int64)
+            return counts, tc, torch.from_numpy(tl.astype(np.int32)), torch.from_numpy(task.astype(np.int32))
+
+    class Eng:
+        lib, h = pkg.engine.load_library(), None
+
+    pos, garbage, _ = T.particle_set(n, box)
+    cut = T.shares(n, world)
+    sl = [slice(int(a), int(b)) for a, b in zip(cut[:-1], cut[1:])]
+    mine = sl[rank]
+    dom = HostPasses(Eng(), box, rank, world, overdecomposition=4, global_sorting=global_sort)
+    dom.decompose(torch.from_numpy(pos[mine]), torch.from_numpy(garbage[mine]))
+    ids, got_pos = dom.exchange(torch.arange(mine.start, mine.stop, dtype=torch.int64), torch.from_numpy(pos[mine]))
+    keys = keys_of(pos, box)
+    ref = D.decompose([keys[s] for s in sl], 4 * world, presort=0, subsample=256, global_sort=global_sort, garbage=[garbage[s] for s in sl])
+    ok = True
+    try:
+        assert_tree_equal(dom.TopNodes, dom.NTopNodes, ref["tree"], ref["Leaf"])
+        assert np.array_equal(dom.leaf_task, ref["Task"]) and np.array_equal(dom.StartLeaf, ref["StartLeaf"]) and np.array_equal(dom.EndLeaf, ref["EndLeaf"])
+        assert np.array_equal(dom.TopLeafCount, ref["TopLeafCount"])
+        task_of = np.full(n, -1, np.int64)
+        for s, tl in zip(sl, ref["TopLeaf"]):
+            task_of[s] = np.where(garbage[s] == 0, np.array(ref["Task"])[tl], -1)
+        assert np.array_equal(ids.numpy(), np.nonzero(task_of == rank)[0])
+        assert np.array_equal(got_pos.numpy(), pos[ids.numpy()])
+    except AssertionError as e:
+        ok = repr(e)[:500]
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,global_sort", [(2, True), (3, False)])
+def test_decomposition_collectives_gloo(world, global_sort):
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_domain_worker, args=(r, world, port, 150000, global_sort, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)], res
