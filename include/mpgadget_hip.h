@@ -135,7 +135,10 @@ int mpg_dev_bind_particles(mpg_engine *eng, int64_t n, const double *d_pos, cons
                            double BoxSize);
 /* gravpm_force on bound particles: d_gravpm[n][3] (=), d_potential[n] (+=; may be NULL). */
 int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential);
-/* force_tree_full / force_tree_rebuild_mask on bound particles. */
+/* force_tree_full / force_tree_rebuild_mask on bound particles.  Called right after mpg_dev_gravpm_force (the order of run.c:522-548)
+ * the build runs on an engine-internal second stream next to the PM force - neither depends on the other - and everything queued
+ * afterwards waits for both.  The bound positions must not change between the two calls other than through this API
+ * (mpg_dev_bind_particles / mpg_dev_drift_all_particles switch the overlap off for the next build); MPG_NO_TREE_OVERLAP=1 disables it. */
 int mpg_dev_force_tree_build(mpg_engine *eng, int mask);
 /* grav_short_tree on bound particles.  d_oldacc[n] = |FullTreeGravAccel + GravPM| / G (grav_get_abs_accel,
  * gravshort.h:70-80) or NULL to have it computed from d_prev_accel[n][3] + d_gravpm[n][3].

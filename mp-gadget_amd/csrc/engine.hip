@@ -82,6 +82,12 @@ struct mpg_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // the tree build of a step has no data dependence on the step's PM force (both read the bound positions): when a PM
+    // force has just been queued, force_tree_build runs on this second stream next to it (engine-internal; MPG_NO_TREE_OVERLAP=1
+    // keeps everything on one stream)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_tree_done = nullptr;
+    bool pm_queued = false;
     // module state (static variables of gravshort-tree.c:30-32, gravity.c:20, forcetree.c:30-37)
     mpg_gravshort_tree_params treepar{0.002, 0.175, 0.9, 2, 6.0, 1.0 / 30.};
     double GravitySoftening = 0;
@@ -198,6 +204,12 @@ void mpg_engine_destroy(mpg_engine *eng)
         if(e)
             (void)hipEventDestroy(e);
     eng->pm.destroy();
+    if(eng->aux_stream) {
+        (void)hipStreamSynchronize(eng->aux_stream);
+        (void)hipStreamDestroy(eng->aux_stream);
+        (void)hipEventDestroy(eng->ev_inputs);
+        (void)hipEventDestroy(eng->ev_tree_done);
+    }
     if(eng->own_stream && eng->stream)
         (void)hipStreamDestroy(eng->stream);
     delete eng;
@@ -349,6 +361,7 @@ int mpg_dev_bind_particles(mpg_engine *eng, int64_t n, const double *d_pos, cons
     eng->d_mass = d_mass;
     eng->d_type = d_type;
     eng->box = BoxSize;
+    eng->pm_queued = false; // a tree build that follows sees new arrays: it stays behind everything on the main stream
     API_END
 }
 
@@ -359,6 +372,16 @@ int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential)
     MPG_HIP(hipSetDevice(eng->device));
     MPG_CHECK(eng->pm.nmesh > 0, "gravpm_force called before gravpm_init_periodic");
     MPG_CHECK(eng->pm.box == eng->box, "gravpm_force: BoxSize of the mesh differs from the bound particles");
+    static const bool no_overlap = getenv("MPG_NO_TREE_OVERLAP") != nullptr;
+    if(!no_overlap && !eng->timer.enabled) {
+        if(!eng->aux_stream) {
+            MPG_HIP(hipStreamCreateWithFlags(&eng->aux_stream, hipStreamNonBlocking));
+            MPG_HIP(hipEventCreateWithFlags(&eng->ev_inputs, hipEventDisableTiming));
+            MPG_HIP(hipEventCreateWithFlags(&eng->ev_tree_done, hipEventDisableTiming));
+        }
+        MPG_HIP(hipEventRecord(eng->ev_inputs, eng->stream)); // everything queued so far: the particle arrays are final, the last walk is done
+        eng->pm_queued = true;
+    }
     eng->pm.force(eng->n, eng->d_pos, eng->d_mass, nullptr, d_gravpm, d_potential, eng->stream, &eng->timer);
     API_END
 }
@@ -439,8 +462,20 @@ int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
     API_BEGIN
     MPG_CHECK(eng, "null engine");
     MPG_HIP(hipSetDevice(eng->device));
-    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
-    eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+    if(eng->pm_queued && !eng->timer.enabled) {
+        // next to the PM force queued on the main stream; whatever is queued on the main stream after this call waits for the tree
+        eng->pm_queued = false;
+        MPG_HIP(hipStreamWaitEvent(eng->aux_stream, eng->ev_inputs, 0));
+        eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->aux_stream, nullptr);
+        eng->tree.calc_moments(nullptr, eng->aux_stream, nullptr);
+        MPG_HIP(hipEventRecord(eng->ev_tree_done, eng->aux_stream));
+        MPG_HIP(hipStreamWaitEvent(eng->stream, eng->ev_tree_done, 0));
+    }
+    else {
+        eng->pm_queued = false;
+        eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
+        eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+    }
     if(eng->timer.enabled)
         eng->timer.t.tree_total = eng->timer.t.tree_keys + eng->timer.t.tree_sort + eng->timer.t.tree_nodes + eng->timer.t.tree_moments;
     eng->tree_allocated = true;
@@ -614,6 +649,7 @@ int mpg_dev_drift_all_particles(mpg_engine *eng, int64_t n, double *d_pos, const
     MPG_CHECK(eng && d_pos && d_vel && random_shift && n >= 0, "null argument");
     MPG_CHECK(!d_hsml || (d_dthsml && d_type), "drift: Hsml needs DtHsml and Type");
     MPG_HIP(hipSetDevice(eng->device));
+    eng->pm_queued = false; // positions move: a tree build that follows must stay behind this on the main stream
     eng->ts_flag.reserve(4);
     MPG_HIP(hipMemsetAsync(eng->ts_flag.p, 0, sizeof(unsigned), eng->stream));
     launch_drift(n, d_pos, d_vel, d_type, d_flags, d_hsml, d_dthsml, ddrift, BoxSize, random_shift, eng->ts_flag.p, eng->stream);
