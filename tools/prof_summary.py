@@ -25,6 +25,32 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
         print("  %-70s calls %6s  total %10.3f ms  avg %10.3f ms  %5s%%" % (
             short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e6, r["Percentage"]))
 
+# ---- one walk (bench.py's roofline "launch") from the kernel trace: kernels 6 run as k_walk_lists / k_walk_eval pairs over slices,
+# on two streams; a walk's duration is the span from its first list kernel to the end of its last evaluation kernel.  This is the
+# figure that must agree with roofline.avg_launch_ms (HIP events inside bench.py); the per-kernel averages above overlap each other.
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    walks, cur = [], None
+    for r in rows:
+        nm = r["Kernel_Name"]
+        w = "k_walk_lists<" in nm or "k_walk_eval<" in nm
+        if w:
+            if cur is None:
+                cur = dict(t0=int(r["Start_Timestamp"]), t1=0, count="k_walk_lists<true" in nm, n=0)
+            cur["t1"] = max(cur["t1"], int(r["End_Timestamp"]))
+            cur["n"] += 1
+        elif cur is not None and "rocclr" not in nm and "k_grav_walk" not in nm:
+            walks.append(cur)
+            cur = None
+    if cur is not None:
+        walks.append(cur)
+    timed = [w for w in walks if not w["count"]]
+    if timed:
+        spans = [(w["t1"] - w["t0"]) / 1e6 for w in timed]
+        print("== walks (first k_walk_lists start .. last k_walk_eval end):", len(walks), "of which", len(timed), "without counters")
+        print("  span ms:", " ".join("%.2f" % x for x in spans), "  kernels per walk:", timed[-1]["n"])
+        print("  steady state (last %d): %.3f ms per walk" % (min(len(spans), 2), sum(spans[-2:]) / len(spans[-2:])))
+
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
         continue
