@@ -290,6 +290,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
                          "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
+                         "nodes_used_per_launch": cnt["nodes_used"], "children_per_node_step": round(cnt["node_lanes"] / max(cnt["node_steps"], 1), 2),
                          "note": "one launch = one short-range walk over all targets (variant 6: list-construction + evaluation "
                                  "kernel pairs over slices of 2^21 targets); algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 "
                                  "(SURVEY 8(d)); reuse through L1/L2/LDS makes this exceed HBM traffic; the walk is bound by fp64 "
