@@ -290,6 +290,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
                          "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
+                         "fp64_valu": {"achieved": round(flops / (walk_avg_ms * 1e-3) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
+                                       "frac": round(flops / (walk_avg_ms * 1e-3) / 1e12 / 78.6, 4),
+                                       "note": "the bound that applies: 38 flop per pair or node interaction (the node tests of the "
+                                               "traversal not counted) against the fp64 vector peak; profiles/*/summary.txt: VALU busy "
+                                               "88 % of the kernels' cycles"},
                          "nodes_used_per_launch": cnt["nodes_used"], "children_per_node_step": round(cnt["node_lanes"] / max(cnt["node_steps"], 1), 2),
                          "note": "one launch = one short-range walk over all targets (variant 6: list-construction + evaluation "
                                  "kernel pairs over slices of 2^21 targets); algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 "

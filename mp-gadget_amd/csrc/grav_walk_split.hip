@@ -230,7 +230,10 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
                 dy = mom.y - py;
                 dz = mom.z - pz;
             }
-            if(g.len + gp.rcut > 0.49 * gp.box) { // the root and its children
+            // the root and its children: with FASTWRAP (Rcut < 0.2 Box) they are the only nodes with len + Rcut > 0.49 Box, and in
+            // level order they are nodes 0 .. nchild(root) <= 8 (for a node beyond them the branch is exact too, only not needed).
+            // Idle lanes (which point at the root) stay out: they used to drag the wave through this branch on most steps.
+            if(mine && my <= 8u) {
                 const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
                 dx = fma(-jx, gp.box, mom.x - px);
                 dy = fma(-jy, gp.box, mom.y - py);
