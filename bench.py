@@ -253,6 +253,13 @@ def main():
     cnt = eng.walk_counters()
     eng.set_instrumentation(False, False)
     eng.walk_events_collect()
+    if os.environ.get("MPG_BENCH_DEBUG") and rank == 0:
+        if multi and args.mgpu == "domain":
+            a, b, g = loc["acc"][:n_own], loc["prev"][:n_own], loc["gravpm"][:n_own]
+        else:
+            a, b, g = acc, prev, gravpm
+        nrm = lambda t: float(t.norm(dim=1).mean())
+        print("debug: mean |acc| %.6e |prev| %.6e |gravpm| %.6e |prev+gravpm| %.6e |acc+gravpm| %.6e" % (nrm(a), nrm(b), nrm(g), nrm(b + g), nrm(a + g)), flush=True)
 
     out = None
     if rank == 0:

@@ -25,6 +25,9 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
 
 
+A2A_MAX_BLOCK = 1 << 26          # elements per peer in one all_to_all_single (see _all_to_all)
+
+
 def _scratch(*shape, **kw):
     """an uninitialised work buffer; MPG_POISON=1 (the engine's debugging aid, csrc/mpg_common.h) fills it with NaN so that a read of
     an element nobody wrote shows up in the results"""
@@ -39,6 +42,17 @@ def _all_to_all(recv, send, world, group=None):
     if world == 1 and not FORCE_COLLECTIVES:
         recv.copy_(send)
         return
+    blk = send.numel() // world
+    if blk > A2A_MAX_BLOCK:
+        # RCCL 2.26 (torch 2.10 / ROCm 7) returns garbage in the second half of a block of more than 2^27 elements (measured:
+        # 1.08 GB of doubles per peer, tools/a2a_selftest.py; 0.54 GB is fine): larger blocks go in pieces
+        sv, rv = send.view(world, blk), recv.view(world, blk)
+        for c in range(0, blk, A2A_MAX_BLOCK):
+            part = sv[:, c:c + A2A_MAX_BLOCK].contiguous()
+            got = torch.empty_like(part)
+            _all_to_all(got.view(-1), part.view(-1), world, group)
+            rv[:, c:c + A2A_MAX_BLOCK] = got
+        return
     try:
         dist.all_to_all_single(recv, send, group=group)
         return
@@ -47,7 +61,6 @@ def _all_to_all(recv, send, world, group=None):
     rank = dist.get_rank(group)
     parts = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(parts, send, group=group)
-    blk = send.numel() // world
     for s in range(world):
         recv.view(-1)[s * blk:(s + 1) * blk] = parts[s].view(-1)[rank * blk:(rank + 1) * blk]
 

@@ -548,3 +548,29 @@ def test_pm_power_spectrum(pkg, engine, tmp_path):
     engine.gravpm_measure_power(True)
     engine.synchronize()
     assert np.abs(gpm.cpu().numpy() - g1).max() <= 1e-10 * np.abs(g1).max()
+
+
+def test_rccl_one_rank_group_matches_single(tmp_path):
+    """The slab PM, the domain path and their collectives through RCCL itself (backend "nccl", a one-rank group on this GPU)
+    against the plain single-GPU step: same accelerations, GravPM / Potential to FFT round-off.  (The gloo tests above cover
+    several ranks; this one covers the backend the multi-GPU runs use.  It once failed at Nmesh = 512, where one all-to-all
+    block exceeds 1 GiB - RCCL returns garbage there - hence pm_slab._all_to_all's piecewise path, tools/a2a_selftest.py.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "mgpu_check.py")
+    res = {}
+    for k, (mode, force) in enumerate((("single", ""), ("slab1", "1"), ("domain1", "1"))):
+        out = str(tmp_path / (mode + ".npy"))
+        env = dict(os.environ, MPG_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29590 + k), MPG_MGPU_MODE=mode, MPG_MGPU_IC="s_zel")
+        if force:
+            env["MPG_FORCE_COLLECTIVES"] = force
+        r = subprocess.run([sys.executable, script, out, "48"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = np.load(out)
+    one = res["single"]
+    for mode in ("slab1", "domain1"):
+        got = res[mode]
+        assert np.array_equal(one[:, 0:3], got[:, 0:3]), mode
+        assert np.abs(got[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * np.abs(one[:, 3:6]).mean(), mode
+        assert np.abs(got[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), mode

@@ -40,7 +40,7 @@ acc = torch.zeros_like(gravpm)
 old = torch.full((N,), 1e-7, dtype=torch.float64, device=dev)
 mode = os.environ.get("MPG_MGPU_MODE", "slab")
 pot = torch.zeros(N, dtype=torch.float64, device=dev)
-if world == 1 and mode != "slab1":
+if world == 1 and mode not in ("slab1", "domain1"):
     eng.dev_gravpm_force(gravpm, pot)
     eng.dev_force_tree_build()
     eng.dev_grav_short_tree(acc, oldacc=old)
@@ -87,7 +87,7 @@ else:
     acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
 # the matter power spectrum measured on the way (gravpm.c:331-382): rows of (k, P, Nmodes)
 mpc = box / 1000.0
-if world == 1 and mode != "slab1" or mode == "replicated":
+if world == 1 and mode not in ("slab1", "domain1") or mode == "replicated":
     ps = eng.gravpm_get_powerspectrum(2 * n, mpc)
 else:
     ps = spm.power_spectrum(mpc)
