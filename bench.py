@@ -62,7 +62,7 @@ def main():
                          "slab PM and slab targets; replicated = everything but the walk targets replicated")
     ap.add_argument("--sph", default="auto", choices=["auto", "de", "pe"],
                     help="hydro workload: density-entropy (BASELINE configs[2]) or pressure-entropy SPH (configs[4]); auto: de on one GPU, pe on several")
-    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof"],
+    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof", "domain"],
                     help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
                          "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
     args = ap.parse_args()
@@ -101,6 +101,10 @@ def main():
         if world != 1:
             raise SystemExit("--workload fof is single-GPU")
         return fof_bench(pkg, torch, args, dev)
+    if args.workload == "domain":
+        if world != 1:
+            raise SystemExit("--workload domain is a one-rank line (tests/test_gpu_domain.py runs the decomposition on several ranks)")
+        return domain_bench(pkg, torch, args, dev)
     if multi and world == 1:
         pkg.pm_slab.FORCE_COLLECTIVES = True
     if args.workload == "hydro":
@@ -435,6 +439,77 @@ def fof_bench(pkg, torch, args, dev):
                         "avg_launch_ms": 1e3 * el / args.steps,
                         "note": "whole fof_fof call (about 30 launches, three host synchronisations for counts); the link walk is a "
                                 "neighbour search bound by instruction issue and latency, not by HBM"}}
+    eng.close()
+    emit(out)
+    return out
+
+
+def domain_bench(pkg, torch, args, dev):
+    """one Peano-Hilbert domain decomposition (domain_decompose_full up to the exchange, domain.c:153-225) of n^3
+    particles for 8 tasks, as ONE rank sees it: key sample, top-tree arithmetic, the count pass, the balanced assignment and the pass
+    that gives every particle its TopLeaf and destination task (mp-gadget_amd/domain_peano.py; the collectives of a real run are
+    sums of a few integers and one small broadcast).  One step = one decomposition."""
+    DP = importlib.import_module("mp-gadget_amd.domain_peano")
+    n = args.n or 256
+    ntask = 8
+    ic = args.ic if args.ic != "s_grid" else "s_zel"      # (the default set of the force bench is a jittered lattice: use the displaced one)
+    pos, mass, box = getattr(pkg.ics, ic)(n)
+    N = len(pos)
+    d_pos = torch.from_numpy(pos).to(dev)
+    eng = pkg.Engine(dev.index or 0)
+    eng.use_torch_stream()
+
+    class EightTasks(DP.PeanoDomain):   # one process stands for rank 0 of 8: the sums over ranks see this rank's share only
+        def _sum(self, *vals):
+            return [int(v) for v in vals]
+
+        def _recv_tree(self, src):      # the other seven hold no particles: empty trees
+            import numpy as np
+            return np.zeros(0, DP.TOPNODE_DTYPE), 0
+
+        def _bcast_bytes(self, arr, src, n=None):
+            return arr
+
+    dom = EightTasks(eng, box, 0, 1, global_sorting=False)
+    dom.world = ntask
+    dom._cdev = torch.device("cpu")
+
+    def one():
+        policy = DP.DomainPolicy(0, ntask)
+        tree, size = dom._global_toptree(d_pos, None, policy, max(int(0.5 * (N + 1)), 1))
+        import ctypes as C
+        import numpy as np
+        ltn = np.zeros(size, np.int32)
+        nl = C.c_int(0)
+        P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        assert eng.lib.mpg_domain_create_topleaves(P(tree, DP.TopNode), size, P(ltn, C.c_int), C.byref(nl)) == 0
+        counts = dom._topleaves(d_pos, None, tree, size, nl.value, None)[0]
+        lt, st, en = np.zeros(nl.value, np.int32), np.zeros(ntask, np.int32), np.zeros(ntask, np.int32)
+        assert eng.lib.mpg_domain_assign_topleaves_balanced(P(tree, DP.TopNode), size, P(ltn, C.c_int), nl.value, P(counts, C.c_int64), ntask, 1,
+                                                            P(lt, C.c_int), P(st, C.c_int), P(en, C.c_int)) == 0
+        fc, tc, topleaf, task = dom._topleaves(d_pos, None, tree, size, nl.value, lt)
+        return size, nl.value, tc
+
+    for _ in range(args.warmup + 1):
+        size, nleaves, tc = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        size, nleaves, tc = one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    b_alg = N * (32 + 24 + 24 + 8)      # sample pass: positions + keys (32); count pass: positions (24); layout pass: positions + TopLeaf + Task (32)
+    ach = b_alg * args.steps / el / 1e9
+    out = {"metric": "particles/sec through one Peano-Hilbert domain decomposition (8 tasks)", "value": N * args.steps / el, "unit": "particles/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "domain decomposition of %d^3 particles (%s) for %d tasks: TopNodes %d, TopLeaves %d" % (n, ic, ntask, size, nleaves),
+                      "particles": N, "max_load_over_mean": float(tc.max() / tc.mean())},
+           "roofline": {"bound": "hbm", "kernel": "k_peano_keys + k_topleaf (three passes over the positions)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_alg,
+                        "avg_launch_ms": 1e3 * el / args.steps,
+                        "note": "whole decomposition incl. the host tree arithmetic on the 1/256 sample (about half of the time); the key of a "
+                                "particle is 21 dependent table steps, which bounds the passes rather than HBM"}}
     eng.close()
     emit(out)
     return out

@@ -46,3 +46,5 @@ def test_other_workloads():
     assert KEYS <= set(f) and f["config"]["groups"] > 0 and f["config"]["particles_in_groups"] > 0
     p = run_bench(["--workload", "hydro", "--sph", "pe", "--size", "32", "--steps", "1", "--warmup", "0"])
     assert KEYS <= set(p) and "pressure-entropy" in p["config"]["workload"]
+    d = run_bench(["--workload", "domain", "--size", "64", "--steps", "1", "--warmup", "0"])
+    assert KEYS <= set(d) and d["config"]["max_load_over_mean"] < 1.5 and "TopLeaves" in d["config"]["workload"]
