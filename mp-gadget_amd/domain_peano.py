@@ -240,3 +240,15 @@ class PeanoDomain:
             return [c[order] for c in columns]
         allc = pm_slab.count_matrix(counts, self.world, columns[0].device if dist.get_backend(self.group) == "nccl" else torch.device("cpu"), self.group)
         return [pm_slab.exchange_rows(c[order].contiguous(), counts, self.world, self.group, allc) for c in columns]
+
+    def peano_order(self, pos, type=None):
+        """The last step of domain_decompose_full (slots_gc_sorted, domain.c:238-241, slotsmanager.c:404-452): the permutation that
+        puts this rank's particles (after the exchange) in (Type, Peano-Hilbert key) order; apply it to every column."""
+        n = int(pos.shape[0])
+        keys = torch.zeros(n, dtype=torch.int64, device=pos.device)
+        perm = torch.zeros(n, dtype=torch.int32, device=pos.device)
+        if n:
+            self.eng.dev_peano_keys(pos, self.box, keys)
+            self.eng.dev_order_by_type_and_key(keys, perm, type=type)
+        return perm.long()
+

@@ -102,6 +102,8 @@ def test_decomposition_and_exchange_on_ranks(tmp_path):
             ids = got[r]["ids"]
             assert np.array_equal(ids, np.nonzero(task_of == r)[0]), (nproc, r)
             assert np.array_equal(got[r]["pos"], pos[ids])
+            # ... and the final Peano-Hilbert sort of domain_decompose_full: a stable sort by key
+            assert np.array_equal(got[r]["perm"], np.argsort(keys[ids], kind="stable"))
         loads = np.array([len(got[r]["ids"]) for r in range(nproc)])
         assert loads.sum() == int((garbage == 0).sum())
         assert loads.max() <= 1.3 * loads.mean() + 1, loads

@@ -49,10 +49,11 @@ if __name__ == "__main__":
     dom = DP.PeanoDomain(eng, box, rank, world, overdecomposition=4, global_sorting=bool(int(os.environ.get("MPG_GLOBAL_SORT", "1"))))
     dom.decompose(d_pos, d_garb)
     got_ids, got_pos = dom.exchange(ids, d_pos)
+    perm = dom.peano_order(got_pos)              # slots_gc_sorted: the rank's particles in Peano-Hilbert order
     torch.cuda.synchronize()
     np.savez(out + ".%d.npz" % rank, TopNodes=dom.TopNodes, leaf_task=dom.leaf_task, leaf_topnode=dom.leaf_topnode, StartLeaf=dom.StartLeaf,
              EndLeaf=dom.EndLeaf, TopLeafCount=dom.TopLeafCount, topleaf=dom.topleaf.cpu().numpy(), task=dom.task.cpu().numpy(),
-             ids=got_ids.cpu().numpy(), pos=got_pos.cpu().numpy(), policy=np.array([dom.last_policy, dom.policy.SubSampleDistance]),
+             ids=got_ids.cpu().numpy(), pos=got_pos.cpu().numpy(), perm=perm.cpu().numpy(), policy=np.array([dom.last_policy, dom.policy.SubSampleDistance]),
              alloc_factor=dom.alloc_factor)
     if world > 1:
         dist.barrier()
