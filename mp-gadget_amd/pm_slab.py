@@ -25,7 +25,7 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = bool(os.environ.get("MPG_FORCE_COLLECTIVES"))
 
 
-A2A_MAX_BLOCK = 1 << 26          # elements per peer in one all_to_all_single (see _all_to_all)
+A2A_MAX_ELEMENTS = 1 << 26       # elements in one all_to_all_single call, all peers together (see _all_to_all)
 
 
 def _scratch(*shape, **kw):
@@ -43,15 +43,18 @@ def _all_to_all(recv, send, world, group=None):
         recv.copy_(send)
         return
     blk = send.numel() // world
-    if blk > A2A_MAX_BLOCK:
-        # RCCL 2.26 (torch 2.10 / ROCm 7) returns garbage in the second half of a block of more than 2^27 elements (measured:
-        # 1.08 GB of doubles per peer, tools/a2a_selftest.py; 0.54 GB is fine): larger blocks go in pieces
+    piece = max(A2A_MAX_ELEMENTS // world, 1)
+    if blk > piece:
+        # RCCL 2.26 (torch 2.10 / ROCm 7) returns garbage in the second half of a message of more than 1 GiB (measured in a one-rank
+        # group, where message = whole buffer: tools/a2a_selftest.py; up to 1 GiB it is exact).  Whether the limit is per peer or
+        # per call could not be measured on one GPU, so a call never carries more than A2A_MAX_ELEMENTS (512 MiB of doubles) in
+        # total: larger transposes go in pieces (one extra copy of each piece, ~0.1 ms per 100 MB)
         sv, rv = send.view(world, blk), recv.view(world, blk)
-        for c in range(0, blk, A2A_MAX_BLOCK):
-            part = sv[:, c:c + A2A_MAX_BLOCK].contiguous()
+        for c in range(0, blk, piece):
+            part = sv[:, c:c + piece].contiguous()
             got = torch.empty_like(part)
             _all_to_all(got.view(-1), part.view(-1), world, group)
-            rv[:, c:c + A2A_MAX_BLOCK] = got
+            rv[:, c:c + piece] = got
         return
     try:
         dist.all_to_all_single(recv, send, group=group)

@@ -113,11 +113,11 @@ def _slab_worker(rank, world, port, q):
     recv = torch.empty_like(send)
     S._all_to_all(recv.view(-1), send.view(-1), world)
     ok &= bool(torch.equal(recv.reshape(M, P), A[:, rank * P:(rank + 1) * P]))
-    # the same through the piecewise path (blocks above A2A_MAX_BLOCK elements go in several calls: RCCL fails above 1 GiB per peer)
-    keep, S.A2A_MAX_BLOCK = S.A2A_MAX_BLOCK, 5
+    # the same through the piecewise path (calls above A2A_MAX_ELEMENTS elements are split: RCCL fails above 1 GiB)
+    keep, S.A2A_MAX_ELEMENTS = S.A2A_MAX_ELEMENTS, 5 * world
     recv2 = torch.full_like(send, -1.0)
     S._all_to_all(recv2.view(-1), send.view(-1), world)
-    S.A2A_MAX_BLOCK = keep
+    S.A2A_MAX_ELEMENTS = keep
     ok &= bool(torch.equal(recv2, recv))
     # ghost planes of the potential: first 3 planes to the previous rank, last 2 to the next (the same rank when world == 2)
     class _E:   # the exchange only needs the buffers
