@@ -45,6 +45,97 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
+FP64_VALU_PEAK_TF = 78.6   # MI355X_MICROARCH.md: fp64 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+FLOP_PER_INTERACTION = 38  # flop-equivalents of one particle-particle or particle-node evaluation
+
+
+def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
+    """`roofline` of the dominant kernel, the short-range walk.  The ceiling that binds it is fp64 vector issue, not HBM
+    (pairwise 1/r^2 with a table lookup: the gathers are served by L2/LDS), so `achieved` is the reference-required flops
+    38 x (pair interactions + nodes used) per walk over the walk's duration from HIP events on the engine stream; the node
+    tests of the traversal, which the reference also performs, are NOT counted as flops.  The HBM side is reported next to it:
+    algorithmic bytes (SURVEY 8(d) B_walk), measured HBM traffic (PMC) as a fraction of the 8 TB/s peak, and their ratio."""
+    variant, list_cap, list_ovf = eng.walk_choice()
+    kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 5: "k_grav_walk_shared", 6: "k_walk_lists + k_walk_eval",
+               7: "k_walk_leaf"}.get(variant, "?")
+    t = walk_ms / max(walk_launches, 1) * 1e-3
+    flops = (cnt["pp"] + cnt["nodes_used"]) * float(FLOP_PER_INTERACTION)
+    b_alg = cnt["targets"] * 64 + cnt["pp"] * 28 + cnt["nodes_visited"] * 72   # SURVEY 8(d): B_walk
+    ach = flops / t / 1e12
+    r = {"bound": "fp64_valu", "kernel": kernels, "achieved": ach, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+         "frac": ach / FP64_VALU_PEAK_TF, "traffic": traffic, "traffic_note": traffic_note,
+         "flop_per_launch": flops, "flop_per_interaction": FLOP_PER_INTERACTION,
+         "avg_launch_ms": t * 1e3, "launches_timed": walk_launches,
+         "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
+         "nodes_used_per_launch": cnt["nodes_used"], "targets_per_launch": cnt["targets"],
+         "algorithmic_bytes_per_launch": b_alg,
+         "hbm_measured_frac": (traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None,
+         "reuse": (b_alg / traffic) if traffic else None,
+         "walk_variant": variant, "list_capacity": list_cap, "targets_to_fallback_kernel": list_ovf,
+         "children_per_node_step": round(cnt["node_lanes"] / max(cnt["node_steps"], 1), 2),
+         "note": "one launch = one short-range walk over all targets; the walk is bound by fp64 VALU issue (pairwise kernel with a "
+                 "per-pair window-table lookup; MFMA does not apply), so frac = 38 flop x (N_pp + N_nodes_used) / t / 78.6 TFLOP/s; "
+                 "hbm_measured_frac = PMC traffic / t / 8 TB/s; reuse = SURVEY 8(d) B_walk / PMC traffic"}
+    return r
+
+
+def quick_gravity_steps(pkg, torch, eng, ic, n, nmesh, dev, steps=3):
+    """ms per force step of another input set of SURVEY 8(d) on the already configured engine (device-resident, as the headline)."""
+    pos, mass, box = getattr(pkg.ics, ic)(n)
+    N = len(pos)
+    d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
+    z3 = lambda: torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    gravpm, acc, prev, pot = z3(), z3(), z3(), torch.zeros(N, dtype=torch.float64, device=dev)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,
+                              FractionalGravitySoftening=1. / 30.)
+    eng.gravshort_set_softenings(box / n)
+    eng.dev_bind_particles(d_pos, d_mass, box)
+
+    def step():
+        nonlocal acc, prev
+        eng.dev_gravpm_force(gravpm, pot)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+    for _ in range(3):     # Barnes-Hut first walk, list-capacity adaptation, one relative-criterion walk
+        step()
+    torch.cuda.synchronize()
+    eng.walk_events_collect()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    wms, wl = eng.walk_events_collect()
+    return {"ms_per_step": round(1e3 * el / steps, 3), "particles_per_s": N * steps / el, "walk_ms": round(wms / max(wl, 1), 3), "steps": steps}
+
+
+def host_path_steps(pkg, eng, pos, mass, box, steps=3):
+    """SURVEY 8(d)'s metric as the reference's callers see it: the drop-in (host pointer) calls on struct particle_data records in
+    host memory, results written back into them - PCIe transfers and AoS packing included.  Not `value`."""
+    P = pkg.make_particles(pos, mass)
+    N = len(pos)
+    ts = []
+    for it in range(steps + 2):
+        t0 = time.perf_counter()
+        eng.gravpm_force(P)
+        t1 = time.perf_counter()
+        eng.force_tree_full(P, box)
+        t2 = time.perf_counter()
+        eng.grav_short_tree(P)
+        t3 = time.perf_counter()
+        ts.append((t1 - t0, t2 - t1, t3 - t2))
+    ts = np.array(ts[2:])      # the first two steps allocate the pinned staging and run the Barnes-Hut walk
+    tot = ts.sum(1).mean()
+    return {"ms_per_step": round(1e3 * tot, 2), "particles_per_s": N / tot,
+            "calls_ms": {"gravpm_force": round(1e3 * ts[:, 0].mean(), 2), "force_tree_full": round(1e3 * ts[:, 1].mean(), 2),
+                         "grav_short_tree": round(1e3 * ts[:, 2].mean(), 2)},
+            "note": "mpg_gravpm_force + mpg_force_tree_full + mpg_grav_short_tree on %d 160-byte particle_data records in pageable host "
+                    "memory (H2D of Pos/Mass, D2H of GravPM/FullTreeGravAccel/Potential, packing on host threads); the device-resident "
+                    "rate is `value`" % N}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,9 +143,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", "--size", dest="n", type=int, default=int(os.environ.get("MPG_BENCH_N", "0")),
                     help="particles per dimension (default: 256 per GPU, weak scaling)")
-    ap.add_argument("--ic", default="s_grid", choices=["s_grid", "s_zel", "s_clust"])
+    ap.add_argument("--ic", default="s_zel", choices=["s_grid", "s_zel", "s_clust"],
+                    help="synthetic input set (SURVEY 8(d)); s_zel, the Zel'dovich-displaced grid, is the headline set")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the other_inputs (s_grid, s_clust) and host_path (PCIe-inclusive drop-in calls) legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="targets walked by the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--mgpu", choices=["domain", "slab", "replicated"], default="domain",
@@ -268,17 +362,11 @@ def main():
     out = None
     if rank == 0:
         value = N * args.steps / elapsed
-        n_act = cnt["targets"]
-        b_alg = n_act * 64 + cnt["pp"] * 28 + cnt["nodes_visited"] * 72   # B_walk
-        walk_avg_ms = walk_ms / max(walk_launches, 1)
-        achieved = b_alg / (walk_avg_ms * 1e-3) / 1e9
-        flops = (cnt["pp"] + cnt["nodes_used"]) * 38.0
-        variant, list_cap, list_ovf = eng.walk_choice()
-        kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 5: "k_grav_walk_shared", 6: "k_walk_lists + k_walk_eval"}.get(variant, "?")
         traffic, traffic_note = None, "no PMC summary committed for this configuration"
         tpath = os.path.join(ROOT, "profiles", "walk_traffic.json")
-        if os.path.exists(tpath) and N == 256 ** 3 and args.ic == "s_grid":
-            tj = json.load(open(tpath)).get("variants", {}).get(str(variant))
+        variant = eng.walk_choice()[0]
+        if os.path.exists(tpath) and N == 256 ** 3 and world == 1:
+            tj = json.load(open(tpath)).get("by_ic", {}).get(args.ic, {}).get(str(variant))
             if tj:
                 traffic = tj["hbm_bytes_per_launch"]
                 traffic_note = "bytes per walk (%s) from %s" % (tj["kernel"], tj["method"])
@@ -296,22 +384,7 @@ def main():
                         "%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
                         "replicated, one all-gather of accelerations" % world if args.mgpu == "slab" else
                         "targets sharded over %d GPUs (tree-order ranges), PM and tree replicated, all-gather of accelerations" % world)},
-            "roofline": {"bound": "hbm", "kernel": kernels, "walk_variant": variant, "list_capacity": eng.walk_choice()[1],
-                         "targets_to_fallback_kernel": eng.walk_choice()[2], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": b_alg, "avg_launch_ms": walk_avg_ms, "launches_timed": walk_launches,
-                         "pp_interactions_per_launch": cnt["pp"], "nodes_visited_per_launch": cnt["nodes_visited"],
-                         "fp64_valu": {"achieved": round(flops / (walk_avg_ms * 1e-3) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
-                                       "frac": round(flops / (walk_avg_ms * 1e-3) / 1e12 / 78.6, 4),
-                                       "note": "the bound that applies: 38 flop per pair or node interaction (the node tests of the "
-                                               "traversal not counted) against the fp64 vector peak; profiles/*/summary.txt: VALU busy "
-                                               "88 % of the kernels' cycles"},
-                         "nodes_used_per_launch": cnt["nodes_used"], "children_per_node_step": round(cnt["node_lanes"] / max(cnt["node_steps"], 1), 2),
-                         "note": "one launch = one short-range walk over all targets (variant 6: list-construction + evaluation "
-                                 "kernel pairs over slices of 2^21 targets); algorithmic bytes = N_act*64 + N_pp*28 + N_node*72 "
-                                 "(SURVEY 8(d)); reuse through L1/L2/LDS makes this exceed HBM traffic; the walk is bound by fp64 "
-                                 "VALU issue and the vector-memory pipe, not HBM: %.1f TFLOP/s fp64-equivalent (38 flop per "
-                                 "interaction) of 78.6 peak" % (flops / (walk_avg_ms * 1e-3) / 1e12)},
+            "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
             "phases_ms": {k: round(v, 3) for k, v in ph.items()},
         }
         if pm_ms[1]:
@@ -321,6 +394,15 @@ def main():
         if world == 1 and not multi and not args.no_cpu_baseline:    # (MPG_FORCE_MGPU frees the full arrays: no baseline leg)
             out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
                                                args.cpu_sample)
+        if world == 1 and not multi and not args.no_extras:
+            # the other input sets of SURVEY 8(d) at the same size, and the PCIe-inclusive drop-in path (untimed legs: after `value`)
+            host_pos = d_pos.cpu().numpy()
+            del gravpm, acc, prev, pot
+            out["host_path"] = host_path_steps(pkg, eng, host_pos, mass, box)
+            del d_pos, d_mass, host_pos
+            torch.cuda.empty_cache()
+            out["other_inputs"] = {ic: quick_gravity_steps(pkg, torch, eng, ic, n, nmesh, dev)
+                                   for ic in ("s_grid", "s_zel", "s_clust") if ic != args.ic}
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -722,10 +804,44 @@ def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
     return out
 
 
+def host_cpu_info():
+    """(physical cores, logical cpus, model name) of this box from /proc/cpuinfo."""
+    cores, model, logical = set(), "unknown", 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return (len(cores) or os.cpu_count() or 1), (logical or os.cpu_count() or 1), model
+
+
 def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
-    """The CPU "port": oracle built with the reference's flags (-O3 -ffast-math -fopenmp), all host cores.
-    Bounded sample: full tree build (single thread, like one reference rank) + the short-range walk for `sample`
-    targets scaled to N; the PM part (about 10 % of a reference step) is left out, which favours the CPU."""
+    """The CPU "port" (SURVEY 8(d) "CPU baseline timing"): the oracle built with the reference's flags (-O3 -ffast-math -fopenmp),
+    one process, OMP_NUM_THREADS = the physical cores this process may use, OMP_PROC_BIND=spread.  Bounded sample: the full tree
+    build + the short-range walk for `sample` targets that are CONTIGUOUS IN TREE (Morton) ORDER (the reference walks its
+    particles in Peano-Hilbert order, so neighbouring threads share nodes in cache), median of 3 walks after a warm-up, scaled to N;
+    the PM part (about 10 % of a reference step) is left out, which favours the CPU."""
+    phys, logical, model = host_cpu_info()
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    threads = max(1, min(phys, usable))
+    # libgomp reads these when it is loaded (the oracle library is the first OpenMP user in this process)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ["OMP_PROC_BIND"] = "spread"
+    os.environ["OMP_PLACES"] = "cores"
     from oracle import oracle as O
     orc = O.Oracle(fast=True)
     orc.fill_ntab(0, 1.5)
@@ -737,15 +853,36 @@ def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
     par.TreeUseBH = 0
     old = np.sqrt((aold_vec ** 2).sum(1)) / G
     sample = min(sample, N)
-    act = np.arange(sample, dtype=np.int32)
-    tr.grav_short_tree(par, oldacc=old, active=act[:4096])   # warm-up
-    t0 = time.perf_counter()
-    tr.grav_short_tree(par, oldacc=old, active=act)
-    t_walk = time.perf_counter() - t0
+    # Morton order of the particles (10 bits per axis are enough to make consecutive targets neighbours)
+    q = np.minimum((pos / box * 1024).astype(np.int64), 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+    morton = (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+    order = np.argsort(morton, kind="stable").astype(np.int32)
+    del q, morton
+    start = (N - sample) // 2
+    act = np.ascontiguousarray(order[start:start + sample])
+    tr.grav_short_tree(par, oldacc=old, active=act[:65536])   # warm-up
+    walks, pp = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, c, _ = tr.grav_short_tree(par, oldacc=old, active=act)
+        walks.append(time.perf_counter() - t0)
+        pp = int(c[0])     # counters: (pair interactions, nodes visited, nodes used)
+    t_walk = float(np.median(walks))
     t_full = t_tree + t_walk * N / sample
-    return {"value": N / t_full, "unit": "particles/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "oracle (gcc -O3 -ffast-math -fopenmp): tree build of all %d particles (%.1f s, 1 thread) + short-range walk "
-                      "of %d targets (%.1f s, %d threads) scaled to N; PM excluded" % (N, t_tree, sample, t_walk, orc.num_threads())}
+    out = {"value": N / t_full, "unit": "particles/s", "cores": orc.num_threads(), "kind": "port",
+           "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "omp": "OMP_PROC_BIND=spread OMP_PLACES=cores",
+           "walk_s_median_of_3": round(t_walk, 3), "walk_s_all": [round(w, 3) for w in walks], "tree_build_s": round(t_tree, 3),
+           "sample": "oracle (gcc -O3 -ffast-math -fopenmp): tree build of all %d particles (%.2f s) + short-range walk of %d "
+                     "tree-ordered targets (median of 3: %.2f s, %d threads) scaled to N; PM excluded" % (N, t_tree, sample, t_walk, orc.num_threads())}
+    if pp:
+        out["pairs_per_s_per_thread"] = pp / t_walk / orc.num_threads()
+    return out
 
 
 if __name__ == "__main__":

@@ -306,7 +306,14 @@ std::vector<Attr> read_attrs(const std::string &dir)
         a.name = name;
         a.dtype = normalize_dtype(token().c_str());
         a.nmemb = atoi(token().c_str());
-        const std::string raw = token();
+        // "%s %s %d %s #HUMANE [ %s ]" (bigfile.c:1615): a zero-length attribute has an empty hex field, so the next token on its
+        // line is the "#HUMANE" comment - not data
+        std::string raw;
+        if(a.nmemb > 0) {
+            raw = token();
+            if(!raw.empty() && raw[0] == '#')
+                raw.clear();
+        }
         while(i < buf.size() && buf[i] != '\n')
             i++;
         const size_t nbytes = (size_t)a.nmemb * (size_t)itemsize(a.dtype);

@@ -67,24 +67,24 @@ def needed_columns(box, nmesh, world, La, margin):
 
 
 def _pack_rows(tensors, idx):
-    """Rows `idx` of several per-particle tensors ([n] or [n, k], any dtype) side by side in one float64 buffer."""
+    """Rows `idx` of several per-particle tensors ([n] or [n, k], any dtype) side by side as BYTES in one uint8 buffer
+    [len(idx), row bytes]: nothing is converted, so 64-bit integer columns (IDs with the generation in bits 56+, keys) survive
+    bit for bit.  The reference ships whole 160-byte particle_data records (exchange.c)."""
     cols = []
     for t in tensors:
-        w = 1
-        for d in t.shape[1:]:
-            w *= int(d)
-        cols.append(t[idx].reshape(idx.shape[0], w).to(torch.float64))
+        r = t[idx].contiguous()
+        cols.append(r.view(torch.uint8).reshape(idx.shape[0], -1))
     return torch.cat(cols, dim=1).contiguous() if len(cols) > 1 else cols[0].contiguous()
 
 
 def _unpack_rows(buf, like):
-    """Inverse of _pack_rows for the received buffer: one tensor per entry of `like` (shape[1:] and dtype taken from it)."""
+    """Inverse of _pack_rows for the received byte buffer: one tensor per entry of `like` (shape[1:] and dtype taken from it)."""
     out, c = [], 0
     for t in like:
-        w = 1
+        w = t.element_size()
         for d in t.shape[1:]:
             w *= int(d)
-        out.append(buf[:, c:c + w].reshape((buf.shape[0],) + tuple(t.shape[1:])).to(t.dtype))
+        out.append(buf[:, c:c + w].contiguous().view(t.dtype).reshape((buf.shape[0],) + tuple(t.shape[1:])))
         c += w
     return out
 

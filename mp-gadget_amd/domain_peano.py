@@ -39,10 +39,9 @@ class DomainPolicy:
 
     def __init__(self, i, ntask, overdecomposition=4):
         self.PreSort = 1 if i >= 2 else 0
-        d = 256
-        for k in range(5, i + 1):
-            if d > 2:
-                d //= 2
+        d = 256                                  # policies[k].SubSampleDistance for k = 0 .. i: 256 unless k > 4 and the previous
+        for k in range(1, i + 1):                # policy's distance is above 2 (then half of it): 256 x5, 128 ... 2, 256, 128, 64, 32
+            d = d // 2 if (k > 4 and d > 2) else 256
         self.SubSampleDistance = d
         self.NTopLeaves = overdecomposition * ntask * (i + 1)
 

@@ -36,6 +36,14 @@ def _scratch(*shape, **kw):
     return torch.empty(*shape, **kw)
 
 
+def _has_all_to_all(group=None):
+    """RCCL ("nccl") has all_to_all_single / all_gather_into_tensor on device tensors; gloo (the CPU-launched tests that put several
+    ranks on one GPU) does not: there the exchanges gather everything and slice.  The path is chosen ONCE from the backend - not by
+    catching errors, which would let one rank's genuine failure (out of memory, bad sizes) drop it into a different collective
+    than its peers are in."""
+    return dist.get_backend(group) == "nccl"
+
+
 def _all_to_all(recv, send, world, group=None):
     """recv[s-th block] <- rank s's send[my block].  RCCL all_to_all_single; backends without it (gloo, used by the
     CPU-launched tests that put two ranks on one GPU) gather everything and slice."""
@@ -56,11 +64,9 @@ def _all_to_all(recv, send, world, group=None):
             _all_to_all(got.view(-1), part.view(-1), world, group)
             rv[:, c:c + piece] = got
         return
-    try:
-        dist.all_to_all_single(recv, send, group=group)
+    if _has_all_to_all(group):
+        dist.all_to_all_single(recv, send, group=group)      # errors propagate: every rank must stay in the same collective
         return
-    except (RuntimeError, NotImplementedError):
-        pass
     rank = dist.get_rank(group)
     parts = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(parts, send, group=group)
@@ -86,11 +92,9 @@ def exchange_rows(send, counts, world, group=None, allc=None):
     rank = dist.get_rank(group)
     recv_counts = [int(allc[s][rank]) for s in range(world)]
     out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
-    try:
+    if _has_all_to_all(group):
         dist.all_to_all_single(out, send, recv_counts, list(counts), group=group)
         return out
-    except (RuntimeError, NotImplementedError):
-        pass
     nmax = int(allc.sum(1).max())
     pad = torch.zeros((nmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=dev)
     pad[:send.shape[0]] = send
@@ -222,9 +226,9 @@ class TargetExchange:
         self.sv[:n] = values[targets.long()]
         self.si[:n] = targets
         for g, s in ((self.gv, self.sv), (self.gi, self.si)):
-            try:
+            if _has_all_to_all(self.group):
                 dist.all_gather_into_tensor(g, s, group=self.group)
-            except (RuntimeError, NotImplementedError):
+            else:
                 parts = [torch.empty_like(s) for _ in range(self.world)]
                 dist.all_gather(parts, s, group=self.group)
                 for r in range(self.world):

@@ -35,9 +35,9 @@ def exchange_results(values, order, rank, world, sbuf=None, gbuf=None, group=Non
     if gbuf is None:
         gbuf = torch.zeros((world * chunk,) + tuple(values.shape[1:]), dtype=values.dtype, device=values.device)
     sbuf[:hi - lo] = values[order[lo:hi].long()]
-    try:
+    if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(gbuf, sbuf, group=group)
-    except (RuntimeError, NotImplementedError):
+    else:
         # backends without the flat form (gloo on device tensors): gather a list and copy
         parts = [torch.empty_like(sbuf) for _ in range(world)]
         dist.all_gather(parts, sbuf, group=group)

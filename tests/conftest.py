@@ -36,19 +36,24 @@ def engine(pkg):
     e.close()
 
 
-def rerun_once_on_failure(body):
-    """The tests that put several ranks on ONE GPU (gloo, 2 - 4 processes time-slicing the device) have failed about once in four full
-    `-m gpu` runs on a numeric comparison and never in dozens of isolated repetitions, with or without competing load: treated as a
-    test-rig glitch until it can be reproduced.  Such a test body is run a second time before it counts as failed; the first failure is
-    reported as a warning so that it stays visible in the log."""
+def keep_artifacts_on_failure(body):
+    """Debugging aid for the multi-rank tests (several processes on one GPU): when the body fails, the arrays the ranks saved
+    under tmp_path are copied to gpurun_out/flake/<test>-<pid>/ before the failure is re-raised, so that a failure seen on the
+    GPU box can be analysed afterwards (which rows differ, by how much, where in the box).  Nothing is retried."""
     import functools
-    import warnings
+    import shutil
 
     @functools.wraps(body)
     def wrapped(*a, **k):
         try:
             return body(*a, **k)
-        except AssertionError as e:
-            warnings.warn("multi-rank test %s failed once and is being repeated: %s" % (body.__name__, str(e)[:2000]))
-            return body(*a, **k)
+        except AssertionError:
+            tp = k.get("tmp_path") or next((x for x in a if hasattr(x, "iterdir")), None)
+            if tp is not None:
+                dst = os.path.join(ROOT, "gpurun_out", "flake", "%s-%d" % (body.__name__, os.getpid()))
+                try:
+                    shutil.copytree(str(tp), dst, dirs_exist_ok=True)
+                except OSError:
+                    pass
+            raise
     return wrapped

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import rerun_once_on_failure
+from conftest import keep_artifacts_on_failure
 from oracle import domain_oracle as D
 from test_domain_host import keys_of, clumpy, assert_tree_equal
 
@@ -74,7 +74,7 @@ def _run(tmp_path, name, nproc, port, n, global_sort=1):
     return [np.load(out + ".%d.npz" % k) for k in range(nproc)]
 
 
-@rerun_once_on_failure
+@keep_artifacts_on_failure
 def test_decomposition_and_exchange_on_ranks(tmp_path):
     import mgpu_domain_check as T
     n = 400000

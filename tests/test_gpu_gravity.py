@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rerun_once_on_failure
+from conftest import keep_artifacts_on_failure
 
 from oracle import oracle as O
 
@@ -304,6 +304,32 @@ def test_error_behaviour(pkg, engine):
         engine.grav_short_tree(P)                                 # gravshort-tree.c:113-114
 
 
+@pytest.mark.parametrize("kind", ["close", "random", "random2"])
+def test_reference_force_accuracy_vs_direct_sum_on_gpu(pkg, engine, orc, kind):
+    """The reference's own acceptance test of this path, do_force_test + check_against_force_direct (test_gravity.c:146-219), run on
+    the engine through the drop-in calls: 16^3 particles in a box of 8, Nmesh 48, Asmth 1.5, Rcut 7, Barnes-Hut opening on both
+    walks; PM + tree against the direct sum over 27 images: max relative error < 3 ErrTolForceAcc, mean < 0.8 ErrTolForceAcc.
+    "random" / "random2" are the two particle sets test_force_random draws from gsl_rng_mt19937 (seed 0), regenerated bit for bit
+    by oracle/mt19937.py."""
+    from test_oracle_kat import _test_gravity_sets
+    pos, mass, box, n = _test_gravity_sets(kind)
+    nmesh, err = 48, 0.002
+    engine.gravshort_fill_ntab(0, 1.5)
+    engine.gravpm_init_periodic(box, 1.5, nmesh, G)
+    engine.set_gravshort_treepar(ErrTolForceAcc=err, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.0, TreeUseBH=1, Rcut=7.0)
+    engine.gravshort_set_softenings(box / n)
+    P = pkg.make_particles(pos, mass)
+    engine.gravpm_force(P)
+    engine.force_tree_full(P, box)
+    engine.grav_short_tree(P)
+    engine.grav_short_tree(P)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    direct = orc.force_direct(pos, mass, box, par.h, G)
+    relerr = np.abs(direct - (P["GravPM"] + P["FullTreeGravAccel"])) / np.abs(direct).mean()
+    assert relerr.max() < 3 * err, relerr.max()
+    assert relerr.mean() < 0.8 * err, relerr.mean()
+
+
 def test_load_order_torch_first():
     """The library must also work when torch (with its bundled HIP runtime) was imported first."""
     import subprocess
@@ -332,7 +358,7 @@ def _run_mgpu(tmp_path, name, nproc, mode, port, ic="s_zel"):
     return np.load(out)
 
 
-@rerun_once_on_failure
+@keep_artifacts_on_failure
 def test_two_ranks_match_one(tmp_path):
     """N > 1 paths with the real kernels; two ranks (gloo, sharing this GPU).
     replicated: each rank walks half of the tree-order slots, one all-gather -> exactly the single-rank accelerations.
@@ -358,7 +384,7 @@ def test_two_ranks_match_one(tmp_path):
         assert np.abs(dm[:, 6] - one[:, 6]).max() <= 1e-11 * np.abs(one[:, 6]).mean(), name
 
 
-@rerun_once_on_failure
+@keep_artifacts_on_failure
 def test_distributed_particles_clustered(tmp_path):
     """The distributed-particle path on a strongly clustered set (deep tree, thousands of nodes used unopened per target, very
     unequal slabs): 2 and 4 ranks against one GPU."""

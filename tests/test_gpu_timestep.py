@@ -3,7 +3,7 @@ compiled without FMA contraction, like the reference's loops), error codes inclu
 import numpy as np
 import pytest
 
-from conftest import rerun_once_on_failure
+from conftest import keep_artifacts_on_failure
 
 from oracle import oracle as O
 from test_oracle_timestep import make_set
@@ -115,7 +115,7 @@ def test_three_force_kick_drift_steps_track_the_oracle(pkg, engine, orc):
     assert moved > 0.02 * box / n                                   # the particles did move: the tree of step 3 is not the tree of step 1
 
 
-@rerun_once_on_failure
+@keep_artifacts_on_failure
 def test_distributed_evolution_matches_one_gpu(tmp_path):
     """A complete distributed loop - ghost import, tree with the global top, slab PM, walk, kicks, drift, particle migration - for
     three steps on 2 and 4 ranks (sharing this GPU over gloo) against the same three steps on one GPU."""

@@ -227,10 +227,17 @@ def _migrate_worker(rank, world, port, q):
     g = torch.Generator().manual_seed(11)
     pos = torch.rand(3000, 3, dtype=torch.float64, generator=g) * box      # the same global set on every rank
     ids = torch.arange(3000, dtype=torch.float64)
+    # 64-bit IDs as the reference's stars / black holes carry them: Generation in bits 56+ (not representable in a double),
+    # one byte-wide and one float32 column as well: every column must arrive bit for bit
+    big = (torch.arange(3000, dtype=torch.int64) * 2654435761 + 12345) | (torch.arange(3000, dtype=torch.int64) % 5 + 1 << 56) | 1
+    typ8 = (torch.arange(3000) % 6).to(torch.uint8)
+    m32 = torch.rand(3000, dtype=torch.float32, generator=g)
     own = dom.select_own(pos)
     p, i = pos[own].clone(), ids[own].clone()
     p[:, 0] = torch.remainder(p[:, 0] + 1.7, box)                          # a "drift" that carries many particles across slab faces
-    p2, i2 = dom.migrate(p, (i,))
+    p2, i2, big2, typ2, m2 = dom.migrate(p, (i, big[own].clone(), typ8[own].clone(), m32[own].clone()))
+    assert big2.dtype == torch.int64 and typ2.dtype == torch.uint8 and m2.dtype == torch.float32
+    okb = bool(torch.equal(big2, big[i2.long()]) and torch.equal(typ2, typ8[i2.long()]) and torch.equal(m2, m32[i2.long()]))
     owner = pkg.pm_slab.slab_of_cells(p2[:, 0], box / nmesh, nmesh, world)
     ok = bool((owner == rank).all())
     # global check: every id exactly once, carried with its own position
@@ -240,7 +247,7 @@ def _migrate_worker(rank, world, port, q):
     ok &= bool((cnt == 1).all())
     exp = pos[i2.long()].clone()
     exp[:, 0] = torch.remainder(exp[:, 0] + 1.7, box)
-    ok &= bool(torch.equal(exp, p2))
+    ok &= bool(torch.equal(exp, p2)) and okb
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -45,16 +45,15 @@ def _test_gravity_sets(kind):
         pos = np.stack([(8.0 / n) * (i // n // n), (8.0 / n) * ((i // n) % n), (8.0 / n) * (i % n)], 1).astype(np.float64)
     elif kind == "close":   # test_gravity.c:270-276
         pos = np.stack([4. + (i // n // n) / 5000., 4. + ((i // n) % n) / 5000., 4. + (i % n) / 5000.], 1)
-    else:                   # three populations, test_gravity.c:283-305 (numpy MT19937 instead of gsl's draw order)
-        rng = np.random.RandomState(0)
-        pos = np.empty((N, 3))
-        pos[:N // 4] = 8.0 * rng.random_sample((N // 4, 3))
-        pos[N // 4:3 * N // 4] = 4.0 + 1.0 * np.exp((rng.random_sample((N // 2, 3)) - 0.5) ** 2)
-        pos[3 * N // 4:] = 0.8 + 0.25 * np.exp((rng.random_sample((N - 3 * N // 4, 3)) - 0.5) ** 2)
+    else:                   # three populations, test_gravity.c:283-305: gsl_rng_mt19937, gsl_rng_set(r, 0), one 32-bit draw / 2^32
+        from oracle.mt19937 import GslMT19937, three_population_set
+        rng = GslMT19937(0)
+        for _ in range(1 if kind == "random" else 2):     # test_force_random calls do_random_test twice on the same generator
+            pos = three_population_set(rng, N, 8.0)
     return pos, np.ones(N, np.float32), 8.0, n
 
 
-@pytest.mark.parametrize("kind", ["close", "random"])
+@pytest.mark.parametrize("kind", ["close", "random", "random2"])
 def test_reference_force_accuracy_vs_direct_sum(orc, kind):
     """do_force_test + check_against_force_direct of test_gravity.c:162-219,146-160 (Nmesh 48, Asmth 1.5, Rcut 7, BH twice)."""
     pos, mass, box, n = _test_gravity_sets(kind)
@@ -150,3 +149,16 @@ def test_pm_oracle_point_mass_pair():
     assert gpm[0, 0] > 0 and gpm[1, 0] < 0
     assert np.allclose(gpm[0], -gpm[1], atol=1e-12 * np.abs(gpm).max())
     assert np.all(pot < 0) or np.allclose(pot[0], pot[1])
+
+
+def test_gsl_mt19937_restatement():
+    """oracle/mt19937.py against the algorithm's published outputs (seed 5489: first three draws and the 10000th, the check value of
+    the C++ standard's mt19937) and against numpy's independent implementation of the same 32-bit stream (gsl's default seed 4357)."""
+    from oracle.mt19937 import GslMT19937
+    x = GslMT19937(5489).get(10000)
+    assert list(x[:3]) == [3499211612, 581869302, 3890346734] and x[9999] == 4123659995
+    y = np.random.RandomState(4357).randint(0, 2 ** 32, size=5000, dtype=np.uint64).astype(np.uint32)
+    g = GslMT19937(0)                                         # gsl_rng_set(r, 0) -> default seed 4357
+    assert np.array_equal(np.concatenate([g.get(1000), g.get(4000)]), y)
+    u = GslMT19937(0).uniform(4)
+    assert np.all((u >= 0) & (u < 1)) and u[0] == y[0] / 4294967296.0

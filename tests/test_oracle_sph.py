@@ -56,6 +56,11 @@ def density_test_set(kind):
     typ = np.zeros(N, np.int32)
     if kind == "flat":      # test_density.c:154-170
         pos = np.stack([(box / n) * (i // n // n), (box / n) * ((i // n) % n), (box / n) * (i % n)], 1).astype(np.float64)
+    elif kind.startswith("random"):   # do_random_test, test_density.c:206-235: gsl_rng_mt19937 seed 0, called twice on one generator
+        from oracle.mt19937 import GslMT19937, three_population_set
+        rng = GslMT19937(0)
+        for _ in range(2 if kind == "random2" else 1):
+            pos = three_population_set(rng, N, box)
     else:                   # test_density_close, test_density.c:172-204
         close = 500.
         pos = np.empty((N, 3))
@@ -85,10 +90,13 @@ def run_reference_density_test(orc, kind, dev=2.0):
     return A, tr2, dp, t, st
 
 
-@pytest.mark.parametrize("kind,expected", [("flat", 0.501747), ("close", 0.131726)])
-def test_reference_mean_hsml_known_answer(orc, kind, expected):
-    A, tr2, dp, t, st = run_reference_density_test(orc, kind)
-    assert abs(A.hsml.mean() - expected) < 1e-4, A.hsml.mean()
+@pytest.mark.parametrize("kind,expected,tol", [("flat", 0.501747, 1e-4), ("close", 0.131726, 1e-4), ("random", 0.187515, 1e-3),
+                                               ("random2", 0.187515, 1e-3)])
+def test_reference_mean_hsml_known_answer(orc, kind, expected, tol):
+    # the cmocka group shares one parameter block: test_density_flat (the first test) leaves MaxNumNgbDeviation at 0.5
+    # (test_density.c:131-132), so the close and random sets run BOTH their passes with 0.5
+    A, tr2, dp, t, st = run_reference_density_test(orc, kind, dev=2.0 if kind == "flat" else 0.5)
+    assert abs(A.hsml.mean() - expected) < tol, A.hsml.mean()
     gas = A.type == 0
     assert np.all(np.isfinite(A.hsml)) and np.all(np.isfinite(A.density[gas])) and np.all(A.density[gas] > 0)
     assert A.hsml.min() >= 0.006 and A.hsml.max() <= 8.0      # check_densities, test_density.c:35-53

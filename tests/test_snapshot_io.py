@@ -179,3 +179,16 @@ def test_files_written_here_are_read_by_the_reference_library(snap, tmp_path):
     assert ref_get_attr(L, path, "Header", "TotNumPart", np.uint64, "u8", 6).tolist() == [0, 4097, 0, 0, 0, 0]
     assert ref_get_attr(L, path, "Header", "BoxSize", np.float64, "f8", 1)[0] == 8000.0
     assert ref_get_attr(L, path, "Header", "Time", np.float64, "f8", 1)[0] == 0.25
+
+
+def test_zero_length_attribute_does_not_break_the_block(snap, tmp_path):
+    """bigfile writes "name dtype 0  #HUMANE [  ]" for an attribute with no members (bigfile.c:1615): the "#HUMANE" token is a
+    comment, not the hex field - the other attributes of the block must stay readable and writable."""
+    d = tmp_path / "S" / "Header"
+    d.mkdir(parents=True)
+    (d / "header").write_text("DTYPE: <i8\nNMEMB: 1\nNFILE: 0\n")
+    (d / "attr-v2").write_text("Empty <S1 0  #HUMANE [  ]\nTime <f8 1 000000000000D03F #HUMANE [ 0.25 ]\n")
+    path = str(tmp_path / "S")
+    assert snap.get_attr(path, "Header", "Time", "f8")[0] == 0.25
+    snap.set_attr(path, "Header", "BoxSize", 8.0, "f8")
+    assert snap.get_attr(path, "Header", "BoxSize", "f8")[0] == 8.0 and snap.get_attr(path, "Header", "Time", "f8")[0] == 0.25
