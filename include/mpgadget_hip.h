@@ -510,6 +510,79 @@ int mpg_dev_pm_slab_inverse_c(mpg_engine *eng, const double *recvB, double *ghos
 int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int *d_targets, int64_t ntargets, double *d_gravpm,
                             double *d_potential);
 
+/* ---- the force step on several ranks behind the CALLER's communicator ------------------------------------------------------
+ * The reference's entry points are collective over MPI_COMM_WORLD (gravity.h:40,55; forcetree.h:115-148; treewalk.c:801-902;
+ * petapm.c:584-885; domain.c:153-258; exchange.c).  This library links neither MPI nor RCCL: the caller hands it the three
+ * collectives the path needs as callbacks over its own communicator (run.c: MPI_Allreduce / MPI_Alltoall / MPI_Alltoallv;
+ * the Python host side: torch.distributed = RCCL over xGMI), and every rank calls the mpg_dist_* functions collectively, as it
+ * calls gravpm_force / force_tree_full / grav_short_tree today.  All choreography (what is sent where, in which order) is in
+ * the library (csrc/dist.hip); a callback only moves bytes.
+ *
+ * Particles live on the rank that owns their Peano-Hilbert TopLeaf (domain_decompose_full).  Per force step:
+ *   PM     every particle's {Pos, Mass} goes to the rank(s) owning the x-planes its CIC cloud touches (32 B per particle: an
+ *          eighth of what the reference's region meshes cost at Nmesh = 2 N^(1/3)); slab FFT with two all-to-all transposes;
+ *          GravPM / Potential return to the owners.
+ *   tree   a rank imports, as ghosts, the particles of every level-La tree cell within Rcut of its TopLeaves (whole cells: the
+ *          local tree equals the global one at levels >= La); the nodes above get their moments from an all-reduce and are
+ *          kept internal down to level La, the counterpart of the reference's replicated top-tree with pseudo nodes
+ *          (forcetree.c:654-723, 1145-1284).  Ghost import replaces the export of walk targets (treewalk.c:325-793): the
+ *          interaction sets are the same, there is no return trip.
+ * Callback contract: return 0 on success; `on_device` says whether the buffers are device pointers (only if device_buffers
+ * was set; otherwise the library stages through pinned host memory).  Counts and displacements are in BYTES. */
+typedef struct mpg_comm {
+    void *ctx;                 /* handed back to every callback (e.g. the MPI_Comm) */
+    int ThisTask, NTask;       /* NTask <= 64 */
+    int device_buffers;        /* 1: alltoallv / allreduce accept device pointers (RCCL, GPU-aware MPI) */
+    /* MPI_Allreduce(MPI_IN_PLACE, buf, count, dtype ? MPI_INT64_T : MPI_DOUBLE, op ? MPI_MAX : MPI_SUM) */
+    int (*allreduce)(void *ctx, void *buf, int64_t count, int dtype, int op, int on_device);
+    /* MPI_Alltoall of ONE int64 per peer, host memory */
+    int (*alltoall_i64)(void *ctx, const int64_t *send, int64_t *recv);
+    /* MPI_Alltoallv of bytes */
+    int (*alltoallv)(void *ctx, const void *send, const int64_t *sendbytes, const int64_t *sdispls, void *recv, const int64_t *recvbytes,
+                     const int64_t *rdispls, int on_device);
+} mpg_comm;
+
+typedef struct mpg_dist mpg_dist;
+/* eng: configured as for one rank (mpg_gravpm_init_periodic with the GLOBAL Nmesh, tables, tree parameters, softening);
+ * Nmesh % NTask == 0.  The comm struct is copied. */
+int mpg_dist_create(mpg_dist **out, mpg_engine *eng, const mpg_comm *comm);
+void mpg_dist_destroy(mpg_dist *d);
+/* The domain the ranks' particles were distributed by: the TopNodes of domain_decompose_full (same on every rank) and the Task
+ * of every TopLeaf (DomainDecomp.TopNodes / TopLeaves, domain.h:12-43).  margin: at least Rcut in length units (the walk's
+ * cut-off, gravshort-tree.c:102) and, for SPH, the largest smoothing length; La = 0 picks the level whose cells are
+ * [margin, 2 margin) wide. */
+int mpg_dist_set_domain(mpg_dist *d, double BoxSize, const mpg_topnode *TopNodes, int NTopNodes, const int *leaf_task, int NTopLeaves,
+                        double margin, int La);
+/* gravpm_force + force_tree_full + grav_short_tree for the rank's OWN particles (device arrays, n_own rows; all active).
+ * d_prev_accel (may be NULL): last step's FullTreeGravAccel for the relative opening criterion, else d_oldacc (|a|/G per
+ * particle, may be NULL -> Barnes-Hut walk if TreeUseBH says so).  Outputs: d_gravpm[n_own][3] assigned, d_accel[n_own][3]
+ * assigned, d_potential[n_own] (may be NULL) = PM + tree potential as the reference leaves it in P[].Potential. */
+int mpg_dist_gravity_step(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, const double *d_oldacc,
+                          const double *d_prev_accel, double *d_accel, double *d_gravpm, double *d_potential, double rho0);
+/* The three entry points separately, in the reference's order (run.c:522-548) - gravity_step is exactly this sequence:
+ *   gravpm_force (gravity.h:55)          -> GravPM assigned, Potential accumulated (readout_potential, gravpm.c:499-501)
+ *   force_tree_full (forcetree.h:115)    -> ghost import, local tree with the global top
+ *   grav_short_tree (gravity.h:40)       -> accelerations of all own particles (and the tree potential, assigned) */
+int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, double *d_gravpm, double *d_potential);
+int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass);
+int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm, double *d_accel,
+                                 double *d_potential, double rho0);
+/* ... and as drop-in calls on the rank's particle table in host memory (what libgadget's callers hand over; shim/gravity-hip.c):
+ * Pos / Mass are read from P[], GravPM / FullTreeGravAccel / Potential (and AccelStore, may be NULL) are written as the reference's
+ * functions write them; OldAcc of the walk comes from P[].FullTreeGravAccel + P[].GravPM.  All particles active (a PM step). */
+int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *P);
+int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P);
+int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0);
+/* what the last step moved: [0] ghosts imported, [1] particles shipped to PM slabs, [2] local tree particles (own + ghosts),
+ * [3] decomposition level La, [4] bytes sent in personalised exchanges, [5] bytes sent in transposes */
+int mpg_dist_get_stats(mpg_dist *d, int64_t stats[8]);
+/* phase times of the last step in ms (host clock around stream synchronisations): [0] PM shipping + slab PM, [1] ghost import,
+ * [2] tree build + global top, [3] walk */
+int mpg_dist_get_times(mpg_dist *d, double ms[8]);
+/* cells of the tree above this level are kept internal (never leaves) by the next tree builds; 0 restores forcetree.c's rule.
+ * Used by the distributed step; exposed for tests. */
+int mpg_dev_force_tree_set_min_leaf_level(mpg_engine *eng, int level);
+
 /* Tuning knobs of the walk; results do not depend on any of them.
  *   variant   0 = auto (default): time kernels 1, 4 and 6 once on a large walk and keep the fastest (re-tuned every 64 walks);
  *             1 = lane-per-target while-while kernel (grav_walk.hip); 4 = group-cooperative list kernel (grav_walk_coop.hip);

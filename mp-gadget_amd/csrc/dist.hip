@@ -1,0 +1,962 @@
+// dist.hip -- the force step on several ranks (one process per GPU) behind the caller's communicator: mpg_dist_* of
+// include/mpgadget_hip.h.
+//
+// The reference's gravpm_force / force_tree_full / grav_short_tree are collective over MPI_COMM_WORLD: particles live on the
+// rank that owns their Peano-Hilbert TopLeaf (domain.c:153-258), petapm ships region meshes to 2-D pencils and back
+// (petapm.c:584-885), the force tree hangs local sub-trees under a replicated top-tree whose remote leaves are pseudo nodes
+// (forcetree.c:654-723, 1145-1284) and the walk exports targets to the owners of the pseudo nodes they open
+// (treewalk.c:325-793).  Here, MI355X-first (288 GB per GPU, xGMI point-to-point links):
+//
+//   PM    {Pos, Mass} of every particle (32 B) goes to the rank(s) owning the x-planes its CIC cloud touches - at Nmesh = 2 N^(1/3)
+//         a particle is an eighth of the mesh cells it deposits on, so shipping particles beats shipping region meshes -, the
+//         slab solver of pm.hip runs on what arrived (two all-to-all transposes, five neighbour planes), and {GravPM, Potential}
+//         (32 B) returns along the same lists.
+//   tree  a rank imports the particles of every level-La tree cell within `margin` (>= Rcut) of its TopLeaves: WHOLE cells, so
+//         that every node at level >= La a target can reach is complete and identical to the global tree's; cells that are not
+//         imported lie more than Rcut from every own target, where the walk discards on geometry alone.  Nodes above level La
+//         hold remote particles: they are kept internal (TreeBuilder::force_internal_above) and their moments are the
+//         all-reduced sums of the ranks' own particles - the counterpart of the replicated top-tree.  Ghost import replaces the
+//         target export: same interaction sets, no return trip, and the walk kernels are the single-GPU ones.
+//
+// The library links neither MPI nor RCCL; the collectives are the caller's (mpg_comm).  All ordering is on the engine's stream;
+// a callback is entered with the stream idle.
+#include "engine_internal.h"
+#include "peano_tables.h"
+#include <algorithm>
+#include <chrono>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr int PH_BITS = 21;
+const unsigned char H_SUBPIX[MPG_PEANO_NSTATES][8] = MPG_PEANO_SUBPIX;
+const unsigned char H_NEXT[MPG_PEANO_NSTATES][8] = MPG_PEANO_NEXT;
+
+struct alignas(16) PRow { // a particle on the wire
+    double x, y, z;
+    float m;
+    unsigned pad;
+};
+struct alignas(16) RRow { // a PM result on the wire
+    double gx, gy, gz, pot;
+};
+static_assert(sizeof(PRow) == 32 && sizeof(RRow) == 32, "wire rows are 32 bytes");
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+__device__ __forceinline__ int wrapi(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+// slab owner(s) of a particle's CIC cloud: the planes floor(x / cellsize) and that + 1 (periodic), P planes per rank
+__device__ __forceinline__ void pm_owners(double x, double cellsize, int nmesh, int P, int &o0, int &o1)
+{
+    const int ix = (int)floor(x / cellsize);
+    o0 = wrapi(ix, nmesh) / P;
+    o1 = wrapi(ix + 1, nmesh) / P;
+}
+
+__global__ void __launch_bounds__(256) k_pm_mask(int64_t n, const double *__restrict__ pos, double cellsize, int nmesh, int P,
+                                                 unsigned long long *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    int o0, o1;
+    pm_owners(pos[3 * i], cellsize, nmesh, P, o0, o1);
+    mask[i] = (1ull << o0) | (1ull << o1);
+}
+
+// level-La tree cell of a position by the reference's own floating-point descent (forcetree.c get_subnode, as k_keys of
+// tree_build.hip replays it), so that "cell" here is bit for bit the cell of the tree; cells numbered (ix * nc + iy) * nc + iz
+__device__ __forceinline__ unsigned tree_cell(double x, double y, double z, double box, int La)
+{
+    double cx = box / 2., cy = box / 2., cz = box / 2.;
+    double len = box * 1.001;
+    unsigned ix = 0, iy = 0, iz = 0;
+    for(int l = 0; l < La; l++) {
+        const double q = 0.25 * len;
+        const int bx = x > cx, by = y > cy, bz = z > cz;
+        ix = 2 * ix + bx;
+        iy = 2 * iy + by;
+        iz = 2 * iz + bz;
+        cx += bx ? q : -q;
+        cy += by ? q : -q;
+        cz += bz ? q : -q;
+        len *= 0.5;
+    }
+    return ((ix << La) | iy) << La | iz;
+}
+
+__global__ void __launch_bounds__(256) k_need_mask(int64_t n, const double *__restrict__ pos, double box, int La,
+                                                   const unsigned long long *__restrict__ need, int me, unsigned long long *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    mask[i] = need[tree_cell(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], box, La)] & ~(1ull << me);
+}
+
+// rows per destination: one atomic per wave and destination
+__global__ void __launch_bounds__(256) k_count_dests(int64_t n, const unsigned long long *__restrict__ mask, int nt,
+                                                     unsigned long long *__restrict__ counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = i < n ? mask[i] : 0ull;
+    for(int d = 0; d < nt; d++) {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64((m >> d) & 1ull);
+        if(b && (threadIdx.x & 63) == 0)
+            atomicAdd(&counts[d], (unsigned long long)__popcll(b));
+    }
+}
+
+struct BitOf {
+    int d;
+    __host__ __device__ bool operator()(const unsigned long long &m) const { return (m >> d) & 1ull; }
+};
+
+__global__ void __launch_bounds__(256) k_pack_particles(int64_t ns, const int *__restrict__ idx, const double *__restrict__ pos,
+                                                        const float *__restrict__ mass, PRow *__restrict__ rows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= ns)
+        return;
+    const int64_t i = idx[k];
+    PRow r;
+    r.x = pos[3 * i];
+    r.y = pos[3 * i + 1];
+    r.z = pos[3 * i + 2];
+    r.m = mass[i];
+    r.pad = 0u;
+    rows[k] = r;
+}
+
+__global__ void __launch_bounds__(256) k_unpack_particles(int64_t nr, const PRow *__restrict__ rows, double *__restrict__ pos,
+                                                          float *__restrict__ mass)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nr)
+        return;
+    const PRow r = rows[k];
+    pos[3 * k] = r.x;
+    pos[3 * k + 1] = r.y;
+    pos[3 * k + 2] = r.z;
+    mass[k] = r.m;
+}
+
+// the particles a slab rank received whose BASE cell lies in its planes: the ones it reads the mesh out for
+__global__ void __launch_bounds__(256) k_flag_slab_targets(int64_t n, const double *__restrict__ pos, double cellsize, int nmesh, int P, int me,
+                                                           unsigned char *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    int o0, o1;
+    pm_owners(pos[3 * i], cellsize, nmesh, P, o0, o1);
+    flag[i] = o0 == me;
+}
+
+__global__ void __launch_bounds__(256) k_pack_results(int64_t n, const double *__restrict__ gravpm, const double *__restrict__ pot,
+                                                      RRow *__restrict__ rows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    RRow r;
+    r.gx = gravpm[3 * k];
+    r.gy = gravpm[3 * k + 1];
+    r.gz = gravpm[3 * k + 2];
+    r.pot = pot[k];
+    rows[k] = r;
+}
+
+// rows come back in the order of the send list; the row from the owner of the particle's BASE cell carries the result
+__global__ void __launch_bounds__(256) k_scatter_results(int64_t ns, const int *__restrict__ idx, const RRow *__restrict__ rows,
+                                                         const long long *__restrict__ sdsp, int nt, const double *__restrict__ pos,
+                                                         double cellsize, int nmesh, int P, double *__restrict__ gravpm,
+                                                         double *__restrict__ pot)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= ns)
+        return;
+    int d = 0;
+    while(d + 1 < nt && k >= sdsp[d + 1])
+        d++;
+    const int64_t i = idx[k];
+    int o0, o1;
+    pm_owners(pos[3 * i], cellsize, nmesh, P, o0, o1);
+    if(o0 != d)
+        return;
+    const RRow r = rows[k];
+    gravpm[3 * i] = r.gx;
+    gravpm[3 * i + 1] = r.gy;
+    gravpm[3 * i + 2] = r.gz;
+    if(pot)
+        pot[i] += r.pot; // readout_potential accumulates (gravpm.c:499-501)
+}
+
+// own particles of the local tree, in tree order (caller index < n_own)
+struct IsOwn {
+    int n_own;
+    __host__ __device__ bool operator()(const unsigned &ci) const { return (int)ci < n_own; }
+};
+
+// number of OWN particles per level-(La-1) cell (sorted keys: mostly one cell per wave)
+__global__ void __launch_bounds__(256) k_top_counts(int64_t npart, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ order,
+                                                    int64_t n_own, int shift, double *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool own = k < npart && (int64_t)order[k] < n_own;
+    const unsigned long long cell = own ? (unsigned long long)(keys[k] >> shift) : ~0ull;
+    const unsigned long long c0 = __shfl(cell, 0);
+    if(__ballot(cell != c0) == 0) {
+        if(c0 != ~0ull && (threadIdx.x & 63) == 0)
+            unsafeAtomicAdd(&out[c0], (double)__popcll(__ballot(own)));
+    }
+    else if(own)
+        unsafeAtomicAdd(&out[cell], 1.0);
+}
+
+struct Plan { // one personalised exchange: who gets which of my rows, and what I get
+    DevBuf<int> idx;
+    DevBuf<long long> d_sdsp;
+    std::vector<int64_t> scnt, rcnt, sdsp, rdsp; // rows
+    int64_t nsend = 0, nrecv = 0;
+};
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+struct mpg_dist {
+    mpg_engine *eng = nullptr;
+    mpg_comm comm{};
+    int me = 0, nt = 1;
+    // domain
+    double box = 0, margin = 0;
+    int La = 0;
+    bool have_domain = false;
+    DevBuf<unsigned long long> need; // [8^La] ranks that need the cell
+    // work
+    DevBuf<unsigned long long> mask, cnt;
+    DevBuf<char> tmp;
+    DevBuf<char> sendbuf, recvbuf;
+    HostBuf<char> hsend, hrecv;
+    Plan pm, ghost;
+    // PM side
+    DevBuf<double> spos, sgrav, spot;
+    DevBuf<float> smass;
+    DevBuf<unsigned char> sflag;
+    DevBuf<int> starg;
+    DevBuf<unsigned long long> scount;
+    DevBuf<double> sendA, recvA, sendB, recvB, gsend, grecv;
+    int64_t per_peer = 0, plane = 0;
+    bool slab_ready = false;
+    // tree side
+    DevBuf<double> lpos, top;
+    DevBuf<float> lmass;
+    DevBuf<int> targets;
+    HostBuf<double> htop;
+    int64_t ntarg = 0, n_own_tree = -1;
+    int64_t stats[8] = {};
+    double times[8] = {};
+    // host (drop-in) path: the rank's P[] staged on the device
+    DevBuf<double> o_pos, o_gravpm, o_pot, o_acc, o_prev;
+    DevBuf<float> o_mass;
+    std::vector<double> hbuf;
+    std::vector<float> hbuf_f;
+    int64_t o_n = -1;
+};
+
+namespace {
+
+void sync(mpg_dist *d) { MPG_HIP(hipStreamSynchronize(d->eng->stream)); }
+
+void cb(int rc, const char *what) { MPG_CHECK(rc == 0, std::string("mpg_comm callback failed: ") + what); }
+
+// alltoallv of bytes between device buffers (staged through pinned host memory unless the communicator takes device pointers)
+void a2av(mpg_dist *d, const void *dsend, const std::vector<int64_t> &sb, const std::vector<int64_t> &sd, void *drecv,
+          const std::vector<int64_t> &rb, const std::vector<int64_t> &rd, int64_t stot, int64_t rtot)
+{
+    hipStream_t st = d->eng->stream;
+    d->stats[4] += stot;
+    if(d->nt == 1 && !d->comm.alltoallv) {
+        if(stot > 0)
+            MPG_HIP(hipMemcpyAsync(drecv, dsend, (size_t)stot, hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    MPG_CHECK(d->comm.alltoallv, "mpg_comm: alltoallv callback missing");
+    if(d->comm.device_buffers) {
+        sync(d);
+        cb(d->comm.alltoallv(d->comm.ctx, dsend, sb.data(), sd.data(), drecv, rb.data(), rd.data(), 1), "alltoallv");
+        return;
+    }
+    d->hsend.reserve((size_t)stot + 16);
+    d->hrecv.reserve((size_t)rtot + 16);
+    if(stot > 0)
+        MPG_HIP(hipMemcpyAsync(d->hsend.p, dsend, (size_t)stot, hipMemcpyDeviceToHost, st));
+    sync(d);
+    cb(d->comm.alltoallv(d->comm.ctx, d->hsend.p, sb.data(), sd.data(), d->hrecv.p, rb.data(), rd.data(), 0), "alltoallv");
+    if(rtot > 0)
+        MPG_HIP(hipMemcpyAsync(drecv, d->hrecv.p, (size_t)rtot, hipMemcpyHostToDevice, st));
+    sync(d); // (hrecv is reused by the next exchange)
+}
+
+// uniform all-to-all of `bytes_per_peer` per rank pair (the transposes of the slab PM)
+void a2a_uniform(mpg_dist *d, const void *dsend, void *drecv, int64_t bytes_per_peer)
+{
+    std::vector<int64_t> b((size_t)d->nt, bytes_per_peer), dsp((size_t)d->nt);
+    for(int r = 0; r < d->nt; r++)
+        dsp[r] = (int64_t)r * bytes_per_peer;
+    a2av(d, dsend, b, dsp, drecv, b, dsp, bytes_per_peer * d->nt, bytes_per_peer * d->nt);
+    d->stats[4] -= bytes_per_peer * d->nt;
+    d->stats[5] += bytes_per_peer * d->nt;
+}
+
+void allreduce_host_f64(mpg_dist *d, double *h, int64_t n, int op)
+{
+    if(d->nt == 1 && !d->comm.allreduce)
+        return;
+    MPG_CHECK(d->comm.allreduce, "mpg_comm: allreduce callback missing");
+    cb(d->comm.allreduce(d->comm.ctx, h, n, 0, op, 0), "allreduce");
+}
+
+// send lists from per-particle destination masks; the counts travel through alltoall_i64
+void build_plan(mpg_dist *d, Plan &pl, int64_t n, const unsigned long long *mask)
+{
+    hipStream_t st = d->eng->stream;
+    const int nt = d->nt;
+    d->cnt.reserve(64);
+    MPG_HIP(hipMemsetAsync(d->cnt.p, 0, 64 * sizeof(unsigned long long), st));
+    if(n > 0)
+        hipLaunchKernelGGL(k_count_dests, dim3(nblk(n)), dim3(256), 0, st, n, mask, nt, d->cnt.p);
+    unsigned long long hc[64];
+    MPG_HIP(hipMemcpyAsync(hc, d->cnt.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    sync(d);
+    pl.scnt.assign(nt, 0);
+    pl.sdsp.assign(nt + 1, 0);
+    for(int r = 0; r < nt; r++) {
+        pl.scnt[r] = (int64_t)hc[r];
+        pl.sdsp[r + 1] = pl.sdsp[r] + pl.scnt[r];
+    }
+    pl.nsend = pl.sdsp[nt];
+    pl.idx.reserve((size_t)pl.nsend + 1);
+    pl.d_sdsp.reserve((size_t)nt + 1);
+    std::vector<long long> dsp(pl.sdsp.begin(), pl.sdsp.end());
+    MPG_HIP(hipMemcpyAsync(pl.d_sdsp.p, dsp.data(), (nt + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+    if(n > 0) {
+        rocprim::counting_iterator<int> iota(0);
+        size_t tb = 0;
+        auto flags0 = rocprim::make_transform_iterator(mask, BitOf{0});
+        MPG_HIP(rocprim::select(nullptr, tb, iota, flags0, pl.idx.p, d->cnt.p, (size_t)n, st));
+        d->tmp.reserve(tb + 16);
+        for(int r = 0; r < nt; r++) {
+            if(pl.scnt[r] == 0)
+                continue;
+            auto flags = rocprim::make_transform_iterator(mask, BitOf{r});
+            MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, flags, pl.idx.p + pl.sdsp[r], d->cnt.p + 32, (size_t)n, st));
+        }
+    }
+    sync(d); // (dsp is a host vector)
+    pl.rcnt.assign(nt, 0);
+    if(nt == 1 && !d->comm.alltoall_i64)
+        pl.rcnt[0] = pl.scnt[0];
+    else {
+        MPG_CHECK(d->comm.alltoall_i64, "mpg_comm: alltoall_i64 callback missing");
+        cb(d->comm.alltoall_i64(d->comm.ctx, pl.scnt.data(), pl.rcnt.data()), "alltoall_i64");
+    }
+    pl.rdsp.assign(nt + 1, 0);
+    for(int r = 0; r < nt; r++)
+        pl.rdsp[r + 1] = pl.rdsp[r] + pl.rcnt[r];
+    pl.nrecv = pl.rdsp[nt];
+}
+
+// rows (32 bytes each) along a plan; reverse: the answers travel back (what I received, I return; what I sent, I get back)
+void exchange_rows32(mpg_dist *d, const Plan &pl, const void *dsend, void *drecv, bool reverse)
+{
+    const int nt = d->nt;
+    std::vector<int64_t> sb(nt), sd(nt), rb(nt), rd(nt);
+    for(int r = 0; r < nt; r++) {
+        sb[r] = 32 * (reverse ? pl.rcnt[r] : pl.scnt[r]);
+        sd[r] = 32 * (reverse ? pl.rdsp[r] : pl.sdsp[r]);
+        rb[r] = 32 * (reverse ? pl.scnt[r] : pl.rcnt[r]);
+        rd[r] = 32 * (reverse ? pl.sdsp[r] : pl.rdsp[r]);
+    }
+    a2av(d, dsend, sb, sd, drecv, rb, rd, 32 * (reverse ? pl.nrecv : pl.nsend), 32 * (reverse ? pl.nsend : pl.nrecv));
+}
+
+// cube (integer coordinates at its level) of a TopNode: the prefix of its Peano-Hilbert key walked through the curve's state
+// machine backwards (digit -> octant)
+void topnode_cube(const mpg_topnode &tn, int &level, unsigned &x, unsigned &y, unsigned &z)
+{
+    level = (3 * PH_BITS - tn.Shift) / 3;
+    x = y = z = 0;
+    unsigned state = 0;
+    for(int l = 0; l < level; l++) {
+        const unsigned digit = (unsigned)((tn.StartKey >> (3 * (PH_BITS - 1 - l))) & 7ull);
+        unsigned pix = 0;
+        while(pix < 8 && H_SUBPIX[state][pix] != digit)
+            pix++;
+        MPG_CHECK(pix < 8, "mpg_dist_set_domain: corrupt Peano-Hilbert key");
+        x = 2 * x + ((pix >> 2) & 1u);
+        y = 2 * y + ((pix >> 1) & 1u);
+        z = 2 * z + (pix & 1u);
+        state = H_NEXT[state][pix];
+    }
+}
+
+// cells (of nc across the 1.001-Box root cell starting at lo0) that the interval [a, b] touches, periodic with period Box
+void cells_of_interval(double a, double b, double box, double lo0, double w, int nc, std::vector<char> &sel)
+{
+    sel.assign((size_t)nc, 0);
+    if(b - a >= box) {
+        std::fill(sel.begin(), sel.end(), 1);
+        return;
+    }
+    for(int k = -1; k <= 1; k++) {
+        const double aa = a + k * box, bb = b + k * box;
+        int k0 = (int)floor((aa - lo0) / w), k1 = (int)floor((bb - lo0) / w);
+        if(k1 < 0 || k0 >= nc)
+            continue;
+        k0 = std::max(k0, 0);
+        k1 = std::min(k1, nc - 1);
+        for(int c = k0; c <= k1; c++)
+            sel[(size_t)c] = 1;
+    }
+}
+
+void pm_slab_setup(mpg_dist *d)
+{
+    mpg_engine *e = d->eng;
+    MPG_CHECK(e->pm.nmesh > 0, "mpg_dist: gravpm_init_periodic first");
+    MPG_CHECK(e->pm.nmesh % d->nt == 0, "mpg_dist: Nmesh must be a multiple of the number of ranks");
+    e->pm.slab_init(d->me, d->nt);
+    d->per_peer = (int64_t)e->pm.slab_cplx_per_peer();
+    d->plane = (int64_t)e->pm.nmesh * e->pm.nmesh;
+    const size_t tr = (size_t)2 * d->per_peer * d->nt;
+    d->sendA.reserve(tr);
+    d->recvA.reserve(tr);
+    d->sendB.reserve(tr);
+    d->recvB.reserve(tr);
+    d->gsend.reserve((size_t)5 * d->plane);
+    d->grecv.reserve((size_t)5 * d->plane);
+    d->slab_ready = true;
+}
+
+// gravpm_force over the ranks: ship particles to their slabs, solve, return the results
+void pm_step(mpg_dist *d, int64_t n, const double *pos, const float *mass, double *gravpm, double *pot)
+{
+    mpg_engine *e = d->eng;
+    hipStream_t st = e->stream;
+    PMesh &pm = e->pm;
+    if(!d->slab_ready || pm.slab.rank != d->me || pm.slab.world != d->nt || !pm.slab.ready)
+        pm_slab_setup(d);
+    const int nmesh = pm.nmesh, P = nmesh / d->nt;
+    d->mask.reserve((size_t)n + 1);
+    if(n > 0)
+        hipLaunchKernelGGL(k_pm_mask, dim3(nblk(n)), dim3(256), 0, st, n, pos, pm.cellsize, nmesh, P, d->mask.p);
+    build_plan(d, d->pm, n, d->mask.p);
+    Plan &pl = d->pm;
+    d->sendbuf.reserve((size_t)32 * pl.nsend + 32);
+    d->recvbuf.reserve((size_t)32 * pl.nrecv + 32);
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_pack_particles, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, pos, mass, (PRow *)d->sendbuf.p);
+    exchange_rows32(d, pl, d->sendbuf.p, d->recvbuf.p, false);
+    const int64_t nr = pl.nrecv;
+    d->spos.reserve((size_t)3 * nr + 3);
+    d->smass.reserve((size_t)nr + 1);
+    d->sgrav.reserve((size_t)3 * nr + 3);
+    d->spot.reserve((size_t)nr + 1);
+    d->sflag.reserve((size_t)nr + 1);
+    d->starg.reserve((size_t)nr + 1);
+    d->scount.reserve(4);
+    if(nr > 0)
+        hipLaunchKernelGGL(k_unpack_particles, dim3(nblk(nr)), dim3(256), 0, st, nr, (const PRow *)d->recvbuf.p, d->spos.p, d->smass.p);
+    // local stages of the slab solver with the two transposes and the neighbour planes in between (pm.hip, "slab-decomposed form")
+    pm.slab_forward_a(nr, d->spos.p, d->smass.p, d->sendA.p, st);
+    a2a_uniform(d, d->sendA.p, d->recvA.p, 16 * d->per_peer);
+    pm.slab_forward_b(d->recvA.p, d->sendB.p, st);
+    a2a_uniform(d, d->sendB.p, d->recvB.p, 16 * d->per_peer);
+    pm.slab_inverse_c(d->recvB.p, d->gsend.p, st);
+    {
+        // the first 3 planes go to the previous rank (its upper ghosts), the last 2 to the next rank (its lower ghosts);
+        // received: from the next rank its first 3, from the previous rank its last 2.  One alltoallv; with 1 or 2 ranks both
+        // neighbours are the same rank, which then gets [first 3 | last 2] in one block and sends the same
+        const int nt = d->nt, prev = (d->me + nt - 1) % nt, next = (d->me + 1) % nt;
+        const int64_t pb = d->plane * 8;
+        std::vector<int64_t> sb(nt, 0), sd(nt, 0), rb(nt, 0), rd(nt, 0);
+        if(prev == next) { // (nt <= 2)
+            sb[prev] = 5 * pb;
+            rb[prev] = 5 * pb;
+        }
+        else {
+            sb[prev] = 3 * pb;
+            sd[prev] = 0;
+            sb[next] = 2 * pb;
+            sd[next] = 3 * pb;
+            rb[next] = 3 * pb;
+            rd[next] = 0;
+            rb[prev] = 2 * pb;
+            rd[prev] = 3 * pb;
+        }
+        a2av(d, d->gsend.p, sb, sd, d->grecv.p, rb, rd, 5 * pb, 5 * pb);
+    }
+    // targets: the received particles whose base cell is mine
+    int64_t ntarg = 0;
+    if(nr > 0) {
+        hipLaunchKernelGGL(k_flag_slab_targets, dim3(nblk(nr)), dim3(256), 0, st, nr, d->spos.p, pm.cellsize, nmesh, P, d->me, d->sflag.p);
+        rocprim::counting_iterator<int> iota(0);
+        size_t tb = 0;
+        MPG_HIP(rocprim::select(nullptr, tb, iota, d->sflag.p, d->starg.p, d->scount.p, (size_t)nr, st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->sflag.p, d->starg.p, d->scount.p, (size_t)nr, st));
+        unsigned long long c = 0;
+        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        sync(d);
+        ntarg = (int64_t)c;
+        MPG_HIP(hipMemsetAsync(d->sgrav.p, 0, (size_t)3 * nr * sizeof(double), st));
+        MPG_HIP(hipMemsetAsync(d->spot.p, 0, (size_t)nr * sizeof(double), st));
+    }
+    pm.slab_readout(d->grecv.p, d->starg.p, ntarg, d->spos.p, d->sgrav.p, d->spot.p, st);
+    // results back along the same lists
+    if(nr > 0)
+        hipLaunchKernelGGL(k_pack_results, dim3(nblk(nr)), dim3(256), 0, st, nr, d->sgrav.p, d->spot.p, (RRow *)d->recvbuf.p);
+    exchange_rows32(d, pl, d->recvbuf.p, d->sendbuf.p, true);
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_scatter_results, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, (const RRow *)d->sendbuf.p, pl.d_sdsp.p, d->nt,
+                           pos, pm.cellsize, nmesh, P, gravpm, pot);
+    MPG_HIP(hipGetLastError());
+    d->stats[1] = pl.nsend;
+}
+
+// own particles followed by the ghosts of every needed cell: d->lpos / d->lmass; returns the local count
+int64_t import_ghosts(mpg_dist *d, int64_t n, const double *pos, const float *mass)
+{
+    hipStream_t st = d->eng->stream;
+    d->mask.reserve((size_t)n + 1);
+    if(n > 0)
+        hipLaunchKernelGGL(k_need_mask, dim3(nblk(n)), dim3(256), 0, st, n, pos, d->box, d->La, d->need.p, d->me, d->mask.p);
+    build_plan(d, d->ghost, n, d->mask.p);
+    Plan &pl = d->ghost;
+    d->sendbuf.reserve((size_t)32 * pl.nsend + 32);
+    d->recvbuf.reserve((size_t)32 * pl.nrecv + 32);
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_pack_particles, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, pos, mass, (PRow *)d->sendbuf.p);
+    exchange_rows32(d, pl, d->sendbuf.p, d->recvbuf.p, false);
+    const int64_t nl = n + pl.nrecv;
+    d->lpos.reserve((size_t)3 * nl + 3);
+    d->lmass.reserve((size_t)nl + 1);
+    if(n > 0) {
+        MPG_HIP(hipMemcpyAsync(d->lpos.p, pos, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MPG_HIP(hipMemcpyAsync(d->lmass.p, mass, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if(pl.nrecv > 0)
+        hipLaunchKernelGGL(k_unpack_particles, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const PRow *)d->recvbuf.p, d->lpos.p + 3 * n,
+                           d->lmass.p + n);
+    MPG_HIP(hipGetLastError());
+    d->stats[0] = pl.nrecv;
+    d->stats[2] = nl;
+    return nl;
+}
+
+// moments of the nodes above level La from the sums over all ranks (tree_build.hip, "the top of the tree from global sums")
+void global_top(mpg_dist *d, int64_t n_own)
+{
+    mpg_engine *e = d->eng;
+    hipStream_t st = e->stream;
+    const int La = d->La;
+    const size_t nfine = (size_t)1 << (3 * (La - 1));
+    size_t ntot = 0;
+    for(int l = 0; l < La; l++)
+        ntot += (size_t)1 << (3 * l);
+    d->top.reserve(std::max(nfine * 5, ntot * 4) + 8);
+    e->tree.top_partial(La, n_own, d->top.p, st);
+    double *cnt = d->top.p + nfine * 4;
+    MPG_HIP(hipMemsetAsync(cnt, 0, nfine * sizeof(double), st));
+    if(e->tree.npart > 0)
+        hipLaunchKernelGGL(k_top_counts, dim3(nblk(e->tree.npart)), dim3(256), 0, st, e->tree.npart, e->tree.keys_b.p, e->tree.idx_b.p, n_own,
+                           3 * (MAXLEVEL - (La - 1)), cnt);
+    d->htop.reserve(std::max(nfine * 5, ntot * 4) + 8);
+    MPG_HIP(hipMemcpyAsync(d->htop.p, d->top.p, nfine * 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+    sync(d);
+    allreduce_host_f64(d, d->htop.p, (int64_t)(nfine * 5), 0);
+    // a cell above the decomposition level is internal here whatever it holds; the global tree agrees only if it holds more
+    // than NMAXCHILD particles in all
+    for(size_t c = 0; c < nfine; c++) {
+        const double k = d->htop.p[nfine * 4 + c];
+        MPG_CHECK(k == 0 || k > NMAXCHILD, "mpg_dist: a cell above the decomposition level holds <= 8 particles in all (use a coarser level La)");
+    }
+    // levels La-1 .. 0 by summing the 8 children (consecutive in octant-path numbering), laid out level 0 first
+    std::vector<double> lev(d->htop.p, d->htop.p + nfine * 4), all(ntot * 4);
+    size_t off = ntot;
+    for(int l = La - 1; l >= 0; l--) {
+        const size_t nc = (size_t)1 << (3 * l);
+        off -= nc;
+        std::copy(lev.begin(), lev.begin() + nc * 4, all.begin() + off * 4);
+        if(l > 0) {
+            std::vector<double> up(nc / 8 * 4, 0.0);
+            for(size_t c = 0; c < nc; c++)
+                for(int j = 0; j < 4; j++)
+                    up[(c >> 3) * 4 + j] += lev[c * 4 + j];
+            lev.swap(up);
+        }
+    }
+    std::copy(all.begin(), all.end(), d->htop.p);
+    MPG_HIP(hipMemcpyAsync(d->top.p, d->htop.p, ntot * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+    e->tree.top_set(La, d->top.p, st); // (synchronises: htop may be reused afterwards)
+}
+
+} // namespace
+
+extern "C" {
+
+int mpg_dist_create(mpg_dist **out, mpg_engine *eng, const mpg_comm *comm)
+{
+    API_BEGIN
+    MPG_CHECK(out && eng && comm, "null argument");
+    MPG_CHECK(comm->NTask >= 1 && comm->NTask <= 64 && comm->ThisTask >= 0 && comm->ThisTask < comm->NTask, "mpg_dist_create: bad ThisTask / NTask");
+    mpg_dist *d = new mpg_dist();
+    d->eng = eng;
+    d->comm = *comm;
+    d->me = comm->ThisTask;
+    d->nt = comm->NTask;
+    *out = d;
+    API_END
+}
+
+void mpg_dist_destroy(mpg_dist *d)
+{
+    if(!d)
+        return;
+    if(d->eng) {
+        (void)hipSetDevice(d->eng->device);
+        (void)hipStreamSynchronize(d->eng->stream);
+        d->eng->tree.force_internal_above = 0;
+    }
+    delete d;
+}
+
+int mpg_dist_set_domain(mpg_dist *d, double BoxSize, const mpg_topnode *TopNodes, int NTopNodes, const int *leaf_task, int NTopLeaves,
+                        double margin, int La)
+{
+    API_BEGIN
+    MPG_CHECK(d && TopNodes && leaf_task && NTopNodes > 0 && NTopLeaves > 0, "null argument");
+    MPG_CHECK(BoxSize > 0 && margin > 0, "mpg_dist_set_domain: BoxSize and margin must be positive");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    if(La <= 0) // cells [margin, 2 margin) wide: little over-import, few levels above the decomposition level
+        La = (int)floor(log2(1.001 * BoxSize / margin));
+    La = std::max(1, std::min(7, La));
+    const int nc = 1 << La;
+    const double w = 1.001 * BoxSize / nc, lo0 = BoxSize / 2. - 0.5 * 1.001 * BoxSize;
+    // A node above level La that holds no particle of a needed cell is absent from the local tree.  That is harmless only if the
+    // global walk could not have drawn a force from it: a node used unopened has len^2 / r^2 <= MaxBHOpeningAngle^2 <= 1, i.e. lies
+    // at r >= len >= 2 w >= 2 margin from the target, beyond the short-range window's table (15 mesh cells, gravity.c:57-61)
+    // whenever margin >= Rcut = 9 cells - so cells must not be narrower than the margin
+    MPG_CHECK(w >= margin || La == 1, "mpg_dist_set_domain: cells of level La are narrower than the margin");
+    const double grow = margin + 1e-9 * BoxSize; // (ownership is by integer key, cells by floating-point descent)
+    std::vector<unsigned long long> need((size_t)nc * nc * nc, 0ull);
+    std::vector<char> sx, sy, sz;
+    int seen = 0;
+    for(int i = 0; i < NTopNodes; i++) {
+        const mpg_topnode &tn = TopNodes[i];
+        if(tn.Daughter >= 0)
+            continue;
+        MPG_CHECK(tn.Leaf >= 0 && tn.Leaf < NTopLeaves, "mpg_dist_set_domain: TopNode without a valid Leaf");
+        const int task = leaf_task[tn.Leaf];
+        MPG_CHECK(task >= 0 && task < d->nt, "mpg_dist_set_domain: Task of a TopLeaf out of range");
+        seen++;
+        int level;
+        unsigned x, y, z;
+        topnode_cube(tn, level, x, y, z);
+        const double s = 1.001 * BoxSize / (double)(1u << level);
+        cells_of_interval(lo0 + x * s - grow, lo0 + (x + 1) * s + grow, BoxSize, lo0, w, nc, sx);
+        cells_of_interval(lo0 + y * s - grow, lo0 + (y + 1) * s + grow, BoxSize, lo0, w, nc, sy);
+        cells_of_interval(lo0 + z * s - grow, lo0 + (z + 1) * s + grow, BoxSize, lo0, w, nc, sz);
+        const unsigned long long bit = 1ull << task;
+        for(int a = 0; a < nc; a++) {
+            if(!sx[a])
+                continue;
+            for(int b = 0; b < nc; b++) {
+                if(!sy[b])
+                    continue;
+                unsigned long long *row = need.data() + ((size_t)a * nc + b) * nc;
+                for(int c = 0; c < nc; c++)
+                    if(sz[c])
+                        row[c] |= bit;
+            }
+        }
+    }
+    MPG_CHECK(seen == NTopLeaves, "mpg_dist_set_domain: the TopNodes do not hold NTopLeaves leaves");
+    d->need.reserve(need.size());
+    MPG_HIP(hipMemcpy(d->need.p, need.data(), need.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    d->box = BoxSize;
+    d->margin = margin;
+    d->La = La;
+    d->have_domain = true;
+    d->stats[3] = La;
+    API_END
+}
+
+int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, double *d_gravpm, double *d_potential)
+{
+    API_BEGIN
+    MPG_CHECK(d && d_gravpm && (n_own == 0 || (d_pos && d_mass)), "null argument");
+    MPG_CHECK(d->have_domain, "mpg_dist: mpg_dist_set_domain first");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    MPG_CHECK(n_own < (1ll << 31), "mpg_dist: too many particles on one rank");
+    MPG_CHECK(e->pm.box == d->box, "mpg_dist: BoxSize of the mesh differs from the domain's");
+    d->stats[4] = d->stats[5] = 0;
+    sync(d);
+    const double t0 = now_ms();
+    pm_step(d, n_own, d_pos, d_mass, d_gravpm, d_potential);
+    sync(d);
+    d->times[0] = now_ms() - t0;
+    API_END
+}
+
+int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass)
+{
+    API_BEGIN
+    MPG_CHECK(d && (n_own == 0 || (d_pos && d_mass)), "null argument");
+    MPG_CHECK(d->have_domain, "mpg_dist: mpg_dist_set_domain first");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    MPG_CHECK(n_own < (1ll << 31), "mpg_dist: too many particles on one rank");
+    hipStream_t st = e->stream;
+    sync(d);
+    const double t1 = now_ms();
+    // ---- ghosts, local tree, global top
+    const int64_t nl = import_ghosts(d, n_own, d_pos, d_mass);
+    sync(d);
+    const double t2 = now_ms();
+    d->times[1] = t2 - t1;
+    MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, nullptr, d->box) == 0, mpg_last_error());
+    e->tree.force_internal_above = d->La;
+    const int rc = mpg_dev_force_tree_build(e, 63);
+    e->tree.force_internal_above = 0;
+    MPG_CHECK(rc == 0, mpg_last_error());
+    global_top(d, n_own);
+    // own particles in tree order: the walk's targets
+    d->targets.reserve((size_t)nl + 1);
+    d->scount.reserve(4);
+    d->ntarg = 0;
+    d->n_own_tree = n_own;
+    if(nl > 0) {
+        size_t tb = 0;
+        MPG_HIP(rocprim::select(nullptr, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, IsOwn{(int)n_own}, st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, IsOwn{(int)n_own}, st));
+        unsigned long long c = 0;
+        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        sync(d);
+        d->ntarg = (int64_t)c;
+        MPG_CHECK(d->ntarg == n_own, "mpg_dist: own particles missing from the local tree");
+    }
+    d->times[2] = now_ms() - t2;
+    API_END
+}
+
+int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm, double *d_accel,
+                                 double *d_potential, double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(d && d_accel, "null argument");
+    MPG_CHECK(d->n_own_tree >= 0, "mpg_dist_dev_grav_short_tree: mpg_dist_dev_force_tree_build first");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    sync(d);
+    const double t3 = now_ms();
+    if(d->ntarg > 0)
+        MPG_CHECK(mpg_dev_grav_short_tree(e, d_oldacc, d_prev_accel, d_gravpm, d->targets.p, d->ntarg, d_accel, d_potential, rho0) == 0, mpg_last_error());
+    sync(d);
+    d->times[3] = now_ms() - t3;
+    API_END
+}
+
+int mpg_dist_gravity_step(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, const double *d_oldacc,
+                          const double *d_prev_accel, double *d_accel, double *d_gravpm, double *d_potential, double rho0)
+{
+    if(d && d_potential && n_own > 0) // (readout_potential accumulates; the walk then assigns the tree's, gravshort.h:94-95)
+        if(hipMemsetAsync(d_potential, 0, (size_t)n_own * sizeof(double), d->eng->stream) != hipSuccess)
+            return 1;
+    if(int rc = mpg_dist_dev_gravpm_force(d, n_own, d_pos, d_mass, d_gravpm, d_potential))
+        return rc;
+    if(int rc = mpg_dist_dev_force_tree_build(d, n_own, d_pos, d_mass))
+        return rc;
+    return mpg_dist_dev_grav_short_tree(d, d_oldacc, d_prev_accel, d_gravpm, d_accel, d_potential, rho0);
+}
+
+} // extern "C"
+
+/* ---- the drop-in (host pointer) forms: the rank's P[] in host memory, results written back into it ------------------------ */
+namespace {
+// Pos / Mass of the rank's particle table onto the device (d->o_pos, d->o_mass)
+void stage_own(mpg_dist *d, const mpg_particle_view *P)
+{
+    MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
+    MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
+    const int64_t n = P->n;
+    hipStream_t st = d->eng->stream;
+    d->hbuf.resize(3 * (size_t)n + 3);
+    d->hbuf_f.resize((size_t)n + 1);
+    const mpg_particle_view V = *P;
+    const char *b = (const char *)P->base;
+    double *hd = d->hbuf.data();
+    float *hf = d->hbuf_f.data();
+    std::vector<int> bad(64, 0);
+    parallel_for(n, [=, &bad](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++) {
+            const char *rec = b + i * V.stride;
+            const double *pp = (const double *)(rec + V.off_pos);
+            hd[3 * i] = pp[0];
+            hd[3 * i + 1] = pp[1];
+            hd[3 * i + 2] = pp[2];
+            hf[i] = *(const float *)(rec + V.off_mass);
+            if(V.off_flags >= 0 && (*(const uint8_t *)(rec + V.off_flags) & 1))
+                bad[0] = 1;
+        }
+    });
+    // (a PM step follows domain_decompose_full, which has collected the garbage: domain.c:238-241)
+    MPG_CHECK(!bad[0], "mpg_dist: P[] holds garbage particles (run the domain decomposition / slots_gc first)");
+    d->o_pos.reserve(3 * (size_t)n + 3);
+    d->o_mass.reserve((size_t)n + 1);
+    d->o_gravpm.reserve(3 * (size_t)n + 3);
+    d->o_pot.reserve((size_t)n + 1);
+    d->o_acc.reserve(3 * (size_t)n + 3);
+    d->o_prev.reserve(3 * (size_t)n + 3);
+    if(n > 0) {
+        MPG_HIP(hipMemcpyAsync(d->o_pos.p, hd, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        MPG_HIP(hipMemcpyAsync(d->o_mass.p, hf, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    sync(d);
+    d->o_n = n;
+}
+
+// one 3-vector (or scalar) column of P[] <-> a device array
+void column_up(mpg_dist *d, const mpg_particle_view *P, int64_t off, int w, double *dev)
+{
+    const int64_t n = P->n;
+    d->hbuf.resize((size_t)w * n + 3);
+    const mpg_particle_view V = *P;
+    const char *b = (const char *)P->base;
+    double *hd = d->hbuf.data();
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++)
+            for(int k = 0; k < w; k++)
+                hd[w * i + k] = ((const double *)(b + i * V.stride + off))[k];
+    });
+    if(n > 0)
+        MPG_HIP(hipMemcpyAsync(dev, hd, (size_t)w * n * sizeof(double), hipMemcpyHostToDevice, d->eng->stream));
+    sync(d);
+}
+
+template <class F> void column_down(mpg_dist *d, int64_t n, int w, const double *dev, F put)
+{
+    d->hbuf.resize((size_t)w * n + 3);
+    double *hd = d->hbuf.data();
+    if(n > 0)
+        MPG_HIP(hipMemcpyAsync(hd, dev, (size_t)w * n * sizeof(double), hipMemcpyDeviceToHost, d->eng->stream));
+    sync(d);
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++)
+            put(i, hd + (size_t)w * i);
+    });
+}
+} // namespace
+
+extern "C" {
+
+int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *P)
+{
+    API_BEGIN
+    MPG_CHECK(d && P, "null argument");
+    MPG_CHECK(P->off_gravpm >= 0, "particle view needs GravPM");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    stage_own(d, P);
+    const int64_t n = P->n;
+    if(n > 0)
+        MPG_HIP(hipMemsetAsync(d->o_pot.p, 0, (size_t)n * sizeof(double), d->eng->stream));
+    MPG_CHECK(mpg_dist_dev_gravpm_force(d, n, d->o_pos.p, d->o_mass.p, d->o_gravpm.p, d->o_pot.p) == 0, mpg_last_error());
+    const mpg_particle_view V = *P;
+    char *b = (char *)P->base;
+    column_down(d, n, 3, d->o_gravpm.p, [=](int64_t i, const double *v) {
+        double *g = (double *)(b + i * V.stride + V.off_gravpm);
+        g[0] = v[0];
+        g[1] = v[1];
+        g[2] = v[2];
+    });
+    if(P->off_potential >= 0)
+        column_down(d, n, 1, d->o_pot.p, [=](int64_t i, const double *v) { *(double *)(b + i * V.stride + V.off_potential) += v[0]; });
+    API_END
+}
+
+int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P)
+{
+    API_BEGIN
+    MPG_CHECK(d && P, "null argument");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    stage_own(d, P);
+    MPG_CHECK(mpg_dist_dev_force_tree_build(d, P->n, d->o_pos.p, d->o_mass.p) == 0, mpg_last_error());
+    API_END
+}
+
+int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(d && P, "null argument");
+    MPG_CHECK(P->off_accel >= 0 && P->off_gravpm >= 0, "particle view needs FullTreeGravAccel and GravPM");
+    MPG_CHECK(d->o_n == P->n && d->n_own_tree == P->n, "mpg_dist_grav_short_tree: call mpg_dist_force_tree_full on this table first");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    const int64_t n = P->n;
+    // OldAcc = |FullTreeGravAccel + GravPM| / G of the table as it stands (grav_get_abs_accel, gravshort.h:70-80)
+    column_up(d, P, P->off_accel, 3, d->o_prev.p);
+    column_up(d, P, P->off_gravpm, 3, d->o_gravpm.p);
+    MPG_CHECK(mpg_dist_dev_grav_short_tree(d, nullptr, d->o_prev.p, d->o_gravpm.p, d->o_acc.p, P->off_potential >= 0 ? d->o_pot.p : nullptr, rho0) == 0,
+              mpg_last_error());
+    const mpg_particle_view V = *P;
+    char *b = (char *)P->base;
+    column_down(d, n, 3, d->o_acc.p, [=](int64_t i, const double *v) {
+        double *a = (double *)(b + i * V.stride + V.off_accel); // full particle tree: P[i].FullTreeGravAccel (gravshort.h:57-62)
+        a[0] = v[0];
+        a[1] = v[1];
+        a[2] = v[2];
+        if(AccelStore) {
+            AccelStore[i][0] = v[0];
+            AccelStore[i][1] = v[1];
+            AccelStore[i][2] = v[2];
+        }
+    });
+    if(P->off_potential >= 0)
+        column_down(d, n, 1, d->o_pot.p, [=](int64_t i, const double *v) { *(double *)(b + i * V.stride + V.off_potential) = v[0]; });
+    API_END
+}
+
+int mpg_dist_get_stats(mpg_dist *d, int64_t stats[8])
+{
+    API_BEGIN
+    MPG_CHECK(d && stats, "null argument");
+    for(int i = 0; i < 8; i++)
+        stats[i] = d->stats[i];
+    API_END
+}
+
+int mpg_dist_get_times(mpg_dist *d, double ms[8])
+{
+    API_BEGIN
+    MPG_CHECK(d && ms, "null argument");
+    for(int i = 0; i < 8; i++)
+        ms[i] = d->times[i];
+    API_END
+}
+
+int mpg_dev_force_tree_set_min_leaf_level(mpg_engine *eng, int level)
+{
+    API_BEGIN
+    MPG_CHECK(eng && level >= 0 && level <= 8, "mpg_dev_force_tree_set_min_leaf_level: level must be in [0, 8]");
+    eng->tree.force_internal_above = level;
+    API_END
+}
+
+} // extern "C"

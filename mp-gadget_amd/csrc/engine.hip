@@ -5,163 +5,10 @@
 // gravshort.h:47-96.  Every entry point catches mpg::Error and returns non-zero (the reference has no
 // return codes here; the in-tree shim maps failures to endrun()).  There is no CPU fallback anywhere:
 // without a HIP device mpg_engine_create fails.
-#include "../../include/mpgadget_hip.h"
-#include "grav_walk.h"
-#include "mpg_common.h"
-#include "pm.h"
-#include "sph.h"
-#include "timestep.h"
-#include "peano.h"
-#include "domain.h"
-#include "fof.h"
-#include "snapshot_io.h"
-#include "tree_build.h"
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
-#include <thread>
-
-using namespace mpg;
+#include "engine_internal.h"
 
 static thread_local std::string g_err;
-
-
-// ---- host-side staging helpers of the AoS (host pointer) path -------------------------------------------------------------
-// Pinned, growable host buffer: transfers from / to pageable std::vector memory run at a fraction of the PCIe rate.
-template <typename T> struct HostBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    void reserve(size_t n)
-    {
-        if(n <= cap)
-            return;
-        release();
-        const size_t want = n + n / 16 + 64;
-        MPG_HIP(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
-        cap = want;
-    }
-    void release()
-    {
-        if(p)
-            (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    ~HostBuf() { release(); }
-    HostBuf() = default;
-    HostBuf(const HostBuf &) = delete;
-    HostBuf &operator=(const HostBuf &) = delete;
-};
-
-// f(lo, hi) over [0, n) on up to 32 host threads: packing 160-byte records into arrays (and back) is memory-bound and one
-// thread moves ~2 GB/s of them; the reference's callers have the cores of the rank idle while the GPU works anyway.
-template <class F> static void parallel_for(int64_t n, F f)
-{
-    unsigned T = std::thread::hardware_concurrency();
-    if(T > 32)
-        T = 32;
-    if(T < 2 || n < 131072) {
-        f((int64_t)0, n);
-        return;
-    }
-    const int64_t chunk = (n + T - 1) / T;
-    std::vector<std::thread> th;
-    th.reserve(T);
-    for(unsigned t = 0; t < T; t++) {
-        const int64_t lo = (int64_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
-        if(lo >= hi)
-            break;
-        th.emplace_back([=] { f(lo, hi); });
-    }
-    for(auto &x : th)
-        x.join();
-}
-
-struct mpg_engine {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    // the tree build of a step has no data dependence on the step's PM force (both read the bound positions): when a PM
-    // force has just been queued, force_tree_build runs on this second stream next to it (engine-internal; MPG_NO_TREE_OVERLAP=1
-    // keeps everything on one stream)
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_inputs = nullptr, ev_tree_done = nullptr;
-    bool pm_queued = false;
-    // module state (static variables of gravshort-tree.c:30-32, gravity.c:20, forcetree.c:30-37)
-    mpg_gravshort_tree_params treepar{0.002, 0.175, 0.9, 2, 6.0, 1.0 / 30.};
-    double GravitySoftening = 0;
-    double TreeAllocFactor = 0.9;
-    bool have_tab = false;
-    double tab_dx = 0.02935420743639786;
-    DevBuf<float> tab_force, tab_pot;
-    // subsystems
-    PMesh pm;
-    TreeBuilder tree;
-    bool tree_allocated = false;
-    bool full_particle_tree = false;
-    int tree_mask = 63;
-    EventTimer timer;
-    bool count = false;
-    int walk_thresh = 16;
-    // 1: lane-per-target while-while kernel (grav_walk.hip); 4: group-cooperative list kernel (grav_walk_coop.hip); 6: two-kernel walk
-    // (grav_walk_split.hip); 0: 6 for large target sets, 1 for small ones
-    int walk_variant = 0;
-    int walk_choice = 0; // the kernel the default policy used last (0: no walk yet)
-    int walks_since_tune = 0;
-    WalkScratch w3;
-    DevBuf<unsigned long long> counters;
-    int64_t last_targets = 0;
-    // un-synchronised HIP event pairs around every walk launch (collected by mpg_walk_events_collect)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> walk_events, free_events;
-    // SPH module state (static variables of density.c:20, hydra.c:26-34)
-    mpg_density_params denspar{1.0, 2.0, 2.0, 99999., 2 /* quintic */, 0.006};
-    mpg_hydro_params hydropar{1, 100.0, 0.75};
-    SphEngine sph;
-    // bound device particles (caller order)
-    int64_t n = 0;
-    const double *d_pos = nullptr;
-    const float *d_mass = nullptr;
-    const uint8_t *d_type = nullptr;
-    double box = 0;
-    // staging for the host SPH path: one device buffer per mpg_sph_arrays field
-    DevBuf<double> h_sph[19];
-    DevBuf<uint8_t> h_sph_u8[2];
-    // staging for the host (AoS) path
-    DevBuf<double> s_pos, s_accel, s_gravpm, s_pot, s_prev, s_old;
-    DevBuf<float> s_mass;
-    DevBuf<uint8_t> s_type;
-    DevBuf<int> s_active;
-    DevBuf<unsigned> ts_flag;
-    DevBuf<uint8_t> tree_incl; // particles included in an active-particle tree
-    // hierarchical gravity (timestep.c:239-599): active sublists (ping-pong), the per-level acceleration array, scratch
-    DevBuf<int> hier_list[2], hier_val;
-    DevBuf<uint8_t> hier_keep;
-    DevBuf<double> hier_accel, hier_sp;
-    DevBuf<unsigned long long> hier_cnt;
-    DevBuf<char> hier_tmp;
-    PeanoScratch peano;
-    DomainScratch domain;
-    FofEngine fof;
-    HostBuf<double> h_d, h_d2, h_d3; // pinned staging: positions / 3-vectors, scalars
-    HostBuf<float> h_f;
-    HostBuf<uint8_t> h_b;
-    // host path: what is staged (mpg_set_particle_epoch) and the events of the chunked downloads
-    int64_t host_epoch = 0, staged_epoch = 0, staged_n = -1;
-    const void *staged_base = nullptr;
-    double staged_box = 0;
-    hipEvent_t chunk_ev[8] = {};
-};
-
-#define API_BEGIN try {
-#define API_END                      \
-    }                                \
-    catch(const std::exception &e) { \
-        g_err = e.what();            \
-        return 1;                    \
-    }                                \
-    g_err.clear();                   \
-    return 0;
+std::string &mpg_err_slot() { return g_err; }
 
 extern "C" {
 
@@ -540,7 +387,10 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     io.tab_force = eng->tab_force.p;
     io.tab_pot = eng->tab_pot.p;
     io.counters = eng->counters.p;
-    io.pack_leaves = getenv("MPG_PACK_LEAVES") ? 1 : 0; // (experiment knob, see grav_walk_split.hip: measured a wash)
+    { // adjacent opened leaves packed into full 8-particle list entries (grav_walk_split.hip); MPG_PACK_LEAVES=0: one entry per leaf
+        const char *e = getenv("MPG_PACK_LEAVES");
+        io.pack_leaves = (e && e[0] == '0') ? 0 : 1;
+    }
     if(eng->count)
         MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 16 * sizeof(unsigned long long), eng->stream));
     eng->timer.start(eng->stream);

@@ -260,47 +260,27 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
         const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
         const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
         // Leaf entries.  One entry = up to 8 consecutive particles (tree order), evaluated by the 8 lanes of the group in one
-        // pair step.  Opened leaves that are neighbours in tree order (adjacent children of this node) hold consecutive
-        // particles, so SHORT leaves are packed: a run of adjacent opened leaves with T particles becomes ceil(T / 8) entries
-        // instead of one per leaf.  (Away from a regular grid the bucket tree's leaves hold 2 - 4 particles on average: without
-        // packing lanes of the evaluation kernel idle.)  The interaction set is unchanged; only the grouping of the sources
-        // into steps is.  OFF by default (MPG_PACK_LEAVES=1 turns it on): measured at 128^3, the two segmented scans
-        // (~55 instructions on the steps that have a short leaf) cost what the saved pair steps gain - leaves of the test sets
-        // hold 5.8 (Zel'dovich) to 6.9 (clustered) of 8 particles: 15.1 vs 14.4 ms and 131.6 vs 135.5 ms with / without.
+        // pair step.  The children of a node hold consecutive particle ranges (octant order = tree order), so a run of adjacent
+        // opened leaves with T particles in all is ONE contiguous range and becomes ceil(T / 8) full entries instead of one
+        // (partly filled) entry per leaf: leaves hold 5.5 - 5.8 of 8 particles on the S-grid and Zel'dovich sets, so a quarter of
+        // the evaluation kernel's pair steps carried idle lanes.  The interaction set is unchanged; only the grouping of the
+        // sources into steps is.  The run of lane s is found from the group's 8-bit mask of opened leaves with bit operations
+        // (first lane h of the run: highest clear bit below s; last lane: first clear bit above s) and two cross-lane reads
+        // (the run's first particle, the end of its last leaf); lane h + q writes entry q of the run.  (The first form of this,
+        // two segmented scans of ~55 instructions per step, cost what it saved; MPG_PACK_LEAVES=0 restores one entry per leaf.)
         bool has_ent = b_leaf;
         unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
         if(pack && any_lane(b_leaf && lk.pcount != NMAXCHILD)) {
-            const int cnt = b_leaf ? lk.pcount : 0;
-            const int ps_prev = __shfl_up(lk.pstart, 1, 8), cnt_prev = __shfl_up(cnt, 1, 8);
-            // a lane starts a run unless the lane before it holds an opened leaf that ends where this one begins
-            const bool head = !b_leaf || s == 0 || cnt_prev == 0 || ps_prev + cnt_prev != lk.pstart;
-            const bool head_next = __shfl_down(head ? 1 : 0, 1, 8) != 0;
-            const bool tail = !b_leaf || s == 7 || head_next;
-            int v = cnt; // inclusive prefix of the particle counts within the run
-            bool f = head;
-            for(int d = 1; d < 8; d <<= 1) {
-                const int v2 = __shfl_up(v, d, 8);
-                const bool f2 = __shfl_up(f ? 1 : 0, d, 8) != 0;
-                if(s >= d && !f) {
-                    v += v2;
-                    f = f2;
-                }
-            }
-            int tot = v; // the run's total: the prefix at its last lane, handed backwards
-            bool g = tail;
-            for(int d = 1; d < 8; d <<= 1) {
-                const int t2 = __shfl_down(tot, d, 8);
-                const bool g2 = __shfl_down(g ? 1 : 0, d, 8) != 0;
-                if(s + d < 8 && !g) {
-                    tot = t2 > tot ? t2 : tot;
-                    g = g2;
-                }
-            }
-            const int off = v - cnt;                 // particles of the run before this leaf
-            const int e8 = (off + 7) & ~7;           // the entry boundary (multiple of 8 in run coordinates) at or after `off`
-            has_ent = b_leaf && e8 < off + cnt;      // ... lies inside this leaf: this lane writes that entry
-            const int ecnt = (tot - e8 < 8) ? tot - e8 : 8;
-            ent_val = ((unsigned)(lk.pstart - off + e8) << 3) | (unsigned)(ecnt - 1);
+            const unsigned gm_open = (unsigned)((__builtin_amdgcn_ballot_w64(b_leaf) >> gshift) & 0xffull);
+            const unsigned zb = ~gm_open & below;                       // lanes below s that hold no opened leaf
+            const int h = zb ? 32 - __clz((int)zb) : 0;                 // first lane of the run that contains lane s
+            const int last = s + __ffs((int)~(gm_open >> s)) - 2;       // its last lane (bit 0 of gm_open >> s is this lane's own)
+            const int pend = lk.pstart + lk.pcount;
+            const int rs = __shfl(lk.pstart, gshift + h);
+            const int re = __shfl(pend, gshift + (b_leaf ? last : s));
+            const int T = re - rs, q8 = (s - h) << 3;
+            has_ent = b_leaf && q8 < T;
+            ent_val = ((unsigned)(rs + q8) << 3) | (unsigned)(((T - q8 < 8) ? T - q8 : 8) - 1);
         }
         const unsigned gm_leaf = (unsigned)((__builtin_amdgcn_ballot_w64(has_ent) >> gshift) & 0xffull);
         const unsigned gm_node = (unsigned)((__builtin_amdgcn_ballot_w64(b_node) >> gshift) & 0xffull);

@@ -52,6 +52,7 @@ struct TreeBuilder {
     int64_t nnodes = 0;
     int maxlevel = 0;
     int minleaflevel = 0; // depth of the shallowest leaf (largest leaf side = 1.001 Box / 2^minleaflevel)
+    int force_internal_above = 0; // domain-decomposed runs: cells above this level are never leaves (their local particle sets are incomplete)
     double box = 0;
     bool has_moments = false, has_hmax = false;
 

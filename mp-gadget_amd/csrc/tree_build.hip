@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_gather_src(int64_t n, const uint32_t *_
 // flags[0]: error (too many coincident particles), flags[1]: max leaf level, flags[2]: MAXLEVEL - min leaf level
 // Each block stages its 256 keys plus an 8-key halo on either side in LDS (one coalesced read instead of 17 per thread).
 __global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__restrict__ keys, uint8_t *__restrict__ leaflevel,
-                                                   uint32_t *__restrict__ cnt, int *__restrict__ flags, int *__restrict__ wave_ext)
+                                                   uint32_t *__restrict__ cnt, int *__restrict__ flags, int *__restrict__ wave_ext, int minlevel)
 {
     __shared__ uint64_t sk[256 + 16];
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(256) k_leaflevel(int64_t n, const uint64_t *__
             best = m > best ? m : best;
         }
         L = best + 1; // shallowest level whose cell holds <= 8 particles
+        L = L < minlevel ? minlevel : L; // (domain-decomposed runs: cells above `minlevel` stay internal, see TreeBuilder::top_set)
         if(L > MAXLEVEL) {
             flags[0] = 1;
             L = MAXLEVEL;
@@ -481,7 +482,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     if(npart > 0) {
         const int64_t nwaves = (int64_t)nblk(npart) * 4;
         wave_ext.reserve((size_t)nwaves);
-        hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags, wave_ext.p);
+        hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags, wave_ext.p, force_internal_above);
         hipLaunchKernelGGL(k_level_extrema, dim3(64), dim3(256), 0, st, nwaves, wave_ext.p, d_flags);
         size_t sb = 0;
         MPG_HIP(rocprim::exclusive_scan(nullptr, sb, cnt.p, base.p, 0u, (size_t)npart, rocprim::plus<uint32_t>(), st));

@@ -1,0 +1,188 @@
+"""The force step on several ranks through the library's own choreography (csrc/dist.hip, `mpg_dist_*` of
+include/mpgadget_hip.h): Python here only supplies the communicator.
+
+The reference's entry points are collective over MPI_COMM_WORLD; the C-ABI takes the three collectives it needs as callbacks
+(`mpg_comm`).  `TorchComm` implements them over torch.distributed - RCCL over xGMI when the process group's backend is "nccl"
+(device pointers go straight into all_to_all_single), gloo on host memory in the CPU-launched tests that put several ranks on
+one GPU (the library then stages through pinned host buffers).  A C caller supplies MPI_Allreduce / MPI_Alltoall /
+MPI_Alltoallv instead (shim/)."""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+from .domain_peano import TopNode
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int)
+A2A_I64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+A2AV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                      C.POINTER(C.c_int64), C.c_int)
+
+
+class MpgComm(C.Structure):     # mpg_comm, include/mpgadget_hip.h
+    _fields_ = [("ctx", C.c_void_p), ("ThisTask", C.c_int), ("NTask", C.c_int), ("device_buffers", C.c_int),
+                ("allreduce", ALLREDUCE_FN), ("alltoall_i64", A2A_I64_FN), ("alltoallv", A2AV_FN)]
+
+
+class _DevMem:
+    """a raw device pointer as a __cuda_array_interface__ object: torch.as_tensor wraps it without a copy"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _bytes_tensor(ptr, nbytes, on_device, device):
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device if on_device else "cpu")
+    if on_device:
+        return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+    return torch.frombuffer((C.c_char * int(nbytes)).from_address(int(ptr)), dtype=torch.uint8)
+
+
+# RCCL 2.26 (torch 2.10 / ROCm 7) returned garbage in the second half of an all_to_all_single message above 1 GiB (measured with
+# a one-rank group, tools/a2a_selftest.py): no call carries more than this many bytes in total; larger exchanges go in pieces
+A2A_MAX_BYTES = 1 << 29
+
+
+class TorchComm:
+    """mpg_comm over a torch.distributed process group (one process per GPU)."""
+
+    def __init__(self, device, group=None):
+        self.group, self.device = group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.errors = []
+        self._fns = (ALLREDUCE_FN(self._allreduce), A2A_I64_FN(self._alltoall_i64), A2AV_FN(self._alltoallv))   # keep alive
+        self.struct = MpgComm(None, self.rank, self.world, 1 if self.on_device else 0, *self._fns)
+
+    def _guard(self, f, *a):
+        try:
+            f(*a)
+            return 0
+        except Exception as e:      # a callback must not raise through the C frames
+            self.errors.append(repr(e))
+            return 1
+
+    def _allreduce(self, ctx, buf, count, dtype, op, on_device):
+        def go():
+            t = _bytes_tensor(buf, 8 * count, bool(on_device), self.device).view(torch.int64 if dtype else torch.float64)
+            red = dist.ReduceOp.MAX if op else dist.ReduceOp.SUM
+            if self.on_device and not on_device:      # RCCL reduces device memory only: a small host array goes through the GPU
+                g = t.to(self.device)
+                dist.all_reduce(g, op=red, group=self.group)
+                t.copy_(g.cpu())
+            else:
+                dist.all_reduce(t, op=red, group=self.group)
+            if on_device:
+                torch.cuda.current_stream().synchronize()
+        return self._guard(go)
+
+    def _alltoall_i64(self, ctx, send, recv):
+        def go():
+            s = torch.tensor([send[i] for i in range(self.world)], dtype=torch.int64)
+            r = torch.empty_like(s)
+            if self.on_device:
+                s, r = s.to(self.device), r.to(self.device)
+            dist.all_to_all_single(r, s, group=self.group)
+            r = r.cpu()
+            for i in range(self.world):
+                recv[i] = int(r[i])
+        return self._guard(go)
+
+    def _alltoallv(self, ctx, send, sbytes, sdispls, recv, rbytes, rdispls, on_device):
+        def go():
+            w = self.world
+            sb, sd = [sbytes[i] for i in range(w)], [sdispls[i] for i in range(w)]
+            rb, rd = [rbytes[i] for i in range(w)], [rdispls[i] for i in range(w)]
+            S = _bytes_tensor(send, max((d + b for d, b in zip(sd, sb)), default=0), bool(on_device), self.device)
+            R = _bytes_tensor(recv, max((d + b for d, b in zip(rd, rb)), default=0), bool(on_device), self.device)
+            packed = lambda b, d: all(d[i] == sum(b[:i]) for i in range(w))
+            piece = max(A2A_MAX_BYTES // w, 1)
+            nchunk = max((max(max(sb), max(rb)) + piece - 1) // piece, 1)
+            if nchunk == 1 and packed(sb, sd) and packed(rb, rd):
+                dist.all_to_all_single(R[:sum(rb)], S[:sum(sb)], rb, sb, group=self.group)
+            else:
+                for c in range(nchunk):        # blocks in rank order, each block cut into pieces
+                    cs = [min(max(b - c * piece, 0), piece) for b in sb]
+                    cr = [min(max(b - c * piece, 0), piece) for b in rb]
+                    src = torch.cat([S[d + c * piece:d + c * piece + n] for d, n in zip(sd, cs)]) if sum(cs) else S[:0]
+                    dst = torch.empty(sum(cr), dtype=torch.uint8, device=S.device)
+                    dist.all_to_all_single(dst, src, cr, cs, group=self.group)
+                    o = 0
+                    for d, n in zip(rd, cr):
+                        R[d + c * piece:d + c * piece + n] = dst[o:o + n]
+                        o += n
+            if on_device:
+                torch.cuda.current_stream().synchronize()   # the library continues on ITS stream
+        return self._guard(go)
+
+
+class LocalComm:
+    """one rank, no process group: NULL callbacks (the library then copies locally)"""
+
+    def __init__(self):
+        self.errors = []
+        self.rank, self.world = 0, 1
+        self.struct = MpgComm(None, 0, 1, 0, ALLREDUCE_FN(), A2A_I64_FN(), A2AV_FN())
+
+
+def _bind(lib):
+    if getattr(lib, "_dist_bound", False):
+        return
+    lib.mpg_dist_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(MpgComm)]
+    lib.mpg_dist_destroy.argtypes = [C.c_void_p]
+    lib.mpg_dist_destroy.restype = None
+    lib.mpg_dist_set_domain.argtypes = [C.c_void_p, C.c_double, C.POINTER(TopNode), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_int]
+    lib.mpg_dist_gravity_step.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 7 + [C.c_double]
+    lib.mpg_dist_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.mpg_dist_get_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib._dist_bound = True
+
+
+class DistForce:
+    """mpg_dist: gravpm_force + force_tree_full + grav_short_tree for particles distributed over the ranks by a Peano-Hilbert
+    domain decomposition (domain_peano.PeanoDomain)."""
+
+    def __init__(self, eng, comm):
+        self.eng, self.lib, self.comm = eng, eng.lib, comm
+        _bind(self.lib)
+        self.h = C.c_void_p()
+        self._ck(self.lib.mpg_dist_create(C.byref(self.h), eng.h, C.byref(comm.struct)))
+
+    def _ck(self, rc):
+        if rc:
+            msg = self.lib.mpg_last_error().decode()
+            if self.comm.errors:
+                msg += " | callback: " + "; ".join(self.comm.errors[-3:])
+            raise E.EngineError(msg)
+
+    def set_domain(self, dom, margin, La=0):
+        """dom: a decomposed PeanoDomain (TopNodes, leaf_task); margin: at least Rcut in length units"""
+        tn = np.ascontiguousarray(dom.TopNodes)
+        lt = np.ascontiguousarray(dom.leaf_task, np.int32)
+        self._keep = (tn, lt)
+        self._ck(self.lib.mpg_dist_set_domain(self.h, C.c_double(dom.box), tn.ctypes.data_as(C.POINTER(TopNode)), int(dom.NTopNodes),
+                                              lt.ctypes.data_as(C.POINTER(C.c_int)), int(dom.NTopLeaves), C.c_double(margin), int(La)))
+
+    def gravity_step(self, pos, mass, accel, gravpm, potential=None, oldacc=None, prev_accel=None, rho0=0.0):
+        """one force step for this rank's own particles (device tensors, n_own rows)"""
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._ck(self.lib.mpg_dist_gravity_step(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(oldacc), p(prev_accel), p(accel), p(gravpm),
+                                                p(potential), C.c_double(rho0)))
+
+    def stats(self):
+        s = (C.c_int64 * 8)()
+        self._ck(self.lib.mpg_dist_get_stats(self.h, s))
+        return dict(ghosts=s[0], pm_shipped=s[1], local=s[2], La=s[3], exchange_bytes=s[4], transpose_bytes=s[5])
+
+    def times(self):
+        t = (C.c_double * 8)()
+        self._ck(self.lib.mpg_dist_get_times(self.h, t))
+        return dict(pm=t[0], ghosts=t[1], tree=t[2], walk=t[3])
+
+    def close(self):
+        if self.h:
+            self.lib.mpg_dist_destroy(self.h)
+            self.h = C.c_void_p()

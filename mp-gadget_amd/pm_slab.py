@@ -41,6 +41,8 @@ def _has_all_to_all(group=None):
     ranks on one GPU) does not: there the exchanges gather everything and slice.  The path is chosen ONCE from the backend - not by
     catching errors, which would let one rank's genuine failure (out of memory, bad sizes) drop it into a different collective
     than its peers are in."""
+    if os.environ.get("MPG_GLOO_TRY_A2A"):       # experiment: use the backend's own all_to_all_single whatever it is (DESIGN.md section 4)
+        return True
     return dist.get_backend(group) == "nccl"
 
 

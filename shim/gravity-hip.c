@@ -1,0 +1,228 @@
+/* libgadget/gravity-hip.c -- the reference's gravity entry points forwarded to libmpgadget_hip.so.
+ *
+ * Replaces gravpm.o, gravshort-tree.o and gravity.o in the link of libgadget; forcetree.o, treewalk.o and
+ * petapm.o stay for the 14 other tree walks and MP-GenIC.  Compiled inside the reference tree with its own headers:
+ *     $(CC) $(OPTIMIZE) -I$(MPGADGET_HIP)/include -c gravity-hip.c mpg_mpi_comm.c          link: -lmpgadget_hip
+ * (This container cannot compile it - gravity.h pulls in pfft.h and GSL, SURVEY 8(c) - so everything that does not need a
+ * reference type lives behind the C-ABI, where tests/c/test_cabi.c exercises it with the same call sequence.)
+ *
+ * One rank = one GPU.  NTask == 1: the host-pointer calls.  NTask > 1: the mpg_dist_* calls on the rank's own P[] with the
+ * domain of ddecomp and MPI as the communicator (mpg_mpi_comm.c) - collective, as the functions they replace. */
+#include <mpi.h>
+#include <string.h>
+#include "gravity.h"     /* PetaPM, struct gravshort_tree_params, prototypes of everything defined here */
+#include "forcetree.h"   /* ForceTree */
+#include "domain.h"      /* DomainDecomp, struct topnode_data / topleaf_data */
+#include "partmanager.h" /* P, PartManager */
+#include "timestep.h"    /* ActiveParticles */
+#include "walltime.h"
+#include "utils/endrun.h"
+#include "utils/mymalloc.h"
+#include <mpgadget_hip.h>
+#include "mpg_mpi_comm.h"
+
+_Static_assert(sizeof(struct particle_data) == 160 && __builtin_offsetof(struct particle_data, GravPM) == 88 &&
+               __builtin_offsetof(struct particle_data, FullTreeGravAccel) == 64 && __builtin_offsetof(struct particle_data, Potential) == 152,
+               "struct particle_data is not the layout mpg_particle_view_reference_layout assumes (partmanager.h:9-71)");
+
+extern const double shortrange_force_kernels[][5]; /* libgadget/shortrange-kernel.c stays in the link as data */
+
+static mpg_engine *E;
+static mpg_dist *D;
+static MPI_Comm Comm;
+static int NTask = 1;
+static int64_t Epoch;
+static const DomainDecomp *DomainOfD; /* the decomposition D was told about */
+static int NTopLeavesOfD;
+
+static void ck(int rc)
+{
+    if(rc)
+        endrun(5, "mpgadget_hip: %s\n", mpg_last_error());
+}
+
+static mpg_engine *eng(void)
+{
+    if(!E) {
+        int rank, local;
+        MPI_Comm shm;
+        Comm = MPI_COMM_WORLD;
+        MPI_Comm_rank(Comm, &rank);
+        MPI_Comm_size(Comm, &NTask);
+        MPI_Comm_split_type(Comm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &shm); /* rank on this node -> GPU */
+        MPI_Comm_rank(shm, &local);
+        MPI_Comm_free(&shm);
+        ck(mpg_engine_create(&E, local));
+        if(NTask > 1) {
+            mpg_comm c = mpg_mpi_comm(&Comm);
+            ck(mpg_dist_create(&D, E, &c));
+        }
+    }
+    return E;
+}
+
+mpg_engine *mpg_shim_engine(void) { return eng(); } /* sph-hip.c shares the rank's engine */
+
+static mpg_particle_view view(void)
+{
+    mpg_particle_view v;
+    mpg_particle_view_reference_layout(&v, P, PartManager->NumPart);
+    return v;
+}
+
+/* the clocks the reference charges on this path, fed from the engine's per-phase device times */
+static void charge_pm_clocks(void)
+{
+    mpg_phase_times t;
+    if(mpg_get_phase_times(eng(), &t))
+        return;
+    walltime_add("/PMgrav/init", 1e-3 * t.pm_deposit);     /* pm_init_regions + deposit (petapm.c:280) */
+    walltime_add("/PMgrav/r2c", 0.2 * 1e-3 * t.pm_fft);    /* one forward of the five transforms (petapm.c:319) */
+    walltime_add("/PMgrav/calc", 1e-3 * t.pm_transfer);    /* transfer functions (petapm.c:341) */
+    walltime_add("/PMgrav/c2r", 0.8 * 1e-3 * t.pm_fft);    /* the inverse transforms (petapm.c:346) */
+    walltime_add("/PMgrav/readout", 1e-3 * t.pm_readout);  /* petapm.c:355 */
+}
+
+void gravpm_init_periodic(PetaPM *pm, double BoxSize, double Asmth, int Nmesh, double G)
+{
+    pm->BoxSize = BoxSize;
+    pm->Asmth = Asmth;
+    pm->Nmesh = Nmesh;
+    pm->G = G;
+    pm->CellSize = BoxSize / Nmesh;
+    ck(mpg_gravpm_init_periodic(eng(), BoxSize, Asmth, Nmesh, G));
+}
+
+/* petapm_module_init / petapm_destroy stay with petapm.o (MP-GenIC and the reionisation PM use it): the PetaPM object of the
+ * gravity path is never given to petapm_init here, so petapm_destroy on it finds priv == NULL plans... the maintainer guards
+ * runtests.c:204,222 with `if(pm->priv)`; the device mesh is released by mpg_petapm_destroy when the engine is destroyed. */
+
+/* tell the library about the decomposition the particles were exchanged by (domain_decompose_full ran before this step) */
+static void sync_domain(DomainDecomp *ddecomp, double BoxSize, double Rcut)
+{
+    if(DomainOfD == ddecomp && NTopLeavesOfD == ddecomp->NTopLeaves)
+        return;
+    mpg_topnode *tn = (mpg_topnode *)mymalloc("mpg_topnodes", ddecomp->NTopNodes * sizeof(mpg_topnode));
+    int *task = (int *)mymalloc("mpg_leaftask", ddecomp->NTopLeaves * sizeof(int));
+    int i;
+    for(i = 0; i < ddecomp->NTopNodes; i++) {
+        memset(&tn[i], 0, sizeof(tn[i]));
+        tn[i].StartKey = ddecomp->TopNodes[i].StartKey;
+        tn[i].Shift = ddecomp->TopNodes[i].Shift;
+        tn[i].Daughter = ddecomp->TopNodes[i].Daughter;
+        tn[i].Leaf = ddecomp->TopNodes[i].Daughter < 0 ? ddecomp->TopNodes[i].Leaf : -1;
+    }
+    for(i = 0; i < ddecomp->NTopLeaves; i++)
+        task[i] = ddecomp->TopLeaves[i].Task;
+    ck(mpg_dist_set_domain(D, BoxSize, tn, ddecomp->NTopNodes, task, ddecomp->NTopLeaves, Rcut, 0));
+    myfree(task);
+    myfree(tn);
+    DomainOfD = ddecomp;
+    NTopLeavesOfD = ddecomp->NTopLeaves;
+}
+
+void gravpm_force(PetaPM *pm, DomainDecomp *ddecomp, Cosmology *CP, double Time, double UnitLength_in_cm, const char *PowerOutputDir,
+                  double TimeIC)
+{
+    (void)CP;
+    (void)UnitLength_in_cm;
+    (void)TimeIC;
+    mpg_particle_view v = view();
+    walltime_measure("/Misc");
+    /* P[] has just been exchanged / drifted: one upload of Pos / Mass serves the three calls of this step (run.c:522-548) */
+    ck(mpg_set_particle_epoch(eng(), ++Epoch));
+    if(NTask == 1)
+        ck(mpg_gravpm_force(eng(), &v)); /* writes P[i].GravPM, accumulates P[i].Potential */
+    else {
+        const struct gravshort_tree_params tp = get_gravshort_treepar();
+        sync_domain(ddecomp, pm->BoxSize, tp.Rcut * pm->Asmth * pm->CellSize);
+        ck(mpg_dist_gravpm_force(D, &v));
+    }
+    charge_pm_clocks();
+    /* the matter power spectrum gravpm_force saves on every PM step (gravpm.c:110-118) */
+    if(PowerOutputDir && NTask == 1) {
+        double *kk = (double *)mymalloc("pk", 2 * pm->Nmesh * sizeof(double)), *pw = kk + pm->Nmesh;
+        int64_t *nm = (int64_t *)mymalloc("pkn", pm->Nmesh * sizeof(int64_t));
+        int nonzero = 0;
+        ck(mpg_gravpm_get_powerspectrum(eng(), pm->BoxSize * UnitLength_in_cm / 3.085678e24, kk, pw, nm, &nonzero));
+        int rank;
+        MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+        if(rank == 0)
+            ck(mpg_powerspectrum_save(PowerOutputDir, "powerspectrum", Time, 1.0, nonzero, kk, pw, nm));
+        myfree(nm);
+        myfree(kk);
+    }
+    walltime_measure("/PMgrav/PowerSpec");
+}
+
+void gravshort_fill_ntab(const enum ShortRangeForceWindowType t, const double Asmth)
+{
+    ck(mpg_gravshort_fill_ntab(eng(), (int)t, Asmth, &shortrange_force_kernels[0][0], 512));
+}
+
+void set_gravshort_treepar(struct gravshort_tree_params p)
+{
+    _Static_assert(sizeof(struct gravshort_tree_params) == sizeof(mpg_gravshort_tree_params), "gravshort_tree_params (gravity.h:9-22)");
+    ck(mpg_set_gravshort_treepar(eng(), (const mpg_gravshort_tree_params *)&p));
+}
+
+struct gravshort_tree_params get_gravshort_treepar(void)
+{
+    struct gravshort_tree_params p;
+    ck(mpg_get_gravshort_treepar(eng(), (mpg_gravshort_tree_params *)&p));
+    return p;
+}
+
+void gravshort_set_softenings(double MeanSeparation) { ck(mpg_gravshort_set_softenings(eng(), MeanSeparation)); }
+/* (blackhole.c, density.c, timestep.c and run.c read the softening through this) */
+double FORCE_SOFTENING(void) { return mpg_force_softening(eng()); }
+
+/* The CPU ForceTree stays the property of forcetree.c (the other walks use it); the device tree of the gravity path is built
+ * here, when grav_short_tree is entered with a tree whose moments are valid - the point where run.c:546-547 has just called
+ * force_tree_full(). */
+void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, MyFloat (*AccelStore)[3], double rho0, inttime_t Ti_Current)
+{
+    (void)Ti_Current;
+    mpg_particle_view v = view();
+    if(!tree->moments_computed_flag)
+        endrun(2, "Gravtree called before tree moments computed!\n");
+    walltime_measure("/Misc");
+    if(NTask == 1) {
+        ck(mpg_force_tree_rebuild_mask(eng(), &v, tree->BoxSize, tree->mask));
+        ck(mpg_grav_short_tree(eng(), &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
+    }
+    else {
+        if(act->ActiveParticle || !tree->full_particle_tree_flag)
+            endrun(5, "mpgadget_hip: the multi-rank walk serves steps on which every particle is active (PM steps); "
+                      "sub-steps of the hierarchical loop keep the CPU walk\n");
+        (void)pm;
+        ck(mpg_dist_force_tree_full(D, &v));
+        ck(mpg_dist_grav_short_tree(D, &v, AccelStore, rho0));
+    }
+    /* gravshort-tree.c:135-144: no export phase on this path (ghosts are imported before the walk), so the top-tree and
+     * secondary walks cost nothing; the tree build of the device tree is charged to the reference's build clocks */
+    mpg_phase_times t;
+    ck(mpg_get_phase_times(eng(), &t));
+    walltime_add("/Tree/Build/Nodes", 1e-3 * (t.tree_keys + t.tree_sort + t.tree_nodes));
+    walltime_add("/Tree/Build/Moments", 1e-3 * t.tree_moments);
+    walltime_add("/Tree/WalkTop", 0);
+    walltime_add("/Tree/WalkPrim", 1e-3 * t.walk);
+    walltime_add("/Tree/WalkSec", 0);
+    walltime_add("/Tree/Reduce", 0);
+    walltime_add("/Tree/PostPre", 0);
+    walltime_add("/Tree/Wait", 0);
+    const double timeall = walltime_measure(WALLTIME_IGNORE);
+    walltime_add("/Tree/Misc", timeall - 1e-3 * (t.walk + t.tree_total));
+}
+
+/* grav_short_pair (gravshort-pair.c:21-57; runtests.c:131): the exact pair-wise force inside Rcut */
+void grav_short_pair(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, double Rcut, double rho0)
+{
+    (void)pm;
+    mpg_particle_view v = view();
+    if(NTask > 1)
+        endrun(5, "mpgadget_hip: grav_short_pair is a single-rank test helper (runtests.c)\n");
+    ck(mpg_force_tree_rebuild_mask(eng(), &v, tree->BoxSize, tree->mask));
+    ck(mpg_grav_short_pair(eng(), &v, act->ActiveParticle, act->NumActiveParticle, Rcut, rho0));
+    walltime_measure("/Tree/Pairwise");
+}

@@ -1,0 +1,10 @@
+/* mpg_mpi_comm.h -- the three collectives of mpg_comm (include/mpgadget_hip.h) on an MPI communicator: what the in-tree shim
+ * (gravity-hip.c, sph-hip.c) hands to the mpg_dist_* calls.  Host buffers (device_buffers = 0): the library stages through pinned
+ * memory, so any MPI works; set device_buffers after the call if the MPI is GPU-aware. */
+#ifndef MPG_MPI_COMM_H
+#define MPG_MPI_COMM_H
+#include <mpi.h>
+#include <mpgadget_hip.h>
+/* `comm` must stay valid as long as the returned struct is in use (its address is the callback context) */
+mpg_comm mpg_mpi_comm(MPI_Comm *comm);
+#endif

@@ -1,0 +1,401 @@
+/* test_cabi.c -- a C caller of libmpgadget_hip.so, as the reference's run.c would be one: plain gcc, no Python,
+ * no torch.  Built and run by tests/test_gpu_cabi.py on the GPU box.
+ *
+ *   test_cabi single <table.f64> <pos.f64> <expect.f64> n nmesh box
+ *       the drop-in (host pointer) calls on an array of 160-byte `struct particle_data` records: mpg_gravpm_force,
+ *       mpg_force_tree_full, mpg_grav_short_tree (twice: Barnes-Hut opening, then the relative criterion, test_gravity.c:211-213);
+ *       P[].GravPM and P[].FullTreeGravAccel against the committed vectors of tests/golden/ (expect = GravPM[n][3], Accel2[n][3]).
+ *   test_cabi ranks|ranks_host <table.f64> <pos.f64> <expect.f64> n nmesh box NTask
+ *       NTask processes (fork; the collectives of mpg_comm are implemented on a shared-memory segment with a process-shared
+ *       barrier - what MPI_Allreduce / MPI_Alltoall / MPI_Alltoallv would do), every one with its own engine on GPU 0: particles
+ *       handed to the owners of the 8 top-level Peano-Hilbert cells (a legal, unbalanced domain), mpg_dist_set_domain,
+ *       mpg_dist_gravity_step twice (ranks: device arrays) or the drop-in calls mpg_dist_gravpm_force / _force_tree_full /
+ *       _grav_short_tree on each rank's table of 160-byte records (ranks_host); the assembled GravPM / accelerations against the
+ *       same vectors.
+ * Exit code 0 and a last line "PASS ..." on success. */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "mpgadget_hip.h"
+
+/* the four HIP runtime calls a device-resident caller needs (declared here so that plain gcc compiles this file) */
+extern int hipMalloc(void **p, size_t n);
+extern int hipFree(void *p);
+extern int hipMemcpy(void *dst, const void *src, size_t n, int kind); /* 1 = host to device, 2 = device to host */
+extern int hipDeviceSynchronize(void);
+
+/* struct particle_data, libgadget/partmanager.h:9-71 (160 bytes; the fields the force path touches, the rest as padding) */
+struct particle_data {
+    double Pos[3];            /* 0 */
+    int TopLeaf;              /* 24 */
+    float Mass;               /* 28 */
+    int PI;                   /* 32 */
+    unsigned char flags[3];   /* 36: bit fields (IsGarbage, ...), TimeBinHydro, TimeBinGravity */
+    unsigned char Type;       /* 39 */
+    double Vel[3];            /* 40 */
+    double FullTreeGravAccel[3]; /* 64 */
+    double GravPM[3];         /* 88 */
+    int64_t Ti_drift;         /* 112 */
+    double Hsml, DtHsml;      /* 120, 128 */
+    uint64_t ID;              /* 136 */
+    int64_t GrNr;             /* 144 */
+    double Potential;         /* 152 */
+};
+_Static_assert(sizeof(struct particle_data) == 160, "particle_data is 160 bytes");
+_Static_assert(__builtin_offsetof(struct particle_data, Mass) == 28 && __builtin_offsetof(struct particle_data, Type) == 39 &&
+               __builtin_offsetof(struct particle_data, FullTreeGravAccel) == 64 && __builtin_offsetof(struct particle_data, GravPM) == 88 &&
+               __builtin_offsetof(struct particle_data, Potential) == 152, "particle_data layout");
+
+#define CK(call)                                                                    \
+    do {                                                                            \
+        if((call) != 0) {                                                           \
+            fprintf(stderr, "FAIL %s:%d %s: %s\n", __FILE__, __LINE__, #call, mpg_last_error()); \
+            exit(1);                                                                \
+        }                                                                           \
+    } while(0)
+
+static double *read_f64(const char *path, size_t count)
+{
+    FILE *f = fopen(path, "rb");
+    if(!f) {
+        fprintf(stderr, "FAIL cannot open %s\n", path);
+        exit(1);
+    }
+    double *d = malloc(count * sizeof(double));
+    if(fread(d, sizeof(double), count, f) != count) {
+        fprintf(stderr, "FAIL short read of %s\n", path);
+        exit(1);
+    }
+    fclose(f);
+    return d;
+}
+
+static mpg_engine *make_engine(const double *table, double box, int n, int nmesh)
+{
+    mpg_engine *e = NULL;
+    CK(mpg_engine_create(&e, 0));
+    CK(mpg_gravshort_fill_ntab(e, 0, 1.5, table, 512));
+    CK(mpg_gravpm_init_periodic(e, box, 1.5, nmesh, 43.0071));
+    mpg_gravshort_tree_params tp = {0.002, 0.175, 0.9, 2, 6.0, 1.0 / 30.};
+    CK(mpg_set_gravshort_treepar(e, &tp));
+    CK(mpg_gravshort_set_softenings(e, box / n));
+    return e;
+}
+
+/* max |a - b| / mean |b| over count values */
+static double relerr(const double *a, const double *b, size_t count)
+{
+    double mx = 0, mean = 0;
+    for(size_t i = 0; i < count; i++) {
+        const double d = fabs(a[i] - b[i]);
+        mx = d > mx ? d : mx;
+        mean += fabs(b[i]);
+    }
+    return mx / (mean / count);
+}
+
+static int run_single(const double *table, const double *pos, const double *expect, int n, int nmesh, double box)
+{
+    const int64_t N = (int64_t)n * n * n;
+    struct particle_data *P = calloc(N, sizeof(struct particle_data));
+    for(int64_t i = 0; i < N; i++) {
+        memcpy(P[i].Pos, pos + 3 * i, 3 * sizeof(double));
+        P[i].Mass = 1.0f;
+        P[i].Type = 1;
+        P[i].ID = (uint64_t)i;
+    }
+    mpg_engine *e = make_engine(table, box, n, nmesh);
+    mpg_particle_view v;
+    mpg_particle_view_reference_layout(&v, P, N);
+    CK(mpg_gravpm_force(e, &v));
+    CK(mpg_force_tree_full(e, &v, box));
+    CK(mpg_grav_short_tree(e, &v, NULL, 0, NULL, 0.0)); /* Barnes-Hut opening */
+    CK(mpg_grav_short_tree(e, &v, NULL, 0, NULL, 0.0)); /* relative criterion, OldAcc = |FullTreeGravAccel + GravPM| / G */
+    double *gpm = malloc(3 * N * sizeof(double)), *acc = malloc(3 * N * sizeof(double));
+    for(int64_t i = 0; i < N; i++)
+        for(int k = 0; k < 3; k++) {
+            gpm[3 * i + k] = P[i].GravPM[k];
+            acc[3 * i + k] = P[i].FullTreeGravAccel[k];
+        }
+    const double e_pm = relerr(gpm, expect, 3 * N), e_tr = relerr(acc, expect + 3 * N, 3 * N);
+    mpg_engine_destroy(e);
+    printf("single: N %lld  GravPM err %.3e  FullTreeGravAccel err %.3e\n", (long long)N, e_pm, e_tr);
+    if(!(e_pm < 1e-10 && e_tr < 1e-10)) {
+        printf("FAIL\n");
+        return 1;
+    }
+    printf("PASS single\n");
+    return 0;
+}
+
+/* ---- NTask processes on one box: the collectives of mpg_comm on shared memory ---------------------------------------------- */
+#define MAXT 8
+struct shm {
+    pthread_barrier_t bar;
+    int64_t cnt[MAXT][MAXT];
+    int64_t off[MAXT][MAXT];
+    size_t cap;         /* bytes of data[] per rank */
+    int64_t N;
+    int failed;
+    /* followed by: data[MAXT][cap], result[N][6] */
+};
+struct ctx {
+    struct shm *S;
+    int me, nt;
+};
+static char *shm_data(struct shm *S, int r) { return (char *)(S + 1) + (size_t)r * S->cap; }
+static double *shm_result(struct shm *S) { return (double *)((char *)(S + 1) + (size_t)MAXT * S->cap); }
+
+static int cb_allreduce(void *c_, void *buf, int64_t count, int dtype, int op, int on_device)
+{
+    struct ctx *c = c_;
+    if(on_device || (size_t)count * 8 > c->S->cap)
+        return 1;
+    memcpy(shm_data(c->S, c->me), buf, (size_t)count * 8);
+    pthread_barrier_wait(&c->S->bar);
+    for(int64_t i = 0; i < count; i++) {
+        if(dtype) {
+            int64_t a = ((int64_t *)shm_data(c->S, 0))[i];
+            for(int r = 1; r < c->nt; r++) {
+                const int64_t b = ((int64_t *)shm_data(c->S, r))[i];
+                a = op ? (b > a ? b : a) : a + b;
+            }
+            ((int64_t *)buf)[i] = a;
+        }
+        else {
+            double a = ((double *)shm_data(c->S, 0))[i];
+            for(int r = 1; r < c->nt; r++) {
+                const double b = ((double *)shm_data(c->S, r))[i];
+                a = op ? (b > a ? b : a) : a + b;
+            }
+            ((double *)buf)[i] = a;
+        }
+    }
+    pthread_barrier_wait(&c->S->bar);
+    return 0;
+}
+
+static int cb_alltoall_i64(void *c_, const int64_t *send, int64_t *recv)
+{
+    struct ctx *c = c_;
+    for(int d = 0; d < c->nt; d++)
+        c->S->cnt[c->me][d] = send[d];
+    pthread_barrier_wait(&c->S->bar);
+    for(int s = 0; s < c->nt; s++)
+        recv[s] = c->S->cnt[s][c->me];
+    pthread_barrier_wait(&c->S->bar);
+    return 0;
+}
+
+static int cb_alltoallv(void *c_, const void *send, const int64_t *sb, const int64_t *sd, void *recv, const int64_t *rb, const int64_t *rd,
+                        int on_device)
+{
+    struct ctx *c = c_;
+    if(on_device)
+        return 1;
+    size_t o = 0;
+    for(int d = 0; d < c->nt; d++) {
+        if(o + (size_t)sb[d] > c->S->cap)
+            return 1;
+        memcpy(shm_data(c->S, c->me) + o, (const char *)send + sd[d], (size_t)sb[d]);
+        c->S->off[c->me][d] = (int64_t)o;
+        c->S->cnt[c->me][d] = sb[d];
+        o += (size_t)sb[d];
+    }
+    pthread_barrier_wait(&c->S->bar);
+    int bad = 0;
+    for(int s = 0; s < c->nt; s++) {
+        if(c->S->cnt[s][c->me] != rb[s])
+            bad = 1;
+        else
+            memcpy((char *)recv + rd[s], shm_data(c->S, s) + c->S->off[s][c->me], (size_t)rb[s]);
+    }
+    pthread_barrier_wait(&c->S->bar);
+    return bad;
+}
+
+static void rank_main(struct shm *S, int me, int nt, const double *table, const double *pos, int n, int nmesh, double box, int host)
+{
+    const int64_t N = S->N;
+    alarm(300); /* a rank that dies leaves its peers at a barrier: do not hang the test */
+    struct ctx cx = {S, me, nt};
+    mpg_comm comm = {&cx, me, nt, 0, cb_allreduce, cb_alltoall_i64, cb_alltoallv};
+    mpg_engine *e = make_engine(table, box, n, nmesh);
+    /* the domain: the root of the Peano-Hilbert key space cut into its 8 cells, cell k owned by task k % NTask
+     * (struct topnode_data, domain.h:12-18: StartKey, Shift, Daughter, Leaf) */
+    mpg_topnode tn[9];
+    int leaf_task[8];
+    memset(tn, 0, sizeof(tn));
+    tn[0].StartKey = 0;
+    tn[0].Shift = 63;
+    tn[0].Daughter = 1;
+    tn[0].Parent = -1;
+    tn[0].Leaf = -1;
+    for(int k = 0; k < 8; k++) {
+        tn[1 + k].StartKey = (uint64_t)k << 60;
+        tn[1 + k].Shift = 60;
+        tn[1 + k].Daughter = -1;
+        tn[1 + k].Parent = 0;
+        tn[1 + k].Leaf = k;
+        leaf_task[k] = k % nt;
+    }
+    /* own particles: those whose key falls into my cells (keys from the engine: PEANO(), peano.h:15-21) */
+    double *d_all = NULL;
+    uint64_t *d_keys = NULL, *keys = malloc(N * sizeof(uint64_t));
+    if(hipMalloc((void **)&d_all, 3 * N * sizeof(double)) || hipMalloc((void **)&d_keys, N * sizeof(uint64_t)) ||
+       hipMemcpy(d_all, pos, 3 * N * sizeof(double), 1)) {
+        fprintf(stderr, "FAIL hipMalloc\n");
+        exit(1);
+    }
+    CK(mpg_dev_peano_keys(e, N, d_all, box, d_keys));
+    CK(mpg_engine_synchronize(e));
+    hipMemcpy(keys, d_keys, N * sizeof(uint64_t), 2);
+    int64_t n_own = 0;
+    int64_t *ids = malloc(N * sizeof(int64_t));
+    for(int64_t i = 0; i < N; i++)
+        if(leaf_task[keys[i] >> 60] == me)
+            ids[n_own++] = i;
+    double *opos = malloc(3 * (n_own + 1) * sizeof(double));
+    float *omass = malloc((n_own + 1) * sizeof(float));
+    for(int64_t k = 0; k < n_own; k++) {
+        memcpy(opos + 3 * k, pos + 3 * ids[k], 3 * sizeof(double));
+        omass[k] = 1.0f;
+    }
+    double *d_pos, *d_acc, *d_prev, *d_gpm, *d_pot;
+    float *d_mass;
+    const size_t b3 = 3 * (n_own + 1) * sizeof(double);
+    if(hipMalloc((void **)&d_pos, b3) || hipMalloc((void **)&d_acc, b3) || hipMalloc((void **)&d_prev, b3) || hipMalloc((void **)&d_gpm, b3) ||
+       hipMalloc((void **)&d_pot, b3) || hipMalloc((void **)&d_mass, (n_own + 1) * sizeof(float))) {
+        fprintf(stderr, "FAIL hipMalloc\n");
+        exit(1);
+    }
+    hipMemcpy(d_pos, opos, 3 * n_own * sizeof(double), 1);
+    hipMemcpy(d_mass, omass, n_own * sizeof(float), 1);
+    mpg_dist *D = NULL;
+    CK(mpg_dist_create(&D, e, &comm));
+    const double rcut = 6.0 * 1.5 * box / nmesh; /* Rcut * Asmth * cell size, gravshort-tree.c:102 */
+    CK(mpg_dist_set_domain(D, box, tn, 9, leaf_task, 8, rcut, 0));
+    double *acc = malloc(b3), *gpm = malloc(b3);
+    if(host) {
+        /* the drop-in calls on this rank's table of 160-byte records, in run.c's order; twice (Barnes-Hut, then relative) */
+        struct particle_data *P = calloc(n_own + 1, sizeof(struct particle_data));
+        for(int64_t k = 0; k < n_own; k++) {
+            memcpy(P[k].Pos, opos + 3 * k, 3 * sizeof(double));
+            P[k].Mass = 1.0f;
+            P[k].Type = 1;
+            P[k].ID = (uint64_t)ids[k];
+        }
+        mpg_particle_view v;
+        mpg_particle_view_reference_layout(&v, P, n_own);
+        for(int it = 0; it < 2; it++) {
+            CK(mpg_dist_gravpm_force(D, &v));
+            CK(mpg_dist_force_tree_full(D, &v));
+            CK(mpg_dist_grav_short_tree(D, &v, NULL, 0.0));
+        }
+        for(int64_t k = 0; k < n_own; k++)
+            for(int j = 0; j < 3; j++) {
+                gpm[3 * k + j] = P[k].GravPM[j];
+                acc[3 * k + j] = P[k].FullTreeGravAccel[j];
+            }
+        free(P);
+    }
+    else {
+        CK(mpg_dist_gravity_step(D, n_own, d_pos, d_mass, NULL, NULL, d_prev, d_gpm, d_pot, 0.0));  /* Barnes-Hut opening */
+        CK(mpg_dist_gravity_step(D, n_own, d_pos, d_mass, NULL, d_prev, d_acc, d_gpm, d_pot, 0.0)); /* relative criterion */
+        hipMemcpy(acc, d_acc, 3 * n_own * sizeof(double), 2);
+        hipMemcpy(gpm, d_gpm, 3 * n_own * sizeof(double), 2);
+    }
+    int64_t st[8];
+    CK(mpg_dist_get_stats(D, st));
+    double *R = shm_result(S);
+    for(int64_t k = 0; k < n_own; k++)
+        for(int j = 0; j < 3; j++) {
+            R[6 * ids[k] + j] = gpm[3 * k + j];
+            R[6 * ids[k] + 3 + j] = acc[3 * k + j];
+        }
+    printf("rank %d of %d: own %lld ghosts %lld local %lld La %lld\n", me, nt, (long long)n_own, (long long)st[0], (long long)st[2], (long long)st[3]);
+    fflush(stdout);
+    mpg_dist_destroy(D);
+    mpg_engine_destroy(e);
+    pthread_barrier_wait(&S->bar);
+}
+
+static int run_ranks(const double *table, const double *pos, const double *expect, int n, int nmesh, double box, int nt, int host)
+{
+    const int64_t N = (int64_t)n * n * n;
+    if(nt < 1 || nt > MAXT || nmesh % nt) {
+        fprintf(stderr, "FAIL NTask must be in 1..%d and divide Nmesh\n", MAXT);
+        return 1;
+    }
+    const size_t cap = (size_t)nmesh * nmesh * (nmesh / 2 + 1) * 16 * 2 + 64 * N + (1 << 20); /* a transpose, the particle rows, slack */
+    const size_t total = sizeof(struct shm) + MAXT * cap + 6 * N * sizeof(double);
+    struct shm *S = mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if(S == MAP_FAILED) {
+        perror("mmap");
+        return 1;
+    }
+    memset(S, 0, sizeof(*S));
+    S->cap = cap;
+    S->N = N;
+    pthread_barrierattr_t ba;
+    pthread_barrierattr_init(&ba);
+    pthread_barrierattr_setpshared(&ba, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&S->bar, &ba, (unsigned)nt);
+    pid_t pids[MAXT];
+    for(int r = 0; r < nt; r++) { /* (fork before anything touches the HIP runtime) */
+        pids[r] = fork();
+        if(pids[r] == 0) {
+            rank_main(S, r, nt, table, pos, n, nmesh, box, host);
+            _exit(0);
+        }
+    }
+    int bad = 0;
+    for(int r = 0; r < nt; r++) {
+        int status = 0;
+        waitpid(pids[r], &status, 0);
+        if(!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+            bad = 1;
+    }
+    if(bad) {
+        printf("FAIL a rank exited with an error\n");
+        return 1;
+    }
+    const double *R = shm_result(S);
+    double *gpm = malloc(3 * N * sizeof(double)), *acc = malloc(3 * N * sizeof(double));
+    for(int64_t i = 0; i < N; i++)
+        for(int j = 0; j < 3; j++) {
+            gpm[3 * i + j] = R[6 * i + j];
+            acc[3 * i + j] = R[6 * i + 3 + j];
+        }
+    const double e_pm = relerr(gpm, expect, 3 * N), e_tr = relerr(acc, expect + 3 * N, 3 * N);
+    printf("ranks %d (%s): N %lld  GravPM err %.3e  acceleration err %.3e\n", nt, host ? "host tables" : "device arrays", (long long)N, e_pm, e_tr);
+    if(!(e_pm < 1e-10 && e_tr < 1e-10)) {
+        printf("FAIL\n");
+        return 1;
+    }
+    printf("PASS ranks %d\n", nt);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if(argc < 8) {
+        fprintf(stderr, "usage: %s single|ranks table.f64 pos.f64 expect.f64 n nmesh box [NTask]\n", argv[0]);
+        return 2;
+    }
+    const int n = atoi(argv[5]), nmesh = atoi(argv[6]);
+    const double box = atof(argv[7]);
+    const size_t N = (size_t)n * n * n;
+    double *table = read_f64(argv[2], 512 * 5), *pos = read_f64(argv[3], 3 * N), *expect = read_f64(argv[4], 6 * N);
+    if(!strcmp(argv[1], "single"))
+        return run_single(table, pos, expect, n, nmesh, box);
+    return run_ranks(table, pos, expect, n, nmesh, box, argc > 8 ? atoi(argv[8]) : 2, !strcmp(argv[1], "ranks_host"));
+}

@@ -64,3 +64,15 @@ def test_product_never_imports_oracle():
             txt = open(path).read()
             for needle in ("import oracle", "from oracle", "liboracle", "oracle/"):
                 assert needle not in txt, (path, needle)
+
+
+def test_mpi_comm_shim_compiles():
+    """shim/mpg_mpi_comm.c (mpg_comm on an MPI communicator) against the MPI-3 headers of this image, when they are there"""
+    import shutil
+    import subprocess
+    inc = "/opt/conda/include"
+    if not os.path.exists(os.path.join(inc, "mpi.h")) or not shutil.which("gcc"):
+        pytest.skip("no mpi.h in this image")
+    r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", inc,
+                        os.path.join(ROOT, "shim", "mpg_mpi_comm.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

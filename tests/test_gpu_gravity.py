@@ -341,18 +341,18 @@ def test_load_order_torch_first():
     assert out.returncode == 0 and "gfx950" in out.stdout, out.stderr[-2000:]
 
 
-def _run_mgpu(tmp_path, name, nproc, mode, port, ic="s_zel"):
+def _run_mgpu(tmp_path, name, nproc, mode, port, ic="s_zel", n=40, env_extra=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / name)
-    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode, MPG_MGPU_IC=ic)
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode, MPG_MGPU_IC=ic, **(env_extra or {}))
     script = os.path.join(root, "tools", "mgpu_check.py")
     if nproc == 1:
-        cmd = [sys.executable, script, out, "40"]
+        cmd = [sys.executable, script, out, str(n)]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), script, out, "40"]
+               "--master-port", str(port), script, out, str(n)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     return np.load(out)
@@ -393,6 +393,27 @@ def test_distributed_particles_clustered(tmp_path):
         dm = _run_mgpu(tmp_path, name, nproc, "domain", port, ic="s_clust")
         assert_accel_parity(dm[:, 0:3], one[:, 0:3])
         assert np.abs(dm[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * np.abs(one[:, 3:6]).mean(), name
+
+
+@keep_artifacts_on_failure
+@pytest.mark.parametrize("ic", ["s_zel", "s_clust"])
+def test_peano_domain_ranks_match_one(tmp_path, ic):
+    """The force step on the reference's own decomposition, through the library's choreography (csrc/dist.hip, mpg_dist_*): particles on
+    the owners of their Peano-Hilbert TopLeaves (domain_decompose_full + exchange), PM by shipping particles to the x-slabs and the
+    results back, ghosts in whole level-La tree cells around the rank's TopLeaves, the nodes above from an all-reduce.  1 rank (no
+    communicator), 2, 3 and 4 ranks (gloo, sharing this GPU; the collectives are the mpg_comm callbacks) against one GPU: the same
+    decisions except where a node's moments, summed in another order, sit within an ulp of an opening threshold."""
+    n = 36                                                            # Nmesh = 72: a multiple of 2, 3 and 4
+    one = _run_mgpu(tmp_path, "one.npy", 1, "single", 0, ic=ic, n=n)
+    for name, nproc, port in (("p1.npy", 1, 0), ("p2.npy", 2, 29601), ("p3.npy", 3, 29602), ("p4.npy", 4, 29603)):
+        d = _run_mgpu(tmp_path, name, nproc, "peano" if nproc > 1 else "peano1", port, ic=ic, n=n)
+        assert_accel_parity(d[:, 0:3], one[:, 0:3])
+        assert np.abs(d[:, 3:6] - one[:, 3:6]).max() <= 1e-11 * np.abs(one[:, 3:6]).mean(), name
+        # P[].Potential after a PM step is the tree's (grav_short_reduce assigns it in primary mode, gravshort.h:94-95); the one-rank
+        # run of the same code is the reference for it
+        if nproc == 1:
+            pot1 = d[:, 6]
+        assert np.abs(d[:, 6] - pot1).max() <= 1e-9 * np.abs(pot1).mean(), name
 
 
 def test_full_size_256_properties(pkg, orc):

@@ -40,7 +40,7 @@ acc = torch.zeros_like(gravpm)
 old = torch.full((N,), 1e-7, dtype=torch.float64, device=dev)
 mode = os.environ.get("MPG_MGPU_MODE", "slab")
 pot = torch.zeros(N, dtype=torch.float64, device=dev)
-if world == 1 and mode not in ("slab1", "domain1"):
+if world == 1 and mode not in ("slab1", "domain1", "peano1"):
     eng.dev_gravpm_force(gravpm, pot)
     eng.dev_force_tree_build()
     eng.dev_grav_short_tree(acc, oldacc=old)
@@ -51,6 +51,31 @@ elif mode == "replicated":
     optr = eng.dev_tree_order_ptr()
     eng.dev_grav_short_tree(acc, oldacc=old, active=optr + 4 * lo, nactive=hi - lo)
     pkg.shard.exchange_results(acc, eng.dev_tree_order(N, dev), rank, world)
+elif mode.startswith("peano"):
+    # the library's own choreography (csrc/dist.hip): particles on their Peano-Hilbert owners (domain_decompose_full + exchange),
+    # PM by shipping particles to the x-slabs, ghosts in whole level-La cells around the rank's TopLeaves, global top of the tree
+    DP = pkg.domain_peano
+    share = slice((N * rank) // world, (N * (rank + 1)) // world)          # what this rank holds before the decomposition
+    ids = torch.arange(N, dtype=torch.int64, device=dev)[share]
+    dom = DP.PeanoDomain(eng, box, rank, world, overdecomposition=int(os.environ.get("MPG_OVERDECOMP", "4")))
+    dom.decompose(d_pos[share].contiguous())
+    opos, omass, oids = dom.exchange(d_pos[share].contiguous(), d_mass[share].contiguous(), ids)
+    n_own = int(opos.shape[0])
+    comm = pkg.dist.TorchComm(dev) if grouped else pkg.dist.LocalComm()
+    df = pkg.dist.DistForce(eng, comm)
+    rcut = 6.0 * 1.5 * box / (2 * n)
+    df.set_domain(dom, rcut)
+    f8 = dict(dtype=torch.float64, device=dev)
+    ga, gg, gp = torch.zeros(n_own, 3, **f8), torch.zeros(n_own, 3, **f8), torch.zeros(n_own, **f8)
+    df.gravity_step(opos, omass, ga, gg, potential=gp, oldacc=torch.full((n_own,), 1e-7, **f8))
+    both = torch.zeros(N, 7, **f8)
+    both[oids] = torch.cat([ga, gg, gp[:, None]], dim=1)
+    if grouped:
+        pkg.pm_slab.TargetExchange(world, dev).exchange(both, oids.to(torch.int32))
+    acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
+    if rank == 0:
+        print("peano: %s own %d times %s" % (df.stats(), n_own, df.times()), flush=True)
+    df.close()
 elif mode.startswith("domain"):
     # particles distributed: own = x-slab particles, ghosts imported in whole tree-cell columns, global top of the tree
     rcut = 6.0 * 1.5 * box / (2 * n)
@@ -87,13 +112,16 @@ else:
     acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
 # the matter power spectrum measured on the way (gravpm.c:331-382): rows of (k, P, Nmodes)
 mpc = box / 1000.0
-if world == 1 and mode not in ("slab1", "domain1") or mode == "replicated":
+if world == 1 and mode not in ("slab1", "domain1", "peano1") or mode == "replicated":
     ps = eng.gravpm_get_powerspectrum(2 * n, mpc)
+elif mode.startswith("peano"):
+    ps = None
 else:
     ps = spm.power_spectrum(mpc)
 torch.cuda.synchronize()
 if rank == 0:
-    np.save(out + ".ps.npy", np.stack([ps[0], ps[1], ps[2].astype(np.float64)], axis=1))
+    if ps is not None:
+        np.save(out + ".ps.npy", np.stack([ps[0], ps[1], ps[2].astype(np.float64)], axis=1))
     np.save(out, np.concatenate([acc.cpu().numpy(), gravpm.cpu().numpy(), pot.cpu().numpy()[:, None]], axis=1))
 if grouped:
     dist.barrier()
