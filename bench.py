@@ -151,9 +151,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--mgpu", choices=["domain", "slab", "replicated"], default="domain",
-                    help="N > 1: domain = particles distributed (x-slab domains, ghost import, slab PM); slab = particles replicated, "
-                         "slab PM and slab targets; replicated = everything but the walk targets replicated")
+    ap.add_argument("--mgpu", choices=["peano", "domain", "slab", "replicated"], default="peano",
+                    help="N > 1: peano = particles on the owners of their Peano-Hilbert TopLeaves (the reference's domain_decompose_full), "
+                         "force step through the library's own choreography (mpg_dist_*, csrc/dist.hip); domain = x-slab domains with "
+                         "ghost import driven from Python (round 1); slab = particles replicated, slab PM and slab targets; replicated = "
+                         "everything but the walk targets replicated")
+    ap.add_argument("--overdecomp", type=int, default=8, help="peano: DomainOverDecompositionFactor (TopLeaves per rank and policy)")
+    ap.add_argument("--no-rebalance", action="store_true",
+                    help="peano: keep the decomposition by particle number (default: after two set-up steps the TopLeaves are dealt out "
+                         "again by the measured work per particle, domain.c:611)")
     ap.add_argument("--sph", default="auto", choices=["auto", "de", "pe"],
                     help="hydro workload: density-entropy (BASELINE configs[2]) or pressure-entropy SPH (configs[4]); auto: de on one GPU, pe on several")
     ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof", "domain"],
@@ -262,6 +268,24 @@ def main():
         spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         loc = {}                                             # arrays over [own | ghosts], sized on first use
+    elif multi and args.mgpu == "peano":
+        # domain_decompose_full + domain_exchange (untimed): every rank starts from a contiguous share of the set
+        share = slice((N * rank) // world, (N * (rank + 1)) // world)
+        pdom = pkg.domain_peano.PeanoDomain(eng, box, rank, world, overdecomposition=args.overdecomp)
+        sp, sm = d_pos[share].contiguous(), d_mass[share].contiguous()
+        pdom.decompose(sp)
+        own_pos, own_mass = pdom.exchange(sp, sm)
+        n_own = int(own_pos.shape[0])
+        tot = torch.tensor([n_own], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        assert int(tot.item()) == N, "the ranks' own sets do not add up to the particle set (%d of %d)" % (int(tot.item()), N)
+        del d_pos, d_mass, sp, sm, gravpm, acc, prev, pot
+        torch.cuda.empty_cache()
+        comm = pkg.dist.TorchComm(dev)
+        dforce = pkg.dist.DistForce(eng, comm)
+        dforce.set_domain(pdom, 6.0 * 1.5 * box / nmesh)      # margin = Rcut * Asmth * cell size (gravshort-tree.c:102)
+        z3 = lambda: torch.zeros(n_own, 3, dtype=torch.float64, device=dev)
+        loc = dict(acc=z3(), prev=z3(), gravpm=z3(), pot=torch.zeros(n_own, dtype=torch.float64, device=dev), steps=0)
     elif multi and args.mgpu == "slab":
         spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
         tex = pkg.pm_slab.TargetExchange(world, dev)
@@ -293,8 +317,45 @@ def main():
         pm_ms[0] += ev0.elapsed_time(ev1)
         pm_ms[1] += 1
 
+    def rank_sums(x):
+        """max over ranks / mean over ranks of a per-rank number"""
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = float(x)
+        dist.all_reduce(t)
+        return float(t.max() / t.mean())
+
+    def rebalance_peano():
+        """domain_decompose_full again, now with the work the last walk measured per particle as the cost the TopLeaves are balanced
+        by, and the exchange of the particles (with their last acceleration, which the relative opening criterion needs)"""
+        nonlocal own_pos, own_mass, n_own
+        cost = dforce.walk_cost(n_own)
+        loc["work_before"] = rank_sums(cost.sum().item())
+        loc["count_before"] = rank_sums(n_own)
+        # what equal-volume x-slabs (the domains of round 1) would carry of the same work
+        slab = pkg.pm_slab.slab_of_cells(own_pos[:, 0], box / nmesh, nmesh, world)
+        w = torch.zeros(world, dtype=torch.float64, device=dev).index_add_(0, slab, cost.double())
+        dist.all_reduce(w)
+        loc["work_xslab"] = float(w.max() / w.mean())
+        pdom.decompose(own_pos, cost=cost)
+        own_pos, own_mass, pa, pg = pdom.exchange(own_pos, own_mass, loc["acc"], loc["gravpm"])
+        n_own = int(own_pos.shape[0])
+        dforce.set_domain(pdom, 6.0 * 1.5 * box / nmesh)
+        z3 = lambda: torch.zeros(n_own, 3, dtype=torch.float64, device=dev)
+        loc.update(acc=pa.contiguous(), prev=z3(), gravpm=pg.contiguous(), pot=torch.zeros(n_own, dtype=torch.float64, device=dev))
+        step_peano()
+        loc["work_after"] = rank_sums(dforce.walk_cost(n_own).sum().item())
+        loc["count_after"] = rank_sums(n_own)
+
+    def step_peano():
+        loc["prev"], loc["acc"] = loc["acc"], loc["prev"]
+        # the first step has no previous acceleration: Barnes-Hut opening (TreeUseBH = 2), as the reference's first step
+        dforce.gravity_step(own_pos, own_mass, loc["acc"], loc["gravpm"], potential=loc["pot"], prev_accel=loc["prev"] if loc["steps"] else None)
+        loc["steps"] += 1
+
     def step():
         nonlocal acc, prev
+        if multi and args.mgpu == "peano":
+            return step_peano()
         if multi and args.mgpu == "domain":
             return step_domain()
         if not multi:
@@ -328,6 +389,9 @@ def main():
         torch.cuda.synchronize()
 
     step()          # set-up, not a step: first-use allocations, FFT plans, the list-capacity adaptation of the walk and the deposit's timing trial (engine.hip, pm.hip)
+    if multi and args.mgpu == "peano" and not args.no_rebalance:
+        step()      # (a walk with the relative criterion: its per-particle work is what the domains are balanced by)
+        rebalance_peano()
     for _ in range(args.warmup):
         step()
     sync()
@@ -352,7 +416,7 @@ def main():
     eng.set_instrumentation(False, False)
     eng.walk_events_collect()
     if os.environ.get("MPG_BENCH_DEBUG") and rank == 0:
-        if multi and args.mgpu == "domain":
+        if multi and args.mgpu in ("domain", "peano"):
             a, b, g = loc["acc"][:n_own], loc["prev"][:n_own], loc["gravpm"][:n_own]
         else:
             a, b, g = acc, prev, gravpm
@@ -378,7 +442,12 @@ def main():
             "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
                                    "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
                        "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
-                       ("%d GPUs: particles distributed in x-slab domains, ghosts imported in whole tree-cell columns within Rcut "
+                       ("%d GPUs: particles on the owners of their Peano-Hilbert TopLeaves (domain_decompose_full, %d TopLeaves); per step "
+                        "{Pos, Mass} shipped to the x-slab PM (2 all-to-all transposes + neighbour planes) and {GravPM, Potential} back, "
+                        "ghosts imported in whole level-La tree cells within Rcut of the rank's TopLeaves, top of the tree from an "
+                        "all-reduce; choreography in the library (mpg_dist_*), collectives on RCCL" % (world, pdom.NTopLeaves)
+                        if args.mgpu == "peano" else
+                        "%d GPUs: particles distributed in x-slab domains, ghosts imported in whole tree-cell columns within Rcut "
                         "(one personalised exchange per step), top of the tree from an all-reduce, x-slab PM (2 all-to-all "
                         "transposes + ghost planes per step); nothing replicated or all-gathered" % world if args.mgpu == "domain" else
                         "%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
@@ -391,6 +460,22 @@ def main():
             out["phases_ms"]["pm_slab_total_incl_collectives"] = round(pm_ms[0] / pm_ms[1], 3)
         if multi and args.mgpu == "domain":
             out["config"]["ghost_fraction_rank0"] = round(loc["ghost_fraction"], 3)
+        if multi and args.mgpu == "peano":
+            st, tm = dforce.stats(), dforce.times()
+            out["config"]["ghost_fraction_rank0"] = round(st["ghosts"] / max(n_own, 1), 3)
+            out["config"]["decomposition_level_La"] = st["La"]
+            out["config"]["own_particles_max_over_mean"] = round(float(pdom.task_loads.max() / pdom.task_loads.mean()), 4)
+            if "work_after" in loc:
+                out["config"]["load_balance"] = {
+                    "walk_work_max_over_mean": round(loc["work_after"], 4), "particles_max_over_mean": round(loc["count_after"], 4),
+                    "by_particle_number": {"walk_work_max_over_mean": round(loc["work_before"], 4),
+                                           "particles_max_over_mean": round(loc["count_before"], 4)},
+                    "x_slab_domains_walk_work_max_over_mean": round(loc["work_xslab"], 4),
+                    "note": "TopLeaves dealt to the ranks by measured walk work per particle (8 x leaf entries + nodes used + 8 x "
+                            "traversal steps); by_particle_number = the same step on the decomposition balanced by particle counts"}
+            out["phases_ms"].update({"dist_pm_ms": round(tm["pm"], 3), "dist_ghost_import_ms": round(tm["ghosts"], 3),
+                                     "dist_tree_and_top_ms": round(tm["tree"], 3), "dist_walk_ms": round(tm["walk"], 3),
+                                     "dist_exchange_bytes": st["exchange_bytes"], "dist_transpose_bytes": st["transpose_bytes"]})
         if world == 1 and not multi and not args.no_cpu_baseline:    # (MPG_FORCE_MGPU frees the full arrays: no baseline leg)
             out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
                                                args.cpu_sample)
@@ -695,18 +780,7 @@ def hydro_bench(pkg, torch, args, dev):
 
 
 def hydro_ics(pkg, n):
-    """2 x n^3 particles: gas and dark matter offset from a Zel'dovich-displaced grid (genic/main.c:61-63)."""
-    posd, _, box = pkg.ics.s_zel(n)
-    sp = box / n
-    ob, om = 0.045, 0.3
-    posg = np.mod(posd - 0.5 * (om - ob) / om * sp, box)
-    posd = np.mod(posd + 0.5 * ob / om * sp, box)
-    posg[posg <= 0] += box
-    posd[posd <= 0] += box
-    pos = np.concatenate([posg, posd])
-    mass = np.concatenate([np.full(n ** 3, ob / om, np.float32), np.full(n ** 3, 1 - ob / om, np.float32)])
-    typ = np.concatenate([np.zeros(n ** 3, np.uint8), np.ones(n ** 3, np.uint8)])
-    return pos, mass, typ, box
+    return pkg.ics.hydro_pair(n)
 
 
 def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):

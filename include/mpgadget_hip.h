@@ -147,6 +147,11 @@ int mpg_dev_force_tree_build(mpg_engine *eng, int mask);
 int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm,
                             const int *d_active, int64_t nactive, double *d_accel, double *d_potential, double rho0);
 
+/* Work measure for the domain decomposition (the reference balances TopLeaves by cost, domain.c:611): while d_cost is set, the
+ * two-kernel walk writes d_cost[i] = 8 x leaf-list entries + nodes used + 8 x traversal steps for every target i (caller order;
+ * other entries untouched).  NULL switches it off. */
+int mpg_dev_set_walk_cost(mpg_engine *eng, float *d_cost);
+
 /* ---- SPH: density (with the smoothing-length iteration) and hydro force ----------------------------- */
 /* struct density_params, libgadget/density.h:10-25 (same fields, same order; DensityKernelType is the enum value
  * 1 cubic / 2 quintic / 4 quartic of densitykernel.h:17-21). */
@@ -573,6 +578,9 @@ int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const doub
 int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *P);
 int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P);
 int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0);
+/* per-particle work of the last mpg_dist walk for the rank's own particles (device pointer, n_own floats, caller order):
+ * the cost the next domain decomposition balances (mpg_dev_set_walk_cost) */
+const float *mpg_dist_walk_cost(mpg_dist *d);
 /* what the last step moved: [0] ghosts imported, [1] particles shipped to PM slabs, [2] local tree particles (own + ghosts),
  * [3] decomposition level La, [4] bytes sent in personalised exchanges, [5] bytes sent in transposes */
 int mpg_dist_get_stats(mpg_dist *d, int64_t stats[8]);

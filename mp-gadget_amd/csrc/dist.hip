@@ -259,6 +259,7 @@ struct mpg_dist {
     DevBuf<int> targets;
     HostBuf<double> htop;
     int64_t ntarg = 0, n_own_tree = -1;
+    DevBuf<float> cost;
     int64_t stats[8] = {};
     double times[8] = {};
     // host (drop-in) path: the rank's P[] staged on the device
@@ -768,8 +769,15 @@ int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const doub
     MPG_HIP(hipSetDevice(e->device));
     sync(d);
     const double t3 = now_ms();
-    if(d->ntarg > 0)
-        MPG_CHECK(mpg_dev_grav_short_tree(e, d_oldacc, d_prev_accel, d_gravpm, d->targets.p, d->ntarg, d_accel, d_potential, rho0) == 0, mpg_last_error());
+    if(d->ntarg > 0) {
+        d->cost.reserve((size_t)d->n_own_tree + 1);
+        MPG_HIP(hipMemsetAsync(d->cost.p, 0, (size_t)d->n_own_tree * sizeof(float), e->stream));
+        float *keep = e->d_walk_cost;
+        e->d_walk_cost = d->cost.p;
+        const int rc = mpg_dev_grav_short_tree(e, d_oldacc, d_prev_accel, d_gravpm, d->targets.p, d->ntarg, d_accel, d_potential, rho0);
+        e->d_walk_cost = keep;
+        MPG_CHECK(rc == 0, mpg_last_error());
+    }
     sync(d);
     d->times[3] = now_ms() - t3;
     API_END
@@ -932,6 +940,8 @@ int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*A
         column_down(d, n, 1, d->o_pot.p, [=](int64_t i, const double *v) { *(double *)(b + i * V.stride + V.off_potential) = v[0]; });
     API_END
 }
+
+const float *mpg_dist_walk_cost(mpg_dist *d) { return d ? d->cost.p : nullptr; }
 
 int mpg_dist_get_stats(mpg_dist *d, int64_t stats[8])
 {

@@ -359,6 +359,14 @@ static GravParams make_gp(mpg_engine *eng, double rho0)
     return gp;
 }
 
+int mpg_dev_set_walk_cost(mpg_engine *eng, float *d_cost)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->d_walk_cost = d_cost;
+    API_END
+}
+
 int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm,
                             const int *d_active, int64_t nactive, double *d_accel, double *d_potential, double rho0)
 {
@@ -387,6 +395,12 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     io.tab_force = eng->tab_force.p;
     io.tab_pot = eng->tab_pot.p;
     io.counters = eng->counters.p;
+    io.cost = eng->d_walk_cost;
+    {
+        static const int lp = getenv("MPG_LIST_PRIO") ? atoi(getenv("MPG_LIST_PRIO")) : 0, ep = getenv("MPG_EVAL_PRIO") ? atoi(getenv("MPG_EVAL_PRIO")) : 0;
+        io.list_prio = lp;
+        io.eval_prio = ep;
+    }
     { // adjacent opened leaves packed into full 8-particle list entries (grav_walk_split.hip); MPG_PACK_LEAVES=0: one entry per leaf
         const char *e = getenv("MPG_PACK_LEAVES");
         io.pack_leaves = (e && e[0] == '0') ? 0 : 1;

@@ -107,6 +107,7 @@ struct mpg_engine {
     WalkScratch w3;
     DevBuf<unsigned long long> counters;
     int64_t last_targets = 0;
+    float *d_walk_cost = nullptr; // per-target work of the walks, caller order (mpg_dev_set_walk_cost; null: not recorded)
     // un-synchronised HIP event pairs around every walk launch (collected by mpg_walk_events_collect)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> walk_events, free_events;
     // SPH module state (static variables of density.c:20, hydra.c:26-34)

@@ -132,6 +132,17 @@ __device__ __forceinline__ void st32(unsigned *__restrict__ base, const unsigned
 
 __device__ __forceinline__ bool any_lane(const bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }
 
+// wave priority for instruction arbitration between the two kernels when they share the CUs (s_setprio takes an immediate)
+__device__ __forceinline__ void set_wave_prio(const int p)
+{
+    if(p == 1)
+        __builtin_amdgcn_s_setprio(1);
+    else if(p == 2)
+        __builtin_amdgcn_s_setprio(2);
+    else if(p >= 3)
+        __builtin_amdgcn_s_setprio(3);
+}
+
 __device__ __forceinline__ double nearest_img(double d, double box, double invbox) { return fma(-rint(d * invbox), box, d); }
 
 // chunks of 8 targets (one per 8-lane group) of the slice; XCD x (= blockIdx % 8, where the hardware places this block) owns
@@ -163,7 +174,7 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
                                             const int cap, const int lane, const int s, const int gshift, const bool valid, const double px,
                                             const double py, const double pz, const double aold, const bool pack, const unsigned guard_max,
                                             unsigned *__restrict__ ctl, int &nleaf, int &nnode, bool &wrapped, bool &overflow, unsigned &c_pp,
-                                            unsigned &c_vis, unsigned &c_used, unsigned &st_a, unsigned &st_al)
+                                            unsigned &c_vis, unsigned &c_used, unsigned &st_a, unsigned &st_al, unsigned &nsteps)
 {
     const unsigned below = (1u << s) - 1u;
     int sp = 0; // stack pointer (group-uniform)
@@ -190,6 +201,7 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
             err = true;
             break;
         }
+        nsteps += can ? 1u : 0u;
         const unsigned range = can ? stack[sp - 1] : 0u;
         const int nch = (int)(range & 15u);
         const bool mine = s < nch; // false for every lane of a group that is not walking
@@ -329,6 +341,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
                                                      unsigned *__restrict__ ctl, int *__restrict__ ovf)
 {
     __shared__ unsigned s_stack[4 * 8 * STK];
+    set_wave_prio(io.list_prio);
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, s = lane & 7;
     const int gshift = grp * 8;
@@ -367,22 +380,24 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const 
         unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8;
         int nleaf = 0, nnode = 0; // entries in the two lists (group-uniform)
         bool wrapped = false, overflow = false;
-        unsigned c_pp = 0, c_vis = 0, c_used = 0;
+        unsigned c_pp = 0, c_vis = 0, c_used = 0, nsteps = 0;
         bool ok;
         if(FASTWRAP) {
             const bool near_face = valid && (fmin(fmin(px, py), pz) < face || fmax(fmax(px, py), pz) > gp.box - face);
             if(!any_lane(near_face))
                 ok = walk_target<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, io.pack_leaves != 0, guard_max, ctl, nleaf, nnode, wrapped,
-                                           overflow, c_pp, c_vis, c_used, st_a, st_al);
+                                           overflow, c_pp, c_vis, c_used, st_a, st_al, nsteps);
             else
                 ok = walk_target<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, io.pack_leaves != 0, guard_max, ctl, nleaf, nnode, wrapped,
-                                           overflow, c_pp, c_vis, c_used, st_a, st_al);
+                                           overflow, c_pp, c_vis, c_used, st_a, st_al, nsteps);
         }
         else
             ok = walk_target<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, io.pack_leaves != 0, guard_max, ctl, nleaf, nnode, wrapped, overflow,
-                                       c_pp, c_vis, c_used, st_a, st_al);
+                                       c_pp, c_vis, c_used, st_a, st_al, nsteps);
         if(!ok)
             return;
+        if(io.cost && valid && s == 0) // (an overflowed target is at least as expensive as a full list)
+            io.cost[ci] = (float)(8 * (overflow ? cap : nleaf) + nnode + 8 * (int)nsteps);
         if(valid && s == 0) {
             if(overflow) {
                 counts[rel] = make_int2(-1, 0);
@@ -505,6 +520,7 @@ __global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeVi
 {
     constexpr int ROW = POT ? 4 : 2;
     __shared__ __attribute__((aligned(16))) double s_wtab[NTAB * ROW];
+    set_wave_prio(io.eval_prio);
     for(int i = threadIdx.x; i < NTAB; i += blockDim.x) {
         const bool last = i == NTAB - 1; // the row the clamp lands on: zeros
         s_wtab[i * ROW + 0] = last ? 0.0 : (double)io.tab_force[i];

@@ -418,6 +418,8 @@ void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream
     nmesh = Nmesh_;
     G = G_;
     cellsize = box / nmesh; // petapm.c:112
+    dep_single = DepositState(); // (the faster deposit form is chosen again on the next particle set)
+    dep_slab = DepositState();
     // the meshes and the 3-D plans are made by the first gravpm_force (ensure_single): the slab-decomposed form never needs them
     // per-index tables: 1/sinc^2(pi k / N) (gravpm.c:412-418) and the differencing factor (gravpm.c:482)
     std::vector<double> is2(nmesh), dff(nmesh);

@@ -172,6 +172,19 @@ class DistForce:
         self._ck(self.lib.mpg_dist_gravity_step(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(oldacc), p(prev_accel), p(accel), p(gravpm),
                                                 p(potential), C.c_double(rho0)))
 
+    def walk_cost(self, n_own):
+        """per-particle work of the last walk for the rank's own particles (float32 device tensor, a copy): feed it to
+        PeanoDomain.decompose(cost=...)"""
+        self.lib.mpg_dist_walk_cost.restype = C.c_void_p
+        self.lib.mpg_dist_walk_cost.argtypes = [C.c_void_p]
+        ptr = self.lib.mpg_dist_walk_cost(self.h)
+        if not ptr or n_own == 0:
+            return torch.zeros(n_own, dtype=torch.float32, device=self.comm_device())
+        return torch.as_tensor(_DevMem(ptr, 4 * n_own), device=self.comm_device()).view(torch.float32).clone()
+
+    def comm_device(self):
+        return getattr(self.comm, "device", None) or torch.device("cuda", torch.cuda.current_device())
+
     def stats(self):
         s = (C.c_int64 * 8)()
         self._ck(self.lib.mpg_dist_get_stats(self.h, s))

@@ -73,7 +73,10 @@ def _pack_rows(tensors, idx):
     cols = []
     for t in tensors:
         r = t[idx].contiguous()
-        cols.append(r.view(torch.uint8).reshape(idx.shape[0], -1))
+        w = t.element_size()
+        for d in t.shape[1:]:
+            w *= int(d)
+        cols.append(r.view(torch.uint8).reshape(idx.shape[0], w))      # (w spelled out: an empty send list has no -1 to infer)
     return torch.cat(cols, dim=1).contiguous() if len(cols) > 1 else cols[0].contiguous()
 
 
@@ -84,7 +87,10 @@ def _unpack_rows(buf, like):
         w = t.element_size()
         for d in t.shape[1:]:
             w *= int(d)
-        out.append(buf[:, c:c + w].contiguous().view(t.dtype).reshape((buf.shape[0],) + tuple(t.shape[1:])))
+        if buf.shape[0] == 0:
+            out.append(torch.empty((0,) + tuple(t.shape[1:]), dtype=t.dtype, device=buf.device))
+        else:
+            out.append(buf[:, c:c + w].contiguous().view(t.dtype).reshape((buf.shape[0],) + tuple(t.shape[1:])))
         c += w
     return out
 

@@ -175,10 +175,12 @@ class PeanoDomain:
             return None
         return tree, size.value
 
-    def decompose(self, pos, garbage=None):
+    def decompose(self, pos, garbage=None, cost=None):
         """domain_decompose_full up to the exchange (domain.c:153-225).  pos: [n, 3] float64 device tensor of this rank's particles,
-        garbage: uint8 device tensor (IsGarbage) or None.  Afterwards: self.TopNodes, .leaf_task, .leaf_topnode, .StartLeaf,
-        .EndLeaf, .TopLeafCount (global), and per particle .topleaf / .task (int32 device tensors), .send_counts."""
+        garbage: uint8 device tensor (IsGarbage) or None.  cost: per-particle work (float device tensor, e.g. DistForce.walk_cost())
+        - the TopLeaves are then dealt to the tasks by equal WORK instead of equal particle numbers (domain_assign_balanced,
+        domain.c:611: "cost").  Afterwards: self.TopNodes, .leaf_task, .leaf_topnode, .StartLeaf, .EndLeaf, .TopLeafCount (global),
+        .task_loads / .task_costs, and per particle .topleaf / .task (int32 device tensors), .send_counts."""
         lib, n = self.lib, int(pos.shape[0])
         self._cdev = pos.device if (self.world > 1 and dist.get_backend(self.group) == "nccl") else torch.device("cpu")
         for i in range(self.last_policy, NPOLICY):
@@ -203,9 +205,21 @@ class PeanoDomain:
                 t = torch.from_numpy(counts).to(self._cdev)
                 dist.all_reduce(t, group=self.group)
                 counts = t.cpu().numpy()
+            leaf_cost = counts
+            if cost is not None:
+                # work per TopLeaf (leaves still in key order here): the sum of its particles' costs, over all ranks
+                tl = self._topleaves(pos, garbage, tree, size, nleaves, np.zeros(nleaves, np.int32))[2].long()
+                lc = torch.zeros(nleaves, dtype=torch.float64, device=pos.device)
+                if n:
+                    live = tl >= 0
+                    lc.index_add_(0, tl[live], cost.to(torch.float64)[live])
+                lc = lc.to(self._cdev)
+                if self.world > 1:
+                    dist.all_reduce(lc, group=self.group)
+                leaf_cost = np.maximum(np.rint(lc.cpu().numpy()), 1).astype(np.int64)
             leaf_task = np.zeros(nleaves, np.int32)
             start, end = np.zeros(self.world, np.int32), np.zeros(self.world, np.int32)
-            _ck(lib, lib.mpg_domain_assign_topleaves_balanced(_p(tree, TopNode), size, _p(leaf_topnode, C.c_int), nleaves, _p(counts, C.c_int64), self.world, 1,
+            _ck(lib, lib.mpg_domain_assign_topleaves_balanced(_p(tree, TopNode), size, _p(leaf_topnode, C.c_int), nleaves, _p(leaf_cost, C.c_int64), self.world, 1,
                                                               _p(leaf_task, C.c_int), _p(start, C.c_int), _p(end, C.c_int)))
             # (counts were per leaf in key order; the assignment renumbers the leaves by (Task, Key): count again in the final order)
             fcounts, tcounts, self.topleaf, self.task = self._topleaves(pos, garbage, tree, size, nleaves, leaf_task)

@@ -154,3 +154,20 @@ def s_zel(n, box=None, seed=181170, rms_disp=0.5, index=-2.0):
     pos = np.mod((q + psi) * sp, box)
     pos[pos <= 0] += box   # positions live in (0, Box] (drift.c:76-79)
     return pos, np.ones(n ** 3, dtype=np.float32), box
+
+
+def hydro_pair(n, box=None):
+    """2 x n^3 particles for the gas configurations (BASELINE configs[2] and [4]): gas and dark matter offset from a
+    Zel'dovich-displaced grid as MP-GenIC offsets them (genic/main.c:61-63).  Returns (pos, mass float32, type uint8, box): the gas
+    (type 0) first, then the dark matter (type 1)."""
+    posd, _, box = s_zel(n) if box is None else s_zel(n, box=box)
+    sp = box / n
+    ob, om = 0.045, 0.3
+    posg = np.mod(posd - 0.5 * (om - ob) / om * sp, box)
+    posd = np.mod(posd + 0.5 * ob / om * sp, box)
+    posg[posg <= 0] += box
+    posd[posd <= 0] += box
+    pos = np.concatenate([posg, posd])
+    mass = np.concatenate([np.full(n ** 3, ob / om, np.float32), np.full(n ** 3, 1 - ob / om, np.float32)])
+    typ = np.concatenate([np.zeros(n ** 3, np.uint8), np.ones(n ** 3, np.uint8)])
+    return pos, mass, typ, box

@@ -27,10 +27,15 @@ def test_default_workload_line():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["dtype"] == "f64"
     assert j["value"] > 1e6 and abs(j["value"] - 64 ** 3 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and j["cpu_baseline"]["kind"] == "port"
-    assert "workload" in j["config"]
+    assert "workload" in j["config"] and "s_zel" in j["config"]["workload"]          # the headline set of SURVEY 8(d)
+    r = j["roofline"]
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert j["cpu_baseline"]["physical_cores"] >= 1 and len(j["cpu_baseline"]["walk_s_all"]) == 3 and j["cpu_baseline"]["cpu_model"]
+    assert set(j["other_inputs"]) == {"s_grid", "s_clust"} and all(v["ms_per_step"] > 0 for v in j["other_inputs"].values())
+    assert j["host_path"]["ms_per_step"] > j["ms_per_step"]                           # PCIe transfers and AoS packing included
 
 
-@pytest.mark.parametrize("mode", ["domain", "slab", "replicated"])
+@pytest.mark.parametrize("mode", ["peano", "domain", "slab", "replicated"])
 def test_multi_gpu_paths_in_a_one_rank_group(mode):
     j = run_bench(["--gpus", "1", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--mgpu", mode],
                   env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29%03d" % (hash(mode) % 900 + 50)})
@@ -48,3 +53,39 @@ def test_other_workloads():
     assert KEYS <= set(p) and "pressure-entropy" in p["config"]["workload"]
     d = run_bench(["--workload", "domain", "--size", "64", "--steps", "1", "--warmup", "0"])
     assert KEYS <= set(d) and d["config"]["max_load_over_mean"] < 1.5 and "TopLeaves" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("ic", ["s_zel", "s_clust"])
+def test_c4_shape_through_rccl_at_full_per_gpu_size(ic):
+    """BASELINE configs[3] (512^3 on 8 GPUs) as ONE rank sees it: 256^3 own particles, the distributed choreography of mpg_dist_*
+    with every collective issued through RCCL (a one-rank group: MPG_FORCE_MGPU) on device buffers - the decomposition, the particle
+    shipping of the PM, the transposes, the ghost import and the all-reduce of the top of the tree at their full per-GPU sizes."""
+    j = run_bench(["--gpus", "1", "--size", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--mgpu", "peano", "--ic", ic],
+                  env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29871"})
+    assert KEYS <= set(j) and j["value"] > 2e7 and j["config"]["particles"] == 256 ** 3
+    assert j["roofline"]["pp_interactions_per_launch"] > 0 and j["phases_ms"]["dist_transpose_bytes"] > 2 * 512 ** 3 * 8
+
+
+def test_c5_shape_through_rccl_at_full_per_gpu_size():
+    """BASELINE configs[4] (2 x 256^3 pressure-entropy hydro on 8 GPUs) as ONE rank sees it: 2 x 128^3 own particles, gravity + the
+    distributed SPH loops (ghost import, the ghosts' SPH fields refreshed from their owners between density and hydro) with the
+    collectives on RCCL (one-rank group)."""
+    j = run_bench(["--workload", "hydro", "--gpus", "1", "--size", "128", "--steps", "1", "--warmup", "1", "--sph", "pe"],
+                  env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29872"})
+    assert KEYS - {"roofline"} <= set(j) and j["config"]["particles"] == 2 * 128 ** 3 and "pressure-entropy" in j["config"]["workload"]
+    assert j["value"] > 5e6
+
+
+def test_peano_domains_balance_the_walk_work_on_the_clustered_set():
+    """4 ranks (gloo, sharing this GPU) on the strongly clustered set: the TopLeaves dealt out by the measured work per particle
+    (domain.c:611) even out the walk's work; equal-volume x-slabs (round 1's domains) and equal particle numbers do not."""
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port",
+           "29873", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "64", "--ic", "s_clust", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--mgpu", "peano", "--overdecomp", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    lb = j["config"]["load_balance"]
+    assert lb["walk_work_max_over_mean"] < 1.15, lb
+    assert lb["x_slab_domains_walk_work_max_over_mean"] > 1.5 * lb["walk_work_max_over_mean"], lb

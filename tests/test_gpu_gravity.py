@@ -205,7 +205,10 @@ def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
 
 
 @pytest.mark.parametrize("name", ["grav_sgrid16", "grav_sclust12"])
-def test_golden_vectors(pkg, engine, name):
+def test_committed_oracle_vectors(pkg, engine, name):
+    """The committed vectors of tests/golden/grav_*.npz are outputs of the ORACLE (make_golden.py), frozen at the state in which it
+    reproduced the reference's known answers - a regression fixture for both sides, not an independent reference-derived pin (those
+    are test_reference_probe_known_answer, test_reference_force_accuracy_vs_direct_sum_on_gpu and tests/test_oracle_kat.py)."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     n, nmesh, box = int(g["n"]), int(g["nmesh"]), float(g["box"])
     if name == "grav_sgrid16":
@@ -416,8 +419,11 @@ def test_peano_domain_ranks_match_one(tmp_path, ic):
         assert np.abs(d[:, 6] - pot1).max() <= 1e-9 * np.abs(pot1).mean(), name
 
 
-def test_full_size_256_properties(pkg, orc):
-    """256^3, Nmesh 512 on the device-resident path: size-independent properties + a sampled oracle comparison.
+@pytest.mark.parametrize("ic", ["s_grid", "s_zel", "s_clust"])
+def test_full_size_256_properties(pkg, orc, ic):
+    """256^3, Nmesh 512 (BASELINE configs[1]) on the device-resident path, on the three input sets of SURVEY 8(d) (the jittered grid,
+    the Zel'dovich-displaced grid of the headline, the strongly clustered set): size-independent properties + a sampled oracle
+    comparison.
       * S-grid opens every node, so the short-range force is a pure pair sum; pairs are antisymmetric except where
         only one of the two targets keeps the other's leaf (cube cut at Rcut + len/2, gravshort-tree.c:198-215), where
         the window has already suppressed the force by >1e4: |sum_i a_i| <= 1e-6 sum_i |a_i|;
@@ -425,7 +431,7 @@ def test_full_size_256_properties(pkg, orc):
       * 2048 random targets agree with the oracle walking the oracle-built tree of all 16.8 M particles."""
     import torch
     n, nmesh = 256, 512
-    pos, mass, box = pkg.ics.s_grid(n)
+    pos, mass, box = getattr(pkg.ics, ic)(n)
     N = len(pos)
     eng = pkg.Engine(0)
     setup_engine(eng, box, n, nmesh, TreeUseBH=0)
@@ -437,13 +443,20 @@ def test_full_size_256_properties(pkg, orc):
     old = torch.full((N,), 1e-7, dtype=torch.float64, device="cuda")
     eng.dev_gravpm_force(gpm, None)
     eng.dev_force_tree_build()
+    if ic != "s_grid":       # a realistic OldAcc for the relative criterion (with 1e-7 every node of the dense clump would be opened)
+        old = torch.clamp(gpm.norm(dim=1) / G, min=1e-7).contiguous()
     eng.dev_grav_short_tree(acc, oldacc=old)
     eng.synchronize()
     c = eng.walk_counters()
     a = acc.cpu().numpy()
     g = gpm.cpu().numpy()
-    assert c["nodes_used"] == 0
-    assert np.abs(a.sum(0)).max() <= 1e-6 * np.abs(a).sum()
+    if ic == "s_grid":                                            # (every node is opened there: a pure pair sum)
+        assert c["nodes_used"] == 0
+        assert np.abs(a.sum(0)).max() <= 1e-6 * np.abs(a).sum()
+    else:                                                         # monopoles break the pair antisymmetry at the level of ErrTolForceAcc
+        assert c["nodes_used"] > 0
+        assert np.abs(a.sum(0)).max() <= 0.002 * np.abs(a).sum()
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(g))
     assert np.abs(g.sum(0)).max() <= 1e-9 * np.abs(g).sum()
     st = eng.tree_stats()
     assert st.NumParticles == N and abs(st.root_mass - N) < 1e-6
@@ -452,7 +465,7 @@ def test_full_size_256_properties(pkg, orc):
     par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
     par.TreeUseBH = 0
     act = np.sort(np.random.RandomState(1).choice(N, 2048, replace=False)).astype(np.int32)
-    ao, _, co, _ = tr.grav_short_tree(par, oldacc=np.full(N, 1e-7), active=act)
+    ao, _, co, _ = tr.grav_short_tree(par, oldacc=old.cpu().numpy(), active=act)
     assert_accel_parity(a[act], ao[act])
     eng.close()
 

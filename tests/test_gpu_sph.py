@@ -184,6 +184,73 @@ def test_density_hmax_hydro_parity(pkg, orc, pe):
     eng.close()
 
 
+@pytest.mark.parametrize("pe", [0, 1])
+def test_full_size_hydro_2x128(pkg, orc, pe):
+    """BASELINE configs[2] at its full size (2 x 128^3 = 4.2 M particles, half gas; density-entropy SPH; pe = 1: the
+    pressure-entropy formulation of configs[4]) on the device-resident path: size-independent properties of the whole set and a
+    sampled comparison with the oracle.
+      * check_densities of the reference's own test (test_density.c:35-53): finite, positive densities, Hsml within [MinGasHsml, Box];
+      * the hydro force is pair-antisymmetric when every gas particle is active in one time bin: |sum m a| <= 1e-9 sum |m a|, and the
+        entropy production is non-negative;
+      * 2048 sampled gas targets: the oracle's density loop from the same initial Hsml (same iteration path: Hsml to 1e-12, fields
+        to 1e-10), then the oracle's hydro loop for those targets on the SAME density-stage fields (the engine's, for all gas)."""
+    import torch
+    n = 128
+    pos, mass, typ8, box = pkg.ics.hydro_pair(n)
+    typ = typ8.astype(np.int32)
+    N = len(pos)
+    eng = pkg.Engine(0)
+    eng.set_gravshort_treepar()
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(pe, 100.0, 0.75)
+    a, keep = gpu_arrays(torch, pos, mass, typ, np.zeros(N), np.zeros((N, 3)), np.ones(N))
+    eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK + pkg.engine.BHMASK, with_moments=True)
+    eng.dev_set_init_hsml(a, box / n)
+    eng.synchronize()
+    h0 = a["hsml"].cpu().numpy().copy()
+    tk = dict(atime=0.1, hubble=0.1, dloga_bin=[0.01] * 47)
+    t = make_times(pkg, **tk)
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    eng.dev_density(a, t, DoEgyDensity=pe)
+    eng.dev_force_tree_calc_hmax()
+    eng.dev_hydro_force(a, t)
+    eng.synchronize()
+    g = {k: a[k].cpu().numpy() for k in ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel", "hydroacc_out", "dtentropy_out",
+                                         "maxsignalvel")}
+    gas = typ == 0
+    # ---- whole-set properties
+    assert np.all(np.isfinite(g["hsml"][gas])) and np.all(np.isfinite(g["density"][gas])) and np.all(g["density"][gas] > 0)
+    minhsml = 0.006 * 2.8 * (box / n) / 30.                    # MinGasHsmlFractional * FORCE_SOFTENING (density.c:246)
+    assert g["hsml"][gas].min() >= minhsml and g["hsml"][gas].max() <= box
+    ma = mass[gas, None].astype(np.float64) * g["hydroacc_out"][gas]
+    assert np.abs(ma.sum(0)).max() <= 1e-9 * np.abs(ma).sum()
+    assert np.all(np.isfinite(g["dtentropy_out"][gas])) and g["dtentropy_out"][gas].min() >= 0
+    # ---- sampled targets against the oracle
+    act = np.sort(np.random.RandomState(7).choice(np.flatnonzero(gas), 2048, replace=False)).astype(np.int32)
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 2, 0.006)
+    O.sph_set_softening(orc, 2.8 * (box / n) / 30.)
+    A = O.SphArrays(pos, mass, type=typ, hsml=h0, vel=np.zeros((N, 3)), entropy=np.ones(N))
+    to = O.sph_times(**tk)
+    tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    O.sph_density(orc, tr, dp, A, to, active=act, DoEgyDensity=pe)
+    same = assert_hsml_parity(g["hsml"][act], A.hsml[act], 113.1)
+    s_ = act[same]
+    for k in ("density", "divvel", "curlvel", "dhsmlegyfac") + (("egywtdensity",) if pe else ()):
+        assert rel(g[k][s_], getattr(A, k)[s_]) <= 1e-10, k
+    # hydro of the sampled targets on the engine's density-stage fields of ALL gas particles
+    for k in ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel"):
+        getattr(A, k)[:] = g[k]
+    tr2 = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    tr2.calc_moments()
+    O.sph_hydro_force(orc, tr2, dp, O.HydroParams(pe, 100.0, 0.75), A, to, active=act)
+    assert rel(g["hydroacc_out"][act], A.hydroacc_out[act]) <= 1e-10
+    assert rel(g["dtentropy_out"][act], A.dtentropy_out[act]) <= 1e-10
+    assert rel(g["maxsignalvel"][act], A.maxsignalvel[act]) <= 1e-12
+    eng.close()
+
+
 def test_density_active_subset_and_errors(pkg, orc):
     import torch
     n = 16
