@@ -572,6 +572,14 @@ int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, c
 int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass);
 int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm, double *d_accel,
                                  double *d_potential, double rho0);
+/* density() and hydro_force() (density.h:42, hydra.h) for the rank's own gas on the particle set of the last
+ * mpg_dist_dev_force_tree_build (own + ghosts; the domain margin must cover the largest smoothing length: checked).  d_type and the
+ * arrays of A are device arrays over the n_own own particles (mpg_sph_arrays; optional inputs may be NULL); the ghosts' columns
+ * travel along the ghost plan, and between the two loops the ghosts' Hsml / Density / EgyWtDensity / DhsmlEgyDensityFactor / DivVel /
+ * CurlVel are refreshed from their owners. */
+int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml,
+                         int DoEgyDensity);
+int mpg_dist_dev_hydro_force(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T);
 /* ... and as drop-in calls on the rank's particle table in host memory (what libgadget's callers hand over; shim/gravity-hip.c):
  * Pos / Mass are read from P[], GravPM / FullTreeGravAccel / Potential (and AccelStore, may be NULL) are written as the reference's
  * functions write them; OldAcc of the walk comes from P[].FullTreeGravAccel + P[].GravPM.  All particles active (a PM step). */

@@ -207,12 +207,138 @@ __global__ void __launch_bounds__(256) k_top_counts(int64_t npart, const uint64_
     const bool own = k < npart && (int64_t)order[k] < n_own;
     const unsigned long long cell = own ? (unsigned long long)(keys[k] >> shift) : ~0ull;
     const unsigned long long c0 = __shfl(cell, 0);
+    const unsigned long long nown = __popcll(__ballot(own)); // (taken by all lanes: inside the branch below only lane 0 would vote)
     if(__ballot(cell != c0) == 0) {
         if(c0 != ~0ull && (threadIdx.x & 63) == 0)
-            unsafeAtomicAdd(&out[c0], (double)__popcll(__ballot(own)));
+            unsafeAtomicAdd(&out[c0], (double)nown);
     }
     else if(own)
         unsafeAtomicAdd(&out[cell], 1.0);
+}
+
+// ---- SPH columns of the ghosts: 16 words per row before the density loop, 6 after it
+struct SphIn { // own arrays (device, may be null)
+    const uint8_t *type, *tbh, *tbg;
+    const double *hsml, *vel, *entropy, *gacc, *gpm, *hin, *dte;
+};
+
+__global__ void __launch_bounds__(256) k_pack_sph_in(int64_t ns, const int *__restrict__ idx, SphIn a, double *__restrict__ rows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= ns)
+        return;
+    const int64_t i = idx[k];
+    double *r = rows + 16 * k;
+    r[0] = a.hsml[i];
+    for(int j = 0; j < 3; j++) {
+        r[1 + j] = a.vel ? a.vel[3 * i + j] : 0.0;
+        r[5 + j] = a.gacc ? a.gacc[3 * i + j] : 0.0;
+        r[8 + j] = a.gpm ? a.gpm[3 * i + j] : 0.0;
+        r[11 + j] = a.hin ? a.hin[3 * i + j] : 0.0;
+    }
+    r[4] = a.entropy ? a.entropy[i] : 0.0;
+    r[14] = a.dte ? a.dte[i] : 0.0;
+    const unsigned long long w = (unsigned long long)(a.type ? a.type[i] : 0) | ((unsigned long long)(a.tbh ? a.tbh[i] : 0) << 8) |
+                                 ((unsigned long long)(a.tbg ? a.tbg[i] : 0) << 16);
+    r[15] = __longlong_as_double((long long)w);
+}
+
+struct SphLocal { // arrays over [own | ghosts]
+    uint8_t *type, *tbh, *tbg;
+    double *hsml, *vel, *entropy, *gacc, *gpm, *hin, *dte;
+};
+
+__global__ void __launch_bounds__(256) k_unpack_sph_in(int64_t nr, const double *__restrict__ rows, SphLocal a, int64_t off)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nr)
+        return;
+    const double *r = rows + 16 * k;
+    const int64_t i = off + k;
+    a.hsml[i] = r[0];
+    for(int j = 0; j < 3; j++) {
+        a.vel[3 * i + j] = r[1 + j];
+        a.gacc[3 * i + j] = r[5 + j];
+        a.gpm[3 * i + j] = r[8 + j];
+        a.hin[3 * i + j] = r[11 + j];
+    }
+    a.entropy[i] = r[4];
+    a.dte[i] = r[14];
+    const unsigned long long w = (unsigned long long)__double_as_longlong(r[15]);
+    a.type[i] = (uint8_t)(w & 255);
+    a.tbh[i] = (uint8_t)((w >> 8) & 255);
+    a.tbg[i] = (uint8_t)((w >> 16) & 255);
+}
+
+// own rows of the local inputs (absent optional inputs read as zero)
+__global__ void __launch_bounds__(256) k_fill_sph_own(int64_t n, SphIn a, SphLocal l)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    l.hsml[i] = a.hsml[i];
+    for(int j = 0; j < 3; j++) {
+        l.vel[3 * i + j] = a.vel ? a.vel[3 * i + j] : 0.0;
+        l.gacc[3 * i + j] = a.gacc ? a.gacc[3 * i + j] : 0.0;
+        l.gpm[3 * i + j] = a.gpm ? a.gpm[3 * i + j] : 0.0;
+        l.hin[3 * i + j] = a.hin ? a.hin[3 * i + j] : 0.0;
+    }
+    l.entropy[i] = a.entropy ? a.entropy[i] : 0.0;
+    l.dte[i] = a.dte ? a.dte[i] : 0.0;
+    l.type[i] = a.type ? a.type[i] : (uint8_t)0;
+    l.tbh[i] = a.tbh ? a.tbh[i] : (uint8_t)0;
+    l.tbg[i] = a.tbg ? a.tbg[i] : (uint8_t)0;
+}
+
+// the six fields the hydro loop reads of its neighbours, of the own particles that are somebody's ghosts
+__global__ void __launch_bounds__(256) k_pack_sph_mid(int64_t ns, const int *__restrict__ idx, const double *hsml, const double *density,
+                                                      const double *egy, const double *dhsml, const double *divvel, const double *curlvel,
+                                                      double *__restrict__ rows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= ns)
+        return;
+    const int64_t i = idx[k];
+    double *r = rows + 6 * k;
+    r[0] = hsml[i];
+    r[1] = density[i];
+    r[2] = egy ? egy[i] : 0.0;
+    r[3] = dhsml[i];
+    r[4] = divvel[i];
+    r[5] = curlvel[i];
+}
+
+__global__ void __launch_bounds__(256) k_unpack_sph_mid(int64_t nr, const double *__restrict__ rows, int64_t off, double *hsml, double *density,
+                                                        double *egy, double *dhsml, double *divvel, double *curlvel)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nr)
+        return;
+    const double *r = rows + 6 * k;
+    const int64_t i = off + k;
+    hsml[i] = r[0];
+    density[i] = r[1];
+    if(egy)
+        egy[i] = r[2];
+    dhsml[i] = r[3];
+    divvel[i] = r[4];
+    curlvel[i] = r[5];
+}
+
+struct IsOwnGas {
+    const uint8_t *type;
+    __host__ __device__ bool operator()(const int &i) const { return type[i] == 0; }
+};
+
+__global__ void __launch_bounds__(256) k_max_gas_hsml(int64_t n, const uint8_t *__restrict__ type, const double *__restrict__ hsml,
+                                                      unsigned long long *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double h = (i < n && type[i] == 0) ? hsml[i] : 0.0;
+    for(int off = 32; off > 0; off >>= 1)
+        h = fmax(h, __shfl_down(h, off));
+    if((threadIdx.x & 63) == 0 && h > 0)
+        atomicMax(out, (unsigned long long)__double_as_longlong(h)); // (positive doubles order like their bit patterns)
 }
 
 struct Plan { // one personalised exchange: who gets which of my rows, and what I get
@@ -260,6 +386,12 @@ struct mpg_dist {
     HostBuf<double> htop;
     int64_t ntarg = 0, n_own_tree = -1;
     DevBuf<float> cost;
+    // SPH loops on the local set: inputs and outputs over [own | ghosts]
+    DevBuf<uint8_t> s_type, s_tbh, s_tbg;
+    DevBuf<double> s_in[7];   // hsml, vel, entropy, gacc, gpm, hydroacc_in, dtentropy_in
+    DevBuf<double> s_out[11]; // dthsml, density, egywtdensity, dhsmlegyfac, divvel, curlvel, gradrho, hydroacc_out, dtentropy_out, maxsignalvel
+    DevBuf<int> gas;
+    int64_t ngas = 0, sph_nl = -1, sph_n_own = -1;
     int64_t stats[8] = {};
     double times[8] = {};
     // host (drop-in) path: the rank's P[] staged on the device
@@ -373,19 +505,20 @@ void build_plan(mpg_dist *d, Plan &pl, int64_t n, const unsigned long long *mask
     pl.nrecv = pl.rdsp[nt];
 }
 
-// rows (32 bytes each) along a plan; reverse: the answers travel back (what I received, I return; what I sent, I get back)
-void exchange_rows32(mpg_dist *d, const Plan &pl, const void *dsend, void *drecv, bool reverse)
+// rows of `rb_` bytes each along a plan; reverse: the answers travel back (what I received, I return; what I sent, I get back)
+void exchange_rows(mpg_dist *d, const Plan &pl, const void *dsend, void *drecv, bool reverse, int64_t rb_)
 {
     const int nt = d->nt;
     std::vector<int64_t> sb(nt), sd(nt), rb(nt), rd(nt);
     for(int r = 0; r < nt; r++) {
-        sb[r] = 32 * (reverse ? pl.rcnt[r] : pl.scnt[r]);
-        sd[r] = 32 * (reverse ? pl.rdsp[r] : pl.sdsp[r]);
-        rb[r] = 32 * (reverse ? pl.scnt[r] : pl.rcnt[r]);
-        rd[r] = 32 * (reverse ? pl.sdsp[r] : pl.rdsp[r]);
+        sb[r] = rb_ * (reverse ? pl.rcnt[r] : pl.scnt[r]);
+        sd[r] = rb_ * (reverse ? pl.rdsp[r] : pl.sdsp[r]);
+        rb[r] = rb_ * (reverse ? pl.scnt[r] : pl.rcnt[r]);
+        rd[r] = rb_ * (reverse ? pl.sdsp[r] : pl.rdsp[r]);
     }
-    a2av(d, dsend, sb, sd, drecv, rb, rd, 32 * (reverse ? pl.nrecv : pl.nsend), 32 * (reverse ? pl.nsend : pl.nrecv));
+    a2av(d, dsend, sb, sd, drecv, rb, rd, rb_ * (reverse ? pl.nrecv : pl.nsend), rb_ * (reverse ? pl.nsend : pl.nrecv));
 }
+void exchange_rows32(mpg_dist *d, const Plan &pl, const void *dsend, void *drecv, bool reverse) { exchange_rows(d, pl, dsend, drecv, reverse, 32); }
 
 // cube (integer coordinates at its level) of a TopNode: the prefix of its Peano-Hilbert key walked through the curve's state
 // machine backwards (digit -> octant)
@@ -773,9 +906,13 @@ int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const doub
         d->cost.reserve((size_t)d->n_own_tree + 1);
         MPG_HIP(hipMemsetAsync(d->cost.p, 0, (size_t)d->n_own_tree * sizeof(float), e->stream));
         float *keep = e->d_walk_cost;
+        const int keep_variant = e->walk_variant;
         e->d_walk_cost = d->cost.p;
+        if(e->walk_variant == 0) // the two-kernel walk whatever the target count: it is the one that records the work per target
+            e->walk_variant = 6;
         const int rc = mpg_dev_grav_short_tree(e, d_oldacc, d_prev_accel, d_gravpm, d->targets.p, d->ntarg, d_accel, d_potential, rho0);
         e->d_walk_cost = keep;
+        e->walk_variant = keep_variant;
         MPG_CHECK(rc == 0, mpg_last_error());
     }
     sync(d);
@@ -938,6 +1075,163 @@ int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*A
     });
     if(P->off_potential >= 0)
         column_down(d, n, 1, d->o_pot.p, [=](int64_t i, const double *v) { *(double *)(b + i * V.stride + V.off_potential) = v[0]; });
+    API_END
+}
+
+/* ---- density() and hydro_force() for the rank's own gas (density.h:42, hydra.h) on the particle set of the last
+ * mpg_dist_dev_force_tree_build: own particles + the ghosts of every tree cell within the domain margin, which must cover the largest
+ * smoothing length (checked).  The ghosts' inputs arrive along the ghost plan before the density loop; their Hsml, Density,
+ * EgyWtDensity, DhsmlEgyDensityFactor, DivVel, CurlVel are refreshed from their owners before the hydro loop (the search of
+ * hydro_force is symmetric in the two smoothing lengths, treewalk.c:1015-1042). */
+int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml,
+                         int DoEgyDensity)
+{
+    API_BEGIN
+    MPG_CHECK(d && A && T && A->hsml && A->density && A->dhsmlegyfac && A->divvel && A->curlvel, "null argument");
+    MPG_CHECK(d->n_own_tree == n_own, "mpg_dist_dev_density: mpg_dist_dev_force_tree_build of this particle set first");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const Plan &pl = d->ghost;
+    const int64_t nl = n_own + pl.nrecv;
+    d->s_type.reserve((size_t)nl + 1);
+    d->s_tbh.reserve((size_t)nl + 1);
+    d->s_tbg.reserve((size_t)nl + 1);
+    const int w_in[7] = {1, 3, 1, 3, 3, 3, 1}, w_out[11] = {1, 1, 1, 1, 1, 1, 3, 3, 1, 1, 0};
+    for(int k = 0; k < 7; k++)
+        d->s_in[k].reserve((size_t)w_in[k] * nl + 3);
+    for(int k = 0; k < 10; k++) {
+        d->s_out[k].reserve((size_t)w_out[k] * nl + 3);
+        MPG_HIP(hipMemsetAsync(d->s_out[k].p, 0, (size_t)w_out[k] * nl * sizeof(double), st));
+    }
+    const SphIn in{d_type, A->tb_hydro, A->tb_grav, A->hsml, A->vel, A->entropy, A->gacc, A->gpm, A->hydroacc_in, A->dtentropy_in};
+    const SphLocal loc{d->s_type.p, d->s_tbh.p, d->s_tbg.p, d->s_in[0].p, d->s_in[1].p, d->s_in[2].p, d->s_in[3].p, d->s_in[4].p, d->s_in[5].p,
+                       d->s_in[6].p};
+    if(n_own > 0)
+        hipLaunchKernelGGL(k_fill_sph_own, dim3(nblk(n_own)), dim3(256), 0, st, n_own, in, loc);
+    d->sendbuf.reserve((size_t)128 * pl.nsend + 128);
+    d->recvbuf.reserve((size_t)128 * pl.nrecv + 128);
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_pack_sph_in, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, in, (double *)d->sendbuf.p);
+    exchange_rows(d, pl, d->sendbuf.p, d->recvbuf.p, false, 128);
+    if(pl.nrecv > 0)
+        hipLaunchKernelGGL(k_unpack_sph_in, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const double *)d->recvbuf.p, loc, n_own);
+    // the gas tree of the local set (force_tree_rebuild_mask(GASMASK), run.c:466)
+    MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, d->s_type.p, d->box) == 0, mpg_last_error());
+    MPG_CHECK(mpg_dev_force_tree_rebuild_mask(e, 1, 0) == 0, mpg_last_error());
+    // active: the own gas
+    d->gas.reserve((size_t)n_own + 1);
+    d->scount.reserve(4);
+    d->ngas = 0;
+    if(n_own > 0) {
+        rocprim::counting_iterator<int> iota(0);
+        size_t tb = 0;
+        MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
+        unsigned long long c = 0;
+        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        sync(d);
+        d->ngas = (int64_t)c;
+    }
+    mpg_sph_arrays L;
+    memset(&L, 0, sizeof(L));
+    L.hsml = d->s_in[0].p;
+    L.vel = d->s_in[1].p;
+    L.entropy = d->s_in[2].p;
+    L.gacc = d->s_in[3].p;
+    L.gpm = d->s_in[4].p;
+    L.hydroacc_in = d->s_in[5].p;
+    L.dtentropy_in = d->s_in[6].p;
+    L.tb_hydro = d->s_tbh.p;
+    L.tb_grav = d->s_tbg.p;
+    L.dthsml = d->s_out[0].p;
+    L.density = d->s_out[1].p;
+    L.egywtdensity = d->s_out[2].p;
+    L.dhsmlegyfac = d->s_out[3].p;
+    L.divvel = d->s_out[4].p;
+    L.curlvel = d->s_out[5].p;
+    L.gradrho = A->gradrho ? d->s_out[6].p : nullptr;
+    L.hydroacc_out = d->s_out[7].p;
+    L.dtentropy_out = d->s_out[8].p;
+    L.maxsignalvel = d->s_out[9].p;
+    MPG_CHECK(mpg_dev_density(e, &L, T, d->gas.p, d->ngas, update_hsml, DoEgyDensity, 0) == 0, mpg_last_error());
+    // every neighbour within a smoothing length must be local: the largest one against the domain margin
+    d->scount.reserve(4);
+    MPG_HIP(hipMemsetAsync(d->scount.p, 0, sizeof(unsigned long long), st));
+    if(n_own > 0)
+        hipLaunchKernelGGL(k_max_gas_hsml, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d->s_type.p, d->s_in[0].p, d->scount.p);
+    unsigned long long hb = 0;
+    MPG_HIP(hipMemcpyAsync(&hb, d->scount.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    sync(d);
+    double hmax;
+    memcpy(&hmax, &hb, sizeof(double));
+    allreduce_host_f64(d, &hmax, 1, 1);
+    MPG_CHECK(hmax <= d->margin, "mpg_dist_dev_density: the largest smoothing length exceeds the domain margin (mpg_dist_set_domain with a larger one)");
+    // own rows out
+    auto out = [&](double *dst, const double *src, int w) {
+        if(dst && n_own > 0)
+            MPG_HIP(hipMemcpyAsync(dst, src, (size_t)w * n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+    };
+    out(A->hsml, L.hsml, 1);
+    out(A->dthsml, L.dthsml, 1);
+    out(A->density, L.density, 1);
+    out(A->egywtdensity, L.egywtdensity, 1);
+    out(A->dhsmlegyfac, L.dhsmlegyfac, 1);
+    out(A->divvel, L.divvel, 1);
+    out(A->curlvel, L.curlvel, 1);
+    out(A->gradrho, L.gradrho, 3);
+    d->sph_nl = nl;
+    d->sph_n_own = n_own;
+    API_END
+}
+
+int mpg_dist_dev_hydro_force(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T)
+{
+    API_BEGIN
+    MPG_CHECK(d && A && T && A->hydroacc_out && A->dtentropy_out && A->maxsignalvel, "null argument");
+    MPG_CHECK(d->sph_n_own == n_own && d->sph_nl >= n_own, "mpg_dist_dev_hydro_force: mpg_dist_dev_density of this particle set first");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const Plan &pl = d->ghost;
+    // the ghosts' density-loop results from their owners
+    d->sendbuf.reserve((size_t)48 * pl.nsend + 48);
+    d->recvbuf.reserve((size_t)48 * pl.nrecv + 48);
+    double *hs = d->s_in[0].p, *de = d->s_out[1].p, *eg = d->s_out[2].p, *dh = d->s_out[3].p, *dv = d->s_out[4].p, *cv = d->s_out[5].p;
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_pack_sph_mid, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, hs, de, eg, dh, dv, cv, (double *)d->sendbuf.p);
+    exchange_rows(d, pl, d->sendbuf.p, d->recvbuf.p, false, 48);
+    if(pl.nrecv > 0)
+        hipLaunchKernelGGL(k_unpack_sph_mid, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const double *)d->recvbuf.p, n_own, hs, de, eg, dh, dv, cv);
+    MPG_CHECK(mpg_dev_force_tree_calc_hmax(e) == 0, mpg_last_error()); // force_tree_calc_moments of the gas tree, run.c:477
+    mpg_sph_arrays L;
+    memset(&L, 0, sizeof(L));
+    L.hsml = hs;
+    L.vel = d->s_in[1].p;
+    L.entropy = d->s_in[2].p;
+    L.gacc = d->s_in[3].p;
+    L.gpm = d->s_in[4].p;
+    L.hydroacc_in = d->s_in[5].p;
+    L.dtentropy_in = d->s_in[6].p;
+    L.tb_hydro = d->s_tbh.p;
+    L.tb_grav = d->s_tbg.p;
+    L.dthsml = d->s_out[0].p;
+    L.density = de;
+    L.egywtdensity = eg;
+    L.dhsmlegyfac = dh;
+    L.divvel = dv;
+    L.curlvel = cv;
+    L.hydroacc_out = d->s_out[7].p;
+    L.dtentropy_out = d->s_out[8].p;
+    L.maxsignalvel = d->s_out[9].p;
+    MPG_CHECK(mpg_dev_hydro_force(e, &L, T, d->gas.p, d->ngas) == 0, mpg_last_error());
+    if(n_own > 0) {
+        MPG_HIP(hipMemcpyAsync(A->hydroacc_out, L.hydroacc_out, (size_t)3 * n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MPG_HIP(hipMemcpyAsync(A->dtentropy_out, L.dtentropy_out, (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MPG_HIP(hipMemcpyAsync(A->maxsignalvel, L.maxsignalvel, (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    sync(d);
     API_END
 }
 

@@ -278,8 +278,10 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
         // the evaluation kernel's pair steps carried idle lanes.  The interaction set is unchanged; only the grouping of the
         // sources into steps is.  The run of lane s is found from the group's 8-bit mask of opened leaves with bit operations
         // (first lane h of the run: highest clear bit below s; last lane: first clear bit above s) and two cross-lane reads
-        // (the run's first particle, the end of its last leaf); lane h + q writes entry q of the run.  (The first form of this,
-        // two segmented scans of ~55 instructions per step, cost what it saved; MPG_PACK_LEAVES=0 restores one entry per leaf.)
+        // (the run's first particle, the end of its last leaf); lane h + q writes entry q of the run.  MPG_PACK_LEAVES=1 turns it
+        // on; measured at 256^3 (Zel'dovich set): 117.9 ms per step with, 113.6 without - runs are short in the shell of the cut-off
+        // cube, where most leaves are, and the list kernel, not the evaluation, is on the critical path.  (The first form, two
+        // segmented scans of ~55 instructions per step, was no better.)
         bool has_ent = b_leaf;
         unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
         if(pack && any_lane(b_leaf && lk.pcount != NMAXCHILD)) {

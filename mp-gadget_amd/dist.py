@@ -136,6 +136,9 @@ def _bind(lib):
     lib.mpg_dist_destroy.restype = None
     lib.mpg_dist_set_domain.argtypes = [C.c_void_p, C.c_double, C.POINTER(TopNode), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_int]
     lib.mpg_dist_gravity_step.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 7 + [C.c_double]
+    lib.mpg_dist_dev_force_tree_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.mpg_dist_dev_density.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.mpg_dist_dev_hydro_force.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.mpg_dist_get_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.mpg_dist_get_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib._dist_bound = True
@@ -171,6 +174,21 @@ class DistForce:
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         self._ck(self.lib.mpg_dist_gravity_step(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(oldacc), p(prev_accel), p(accel), p(gravpm),
                                                 p(potential), C.c_double(rho0)))
+
+    def force_tree_build(self, pos, mass):
+        """mpg_dist_dev_force_tree_build alone: ghost import, local tree, global top (what the SPH loops need when no gravity step
+        ran on this particle set)"""
+        self._ck(self.lib.mpg_dist_dev_force_tree_build(self.h, C.c_int64(pos.shape[0]), C.c_void_p(pos.data_ptr()), C.c_void_p(mass.data_ptr())))
+
+    def density(self, type, arrays, times, update_hsml=1, DoEgyDensity=0):
+        """density() for the rank's own gas; type: uint8 device tensor, arrays: dict of device tensors over the own particles"""
+        a = self.eng._sph_arrays(arrays)
+        self._ck(self.lib.mpg_dist_dev_density(self.h, C.c_int64(type.shape[0]), C.c_void_p(type.data_ptr()), C.byref(a), C.byref(times),
+                                               int(update_hsml), int(DoEgyDensity)))
+
+    def hydro_force(self, n_own, arrays, times):
+        a = self.eng._sph_arrays(arrays)
+        self._ck(self.lib.mpg_dist_dev_hydro_force(self.h, C.c_int64(n_own), C.byref(a), C.byref(times)))
 
     def walk_cost(self, n_own):
         """per-particle work of the last walk for the rank's own particles (float32 device tensor, a copy): feed it to

@@ -119,6 +119,21 @@ def test_reference_density_known_answer_on_gpu(pkg, orc, kind, dev, tol):
     eng.close()
 
 
+@keep_artifacts_on_failure
+def test_sph_peano_ranks_match_one(tmp_path):
+    """density -> hydro_force through the library's distributed choreography (mpg_dist_dev_density / _hydro_force) on the reference's
+    Peano-Hilbert decomposition: 1 rank (no communicator), 2 and 4 ranks (gloo, the mpg_comm callbacks) against one GPU."""
+    one = _run_hydro(tmp_path, "one.npz", 1, "single", 0)
+    gas = one["typ"] == 0
+    for name, nproc, port in (("p1.npz", 1, 0), ("p2.npz", 2, 29605), ("p4.npz", 4, 29606)):
+        d = _run_hydro(tmp_path, name, nproc, "peano", port)
+        same = assert_hsml_parity(d["hsml"][gas], one["hsml"][gas], 113.1)
+        g = np.flatnonzero(gas)[same]
+        for k in ("density", "divvel", "curlvel", "dhsmlegyfac", "hydroacc_out", "dtentropy_out"):
+            assert rel(d[k][g], one[k][g]) <= 1e-9, (name, k)
+        assert rel(d["maxsignalvel"][g], one["maxsignalvel"][g]) <= 1e-12, name
+
+
 @pytest.mark.parametrize("pe", [0, 1])
 def test_density_hmax_hydro_parity(pkg, orc, pe):
     """density -> hmax moments -> hydro_force (run.c:466-489) with non-trivial velocities, entropies, kick / drift factors
@@ -204,7 +219,11 @@ def test_full_size_hydro_2x128(pkg, orc, pe):
     eng.gravshort_set_softenings(box / n)
     eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
     eng.set_hydropar(pe, 100.0, 0.75)
-    a, keep = gpu_arrays(torch, pos, mass, typ, np.zeros(N), np.zeros((N, 3)), np.ones(N))
+    # a smooth velocity field (non-zero divergence and curl) and a mild entropy gradient
+    ph = 2 * np.pi * pos / box
+    vel = 30.0 * np.stack([np.sin(ph[:, 1]) + np.cos(ph[:, 2]), np.sin(ph[:, 2]) + np.cos(ph[:, 0]), np.sin(ph[:, 0]) * np.cos(ph[:, 1])], 1)
+    ent = 1.0 + 0.2 * np.sin(ph[:, 0]) * np.sin(ph[:, 1])
+    a, keep = gpu_arrays(torch, pos, mass, typ, np.zeros(N), vel, ent)
     eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
     eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK + pkg.engine.BHMASK, with_moments=True)
     eng.dev_set_init_hsml(a, box / n)
@@ -226,12 +245,12 @@ def test_full_size_hydro_2x128(pkg, orc, pe):
     assert g["hsml"][gas].min() >= minhsml and g["hsml"][gas].max() <= box
     ma = mass[gas, None].astype(np.float64) * g["hydroacc_out"][gas]
     assert np.abs(ma.sum(0)).max() <= 1e-9 * np.abs(ma).sum()
-    assert np.all(np.isfinite(g["dtentropy_out"][gas])) and g["dtentropy_out"][gas].min() >= 0
+    assert np.all(np.isfinite(g["dtentropy_out"][gas])) and g["dtentropy_out"][gas].min() >= 0       # viscous heating only
     # ---- sampled targets against the oracle
     act = np.sort(np.random.RandomState(7).choice(np.flatnonzero(gas), 2048, replace=False)).astype(np.int32)
     dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 2, 0.006)
     O.sph_set_softening(orc, 2.8 * (box / n) / 30.)
-    A = O.SphArrays(pos, mass, type=typ, hsml=h0, vel=np.zeros((N, 3)), entropy=np.ones(N))
+    A = O.SphArrays(pos, mass, type=typ, hsml=h0, vel=vel, entropy=ent)
     to = O.sph_times(**tk)
     tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
     O.sph_density(orc, tr, dp, A, to, active=act, DoEgyDensity=pe)

@@ -60,6 +60,37 @@ if mode == "single":
     eng.dev_force_tree_calc_hmax()
     eng.dev_hydro_force(a, t)
     res = {k: a[k] for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel")}
+elif mode == "peano":
+    # the library's choreography on the reference's decomposition (csrc/dist.hip): particles on the owners of their TopLeaves,
+    # ghosts of every tree cell within the margin (>= the largest smoothing length), SPH columns along the ghost plan
+    DP = pkg.domain_peano
+    share = slice((N * rank) // world, (N * (rank + 1)) // world)
+    ids = torch.arange(N, dtype=torch.int64, device=dev)[share]
+    dom = DP.PeanoDomain(eng, box, rank, world)
+    dom.decompose(g_pos[share].contiguous())
+    o_pos, o_mass, o_typ, o_vel, o_ent, o_hsml, o_ids = dom.exchange(g_pos[share].contiguous(), g_mass[share].contiguous(), g_typ[share].contiguous(),
+                                                                     g_vel[share].contiguous(), g_ent[share].contiguous(),
+                                                                     g_hsml[share].contiguous(), ids)
+    n_own = int(o_pos.shape[0])
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, 2 * n, 43.0071)
+    comm = pkg.dist.TorchComm(dev) if grouped else pkg.dist.LocalComm()
+    df = pkg.dist.DistForce(eng, comm)
+    df.set_domain(dom, 6.0 * box / n)
+    a = arrays(n_own, o_hsml.contiguous(), o_vel.contiguous(), o_ent.contiguous())
+    df.force_tree_build(o_pos, o_mass)
+    df.density(o_typ.contiguous(), a, t)
+    df.hydro_force(n_own, a, t)
+    res = {}
+    for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel"):
+        full = torch.zeros((N,) + tuple(a[k].shape[1:]), **f8)
+        full[o_ids] = a[k]
+        if grouped:
+            pkg.pm_slab.TargetExchange(world, dev).exchange(full.reshape(N, -1), o_ids.to(torch.int32))
+        res[k] = full
+    if rank == 0:
+        print("hydro peano: %s own %d" % (df.stats(), n_own), flush=True)
+    df.close()
 else:
     nmesh = 2 * n
     dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut=6.0 * 1.5 * box / nmesh, margin=6.0 * box / n)
