@@ -552,6 +552,25 @@ typedef struct mpg_dist mpg_dist;
  * Nmesh % NTask == 0.  The comm struct is copied. */
 int mpg_dist_create(mpg_dist **out, mpg_engine *eng, const mpg_comm *comm);
 void mpg_dist_destroy(mpg_dist *d);
+/* domain_decompose_full (domain.c:153-258) over the communicator: policies, the rank's key sample, local refinement, the pairwise
+ * combination of the ranks' trees, global refinement, the TopLeaves and their balanced assignment (by particle number, or by the
+ * per-particle work d_cost[n] when given: mpg_dist_walk_cost), P[].TopLeaf and the destination task of every particle.  d_garbage:
+ * device bytes (IsGarbage) or NULL.  Then mpg_dist_domain_exchange moves the particles (domain_exchange, exchange.c): ncols <= 16
+ * columns of col_bytes[j] bytes per particle each (device arrays over the n particles); on return *n_new particles live on this
+ * rank and d_new_cols[j] point to their columns in library-owned device buffers (valid until the next exchange), the particles that
+ * stayed and those that arrived in source-rank order; garbage is dropped.  mpg_dist_domain_get copies the decomposition out (arrays
+ * sized by the counts mpg_dist_domain_decompose returned; any may be NULL); mpg_dist_use_decomposition hands it to the force step
+ * (= mpg_dist_set_domain with it). */
+int mpg_dist_domain_decompose(mpg_dist *d, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize,
+                              int DomainOverDecompositionFactor, int DomainUseGlobalSorting, const float *d_cost, int *NTopNodes,
+                              int *NTopLeaves);
+int mpg_dist_domain_get(mpg_dist *d, mpg_topnode *TopNodes, int *leaf_task, int *StartLeaf, int *EndLeaf, int64_t *TopLeafCount);
+int mpg_dist_domain_exchange(mpg_dist *d, int64_t n, int ncols, const void *const *d_cols, const int *col_bytes, int64_t *n_new,
+                             void **d_new_cols);
+int mpg_dist_use_decomposition(mpg_dist *d, double BoxSize, double margin, int La);
+/* domain_maintain (domain.c:262-319) after a drift: the decomposition is kept, TopLeaf and destination task of every particle are
+ * found again; *n_leaving (may be NULL) = the particles that mpg_dist_domain_exchange will now move to other ranks */
+int mpg_dist_domain_maintain(mpg_dist *d, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize, int64_t *n_leaving);
 /* The domain the ranks' particles were distributed by: the TopNodes of domain_decompose_full (same on every rank) and the Task
  * of every TopLeaf (DomainDecomp.TopNodes / TopLeaves, domain.h:12-43).  margin: at least Rcut in length units (the walk's
  * cut-off, gravshort-tree.c:102) and, for SPH, the largest smoothing length; La = 0 picks the level whose cells are

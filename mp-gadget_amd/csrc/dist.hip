@@ -341,6 +341,72 @@ __global__ void __launch_bounds__(256) k_max_gas_hsml(int64_t n, const uint8_t *
         atomicMax(out, (unsigned long long)__double_as_longlong(h)); // (positive doubles order like their bit patterns)
 }
 
+// ---- domain decomposition: destination masks, generic columns on the wire, cost per TopLeaf
+__global__ void __launch_bounds__(256) k_task_mask(int64_t n, const int *__restrict__ task, unsigned long long *__restrict__ mask)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        mask[i] = task[i] >= 0 ? (1ull << task[i]) : 0ull; // garbage (-1) goes nowhere: domain_exchange drops it
+}
+
+struct Cols {
+    const char *src[16];
+    char *dst[16];
+    int w[16], off[16]; // bytes of a column, its offset in the wire row (8-byte aligned)
+    int n, row;
+};
+
+__device__ __forceinline__ void copy_bytes(char *d, const char *s, int w)
+{
+    if((w & 7) == 0)
+        for(int k = 0; k < w; k += 8)
+            *(unsigned long long *)(d + k) = *(const unsigned long long *)(s + k);
+    else if((w & 3) == 0)
+        for(int k = 0; k < w; k += 4)
+            *(unsigned *)(d + k) = *(const unsigned *)(s + k);
+    else
+        for(int k = 0; k < w; k++)
+            d[k] = s[k];
+}
+
+__global__ void __launch_bounds__(256) k_pack_cols(int64_t ns, const int *__restrict__ idx, Cols c, char *__restrict__ rows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= ns)
+        return;
+    const int64_t i = idx[k];
+    for(int j = 0; j < c.n; j++)
+        copy_bytes(rows + k * c.row + c.off[j], c.src[j] + i * c.w[j], c.w[j]);
+}
+
+__global__ void __launch_bounds__(256) k_unpack_cols(int64_t nr, const char *__restrict__ rows, Cols c)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nr)
+        return;
+    for(int j = 0; j < c.n; j++)
+        copy_bytes(c.dst[j] + k * c.w[j], rows + k * c.row + c.off[j], c.w[j]);
+}
+
+// work per TopLeaf: block-local sums in LDS, one atomic per block and occupied leaf
+__global__ void __launch_bounds__(256) k_leaf_cost(int64_t n, const int *__restrict__ topleaf, const float *__restrict__ cost, int nleaves,
+                                                   double *__restrict__ out)
+{
+    extern __shared__ double s_sum[];
+    for(int l = threadIdx.x; l < nleaves; l += blockDim.x)
+        s_sum[l] = 0;
+    __syncthreads();
+    for(int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = topleaf[i];
+        if(l >= 0 && l < nleaves)
+            atomicAdd(&s_sum[l], (double)cost[i]);
+    }
+    __syncthreads();
+    for(int l = threadIdx.x; l < nleaves; l += blockDim.x)
+        if(s_sum[l] != 0)
+            unsafeAtomicAdd(&out[l], s_sum[l]);
+}
+
 struct Plan { // one personalised exchange: who gets which of my rows, and what I get
     DevBuf<int> idx;
     DevBuf<long long> d_sdsp;
@@ -392,6 +458,17 @@ struct mpg_dist {
     DevBuf<double> s_out[11]; // dthsml, density, egywtdensity, dhsmlegyfac, divvel, curlvel, gradrho, hydroacc_out, dtentropy_out, maxsignalvel
     DevBuf<int> gas;
     int64_t ngas = 0, sph_nl = -1, sph_n_own = -1;
+    // domain decomposition (mpg_dist_domain_decompose): the global tree, its leaves, where every particle goes
+    std::vector<mpg_topnode> dom_tree;
+    std::vector<int> dom_leaf_task, dom_leaf_topnode, dom_start, dom_end;
+    std::vector<int64_t> dom_leaf_count, dom_send_counts;
+    int dom_size = 0, dom_nleaves = 0, dom_policy = 0;
+    double dom_alloc_factor = 0.5;
+    DevBuf<int> dom_topleaf, dom_task;
+    DevBuf<double> dom_cost;
+    int64_t dom_n = -1;
+    Plan dom_plan;
+    DevBuf<char> dom_out[16];
     int64_t stats[8] = {};
     double times[8] = {};
     // host (drop-in) path: the rank's P[] staged on the device
@@ -1261,6 +1338,313 @@ int mpg_dev_force_tree_set_min_leaf_level(mpg_engine *eng, int level)
     MPG_CHECK(eng && level >= 0 && level <= 8, "mpg_dev_force_tree_set_min_leaf_level: level must be in [0, 8]");
     eng->tree.force_internal_above = level;
     API_END
+}
+
+} // extern "C"
+
+/* ---- domain_decompose_full (domain.c:153-258) and domain_exchange (exchange.c) over the caller's communicator ----------------
+ * The device passes (domain_sample, domain_topleaves) and the host arithmetic on the top-level tree (toptree_*) are domain.hip's;
+ * here is the sequence the reference's MPI code runs them in.  The pairwise hand-over of trees (domain.c:1206-1259) is done on an
+ * all-gather: every rank receives all local trees and folds them in the pairwise order itself - the same tree on every rank
+ * without a broadcast. */
+namespace {
+
+void allreduce_i64(mpg_dist *d, int64_t *v, int64_t n, int op)
+{
+    if(d->nt == 1 && !d->comm.allreduce)
+        return;
+    MPG_CHECK(d->comm.allreduce, "mpg_comm: allreduce callback missing");
+    cb(d->comm.allreduce(d->comm.ctx, v, n, 1, op, 0), "allreduce");
+}
+
+bool any_rank(mpg_dist *d, bool f)
+{
+    int64_t v = f ? 1 : 0;
+    allreduce_i64(d, &v, 1, 0);
+    return v > 0;
+}
+
+// every rank's block of host bytes (padded to 8): out[r] = the block of rank r
+void allgather_host(mpg_dist *d, const void *buf, int64_t nbytes, std::vector<std::vector<char>> &out)
+{
+    const int nt = d->nt;
+    out.assign(nt, {});
+    if(nt == 1) {
+        out[0].assign((const char *)buf, (const char *)buf + nbytes);
+        return;
+    }
+    const int64_t pad = (nbytes + 7) / 8 * 8;
+    std::vector<int64_t> sc(nt, pad), rc(nt, 0), sd(nt, 0), rd(nt + 1, 0);
+    cb(d->comm.alltoall_i64(d->comm.ctx, sc.data(), rc.data()), "alltoall_i64");
+    for(int r = 0; r < nt; r++)
+        rd[r + 1] = rd[r] + rc[r];
+    std::vector<char> sb((size_t)pad + 8, 0), rb((size_t)rd[nt] + 8);
+    memcpy(sb.data(), buf, (size_t)nbytes);
+    std::vector<int64_t> rdv(rd.begin(), rd.begin() + nt);
+    cb(d->comm.alltoallv(d->comm.ctx, sb.data(), sc.data(), sd.data(), rb.data(), rc.data(), rdv.data(), 0), "alltoallv");
+    for(int r = 0; r < nt; r++)
+        out[r].assign(rb.begin() + rd[r], rb.begin() + rd[r] + rc[r]); // (padded: the receiver knows the true sizes from the data)
+}
+
+struct Policy { // DomainDecompositionPolicy as domain_policies_init fills it (domain.c:351-375)
+    int PreSort, SubSampleDistance, NTopLeaves;
+    Policy(int i, int ntask, int overdecomp)
+    {
+        PreSort = i >= 2 ? 1 : 0;
+        int dd = 256;
+        for(int k = 1; k <= i; k++)
+            dd = (k > 4 && dd > 2) ? dd / 2 : 256;
+        SubSampleDistance = dd;
+        NTopLeaves = overdecomp * ntask * (i + 1);
+    }
+};
+
+// domain_determine_global_toptree (domain.c:1280-1341): false when the top nodes ran out
+bool global_toptree(mpg_dist *d, int64_t n, const double *pos, const uint8_t *garbage, double box, const Policy &pol, int global_sorting, int maxn,
+                    std::vector<TopNode> &tree, int &size)
+{
+    mpg_engine *e = d->eng;
+    const int nt = d->nt;
+    const int64_t cap = n / pol.SubSampleDistance + 2;
+    std::vector<uint64_t> keys((size_t)cap);
+    int64_t ns = domain_sample(n, pos, garbage, box, pol.PreSort, pol.SubSampleDistance, keys.data(), cap, e->domain, e->stream);
+    keys.resize((size_t)ns);
+    if(global_sorting && nt > 1) { // mpsort_mpi (domain.c:1076-1077): sorted over all ranks, every rank keeps as many as it had
+        struct Hdr {
+            int64_t n;
+        } h{ns};
+        std::vector<char> blk(sizeof(Hdr) + (size_t)ns * 8);
+        memcpy(blk.data(), &h, sizeof(h));
+        if(ns)
+            memcpy(blk.data() + sizeof(h), keys.data(), (size_t)ns * 8);
+        std::vector<std::vector<char>> all;
+        allgather_host(d, blk.data(), (int64_t)blk.size(), all);
+        std::vector<uint64_t> allk;
+        int64_t off = 0;
+        for(int r = 0; r < nt; r++) {
+            Hdr hr;
+            memcpy(&hr, all[r].data(), sizeof(hr));
+            const uint64_t *k = (const uint64_t *)(all[r].data() + sizeof(hr));
+            if(r < d->me)
+                off += hr.n;
+            allk.insert(allk.end(), k, k + hr.n);
+        }
+        std::stable_sort(allk.begin(), allk.end());
+        std::copy(allk.begin() + off, allk.begin() + off + ns, keys.begin());
+    }
+    tree.assign((size_t)maxn + 8, TopNode{});
+    size = 0;
+    bool ok = toptree_local_refine(keys.data(), nullptr, ns, tree.data(), &size, maxn);
+    if(any_rank(d, !ok))
+        return false;
+    int64_t tot[2] = {tree[0].Cost, tree[0].Count};
+    allreduce_i64(d, tot, 2, 0);
+    const int64_t costlimit = tot[0] / pol.NTopLeaves, countlimit = tot[1] / pol.NTopLeaves;
+    toptree_truncate(tree.data(), &size, countlimit, costlimit);
+    bool err = false;
+    if(nt > 1) {
+        std::vector<char> blk(8 + (size_t)size * sizeof(TopNode));
+        const int64_t sz = size;
+        memcpy(blk.data(), &sz, 8);
+        memcpy(blk.data() + 8, tree.data(), (size_t)size * sizeof(TopNode));
+        std::vector<std::vector<char>> all;
+        allgather_host(d, blk.data(), (int64_t)blk.size(), all);
+        // the pairwise combination of domain.c:1206-1259, replayed on every rank: tree r absorbs tree r + sep, sep = 1, 2, 4 ...
+        std::vector<std::vector<TopNode>> T((size_t)nt);
+        std::vector<int> S((size_t)nt);
+        for(int r = 0; r < nt; r++) {
+            int64_t z;
+            memcpy(&z, all[r].data(), 8);
+            S[r] = (int)z;
+            T[r].assign((size_t)maxn + 8, TopNode{});
+            memcpy(T[r].data(), all[r].data() + 8, (size_t)z * sizeof(TopNode));
+        }
+        for(int sep = 1; sep < nt; sep *= 2)
+            for(int r = 0; r + sep < nt; r += 2 * sep)
+                if(!toptree_merge(T[r].data(), &S[r], T[r + sep].data(), S[r + sep], maxn))
+                    err = true;
+        tree.swap(T[0]);
+        size = S[0];
+        if(size >= maxn)
+            err = true;
+    }
+    if(any_rank(d, err))
+        return false;
+    ok = toptree_global_refine(tree.data(), &size, maxn, countlimit, costlimit);
+    return !any_rank(d, !ok);
+}
+
+} // namespace
+
+extern "C" {
+
+int mpg_dist_domain_decompose(mpg_dist *d, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize,
+                              int DomainOverDecompositionFactor, int DomainUseGlobalSorting, const float *d_cost, int *NTopNodes,
+                              int *NTopLeaves)
+{
+    API_BEGIN
+    MPG_CHECK(d && n >= 0 && (n == 0 || d_pos) && BoxSize > 0 && DomainOverDecompositionFactor >= 1, "mpg_dist_domain_decompose: bad argument");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const int nt = d->nt;
+    for(int i = d->dom_policy; i < 16; i++) { // NPOLICY, domain.c:48
+        const Policy pol(i, nt, DomainOverDecompositionFactor);
+        std::vector<TopNode> tree;
+        int size = 0;
+        for(;;) { // domain.c:180-195: more top nodes until they suffice
+            const int maxn = std::max((int)(d->dom_alloc_factor * (double)(n + 1)), 1);
+            if(global_toptree(d, n, d_pos, d_garbage, BoxSize, pol, DomainUseGlobalSorting, maxn, tree, size))
+                break;
+            d->dom_alloc_factor *= 1.2;
+            MPG_CHECK(d->dom_alloc_factor <= 10, "TopNodeAllocFactor unreasonably large");
+        }
+        std::vector<int> leaf_topnode((size_t)size);
+        const int nleaves = toptree_create_leaves(tree.data(), size, leaf_topnode.data());
+        // domain_balance (domain.c:481-500): particles per leaf over all ranks
+        std::vector<int64_t> counts((size_t)nleaves, 0);
+        domain_topleaves(n, d_pos, d_garbage, BoxSize, tree.data(), size, nleaves, nullptr, nt, nullptr, nullptr, counts.data(), nullptr, e->domain, st);
+        allreduce_i64(d, counts.data(), nleaves, 0);
+        std::vector<int64_t> leaf_cost = counts;
+        d->dom_topleaf.reserve((size_t)n + 1);
+        d->dom_task.reserve((size_t)n + 1);
+        if(d_cost) { // the work of every TopLeaf: its particles' costs, over all ranks (leaves are still in key order here)
+            std::vector<int> zero((size_t)nleaves, 0);
+            domain_topleaves(n, d_pos, d_garbage, BoxSize, tree.data(), size, nleaves, zero.data(), nt, d->dom_topleaf.p, d->dom_task.p, nullptr,
+                             nullptr, e->domain, st);
+            d->dom_cost.reserve((size_t)nleaves + 1);
+            MPG_HIP(hipMemsetAsync(d->dom_cost.p, 0, (size_t)nleaves * sizeof(double), st));
+            MPG_CHECK((size_t)nleaves * sizeof(double) <= 60000, "mpg_dist_domain_decompose: too many TopLeaves for the cost pass");
+            if(n > 0)
+                hipLaunchKernelGGL(k_leaf_cost, dim3(std::min<unsigned>(nblk(n), 2048u)), dim3(256), (size_t)nleaves * sizeof(double), st, n,
+                                   d->dom_topleaf.p, d_cost, nleaves, d->dom_cost.p);
+            std::vector<double> lc((size_t)nleaves);
+            MPG_HIP(hipMemcpyAsync(lc.data(), d->dom_cost.p, (size_t)nleaves * sizeof(double), hipMemcpyDeviceToHost, st));
+            sync(d);
+            allreduce_host_f64(d, lc.data(), nleaves, 0);
+            for(int l = 0; l < nleaves; l++)
+                leaf_cost[l] = std::max<int64_t>((int64_t)llround(lc[l]), 1);
+        }
+        std::vector<int> leaf_task((size_t)nleaves), start((size_t)nt), end((size_t)nt);
+        toptree_assign_balanced(tree.data(), size, leaf_topnode.data(), nleaves, leaf_cost.data(), nt, 1, leaf_task.data(), start.data(), end.data());
+        // the assignment renumbers the leaves by (Task, Key): TopLeaf and destination of every particle, counts in the final order
+        std::vector<int64_t> fcounts((size_t)nleaves, 0), tcounts((size_t)nt, 0);
+        domain_topleaves(n, d_pos, d_garbage, BoxSize, tree.data(), size, nleaves, leaf_task.data(), nt, d->dom_topleaf.p, d->dom_task.p, fcounts.data(),
+                         tcounts.data(), e->domain, st);
+        sync(d);
+        allreduce_i64(d, fcounts.data(), nleaves, 0);
+        d->dom_policy = i;
+        d->dom_tree.assign((const mpg_topnode *)tree.data(), (const mpg_topnode *)tree.data() + size);
+        d->dom_size = size;
+        d->dom_nleaves = nleaves;
+        d->dom_leaf_task = leaf_task;
+        d->dom_leaf_topnode.assign(leaf_topnode.begin(), leaf_topnode.begin() + nleaves);
+        d->dom_start = start;
+        d->dom_end = end;
+        d->dom_leaf_count = fcounts;
+        d->dom_send_counts = tcounts;
+        d->dom_n = n;
+        if(NTopNodes)
+            *NTopNodes = size;
+        if(NTopLeaves)
+            *NTopLeaves = nleaves;
+        break;
+    }
+    API_END
+}
+
+/* domain_maintain (domain.c:262-319): the decomposition is kept, only P[].TopLeaf and the destination tasks are found again for the
+ * (drifted) positions; mpg_dist_domain_exchange then moves the particles that left their owner's TopLeaves */
+int mpg_dist_domain_maintain(mpg_dist *d, int64_t n, const double *d_pos, const unsigned char *d_garbage, double BoxSize, int64_t *n_leaving)
+{
+    API_BEGIN
+    MPG_CHECK(d && d->dom_size > 0 && n >= 0 && (n == 0 || d_pos), "mpg_dist_domain_maintain: no decomposition / bad argument");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    d->dom_topleaf.reserve((size_t)n + 1);
+    d->dom_task.reserve((size_t)n + 1);
+    std::vector<int64_t> fcounts((size_t)d->dom_nleaves, 0), tcounts((size_t)d->nt, 0);
+    domain_topleaves(n, d_pos, d_garbage, BoxSize, (const TopNode *)d->dom_tree.data(), d->dom_size, d->dom_nleaves, d->dom_leaf_task.data(), d->nt,
+                     d->dom_topleaf.p, d->dom_task.p, fcounts.data(), tcounts.data(), e->domain, e->stream);
+    sync(d);
+    d->dom_send_counts = tcounts;
+    d->dom_n = n;
+    if(n_leaving) {
+        int64_t stay = tcounts[(size_t)d->me], live = 0;
+        for(int64_t c : tcounts)
+            live += c;
+        *n_leaving = live - stay;
+    }
+    API_END
+}
+
+int mpg_dist_domain_get(mpg_dist *d, mpg_topnode *TopNodes, int *leaf_task, int *StartLeaf, int *EndLeaf, int64_t *TopLeafCount)
+{
+    API_BEGIN
+    MPG_CHECK(d && d->dom_size > 0, "mpg_dist_domain_get: no decomposition");
+    if(TopNodes)
+        std::copy(d->dom_tree.begin(), d->dom_tree.end(), TopNodes);
+    if(leaf_task)
+        std::copy(d->dom_leaf_task.begin(), d->dom_leaf_task.end(), leaf_task);
+    if(StartLeaf)
+        std::copy(d->dom_start.begin(), d->dom_start.end(), StartLeaf);
+    if(EndLeaf)
+        std::copy(d->dom_end.begin(), d->dom_end.end(), EndLeaf);
+    if(TopLeafCount)
+        std::copy(d->dom_leaf_count.begin(), d->dom_leaf_count.end(), TopLeafCount);
+    API_END
+}
+
+int mpg_dist_domain_exchange(mpg_dist *d, int64_t n, int ncols, const void *const *d_cols, const int *col_bytes, int64_t *n_new, void **d_new_cols)
+{
+    API_BEGIN
+    MPG_CHECK(d && n_new && d_new_cols && d_cols && col_bytes && ncols >= 1 && ncols <= 16, "mpg_dist_domain_exchange: bad argument");
+    MPG_CHECK(d->dom_n == n, "mpg_dist_domain_exchange: mpg_dist_domain_decompose of this particle set first");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    d->mask.reserve((size_t)n + 1);
+    if(n > 0)
+        hipLaunchKernelGGL(k_task_mask, dim3(nblk(n)), dim3(256), 0, st, n, d->dom_task.p, d->mask.p);
+    build_plan(d, d->dom_plan, n, d->mask.p);
+    Plan &pl = d->dom_plan;
+    Cols c;
+    memset(&c, 0, sizeof(c));
+    c.n = ncols;
+    int row = 0;
+    for(int j = 0; j < ncols; j++) {
+        MPG_CHECK(col_bytes[j] > 0 && d_cols[j], "mpg_dist_domain_exchange: bad column");
+        c.src[j] = (const char *)d_cols[j];
+        c.w[j] = col_bytes[j];
+        c.off[j] = row;
+        row += (col_bytes[j] + 7) / 8 * 8;
+    }
+    c.row = row;
+    d->sendbuf.reserve((size_t)row * pl.nsend + 64);
+    d->recvbuf.reserve((size_t)row * pl.nrecv + 64);
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_pack_cols, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, c, d->sendbuf.p);
+    exchange_rows(d, pl, d->sendbuf.p, d->recvbuf.p, false, row);
+    for(int j = 0; j < ncols; j++) {
+        d->dom_out[j].reserve((size_t)col_bytes[j] * pl.nrecv + 64);
+        c.dst[j] = d->dom_out[j].p;
+        d_new_cols[j] = d->dom_out[j].p;
+    }
+    if(pl.nrecv > 0)
+        hipLaunchKernelGGL(k_unpack_cols, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const char *)d->recvbuf.p, c);
+    MPG_HIP(hipGetLastError());
+    sync(d);
+    *n_new = pl.nrecv;
+    d->dom_n = -1; // the particle set has changed
+    API_END
+}
+
+/* the decomposition just made becomes the domain of the force step (mpg_dist_set_domain with its own tree) */
+int mpg_dist_use_decomposition(mpg_dist *d, double BoxSize, double margin, int La)
+{
+    if(!d || d->dom_size <= 0)
+        return 1;
+    return mpg_dist_set_domain(d, BoxSize, d->dom_tree.data(), d->dom_size, d->dom_leaf_task.data(), d->dom_nleaves, margin, La);
 }
 
 } // extern "C"

@@ -98,6 +98,9 @@ class TorchComm:
             rb, rd = [rbytes[i] for i in range(w)], [rdispls[i] for i in range(w)]
             S = _bytes_tensor(send, max((d + b for d, b in zip(sd, sb)), default=0), bool(on_device), self.device)
             R = _bytes_tensor(recv, max((d + b for d, b in zip(rd, rb)), default=0), bool(on_device), self.device)
+            Rhost = None
+            if self.on_device and not on_device:      # RCCL moves device memory only: small host blocks (trees, samples) go through the GPU
+                Rhost, S, R = R, S.to(self.device), torch.empty(R.shape[0], dtype=torch.uint8, device=self.device)
             packed = lambda b, d: all(d[i] == sum(b[:i]) for i in range(w))
             piece = max(A2A_MAX_BYTES // w, 1)
             nchunk = max((max(max(sb), max(rb)) + piece - 1) // piece, 1)
@@ -114,6 +117,8 @@ class TorchComm:
                     for d, n in zip(rd, cr):
                         R[d + c * piece:d + c * piece + n] = dst[o:o + n]
                         o += n
+            if Rhost is not None:
+                Rhost.copy_(R.cpu())
             if on_device:
                 torch.cuda.current_stream().synchronize()   # the library continues on ITS stream
         return self._guard(go)
@@ -174,6 +179,62 @@ class DistForce:
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         self._ck(self.lib.mpg_dist_gravity_step(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(oldacc), p(prev_accel), p(accel), p(gravpm),
                                                 p(potential), C.c_double(rho0)))
+
+    # ---- domain_decompose_full + domain_exchange through the library (the C++ form of domain_peano.PeanoDomain)
+    def domain_decompose(self, pos, box, garbage=None, overdecomposition=4, global_sorting=True, cost=None):
+        """Returns (NTopNodes, NTopLeaves); the decomposition stays in the library (domain_get copies it out)."""
+        ntn, ntl = C.c_int(0), C.c_int(0)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self.lib.mpg_dist_domain_decompose.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self._ck(self.lib.mpg_dist_domain_decompose(self.h, C.c_int64(pos.shape[0]), p(pos), p(garbage), C.c_double(box), int(overdecomposition),
+                                                    int(bool(global_sorting)), p(cost), C.byref(ntn), C.byref(ntl)))
+        self._dom_sizes = (ntn.value, ntl.value)
+        return self._dom_sizes
+
+    def domain_get(self):
+        from .domain_peano import TOPNODE_DTYPE
+        ntn, ntl = self._dom_sizes
+        w = self.comm.world
+        tn = np.zeros(ntn, TOPNODE_DTYPE)
+        lt, st, en, cnt = np.zeros(ntl, np.int32), np.zeros(w, np.int32), np.zeros(w, np.int32), np.zeros(ntl, np.int64)
+        P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        self.lib.mpg_dist_domain_get.argtypes = [C.c_void_p, C.POINTER(TopNode), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_int64)]
+        self._ck(self.lib.mpg_dist_domain_get(self.h, P(tn, TopNode), P(lt, C.c_int), P(st, C.c_int), P(en, C.c_int), P(cnt, C.c_int64)))
+        return dict(TopNodes=tn, leaf_task=lt, StartLeaf=st, EndLeaf=en, TopLeafCount=cnt)
+
+    def domain_exchange(self, *columns):
+        """domain_exchange: every live particle to the task of its TopLeaf; returns this rank's columns afterwards (copies)."""
+        n, k = int(columns[0].shape[0]), len(columns)
+        cols = [c.contiguous() for c in columns]
+        ptrs = (C.c_void_p * k)(*[c.data_ptr() for c in cols])
+        widths = (C.c_int * k)(*[c.element_size() * int(np.prod(c.shape[1:], dtype=np.int64)) for c in cols])
+        outp = (C.c_void_p * k)()
+        nn = C.c_int64(0)
+        self.lib.mpg_dist_domain_exchange.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+        self._ck(self.lib.mpg_dist_domain_exchange(self.h, C.c_int64(n), k, ptrs, widths, C.byref(nn), outp))
+        out = []
+        dev = self.comm_device()
+        for c, w, ptr in zip(cols, widths, outp):
+            shape = (nn.value,) + tuple(c.shape[1:])
+            if nn.value == 0:
+                out.append(torch.empty(shape, dtype=c.dtype, device=dev))
+            else:
+                out.append(torch.as_tensor(_DevMem(ptr, w * nn.value), device=dev).view(c.dtype).reshape(shape).clone())
+        return out
+
+    def domain_maintain(self, pos, box, garbage=None):
+        """domain_maintain after a drift; returns the number of particles about to leave this rank"""
+        nl = C.c_int64(0)
+        self.lib.mpg_dist_domain_maintain.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_int64)]
+        self._ck(self.lib.mpg_dist_domain_maintain(self.h, C.c_int64(pos.shape[0]), C.c_void_p(pos.data_ptr()),
+                                                   None if garbage is None else C.c_void_p(garbage.data_ptr()), C.c_double(box), C.byref(nl)))
+        return nl.value
+
+    def use_decomposition(self, box, margin, La=0):
+        self.lib.mpg_dist_use_decomposition.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        self._ck(self.lib.mpg_dist_use_decomposition(self.h, C.c_double(box), C.c_double(margin), int(La)))
 
     def force_tree_build(self, pos, mass):
         """mpg_dist_dev_force_tree_build alone: ghost import, local tree, global top (what the SPH loops need when no gravity step

@@ -7,11 +7,13 @@
  *       P[].GravPM and P[].FullTreeGravAccel against the committed vectors of tests/golden/ (expect = GravPM[n][3], Accel2[n][3]).
  *   test_cabi ranks|ranks_host <table.f64> <pos.f64> <expect.f64> n nmesh box NTask
  *       NTask processes (fork; the collectives of mpg_comm are implemented on a shared-memory segment with a process-shared
- *       barrier - what MPI_Allreduce / MPI_Alltoall / MPI_Alltoallv would do), every one with its own engine on GPU 0: particles
- *       handed to the owners of the 8 top-level Peano-Hilbert cells (a legal, unbalanced domain), mpg_dist_set_domain,
- *       mpg_dist_gravity_step twice (ranks: device arrays) or the drop-in calls mpg_dist_gravpm_force / _force_tree_full /
- *       _grav_short_tree on each rank's table of 160-byte records (ranks_host); the assembled GravPM / accelerations against the
- *       same vectors.
+ *       barrier - what MPI_Allreduce / MPI_Alltoall / MPI_Alltoallv would do), every one with its own engine on GPU 0.
+ *       ranks:      mpg_dist_domain_decompose + mpg_dist_domain_exchange (domain_decompose_full and the particle exchange through
+ *                   the library), mpg_dist_use_decomposition, mpg_dist_gravity_step twice on device arrays;
+ *       ranks_host: particles handed to the owners of the 8 top-level Peano-Hilbert cells (a legal, unbalanced domain given from
+ *                   outside: mpg_dist_set_domain), then the drop-in calls mpg_dist_gravpm_force / _force_tree_full /
+ *                   _grav_short_tree on each rank's table of 160-byte records;
+ *       the assembled GravPM / accelerations against the same vectors.
  * Exit code 0 and a last line "PASS ..." on success. */
 #define _GNU_SOURCE
 #include <math.h>
@@ -247,28 +249,62 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
         tn[1 + k].Leaf = k;
         leaf_task[k] = k % nt;
     }
-    /* own particles: those whose key falls into my cells (keys from the engine: PEANO(), peano.h:15-21) */
-    double *d_all = NULL;
-    uint64_t *d_keys = NULL, *keys = malloc(N * sizeof(uint64_t));
-    if(hipMalloc((void **)&d_all, 3 * N * sizeof(double)) || hipMalloc((void **)&d_keys, N * sizeof(uint64_t)) ||
-       hipMemcpy(d_all, pos, 3 * N * sizeof(double), 1)) {
-        fprintf(stderr, "FAIL hipMalloc\n");
-        exit(1);
-    }
-    CK(mpg_dev_peano_keys(e, N, d_all, box, d_keys));
-    CK(mpg_engine_synchronize(e));
-    hipMemcpy(keys, d_keys, N * sizeof(uint64_t), 2);
+    mpg_dist *D = NULL;
+    CK(mpg_dist_create(&D, e, &comm));
     int64_t n_own = 0;
     int64_t *ids = malloc(N * sizeof(int64_t));
-    for(int64_t i = 0; i < N; i++)
-        if(leaf_task[keys[i] >> 60] == me)
-            ids[n_own++] = i;
-    double *opos = malloc(3 * (n_own + 1) * sizeof(double));
-    float *omass = malloc((n_own + 1) * sizeof(float));
-    for(int64_t k = 0; k < n_own; k++) {
-        memcpy(opos + 3 * k, pos + 3 * ids[k], 3 * sizeof(double));
-        omass[k] = 1.0f;
+    double *opos = malloc(3 * (N + 1) * sizeof(double));
+    float *omass = malloc((N + 1) * sizeof(float));
+    if(host) {
+        /* own particles: those whose key falls into my cells (keys from the engine: PEANO(), peano.h:15-21) */
+        double *d_all = NULL;
+        uint64_t *d_keys = NULL, *keys = malloc(N * sizeof(uint64_t));
+        if(hipMalloc((void **)&d_all, 3 * N * sizeof(double)) || hipMalloc((void **)&d_keys, N * sizeof(uint64_t)) ||
+           hipMemcpy(d_all, pos, 3 * N * sizeof(double), 1)) {
+            fprintf(stderr, "FAIL hipMalloc\n");
+            exit(1);
+        }
+        CK(mpg_dev_peano_keys(e, N, d_all, box, d_keys));
+        CK(mpg_engine_synchronize(e));
+        hipMemcpy(keys, d_keys, N * sizeof(uint64_t), 2);
+        for(int64_t i = 0; i < N; i++)
+            if(leaf_task[keys[i] >> 60] == me)
+                ids[n_own++] = i;
+        for(int64_t k = 0; k < n_own; k++)
+            memcpy(opos + 3 * k, pos + 3 * ids[k], 3 * sizeof(double));
+        free(keys);
+        hipFree(d_all);
+        hipFree(d_keys);
     }
+    else {
+        /* domain_decompose_full + domain_exchange through the library (mpg_dist_domain_*): every rank starts from a contiguous
+         * share of the particle set, as after reading a snapshot */
+        const int64_t lo = N * me / nt, hi = N * (me + 1) / nt, ns = hi - lo;
+        double *d_sp = NULL;
+        int64_t *d_sid = NULL, *sid = malloc((ns + 1) * sizeof(int64_t));
+        for(int64_t i = 0; i < ns; i++)
+            sid[i] = lo + i;
+        if(hipMalloc((void **)&d_sp, 3 * (ns + 1) * sizeof(double)) || hipMalloc((void **)&d_sid, (ns + 1) * sizeof(int64_t)) ||
+           hipMemcpy(d_sp, pos + 3 * lo, 3 * ns * sizeof(double), 1) || hipMemcpy(d_sid, sid, ns * sizeof(int64_t), 1)) {
+            fprintf(stderr, "FAIL hipMalloc\n");
+            exit(1);
+        }
+        int ntn = 0, ntl = 0;
+        CK(mpg_dist_domain_decompose(D, ns, d_sp, NULL, box, 4, 1, NULL, &ntn, &ntl));
+        const void *cols[2] = {d_sp, d_sid};
+        const int widths[2] = {24, 8};
+        void *newc[2];
+        CK(mpg_dist_domain_exchange(D, ns, 2, cols, widths, &n_own, newc));
+        hipMemcpy(opos, newc[0], 3 * n_own * sizeof(double), 2);
+        hipMemcpy(ids, newc[1], n_own * sizeof(int64_t), 2);
+        if(me == 0)
+            printf("decomposition: %d TopNodes, %d TopLeaves\n", ntn, ntl);
+        free(sid);
+        hipFree(d_sp);
+        hipFree(d_sid);
+    }
+    for(int64_t k = 0; k < n_own; k++)
+        omass[k] = 1.0f;
     double *d_pos, *d_acc, *d_prev, *d_gpm, *d_pot;
     float *d_mass;
     const size_t b3 = 3 * (n_own + 1) * sizeof(double);
@@ -279,10 +315,11 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
     }
     hipMemcpy(d_pos, opos, 3 * n_own * sizeof(double), 1);
     hipMemcpy(d_mass, omass, n_own * sizeof(float), 1);
-    mpg_dist *D = NULL;
-    CK(mpg_dist_create(&D, e, &comm));
     const double rcut = 6.0 * 1.5 * box / nmesh; /* Rcut * Asmth * cell size, gravshort-tree.c:102 */
-    CK(mpg_dist_set_domain(D, box, tn, 9, leaf_task, 8, rcut, 0));
+    if(host)
+        CK(mpg_dist_set_domain(D, box, tn, 9, leaf_task, 8, rcut, 0));
+    else
+        CK(mpg_dist_use_decomposition(D, box, rcut, 0));
     double *acc = malloc(b3), *gpm = malloc(b3);
     if(host) {
         /* the drop-in calls on this rank's table of 160-byte records, in run.c's order; twice (Barnes-Hut, then relative) */

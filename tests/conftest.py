@@ -57,3 +57,19 @@ def keep_artifacts_on_failure(body):
                     pass
             raise
     return wrapped
+
+
+def run_ranks(cmd, env, log_path, timeout=900):
+    """subprocess.run of a (multi-)rank helper script; on a non-zero exit the COMPLETE stdout / stderr are written to `log_path`
+    (under the test's tmp_path, which keep_artifacts_on_failure copies to gpurun_out/flake/) before the assertion fires: a rank that
+    aborts leaves its message far above the launcher's own traceback."""
+    import subprocess
+    env = dict(env)
+    env.setdefault("AMD_LOG_LEVEL", "1")          # HIP runtime errors to stderr
+    env.setdefault("TORCH_SHOW_CPP_STACKTRACES", "1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    if r.returncode != 0:
+        with open(str(log_path) + ".failed.log", "w") as f:
+            f.write("cmd: %s\n---- stdout ----\n%s\n---- stderr ----\n%s\n" % (" ".join(cmd), r.stdout, r.stderr))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r

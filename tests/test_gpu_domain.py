@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import keep_artifacts_on_failure
+from conftest import keep_artifacts_on_failure, run_ranks
 from oracle import domain_oracle as D
 from test_domain_host import keys_of, clumpy, assert_tree_equal
 
@@ -69,8 +69,7 @@ def _run(tmp_path, name, nproc, port, n, global_sort=1):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), script, out, str(n)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
+    run_ranks(cmd, env, out)
     return [np.load(out + ".%d.npz" % k) for k in range(nproc)]
 
 
@@ -102,6 +101,15 @@ def test_decomposition_and_exchange_on_ranks(tmp_path):
             ids = got[r]["ids"]
             assert np.array_equal(ids, np.nonzero(task_of == r)[0]), (nproc, r)
             assert np.array_equal(got[r]["pos"], pos[ids])
+            # the library's own choreography (mpg_dist_domain_decompose / _exchange over the mpg_comm callbacks): the same tree,
+            # the same assignment, the same particles in the same order
+            g = got[r]
+            assert len(g["lib_TopNodes"]) == len(g["TopNodes"])
+            for f in ("StartKey", "Shift", "Daughter", "Leaf", "Count"):
+                assert np.array_equal(g["lib_TopNodes"][f], g["TopNodes"][f]), (nproc, r, f)
+            assert np.array_equal(g["lib_leaf_task"], g["leaf_task"]) and np.array_equal(g["lib_StartLeaf"], g["StartLeaf"])
+            assert np.array_equal(g["lib_EndLeaf"], g["EndLeaf"]) and np.array_equal(g["lib_TopLeafCount"], g["TopLeafCount"])
+            assert np.array_equal(g["lib_ids"], ids) and np.array_equal(g["lib_pos"], g["pos"])
             # ... and the final Peano-Hilbert sort of domain_decompose_full: a stable sort by key
             assert np.array_equal(got[r]["perm"], np.argsort(keys[ids], kind="stable"))
         loads = np.array([len(got[r]["ids"]) for r in range(nproc)])

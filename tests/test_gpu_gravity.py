@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import keep_artifacts_on_failure
+from conftest import keep_artifacts_on_failure, run_ranks
 
 from oracle import oracle as O
 
@@ -356,8 +356,7 @@ def _run_mgpu(tmp_path, name, nproc, mode, port, ic="s_zel", n=40, env_extra=Non
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), script, out, str(n)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
+    run_ranks(cmd, env, out)
     return np.load(out)
 
 

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import keep_artifacts_on_failure
+from conftest import keep_artifacts_on_failure, run_ranks
 
 from oracle import oracle as O
 from test_oracle_sph import density_test_set
@@ -264,7 +264,13 @@ def test_full_size_hydro_2x128(pkg, orc, pe):
     tr2 = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
     tr2.calc_moments()
     O.sph_hydro_force(orc, tr2, dp, O.HydroParams(pe, 100.0, 0.75), A, to, active=act)
-    assert rel(g["hydroacc_out"][act], A.hydroacc_out[act]) <= 1e-10
+    if rel(g["hydroacc_out"][act], A.hydroacc_out[act]) > 1e-10:     # (say where: a failure at this size has to be diagnosable from the log)
+        dd = np.abs(g["hydroacc_out"][act] - A.hydroacc_out[act]).max(1)
+        worst = act[np.argsort(-dd)[:6]]
+        lines = ["%d pos %s hsml %.6g dens %.6g gpu %s oracle %s maxsig %.6g/%.6g" % (i, pos[i], g["hsml"][i], g["density"][i], g["hydroacc_out"][i],
+                                                                                     A.hydroacc_out[i], g["maxsignalvel"][i], A.maxsignalvel[i]) for i in worst]
+        raise AssertionError("hydro_force differs for %d of %d sampled targets (> 1e-10 of the largest); worst:\n%s"
+                             % (int((dd > 1e-10 * np.abs(A.hydroacc_out[act]).max()).sum()), len(act), "\n".join(lines)))
     assert rel(g["dtentropy_out"][act], A.dtentropy_out[act]) <= 1e-10
     assert rel(g["maxsignalvel"][act], A.maxsignalvel[act]) <= 1e-12
     eng.close()
@@ -362,8 +368,7 @@ def _run_hydro(tmp_path, name, nproc, mode, port):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), script, out, "24"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
+    run_ranks(cmd, env, out)
     return np.load(out)
 
 

@@ -3,7 +3,7 @@ compiled without FMA contraction, like the reference's loops), error codes inclu
 import numpy as np
 import pytest
 
-from conftest import keep_artifacts_on_failure
+from conftest import keep_artifacts_on_failure, run_ranks
 
 from oracle import oracle as O
 from test_oracle_timestep import make_set
@@ -131,13 +131,15 @@ def test_distributed_evolution_matches_one_gpu(tmp_path):
         cmd = [sys.executable, script, out, "24"] if nproc == 1 else \
               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), script, out, "24"]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-        assert r.returncode == 0, r.stderr[-3000:]
+        run_ranks(cmd, env, out)
         return np.load(out)
 
     one = run("one.npy", 1, "single", 0)
-    for name, nproc, port in (("e2.npy", 2, 29595), ("e4.npy", 4, 29596)):
-        d = run(name, nproc, "domain", port)
+    # x-slab domains driven from Python (round 1), then the library's own choreography on the Peano-Hilbert domains: decomposition,
+    # exchange, force, kicks, drift, domain_maintain + exchange (mpg_dist_*, csrc/dist.hip)
+    for name, nproc, port, mode in (("e2.npy", 2, 29595, "domain"), ("e4.npy", 4, 29596, "domain"), ("p1.npy", 1, 0, "peano"),
+                                    ("p2.npy", 2, 29597, "peano"), ("p4.npy", 4, 29598, "peano")):
+        d = run(name, nproc, mode, port)
         dp = np.abs(d[:, 0:3] - one[:, 0:3])
         dp = np.minimum(dp, np.abs(dp - np.abs(one[:, 0:3]).max()))       # (a particle sitting on the periodic seam)
         assert np.median(dp) <= 1e-12 * np.abs(one[:, 0:3]).max(), name

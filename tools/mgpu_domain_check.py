@@ -51,7 +51,18 @@ if __name__ == "__main__":
     got_ids, got_pos = dom.exchange(ids, d_pos)
     perm = dom.peano_order(got_pos)              # slots_gc_sorted: the rank's particles in Peano-Hilbert order
     torch.cuda.synchronize()
-    np.savez(out + ".%d.npz" % rank, TopNodes=dom.TopNodes, leaf_task=dom.leaf_task, leaf_topnode=dom.leaf_topnode, StartLeaf=dom.StartLeaf,
+    # the same decomposition and exchange through the library's own choreography (csrc/dist.hip, mpg_dist_domain_*)
+    lib_res = {}
+    if os.environ.get("MPG_CHECK_LIB_DOMAIN", "1") != "0":
+        comm = pkg.dist.TorchComm(dev) if world > 1 else pkg.dist.LocalComm()
+        df = pkg.dist.DistForce(eng, comm)
+        df.domain_decompose(d_pos, box, garbage=d_garb, overdecomposition=4, global_sorting=bool(int(os.environ.get("MPG_GLOBAL_SORT", "1"))))
+        g = df.domain_get()
+        l_ids, l_pos = df.domain_exchange(ids, d_pos)
+        lib_res = dict(lib_TopNodes=g["TopNodes"], lib_leaf_task=g["leaf_task"], lib_StartLeaf=g["StartLeaf"], lib_EndLeaf=g["EndLeaf"],
+                       lib_TopLeafCount=g["TopLeafCount"], lib_ids=l_ids.cpu().numpy(), lib_pos=l_pos.cpu().numpy())
+        df.close()
+    np.savez(out + ".%d.npz" % rank, **lib_res, TopNodes=dom.TopNodes, leaf_task=dom.leaf_task, leaf_topnode=dom.leaf_topnode, StartLeaf=dom.StartLeaf,
              EndLeaf=dom.EndLeaf, TopLeafCount=dom.TopLeafCount, topleaf=dom.topleaf.cpu().numpy(), task=dom.task.cpu().numpy(),
              ids=got_ids.cpu().numpy(), pos=got_pos.cpu().numpy(), perm=perm.cpu().numpy(), policy=np.array([dom.last_policy, dom.policy.SubSampleDistance]),
              alloc_factor=dom.alloc_factor)
