@@ -599,6 +599,13 @@ int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const doub
 int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml,
                          int DoEgyDensity);
 int mpg_dist_dev_hydro_force(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T);
+/* fof_fof (fof.c:157-253) with the particles on their owners: groups may span ranks.  Device arrays over the n_own own particles
+ * (d_type NULL: all type 1; d_vel NULL: zero); the linking length must not exceed the domain margin.  d_grnr[n_own] (may be NULL)
+ * receives P[].GrNr with GLOBAL group numbers (length descending, then MinID); *ngroups_total = fof.TotNgroups; this rank keeps the
+ * *ngroups_here groups with MinID % NTask == ThisTask: mpg_dist_fof_groups copies their table into HOST arrays. */
+int mpg_dist_dev_fof_fof(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, const uint8_t *d_type, const uint64_t *d_id,
+                         const double *d_vel, const mpg_fof_params *par, int64_t *d_grnr, int64_t *ngroups_total, int64_t *ngroups_here);
+int mpg_dist_fof_groups(mpg_dist *d, const mpg_fof_groups *out);
 /* ... and as drop-in calls on the rank's particle table in host memory (what libgadget's callers hand over; shim/gravity-hip.c):
  * Pos / Mass are read from P[], GravPM / FullTreeGravAccel / Potential (and AccelStore, may be NULL) are written as the reference's
  * functions write them; OldAcc of the walk comes from P[].FullTreeGravAccel + P[].GravPM.  All particles active (a PM step). */

@@ -407,6 +407,100 @@ __global__ void __launch_bounds__(256) k_leaf_cost(int64_t n, const int *__restr
             unsafeAtomicAdd(&out[l], s_sum[l]);
 }
 
+// ---- friends-of-friends over ranks: ghost columns, label exchange, label maps, group numbers
+struct alignas(16) IdRow {
+    unsigned long long id;
+    unsigned long long type;
+};
+
+__global__ void __launch_bounds__(256) k_pack_idtype(int64_t ns, const int *__restrict__ idx, const unsigned long long *__restrict__ id,
+                                                     const uint8_t *__restrict__ type, IdRow *__restrict__ rows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= ns)
+        return;
+    const int64_t i = idx[k];
+    rows[k].id = id[i];
+    rows[k].type = type ? type[i] : 1ull;
+}
+
+__global__ void __launch_bounds__(256) k_unpack_idtype(int64_t nr, const IdRow *__restrict__ rows, unsigned long long *__restrict__ id,
+                                                       uint8_t *__restrict__ type)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nr)
+        return;
+    id[k] = rows[k].id;
+    type[k] = (uint8_t)rows[k].type;
+}
+
+__global__ void __launch_bounds__(256) k_fill_type(int64_t n, const uint8_t *__restrict__ type, uint8_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        out[i] = type ? type[i] : (uint8_t)1;
+}
+
+__global__ void __launch_bounds__(256) k_gather_u64(int64_t ns, const int *__restrict__ idx, const unsigned long long *__restrict__ src,
+                                                    unsigned long long *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < ns)
+        out[k] = src[idx[k]];
+}
+
+// a ghost whose owner knows a smaller label than this rank's component of it: (this rank's label, the owner's) is a relabelling
+__global__ void __launch_bounds__(256) k_label_pairs(int64_t nr, const unsigned long long *__restrict__ mine, const unsigned long long *__restrict__ ext,
+                                                     unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals,
+                                                     uint8_t *__restrict__ flag)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= nr)
+        return;
+    keys[k] = mine[k];
+    vals[k] = ext[k];
+    flag[k] = ext[k] < mine[k];
+}
+
+// label[i] <- map(label[i]) where the (sorted, unique) keys hold it
+__global__ void __launch_bounds__(256) k_apply_label_map(int64_t n, unsigned long long *__restrict__ label, const unsigned long long *__restrict__ keys,
+                                                         const unsigned long long *__restrict__ vals, int64_t m)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const unsigned long long l = label[i];
+    int64_t lo = 0, hi = m;
+    while(lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if(keys[mid] < l)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if(lo < m && keys[lo] == l)
+        label[i] = vals[lo];
+}
+
+// P[].GrNr from the table of all groups (MinID ascending)
+__global__ void __launch_bounds__(256) k_lookup_grnr(int64_t n, const unsigned long long *__restrict__ label, const unsigned long long *__restrict__ minid,
+                                                     const long long *__restrict__ grnr, int64_t ng, long long *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const unsigned long long l = label[i];
+    int64_t lo = 0, hi = ng;
+    while(lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if(minid[mid] < l)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[i] = (lo < ng && minid[lo] == l) ? grnr[lo] : -1ll;
+}
+
 struct Plan { // one personalised exchange: who gets which of my rows, and what I get
     DevBuf<int> idx;
     DevBuf<long long> d_sdsp;
@@ -469,6 +563,21 @@ struct mpg_dist {
     int64_t dom_n = -1;
     Plan dom_plan;
     DevBuf<char> dom_out[16];
+    // friends-of-friends over ranks
+    DevBuf<unsigned long long> f_id, f_ext, f_keys, f_vals, f_keys2, f_vals2, f_ukeys, f_uvals, f_glab, f_minid;
+    DevBuf<uint8_t> f_type, f_flag;
+    DevBuf<long long> f_grnr_tab, f_pgrnr;
+    struct GroupRec { // one (part of a) group: struct BaseGroup / Group (fof.h:14-49) with raw sums about FirstPos
+        unsigned long long MinID;
+        long long Length;
+        int LenType[6];
+        float FirstPos[3];
+        int src;
+        double acc[27]; // Mass, MassType[6], sum m x[3], sum m v[3], sum m (rel x v)[3], sum m rel rel^T [9]
+    };
+    std::vector<GroupRec> f_groups; // the complete groups this rank holds (MinID % NTask == ThisTask), finished
+    std::vector<long long> f_group_grnr;
+    int64_t f_total = 0;
     int64_t stats[8] = {};
     double times[8] = {};
     // host (drop-in) path: the rank's P[] staged on the device
@@ -1645,6 +1754,367 @@ int mpg_dist_use_decomposition(mpg_dist *d, double BoxSize, double margin, int L
     if(!d || d->dom_size <= 0)
         return 1;
     return mpg_dist_set_domain(d, BoxSize, d->dom_tree.data(), d->dom_size, d->dom_leaf_task.data(), d->dom_nleaves, margin, La);
+}
+
+} // extern "C"
+
+/* ---- fof_fof (fof.c:157-253) with the particles on their Peano-Hilbert owners ---------------------------------------------------
+ * The reference labels every particle with the smallest ID it is linked to by repeated tree walks with exports until no label
+ * changes anywhere, then ships parts of groups to one task per group and numbers the groups globally.  Here: ghosts within the
+ * domain margin (>= the linking length) make every link of an own particle local; the components of the local set are found as
+ * on one GPU (fof.hip); the labels of the ghosts are then compared with their owners' until nothing changes (a group that crosses
+ * k domain boundaries needs about k rounds of one 8-byte-per-ghost exchange); the parts of the groups found among the OWN
+ * particles go to rank MinID % NTask, which adds them up (fof_reduce_groups), drops groups below FOFHaloMinLength and finishes
+ * their properties; one all-gather of (Length, MinID) numbers the groups as fof_assign_grnr does (length descending). */
+namespace {
+
+using GroupRec = mpg_dist::GroupRec;
+
+inline double nearest(double x, double box) { return x > 0.5 * box ? x - box : (x < -0.5 * box ? x + box : x); }
+
+// b (a part of the same group, sums about its own FirstPos) into a
+void add_group_part(GroupRec &a, const GroupRec &b, double box)
+{
+    double s[3], mrel[3]; // shift of b's reference point into a's frame; sum m rel of b about b's FirstPos
+    const double Mb = b.acc[0];
+    for(int k = 0; k < 3; k++) {
+        s[k] = nearest((double)b.FirstPos[k] - (double)a.FirstPos[k], box);
+        mrel[k] = b.acc[7 + k] - Mb * (double)b.FirstPos[k];
+    }
+    a.Length += b.Length;
+    for(int t = 0; t < 6; t++)
+        a.LenType[t] += b.LenType[t];
+    for(int c = 0; c < 7; c++)
+        a.acc[c] += b.acc[c];
+    const double *mv = b.acc + 10;
+    const double sxmv[3] = {s[1] * mv[2] - s[2] * mv[1], s[2] * mv[0] - s[0] * mv[2], s[0] * mv[1] - s[1] * mv[0]};
+    for(int k = 0; k < 3; k++) {
+        a.acc[7 + k] += mrel[k] + Mb * (s[k] + (double)a.FirstPos[k]); // sum m (rel_b + s + FirstPos_a)
+        a.acc[10 + k] += mv[k];
+        a.acc[13 + k] += b.acc[13 + k] + sxmv[k];
+        for(int e = 0; e < 3; e++)
+            a.acc[16 + 3 * k + e] += b.acc[16 + 3 * k + e] + s[k] * mrel[e] + mrel[k] * s[e] + Mb * s[k] * s[e];
+    }
+}
+
+// fof_finish_group_properties (fof.c:705-755), as k_fof_finish of fof.hip
+void finish_group(GroupRec &g, double box)
+{
+    double *a = g.acc;
+    const double M = a[0];
+    double cm[3], rel[3], vcm[3];
+    for(int d = 0; d < 3; d++) {
+        a[10 + d] /= M;
+        vcm[d] = a[10 + d];
+        cm[d] = a[7 + d] / M;
+        rel[d] = nearest(cm[d] - (double)g.FirstPos[d], box);
+        while(cm[d] >= box)
+            cm[d] -= box;
+        while(cm[d] < 0)
+            cm[d] += box;
+        a[7 + d] = cm[d];
+    }
+    const double jcm[3] = {rel[1] * vcm[2] - rel[2] * vcm[1], rel[2] * vcm[0] - rel[0] * vcm[2], rel[0] * vcm[1] - rel[1] * vcm[0]};
+    for(int d = 0; d < 3; d++)
+        a[13 + d] -= jcm[d] * M;
+    for(int d = 0; d < 3; d++)
+        for(int e = 0; e < 3; e++)
+            a[16 + 3 * d + e] -= M * rel[d] * rel[e];
+}
+
+// host alltoallv of records: out = what the other ranks sent here, in source-rank order
+template <class T> void exchange_host_records(mpg_dist *d, const std::vector<std::vector<T>> &to, std::vector<T> &out)
+{
+    static_assert(sizeof(T) % 8 == 0, "records travel in 8-byte units");
+    const int nt = d->nt;
+    out.clear();
+    if(nt == 1) {
+        out = to[0];
+        return;
+    }
+    std::vector<int64_t> sc(nt), rc(nt), sd(nt + 1, 0), rd(nt + 1, 0);
+    for(int r = 0; r < nt; r++) {
+        sc[r] = (int64_t)(to[r].size() * sizeof(T));
+        sd[r + 1] = sd[r] + sc[r];
+    }
+    cb(d->comm.alltoall_i64(d->comm.ctx, sc.data(), rc.data()), "alltoall_i64");
+    for(int r = 0; r < nt; r++)
+        rd[r + 1] = rd[r] + rc[r];
+    std::vector<char> sb((size_t)sd[nt] + 8), rb((size_t)rd[nt] + 8);
+    for(int r = 0; r < nt; r++)
+        if(sc[r])
+            memcpy(sb.data() + sd[r], to[r].data(), (size_t)sc[r]);
+    std::vector<int64_t> sdv(sd.begin(), sd.begin() + nt), rdv(rd.begin(), rd.begin() + nt);
+    cb(d->comm.alltoallv(d->comm.ctx, sb.data(), sc.data(), sdv.data(), rb.data(), rc.data(), rdv.data(), 0), "alltoallv");
+    out.resize((size_t)rd[nt] / sizeof(T));
+    if(rd[nt])
+        memcpy(out.data(), rb.data(), (size_t)rd[nt]);
+}
+
+} // namespace
+
+extern "C" {
+
+int mpg_dist_dev_fof_fof(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, const uint8_t *d_type, const uint64_t *d_id,
+                         const double *d_vel, const mpg_fof_params *par, int64_t *d_grnr, int64_t *ngroups_total, int64_t *ngroups_here)
+{
+    API_BEGIN
+    MPG_CHECK(d && par && (n_own == 0 || (d_pos && d_mass && d_id)), "mpg_dist_dev_fof_fof: null argument");
+    MPG_CHECK(d->have_domain, "mpg_dist_dev_fof_fof: mpg_dist_set_domain first");
+    MPG_CHECK(par->FOFHaloComovingLinkingLength > 0 && par->FOFHaloMinLength >= 1, "fof_fof: bad parameters");
+    MPG_CHECK((par->FOFPrimaryLinkTypes & par->FOFSecondaryLinkTypes) == 0, "fof_fof: primary and secondary link types must be disjoint");
+    // primary links reach one linking length; the doubling search of the secondary attachment (0.4 LL, doubled while below 4 LL:
+    // fof.c:1235-1239, 1286) ends at 6.4 linking lengths
+    MPG_CHECK((par->FOFSecondaryLinkTypes ? 6.4 : 1.0) * par->FOFHaloComovingLinkingLength <= d->margin,
+              "mpg_dist_dev_fof_fof: the domain margin must cover the linking length (6.4 linking lengths with secondary link types)");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const int nt = d->nt;
+    // ---- ghosts with their IDs and types; the tree of the primary types over the local set
+    const int64_t nl = import_ghosts(d, n_own, d_pos, d_mass);
+    const Plan &pl = d->ghost;
+    d->f_id.reserve((size_t)nl + 1);
+    d->f_type.reserve((size_t)nl + 1);
+    if(n_own > 0) {
+        MPG_HIP(hipMemcpyAsync(d->f_id.p, d_id, (size_t)n_own * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_fill_type, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d_type, d->f_type.p);
+    }
+    d->sendbuf.reserve((size_t)16 * pl.nsend + 16);
+    d->recvbuf.reserve((size_t)16 * pl.nrecv + 16);
+    if(pl.nsend > 0)
+        hipLaunchKernelGGL(k_pack_idtype, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, (const unsigned long long *)d_id, d_type,
+                           (IdRow *)d->sendbuf.p);
+    exchange_rows(d, pl, d->sendbuf.p, d->recvbuf.p, false, 16);
+    if(pl.nrecv > 0)
+        hipLaunchKernelGGL(k_unpack_idtype, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const IdRow *)d->recvbuf.p, d->f_id.p + n_own,
+                           d->f_type.p + n_own);
+    MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, d->f_type.p, d->box) == 0, mpg_last_error());
+    e->tree.build(nl, d->lpos.p, d->lmass.p, d->f_type.p, par->FOFPrimaryLinkTypes, d->box, st, &e->timer, nullptr);
+    e->tree_allocated = true;
+    e->tree_mask = par->FOFPrimaryLinkTypes;
+    e->full_particle_tree = false;
+    e->sph.hmax_pending = false;
+    FofInput in;
+    in.n = nl;
+    in.pos = d->lpos.p;
+    in.vel = nullptr;
+    in.mass = d->lmass.p;
+    in.type = d->f_type.p;
+    in.flags = nullptr;
+    in.id = d->f_id.p;
+    in.hsml = nullptr;
+    in.box = d->box;
+    in.LL = par->FOFHaloComovingLinkingLength;
+    in.minlen = par->FOFHaloMinLength;
+    in.secondary_mask = par->FOFSecondaryLinkTypes;
+    FofEngine &F = e->fof;
+    F.compute_labels(e->tree, in, st);
+    // ---- the labels of the ghosts against their owners', until no rank changes any
+    const int64_t ng_ = pl.nrecv;
+    d->f_ext.reserve((size_t)ng_ + 1);
+    d->f_keys.reserve((size_t)ng_ + 1);
+    d->f_vals.reserve((size_t)ng_ + 1);
+    d->f_keys2.reserve((size_t)ng_ + 1);
+    d->f_vals2.reserve((size_t)ng_ + 1);
+    d->f_ukeys.reserve((size_t)ng_ + 1);
+    d->f_uvals.reserve((size_t)ng_ + 1);
+    d->f_flag.reserve((size_t)ng_ + 1);
+    d->scount.reserve(4);
+    int rounds = 0;
+    for(;; rounds++) {
+        MPG_CHECK(rounds < 10000, "mpg_dist_dev_fof_fof: the labels do not converge");
+        d->sendbuf.reserve((size_t)8 * pl.nsend + 8);
+        if(pl.nsend > 0)
+            hipLaunchKernelGGL(k_gather_u64, dim3(nblk(pl.nsend)), dim3(256), 0, st, pl.nsend, pl.idx.p, F.label.p, (unsigned long long *)d->sendbuf.p);
+        exchange_rows(d, pl, d->sendbuf.p, d->f_ext.p, false, 8);
+        int64_t changed = 0;
+        if(ng_ > 0) {
+            hipLaunchKernelGGL(k_label_pairs, dim3(nblk(ng_)), dim3(256), 0, st, ng_, F.label.p + n_own, d->f_ext.p, d->f_keys.p, d->f_vals.p, d->f_flag.p);
+            size_t tb = 0, tb2 = 0;
+            MPG_HIP(rocprim::select(nullptr, tb, d->f_keys.p, d->f_flag.p, d->f_keys2.p, d->scount.p, (size_t)ng_, st));
+            d->tmp.reserve(tb + 16);
+            MPG_HIP(rocprim::select((void *)d->tmp.p, tb, d->f_keys.p, d->f_flag.p, d->f_keys2.p, d->scount.p, (size_t)ng_, st));
+            MPG_HIP(rocprim::select((void *)d->tmp.p, tb, d->f_vals.p, d->f_flag.p, d->f_vals2.p, d->scount.p, (size_t)ng_, st));
+            unsigned long long m = 0;
+            MPG_HIP(hipMemcpyAsync(&m, d->scount.p, sizeof(m), hipMemcpyDeviceToHost, st));
+            sync(d);
+            if(m > 0) {
+                // the smallest owner label per local label: sort by the local label, reduce by key with min
+                MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb2, d->f_keys2.p, d->f_keys.p, d->f_vals2.p, d->f_vals.p, (size_t)m, 0, 64, st));
+                d->tmp.reserve(tb2 + 16);
+                MPG_HIP(rocprim::radix_sort_pairs((void *)d->tmp.p, tb2, d->f_keys2.p, d->f_keys.p, d->f_vals2.p, d->f_vals.p, (size_t)m, 0, 64, st));
+                size_t tb3 = 0;
+                MPG_HIP(rocprim::reduce_by_key(nullptr, tb3, d->f_keys.p, d->f_vals.p, (unsigned)m, d->f_ukeys.p, d->f_uvals.p, d->scount.p + 1,
+                                               rocprim::minimum<unsigned long long>(), rocprim::equal_to<unsigned long long>(), st));
+                d->tmp.reserve(tb3 + 16);
+                MPG_HIP(rocprim::reduce_by_key((void *)d->tmp.p, tb3, d->f_keys.p, d->f_vals.p, (unsigned)m, d->f_ukeys.p, d->f_uvals.p, d->scount.p + 1,
+                                               rocprim::minimum<unsigned long long>(), rocprim::equal_to<unsigned long long>(), st));
+                unsigned long long mu = 0;
+                MPG_HIP(hipMemcpyAsync(&mu, d->scount.p + 1, sizeof(mu), hipMemcpyDeviceToHost, st));
+                sync(d);
+                hipLaunchKernelGGL(k_apply_label_map, dim3(nblk(nl)), dim3(256), 0, st, nl, F.label.p, d->f_ukeys.p, d->f_uvals.p, (int64_t)mu);
+                changed = 1;
+            }
+        }
+        allreduce_i64(d, &changed, 1, 0);
+        if(changed == 0)
+            break;
+    }
+    d->stats[6] = rounds + 1;
+    // ---- the parts of the groups among the OWN particles: all parts of a label that a ghost carries too, and the large ones
+    int64_t nglab = 0;
+    if(ng_ > 0) {
+        size_t tb = 0;
+        MPG_HIP(rocprim::radix_sort_keys(nullptr, tb, F.label.p + n_own, d->f_keys.p, (size_t)ng_, 0, 64, st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::radix_sort_keys((void *)d->tmp.p, tb, F.label.p + n_own, d->f_keys.p, (size_t)ng_, 0, 64, st));
+        d->f_glab.reserve((size_t)ng_ + 1);
+        size_t tb2 = 0;
+        MPG_HIP(rocprim::unique(nullptr, tb2, d->f_keys.p, d->f_glab.p, d->scount.p, (size_t)ng_, rocprim::equal_to<unsigned long long>(), st));
+        d->tmp.reserve(tb2 + 16);
+        MPG_HIP(rocprim::unique((void *)d->tmp.p, tb2, d->f_keys.p, d->f_glab.p, d->scount.p, (size_t)ng_, rocprim::equal_to<unsigned long long>(), st));
+        unsigned long long c = 0;
+        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        sync(d);
+        nglab = (int64_t)c;
+    }
+    in.vel = d_vel;
+    const int64_t nparts = F.catalogue(in, n_own, d->f_glab.p, nglab, false, st);
+    // ---- the parts to the rank that keeps the group (MinID % NTask), which adds them up
+    std::vector<unsigned long long> h_minid((size_t)nparts + 1);
+    std::vector<unsigned> h_len((size_t)nparts + 1);
+    std::vector<int> h_lt((size_t)nparts * 6 + 6);
+    std::vector<float> h_first((size_t)nparts * 3 + 3);
+    std::vector<double> h_acc((size_t)nparts * 27 + 27);
+    if(nparts > 0) {
+        MPG_HIP(hipMemcpyAsync(h_minid.data(), F.g_minid.p, (size_t)nparts * 8, hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(h_len.data(), F.g_len.p, (size_t)nparts * 4, hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(h_lt.data(), F.g_lentype.p, (size_t)nparts * 6 * 4, hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(h_first.data(), F.g_first.p, (size_t)nparts * 3 * 4, hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(h_acc.data(), F.g_acc.p, (size_t)nparts * 27 * 8, hipMemcpyDeviceToHost, st));
+        sync(d);
+    }
+    std::vector<std::vector<GroupRec>> to((size_t)nt);
+    for(int64_t g = 0; g < nparts; g++) {
+        GroupRec r;
+        memset(&r, 0, sizeof(r));
+        r.MinID = h_minid[g];
+        r.Length = h_len[g];
+        r.src = d->me;
+        for(int t = 0; t < 6; t++)
+            r.LenType[t] = h_lt[6 * g + t];
+        for(int k = 0; k < 3; k++)
+            r.FirstPos[k] = h_first[3 * g + k];
+        memcpy(r.acc, h_acc.data() + 27 * g, 27 * sizeof(double));
+        to[(size_t)(r.MinID % (unsigned long long)nt)].push_back(r);
+    }
+    std::vector<GroupRec> got;
+    exchange_host_records(d, to, got);
+    // parts of one group side by side, the lowest source rank first (its FirstPos becomes the group's: fof_reduce_base_group keeps the
+    // first in the same way); the sums do not depend on the order beyond rounding
+    std::stable_sort(got.begin(), got.end(), [](const GroupRec &a, const GroupRec &b) { return a.MinID != b.MinID ? a.MinID < b.MinID : a.src < b.src; });
+    d->f_groups.clear();
+    for(size_t k = 0; k < got.size();) {
+        GroupRec g = got[k];
+        size_t j = k + 1;
+        for(; j < got.size() && got[j].MinID == g.MinID; j++)
+            add_group_part(g, got[j], d->box);
+        k = j;
+        if(g.Length >= par->FOFHaloMinLength) { // fof.c:800-808
+            finish_group(g, d->box);
+            d->f_groups.push_back(g);
+        }
+    }
+    // ---- global numbers: by (Length descending, MinID ascending), fof_assign_grnr (fof.c:1106-1155)
+    struct LM {
+        long long Length;
+        unsigned long long MinID;
+    };
+    std::vector<LM> mine(d->f_groups.size());
+    for(size_t k = 0; k < mine.size(); k++)
+        mine[k] = LM{d->f_groups[k].Length, d->f_groups[k].MinID};
+    std::vector<std::vector<LM>> toall((size_t)nt, mine);
+    std::vector<LM> all;
+    exchange_host_records(d, toall, all);
+    std::vector<size_t> ord(all.size());
+    for(size_t k = 0; k < ord.size(); k++)
+        ord[k] = k;
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+        return all[a].Length != all[b].Length ? all[a].Length > all[b].Length : all[a].MinID < all[b].MinID;
+    });
+    std::vector<std::pair<unsigned long long, long long>> tab(all.size()); // (MinID, GrNr), then by MinID
+    for(size_t k = 0; k < ord.size(); k++)
+        tab[k] = {all[ord[k]].MinID, (long long)k};
+    std::sort(tab.begin(), tab.end());
+    d->f_total = (int64_t)all.size();
+    d->f_group_grnr.assign(d->f_groups.size(), -1);
+    for(size_t k = 0; k < d->f_groups.size(); k++) {
+        auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(d->f_groups[k].MinID, (long long)-1));
+        d->f_group_grnr[k] = it->second;
+    }
+    // ---- P[].GrNr of the own particles
+    if(d_grnr && n_own > 0) {
+        const size_t nall = tab.size();
+        std::vector<unsigned long long> hk(nall + 1);
+        std::vector<long long> hv(nall + 1);
+        for(size_t k = 0; k < nall; k++) {
+            hk[k] = tab[k].first;
+            hv[k] = tab[k].second;
+        }
+        d->f_minid.reserve(nall + 1);
+        d->f_grnr_tab.reserve(nall + 1);
+        if(nall) {
+            MPG_HIP(hipMemcpyAsync(d->f_minid.p, hk.data(), nall * 8, hipMemcpyHostToDevice, st));
+            MPG_HIP(hipMemcpyAsync(d->f_grnr_tab.p, hv.data(), nall * 8, hipMemcpyHostToDevice, st));
+        }
+        hipLaunchKernelGGL(k_lookup_grnr, dim3(nblk(n_own)), dim3(256), 0, st, n_own, F.label.p, d->f_minid.p, d->f_grnr_tab.p, (int64_t)nall,
+                           (long long *)d_grnr);
+        sync(d);
+    }
+    if(ngroups_total)
+        *ngroups_total = d->f_total;
+    if(ngroups_here)
+        *ngroups_here = (int64_t)d->f_groups.size();
+    API_END
+}
+
+/* the groups this rank keeps after the last mpg_dist_dev_fof_fof (HOST arrays of *ngroups_here entries; NULL = not wanted) */
+int mpg_dist_fof_groups(mpg_dist *d, const mpg_fof_groups *out)
+{
+    API_BEGIN
+    MPG_CHECK(d && out, "null argument");
+    for(size_t g = 0; g < d->f_groups.size(); g++) {
+        const GroupRec &r = d->f_groups[g];
+        if(out->MinID)
+            out->MinID[g] = r.MinID;
+        if(out->Length)
+            out->Length[g] = (int)r.Length;
+        if(out->GrNr)
+            out->GrNr[g] = (int)d->f_group_grnr[g];
+        if(out->Mass)
+            out->Mass[g] = r.acc[0];
+        for(int t = 0; t < 6; t++) {
+            if(out->LenType)
+                out->LenType[6 * g + t] = r.LenType[t];
+            if(out->MassType)
+                out->MassType[6 * g + t] = r.acc[1 + t];
+        }
+        for(int k = 0; k < 3; k++) {
+            if(out->CM)
+                out->CM[3 * g + k] = r.acc[7 + k];
+            if(out->Vel)
+                out->Vel[3 * g + k] = r.acc[10 + k];
+            if(out->Jmom)
+                out->Jmom[3 * g + k] = r.acc[13 + k];
+            if(out->FirstPos)
+                out->FirstPos[3 * g + k] = r.FirstPos[k];
+        }
+        if(out->Imom)
+            for(int c = 0; c < 9; c++)
+                out->Imom[9 * g + c] = r.acc[16 + c];
+    }
+    API_END
 }
 
 } // extern "C"

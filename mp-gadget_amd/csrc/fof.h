@@ -41,6 +41,11 @@ struct FofEngine {
     DevBuf<char> tmp;
     // the tree must hold the particles of the primary link types (force_tree_rebuild_mask); returns the number of groups
     int64_t run(TreeBuilder &tree, const FofInput &in, hipStream_t st);
+    // the two halves of run(), used separately when groups span ranks (dist.hip): labels of all in.n particles; then the catalogue
+    // of the first n of them (also_keep: sorted labels whose runs are reported whatever their length; finish = false leaves raw sums)
+    void compute_labels(TreeBuilder &tree, const FofInput &in, hipStream_t st);
+    int64_t catalogue(const FofInput &in, int64_t n, const unsigned long long *also_keep, int64_t nalso, bool finish, hipStream_t st);
+    static constexpr int NQ_ = 27; // doubles per group in g_acc (fof.hip NQ)
     void export_groups(const FofTable &out, hipStream_t st);
 };
 

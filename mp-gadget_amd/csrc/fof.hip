@@ -224,11 +224,27 @@ __global__ void __launch_bounds__(256) k_iota(int64_t n, int *__restrict__ idx)
         idx[i] = (int)i;
 }
 
-__global__ void __launch_bounds__(256) k_fof_keep_runs(int64_t nruns, const unsigned *__restrict__ counts, int minlen, uint8_t *__restrict__ keep)
+__global__ void __launch_bounds__(256) k_fof_keep_runs(int64_t nruns, const unsigned *__restrict__ counts, int minlen, uint8_t *__restrict__ keep,
+                                                       const unsigned long long *__restrict__ run_label, const unsigned long long *__restrict__ also,
+                                                       int64_t nalso)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if(r < nruns)
-        keep[r] = counts[r] >= (unsigned)minlen ? 1 : 0; // fof.c:800-808
+    if(r >= nruns)
+        return;
+    bool k = counts[r] >= (unsigned)minlen; // fof.c:800-808
+    if(!k && nalso > 0) { // a part of a group that continues on another rank: reported whatever its size (binary search of the label)
+        const unsigned long long l = run_label[r];
+        int64_t lo = 0, hi = nalso;
+        while(lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if(also[mid] < l)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        k = lo < nalso && also[lo] == l;
+    }
+    keep[r] = k ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_fof_lenkeys(int64_t ng, const unsigned *__restrict__ length, unsigned *__restrict__ key)
@@ -417,6 +433,13 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 int64_t FofEngine::run(TreeBuilder &tree, const FofInput &in, hipStream_t st)
 {
+    compute_labels(tree, in, st);
+    return catalogue(in, in.n, nullptr, 0, true, st);
+}
+
+// primary linking + secondary attachment: label[i] = the smallest ID of the particles linked with i (its own ID if none)
+void FofEngine::compute_labels(TreeBuilder &tree, const FofInput &in, hipStream_t st)
+{
     const int64_t n = in.n;
     const int64_t np = tree.npart;
     ngroups = 0;
@@ -424,7 +447,7 @@ int64_t FofEngine::run(TreeBuilder &tree, const FofInput &in, hipStream_t st)
     MPG_HIP(hipMemsetAsync(err.p, 0, sizeof(unsigned), st));
     label.reserve((size_t)n + 1);
     if(n == 0)
-        return 0;
+        return;
     hipLaunchKernelGGL(k_fof_own_labels, dim3(nblk(n)), dim3(256), 0, st, n, in.id, label.p);
     const TreeView tv = tree.view();
     if(np > 0) {
@@ -456,12 +479,27 @@ int64_t FofEngine::run(TreeBuilder &tree, const FofInput &in, hipStream_t st)
         }
     }
     (void)tv;
+    unsigned e = 0;
+    MPG_HIP(hipMemcpyAsync(&e, err.p, sizeof(e), hipMemcpyDeviceToHost, st));
+    MPG_HIP(hipStreamSynchronize(st));
+    MPG_CHECK(e == 0, "fof: the neighbour walk overflowed its stack (corrupt tree?)");
+}
+
+// The catalogue of the first `n` particles (n <= in.n: with ghosts behind them, only the own ones) from label[]: particles in label
+// order, runs = groups.  A run is kept when it has at least in.minlen members or its label is in `also_keep` (sorted, unique: the
+// labels shared with other ranks, whose parts must all be reported).  finish: fof_finish_group_properties; without it the sums stay
+// raw (about FirstPos) so that parts of a group can be added up.
+int64_t FofEngine::catalogue(const FofInput &in, int64_t n, const unsigned long long *also_keep, int64_t nalso, bool finish, hipStream_t st)
+{
+    ngroups = 0;
+    if(n == 0)
+        return 0;
+    size_t b = 0;
     // ---- catalogue: particles in label order, runs = groups
     slabel.reserve((size_t)n + 1);
     sidx.reserve((size_t)n + 1);
     val.reserve((size_t)n + 1);
     hipLaunchKernelGGL(k_iota, dim3(nblk(n)), dim3(256), 0, st, n, val.p);
-    size_t b = 0;
     MPG_HIP(rocprim::radix_sort_pairs(nullptr, b, label.p, slabel.p, val.p, sidx.p, (size_t)n, 0, 64, st));
     tmp.reserve(b + 16);
     MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, b, label.p, slabel.p, val.p, sidx.p, (size_t)n, 0, 64, st));
@@ -469,6 +507,7 @@ int64_t FofEngine::run(TreeBuilder &tree, const FofInput &in, hipStream_t st)
     run_count.reserve((size_t)n + 1);
     run_start.reserve((size_t)n + 1);
     cnt.reserve(8);
+    tmp.reserve(64);
     b = 0;
     MPG_HIP(rocprim::run_length_encode(nullptr, b, slabel.p, (unsigned)n, run_label.p, run_count.p, cnt.p + 1, st));
     tmp.reserve(b + 16);
@@ -481,7 +520,8 @@ int64_t FofEngine::run(TreeBuilder &tree, const FofInput &in, hipStream_t st)
     tmp.reserve(b + 16);
     MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, b, run_count.p, run_start.p, 0u, (size_t)nruns, rocprim::plus<unsigned>(), st));
     keep.reserve((size_t)nruns + 1);
-    hipLaunchKernelGGL(k_fof_keep_runs, dim3(nblk((int64_t)nruns)), dim3(256), 0, st, (int64_t)nruns, run_count.p, in.minlen, keep.p);
+    hipLaunchKernelGGL(k_fof_keep_runs, dim3(nblk((int64_t)nruns)), dim3(256), 0, st, (int64_t)nruns, run_count.p, in.minlen, keep.p, run_label.p,
+                       also_keep, nalso);
     g_minid.reserve((size_t)nruns + 1);
     g_len.reserve((size_t)nruns + 1);
     g_start.reserve((size_t)nruns + 1);
@@ -522,12 +562,9 @@ int64_t FofEngine::run(TreeBuilder &tree, const FofInput &in, hipStream_t st)
     }
     hipLaunchKernelGGL(k_fof_accumulate, dim3(nblk(n)), dim3(256), 0, st, n, (int64_t)ng, g_start.p, g_len.p, g_grnr.p, sidx.p, in.pos, in.vel, in.mass,
                        in.type, g_first.p, in.box, p_grnr.p, g_acc.p, g_lentype.p);
-    if(ng > 0)
+    if(ng > 0 && finish)
         hipLaunchKernelGGL(k_fof_finish, dim3(nblk((int64_t)ng)), dim3(256), 0, st, (int64_t)ng, g_first.p, in.box, g_acc.p);
-    unsigned e = 0;
-    MPG_HIP(hipMemcpyAsync(&e, err.p, sizeof(e), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipStreamSynchronize(st));
-    MPG_CHECK(e == 0, "fof: the neighbour walk overflowed its stack (corrupt tree?)");
     MPG_HIP(hipGetLastError());
     return ngroups;
 }

@@ -38,9 +38,10 @@ struct WalkScratch {
     DevBuf<int2> split_counts;    // [slice] {leaf entries | wrapped << 30, node entries} or {-1, 0}: overflowed
     DevBuf<int> split_ovf;        // caller indices of overflowed targets
     int split_cap = 512;          // list entries per target (multiple of 8)
-    int split_slice = 1 << 22;    // most targets per list-construction / evaluation kernel pair (2^21 -> 2^22: 113.8 -> 111.1 ms per step
-                                  // at 256^3 Zel'dovich: half as many pipeline fill / drain phases, profiles/r02b_walk_knobs.txt)
-    size_t split_bytes = 40ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes (x 2 buffers; 288 GB of HBM)
+    int split_slice = 1 << 23;    // most targets per list-construction / evaluation kernel pair (2^21 / 2^22 / 2^23: 113.8 / 110.6 /
+                                  // 106.5 ms per step at 256^3 Zel'dovich: every kernel ends with a tail in which the slowest waves
+                                  // hold the chip, and there are half as many of them each time; profiles/r02b_walk_knobs.txt)
+    size_t split_bytes = 36ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes (x 2 buffers; 288 GB of HBM)
     unsigned split_last_overflow = 0, split_last_maxlen = 0;
     bool split_overlap = true;        // build the lists of slice k+1 (second stream) while slice k is evaluated
     int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)

@@ -638,7 +638,8 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         slice = atoll(e);
     const int64_t nmax = io.ntargets < slice ? io.ntargets : slice;
     const int64_t nslices = (io.ntargets + slice - 1) / slice;
-    const bool overlap = ws.split_overlap && nslices > 1;
+    static const bool no_overlap = getenv("MPG_SPLIT_OVERLAP") && getenv("MPG_SPLIT_OVERLAP")[0] == '0'; // experiment knob
+    const bool overlap = ws.split_overlap && nslices > 1 && !no_overlap;
     const size_t lists_sz = (size_t)((nmax + 7) / 8) * 8 * (size_t)cap, counts_sz = (size_t)nmax + 8;
     ws.split_lists.reserve(lists_sz * (overlap ? 2 : 1));
     ws.split_counts.reserve(counts_sz * (overlap ? 2 : 1));

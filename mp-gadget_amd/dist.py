@@ -236,6 +236,26 @@ class DistForce:
         self.lib.mpg_dist_use_decomposition.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
         self._ck(self.lib.mpg_dist_use_decomposition(self.h, C.c_double(box), C.c_double(margin), int(La)))
 
+    def fof_fof(self, pos, mass, ids, linking_length, min_length=32, type=None, vel=None, primary=2, secondary=1 + 16 + 32):
+        """fof_fof with groups spanning ranks.  Returns (grnr int64 device tensor over the own particles with GLOBAL group numbers,
+        total number of groups, table of the groups this rank keeps as a dict of numpy arrays)."""
+        n = int(pos.shape[0])
+        par = E.FofParams(int(primary), int(secondary), float(linking_length), int(min_length))
+        grnr = torch.zeros(n, dtype=torch.int64, device=pos.device)
+        tot, here = C.c_int64(0), C.c_int64(0)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self.lib.mpg_dist_dev_fof_fof.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 7 + [C.POINTER(C.c_int64)] * 2
+        self._ck(self.lib.mpg_dist_dev_fof_fof(self.h, C.c_int64(n), p(pos), p(mass), p(type), p(ids), p(vel), C.cast(C.pointer(par), C.c_void_p), p(grnr),
+                                               C.byref(tot), C.byref(here)))
+        m = here.value
+        g = dict(MinID=np.zeros(m, np.uint64), Length=np.zeros(m, np.int32), GrNr=np.zeros(m, np.int32), LenType=np.zeros((m, 6), np.int32),
+                 Mass=np.zeros(m), MassType=np.zeros((m, 6)), CM=np.zeros((m, 3)), Vel=np.zeros((m, 3)), Jmom=np.zeros((m, 3)),
+                 Imom=np.zeros((m, 3, 3)), FirstPos=np.zeros((m, 3), np.float32))
+        out = E.FofGroupsC(*[g[k].ctypes.data for k in ("MinID", "Length", "GrNr", "LenType", "Mass", "MassType", "CM", "Vel", "Jmom", "Imom", "FirstPos")])
+        self.lib.mpg_dist_fof_groups.argtypes = [C.c_void_p, C.c_void_p]
+        self._ck(self.lib.mpg_dist_fof_groups(self.h, C.byref(out)))
+        return grnr, tot.value, g
+
     def force_tree_build(self, pos, mass):
         """mpg_dist_dev_force_tree_build alone: ghost import, local tree, global top (what the SPH loops need when no gravity step
         ran on this particle set)"""
@@ -263,6 +283,11 @@ class DistForce:
 
     def comm_device(self):
         return getattr(self.comm, "device", None) or torch.device("cuda", torch.cuda.current_device())
+
+    def stats_raw(self):
+        s = (C.c_int64 * 8)()
+        self._ck(self.lib.mpg_dist_get_stats(self.h, s))
+        return list(s)
 
     def stats(self):
         s = (C.c_int64 * 8)()

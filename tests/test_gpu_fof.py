@@ -129,3 +129,42 @@ def test_fof_edge_cases(engine, orc):
     z = torch.zeros(0, 3, dtype=torch.float64, device="cuda")
     engine.dev_bind_particles(z, torch.zeros(0, dtype=torch.float32, device="cuda"), box)
     assert engine.dev_fof_fof(torch.zeros(0, dtype=torch.int64, device="cuda"), LL, 1) == 0
+
+
+def test_fof_groups_spanning_ranks(tmp_path):
+    """fof_fof with the particles on their Peano-Hilbert owners (mpg_dist_dev_fof_fof, csrc/dist.hip): clumps up to 3000 members wide
+    enough to straddle domain boundaries, gas attached to the nearest dark matter.  1, 2 and 4 ranks (gloo, sharing this GPU) against
+    the single-GPU finder: P[].GrNr of every particle and the number of groups EQUAL; MinID / Length / LenType / GrNr of every group
+    equal; Mass, Vel, CM, Jmom, Imom to rounding (the parts of a group are added up in another order)."""
+    import os
+    import sys
+    from conftest import run_ranks
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "mgpu_fof_check.py")
+
+    def run(name, nproc, mode, port):
+        out = str(tmp_path / name)
+        env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode)
+        cmd = [sys.executable, script, out] if nproc == 1 else \
+              [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, out]
+        run_ranks(cmd, env, out)
+        return np.load(out + ".npz")
+
+    one = run("one", 1, "single", 0)
+    assert int(one["total"]) >= 60 and one["G_Length"].max() >= 1000
+    box = 100.0
+    for name, nproc, port in (("p1", 1, 0), ("p2", 2, 29611), ("p4", 4, 29612)):
+        d = run(name, nproc, "peano", port)
+        assert int(d["total"]) == int(one["total"]), name
+        assert np.array_equal(d["grnr"], one["grnr"]), name
+        for k in ("MinID", "Length", "GrNr", "LenType"):
+            assert np.array_equal(d["G_" + k].astype(np.int64), one["G_" + k].astype(np.int64)), (name, k)
+        for k in ("Mass", "MassType", "Vel"):
+            assert np.allclose(d["G_" + k], one["G_" + k], rtol=1e-12, atol=1e-12 * np.abs(one["G_" + k]).max()), (name, k)
+        dc = np.abs(d["G_CM"] - one["G_CM"])
+        assert np.minimum(dc, box - dc).max() <= 1e-11 * box, name
+        for k in ("Jmom", "Imom"):
+            assert np.allclose(d["G_" + k], one["G_" + k], rtol=1e-8, atol=1e-8 * np.abs(one["G_" + k]).max()), (name, k)
+        if nproc > 1:
+            assert int(d["rounds"]) >= 2, name           # some group did cross a boundary: a second round was needed

@@ -261,7 +261,9 @@ def test_full_size_hydro_2x128(pkg, orc, pe):
     # hydro of the sampled targets on the engine's density-stage fields of ALL gas particles
     for k in ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel"):
         getattr(A, k)[:] = g[k]
-    tr2 = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    # (hydro_active = 0: every particle's final Hsml enters the hmax of its leaf, the state update_tree_hmax_father leaves behind
+    #  after the density loop, forcetree.c:1286-1315 - this tree has not seen a density loop)
+    tr2 = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.zeros(N, np.uint8), mask=1, moments=False)
     tr2.calc_moments()
     O.sph_hydro_force(orc, tr2, dp, O.HydroParams(pe, 100.0, 0.75), A, to, active=act)
     if rel(g["hydroacc_out"][act], A.hydroacc_out[act]) > 1e-10:     # (say where: a failure at this size has to be diagnosable from the log)
