@@ -208,6 +208,8 @@ def main():
     if multi and world == 1:
         pkg.pm_slab.FORCE_COLLECTIVES = True
     if args.workload == "hydro":
+        if multi and args.mgpu == "peano":
+            return hydro_bench_peano(pkg, torch, dist, args, dev, rank, world)
         if multi:
             return hydro_bench_domain(pkg, torch, dist, args, dev, rank, world)
         return hydro_bench(pkg, torch, args, dev)
@@ -781,6 +783,86 @@ def hydro_bench(pkg, torch, args, dev):
 
 def hydro_ics(pkg, n):
     return pkg.ics.hydro_pair(n)
+
+
+def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
+    """configs[2] / [4] weak-scaled over GPUs on the reference's decomposition, everything through the library's choreography
+    (mpg_dist_*, csrc/dist.hip): domain_decompose_full + exchange (untimed), then per step gravity (PM by particle shipping, ghost
+    import, global top, walk) and the SPH loops (ghost columns along the ghost plan, density, the ghosts' fields from their owners,
+    hmax, hydro force)."""
+    n = args.n or {2: 160, 4: 200, 8: 256}.get(world, int(round(128 * world ** (1. / 3) / (4 * world))) * 4 * world)
+    nmesh = 2 * n
+    PE = 0 if args.sph == "de" else 1                        # configs[4]: pressure-entropy SPH on several GPUs
+    pos, mass, typ, box = hydro_ics(pkg, n)
+    N = len(pos)
+    f8 = dict(dtype=torch.float64, device=dev)
+    eng = pkg.Engine(dev.index or 0)
+    eng.use_torch_stream()
+    eng.set_walk_variant(args.variant)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(TreeUseBH=2)
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(PE, 100.0, 0.75)
+    df = pkg.dist.DistForce(eng, pkg.dist.TorchComm(dev))
+    share = slice((N * rank) // world, (N * (rank + 1)) // world)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a[share])).to(dev)
+    s_pos = T(pos)
+    df.domain_decompose(s_pos, box, overdecomposition=args.overdecomp)
+    o_pos, o_mass, o_typ = df.domain_exchange(s_pos, T(mass), T(typ))
+    n_own = int(o_pos.shape[0])
+    df.use_decomposition(box, max(6.0 * 1.5 * box / nmesh, 6.0 * box / n))       # margin: Rcut and the largest smoothing length
+    z1, z3 = (lambda: torch.zeros(n_own, **f8)), (lambda: torch.zeros(n_own, 3, **f8))
+    a = dict(hsml=torch.full((n_own,), 2.0 * box / n, **f8), dthsml=z1(), vel=z3(), entropy=torch.ones(n_own, **f8), density=z1(), egywtdensity=z1(),
+             dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(), hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
+    acc, prev, gravpm, pot = z3(), z3(), z3(), z1()
+    t = pkg.SphTimes()
+    t.atime, t.hubble = 0.1, 0.1
+    for i in range(47):
+        t.dloga_bin[i] = 0.01
+    state = dict(steps=0)
+
+    def step():
+        nonlocal acc, prev
+        prev, acc = acc, prev
+        df.gravity_step(o_pos, o_mass, acc, gravpm, potential=pot, prev_accel=prev if state["steps"] else None)
+        df.density(o_typ, a, t, DoEgyDensity=PE)
+        df.hydro_force(n_own, a, t)
+        state["steps"] += 1
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup + 1):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], **f8)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    el = float(dt.item())
+    out = None
+    if rank == 0:
+        st = df.stats()
+        out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
+                          "particles": N, "parallelism": "%d GPUs: particles on the owners of their Peano-Hilbert TopLeaves, choreography in the library "
+                                                         "(mpg_dist_*), collectives on RCCL" % world,
+                          "ghost_fraction_rank0": round(st["ghosts"] / max(n_own, 1), 3), "density_iterations_last": eng.sph_stats()["iterations"]}}
+    dist.barrier()
+    dist.destroy_process_group()
+    df.close()
+    eng.close()
+    if out is not None:
+        emit(out)
+    return out
 
 
 def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
