@@ -2045,7 +2045,7 @@ int mpg_dist_dev_fof_fof(mpg_dist *d, int64_t n_own, const double *d_pos, const 
     });
     std::vector<std::pair<unsigned long long, long long>> tab(all.size()); // (MinID, GrNr), then by MinID
     for(size_t k = 0; k < ord.size(); k++)
-        tab[k] = {all[ord[k]].MinID, (long long)k};
+        tab[k] = {all[ord[k]].MinID, (long long)k + 1}; // group numbers start at 1 (fof.c:1150, as fof.hip's k_fof_grnr)
     std::sort(tab.begin(), tab.end());
     d->f_total = (int64_t)all.size();
     d->f_group_grnr.assign(d->f_groups.size(), -1);

@@ -38,12 +38,15 @@ struct WalkScratch {
     DevBuf<int2> split_counts;    // [slice] {leaf entries | wrapped << 30, node entries} or {-1, 0}: overflowed
     DevBuf<int> split_ovf;        // caller indices of overflowed targets
     int split_cap = 512;          // list entries per target (multiple of 8)
-    int split_slice = 1 << 23;    // most targets per list-construction / evaluation kernel pair (2^21 / 2^22 / 2^23: 113.8 / 110.6 /
-                                  // 106.5 ms per step at 256^3 Zel'dovich: every kernel ends with a tail in which the slowest waves
-                                  // hold the chip, and there are half as many of them each time; profiles/r02b_walk_knobs.txt)
-    size_t split_bytes = 36ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes (x 2 buffers; 288 GB of HBM)
+    int split_slice = 1 << 25;    // most targets per list-construction / evaluation kernel pair.  Measured at 256^3 Zel'dovich
+                                  // (profiles/r02b_walk_knobs.txt): slices of 2^21 / 2^22 / 2^23 targets with the two kernels overlapped on
+                                  // two streams 113.8 / 110.6 / 105.9 ms per step, the same slices one after the other 104.6 (2^22) /
+                                  // 102.3 (2^23), ONE slice 101.5: every kernel ends with a tail in which its slowest waves hold the
+                                  // chip, and two kernels sharing the chip slow each other by more than their mix gains
+    size_t split_bytes = 80ull << 30; // list area (bytes) that bounds the slice: slice * cap * 4 <= split_bytes (288 GB of HBM)
     unsigned split_last_overflow = 0, split_last_maxlen = 0;
-    bool split_overlap = true;        // build the lists of slice k+1 (second stream) while slice k is evaluated
+    bool split_overlap = false;       // true: build the lists of slice k+1 on a second stream while slice k is evaluated (two list areas);
+                                      // the default of round 1, measured slower than serial slices in round 2 (see split_slice)
     int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)
     hipStream_t split_stream = nullptr;
     hipEvent_t ev_lists[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_begin = nullptr;

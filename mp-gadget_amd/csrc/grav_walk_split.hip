@@ -337,8 +337,8 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
 
 // ctl words: [0] number of overflowed targets, [1] error flag (loop guard / stack), [2] longest list seen
 // counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] group steps [4] children tested
-template <bool COUNT, bool FASTWRAP, bool O32>
-__global__ void __launch_bounds__(256, 6) k_walk_lists(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
+template <bool COUNT, bool FASTWRAP, bool O32, int BLK>
+__global__ void __launch_bounds__(256, BLK) k_walk_lists(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
                                                      int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
                                                      unsigned *__restrict__ ctl, int *__restrict__ ovf)
 {
@@ -516,8 +516,8 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
 #undef MPG_EVAL
 }
 
-template <bool POT, bool FASTWRAP, bool O32>
-__global__ void __launch_bounds__(256, MPG_EVAL_BLOCKS) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
+template <bool POT, bool FASTWRAP, bool O32, int BLK>
+__global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
                                                     const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
 {
     constexpr int ROW = POT ? 4 : 2;
@@ -625,8 +625,12 @@ int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_p
 template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
-    auto kl = k_walk_lists<COUNT, FASTWRAP, O32>;
-    auto ke = k_walk_eval<POT, FASTWRAP, O32>;
+    // resident 256-thread blocks per CU each kernel is compiled for (= waves per SIMD: 512 VGPRs / that many).  Experiment knobs
+    // MPG_LISTS_BLOCKS (6 | 8) and MPG_EVAL_BLOCKS (4 | 5 | 6); the defaults are the measured best (profiles/r02b_walk_knobs.txt)
+    static const int lists_blk = getenv("MPG_LISTS_BLOCKS") ? atoi(getenv("MPG_LISTS_BLOCKS")) : 6;
+    static const int eval_blk = getenv("MPG_EVAL_BLOCKS") ? atoi(getenv("MPG_EVAL_BLOCKS")) : MPG_EVAL_BLOCKS;
+    auto kl = lists_blk == 8 ? k_walk_lists<COUNT, FASTWRAP, O32, 8> : k_walk_lists<COUNT, FASTWRAP, O32, 6>;
+    auto ke = eval_blk == 4 ? k_walk_eval<POT, FASTWRAP, O32, 4> : (eval_blk == 5 ? k_walk_eval<POT, FASTWRAP, O32, 5> : k_walk_eval<POT, FASTWRAP, O32, 6>);
     const int cap = ws.split_cap;
     // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
     int64_t slice = (int64_t)(ws.split_bytes / ((size_t)cap * sizeof(unsigned))) / 2048 * 2048;
@@ -638,8 +642,8 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         slice = atoll(e);
     const int64_t nmax = io.ntargets < slice ? io.ntargets : slice;
     const int64_t nslices = (io.ntargets + slice - 1) / slice;
-    static const bool no_overlap = getenv("MPG_SPLIT_OVERLAP") && getenv("MPG_SPLIT_OVERLAP")[0] == '0'; // experiment knob
-    const bool overlap = ws.split_overlap && nslices > 1 && !no_overlap;
+    static const int ov_env = getenv("MPG_SPLIT_OVERLAP") ? (getenv("MPG_SPLIT_OVERLAP")[0] == '0' ? 0 : 1) : -1; // experiment knob
+    const bool overlap = (ov_env >= 0 ? ov_env != 0 : ws.split_overlap) && nslices > 1;
     const size_t lists_sz = (size_t)((nmax + 7) / 8) * 8 * (size_t)cap, counts_sz = (size_t)nmax + 8;
     ws.split_lists.reserve(lists_sz * (overlap ? 2 : 1));
     ws.split_counts.reserve(counts_sz * (overlap ? 2 : 1));

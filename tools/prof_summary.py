@@ -106,7 +106,7 @@ for var, pats in WALK_KERNELS.items():
                 ndisp[[p_ for p_ in pats if p_ in kn][0]].add(r["Dispatch_Id"])
             if ndisp:
                 # dispatches of the first kernel of the group per walk: 1 for kernels 1 and 4, ceil(N / 2^21) slices for 6
-                per_walk = int(os.environ.get("MPG_SLICES_PER_WALK", "2")) if var == "6" else 1   # 256^3 in slices of 2^23 targets
+                per_walk = int(os.environ.get("MPG_SLICES_PER_WALK", "1")) if var == "6" else 1   # 256^3 is one slice (list capacity 1024)
                 walks[name] += len(ndisp[pats[0]]) / per_walk
     if walks["FETCH_SIZE"] and walks["WRITE_SIZE"]:
         fb = 2 * 1024 * tot["FETCH_SIZE"] / walks["FETCH_SIZE"]
