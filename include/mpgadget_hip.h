@@ -612,6 +612,10 @@ int mpg_dist_fof_groups(mpg_dist *d, const mpg_fof_groups *out);
 int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *P);
 int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P);
 int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0);
+/* density() / hydro_force() as drop-in calls on the same table (after mpg_dist_force_tree_full on it): A holds HOST arrays in particle
+ * order, as for mpg_density / mpg_hydro_force (the shim gathers SphP[P[i].PI].X into them); inputs are read, outputs written */
+int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml, int DoEgyDensity);
+int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T);
 /* per-particle work of the last mpg_dist walk for the rank's own particles (device pointer, n_own floats, caller order):
  * the cost the next domain decomposition balances (mpg_dev_set_walk_cost) */
 const float *mpg_dist_walk_cost(mpg_dist *d);

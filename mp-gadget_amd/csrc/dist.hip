@@ -586,6 +586,8 @@ struct mpg_dist {
     std::vector<double> hbuf;
     std::vector<float> hbuf_f;
     int64_t o_n = -1;
+    DevBuf<double> o_sph[17]; // the double-valued fields of mpg_sph_arrays over the own particles (host SPH path)
+    DevBuf<uint8_t> o_u8[3];  // type, tb_hydro, tb_grav
 };
 
 namespace {
@@ -2114,6 +2116,167 @@ int mpg_dist_fof_groups(mpg_dist *d, const mpg_fof_groups *out)
             for(int c = 0; c < 9; c++)
                 out->Imom[9 * g + c] = r.acc[16 + c];
     }
+    API_END
+}
+
+} // extern "C"
+
+/* ---- the SPH loops as drop-in calls: the rank's table and the SPH fields in HOST arrays (what shim/sph-hip.c gathers from the
+ * slots), after mpg_dist_force_tree_full on the same table ------------------------------------------------------------------ */
+namespace {
+
+struct SphField {
+    int w;       // doubles per particle
+    bool in, out_density, out_hydro;
+};
+// the double-valued members of mpg_sph_arrays in declaration order, without the two time-bin byte arrays
+const SphField SPH_FIELDS[17] = {{1, true, true, false},   // hsml
+                                 {1, false, true, false},  // dthsml
+                                 {3, true, false, false},  // vel
+                                 {3, true, false, false},  // gacc
+                                 {3, true, false, false},  // gpm
+                                 {3, true, false, false},  // hydroacc_in
+                                 {1, true, false, false},  // entropy
+                                 {1, true, false, false},  // dtentropy_in
+                                 {1, false, true, false},  // density
+                                 {1, false, true, false},  // egywtdensity
+                                 {1, false, true, false},  // dhsmlegyfac
+                                 {1, false, true, false},  // divvel
+                                 {1, false, true, false},  // curlvel
+                                 {3, false, true, false},  // gradrho
+                                 {3, false, false, true},  // hydroacc_out
+                                 {1, false, false, true},  // dtentropy_out
+                                 {1, false, false, true}}; // maxsignalvel
+
+// pointers of the 17 double fields of a mpg_sph_arrays, in the order of SPH_FIELDS
+void sph_field_ptrs(const mpg_sph_arrays *A, const double *p[17])
+{
+    p[0] = A->hsml;
+    p[1] = A->dthsml;
+    p[2] = A->vel;
+    p[3] = A->gacc;
+    p[4] = A->gpm;
+    p[5] = A->hydroacc_in;
+    p[6] = A->entropy;
+    p[7] = A->dtentropy_in;
+    p[8] = A->density;
+    p[9] = A->egywtdensity;
+    p[10] = A->dhsmlegyfac;
+    p[11] = A->divvel;
+    p[12] = A->curlvel;
+    p[13] = A->gradrho;
+    p[14] = A->hydroacc_out;
+    p[15] = A->dtentropy_out;
+    p[16] = A->maxsignalvel;
+}
+
+// device copy of the host arrays: inputs uploaded, outputs allocated; returns the device-side struct
+mpg_sph_arrays stage_sph(mpg_dist *d, const mpg_sph_arrays *A, int64_t n, bool upload)
+{
+    hipStream_t st = d->eng->stream;
+    const double *hp[17];
+    sph_field_ptrs(A, hp);
+    double *dp[17];
+    for(int k = 0; k < 17; k++) {
+        dp[k] = nullptr;
+        if(!hp[k])
+            continue;
+        d->o_sph[k].reserve((size_t)SPH_FIELDS[k].w * n + 3);
+        dp[k] = d->o_sph[k].p;
+        if(upload && SPH_FIELDS[k].in && n > 0)
+            MPG_HIP(hipMemcpyAsync(dp[k], hp[k], (size_t)SPH_FIELDS[k].w * n * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    const uint8_t *hb[2] = {A->tb_hydro, A->tb_grav};
+    uint8_t *db[2] = {nullptr, nullptr};
+    for(int k = 0; k < 2; k++)
+        if(hb[k]) {
+            d->o_u8[1 + k].reserve((size_t)n + 1);
+            db[k] = d->o_u8[1 + k].p;
+            if(upload && n > 0)
+                MPG_HIP(hipMemcpyAsync(db[k], hb[k], (size_t)n, hipMemcpyHostToDevice, st));
+        }
+    sync(d);
+    mpg_sph_arrays D;
+    memset(&D, 0, sizeof(D));
+    D.hsml = dp[0];
+    D.dthsml = dp[1];
+    D.vel = dp[2];
+    D.gacc = dp[3];
+    D.gpm = dp[4];
+    D.hydroacc_in = dp[5];
+    D.tb_hydro = db[0];
+    D.tb_grav = db[1];
+    D.entropy = dp[6];
+    D.dtentropy_in = dp[7];
+    D.density = dp[8];
+    D.egywtdensity = dp[9];
+    D.dhsmlegyfac = dp[10];
+    D.divvel = dp[11];
+    D.curlvel = dp[12];
+    D.gradrho = dp[13];
+    D.hydroacc_out = dp[14];
+    D.dtentropy_out = dp[15];
+    D.maxsignalvel = dp[16];
+    return D;
+}
+
+void download_sph(mpg_dist *d, const mpg_sph_arrays *A, int64_t n, bool hydro)
+{
+    hipStream_t st = d->eng->stream;
+    const double *hp[17];
+    sph_field_ptrs(A, hp);
+    for(int k = 0; k < 17; k++) {
+        const bool want = hydro ? SPH_FIELDS[k].out_hydro : SPH_FIELDS[k].out_density;
+        if(want && hp[k] && n > 0)
+            MPG_HIP(hipMemcpyAsync((double *)hp[k], d->o_sph[k].p, (size_t)SPH_FIELDS[k].w * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    sync(d);
+}
+
+// P[].Type (garbage has been refused by mpg_dist_force_tree_full) onto the device
+const uint8_t *stage_types(mpg_dist *d, const mpg_particle_view *P)
+{
+    const int64_t n = P->n;
+    std::vector<uint8_t> ty((size_t)n + 1);
+    const mpg_particle_view V = *P;
+    const char *b = (const char *)P->base;
+    uint8_t *t = ty.data();
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t i = lo; i < hi; i++)
+            t[i] = V.off_type >= 0 ? (uint8_t)(*(const uint8_t *)(b + i * V.stride + V.off_type) & 7) : (uint8_t)1;
+    });
+    d->o_u8[0].reserve((size_t)n + 1);
+    if(n > 0)
+        MPG_HIP(hipMemcpy(d->o_u8[0].p, ty.data(), (size_t)n, hipMemcpyHostToDevice));
+    return d->o_u8[0].p;
+}
+
+} // namespace
+
+extern "C" {
+
+int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml, int DoEgyDensity)
+{
+    API_BEGIN
+    MPG_CHECK(d && P && A && T, "null argument");
+    MPG_CHECK(d->o_n == P->n && d->n_own_tree == P->n, "mpg_dist_density: call mpg_dist_force_tree_full on this table first");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    const uint8_t *ty = stage_types(d, P);
+    const mpg_sph_arrays D = stage_sph(d, A, P->n, true);
+    MPG_CHECK(mpg_dist_dev_density(d, P->n, ty, &D, T, update_hsml, DoEgyDensity) == 0, mpg_last_error());
+    download_sph(d, A, P->n, false);
+    API_END
+}
+
+int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T)
+{
+    API_BEGIN
+    MPG_CHECK(d && P && A && T, "null argument");
+    MPG_CHECK(d->sph_n_own == P->n, "mpg_dist_hydro_force: call mpg_dist_density on this table first");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    const mpg_sph_arrays D = stage_sph(d, A, P->n, false); // (the inputs are the library's from the density call)
+    MPG_CHECK(mpg_dist_dev_hydro_force(d, P->n, &D, T) == 0, mpg_last_error());
+    download_sph(d, A, P->n, true);
     API_END
 }
 

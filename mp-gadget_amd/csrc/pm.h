@@ -16,6 +16,7 @@ struct PMesh {
     DevBuf<double> real;    // Nmesh^3
     DevBuf<double> rho_k;   // 2 * Nmesh^2 (Nmesh/2+1): potential in Fourier space after the transfer
     DevBuf<double> work_k;  // same size: per-component work array (Z2D overwrites its input)
+    DevBuf<double> grad_z;  // Nmesh^3: the third force mesh of the one-pass gradient (the other two live in work_k / rho_k)
     DevBuf<double> invsinc2, difffac;
     // deposit: 0 not tuned yet, 1 plain atomics, 2 cell-sorted with wave-aggregated atomics (pm.hip)
     struct DepositState {

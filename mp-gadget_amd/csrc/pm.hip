@@ -407,6 +407,33 @@ __global__ void __launch_bounds__(256) k_gradient_axis(int nmesh, int nplanes, i
     out[ip] = -((2.0 / 3.0) * (p1 - m1) - (1.0 / 12.0) * (p2 - m2)) * scale;
 }
 
+// The three force components in ONE pass over the potential (single-GPU form: x wraps periodically): the twelve neighbours of a
+// cell are read once (the z row from registers of neighbouring lanes' cache lines, the y and x neighbours from L2), three meshes
+// are written - 4.3 GB at Nmesh = 512 instead of the 6.4 GB of three k_gradient_axis passes.  Same arithmetic per component.
+__global__ void __launch_bounds__(256) k_gradient3(int nmesh, double scale, const double *__restrict__ phi, double *__restrict__ gx,
+                                                   double *__restrict__ gy, double *__restrict__ gz)
+{
+    const size_t total = (size_t)nmesh * nmesh * nmesh;
+    const size_t ip = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(ip >= total)
+        return;
+    const int iz = (int)(ip % nmesh);
+    const size_t t = ip / nmesh;
+    const int iy = (int)(t % nmesh);
+    const int ix = (int)(t / nmesh);
+    const size_t plane = (size_t)nmesh * nmesh;
+    const size_t row = (size_t)iy * nmesh + iz;
+    const double *px = phi + row;
+    const double *py = phi + (size_t)ix * plane + iz;
+    const double *pz = phi + (size_t)ix * plane + (size_t)iy * nmesh;
+    const double c1 = 2.0 / 3.0, c2 = 1.0 / 12.0;
+    gx[ip] = -(c1 * (px[(size_t)wrap(ix + 1, nmesh) * plane] - px[(size_t)wrap(ix - 1, nmesh) * plane]) -
+               c2 * (px[(size_t)wrap(ix + 2, nmesh) * plane] - px[(size_t)wrap(ix - 2, nmesh) * plane])) * scale;
+    gy[ip] = -(c1 * (py[(size_t)wrap(iy + 1, nmesh) * nmesh] - py[(size_t)wrap(iy - 1, nmesh) * nmesh]) -
+               c2 * (py[(size_t)wrap(iy + 2, nmesh) * nmesh] - py[(size_t)wrap(iy - 2, nmesh) * nmesh])) * scale;
+    gz[ip] = -(c1 * (pz[wrap(iz + 1, nmesh)] - pz[wrap(iz - 1, nmesh)]) - c2 * (pz[wrap(iz + 2, nmesh)] - pz[wrap(iz - 2, nmesh)])) * scale;
+}
+
 static inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
 void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream_t st)
@@ -475,6 +502,7 @@ void PMesh::destroy()
     real.release();
     rho_k.release();
     work_k.release();
+    grad_z.release();
     nmesh = 0;
 }
 
@@ -596,19 +624,36 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
             tm->lap(st, &t);
             t_ro += t;
         }
-        for(int axis = 0; axis < 3; axis++) {
-            hipLaunchKernelGGL(k_gradient_axis, dim3(nblk(nreal)), dim3(256), 0, st, nmesh, nmesh, axis, (double)nmesh / box, real.p, work_k.p, 0);
+        static const bool one_pass = !(getenv("MPG_PM_GRADIENT_PASSES") && getenv("MPG_PM_GRADIENT_PASSES")[0] == '3');
+        if(one_pass) { // the Fourier buffers are free now (Z2D consumed rho_k): they hold two of the three force meshes
+            grad_z.reserve(nreal);
+            double *g[3] = {work_k.p, rho_k.p, grad_z.p};
+            hipLaunchKernelGGL(k_gradient3, dim3(nblk(nreal)), dim3(256), 0, st, nmesh, (double)nmesh / box, real.p, g[0], g[1], g[2]);
             if(tm) {
                 tm->lap(st, &t);
                 t_tr += t;
             }
-            if(n > 0)
-                hipLaunchKernelGGL(k_cic_readout, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, work_k.p, axis, d_gravpm);
+            for(int axis = 0; axis < 3 && n > 0; axis++)
+                hipLaunchKernelGGL(k_cic_readout, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, g[axis], axis, d_gravpm);
             if(tm) {
                 tm->lap(st, &t);
                 t_ro += t;
             }
         }
+        else
+            for(int axis = 0; axis < 3; axis++) {
+                hipLaunchKernelGGL(k_gradient_axis, dim3(nblk(nreal)), dim3(256), 0, st, nmesh, nmesh, axis, (double)nmesh / box, real.p, work_k.p, 0);
+                if(tm) {
+                    tm->lap(st, &t);
+                    t_tr += t;
+                }
+                if(n > 0)
+                    hipLaunchKernelGGL(k_cic_readout, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, work_k.p, axis, d_gravpm);
+                if(tm) {
+                    tm->lap(st, &t);
+                    t_ro += t;
+                }
+            }
     }
     else
         for(int f = 0; f < 4; f++) {

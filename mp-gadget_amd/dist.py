@@ -271,6 +271,21 @@ class DistForce:
         a = self.eng._sph_arrays(arrays)
         self._ck(self.lib.mpg_dist_dev_hydro_force(self.h, C.c_int64(n_own), C.byref(a), C.byref(times)))
 
+    # drop-in forms on the rank's particle_data records (numpy, engine.PARTICLE_DTYPE) and host SPH arrays: what shim/sph-hip.c calls
+    def host_force_tree_full(self, P):
+        v = self.eng._view(P)
+        self._ck(self.lib.mpg_dist_force_tree_full(self.h, C.byref(v)))
+
+    def host_density(self, P, arrays, times, update_hsml=1, DoEgyDensity=0):
+        v = self.eng._view(P)
+        a = self.eng._sph_host_arrays(arrays)
+        self._ck(self.lib.mpg_dist_density(self.h, C.byref(v), C.byref(a), C.byref(times), int(update_hsml), int(DoEgyDensity)))
+
+    def host_hydro_force(self, P, arrays, times):
+        v = self.eng._view(P)
+        a = self.eng._sph_host_arrays(arrays)
+        self._ck(self.lib.mpg_dist_hydro_force(self.h, C.byref(v), C.byref(a), C.byref(times)))
+
     def walk_cost(self, n_own):
         """per-particle work of the last walk for the rank's own particles (float32 device tensor, a copy): feed it to
         PeanoDomain.decompose(cost=...)"""

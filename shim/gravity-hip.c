@@ -62,6 +62,7 @@ static mpg_engine *eng(void)
 }
 
 mpg_engine *mpg_shim_engine(void) { return eng(); } /* sph-hip.c shares the rank's engine */
+mpg_dist *mpg_shim_dist(void) { return eng(), D; }  /* ... and its multi-rank state (NULL with one rank) */
 
 static mpg_particle_view view(void)
 {

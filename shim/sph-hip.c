@@ -9,8 +9,9 @@
  * slots, SphP[P[i].PI] (slotsmanager.h:93-129); the C-ABI takes plain arrays in particle order (mpg_sph_arrays), so this file
  * gathers the slot fields before the call and scatters the results after it.  The time-dependent scalars the reference derives
  * before its loops come from the reference's own functions and go over as one mpg_sph_times.
- * Compiled inside the reference tree (see gravity-hip.c).  Single rank per GPU; with NTask > 1 the distributed SPH path of the
- * engine (mp-gadget_amd/domain.py) is driven from Python and has no C entry point yet. */
+ * Compiled inside the reference tree (see gravity-hip.c).  One rank per GPU.  NTask > 1: mpg_dist_density / mpg_dist_hydro_force on the
+ * table gravity-hip.c last handed to mpg_dist_force_tree_full (ghost columns travel inside the library); that path
+ * takes every own gas particle as active, so it serves the steps on which all bins are active and stops with a message otherwise. */
 #include <mpi.h>
 #include <math.h>
 #include <string.h>
@@ -28,6 +29,17 @@
 #include <mpgadget_hip.h>
 
 extern mpg_engine *mpg_shim_engine(void); /* gravity-hip.c: the rank's engine */
+extern mpg_dist *mpg_shim_dist(void);     /* gravity-hip.c: the rank's multi-rank state, NULL with one rank */
+
+/* the multi-rank SPH loops treat all own gas as active (mpgadget_hip.h, mpg_dist_density) */
+static void need_full_step(const ActiveParticles *act, int BlackHoleOn)
+{
+    if(act->ActiveParticle && act->NumActiveParticle != PartManager->NumPart)
+        endrun(5, "mpgadget_hip: the multi-rank SPH loops need a step with every particle active (%ld of %ld are)\n",
+               (long)act->NumActiveParticle, (long)PartManager->NumPart);
+    if(BlackHoleOn)
+        endrun(5, "mpgadget_hip: the multi-rank density loop does not serve black holes\n");
+}
 
 static void ck(int rc)
 {
@@ -167,8 +179,13 @@ void density(const ActiveParticles *act, int update_hsml, int DoEgyDensity, int 
     gather(&H);
     fill_times(&t, &times, CP, 0);
     walltime_measure("/SPH/Density/Init");
-    ck(mpg_density(mpg_shim_engine(), &v, tree->BoxSize, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml, DoEgyDensity,
-                   BlackHoleOn));
+    if(mpg_shim_dist()) {
+        need_full_step(act, BlackHoleOn);
+        ck(mpg_dist_density(mpg_shim_dist(), &v, &H.A, &t, update_hsml, DoEgyDensity));
+    }
+    else
+        ck(mpg_density(mpg_shim_engine(), &v, tree->BoxSize, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml,
+                       DoEgyDensity, BlackHoleOn));
     #pragma omp parallel for
     for(i = 0; i < PartManager->NumPart; i++) {
         if(P[i].Type != 0 && P[i].Type != 5)
@@ -218,7 +235,12 @@ void hydro_force(const ActiveParticles *act, const double atime, struct sph_pred
     gather(&H);
     fill_times(&t, &times, CP, atime);
     walltime_measure("/SPH/Hydro/Init");
-    ck(mpg_hydro_force(mpg_shim_engine(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle));
+    if(mpg_shim_dist()) {
+        need_full_step(act, 0);
+        ck(mpg_dist_hydro_force(mpg_shim_dist(), &v, &H.A, &t));
+    }
+    else
+        ck(mpg_hydro_force(mpg_shim_engine(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle));
     #pragma omp parallel for
     for(i = 0; i < PartManager->NumPart; i++) {
         int k;

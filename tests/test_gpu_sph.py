@@ -125,8 +125,9 @@ def test_sph_peano_ranks_match_one(tmp_path):
     Peano-Hilbert decomposition: 1 rank (no communicator), 2 and 4 ranks (gloo, the mpg_comm callbacks) against one GPU."""
     one = _run_hydro(tmp_path, "one.npz", 1, "single", 0)
     gas = one["typ"] == 0
-    for name, nproc, port in (("p1.npz", 1, 0), ("p2.npz", 2, 29605), ("p4.npz", 4, 29606)):
-        d = _run_hydro(tmp_path, name, nproc, "peano", port)
+    for name, nproc, port, host in (("p1.npz", 1, 0, False), ("p2.npz", 2, 29605, False), ("p4.npz", 4, 29606, False),
+                                    ("h2.npz", 2, 29607, True)):   # h2: the host drop-in forms (mpg_dist_density / _hydro_force)
+        d = _run_hydro(tmp_path, name, nproc, "peano", port, host)
         same = assert_hsml_parity(d["hsml"][gas], one["hsml"][gas], 113.1)
         g = np.flatnonzero(gas)[same]
         for k in ("density", "divvel", "curlvel", "dhsmlegyfac", "hydroacc_out", "dtentropy_out"):
@@ -357,13 +358,15 @@ def test_host_pointer_sph_path(pkg, orc):
     eng.close()
 
 
-def _run_hydro(tmp_path, name, nproc, mode, port):
+def _run_hydro(tmp_path, name, nproc, mode, port, host=False):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / name)
     env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode)
+    if host:
+        env["MPG_SPH_HOST"] = "1"
     script = os.path.join(root, "tools", "mgpu_hydro_check.py")
     if nproc == 1:
         cmd = [sys.executable, script, out, "24"]

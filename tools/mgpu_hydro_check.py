@@ -78,9 +78,18 @@ elif mode == "peano":
     df = pkg.dist.DistForce(eng, comm)
     df.set_domain(dom, 6.0 * box / n)
     a = arrays(n_own, o_hsml.contiguous(), o_vel.contiguous(), o_ent.contiguous())
-    df.force_tree_build(o_pos, o_mass)
-    df.density(o_typ.contiguous(), a, t)
-    df.hydro_force(n_own, a, t)
+    if os.environ.get("MPG_SPH_HOST"):
+        # the drop-in forms: the rank's particle_data records and host arrays, as shim/sph-hip.c hands them over
+        Prec = pkg.make_particles(o_pos.cpu().numpy(), o_mass.cpu().numpy(), type=o_typ.cpu().numpy())
+        ha = {k: np.ascontiguousarray(v.cpu().numpy()) for k, v in a.items()}
+        df.host_force_tree_full(Prec)
+        df.host_density(Prec, ha, t)
+        df.host_hydro_force(Prec, ha, t)
+        a = {k: torch.from_numpy(v).to(dev) for k, v in ha.items()}
+    else:
+        df.force_tree_build(o_pos, o_mass)
+        df.density(o_typ.contiguous(), a, t)
+        df.hydro_force(n_own, a, t)
     res = {}
     for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel"):
         full = torch.zeros((N,) + tuple(a[k].shape[1:]), **f8)
