@@ -436,6 +436,307 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists(const TreeView tv, cons
     }
 }
 
+// ---- list construction for PAIRS of targets --------------------------------------------------------------------------------
+// The two targets of a pair are neighbours in tree order (leaf-mates, mostly), so their walks open almost the same nodes.  A group
+// of 8 lanes walks the UNION of the two walks: a stack entry carries a 2-bit mask of the targets that reached the node, lane s
+// loads child s once and applies the reference's tests to it for both targets, a child is pushed with the mask of the targets
+// that open it.  Restricted to one target the union walk visits that target's nodes in the order its own walk would (a depth-first
+// walk with a fixed child order), so each target's two lists are entry for entry what k_walk_lists writes.  What is shared per step:
+// the stack, the range decode, the three node loads and their address arithmetic, the loop control, and the four node-only
+// products of the tests; what is per target: 21 fp64 instructions and the two list appends.
+//
+// the reference's tests for one node and one target (shall_we_discard_node / shall_we_open_node, gravshort-tree.c:198-241);
+// MODE as in walk_target; special: the root or one of its children (exact images for both the centre and the centre of mass)
+template <int MODE>
+__device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &g, const Src4 &mom, const bool special, const double eff,
+                                           const double l2, const double inside, const double ml2, const double px, const double py,
+                                           const double pz, const double aold, bool &discard, bool &open, bool &wr)
+{
+    double dx, dy, dz, cdx, cdy, cdz;
+    wr = false;
+    if(MODE == 0) {
+        cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
+        cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
+        cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+        dx = nearest_img(mom.x - px, gp.box, gp.invbox);
+        dy = nearest_img(mom.y - py, gp.box, gp.invbox);
+        dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
+    }
+    else {
+        if(MODE == 1) {
+            const double kx = rint((g.cx - px) * gp.invbox);
+            const double ky = rint((g.cy - py) * gp.invbox);
+            const double kz = rint((g.cz - pz) * gp.invbox);
+            const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
+            cdx = fabs(g.cx - qx);
+            cdy = fabs(g.cy - qy);
+            cdz = fabs(g.cz - qz);
+            dx = mom.x - qx;
+            dy = mom.y - qy;
+            dz = mom.z - qz;
+            wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
+        }
+        else {
+            cdx = fabs(g.cx - px);
+            cdy = fabs(g.cy - py);
+            cdz = fabs(g.cz - pz);
+            dx = mom.x - px;
+            dy = mom.y - py;
+            dz = mom.z - pz;
+        }
+        if(special) { // (see walk_target)
+            const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
+            dx = fma(-jx, gp.box, mom.x - px);
+            dy = fma(-jy, gp.box, mom.y - py);
+            dz = fma(-jz, gp.box, mom.z - pz);
+            wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
+            if(MODE == 2) {
+                cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
+                cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
+                cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+            }
+        }
+    }
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
+    open = ((!gp.use_bh) && (ml2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cdx < inside && cdy < inside && cdz < inside);
+}
+
+// state of one target of a pair (group-uniform except wrap_lane)
+struct PairTarget {
+    double px, py, pz, aold;
+    unsigned off;  // entry offset of the target's interleaved lists from the wave's list base: chunk half * cap * 8 + slot * 8
+    int nleaf, nnode;
+    unsigned nsteps, c_pp, c_vis, c_used;
+    bool wrap_lane, wrapped;
+};
+
+// stack entry: first child << 5 | (children - 1) << 2 | mask of the targets (needs nnodes < 2^27: checked by the launcher)
+template <bool COUNT, int MODE, bool O32>
+__device__ __forceinline__ bool walk_pair(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ stack,
+                                          const int cap, const int lane, const int s, const int gshift, const unsigned live0, PairTarget &A,
+                                          PairTarget &B, unsigned &overflowed, const unsigned guard_max, unsigned *__restrict__ ctl, unsigned &st_a,
+                                          unsigned &st_al)
+{
+    const unsigned below = (1u << s) - 1u;
+    unsigned live = live0; // targets still walking (bit 0: A, bit 1: B)
+    int sp = 0;
+    if(live) {
+        if(s == 0)
+            stack[0] = live; // the root: first 0, one "child"
+        sp = 1;
+    }
+    unsigned guard = 0;
+    bool err = false;
+    for(;;) {
+        const bool can = sp > 0;
+        if(!any_lane(can))
+            break;
+        if(++guard > guard_max || any_lane(sp + 8 > STK)) {
+            err = true;
+            break;
+        }
+        const unsigned range = can ? stack[sp - 1] : 0u;
+        unsigned m2 = range & live; // (live < 4)
+        // a target whose step might not fit its lists goes to the fallback kernel (the test k_walk_lists makes before each of a
+        // target's steps); its mate walks on, and the entries it leaves on the stack alone are popped unused
+        const unsigned ov = (((A.nleaf + A.nnode + 8 > cap) ? 1u : 0u) | ((B.nleaf + B.nnode + 8 > cap) ? 2u : 0u)) & m2;
+        overflowed |= ov;
+        live &= ~ov;
+        m2 &= ~ov;
+        const int nch = m2 ? (int)((range >> 2) & 7u) + 1 : 0;
+        const bool mine = s < nch;
+        const unsigned my = mine ? (range >> 5) + (unsigned)s : 0u;
+        const NodeGeo g = ld<O32>(tv.geoB, my);
+        const Src4 mom = ld<O32>(tv.momB, my);
+        const NodeLinkB lk = ld<O32>(tv.linkB, my);
+        A.nsteps += m2 & 1u;
+        B.nsteps += m2 >> 1;
+        const double eff = fma(0.5, g.len, gp.rcut);
+        const double l2 = g.len * g.len;
+        const double inside = 0.6 * g.len;
+        const double ml2 = mom.m * l2;
+        const bool special = MODE != 0 && mine && my <= 8u;
+        bool dA, oA, wA, dB, oB, wB;
+        node_tests<MODE>(gp, g, mom, special, eff, l2, inside, ml2, A.px, A.py, A.pz, A.aold, dA, oA, wA);
+        node_tests<MODE>(gp, g, mom, special, eff, l2, inside, ml2, B.px, B.py, B.pz, B.aold, dB, oB, wB);
+        const bool keepA = mine && (m2 & 1u) && !dA, keepB = mine && (m2 & 2u) && !dB;
+        const bool isleaf = lk.pcount > 0, isint = lk.pcount <= 0 && lk.nchild > 0;
+        const bool nodeA = keepA && !oA, nodeB = keepB && !oB;
+        const bool leafA = keepA && oA && isleaf, leafB = keepB && oB && isleaf;
+        const unsigned pushm = ((keepA && oA && isint) ? 1u : 0u) | ((keepB && oB && isint) ? 2u : 0u);
+        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+        const unsigned gm_leafA = (unsigned)((__builtin_amdgcn_ballot_w64(leafA) >> gshift) & 0xffull);
+        const unsigned gm_leafB = (unsigned)((__builtin_amdgcn_ballot_w64(leafB) >> gshift) & 0xffull);
+        const unsigned gm_nodeA = (unsigned)((__builtin_amdgcn_ballot_w64(nodeA) >> gshift) & 0xffull);
+        const unsigned gm_nodeB = (unsigned)((__builtin_amdgcn_ballot_w64(nodeB) >> gshift) & 0xffull);
+        const unsigned gm_push = (unsigned)((__builtin_amdgcn_ballot_w64(pushm != 0) >> gshift) & 0xffull);
+        if(leafA) {
+            const unsigned e = (unsigned)(A.nleaf + __popc(gm_leafA & below));
+            st32(Lw, A.off + ((e >> 3) << 6) + (e & 7u), ent_val);
+        }
+        if(leafB) {
+            const unsigned e = (unsigned)(B.nleaf + __popc(gm_leafB & below));
+            st32(Lw, B.off + ((e >> 3) << 6) + (e & 7u), ent_val);
+        }
+        if(nodeA) {
+            const unsigned e = (unsigned)(cap - 1 - (A.nnode + __popc(gm_nodeA & below)));
+            st32(Lw, A.off + ((e >> 3) << 6) + (e & 7u), my);
+        }
+        if(nodeB) {
+            const unsigned e = (unsigned)(cap - 1 - (B.nnode + __popc(gm_nodeB & below)));
+            st32(Lw, B.off + ((e >> 3) << 6) + (e & 7u), my);
+        }
+        if(pushm)
+            stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 5) | ((unsigned)(lk.nchild - 1) << 2) | pushm;
+        A.nleaf += __popc(gm_leafA);
+        B.nleaf += __popc(gm_leafB);
+        A.nnode += __popc(gm_nodeA);
+        B.nnode += __popc(gm_nodeB);
+        sp += __popc(gm_push) - (can ? 1 : 0);
+        if(MODE != 0) {
+            A.wrap_lane = A.wrap_lane || (wA && (leafA || nodeA));
+            B.wrap_lane = B.wrap_lane || (wB && (leafB || nodeB));
+        }
+        if(COUNT) {
+            A.c_vis += (mine && (m2 & 1u)) ? 1u : 0u;
+            B.c_vis += (mine && (m2 & 2u)) ? 1u : 0u;
+            A.c_used += nodeA ? 1u : 0u;
+            B.c_used += nodeB ? 1u : 0u;
+            A.c_pp += leafA ? (unsigned)lk.pcount : 0u;
+            B.c_pp += leafB ? (unsigned)lk.pcount : 0u;
+            if(m2 && s == 0) {
+                st_a++;
+                st_al += nch;
+            }
+        }
+    }
+    if(err) {
+        if(lane == 0)
+            atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
+        return false;
+    }
+    if(MODE != 0) {
+        A.wrapped = ((__builtin_amdgcn_ballot_w64(A.wrap_lane) >> gshift) & 0xffull) != 0;
+        B.wrapped = ((__builtin_amdgcn_ballot_w64(B.wrap_lane) >> gshift) & 0xffull) != 0;
+    }
+    return true;
+}
+
+// one wave = 16 consecutive targets (two chunks of the list layout k_walk_eval reads): group g walks targets 2g and 2g + 1 of them
+template <bool COUNT, bool FASTWRAP, bool O32, int BLK>
+__global__ void __launch_bounds__(256, BLK) k_walk_lists2(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
+                                                      int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
+                                                      unsigned *__restrict__ ctl, int *__restrict__ ovf)
+{
+    __shared__ unsigned s_stack[4 * 8 * STK];
+    set_wave_prio(io.list_prio);
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, s = lane & 7;
+    const int gshift = grp * 8;
+    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * STK;
+    const unsigned nunits = (unsigned)((nslots + 15) / 16);
+    const ChunkIter it(nunits);
+    const unsigned guard_max = (unsigned)min((long long)(64ll * (tv.nnodes + 1024)), 0x7fffffffll);
+    const double face = gp.rcut + 0.002 * gp.box;
+    unsigned n_pp = 0, n_vis = 0, n_used = 0, st_a = 0, st_al = 0;
+
+    for(unsigned unit = it.lo + it.first; unit < it.hi; unit += it.stride) {
+        PairTarget T[2];
+        int ci[2];
+        unsigned live = 0;
+        bool near_face = false;
+        const int64_t rel0 = (int64_t)unit * 16 + 2 * grp;
+#pragma unroll
+        for(int k = 0; k < 2; k++) {
+            PairTarget &t = T[k];
+            const int64_t rel = rel0 + k;
+            t.px = t.py = t.pz = t.aold = 0;
+            t.nleaf = t.nnode = 0;
+            t.nsteps = t.c_pp = t.c_vis = t.c_used = 0;
+            t.wrap_lane = t.wrapped = false;
+            t.off = (unsigned)(grp >> 2) * (unsigned)cap * 8u + (unsigned)(((2 * grp + k) & 7) * 8);
+            ci[k] = -1;
+            if(rel < nslots) {
+                live |= 1u << k;
+                const int64_t slot = slot0 + rel;
+                const int c = io.targets ? io.targets[slot] : tv.order[slot];
+                ci[k] = c;
+                t.px = io.pos[3 * (int64_t)c + 0];
+                t.py = io.pos[3 * (int64_t)c + 1];
+                t.pz = io.pos[3 * (int64_t)c + 2];
+                double old = 0;
+                if(io.oldacc)
+                    old = io.oldacc[c];
+                else if(io.prev_accel) { // grav_get_abs_accel, gravshort.h:70-80
+                    double s2 = 0;
+                    for(int j = 0; j < 3; j++) {
+                        const double a = io.prev_accel[3 * (int64_t)c + j] + (io.gravpm ? io.gravpm[3 * (int64_t)c + j] : 0.0);
+                        s2 += a * a;
+                    }
+                    old = sqrt(s2) / gp.G;
+                }
+                t.aold = gp.errtol * old;
+                near_face = near_face || fmin(fmin(t.px, t.py), t.pz) < face || fmax(fmax(t.px, t.py), t.pz) > gp.box - face;
+            }
+        }
+        unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)unit) * (size_t)cap * 16;
+        unsigned overflowed = 0;
+        bool ok;
+        if(FASTWRAP) {
+            if(!any_lane(near_face))
+                ok = walk_pair<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, live, T[0], T[1], overflowed, guard_max, ctl, st_a, st_al);
+            else
+                ok = walk_pair<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, live, T[0], T[1], overflowed, guard_max, ctl, st_a, st_al);
+        }
+        else
+            ok = walk_pair<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, live, T[0], T[1], overflowed, guard_max, ctl, st_a, st_al);
+        if(!ok)
+            return;
+#pragma unroll
+        for(int k = 0; k < 2; k++) {
+            const PairTarget &t = T[k];
+            const bool valid = (live >> k) & 1u, overflow = (overflowed >> k) & 1u;
+            const int64_t rel = rel0 + k;
+            if(valid && s == 0) {
+                if(io.cost)
+                    io.cost[ci[k]] = (float)(8 * (overflow ? cap : t.nleaf) + t.nnode + 8 * (int)t.nsteps);
+                if(overflow) {
+                    counts[rel] = make_int2(-1, 0);
+                    ovf[atomicAdd(&ctl[0], 1u)] = ci[k];
+                }
+                else {
+                    counts[rel] = make_int2(t.nleaf | (t.wrapped ? (1 << 30) : 0), t.nnode);
+                    if((unsigned)(t.nleaf + t.nnode) > ctl[2])
+                        atomicMax(&ctl[2], (unsigned)(t.nleaf + t.nnode));
+                }
+            }
+            if(COUNT && !overflow) {
+                n_pp += t.c_pp;
+                n_vis += t.c_vis;
+                n_used += t.c_used;
+            }
+        }
+    }
+    if(COUNT) {
+        unsigned long long c0 = n_pp, c1 = n_vis, c2 = n_used, c3 = st_a, c4 = st_al;
+        for(int off = 32; off > 0; off >>= 1) {
+            c0 += __shfl_down(c0, off);
+            c1 += __shfl_down(c1, off);
+            c2 += __shfl_down(c2, off);
+            c3 += __shfl_down(c3, off);
+            c4 += __shfl_down(c4, off);
+        }
+        if(lane == 0) {
+            atomicAdd(&io.counters[0], c0);
+            atomicAdd(&io.counters[1], c1);
+            atomicAdd(&io.counters[2], c2);
+            atomicAdd(&io.counters[3], c3);
+            atomicAdd(&io.counters[4], c4);
+        }
+    }
+}
+
 // The two list loops of one group (8 lanes, lane s <-> source s of a leaf entry / entry r0 + s of the node list).
 // WRAP: take NEAREST() per pair (partmanager.h:99); otherwise plain differences (bit-identical where no image is wrapped).
 //
@@ -627,9 +928,16 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
 {
     // resident 256-thread blocks per CU each kernel is compiled for (= waves per SIMD: 512 VGPRs / that many).  Experiment knobs
     // MPG_LISTS_BLOCKS (6 | 8) and MPG_EVAL_BLOCKS (4 | 5 | 6); the defaults are the measured best (profiles/r02b_walk_knobs.txt)
-    static const int lists_blk = getenv("MPG_LISTS_BLOCKS") ? atoi(getenv("MPG_LISTS_BLOCKS")) : 6;
+    static const int lists_blk_env = getenv("MPG_LISTS_BLOCKS") ? atoi(getenv("MPG_LISTS_BLOCKS")) : 0;
     static const int eval_blk = getenv("MPG_EVAL_BLOCKS") ? atoi(getenv("MPG_EVAL_BLOCKS")) : MPG_EVAL_BLOCKS;
-    auto kl = lists_blk == 8 ? k_walk_lists<COUNT, FASTWRAP, O32, 8> : k_walk_lists<COUNT, FASTWRAP, O32, 6>;
+    // MPG_LISTS_PAIR: 0 one target per group of 8 lanes (k_walk_lists), 1 two (k_walk_lists2; its stack entries hold 27-bit node indices)
+    static const int pair_env = getenv("MPG_LISTS_PAIR") ? atoi(getenv("MPG_LISTS_PAIR")) : 1;
+    const bool pair = pair_env != 0 && tv.nnodes < (1ll << 27);
+    const int lists_blk = lists_blk_env ? lists_blk_env : (pair ? 4 : 6); // (the pair kernel: 98 VGPRs without spills = 5 waves per SIMD)
+    auto kl = pair ? (lists_blk == 4   ? k_walk_lists2<COUNT, FASTWRAP, O32, 4>
+                      : lists_blk == 5 ? k_walk_lists2<COUNT, FASTWRAP, O32, 5>
+                                       : k_walk_lists2<COUNT, FASTWRAP, O32, 6>)
+                   : (lists_blk == 8 ? k_walk_lists<COUNT, FASTWRAP, O32, 8> : k_walk_lists<COUNT, FASTWRAP, O32, 6>);
     auto ke = eval_blk == 4 ? k_walk_eval<POT, FASTWRAP, O32, 4> : (eval_blk == 5 ? k_walk_eval<POT, FASTWRAP, O32, 5> : k_walk_eval<POT, FASTWRAP, O32, 6>);
     const int cap = ws.split_cap;
     // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
@@ -644,7 +952,7 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
     const int64_t nslices = (io.ntargets + slice - 1) / slice;
     static const int ov_env = getenv("MPG_SPLIT_OVERLAP") ? (getenv("MPG_SPLIT_OVERLAP")[0] == '0' ? 0 : 1) : -1; // experiment knob
     const bool overlap = (ov_env >= 0 ? ov_env != 0 : ws.split_overlap) && nslices > 1;
-    const size_t lists_sz = (size_t)((nmax + 7) / 8) * 8 * (size_t)cap, counts_sz = (size_t)nmax + 8;
+    const size_t lists_sz = (size_t)((nmax + 15) / 16) * 16 * (size_t)cap, counts_sz = (size_t)nmax + 8;
     ws.split_lists.reserve(lists_sz * (overlap ? 2 : 1));
     ws.split_counts.reserve(counts_sz * (overlap ? 2 : 1));
     ws.split_ovf.reserve((size_t)io.ntargets);
@@ -671,8 +979,9 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         int2 *counts = ws.split_counts.p + (size_t)b * counts_sz;
         if(overlap && i >= 2)
             MPG_HIP(hipStreamWaitEvent(sl, ws.ev_eval[b], 0)); // the evaluation that read this buffer two slices ago is done
-        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks, cpw)), dim3(256), 0, sl, tv, gp, io, lists, counts, cap, s0,
-                           ns, ws.ctr.p, ws.split_ovf.p);
+        // (the pair kernel's waves take units of 16 targets)
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, pair ? (ns + 15) / 16 : nchunks, cpw)), dim3(256), 0, sl, tv, gp, io,
+                           lists, counts, cap, s0, ns, ws.ctr.p, ws.split_ovf.p);
         if(overlap) {
             MPG_HIP(hipEventRecord(ws.ev_lists[b], sl));
             MPG_HIP(hipStreamWaitEvent(st, ws.ev_lists[b], 0));

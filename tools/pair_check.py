@@ -1,0 +1,40 @@
+"""Accelerations / potentials / per-target walk cost of three force steps (two-kernel walk) written to an .npz: run once with
+MPG_LISTS_PAIR=0 and once with 1 and compare bit for bit (tools/r02_pair.sh).  usage: pair_check.py out.npz ic n"""
+import ctypes as C
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("mp-gadget_amd")
+import torch
+out, ic, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+pos, mass, box = getattr(pkg.ics, ic)(n)
+N = len(pos)
+dev = torch.device("cuda", 0)
+eng = pkg.Engine(0)
+eng.set_walk_variant(6)
+eng.gravpm_init_periodic(box, 1.5, 2 * n, 43.0071)
+eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0, FractionalGravitySoftening=1. / 30.)
+eng.gravshort_set_softenings(box / n)
+p = torch.from_numpy(pos).to(dev)
+m = torch.from_numpy(mass).to(dev)
+z3 = lambda: torch.zeros(N, 3, dtype=torch.float64, device=dev)
+gravpm, acc, prev, pot = z3(), z3(), z3(), torch.zeros(N, dtype=torch.float64, device=dev)
+cost = torch.zeros(N, dtype=torch.float32, device=dev)
+eng.dev_bind_particles(p, m, box)
+eng.lib.mpg_dev_set_walk_cost.argtypes = [C.c_void_p, C.c_void_p]
+eng._ck(eng.lib.mpg_dev_set_walk_cost(eng.h, C.c_void_p(cost.data_ptr())))
+res = {}
+for step in range(3):          # Barnes-Hut first walk, list-capacity adaptation, relative criterion
+    pot.zero_()
+    eng.dev_gravpm_force(gravpm, pot)
+    eng.dev_force_tree_build()
+    prev, acc = acc, prev
+    eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+    torch.cuda.synchronize()
+    res["acc%d" % step] = acc.cpu().numpy().copy()
+    res["pot%d" % step] = pot.cpu().numpy().copy()
+    res["cost%d" % step] = cost.cpu().numpy().copy()
+    print(ic, n, "step", step, "walk", eng.walk_choice(), flush=True)
+np.savez(out, **res)
+eng.close()
