@@ -484,16 +484,18 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
             dy = mom.y - py;
             dz = mom.z - pz;
         }
-        if(special) { // (see walk_target)
+        // (see walk_target.  A wave-uniform branch around per-lane selects: written as `if(special)` the block was flattened into
+        // the step by hipcc - 35 instructions per target on every step for the two steps per target that need them)
+        if(any_lane(special)) {
             const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
-            dx = fma(-jx, gp.box, mom.x - px);
-            dy = fma(-jy, gp.box, mom.y - py);
-            dz = fma(-jz, gp.box, mom.z - pz);
-            wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
+            dx = special ? fma(-jx, gp.box, mom.x - px) : dx;
+            dy = special ? fma(-jy, gp.box, mom.y - py) : dy;
+            dz = special ? fma(-jz, gp.box, mom.z - pz) : dz;
+            wr = wr || (special && ((jx != 0.0) || (jy != 0.0) || (jz != 0.0)));
             if(MODE == 2) {
-                cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
-                cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
-                cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+                cdx = special ? fabs(nearest_img(g.cx - px, gp.box, gp.invbox)) : cdx;
+                cdy = special ? fabs(nearest_img(g.cy - py, gp.box, gp.invbox)) : cdy;
+                cdz = special ? fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)) : cdz;
             }
         }
     }
@@ -931,7 +933,7 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
     static const int lists_blk_env = getenv("MPG_LISTS_BLOCKS") ? atoi(getenv("MPG_LISTS_BLOCKS")) : 0;
     static const int eval_blk = getenv("MPG_EVAL_BLOCKS") ? atoi(getenv("MPG_EVAL_BLOCKS")) : MPG_EVAL_BLOCKS;
     // MPG_LISTS_PAIR: 0 one target per group of 8 lanes (k_walk_lists), 1 two (k_walk_lists2; its stack entries hold 27-bit node indices)
-    static const int pair_env = getenv("MPG_LISTS_PAIR") ? atoi(getenv("MPG_LISTS_PAIR")) : 1;
+    static const int pair_env = getenv("MPG_LISTS_PAIR") ? atoi(getenv("MPG_LISTS_PAIR")) : 0;
     const bool pair = pair_env != 0 && tv.nnodes < (1ll << 27);
     const int lists_blk = lists_blk_env ? lists_blk_env : (pair ? 4 : 6); // (the pair kernel: 98 VGPRs without spills = 5 waves per SIMD)
     auto kl = pair ? (lists_blk == 4   ? k_walk_lists2<COUNT, FASTWRAP, O32, 4>

@@ -13,6 +13,7 @@ N = len(pos)
 dev = torch.device("cuda", 0)
 eng = pkg.Engine(0)
 eng.set_walk_variant(6)
+eng.gravshort_fill_ntab(0, 1.5)
 eng.gravpm_init_periodic(box, 1.5, 2 * n, 43.0071)
 eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0, FractionalGravitySoftening=1. / 30.)
 eng.gravshort_set_softenings(box / n)
