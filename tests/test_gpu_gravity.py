@@ -168,6 +168,28 @@ def test_walk_parity(pkg, engine, orc, ic, n, nmesh):
     engine.set_instrumentation(False, False)
 
 
+@pytest.mark.parametrize("ic,n", [("s_clust", 48), ("s_zel", 40)])
+def test_pair_list_kernel_is_bit_identical(tmp_path, ic, n):
+    """k_walk_lists2 (MPG_LISTS_PAIR=1: two tree-order neighbours per group of 8 lanes share one traversal) writes, per target, the lists
+    k_walk_lists writes: accelerations, potentials and the per-target walk cost of three steps (Barnes-Hut walk, list-capacity
+    adaptation with overflowing targets on the clustered set, relative criterion) are equal bit for bit.  (The knob is read once per
+    process: two processes.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for pr in ("0", "1"):
+        out = str(tmp_path / ("pair%s.npz" % pr))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), out, ic, str(n)], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, MPG_LISTS_PAIR=pr))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert set(res[0].files) == set(res[1].files) and len(res[0].files) == 9
+    for k in res[0].files:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert np.abs(res[0]["acc2"]).max() > 0 and res[0]["cost2"].min() > 0
+
+
 @pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (5, 512), (6, 512), (6, 40)])
 @pytest.mark.parametrize("ic,n,nmesh", [("s_grid", 24, 48), ("s_clust", 20, 40), ("s_zel", 24, 48)])
 def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
