@@ -591,6 +591,11 @@ int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, c
 int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass);
 int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm, double *d_accel,
                                  double *d_potential, double rho0);
+/* the same for a subset of the own particles: d_active[nactive] = their indices (device array, no duplicates), the ActiveParticle list of a
+ * sub-step (run.c:392-470: the tree holds every particle, the active ones are walked).  Only their entries of d_accel / d_potential are
+ * written.  d_active == NULL: all own particles. */
+int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_t nactive, const double *d_oldacc, const double *d_prev_accel,
+                                        const double *d_gravpm, double *d_accel, double *d_potential, double rho0);
 /* density() and hydro_force() (density.h:42, hydra.h) for the rank's own gas on the particle set of the last
  * mpg_dist_dev_force_tree_build (own + ghosts; the domain margin must cover the largest smoothing length: checked).  d_type and the
  * arrays of A are device arrays over the n_own own particles (mpg_sph_arrays; optional inputs may be NULL); the ghosts' columns
@@ -612,6 +617,10 @@ int mpg_dist_fof_groups(mpg_dist *d, const mpg_fof_groups *out);
 int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *P);
 int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P);
 int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0);
+/* ... for the sub-steps: ActiveParticle[NumActiveParticle] (host array of indices into P[], NULL = all) are walked, their
+ * FullTreeGravAccel / Potential / AccelStore entries updated (the tree of mpg_dist_force_tree_full holds every particle) */
+int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                    double (*AccelStore)[3], double rho0);
 /* density() / hydro_force() as drop-in calls on the same table (after mpg_dist_force_tree_full on it): A holds HOST arrays in particle
  * order, as for mpg_density / mpg_hydro_force (the shim gathers SphP[P[i].PI].X into them); inputs are read, outputs written */
 int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml, int DoEgyDensity);

@@ -193,6 +193,25 @@ __global__ void __launch_bounds__(256) k_scatter_results(int64_t ns, const int *
         pot[i] += r.pot; // readout_potential accumulates (gravpm.c:499-501)
 }
 
+// flag[list[i]] = 1; an index outside [0, n) raises *err
+__global__ void __launch_bounds__(256) k_flag_list(int64_t m, const int *__restrict__ list, int n, uint8_t *__restrict__ flag,
+                                                   unsigned *__restrict__ err)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= m)
+        return;
+    const int j = list[i];
+    if(j < 0 || j >= n)
+        atomicOr(err, 1u);
+    else
+        flag[j] = 1;
+}
+
+struct IsFlagged {
+    const uint8_t *flag;
+    __host__ __device__ bool operator()(const int &i) const { return flag[i] != 0; }
+};
+
 // own particles of the local tree, in tree order (caller index < n_own)
 struct IsOwn {
     int n_own;
@@ -542,7 +561,9 @@ struct mpg_dist {
     // tree side
     DevBuf<double> lpos, top;
     DevBuf<float> lmass;
-    DevBuf<int> targets;
+    DevBuf<int> targets, act_targets;
+    DevBuf<uint8_t> actflag;
+    DevBuf<unsigned> err;
     HostBuf<double> htop;
     int64_t ntarg = 0, n_own_tree = -1;
     DevBuf<float> cost;
@@ -586,6 +607,7 @@ struct mpg_dist {
     std::vector<double> hbuf;
     std::vector<float> hbuf_f;
     int64_t o_n = -1;
+    DevBuf<int> o_act;        // ActiveParticle of the host drop-in walk
     DevBuf<double> o_sph[17]; // the double-valued fields of mpg_sph_arrays over the own particles (host SPH path)
     DevBuf<uint8_t> o_u8[3];  // type, tb_hydro, tb_grav
 };
@@ -1083,14 +1105,50 @@ int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_po
 int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm, double *d_accel,
                                  double *d_potential, double rho0)
 {
+    return mpg_dist_dev_grav_short_tree_active(d, nullptr, 0, d_oldacc, d_prev_accel, d_gravpm, d_accel, d_potential, rho0);
+}
+
+int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_t nactive, const double *d_oldacc, const double *d_prev_accel,
+                                        const double *d_gravpm, double *d_accel, double *d_potential, double rho0)
+{
     API_BEGIN
     MPG_CHECK(d && d_accel, "null argument");
     MPG_CHECK(d->n_own_tree >= 0, "mpg_dist_dev_grav_short_tree: mpg_dist_dev_force_tree_build first");
+    MPG_CHECK(nactive >= 0 && nactive <= d->n_own_tree, "mpg_dist_dev_grav_short_tree_active: bad number of active particles");
     mpg_engine *e = d->eng;
     MPG_HIP(hipSetDevice(e->device));
     sync(d);
     const double t3 = now_ms();
-    if(d->ntarg > 0) {
+    // the walk's targets: the own particles in tree order, or those of them the caller lists as active (ActiveParticle of the
+    // sub-steps, run.c:392-470: the tree holds every particle, a subset is walked)
+    const int *targets = d->targets.p;
+    int64_t ntarg = d->ntarg;
+    if(d_active) {
+        hipStream_t st = e->stream;
+        ntarg = 0;
+        if(nactive > 0 && d->ntarg > 0) {
+            d->actflag.reserve((size_t)d->n_own_tree + 1);
+            d->act_targets.reserve((size_t)d->n_own_tree + 1);
+            d->err.reserve(4);
+            MPG_HIP(hipMemsetAsync(d->err.p, 0, sizeof(unsigned), st));
+            MPG_HIP(hipMemsetAsync(d->actflag.p, 0, (size_t)d->n_own_tree, st));
+            hipLaunchKernelGGL(k_flag_list, dim3(nblk(nactive)), dim3(256), 0, st, nactive, d_active, (int)d->n_own_tree, d->actflag.p, d->err.p);
+            size_t tb = 0;
+            MPG_HIP(rocprim::select(nullptr, tb, d->targets.p, d->act_targets.p, d->scount.p, (size_t)d->ntarg, IsFlagged{d->actflag.p}, st));
+            d->tmp.reserve(tb + 16);
+            MPG_HIP(rocprim::select((void *)d->tmp.p, tb, d->targets.p, d->act_targets.p, d->scount.p, (size_t)d->ntarg, IsFlagged{d->actflag.p}, st));
+            unsigned long long c = 0;
+            unsigned bad = 0;
+            MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+            MPG_HIP(hipMemcpyAsync(&bad, d->err.p, sizeof(bad), hipMemcpyDeviceToHost, st));
+            sync(d);
+            MPG_CHECK(bad == 0, "mpg_dist_dev_grav_short_tree_active: an active index is not an own particle");
+            MPG_CHECK((int64_t)c == nactive, "mpg_dist_dev_grav_short_tree_active: the active list holds duplicates");
+            ntarg = (int64_t)c;
+        }
+        targets = d->act_targets.p;
+    }
+    if(ntarg > 0) {
         d->cost.reserve((size_t)d->n_own_tree + 1);
         MPG_HIP(hipMemsetAsync(d->cost.p, 0, (size_t)d->n_own_tree * sizeof(float), e->stream));
         float *keep = e->d_walk_cost;
@@ -1098,7 +1156,7 @@ int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const doub
         e->d_walk_cost = d->cost.p;
         if(e->walk_variant == 0) // the two-kernel walk whatever the target count: it is the one that records the work per target
             e->walk_variant = 6;
-        const int rc = mpg_dev_grav_short_tree(e, d_oldacc, d_prev_accel, d_gravpm, d->targets.p, d->ntarg, d_accel, d_potential, rho0);
+        const int rc = mpg_dev_grav_short_tree(e, d_oldacc, d_prev_accel, d_gravpm, targets, ntarg, d_accel, d_potential, rho0);
         e->d_walk_cost = keep;
         e->walk_variant = keep_variant;
         MPG_CHECK(rc == 0, mpg_last_error());
@@ -1237,32 +1295,59 @@ int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P)
 
 int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0)
 {
+    return mpg_dist_grav_short_tree_active(d, P, nullptr, 0, AccelStore, rho0);
+}
+
+int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                    double (*AccelStore)[3], double rho0)
+{
     API_BEGIN
     MPG_CHECK(d && P, "null argument");
     MPG_CHECK(P->off_accel >= 0 && P->off_gravpm >= 0, "particle view needs FullTreeGravAccel and GravPM");
     MPG_CHECK(d->o_n == P->n && d->n_own_tree == P->n, "mpg_dist_grav_short_tree: call mpg_dist_force_tree_full on this table first");
+    MPG_CHECK(!ActiveParticle || (NumActiveParticle >= 0 && NumActiveParticle <= P->n), "bad NumActiveParticle");
     MPG_HIP(hipSetDevice(d->eng->device));
     const int64_t n = P->n;
     // OldAcc = |FullTreeGravAccel + GravPM| / G of the table as it stands (grav_get_abs_accel, gravshort.h:70-80)
     column_up(d, P, P->off_accel, 3, d->o_prev.p);
     column_up(d, P, P->off_gravpm, 3, d->o_gravpm.p);
-    MPG_CHECK(mpg_dist_dev_grav_short_tree(d, nullptr, d->o_prev.p, d->o_gravpm.p, d->o_acc.p, P->off_potential >= 0 ? d->o_pot.p : nullptr, rho0) == 0,
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        d->o_act.reserve((size_t)NumActiveParticle + 1);
+        if(NumActiveParticle > 0)
+            MPG_HIP(hipMemcpyAsync(d->o_act.p, ActiveParticle, (size_t)NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, d->eng->stream));
+        d_act = d->o_act.p;
+    }
+    const bool pot = P->off_potential >= 0;
+    MPG_CHECK(mpg_dist_dev_grav_short_tree_active(d, d_act, NumActiveParticle, nullptr, d->o_prev.p, d->o_gravpm.p, d->o_acc.p,
+                                                  pot ? d->o_pot.p : nullptr, rho0) == 0,
               mpg_last_error());
+    // results of the walked particles into the table: P[i].FullTreeGravAccel (full particle tree, gravshort.h:57-62), AccelStore[i],
+    // P[i].Potential
     const mpg_particle_view V = *P;
     char *b = (char *)P->base;
-    column_down(d, n, 3, d->o_acc.p, [=](int64_t i, const double *v) {
-        double *a = (double *)(b + i * V.stride + V.off_accel); // full particle tree: P[i].FullTreeGravAccel (gravshort.h:57-62)
-        a[0] = v[0];
-        a[1] = v[1];
-        a[2] = v[2];
-        if(AccelStore) {
-            AccelStore[i][0] = v[0];
-            AccelStore[i][1] = v[1];
-            AccelStore[i][2] = v[2];
+    d->hbuf.resize(4 * (size_t)n + 4);
+    double *ha = d->hbuf.data(), *hp = ha + 3 * (size_t)n;
+    if(n > 0) {
+        MPG_HIP(hipMemcpyAsync(ha, d->o_acc.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, d->eng->stream));
+        if(pot)
+            MPG_HIP(hipMemcpyAsync(hp, d->o_pot.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, d->eng->stream));
+    }
+    sync(d);
+    const int64_t m = ActiveParticle ? NumActiveParticle : n;
+    parallel_for(m, [=](int64_t lo, int64_t hi) {
+        for(int64_t k = lo; k < hi; k++) {
+            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            double *a = (double *)(b + i * V.stride + V.off_accel);
+            for(int j = 0; j < 3; j++) {
+                a[j] = ha[3 * i + j];
+                if(AccelStore)
+                    AccelStore[i][j] = ha[3 * i + j];
+            }
+            if(pot)
+                *(double *)(b + i * V.stride + V.off_potential) = hp[i];
         }
     });
-    if(P->off_potential >= 0)
-        column_down(d, n, 1, d->o_pot.p, [=](int64_t i, const double *v) { *(double *)(b + i * V.stride + V.off_potential) = v[0]; });
     API_END
 }
 

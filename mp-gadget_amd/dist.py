@@ -180,6 +180,17 @@ class DistForce:
         self._ck(self.lib.mpg_dist_gravity_step(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(oldacc), p(prev_accel), p(accel), p(gravpm),
                                                 p(potential), C.c_double(rho0)))
 
+    def gravpm_force(self, pos, mass, gravpm, potential=None):
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._ck(self.lib.mpg_dist_dev_gravpm_force(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(gravpm), p(potential)))
+
+    def grav_short_tree(self, accel, oldacc=None, prev_accel=None, gravpm=None, potential=None, rho0=0.0, active=None):
+        """the walk on the tree of the last force_tree_build; active: int32 device tensor of own-particle indices (a sub-step's
+        ActiveParticle) or None for all"""
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._ck(self.lib.mpg_dist_dev_grav_short_tree_active(self.h, p(active), C.c_int64(0 if active is None else active.shape[0]), p(oldacc),
+                                                              p(prev_accel), p(gravpm), p(accel), p(potential), C.c_double(rho0)))
+
     # ---- domain_decompose_full + domain_exchange through the library (the C++ form of domain_peano.PeanoDomain)
     def domain_decompose(self, pos, box, garbage=None, overdecomposition=4, global_sorting=True, cost=None):
         """Returns (NTopNodes, NTopLeaves); the decomposition stays in the library (domain_get copies it out)."""

@@ -193,12 +193,12 @@ void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, My
         ck(mpg_grav_short_tree(eng(), &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
     }
     else {
-        if(act->ActiveParticle || !tree->full_particle_tree_flag)
-            endrun(5, "mpgadget_hip: the multi-rank walk serves steps on which every particle is active (PM steps); "
-                      "sub-steps of the hierarchical loop keep the CPU walk\n");
+        if(!tree->full_particle_tree_flag)
+            endrun(5, "mpgadget_hip: the multi-rank walk needs the tree of all particles (force_tree_full); the active-only trees of "
+                      "the hierarchical gravity loop keep the CPU walk\n");
         (void)pm;
         ck(mpg_dist_force_tree_full(D, &v));
-        ck(mpg_dist_grav_short_tree(D, &v, AccelStore, rho0));
+        ck(mpg_dist_grav_short_tree_active(D, &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
     }
     /* gravshort-tree.c:135-144: no export phase on this path (ghosts are imported before the walk), so the top-tree and
      * secondary walks cost nothing; the tree build of the device tree is charged to the reference's build clocks */

@@ -440,6 +440,22 @@ def test_peano_domain_ranks_match_one(tmp_path, ic):
         assert np.abs(d[:, 6] - pot1).max() <= 1e-9 * np.abs(pot1).mean(), name
 
 
+@keep_artifacts_on_failure
+def test_peano_domain_substep_active_subset(tmp_path):
+    """A sub-step on several ranks (run.c:392-470 without the hierarchical trees): the tree holds every particle, every fifth one is
+    active and walked (mpg_dist_dev_grav_short_tree_active).  The active particles get the accelerations of the one-GPU sub-step,
+    nothing else is written."""
+    n = 36
+    env = {"MPG_ACTIVE_EVERY": "5"}
+    one = _run_mgpu(tmp_path, "one.npy", 1, "single", 0, ic="s_clust", n=n, env_extra=env)
+    act = np.arange(len(one)) % 5 == 0
+    assert np.abs(one[act, 0:3]).min() > 0 and np.all(one[~act, 0:3] == 0)
+    for name, nproc, port in (("p1.npy", 1, 0), ("p3.npy", 3, 29608)):
+        d = _run_mgpu(tmp_path, name, nproc, "peano" if nproc > 1 else "peano1", port, ic="s_clust", n=n, env_extra=env)
+        assert np.all(d[~act, 0:3] == 0), name
+        assert_accel_parity(d[act, 0:3], one[act, 0:3])
+
+
 @pytest.mark.parametrize("ic", ["s_grid", "s_zel", "s_clust"])
 def test_full_size_256_properties(pkg, orc, ic):
     """256^3, Nmesh 512 (BASELINE configs[1]) on the device-resident path, on the three input sets of SURVEY 8(d) (the jittered grid,

@@ -40,10 +40,12 @@ acc = torch.zeros_like(gravpm)
 old = torch.full((N,), 1e-7, dtype=torch.float64, device=dev)
 mode = os.environ.get("MPG_MGPU_MODE", "slab")
 pot = torch.zeros(N, dtype=torch.float64, device=dev)
+every = int(os.environ.get("MPG_ACTIVE_EVERY", "0"))     # > 0: a sub-step - only the particles with index % every == 0 are walked
 if world == 1 and mode not in ("slab1", "domain1", "peano1"):
     eng.dev_gravpm_force(gravpm, pot)
     eng.dev_force_tree_build()
-    eng.dev_grav_short_tree(acc, oldacc=old)
+    act = torch.arange(0, N, every, dtype=torch.int32, device=dev) if every else None
+    eng.dev_grav_short_tree(acc, oldacc=old, active=act)
 elif mode == "replicated":
     eng.dev_gravpm_force(gravpm, pot)
     eng.dev_force_tree_build()
@@ -67,7 +69,13 @@ elif mode.startswith("peano"):
     df.set_domain(dom, rcut)
     f8 = dict(dtype=torch.float64, device=dev)
     ga, gg, gp = torch.zeros(n_own, 3, **f8), torch.zeros(n_own, 3, **f8), torch.zeros(n_own, **f8)
-    df.gravity_step(opos, omass, ga, gg, potential=gp, oldacc=torch.full((n_own,), 1e-7, **f8))
+    if every:       # the three calls of a sub-step: the tree holds every particle, the active ones are walked
+        df.gravpm_force(opos, omass, gg, gp)
+        df.force_tree_build(opos, omass)
+        act = torch.nonzero(oids % every == 0).squeeze(1).to(torch.int32).contiguous()
+        df.grav_short_tree(ga, oldacc=torch.full((n_own,), 1e-7, **f8), active=act)
+    else:
+        df.gravity_step(opos, omass, ga, gg, potential=gp, oldacc=torch.full((n_own,), 1e-7, **f8))
     both = torch.zeros(N, 7, **f8)
     both[oids] = torch.cat([ga, gg, gp[:, None]], dim=1)
     if grouped:
