@@ -43,6 +43,9 @@ void mpg_engine_destroy(mpg_engine *eng);
 const char *mpg_last_error(void);
 /* Library / build identification string. */
 const char *mpg_version(void);
+/* Hash over the sources, headers and compiler flags this library was built from (build.py); the Python host side refuses a library
+ * whose stamp differs from the sources next to it. */
+const char *mpg_build_stamp(void);
 /* Use an existing HIP stream (hipStream_t passed as void*) for all engine work; NULL = engine's own. */
 int mpg_engine_set_stream(mpg_engine *eng, void *hip_stream);
 void *mpg_engine_get_stream(mpg_engine *eng);

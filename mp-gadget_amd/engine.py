@@ -107,6 +107,15 @@ def load_library():
         raise EngineError("HIP engine library %s is missing: run `python __graft_entry__.py` (build()) first; "
                           "there is no CPU fallback" % LIB_PATH)
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # a library that was not built from the sources next to it is refused (build.py: content hash, not file times)
+    from . import build as _build
+    L.mpg_build_stamp.restype = C.c_char_p
+    have = L.mpg_build_stamp().decode()
+    if os.path.isdir(_build.CSRC) and not os.environ.get("MPG_ALLOW_STALE_LIBRARY"):
+        want = _build.source_stamp()
+        if have != want:
+            raise EngineError("HIP engine library %s is stale (built from other sources: stamp %s, tree %s): run build() again"
+                              % (LIB_PATH, have, want))
     L.mpg_last_error.restype = C.c_char_p
     L.mpg_version.restype = C.c_char_p
     L.mpg_force_softening.restype = C.c_double

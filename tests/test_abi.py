@@ -76,3 +76,17 @@ def test_mpi_comm_shim_compiles():
     r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", inc,
                         os.path.join(ROOT, "shim", "mpg_mpi_comm.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """The library carries the hash of the sources it was built from (mpg_build_stamp, build.py); the host side refuses one that does
+    not match the tree instead of running old kernels silently."""
+    import importlib
+    pkg = importlib.import_module("mp-gadget_amd")
+    E = pkg.engine
+    E.load_library()                                           # the in-tree library matches its sources
+    assert E.load_library().mpg_build_stamp().decode() == pkg.build.source_stamp()
+    monkeypatch.setattr(E, "_lib", None)
+    monkeypatch.setattr(pkg.build, "source_stamp", lambda: "0" * 32)
+    with pytest.raises(E.EngineError, match="stale"):
+        E.load_library()
