@@ -607,6 +607,13 @@ int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_
 int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml,
                          int DoEgyDensity);
 int mpg_dist_dev_hydro_force(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T);
+/* ... for a sub-step: only the own gas among d_active[nactive] (device array of own-particle indices; NULL = all) is treated; the arrays
+ * of A must then hold, for the other particles, the results of their last loops (they are read: the hydro loop and the ghosts need the
+ * inactive particles' Density ... CurlVel) and those entries come back unchanged, as the reference leaves SphP of inactive particles */
+int mpg_dist_dev_density_active(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T,
+                                const int *d_active, int64_t nactive, int update_hsml, int DoEgyDensity);
+int mpg_dist_dev_hydro_force_active(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active,
+                                    int64_t nactive);
 /* fof_fof (fof.c:157-253) with the particles on their owners: groups may span ranks.  Device arrays over the n_own own particles
  * (d_type NULL: all type 1; d_vel NULL: zero); the linking length must not exceed the domain margin.  d_grnr[n_own] (may be NULL)
  * receives P[].GrNr with GLOBAL group numbers (length descending, then MinID); *ngroups_total = fof.TotNgroups; this rank keeps the
@@ -625,9 +632,12 @@ int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*A
 int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
                                     double (*AccelStore)[3], double rho0);
 /* density() / hydro_force() as drop-in calls on the same table (after mpg_dist_force_tree_full on it): A holds HOST arrays in particle
- * order, as for mpg_density / mpg_hydro_force (the shim gathers SphP[P[i].PI].X into them); inputs are read, outputs written */
-int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml, int DoEgyDensity);
-int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T);
+ * order, as for mpg_density / mpg_hydro_force (the shim gathers SphP[P[i].PI].X into them); inputs are read, outputs written.
+ * ActiveParticle[NumActiveParticle]: host array of indices into P[] (NULL = all), see mpg_dist_dev_density_active */
+int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
+                     int64_t NumActiveParticle, int update_hsml, int DoEgyDensity);
+int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
+                         int64_t NumActiveParticle);
 /* per-particle work of the last mpg_dist walk for the rank's own particles (device pointer, n_own floats, caller order):
  * the cost the next domain decomposition balances (mpg_dev_set_walk_cost) */
 const float *mpg_dist_walk_cost(mpg_dist *d);

@@ -348,6 +348,10 @@ struct IsOwnGas {
     const uint8_t *type;
     __host__ __device__ bool operator()(const int &i) const { return type[i] == 0; }
 };
+struct IsActiveGas {
+    const uint8_t *type, *flag;
+    __host__ __device__ bool operator()(const int &i) const { return type[i] == 0 && flag[i] != 0; }
+};
 
 __global__ void __launch_bounds__(256) k_max_gas_hsml(int64_t n, const uint8_t *__restrict__ type, const double *__restrict__ hsml,
                                                       unsigned long long *__restrict__ out)
@@ -1359,6 +1363,49 @@ int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *P, con
 int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml,
                          int DoEgyDensity)
 {
+    return mpg_dist_dev_density_active(d, n_own, d_type, A, T, nullptr, 0, update_hsml, DoEgyDensity);
+}
+
+// the loop's targets: the own gas (d_active == null) or the own gas among the listed particles, ascending
+static void sph_targets(mpg_dist *d, int64_t n_own, const int *d_active, int64_t nactive)
+{
+    hipStream_t st = d->eng->stream;
+    d->gas.reserve((size_t)n_own + 1);
+    d->scount.reserve(4);
+    d->ngas = 0;
+    if(n_own == 0 || (d_active && nactive == 0))
+        return;
+    rocprim::counting_iterator<int> iota(0);
+    size_t tb = 0;
+    unsigned bad = 0;
+    if(d_active) {
+        MPG_CHECK(nactive > 0 && nactive <= n_own, "mpg_dist SPH loop: bad number of active particles");
+        d->actflag.reserve((size_t)n_own + 1);
+        d->err.reserve(4);
+        MPG_HIP(hipMemsetAsync(d->err.p, 0, sizeof(unsigned), st));
+        MPG_HIP(hipMemsetAsync(d->actflag.p, 0, (size_t)n_own, st));
+        hipLaunchKernelGGL(k_flag_list, dim3(nblk(nactive)), dim3(256), 0, st, nactive, d_active, (int)n_own, d->actflag.p, d->err.p);
+        const IsActiveGas pred{d->s_type.p, d->actflag.p};
+        MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, pred, st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, pred, st));
+        MPG_HIP(hipMemcpyAsync(&bad, d->err.p, sizeof(bad), hipMemcpyDeviceToHost, st));
+    }
+    else {
+        MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
+    }
+    unsigned long long c = 0;
+    MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+    sync(d);
+    MPG_CHECK(bad == 0, "mpg_dist SPH loop: an active index is not an own particle");
+    d->ngas = (int64_t)c;
+}
+
+int mpg_dist_dev_density_active(mpg_dist *d, int64_t n_own, const uint8_t *d_type, const mpg_sph_arrays *A, const mpg_sph_times *T,
+                                const int *d_active, int64_t nactive, int update_hsml, int DoEgyDensity)
+{
     API_BEGIN
     MPG_CHECK(d && A && T && A->hsml && A->density && A->dhsmlegyfac && A->divvel && A->curlvel, "null argument");
     MPG_CHECK(d->n_own_tree == n_own, "mpg_dist_dev_density: mpg_dist_dev_force_tree_build of this particle set first");
@@ -1392,20 +1439,21 @@ int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, cons
     // the gas tree of the local set (force_tree_rebuild_mask(GASMASK), run.c:466)
     MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, d->s_type.p, d->box) == 0, mpg_last_error());
     MPG_CHECK(mpg_dev_force_tree_rebuild_mask(e, 1, 0) == 0, mpg_last_error());
-    // active: the own gas
-    d->gas.reserve((size_t)n_own + 1);
-    d->scount.reserve(4);
-    d->ngas = 0;
-    if(n_own > 0) {
-        rocprim::counting_iterator<int> iota(0);
-        size_t tb = 0;
-        MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
-        d->tmp.reserve(tb + 16);
-        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
-        unsigned long long c = 0;
-        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
-        sync(d);
-        d->ngas = (int64_t)c;
+    sph_targets(d, n_own, d_active, nactive);
+    if(d_active && n_own > 0) {
+        // a sub-step: the inactive own particles keep the results of their last density loop, which the hydro loop of this sub-step
+        // reads and their owners hand to the ghosts (the reference leaves SphP of inactive particles alone)
+        auto in = [&](double *dst, const double *src, int w) {
+            if(src)
+                MPG_HIP(hipMemcpyAsync(dst, src, (size_t)w * n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+        };
+        in(d->s_out[0].p, A->dthsml, 1);
+        in(d->s_out[1].p, A->density, 1);
+        in(d->s_out[2].p, A->egywtdensity, 1);
+        in(d->s_out[3].p, A->dhsmlegyfac, 1);
+        in(d->s_out[4].p, A->divvel, 1);
+        in(d->s_out[5].p, A->curlvel, 1);
+        in(d->s_out[6].p, A->gradrho, 3);
     }
     mpg_sph_arrays L;
     memset(&L, 0, sizeof(L));
@@ -1461,6 +1509,12 @@ int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, cons
 
 int mpg_dist_dev_hydro_force(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T)
 {
+    return mpg_dist_dev_hydro_force_active(d, n_own, A, T, nullptr, 0);
+}
+
+int mpg_dist_dev_hydro_force_active(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active,
+                                    int64_t nactive)
+{
     API_BEGIN
     MPG_CHECK(d && A && T && A->hydroacc_out && A->dtentropy_out && A->maxsignalvel, "null argument");
     MPG_CHECK(d->sph_n_own == n_own && d->sph_nl >= n_own, "mpg_dist_dev_hydro_force: mpg_dist_dev_density of this particle set first");
@@ -1498,6 +1552,12 @@ int mpg_dist_dev_hydro_force(mpg_dist *d, int64_t n_own, const mpg_sph_arrays *A
     L.hydroacc_out = d->s_out[7].p;
     L.dtentropy_out = d->s_out[8].p;
     L.maxsignalvel = d->s_out[9].p;
+    sph_targets(d, n_own, d_active, nactive);
+    if(d_active && n_own > 0) { // (inactive particles keep their HydroAccel / DtEntropy / MaxSignalVel)
+        MPG_HIP(hipMemcpyAsync(L.hydroacc_out, A->hydroacc_out, (size_t)3 * n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MPG_HIP(hipMemcpyAsync(L.dtentropy_out, A->dtentropy_out, (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+        MPG_HIP(hipMemcpyAsync(L.maxsignalvel, A->maxsignalvel, (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     MPG_CHECK(mpg_dev_hydro_force(e, &L, T, d->gas.p, d->ngas) == 0, mpg_last_error());
     if(n_own > 0) {
         MPG_HIP(hipMemcpyAsync(A->hydroacc_out, L.hydroacc_out, (size_t)3 * n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2256,7 +2316,7 @@ void sph_field_ptrs(const mpg_sph_arrays *A, const double *p[17])
 }
 
 // device copy of the host arrays: inputs uploaded, outputs allocated; returns the device-side struct
-mpg_sph_arrays stage_sph(mpg_dist *d, const mpg_sph_arrays *A, int64_t n, bool upload)
+mpg_sph_arrays stage_sph(mpg_dist *d, const mpg_sph_arrays *A, int64_t n, bool upload, bool upload_density_out, bool upload_hydro_out)
 {
     hipStream_t st = d->eng->stream;
     const double *hp[17];
@@ -2268,7 +2328,9 @@ mpg_sph_arrays stage_sph(mpg_dist *d, const mpg_sph_arrays *A, int64_t n, bool u
             continue;
         d->o_sph[k].reserve((size_t)SPH_FIELDS[k].w * n + 3);
         dp[k] = d->o_sph[k].p;
-        if(upload && SPH_FIELDS[k].in && n > 0)
+        const bool up = (upload && SPH_FIELDS[k].in) || (upload_density_out && SPH_FIELDS[k].out_density) ||
+                        (upload_hydro_out && SPH_FIELDS[k].out_hydro);
+        if(up && n > 0)
             MPG_HIP(hipMemcpyAsync(dp[k], hp[k], (size_t)SPH_FIELDS[k].w * n * sizeof(double), hipMemcpyHostToDevice, st));
     }
     const uint8_t *hb[2] = {A->tb_hydro, A->tb_grav};
@@ -2340,27 +2402,44 @@ const uint8_t *stage_types(mpg_dist *d, const mpg_particle_view *P)
 
 extern "C" {
 
-int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, int update_hsml, int DoEgyDensity)
+// ActiveParticle of a host call onto the device (null: all)
+static const int *stage_active(mpg_dist *d, const int *ActiveParticle, int64_t n)
+{
+    if(!ActiveParticle)
+        return nullptr;
+    d->o_act.reserve((size_t)n + 1);
+    if(n > 0)
+        MPG_HIP(hipMemcpy(d->o_act.p, ActiveParticle, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    return d->o_act.p;
+}
+
+int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
+                     int64_t NumActiveParticle, int update_hsml, int DoEgyDensity)
 {
     API_BEGIN
     MPG_CHECK(d && P && A && T, "null argument");
     MPG_CHECK(d->o_n == P->n && d->n_own_tree == P->n, "mpg_dist_density: call mpg_dist_force_tree_full on this table first");
     MPG_HIP(hipSetDevice(d->eng->device));
     const uint8_t *ty = stage_types(d, P);
-    const mpg_sph_arrays D = stage_sph(d, A, P->n, true);
-    MPG_CHECK(mpg_dist_dev_density(d, P->n, ty, &D, T, update_hsml, DoEgyDensity) == 0, mpg_last_error());
+    // (a sub-step also uploads the density-loop results the inactive particles hold)
+    const mpg_sph_arrays D = stage_sph(d, A, P->n, true, ActiveParticle != nullptr, false);
+    const int *act = stage_active(d, ActiveParticle, NumActiveParticle);
+    MPG_CHECK(mpg_dist_dev_density_active(d, P->n, ty, &D, T, act, NumActiveParticle, update_hsml, DoEgyDensity) == 0, mpg_last_error());
     download_sph(d, A, P->n, false);
     API_END
 }
 
-int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T)
+int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
+                         int64_t NumActiveParticle)
 {
     API_BEGIN
     MPG_CHECK(d && P && A && T, "null argument");
     MPG_CHECK(d->sph_n_own == P->n, "mpg_dist_hydro_force: call mpg_dist_density on this table first");
     MPG_HIP(hipSetDevice(d->eng->device));
-    const mpg_sph_arrays D = stage_sph(d, A, P->n, false); // (the inputs are the library's from the density call)
-    MPG_CHECK(mpg_dist_dev_hydro_force(d, P->n, &D, T) == 0, mpg_last_error());
+    // (the inputs are the library's from the density call; a sub-step uploads the hydro results the inactive particles hold)
+    const mpg_sph_arrays D = stage_sph(d, A, P->n, false, false, ActiveParticle != nullptr);
+    const int *act = stage_active(d, ActiveParticle, NumActiveParticle);
+    MPG_CHECK(mpg_dist_dev_hydro_force_active(d, P->n, &D, T, act, NumActiveParticle) == 0, mpg_last_error());
     download_sph(d, A, P->n, true);
     API_END
 }

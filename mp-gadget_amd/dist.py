@@ -272,30 +272,44 @@ class DistForce:
         ran on this particle set)"""
         self._ck(self.lib.mpg_dist_dev_force_tree_build(self.h, C.c_int64(pos.shape[0]), C.c_void_p(pos.data_ptr()), C.c_void_p(mass.data_ptr())))
 
-    def density(self, type, arrays, times, update_hsml=1, DoEgyDensity=0):
-        """density() for the rank's own gas; type: uint8 device tensor, arrays: dict of device tensors over the own particles"""
+    def density(self, type, arrays, times, update_hsml=1, DoEgyDensity=0, active=None):
+        """density() for the rank's own gas (active: int32 device tensor of own indices, a sub-step's list, or None for all); type: uint8
+        device tensor, arrays: dict of device tensors over the own particles"""
         a = self.eng._sph_arrays(arrays)
-        self._ck(self.lib.mpg_dist_dev_density(self.h, C.c_int64(type.shape[0]), C.c_void_p(type.data_ptr()), C.byref(a), C.byref(times),
-                                               int(update_hsml), int(DoEgyDensity)))
+        ap = None if active is None else C.c_void_p(active.data_ptr())
+        self._ck(self.lib.mpg_dist_dev_density_active(self.h, C.c_int64(type.shape[0]), C.c_void_p(type.data_ptr()), C.byref(a), C.byref(times),
+                                                      ap, C.c_int64(0 if active is None else active.shape[0]), int(update_hsml),
+                                                      int(DoEgyDensity)))
 
-    def hydro_force(self, n_own, arrays, times):
+    def hydro_force(self, n_own, arrays, times, active=None):
         a = self.eng._sph_arrays(arrays)
-        self._ck(self.lib.mpg_dist_dev_hydro_force(self.h, C.c_int64(n_own), C.byref(a), C.byref(times)))
+        ap = None if active is None else C.c_void_p(active.data_ptr())
+        self._ck(self.lib.mpg_dist_dev_hydro_force_active(self.h, C.c_int64(n_own), C.byref(a), C.byref(times), ap,
+                                                          C.c_int64(0 if active is None else active.shape[0])))
 
     # drop-in forms on the rank's particle_data records (numpy, engine.PARTICLE_DTYPE) and host SPH arrays: what shim/sph-hip.c calls
     def host_force_tree_full(self, P):
         v = self.eng._view(P)
         self._ck(self.lib.mpg_dist_force_tree_full(self.h, C.byref(v)))
 
-    def host_density(self, P, arrays, times, update_hsml=1, DoEgyDensity=0):
-        v = self.eng._view(P)
-        a = self.eng._sph_host_arrays(arrays)
-        self._ck(self.lib.mpg_dist_density(self.h, C.byref(v), C.byref(a), C.byref(times), int(update_hsml), int(DoEgyDensity)))
+    @staticmethod
+    def _host_active(active):
+        if active is None:
+            return None, None, 0
+        act = np.ascontiguousarray(active, np.int32)
+        return act, act.ctypes.data_as(C.c_void_p), len(act)
 
-    def host_hydro_force(self, P, arrays, times):
+    def host_density(self, P, arrays, times, update_hsml=1, DoEgyDensity=0, ActiveParticle=None):
         v = self.eng._view(P)
         a = self.eng._sph_host_arrays(arrays)
-        self._ck(self.lib.mpg_dist_hydro_force(self.h, C.byref(v), C.byref(a), C.byref(times)))
+        keep, ap, na = self._host_active(ActiveParticle)
+        self._ck(self.lib.mpg_dist_density(self.h, C.byref(v), C.byref(a), C.byref(times), ap, C.c_int64(na), int(update_hsml), int(DoEgyDensity)))
+
+    def host_hydro_force(self, P, arrays, times, ActiveParticle=None):
+        v = self.eng._view(P)
+        a = self.eng._sph_host_arrays(arrays)
+        keep, ap, na = self._host_active(ActiveParticle)
+        self._ck(self.lib.mpg_dist_hydro_force(self.h, C.byref(v), C.byref(a), C.byref(times), ap, C.c_int64(na)))
 
     def walk_cost(self, n_own):
         """per-particle work of the last walk for the rank's own particles (float32 device tensor, a copy): feed it to

@@ -10,8 +10,8 @@
  * gathers the slot fields before the call and scatters the results after it.  The time-dependent scalars the reference derives
  * before its loops come from the reference's own functions and go over as one mpg_sph_times.
  * Compiled inside the reference tree (see gravity-hip.c).  One rank per GPU.  NTask > 1: mpg_dist_density / mpg_dist_hydro_force on the
- * table gravity-hip.c last handed to mpg_dist_force_tree_full (ghost columns travel inside the library); that path
- * takes every own gas particle as active, so it serves the steps on which all bins are active and stops with a message otherwise. */
+ * table gravity-hip.c last handed to mpg_dist_force_tree_full (ghost columns travel inside the library), with the
+ * step's ActiveParticle list. */
 #include <mpi.h>
 #include <math.h>
 #include <string.h>
@@ -31,20 +31,11 @@
 extern mpg_engine *mpg_shim_engine(void); /* gravity-hip.c: the rank's engine */
 extern mpg_dist *mpg_shim_dist(void);     /* gravity-hip.c: the rank's multi-rank state, NULL with one rank */
 
-/* the multi-rank SPH loops treat all own gas as active (mpgadget_hip.h, mpg_dist_density) */
-static void need_full_step(const ActiveParticles *act, int BlackHoleOn)
+/* the multi-rank density loop serves gas only */
+static void need_no_bh(int BlackHoleOn)
 {
-    if(act->ActiveParticle && act->NumActiveParticle != PartManager->NumPart)
-        endrun(5, "mpgadget_hip: the multi-rank SPH loops need a step with every particle active (%ld of %ld are)\n",
-               (long)act->NumActiveParticle, (long)PartManager->NumPart);
     if(BlackHoleOn)
         endrun(5, "mpgadget_hip: the multi-rank density loop does not serve black holes\n");
-}
-
-static void ck(int rc)
-{
-    if(rc)
-        endrun(5, "mpgadget_hip: %s\n", mpg_last_error());
 }
 
 void mpg_shim_set_densitypar(const struct density_params *dp)
@@ -180,8 +171,8 @@ void density(const ActiveParticles *act, int update_hsml, int DoEgyDensity, int 
     fill_times(&t, &times, CP, 0);
     walltime_measure("/SPH/Density/Init");
     if(mpg_shim_dist()) {
-        need_full_step(act, BlackHoleOn);
-        ck(mpg_dist_density(mpg_shim_dist(), &v, &H.A, &t, update_hsml, DoEgyDensity));
+        need_no_bh(BlackHoleOn);
+        ck(mpg_dist_density(mpg_shim_dist(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml, DoEgyDensity));
     }
     else
         ck(mpg_density(mpg_shim_engine(), &v, tree->BoxSize, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml,
@@ -236,8 +227,7 @@ void hydro_force(const ActiveParticles *act, const double atime, struct sph_pred
     fill_times(&t, &times, CP, atime);
     walltime_measure("/SPH/Hydro/Init");
     if(mpg_shim_dist()) {
-        need_full_step(act, 0);
-        ck(mpg_dist_hydro_force(mpg_shim_dist(), &v, &H.A, &t));
+        ck(mpg_dist_hydro_force(mpg_shim_dist(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle));
     }
     else
         ck(mpg_hydro_force(mpg_shim_engine(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle));

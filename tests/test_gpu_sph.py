@@ -135,6 +135,29 @@ def test_sph_peano_ranks_match_one(tmp_path):
         assert rel(d["maxsignalvel"][g], one["maxsignalvel"][g]) <= 1e-12, name
 
 
+@keep_artifacts_on_failure
+def test_sph_peano_substep_active_subset(tmp_path):
+    """A full step, then a sub-step (velocities and entropies changed, every third particle active) on 1 GPU and on 3 ranks through
+    mpg_dist_dev_density_active / _hydro_force_active, and on 2 ranks through the host forms with an ActiveParticle list: the active gas
+    gets the one-GPU sub-step's results, the inactive gas keeps the full step's."""
+    full = _run_hydro(tmp_path, "full.npz", 1, "single", 0)
+    one = _run_hydro(tmp_path, "one.npz", 1, "single", 0, every=3)
+    gas = one["typ"] == 0
+    act = gas & (np.arange(len(gas)) % 3 == 0)
+    inact = gas & ~act
+    for k in ("density", "divvel", "hydroacc_out", "dtentropy_out", "hsml"):
+        assert np.array_equal(one[k][inact], full[k][inact]), k           # the sub-step leaves inactive particles alone
+    for k in ("divvel", "hydroacc_out"):                                  # ... and recomputes the active ones (the velocities changed)
+        assert not np.array_equal(one[k][act], full[k][act]), k
+    for name, nproc, port, host in (("p3.npz", 3, 29609, False), ("h2.npz", 2, 29610, True)):
+        d = _run_hydro(tmp_path, name, nproc, "peano", port, host, every=3)
+        same = assert_hsml_parity(d["hsml"][gas], one["hsml"][gas], 113.1)
+        g = np.flatnonzero(gas)[same]
+        for k in ("density", "divvel", "curlvel", "dhsmlegyfac", "hydroacc_out", "dtentropy_out"):
+            assert rel(d[k][g], one[k][g]) <= 1e-9, (name, k)
+        assert rel(d["maxsignalvel"][g], one["maxsignalvel"][g]) <= 1e-12, name
+
+
 @pytest.mark.parametrize("pe", [0, 1])
 def test_density_hmax_hydro_parity(pkg, orc, pe):
     """density -> hmax moments -> hydro_force (run.c:466-489) with non-trivial velocities, entropies, kick / drift factors
@@ -358,7 +381,7 @@ def test_host_pointer_sph_path(pkg, orc):
     eng.close()
 
 
-def _run_hydro(tmp_path, name, nproc, mode, port, host=False):
+def _run_hydro(tmp_path, name, nproc, mode, port, host=False, every=0):
     import os
     import subprocess
     import sys
@@ -367,6 +390,8 @@ def _run_hydro(tmp_path, name, nproc, mode, port, host=False):
     env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MPG_MGPU_MODE=mode)
     if host:
         env["MPG_SPH_HOST"] = "1"
+    if every:
+        env["MPG_ACTIVE_EVERY"] = str(every)
     script = os.path.join(root, "tools", "mgpu_hydro_check.py")
     if nproc == 1:
         cmd = [sys.executable, script, out, "24"]

@@ -52,6 +52,15 @@ def arrays(m, hsml, v, e):
                 hydroacc_out=torch.zeros(m, 3, **f8), dtentropy_out=z1(), maxsignalvel=z1())
 
 
+every = int(os.environ.get("MPG_ACTIVE_EVERY", "0"))   # > 0: after the full step a sub-step in which every `every`-th particle is active
+
+
+def kick(a):
+    """what changes between the full step and the sub-step (stands for the kicks / drifts in between)"""
+    a["vel"] *= 1.1
+    a["entropy"] *= 1.05
+
+
 if mode == "single":
     a = arrays(N, g_hsml.clone(), g_vel, g_ent)
     eng.dev_bind_particles(g_pos, g_mass, box, type=g_typ)
@@ -59,6 +68,13 @@ if mode == "single":
     eng.dev_density(a, t)
     eng.dev_force_tree_calc_hmax()
     eng.dev_hydro_force(a, t)
+    if every:
+        kick(a)
+        ids = torch.arange(N, device=dev)
+        act = torch.nonzero((ids % every == 0) & (g_typ == 0)).squeeze(1).to(torch.int32).contiguous()
+        eng.dev_density(a, t, active=act)
+        eng.dev_force_tree_calc_hmax()
+        eng.dev_hydro_force(a, t, active=act)
     res = {k: a[k] for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel")}
 elif mode == "peano":
     # the library's choreography on the reference's decomposition (csrc/dist.hip): particles on the owners of their TopLeaves,
@@ -85,11 +101,21 @@ elif mode == "peano":
         df.host_force_tree_full(Prec)
         df.host_density(Prec, ha, t)
         df.host_hydro_force(Prec, ha, t)
+        if every:
+            kick(ha)
+            act = np.flatnonzero(o_ids.cpu().numpy() % every == 0).astype(np.int32)     # (dark matter among them: the library skips it)
+            df.host_density(Prec, ha, t, ActiveParticle=act)
+            df.host_hydro_force(Prec, ha, t, ActiveParticle=act)
         a = {k: torch.from_numpy(v).to(dev) for k, v in ha.items()}
     else:
         df.force_tree_build(o_pos, o_mass)
         df.density(o_typ.contiguous(), a, t)
         df.hydro_force(n_own, a, t)
+        if every:
+            kick(a)
+            act = torch.nonzero(o_ids % every == 0).squeeze(1).to(torch.int32).contiguous()
+            df.density(o_typ.contiguous(), a, t, active=act)
+            df.hydro_force(n_own, a, t, active=act)
     res = {}
     for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel"):
         full = torch.zeros((N,) + tuple(a[k].shape[1:]), **f8)
