@@ -2445,3 +2445,88 @@ int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_
 }
 
 } // extern "C"
+
+/* ---- hierarchical gravity on several ranks: the tree of the ACTIVE particles only (force_tree_active_moments, forcetree.c:129-148;
+ * hierarchical_gravity_accelerations of timestep.c) -------------------------------------------------------------------------------
+ * The active sets of the short time bins are sparse: the tree of such a set has cells with <= 8 particles far above any domain level,
+ * which the all-reduced top of mpg_dist_dev_force_tree_build excludes.  They are also small.  So every rank receives the whole active
+ * set (28 bytes per particle, one all-gather), builds ITS tree itself - the tree one GPU would build - and walks its own members. */
+namespace {
+struct InRange {
+    int lo, hi;
+    __host__ __device__ bool operator()(const unsigned &ci) const { return (int)ci >= lo && (int)ci < hi; }
+};
+} // namespace
+
+extern "C" int mpg_dist_dev_grav_short_tree_active_tree(mpg_dist *d, int64_t n_act, const double *d_pos, const float *d_mass, const double *d_oldacc,
+                                                        double *d_accel, double *d_potential, double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(d && (n_act == 0 || (d_pos && d_mass && d_accel)), "null argument");
+    MPG_CHECK(d->box > 0, "mpg_dist: mpg_dist_set_domain first (the box size)");
+    mpg_engine *e = d->eng;
+    MPG_HIP(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    // this rank's active particles as one host block: [n][3] positions, then [n] masses
+    std::vector<char> blk(sizeof(int64_t) + (size_t)n_act * 28);
+    memcpy(blk.data(), &n_act, sizeof(int64_t));
+    if(n_act > 0) {
+        MPG_HIP(hipMemcpyAsync(blk.data() + 8, d_pos, (size_t)n_act * 24, hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipMemcpyAsync(blk.data() + 8 + (size_t)n_act * 24, d_mass, (size_t)n_act * 4, hipMemcpyDeviceToHost, st));
+    }
+    sync(d);
+    std::vector<std::vector<char>> all;
+    allgather_host(d, blk.data(), (int64_t)blk.size(), all);
+    int64_t ntot = 0, off = 0;
+    std::vector<int64_t> cnt(d->nt);
+    for(int r = 0; r < d->nt; r++) {
+        memcpy(&cnt[r], all[r].data(), sizeof(int64_t));
+        if(r < d->me)
+            off += cnt[r];
+        ntot += cnt[r];
+    }
+    MPG_CHECK(ntot < (1ll << 27), "mpg_dist_dev_grav_short_tree_active_tree: the active set is not small (use the tree of all particles)");
+    d->n_own_tree = -1; // the local tree of mpg_dist_dev_force_tree_build is gone after this call
+    d->sph_n_own = -1;
+    if(ntot == 0)
+        return 0;
+    d->lpos.reserve(3 * (size_t)ntot + 3);
+    d->lmass.reserve((size_t)ntot + 1);
+    int64_t at = 0;
+    for(int r = 0; r < d->nt; r++) {
+        if(cnt[r] > 0) {
+            MPG_HIP(hipMemcpyAsync(d->lpos.p + 3 * at, all[r].data() + 8, (size_t)cnt[r] * 24, hipMemcpyHostToDevice, st));
+            MPG_HIP(hipMemcpyAsync(d->lmass.p + at, all[r].data() + 8 + (size_t)cnt[r] * 24, (size_t)cnt[r] * 4, hipMemcpyHostToDevice, st));
+        }
+        at += cnt[r];
+    }
+    sync(d); // (`all` is read by the copies)
+    MPG_CHECK(mpg_dev_bind_particles(e, ntot, d->lpos.p, d->lmass.p, nullptr, d->box) == 0, mpg_last_error());
+    MPG_CHECK(mpg_dev_force_tree_build(e, 63) == 0, mpg_last_error());
+    if(n_act == 0)
+        return 0;
+    // own members in tree order; inputs / outputs over the whole set, the own range copied in and out
+    d->targets.reserve((size_t)ntot + 1);
+    d->scount.reserve(4);
+    size_t tb = 0;
+    const InRange mine{(int)off, (int)(off + n_act)};
+    MPG_HIP(rocprim::select(nullptr, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, mine, st));
+    d->tmp.reserve(tb + 16);
+    MPG_HIP(rocprim::select((void *)d->tmp.p, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, mine, st));
+    d->o_prev.reserve((size_t)ntot + 1);
+    d->o_acc.reserve(3 * (size_t)ntot + 3);
+    d->o_pot.reserve((size_t)ntot + 1);
+    MPG_HIP(hipMemsetAsync(d->o_prev.p, 0, (size_t)ntot * sizeof(double), st));
+    if(d_oldacc)
+        MPG_HIP(hipMemcpyAsync(d->o_prev.p + off, d_oldacc, (size_t)n_act * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if(d_potential)
+        MPG_HIP(hipMemcpyAsync(d->o_pot.p + off, d_potential, (size_t)n_act * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MPG_CHECK(mpg_dev_grav_short_tree(e, d->o_prev.p, nullptr, nullptr, d->targets.p, n_act, d->o_acc.p, d_potential ? d->o_pot.p : nullptr, rho0) == 0,
+              mpg_last_error());
+    MPG_HIP(hipMemcpyAsync(d_accel, d->o_acc.p + 3 * off, (size_t)n_act * 24, hipMemcpyDeviceToDevice, st));
+    if(d_potential)
+        MPG_HIP(hipMemcpyAsync(d_potential, d->o_pot.p + off, (size_t)n_act * sizeof(double), hipMemcpyDeviceToDevice, st));
+    sync(d);
+    d->o_n = -1; // (the staging columns of the host drop-in calls were reused)
+    API_END
+}

@@ -191,6 +191,12 @@ class DistForce:
         self._ck(self.lib.mpg_dist_dev_grav_short_tree_active(self.h, p(active), C.c_int64(0 if active is None else active.shape[0]), p(oldacc),
                                                               p(prev_accel), p(gravpm), p(accel), p(potential), C.c_double(rho0)))
 
+    def grav_short_tree_active_tree(self, pos, mass, accel, oldacc=None, potential=None, rho0=0.0):
+        """hierarchical gravity: the active particles (compacted device tensors of this rank's members) on the tree of the active set"""
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._ck(self.lib.mpg_dist_dev_grav_short_tree_active_tree(self.h, C.c_int64(pos.shape[0]), p(pos), p(mass), p(oldacc), p(accel),
+                                                                   p(potential), C.c_double(rho0)))
+
     # ---- domain_decompose_full + domain_exchange through the library (the C++ form of domain_peano.PeanoDomain)
     def domain_decompose(self, pos, box, garbage=None, overdecomposition=4, global_sorting=True, cost=None):
         """Returns (NTopNodes, NTopLeaves); the decomposition stays in the library (domain_get copies it out)."""

@@ -456,6 +456,22 @@ def test_peano_domain_substep_active_subset(tmp_path):
         assert_accel_parity(d[act, 0:3], one[act, 0:3])
 
 
+@keep_artifacts_on_failure
+def test_peano_domain_hierarchical_active_tree(tmp_path):
+    """The hierarchical gravity loop's force on several ranks (force_tree_active_moments + grav_short_tree on the ACTIVE particles only):
+    every seventh particle is active, spread over 3 ranks; mpg_dist_dev_grav_short_tree_active_tree gathers the (small) active set on
+    every rank, builds the tree one GPU builds and walks the rank's members: the one-GPU accelerations, to rounding."""
+    n = 36
+    env = {"MPG_ACTIVE_EVERY": "7", "MPG_ACTIVE_TREE": "1"}
+    one = _run_mgpu(tmp_path, "one.npy", 1, "single", 0, ic="s_clust", n=n, env_extra=env)
+    act = np.arange(len(one)) % 7 == 0
+    assert np.abs(one[act, 0:3]).min() > 0 and np.all(one[~act, 0:3] == 0)
+    for name, nproc, port in (("p1.npy", 1, 0), ("p3.npy", 3, 29611)):
+        d = _run_mgpu(tmp_path, name, nproc, "peano" if nproc > 1 else "peano1", port, ic="s_clust", n=n, env_extra=env)
+        assert np.all(d[~act, 0:3] == 0), name
+        assert np.abs(d[act, 0:3] - one[act, 0:3]).max() <= 1e-13 * np.abs(one[act, 0:3]).max(), name
+
+
 @pytest.mark.parametrize("ic", ["s_grid", "s_zel", "s_clust"])
 def test_full_size_256_properties(pkg, orc, ic):
     """256^3, Nmesh 512 (BASELINE configs[1]) on the device-resident path, on the three input sets of SURVEY 8(d) (the jittered grid,

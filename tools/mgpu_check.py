@@ -45,6 +45,8 @@ if world == 1 and mode not in ("slab1", "domain1", "peano1"):
     eng.dev_gravpm_force(gravpm, pot)
     eng.dev_force_tree_build()
     act = torch.arange(0, N, every, dtype=torch.int32, device=dev) if every else None
+    if every and os.environ.get("MPG_ACTIVE_TREE"):      # hierarchical gravity: the tree holds the active particles only
+        eng.dev_force_tree_active_moments(act)
     eng.dev_grav_short_tree(acc, oldacc=old, active=act)
 elif mode == "replicated":
     eng.dev_gravpm_force(gravpm, pot)
@@ -69,7 +71,13 @@ elif mode.startswith("peano"):
     df.set_domain(dom, rcut)
     f8 = dict(dtype=torch.float64, device=dev)
     ga, gg, gp = torch.zeros(n_own, 3, **f8), torch.zeros(n_own, 3, **f8), torch.zeros(n_own, **f8)
-    if every:       # the three calls of a sub-step: the tree holds every particle, the active ones are walked
+    if every and os.environ.get("MPG_ACTIVE_TREE"):
+        df.gravpm_force(opos, omass, gg, gp)
+        act = torch.nonzero(oids % every == 0).squeeze(1)
+        aa = torch.zeros(act.shape[0], 3, **f8)
+        df.grav_short_tree_active_tree(opos[act].contiguous(), omass[act].contiguous(), aa, oldacc=torch.full((act.shape[0],), 1e-7, **f8))
+        ga[act] = aa
+    elif every:     # the three calls of a sub-step: the tree holds every particle, the active ones are walked
         df.gravpm_force(opos, omass, gg, gp)
         df.force_tree_build(opos, omass)
         act = torch.nonzero(oids % every == 0).squeeze(1).to(torch.int32).contiguous()
