@@ -401,12 +401,6 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         io.list_prio = lp;
         io.eval_prio = ep;
     }
-    { // adjacent opened leaves packed into full 8-particle list entries (grav_walk_split.hip): MPG_PACK_LEAVES=1.  Off by default:
-      // measured at 256^3 (profiles/r02b_walk_knobs.txt) the evaluation kernel's saving is eaten by the list kernel, which is the
-      // one on the critical path of the two overlapped streams
-        const char *e = getenv("MPG_PACK_LEAVES");
-        io.pack_leaves = (e && e[0] == '1') ? 1 : 0;
-    }
     if(eng->count)
         MPG_HIP(hipMemsetAsync(eng->counters.p, 0, 16 * sizeof(unsigned long long), eng->stream));
     eng->timer.start(eng->stream);

@@ -53,9 +53,10 @@ template <typename T> struct HostBuf {
 // thread moves ~2 GB/s of them; the reference's callers have the cores of the rank idle while the GPU works anyway.
 template <class F> inline void parallel_for(int64_t n, F f)
 {
+    static const unsigned cap = getenv("MPG_HOST_THREADS") ? (unsigned)atoi(getenv("MPG_HOST_THREADS")) : 32u;
     unsigned T = std::thread::hardware_concurrency();
-    if(T > 32)
-        T = 32;
+    if(T > cap)
+        T = cap;
     if(T < 2 || n < 131072) {
         f((int64_t)0, n);
         return;

@@ -17,7 +17,6 @@ struct WalkIO {
     const float *tab_force = nullptr;  // [NTAB] shortrange_table           (gravity.c:20)
     const float *tab_pot = nullptr;    // [NTAB] shortrange_table_potential
     unsigned long long *counters = nullptr; // [8] pp interactions, nodes visited, nodes used, burst statistics (COUNT builds only)
-    int pack_leaves = 0;               // split walk: pack short adjacent leaves into full list entries (0: one entry per leaf)
     int list_prio = 0, eval_prio = 0;  // split walk: s_setprio of the two kernels' waves (experiment knobs MPG_LIST_PRIO / MPG_EVAL_PRIO)
     float *cost = nullptr;             // caller order [n] or null: per-target work of this walk (split walk: 8 per leaf entry + 1 per node
                                        // used + 8 per traversal step), the load measure of the domain decomposition (domain.c:611)

@@ -172,7 +172,7 @@ struct ChunkIter {
 template <bool COUNT, int MODE, bool O32>
 __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ stack,
                                             const int cap, const int lane, const int s, const int gshift, const bool valid, const double px,
-                                            const double py, const double pz, const double aold, const bool pack, const unsigned guard_max,
+                                            const double py, const double pz, const double aold, const unsigned guard_max,
                                             unsigned *__restrict__ ctl, int &nleaf, int &nnode, bool &wrapped, bool &overflow, unsigned &c_pp,
                                             unsigned &c_vis, unsigned &c_used, unsigned &st_a, unsigned &st_al, unsigned &nsteps)
 {
@@ -209,12 +209,15 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
         const NodeGeo g = ld<O32>(tv.geoB, my);
         const Src4 mom = ld<O32>(tv.momB, my);
         const NodeLinkB lk = ld<O32>(tv.linkB, my);
-        double dx, dy, dz, cdx, cdy, cdz;
+        // Both tests on the centre distances are tests on their LARGEST: "cdx > eff || cdy > eff || cdz > eff" is cmax > eff and
+        // "cdx < inside && cdy < inside && cdz < inside" is cmax < inside (no NaNs here).  Written with the three values, hipcc
+        // materialised each |.| in registers and chained five v_max_f64 plus three compares; this form is two v_max_f64 with |.|
+        // source modifiers and two compares (10 VALU instructions less per step of ~87).
+        double dx, dy, dz, cmax;
         bool wr = false;
         if(MODE == 0) {
-            cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
-            cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
-            cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+            cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
+                        fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
             dx = nearest_img(mom.x - px, gp.box, gp.invbox);
             dy = nearest_img(mom.y - py, gp.box, gp.invbox);
             dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
@@ -226,18 +229,14 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
                 const double ky = rint((g.cy - py) * gp.invbox);
                 const double kz = rint((g.cz - pz) * gp.invbox);
                 const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
-                cdx = fabs(g.cx - qx);
-                cdy = fabs(g.cy - qy);
-                cdz = fabs(g.cz - qz);
+                cmax = fmax(fmax(fabs(g.cx - qx), fabs(g.cy - qy)), fabs(g.cz - qz));
                 dx = mom.x - qx;
                 dy = mom.y - qy;
                 dz = mom.z - qz;
                 wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
             }
             else {
-                cdx = fabs(g.cx - px);
-                cdy = fabs(g.cy - py);
-                cdz = fabs(g.cz - pz);
+                cmax = fmax(fmax(fabs(g.cx - px), fabs(g.cy - py)), fabs(g.cz - pz));
                 dx = mom.x - px;
                 dy = mom.y - py;
                 dz = mom.z - pz;
@@ -251,51 +250,30 @@ __device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams
                 dy = fma(-jy, gp.box, mom.y - py);
                 dz = fma(-jz, gp.box, mom.z - pz);
                 wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
-                if(MODE == 2) {
-                    cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
-                    cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
-                    cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
-                }
+                if(MODE == 2)
+                    cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
+                                fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
             }
         }
         const double r2 = dx * dx + dy * dy + dz * dz;
         // shall_we_discard_node, gravshort-tree.c:198-215
         const double eff = fma(0.5, g.len, gp.rcut);
-        const bool discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
+        const bool discard = (r2 > gp.rcut2) && (cmax > eff);
         // shall_we_open_node, gravshort-tree.c:220-241
         const double l2 = g.len * g.len;
         const double inside = 0.6 * g.len;
-        const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) ||
-                          (cdx < inside && cdy < inside && cdz < inside);
+        const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cmax < inside);
         const bool keep = mine && !discard;
         const bool b_node = keep && !open;                                   // used unopened: a 1-element source
         const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
         const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
-        // Leaf entries.  One entry = up to 8 consecutive particles (tree order), evaluated by the 8 lanes of the group in one
-        // pair step.  The children of a node hold consecutive particle ranges (octant order = tree order), so a run of adjacent
-        // opened leaves with T particles in all is ONE contiguous range and becomes ceil(T / 8) full entries instead of one
-        // (partly filled) entry per leaf: leaves hold 5.5 - 5.8 of 8 particles on the S-grid and Zel'dovich sets, so a quarter of
-        // the evaluation kernel's pair steps carried idle lanes.  The interaction set is unchanged; only the grouping of the
-        // sources into steps is.  The run of lane s is found from the group's 8-bit mask of opened leaves with bit operations
-        // (first lane h of the run: highest clear bit below s; last lane: first clear bit above s) and two cross-lane reads
-        // (the run's first particle, the end of its last leaf); lane h + q writes entry q of the run.  MPG_PACK_LEAVES=1 turns it
-        // on; measured at 256^3 (Zel'dovich set): 117.9 ms per step with, 113.6 without - runs are short in the shell of the cut-off
-        // cube, where most leaves are, and the list kernel, not the evaluation, is on the critical path.  (The first form, two
-        // segmented scans of ~55 instructions per step, was no better.)
-        bool has_ent = b_leaf;
-        unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-        if(pack && any_lane(b_leaf && lk.pcount != NMAXCHILD)) {
-            const unsigned gm_open = (unsigned)((__builtin_amdgcn_ballot_w64(b_leaf) >> gshift) & 0xffull);
-            const unsigned zb = ~gm_open & below;                       // lanes below s that hold no opened leaf
-            const int h = zb ? 32 - __clz((int)zb) : 0;                 // first lane of the run that contains lane s
-            const int last = s + __ffs((int)~(gm_open >> s)) - 2;       // its last lane (bit 0 of gm_open >> s is this lane's own)
-            const int pend = lk.pstart + lk.pcount;
-            const int rs = __shfl(lk.pstart, gshift + h);
-            const int re = __shfl(pend, gshift + (b_leaf ? last : s));
-            const int T = re - rs, q8 = (s - h) << 3;
-            has_ent = b_leaf && q8 < T;
-            ent_val = ((unsigned)(rs + q8) << 3) | (unsigned)(((T - q8 < 8) ? T - q8 : 8) - 1);
-        }
+        // Leaf entries: one entry = one opened leaf (<= 8 consecutive particles in tree order), evaluated by the 8 lanes of the group
+        // in one pair step.  (Packing runs of adjacent opened leaves into full entries was built and measured twice - 117.9 against
+        // 113.6 ms per step with overlapped slices, 109.2 against 102.0 with one slice: two thirds of the leaves lie in the shell of
+        // the cut-off cube, where discards fragment the runs, and the list kernel pays more than the evaluation saves.  Removed in
+        // round 2; the code is in the history.)
+        const bool has_ent = b_leaf;
+        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
         const unsigned gm_leaf = (unsigned)((__builtin_amdgcn_ballot_w64(has_ent) >> gshift) & 0xffull);
         const unsigned gm_node = (unsigned)((__builtin_amdgcn_ballot_w64(b_node) >> gshift) & 0xffull);
         const unsigned gm_push = (unsigned)((__builtin_amdgcn_ballot_w64(b_push) >> gshift) & 0xffull);
@@ -387,14 +365,14 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists(const TreeView tv, cons
         if(FASTWRAP) {
             const bool near_face = valid && (fmin(fmin(px, py), pz) < face || fmax(fmax(px, py), pz) > gp.box - face);
             if(!any_lane(near_face))
-                ok = walk_target<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, io.pack_leaves != 0, guard_max, ctl, nleaf, nnode, wrapped,
+                ok = walk_target<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
                                            overflow, c_pp, c_vis, c_used, st_a, st_al, nsteps);
             else
-                ok = walk_target<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, io.pack_leaves != 0, guard_max, ctl, nleaf, nnode, wrapped,
+                ok = walk_target<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
                                            overflow, c_pp, c_vis, c_used, st_a, st_al, nsteps);
         }
         else
-            ok = walk_target<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, io.pack_leaves != 0, guard_max, ctl, nleaf, nnode, wrapped, overflow,
+            ok = walk_target<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped, overflow,
                                        c_pp, c_vis, c_used, st_a, st_al, nsteps);
         if(!ok)
             return;
@@ -452,12 +430,11 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
                                            const double l2, const double inside, const double ml2, const double px, const double py,
                                            const double pz, const double aold, bool &discard, bool &open, bool &wr)
 {
-    double dx, dy, dz, cdx, cdy, cdz;
+    double dx, dy, dz, cmax; // (cmax: see walk_target)
     wr = false;
     if(MODE == 0) {
-        cdx = fabs(nearest_img(g.cx - px, gp.box, gp.invbox));
-        cdy = fabs(nearest_img(g.cy - py, gp.box, gp.invbox));
-        cdz = fabs(nearest_img(g.cz - pz, gp.box, gp.invbox));
+        cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
+                    fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
         dx = nearest_img(mom.x - px, gp.box, gp.invbox);
         dy = nearest_img(mom.y - py, gp.box, gp.invbox);
         dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
@@ -468,24 +445,20 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
             const double ky = rint((g.cy - py) * gp.invbox);
             const double kz = rint((g.cz - pz) * gp.invbox);
             const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
-            cdx = fabs(g.cx - qx);
-            cdy = fabs(g.cy - qy);
-            cdz = fabs(g.cz - qz);
+            cmax = fmax(fmax(fabs(g.cx - qx), fabs(g.cy - qy)), fabs(g.cz - qz));
             dx = mom.x - qx;
             dy = mom.y - qy;
             dz = mom.z - qz;
             wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
         }
         else {
-            cdx = fabs(g.cx - px);
-            cdy = fabs(g.cy - py);
-            cdz = fabs(g.cz - pz);
+            cmax = fmax(fmax(fabs(g.cx - px), fabs(g.cy - py)), fabs(g.cz - pz));
             dx = mom.x - px;
             dy = mom.y - py;
             dz = mom.z - pz;
         }
         // (see walk_target.  A wave-uniform branch around per-lane selects: written as `if(special)` the block was flattened into
-        // the step by hipcc - 35 instructions per target on every step for the two steps per target that need them)
+        // the step by hipcc)
         if(any_lane(special)) {
             const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
             dx = special ? fma(-jx, gp.box, mom.x - px) : dx;
@@ -493,15 +466,15 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
             dz = special ? fma(-jz, gp.box, mom.z - pz) : dz;
             wr = wr || (special && ((jx != 0.0) || (jy != 0.0) || (jz != 0.0)));
             if(MODE == 2) {
-                cdx = special ? fabs(nearest_img(g.cx - px, gp.box, gp.invbox)) : cdx;
-                cdy = special ? fabs(nearest_img(g.cy - py, gp.box, gp.invbox)) : cdy;
-                cdz = special ? fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)) : cdz;
+                const double cm = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
+                                       fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
+                cmax = special ? cm : cmax;
             }
         }
     }
     const double r2 = dx * dx + dy * dy + dz * dz;
-    discard = (r2 > gp.rcut2) && (cdx > eff || cdy > eff || cdz > eff);
-    open = ((!gp.use_bh) && (ml2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cdx < inside && cdy < inside && cdz < inside);
+    discard = (r2 > gp.rcut2) && (cmax > eff);
+    open = ((!gp.use_bh) && (ml2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cmax < inside);
 }
 
 // state of one target of a pair (group-uniform except wrap_lane)
@@ -932,10 +905,12 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
     // MPG_LISTS_BLOCKS (6 | 8) and MPG_EVAL_BLOCKS (4 | 5 | 6); the defaults are the measured best (profiles/r02b_walk_knobs.txt)
     static const int lists_blk_env = getenv("MPG_LISTS_BLOCKS") ? atoi(getenv("MPG_LISTS_BLOCKS")) : 0;
     static const int eval_blk = getenv("MPG_EVAL_BLOCKS") ? atoi(getenv("MPG_EVAL_BLOCKS")) : MPG_EVAL_BLOCKS;
-    // MPG_LISTS_PAIR: 0 one target per group of 8 lanes (k_walk_lists), 1 two (k_walk_lists2; its stack entries hold 27-bit node indices)
-    static const int pair_env = getenv("MPG_LISTS_PAIR") ? atoi(getenv("MPG_LISTS_PAIR")) : 0;
+    // MPG_LISTS_PAIR: 1 (default) two targets per group of 8 lanes (k_walk_lists2; its stack entries hold 27-bit node indices, larger
+    // trees take the other kernel), 0 one (k_walk_lists).  Measured at 256^3, ms per step, pair / single: Zel'dovich 97.9 / 100.2,
+    // S-grid 82.0 / 83.7, clustered 177.5 / 187.1 (same lists, bit-identical results)
+    static const int pair_env = getenv("MPG_LISTS_PAIR") ? atoi(getenv("MPG_LISTS_PAIR")) : 1;
     const bool pair = pair_env != 0 && tv.nnodes < (1ll << 27);
-    const int lists_blk = lists_blk_env ? lists_blk_env : (pair ? 4 : 6); // (the pair kernel: 98 VGPRs without spills = 5 waves per SIMD)
+    const int lists_blk = lists_blk_env ? lists_blk_env : (pair ? 5 : 6); // (the pair kernel: 5 waves per SIMD, 96 VGPRs; measured best)
     auto kl = pair ? (lists_blk == 4   ? k_walk_lists2<COUNT, FASTWRAP, O32, 4>
                       : lists_blk == 5 ? k_walk_lists2<COUNT, FASTWRAP, O32, 5>
                                        : k_walk_lists2<COUNT, FASTWRAP, O32, 6>)
