@@ -426,7 +426,8 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists(const TreeView tv, cons
 // the reference's tests for one node and one target (shall_we_discard_node / shall_we_open_node, gravshort-tree.c:198-241);
 // MODE as in walk_target; special: the root or one of its children (exact images for both the centre and the centre of mass)
 template <int MODE>
-__device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &g, const Src4 &mom, const bool special, const double eff,
+__device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &g, const Src4 &mom, const bool special,
+                                           const bool any_special /* wave-uniform */, const double eff,
                                            const double l2, const double inside, const double ml2, const double px, const double py,
                                            const double pz, const double aold, bool &discard, bool &open, bool &wr)
 {
@@ -459,7 +460,7 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
         }
         // (see walk_target.  A wave-uniform branch around per-lane selects: written as `if(special)` the block was flattened into
         // the step by hipcc)
-        if(any_lane(special)) {
+        if(any_special) {
             const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
             dx = special ? fma(-jx, gp.box, mom.x - px) : dx;
             dy = special ? fma(-jy, gp.box, mom.y - py) : dy;
@@ -501,7 +502,7 @@ __device__ __forceinline__ bool walk_pair(const TreeView &tv, const GravParams &
             stack[0] = live; // the root: first 0, one "child"
         sp = 1;
     }
-    unsigned guard = 0;
+    unsigned guard = 0, steps2 = 0;
     bool err = false;
     for(;;) {
         const bool can = sp > 0;
@@ -515,26 +516,29 @@ __device__ __forceinline__ bool walk_pair(const TreeView &tv, const GravParams &
         unsigned m2 = range & live; // (live < 4)
         // a target whose step might not fit its lists goes to the fallback kernel (the test k_walk_lists makes before each of a
         // target's steps); its mate walks on, and the entries it leaves on the stack alone are popped unused
-        const unsigned ov = (((A.nleaf + A.nnode + 8 > cap) ? 1u : 0u) | ((B.nleaf + B.nnode + 8 > cap) ? 2u : 0u)) & m2;
-        overflowed |= ov;
-        live &= ~ov;
-        m2 &= ~ov;
+        // (rare: a wave-uniform branch keeps the mask arithmetic off the common path)
+        if(any_lane(A.nleaf + A.nnode + 8 > cap || B.nleaf + B.nnode + 8 > cap)) {
+            const unsigned ov = (((A.nleaf + A.nnode + 8 > cap) ? 1u : 0u) | ((B.nleaf + B.nnode + 8 > cap) ? 2u : 0u)) & m2;
+            overflowed |= ov;
+            live &= ~ov;
+            m2 &= ~ov;
+        }
         const int nch = m2 ? (int)((range >> 2) & 7u) + 1 : 0;
         const bool mine = s < nch;
         const unsigned my = mine ? (range >> 5) + (unsigned)s : 0u;
         const NodeGeo g = ld<O32>(tv.geoB, my);
         const Src4 mom = ld<O32>(tv.momB, my);
         const NodeLinkB lk = ld<O32>(tv.linkB, my);
-        A.nsteps += m2 & 1u;
-        B.nsteps += m2 >> 1;
+        steps2 += (m2 & 1u) | ((m2 & 2u) << 15); // both targets' step counts in one word (A: low half, B: high half; < 2^16 each)
         const double eff = fma(0.5, g.len, gp.rcut);
         const double l2 = g.len * g.len;
         const double inside = 0.6 * g.len;
         const double ml2 = mom.m * l2;
         const bool special = MODE != 0 && mine && my <= 8u;
+        const bool any_special = MODE != 0 && any_lane(special);
         bool dA, oA, wA, dB, oB, wB;
-        node_tests<MODE>(gp, g, mom, special, eff, l2, inside, ml2, A.px, A.py, A.pz, A.aold, dA, oA, wA);
-        node_tests<MODE>(gp, g, mom, special, eff, l2, inside, ml2, B.px, B.py, B.pz, B.aold, dB, oB, wB);
+        node_tests<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, A.px, A.py, A.pz, A.aold, dA, oA, wA);
+        node_tests<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, B.px, B.py, B.pz, B.aold, dB, oB, wB);
         const bool keepA = mine && (m2 & 1u) && !dA, keepB = mine && (m2 & 2u) && !dB;
         const bool isleaf = lk.pcount > 0, isint = lk.pcount <= 0 && lk.nchild > 0;
         const bool nodeA = keepA && !oA, nodeB = keepB && !oB;
@@ -586,6 +590,8 @@ __device__ __forceinline__ bool walk_pair(const TreeView &tv, const GravParams &
             }
         }
     }
+    A.nsteps = steps2 & 0xffffu;
+    B.nsteps = steps2 >> 16;
     if(err) {
         if(lane == 0)
             atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
