@@ -73,3 +73,26 @@ def run_ranks(cmd, env, log_path, timeout=900):
             f.write("cmd: %s\n---- stdout ----\n%s\n---- stderr ----\n%s\n" % (" ".join(cmd), r.stdout, r.stderr))
     assert r.returncode == 0, r.stderr[-3000:]
     return r
+
+
+class phase_clock:
+    """Wall-clock of the phases of a long test, appended to gpurun_out/flake/phases.log (one line per test run): two of ~40 full suites
+    of round 2 spent 10 extra minutes inside test_full_size_256_properties[s_clust] and passed; this shows in which phase the next time."""
+
+    def __init__(self, name):
+        import time
+        self.name, self.t0, self.marks, self.time = name, time.perf_counter(), [], time
+
+    def mark(self, what):
+        t = self.time.perf_counter()
+        self.marks.append("%s %.1fs" % (what, t - self.t0))
+        self.t0 = t
+
+    def write(self):
+        try:
+            d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "flake")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "phases.log"), "a") as f:
+                f.write("%s pid %d: %s\n" % (self.name, os.getpid(), ", ".join(self.marks)))
+        except OSError:
+            pass

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import keep_artifacts_on_failure, run_ranks
+from conftest import keep_artifacts_on_failure, phase_clock, run_ranks
 
 from oracle import oracle as O
 
@@ -483,8 +483,10 @@ def test_full_size_256_properties(pkg, orc, ic):
       * PM momentum conservation: sum_i m_i GravPM_i = 0;
       * 2048 random targets agree with the oracle walking the oracle-built tree of all 16.8 M particles."""
     import torch
+    clk = phase_clock("full_size_256[%s]" % ic)
     n, nmesh = 256, 512
     pos, mass, box = getattr(pkg.ics, ic)(n)
+    clk.mark("ics")
     N = len(pos)
     eng = pkg.Engine(0)
     setup_engine(eng, box, n, nmesh, TreeUseBH=0)
@@ -498,8 +500,11 @@ def test_full_size_256_properties(pkg, orc, ic):
     eng.dev_force_tree_build()
     if ic != "s_grid":       # a realistic OldAcc for the relative criterion (with 1e-7 every node of the dense clump would be opened)
         old = torch.clamp(gpm.norm(dim=1) / G, min=1e-7).contiguous()
+    eng.synchronize()
+    clk.mark("pm+tree")
     eng.dev_grav_short_tree(acc, oldacc=old)
     eng.synchronize()
+    clk.mark("walk (kernel, capacity, fallback targets) = %s" % (eng.walk_choice(),))
     c = eng.walk_counters()
     a = acc.cpu().numpy()
     g = gpm.cpu().numpy()
@@ -513,12 +518,16 @@ def test_full_size_256_properties(pkg, orc, ic):
     assert np.abs(g.sum(0)).max() <= 1e-9 * np.abs(g).sum()
     st = eng.tree_stats()
     assert st.NumParticles == N and abs(st.root_mass - N) < 1e-6
+    clk.mark("checks")
     tr = orc.tree(pos, mass, box, father=False)
+    clk.mark("oracle tree")
     assert tr.numnodes >= st.numnodes
     par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
     par.TreeUseBH = 0
     act = np.sort(np.random.RandomState(1).choice(N, 2048, replace=False)).astype(np.int32)
     ao, _, co, _ = tr.grav_short_tree(par, oldacc=old.cpu().numpy(), active=act)
+    clk.mark("oracle walk")
+    clk.write()
     assert_accel_parity(a[act], ao[act])
     eng.close()
 
