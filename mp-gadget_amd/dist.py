@@ -103,7 +103,12 @@ class TorchComm:
                 Rhost, S, R = R, S.to(self.device), torch.empty(R.shape[0], dtype=torch.uint8, device=self.device)
             packed = lambda b, d: all(d[i] == sum(b[:i]) for i in range(w))
             piece = max(A2A_MAX_BYTES // w, 1)
-            nchunk = max((max(max(sb), max(rb)) + piece - 1) // piece, 1)
+            # the number of pieces must be the same on every rank (each piece is one collective): the largest block of ANY rank decides.
+            # (Round 2 first took the local maximum; ranks whose largest blocks fell on different sides of a piece boundary then issued
+            # different numbers of collectives - gloo aborts the process on the size mismatch, RCCL would hang.)
+            big = torch.tensor([max(max(sb), max(rb))], dtype=torch.int64, device=self.device if self.on_device else "cpu")
+            dist.all_reduce(big, op=dist.ReduceOp.MAX, group=self.group)
+            nchunk = max((int(big.item()) + piece - 1) // piece, 1)
             if nchunk == 1 and packed(sb, sd) and packed(rb, rd):
                 dist.all_to_all_single(R[:sum(rb)], S[:sum(sb)], rb, sb, group=self.group)
             else:

@@ -16,8 +16,10 @@ static int cb_alltoall_i64(void *ctx, const int64_t *send, int64_t *recv)
     return MPI_Alltoall((void *)send, 1, MPI_INT64_T, recv, 1, MPI_INT64_T, *(MPI_Comm *)ctx) != MPI_SUCCESS;
 }
 
-/* counts arrive in bytes; every message of the library is a multiple of 8 bytes (32-byte rows, complex doubles, mesh planes), so
- * the exchange runs in 8-byte units and int counts reach 16 GiB per peer */
+/* counts arrive in bytes.  MPI counts are ints: an exchange whose blocks and displacements all stay below 2 GiB ON EVERY RANK goes in
+ * bytes; otherwise in 8-byte units (the large messages of the library - 32 / 48 / 128-byte rows, complex doubles, mesh planes - are
+ * multiples of 8 bytes), which reaches 16 GiB per peer.  The unit is agreed with one MPI_Allreduce so that all ranks use the same
+ * datatype (the type signatures of sender and receiver must match). */
 static int cb_alltoallv(void *ctx, const void *send, const int64_t *sb, const int64_t *sd, void *recv, const int64_t *rb, const int64_t *rd,
                         int on_device)
 {
@@ -25,19 +27,32 @@ static int cb_alltoallv(void *ctx, const void *send, const int64_t *sb, const in
     MPI_Comm comm = *(MPI_Comm *)ctx;
     int nt, rc = 0;
     MPI_Comm_size(comm, &nt);
+    int small = 1, all_small = 0;
+    for(int r = 0; r < nt; r++)
+        if(sb[r] > INT_MAX || sd[r] > INT_MAX || rb[r] > INT_MAX || rd[r] > INT_MAX)
+            small = 0;
+    if(MPI_Allreduce(&small, &all_small, 1, MPI_INT, MPI_MIN, comm) != MPI_SUCCESS)
+        return 1;
+    const int64_t unit = all_small ? 1 : 8;
     int *c = (int *)malloc(4 * (size_t)nt * sizeof(int));
     if(!c)
         return 1;
-    for(int r = 0; r < nt && !rc; r++) {
-        if((sb[r] | sd[r] | rb[r] | rd[r]) & 7 || sb[r] / 8 > INT_MAX || sd[r] / 8 > INT_MAX || rb[r] / 8 > INT_MAX || rd[r] / 8 > INT_MAX)
+    for(int r = 0; r < nt; r++) {
+        if((sb[r] | sd[r] | rb[r] | rd[r]) % unit || sb[r] / unit > INT_MAX || sd[r] / unit > INT_MAX || rb[r] / unit > INT_MAX ||
+           rd[r] / unit > INT_MAX)
             rc = 1;
-        c[r] = (int)(sb[r] / 8);
-        c[nt + r] = (int)(sd[r] / 8);
-        c[2 * nt + r] = (int)(rb[r] / 8);
-        c[3 * nt + r] = (int)(rd[r] / 8);
+        c[r] = (int)(sb[r] / unit);
+        c[nt + r] = (int)(sd[r] / unit);
+        c[2 * nt + r] = (int)(rb[r] / unit);
+        c[3 * nt + r] = (int)(rd[r] / unit);
     }
-    if(!rc)
-        rc = MPI_Alltoallv((void *)send, c, c + nt, MPI_INT64_T, recv, c + 2 * nt, c + 3 * nt, MPI_INT64_T, comm) != MPI_SUCCESS;
+    /* (a rank that cannot express its blocks still takes part, with empty ones, so that the others do not hang; it reports the error) */
+    if(rc)
+        for(int r = 0; r < 4 * nt; r++)
+            c[r] = 0;
+    const MPI_Datatype ty = all_small ? MPI_BYTE : MPI_INT64_T;
+    if(MPI_Alltoallv((void *)send, c, c + nt, ty, recv, c + 2 * nt, c + 3 * nt, ty, comm) != MPI_SUCCESS)
+        rc = 1;
     free(c);
     return rc;
 }

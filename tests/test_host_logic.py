@@ -272,3 +272,74 @@ def test_sgrid_planes_equal_slices_of_the_full_set(pkg):
     for a, b in ((0, 5), (7, 19), (23, 24)):
         part, m, box2 = pkg.ics.s_grid_planes(n, a, b)
         assert box2 == box and np.array_equal(part, full[a * n * n:b * n * n]) and len(m) == len(part)
+
+
+def _comm_worker(rank, world, port, q):
+    """The mpg_comm callbacks of the multi-rank library path (mp-gadget_amd/dist.py::TorchComm) on host buffers over gloo: called
+    through the C function pointers exactly as csrc/dist.hip calls them."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import importlib
+    import numpy as np
+    pkg = importlib.import_module("mp-gadget_amd")
+    D = pkg.dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = D.TorchComm(torch.device("cpu"))
+    c = comm.struct
+    ok = c.ThisTask == rank and c.NTask == world and c.device_buffers == 0
+    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    # allreduce: float64 SUM, int64 MAX (dtype 0 / 1, op 0 / 1; mpgadget_hip.h)
+    a = np.arange(5, dtype=np.float64) + 10.0 * rank
+    ok &= c.allreduce(None, a.ctypes.data, 5, 0, 0, 0) == 0
+    ok &= bool(np.array_equal(a, world * np.arange(5.0) + 10.0 * sum(range(world))))
+    b = np.array([rank, -rank, 7], dtype=np.int64)
+    ok &= c.allreduce(None, b.ctypes.data, 3, 1, 1, 0) == 0
+    ok &= bool(np.array_equal(b, [world - 1, 0, 7]))
+    # alltoall of one int64 per pair
+    s = np.array([100 * rank + d for d in range(world)], dtype=np.int64)
+    r = np.zeros(world, dtype=np.int64)
+    ok &= c.alltoall_i64(None, i64(s), i64(r)) == 0
+    ok &= bool(np.array_equal(r, [100 * src + rank for src in range(world)]))
+    # alltoallv of bytes: rank r sends (r + d + 1) bytes of value 16 r + d to rank d, packed
+    sb = np.array([rank + d + 1 for d in range(world)], dtype=np.int64)
+    sd = np.concatenate([[0], np.cumsum(sb)[:-1]]).astype(np.int64)
+    rb = np.array([src + rank + 1 for src in range(world)], dtype=np.int64)
+    rd = np.concatenate([[0], np.cumsum(rb)[:-1]]).astype(np.int64)
+    send = np.concatenate([np.full(sb[d], 16 * rank + d, np.uint8) for d in range(world)])
+    want = np.concatenate([np.full(rb[src], 16 * src + rank, np.uint8) for src in range(world)])
+    for piece in (None, 2):      # 2: the exchange cut into pieces of 2 bytes per peer (the path of calls above A2A_MAX_BYTES)
+        keep = D.A2A_MAX_BYTES
+        if piece:
+            D.A2A_MAX_BYTES = piece * world
+        recv = np.zeros(int(rb.sum()), np.uint8)
+        ok &= c.alltoallv(None, send.ctypes.data, i64(sb), i64(sd), recv.ctypes.data, i64(rb), i64(rd), 0) == 0
+        D.A2A_MAX_BYTES = keep
+        ok &= bool(np.array_equal(recv, want))
+    # the all-gather pattern of csrc/dist.hip (allgather_host): every peer gets the SAME block (send displacements all 0)
+    blk = np.full(8, rank + 1, np.uint8)
+    sb2, sd2 = np.full(world, 8, np.int64), np.zeros(world, np.int64)
+    rb2, rd2 = np.full(world, 8, np.int64), (8 * np.arange(world)).astype(np.int64)
+    recv = np.zeros(8 * world, np.uint8)
+    ok &= c.alltoallv(None, blk.ctypes.data, i64(sb2), i64(sd2), recv.ctypes.data, i64(rb2), i64(rd2), 0) == 0
+    ok &= bool(np.array_equal(recv, np.repeat(np.arange(1, world + 1, dtype=np.uint8), 8)))
+    ok &= not comm.errors
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mpg_comm_callbacks_world2_gloo():
+    """N > 1 on CPU: the three collectives the library asks its caller for (allreduce, alltoall_i64, alltoallv of bytes) as
+    TorchComm implements them, two gloo ranks, host buffers, called through the mpg_comm function pointers."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
