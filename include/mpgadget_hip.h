@@ -596,12 +596,16 @@ int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const doub
                                  double *d_potential, double rho0);
 /* Hierarchical gravity (timestep.c: hierarchical_gravity_accelerations; force_tree_active_moments, forcetree.c:129-148): the short-range
  * force of the ACTIVE particles on each other, on the tree of the active particles only.  d_pos / d_mass / d_oldacc hold the rank's
- * n_act active particles (compacted by the caller), d_accel[n_act][3] is assigned, d_potential[n_act] (may be NULL) gets the tree's
- * potential as grav_short_postprocess leaves it.  Such sets are sparse and small: every rank receives the whole set (one all-gather of
+ * n_act active particles (compacted by the caller), d_accel[n_act][3] is assigned; d_potential is not touched (the tree is not the full
+ * particle tree: gravshort.h:57-67 leaves P[].Potential and FullTreeGravAccel alone then).  Such sets are sparse and small: every rank receives the whole set (one all-gather of
  * 28 bytes per particle), builds the tree one GPU would build and walks its own members, so the results are those of one GPU.  The
  * local tree of mpg_dist_dev_force_tree_build is replaced (build it again before the next walk on all particles). */
 int mpg_dist_dev_grav_short_tree_active_tree(mpg_dist *d, int64_t n_act, const double *d_pos, const float *d_mass, const double *d_oldacc,
                                              double *d_accel, double *d_potential, double rho0);
+/* ... as a drop-in call: the active particles are gathered from the rank's P[] (OldAcc from P[].FullTreeGravAccel + GravPM), their
+ * AccelStore[i] is assigned, P[] is left alone.  ActiveParticle == NULL: all particles of the table. */
+int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                         double (*AccelStore)[3], double rho0);
 /* the same for a subset of the own particles: d_active[nactive] = their indices (device array, no duplicates), the ActiveParticle list of a
  * sub-step (run.c:392-470: the tree holds every particle, the active ones are walked).  Only their entries of d_accel / d_potential are
  * written.  d_active == NULL: all own particles. */

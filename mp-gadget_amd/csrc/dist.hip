@@ -2503,6 +2503,7 @@ extern "C" int mpg_dist_dev_grav_short_tree_active_tree(mpg_dist *d, int64_t n_a
     sync(d); // (`all` is read by the copies)
     MPG_CHECK(mpg_dev_bind_particles(e, ntot, d->lpos.p, d->lmass.p, nullptr, d->box) == 0, mpg_last_error());
     MPG_CHECK(mpg_dev_force_tree_build(e, 63) == 0, mpg_last_error());
+    e->full_particle_tree = false; // (force_tree_active_moments, forcetree.c:129-148: P[].Potential and FullTreeGravAccel are not this walk's)
     if(n_act == 0)
         return 0;
     // own members in tree order; inputs / outputs over the whole set, the own range copied in and out
@@ -2519,14 +2520,69 @@ extern "C" int mpg_dist_dev_grav_short_tree_active_tree(mpg_dist *d, int64_t n_a
     MPG_HIP(hipMemsetAsync(d->o_prev.p, 0, (size_t)ntot * sizeof(double), st));
     if(d_oldacc)
         MPG_HIP(hipMemcpyAsync(d->o_prev.p + off, d_oldacc, (size_t)n_act * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if(d_potential)
-        MPG_HIP(hipMemcpyAsync(d->o_pot.p + off, d_potential, (size_t)n_act * sizeof(double), hipMemcpyDeviceToDevice, st));
-    MPG_CHECK(mpg_dev_grav_short_tree(e, d->o_prev.p, nullptr, nullptr, d->targets.p, n_act, d->o_acc.p, d_potential ? d->o_pot.p : nullptr, rho0) == 0,
-              mpg_last_error());
+    (void)d_potential; // (left alone: the tree does not hold every particle, gravshort.h:57-67)
+    MPG_CHECK(mpg_dev_grav_short_tree(e, d->o_prev.p, nullptr, nullptr, d->targets.p, n_act, d->o_acc.p, nullptr, rho0) == 0, mpg_last_error());
     MPG_HIP(hipMemcpyAsync(d_accel, d->o_acc.p + 3 * off, (size_t)n_act * 24, hipMemcpyDeviceToDevice, st));
-    if(d_potential)
-        MPG_HIP(hipMemcpyAsync(d_potential, d->o_pot.p + off, (size_t)n_act * sizeof(double), hipMemcpyDeviceToDevice, st));
     sync(d);
     d->o_n = -1; // (the staging columns of the host drop-in calls were reused)
+    API_END
+}
+
+/* the drop-in form: the active particles are gathered from the rank's table, AccelStore[i] of the active particles is assigned
+ * (grav_short_reduce / _postprocess with a tree that is not the full particle tree: P[] itself is left alone) */
+extern "C" int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                                    double (*AccelStore)[3], double rho0)
+{
+    API_BEGIN
+    MPG_CHECK(d && P && AccelStore, "null argument (the walk on an active-only tree returns its result in AccelStore)");
+    MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0 && P->off_accel >= 0 && P->off_gravpm >= 0, "particle view needs Pos, Mass, FullTreeGravAccel, GravPM");
+    const int64_t n = ActiveParticle ? NumActiveParticle : P->n;
+    MPG_CHECK(n >= 0 && n <= P->n, "bad NumActiveParticle");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    hipStream_t st = d->eng->stream;
+    std::vector<double> hp(3 * (size_t)n + 3), ho((size_t)n + 1);
+    std::vector<float> hm((size_t)n + 1);
+    const mpg_particle_view V = *P;
+    const char *b = (const char *)P->base;
+    const double G = d->eng->pm.G;
+    double *pp = hp.data(), *po = ho.data();
+    float *pm = hm.data();
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t k = lo; k < hi; k++) {
+            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            const char *rec = b + i * V.stride;
+            const double *x = (const double *)(rec + V.off_pos), *a = (const double *)(rec + V.off_accel), *g = (const double *)(rec + V.off_gravpm);
+            double s2 = 0;
+            for(int j = 0; j < 3; j++) {
+                pp[3 * k + j] = x[j];
+                s2 += (a[j] + g[j]) * (a[j] + g[j]);
+            }
+            pm[k] = *(const float *)(rec + V.off_mass);
+            po[k] = sqrt(s2) / G; // grav_get_abs_accel, gravshort.h:70-80
+        }
+    });
+    DevBuf<double> dp, dold, dacc;
+    DevBuf<float> dm;
+    dp.reserve(3 * (size_t)n + 3);
+    dold.reserve((size_t)n + 1);
+    dacc.reserve(3 * (size_t)n + 3);
+    dm.reserve((size_t)n + 1);
+    if(n > 0) {
+        MPG_HIP(hipMemcpyAsync(dp.p, pp, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        MPG_HIP(hipMemcpyAsync(dold.p, po, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        MPG_HIP(hipMemcpyAsync(dm.p, pm, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    sync(d);
+    MPG_CHECK(mpg_dist_dev_grav_short_tree_active_tree(d, n, dp.p, dm.p, dold.p, dacc.p, nullptr, rho0) == 0, mpg_last_error());
+    if(n > 0)
+        MPG_HIP(hipMemcpyAsync(pp, dacc.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    sync(d);
+    parallel_for(n, [=](int64_t lo, int64_t hi) {
+        for(int64_t k = lo; k < hi; k++) {
+            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            for(int j = 0; j < 3; j++)
+                AccelStore[i][j] = pp[3 * k + j];
+        }
+    });
     API_END
 }

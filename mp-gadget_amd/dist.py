@@ -310,6 +310,13 @@ class DistForce:
         act = np.ascontiguousarray(active, np.int32)
         return act, act.ctypes.data_as(C.c_void_p), len(act)
 
+    def host_grav_short_tree_active_tree(self, P, AccelStore, ActiveParticle=None, rho0=0.0):
+        """hierarchical gravity through the drop-in form: AccelStore [len(P), 3] float64 (numpy) gets the active particles' accelerations"""
+        v = self.eng._view(P)
+        keep, ap, na = self._host_active(ActiveParticle)
+        self._ck(self.lib.mpg_dist_grav_short_tree_active_tree(self.h, C.byref(v), ap, C.c_int64(na), AccelStore.ctypes.data_as(C.c_void_p),
+                                                               C.c_double(rho0)))
+
     def host_density(self, P, arrays, times, update_hsml=1, DoEgyDensity=0, ActiveParticle=None):
         v = self.eng._view(P)
         a = self.eng._sph_host_arrays(arrays)

@@ -193,12 +193,18 @@ void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, My
         ck(mpg_grav_short_tree(eng(), &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
     }
     else {
-        if(!tree->full_particle_tree_flag)
-            endrun(5, "mpgadget_hip: the multi-rank walk needs the tree of all particles (force_tree_full); the active-only trees of "
-                      "the hierarchical gravity loop keep the CPU walk\n");
         (void)pm;
-        ck(mpg_dist_force_tree_full(D, &v));
-        ck(mpg_dist_grav_short_tree_active(D, &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
+        if(!tree->full_particle_tree_flag) {
+            /* hierarchical_gravity_accelerations: the tree of force_tree_active_moments holds the active particles only; the library
+             * gathers that (small) set on every rank and builds its tree itself, results in AccelStore */
+            if(!AccelStore)
+                endrun(5, "mpgadget_hip: a walk on an active-only tree needs AccelStore\n");
+            ck(mpg_dist_grav_short_tree_active_tree(D, &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
+        }
+        else {
+            ck(mpg_dist_force_tree_full(D, &v));
+            ck(mpg_dist_grav_short_tree_active(D, &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
+        }
     }
     /* gravshort-tree.c:135-144: no export phase on this path (ghosts are imported before the walk), so the top-tree and
      * secondary walks cost nothing; the tree build of the device tree is charged to the reference's build clocks */

@@ -466,8 +466,9 @@ def test_peano_domain_hierarchical_active_tree(tmp_path):
     one = _run_mgpu(tmp_path, "one.npy", 1, "single", 0, ic="s_clust", n=n, env_extra=env)
     act = np.arange(len(one)) % 7 == 0
     assert np.abs(one[act, 0:3]).min() > 0 and np.all(one[~act, 0:3] == 0)
-    for name, nproc, port in (("p1.npy", 1, 0), ("p3.npy", 3, 29611)):
-        d = _run_mgpu(tmp_path, name, nproc, "peano" if nproc > 1 else "peano1", port, ic="s_clust", n=n, env_extra=env)
+    for name, nproc, port, form in (("p1.npy", 1, 0, "1"), ("p3.npy", 3, 29611, "1"), ("h2.npy", 2, 29612, "host")):
+        d = _run_mgpu(tmp_path, name, nproc, "peano" if nproc > 1 else "peano1", port, ic="s_clust", n=n,
+                      env_extra=dict(env, MPG_ACTIVE_TREE=form))       # host: mpg_dist_grav_short_tree_active_tree on particle_data records
         assert np.all(d[~act, 0:3] == 0), name
         assert np.abs(d[act, 0:3] - one[act, 0:3]).max() <= 1e-13 * np.abs(one[act, 0:3]).max(), name
 

@@ -71,7 +71,16 @@ elif mode.startswith("peano"):
     df.set_domain(dom, rcut)
     f8 = dict(dtype=torch.float64, device=dev)
     ga, gg, gp = torch.zeros(n_own, 3, **f8), torch.zeros(n_own, 3, **f8), torch.zeros(n_own, **f8)
-    if every and os.environ.get("MPG_ACTIVE_TREE"):
+    if every and os.environ.get("MPG_ACTIVE_TREE") == "host":
+        # the drop-in form on the rank's particle_data records: OldAcc from P[].FullTreeGravAccel + GravPM, results in AccelStore
+        df.gravpm_force(opos, omass, gg, gp)
+        act = torch.nonzero(oids % every == 0).squeeze(1)
+        Prec = pkg.make_particles(opos.cpu().numpy(), omass.cpu().numpy())
+        Prec["FullTreeGravAccel"][:, 0] = 1e-7 * G         # |FullTreeGravAccel + GravPM| / G = 1e-7: the OldAcc of the other forms
+        store = np.zeros((n_own, 3))
+        df.host_grav_short_tree_active_tree(Prec, store, ActiveParticle=act.cpu().numpy())
+        ga[:] = torch.from_numpy(store).to(dev)
+    elif every and os.environ.get("MPG_ACTIVE_TREE"):
         df.gravpm_force(opos, omass, gg, gp)
         act = torch.nonzero(oids % every == 0).squeeze(1)
         aa = torch.zeros(act.shape[0], 3, **f8)
