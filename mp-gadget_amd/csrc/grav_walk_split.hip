@@ -101,12 +101,14 @@ __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const 
     // interpolation of gravity.c:63 up to one rounding.  (i - t) = fract(i) exactly for i >= 0.
     const int t = min((int)ti, NTAB - 1);
     const double w1 = __builtin_amdgcn_fract(ti);
-    // one row = {force T, force dT, potential T, potential dT} (the last two only with POT): both reads are issued together
-    const double *__restrict__ row = wtab + t * (POT ? 4 : 2);
+    // two tables of 16-byte rows, {T, dT} of the force, then (with POT) {T, dT} of the potential NTAB rows further on: both reads are
+    // issued together.  (One 32-byte row holding both put every force read on one half of the LDS banks and every potential read on
+    // the other half; with 16-byte rows the random rows of a wave's 64 lanes spread over all banks.)
+    const double *__restrict__ row = wtab + t * 2;
     const double2 f = *(const double2 *)row;
     double2 p = f;
     if(POT)
-        p = *(const double2 *)(row + 2);
+        p = *(const double2 *)(row + 2 * NTAB);
     fac *= fma(w1, f.y, f.x);
     ax = fma(dx, fac, ax);
     ay = fma(dy, fac, ay);
@@ -807,11 +809,11 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
     set_wave_prio(io.eval_prio);
     for(int i = threadIdx.x; i < NTAB; i += blockDim.x) {
         const bool last = i == NTAB - 1; // the row the clamp lands on: zeros
-        s_wtab[i * ROW + 0] = last ? 0.0 : (double)io.tab_force[i];
-        s_wtab[i * ROW + 1] = last ? 0.0 : (double)io.tab_force[i + 1] - (double)io.tab_force[i];
+        s_wtab[i * 2 + 0] = last ? 0.0 : (double)io.tab_force[i];
+        s_wtab[i * 2 + 1] = last ? 0.0 : (double)io.tab_force[i + 1] - (double)io.tab_force[i];
         if(POT) {
-            s_wtab[i * ROW + 2] = last ? 0.0 : (double)io.tab_pot[i];
-            s_wtab[i * ROW + 3] = last ? 0.0 : (double)io.tab_pot[i + 1] - (double)io.tab_pot[i];
+            s_wtab[2 * NTAB + i * 2 + 0] = last ? 0.0 : (double)io.tab_pot[i];
+            s_wtab[2 * NTAB + i * 2 + 1] = last ? 0.0 : (double)io.tab_pot[i + 1] - (double)io.tab_pot[i];
         }
     }
     __syncthreads();
