@@ -12,7 +12,8 @@
  *                   the library), mpg_dist_use_decomposition, mpg_dist_gravity_step twice on device arrays;
  *       ranks_host: particles handed to the owners of the 8 top-level Peano-Hilbert cells (a legal, unbalanced domain given from
  *                   outside: mpg_dist_set_domain), then the drop-in calls mpg_dist_gravpm_force / _force_tree_full /
- *                   _grav_short_tree on each rank's table of 160-byte records;
+ *                   _grav_short_tree on each rank's table of 160-byte records, then a sub-step (every third particle active:
+ *                   mpg_dist_grav_short_tree_active) that must reproduce the full walk's accelerations bit for bit;
  *       the assembled GravPM / accelerations against the same vectors.
  * Exit code 0 and a last line "PASS ..." on success. */
 #define _GNU_SOURCE
@@ -147,6 +148,7 @@ struct shm {
     size_t cap;         /* bytes of data[] per rank */
     int64_t N;
     int failed;
+    int substep_bad;    /* a rank's sub-step check failed (ranks_host) */
     /* followed by: data[MAXT][cap], result[N][6] */
 };
 struct ctx {
@@ -332,7 +334,10 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
         }
         mpg_particle_view v;
         mpg_particle_view_reference_layout(&v, P, n_own);
+        double *prev = malloc((3 * n_own + 3) * sizeof(double));
         for(int it = 0; it < 2; it++) {
+            for(int64_t k = 0; k < n_own; k++)
+                memcpy(prev + 3 * k, P[k].FullTreeGravAccel, 3 * sizeof(double));
             CK(mpg_dist_gravpm_force(D, &v));
             CK(mpg_dist_force_tree_full(D, &v));
             CK(mpg_dist_grav_short_tree(D, &v, NULL, 0.0));
@@ -342,6 +347,34 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
                 gpm[3 * k + j] = P[k].GravPM[j];
                 acc[3 * k + j] = P[k].FullTreeGravAccel[j];
             }
+        /* a sub-step on the same tree: every third particle active (mpg_dist_grav_short_tree_active), P[] put back to what the second
+         * walk saw.  The active particles must get that walk's accelerations bit for bit (same tree, same OldAcc, same lists), in P[]
+         * and in AccelStore; the others keep what they had. */
+        {
+            int64_t nact = 0, nbad = 0;
+            int *act = malloc((n_own + 1) * sizeof(int));
+            double(*store)[3] = calloc(n_own + 1, sizeof(*store));
+            for(int64_t k = 0; k < n_own; k++) {
+                memcpy(P[k].FullTreeGravAccel, prev + 3 * k, 3 * sizeof(double));
+                if(k % 3 == 0)
+                    act[nact++] = (int)k;
+            }
+            CK(mpg_dist_grav_short_tree_active(D, &v, act, nact, store, 0.0));
+            for(int64_t k = 0; k < n_own; k++) {
+                const double *want = (k % 3 == 0) ? acc + 3 * k : prev + 3 * k;
+                if(memcmp(P[k].FullTreeGravAccel, want, 3 * sizeof(double)))
+                    nbad++;
+                if(k % 3 == 0 ? memcmp(store[k], acc + 3 * k, 3 * sizeof(double)) != 0 : (store[k][0] != 0 || store[k][1] != 0 || store[k][2] != 0))
+                    nbad++;
+            }
+            if(nbad) {
+                fprintf(stderr, "rank %d: FAIL sub-step: %lld entries differ from the full walk\n", me, (long long)nbad);
+                S->substep_bad = 1;
+            }
+            free(act);
+            free(store);
+        }
+        free(prev);
         free(P);
     }
     else {
@@ -403,6 +436,10 @@ static int run_ranks(const double *table, const double *pos, const double *expec
     }
     if(bad) {
         printf("FAIL a rank exited with an error\n");
+        return 1;
+    }
+    if(S->substep_bad) {
+        printf("FAIL the sub-step (mpg_dist_grav_short_tree_active) differs from the full walk\n");
         return 1;
     }
     const double *R = shm_result(S);
