@@ -8,6 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The test process holds two OpenMP runtimes (the oracle's libgomp and the one torch brings), each with a pool as wide as the box
+# (256 hardware threads on the GPU box).  Idle threads that SPIN at barriers starve the other pool's; sleeping ones do not.  Set before
+# either runtime starts.  (Test infrastructure only: bench.py's cpu_baseline runs the oracle in its own process with its own settings.)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
