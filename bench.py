@@ -56,7 +56,7 @@ def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
     tests of the traversal, which the reference also performs, are NOT counted as flops.  The HBM side is reported next to it:
     algorithmic bytes (SURVEY 8(d) B_walk), measured HBM traffic (PMC) as a fraction of the 8 TB/s peak, and their ratio."""
     variant, list_cap, list_ovf = eng.walk_choice()
-    kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 5: "k_grav_walk_shared", 6: ("k_walk_lists + k_walk_eval" if os.environ.get("MPG_LISTS_PAIR") == "0" else "k_walk_lists2 + k_walk_eval"),
+    kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 5: "k_grav_walk_shared", 6: {"0": "k_walk_lists", "1": "k_walk_lists2"}.get(os.environ.get("MPG_LISTS_MODE", "2"), "k_walk_lists8") + " + k_walk_eval",
                7: "k_walk_leaf"}.get(variant, "?")
     t = walk_ms / max(walk_launches, 1) * 1e-3
     flops = (cnt["pp"] + cnt["nodes_used"]) * float(FLOP_PER_INTERACTION)
@@ -73,6 +73,7 @@ def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
          "reuse": (b_alg / traffic) if traffic else None,
          "walk_variant": variant, "list_capacity": list_cap, "targets_to_fallback_kernel": list_ovf,
          "children_per_node_step": round(cnt["node_lanes"] / max(cnt["node_steps"], 1), 2),
+         "node_steps_per_launch": cnt["node_steps"], "node_lanes_per_launch": cnt["node_lanes"],
          "note": "one launch = one short-range walk over all targets; the walk is bound by fp64 VALU issue (pairwise kernel with a "
                  "per-pair window-table lookup; MFMA does not apply), so frac = 38 flop x (N_pp + N_nodes_used) / t / 78.6 TFLOP/s; "
                  "hbm_measured_frac = PMC traffic / t / 8 TB/s; reuse = SURVEY 8(d) B_walk / PMC traffic"}

@@ -100,7 +100,7 @@ typedef struct mpg_particle_view {
     int32_t off_pi;        /* int32      PI (slot index) */
 } mpg_particle_view;
 /* Fill the offsets for the reference's struct particle_data (partmanager.h:9-71, offsets verified in SURVEY 8(a)). */
-void mpg_particle_view_reference_layout(mpg_particle_view *v, void *P, int64_t NumPart);
+void mpg_particle_view_reference_layout(mpg_particle_view *v, void *particles, int64_t NumPart);
 
 /* ---- host (drop-in) entry points ------------------------------------------------------------- */
 /* Every host entry point that needs positions packs Pos / Mass / Type of P[] and uploads them, because P may have moved or
@@ -111,24 +111,24 @@ void mpg_particle_view_reference_layout(mpg_particle_view *v, void *P, int64_t N
 int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch);
 /* gravpm_force, libgadget/gravpm.c:61-119: zero GravPM, CIC deposit, r2c, Green's function, 4 x (transfer, c2r,
  * CIC readout).  Writes P[i].GravPM[3] (=) and P[i].Potential (+=, as readout_potential does). */
-int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P);
+int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *pv);
 /* force_tree_full, libgadget/forcetree.c:110-128: tree of all particles with moments.  `mask` as ALLMASK etc.
  * (forcetree.h:22-27); particles whose type bit is clear are left out. */
-int mpg_force_tree_full(mpg_engine *eng, const mpg_particle_view *P, double BoxSize);
+int mpg_force_tree_full(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize);
 /* force_tree_rebuild_mask, libgadget/forcetree.c:151-166 */
-int mpg_force_tree_rebuild_mask(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, int mask);
+int mpg_force_tree_rebuild_mask(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize, int mask);
 /* force_tree_free, libgadget/forcetree.c:1403-1413 */
 int mpg_force_tree_free(mpg_engine *eng);
 /* force_tree_active_moments (forcetree.c:129-148): a tree of the active particles only (ActiveParticle == NULL: all), with
  * moments; HybridNuTracer != 0 leaves neutrinos (type 2) out.  A walk over it takes the same active list as its targets. */
-int mpg_force_tree_active_moments(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const int *ActiveParticle,
+int mpg_force_tree_active_moments(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize, const int *ActiveParticle,
                                   int64_t NumActiveParticle, int HybridNuTracer);
 int mpg_dev_force_tree_active_moments(mpg_engine *eng, const int *d_active, int64_t nactive, int HybridNuTracer);
 /* grav_short_tree, libgadget/gravshort-tree.c:96-154.  ActiveParticle == NULL means all particles
  * (timestep.c:77-84).  AccelStore may be NULL.  When the tree holds all particles (full_particle_tree_flag)
  * P[i].FullTreeGravAccel and P[i].Potential are updated as grav_short_postprocess does (gravshort.h:47-67).
  * After the call TreeUseBH > 1 is reset to 0 (gravshort-tree.c:148-151). */
-int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
                         double (*AccelStore)[3], double rho0);
 
 /* ---- device-resident entry points (inputs and outputs stay in HBM) ---------------------------- */
@@ -232,10 +232,10 @@ int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_
 /* Host-pointer forms of the four calls above: `P` supplies Pos / Mass / Type / flags (the reference AoS table), `A` holds HOST
  * arrays in particle order (the in-tree shim gathers SphP[P[i].PI].X into them).  Inputs are copied to HBM,
  * outputs copied back; the gas tree is (re)built inside, as force_tree_rebuild_mask does in run.c:466. */
-int mpg_set_init_hsml(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, double MeanGasSeparation);
-int mpg_density(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, const mpg_sph_times *T,
+int mpg_set_init_hsml(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize, const mpg_sph_arrays *A, double MeanGasSeparation);
+int mpg_density(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize, const mpg_sph_arrays *A, const mpg_sph_times *T,
                 const int *ActiveParticle, int64_t NumActiveParticle, int update_hsml, int DoEgyDensity, int BlackHoleOn);
-int mpg_hydro_force(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T,
+int mpg_hydro_force(mpg_engine *eng, const mpg_particle_view *pv, const mpg_sph_arrays *A, const mpg_sph_times *T,
                     const int *ActiveParticle, int64_t NumActiveParticle);
 /* statistics of the last SPH call: [0] density iterations, [1] targets summed over iterations,
  * [2] successful distance tests / hydro pairs evaluated, [3] candidates distance-tested */
@@ -281,7 +281,7 @@ const int *mpg_dev_tree_order(mpg_engine *eng);
  * size of each target (a sphere, not the tree walk's cube), same softening spline and window; runtests.c:131 checks the tree force
  * against it.  Needs a tree (any walk order); results as for grav_short_tree: FullTreeGravAccel and Potential when the tree holds
  * every particle. */
-int mpg_grav_short_pair(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle, double Rcut,
+int mpg_grav_short_pair(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle, double Rcut,
                         double rho0);
 int mpg_dev_grav_short_pair(mpg_engine *eng, const int *d_active, int64_t nactive, double Rcut, double *d_accel, double *d_potential,
                             double rho0);
@@ -604,7 +604,7 @@ int mpg_dist_dev_grav_short_tree_active_tree(mpg_dist *d, int64_t n_act, const d
                                              double *d_accel, double *d_potential, double rho0);
 /* ... as a drop-in call: the active particles are gathered from the rank's P[] (OldAcc from P[].FullTreeGravAccel + GravPM), their
  * AccelStore[i] is assigned, P[] is left alone.  ActiveParticle == NULL: all particles of the table. */
-int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
                                          double (*AccelStore)[3], double rho0);
 /* the same for a subset of the own particles: d_active[nactive] = their indices (device array, no duplicates), the ActiveParticle list of a
  * sub-step (run.c:392-470: the tree holds every particle, the active ones are walked).  Only their entries of d_accel / d_potential are
@@ -636,19 +636,33 @@ int mpg_dist_fof_groups(mpg_dist *d, const mpg_fof_groups *out);
 /* ... and as drop-in calls on the rank's particle table in host memory (what libgadget's callers hand over; shim/gravity-hip.c):
  * Pos / Mass are read from P[], GravPM / FullTreeGravAccel / Potential (and AccelStore, may be NULL) are written as the reference's
  * functions write them; OldAcc of the walk comes from P[].FullTreeGravAccel + P[].GravPM.  All particles active (a PM step). */
-int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *P);
-int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *P);
-int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *P, double (*AccelStore)[3], double rho0);
+int mpg_dist_gravpm_force(mpg_dist *d, const mpg_particle_view *pv);
+int mpg_dist_force_tree_full(mpg_dist *d, const mpg_particle_view *pv);
+int mpg_dist_grav_short_tree(mpg_dist *d, const mpg_particle_view *pv, double (*AccelStore)[3], double rho0);
 /* ... for the sub-steps: ActiveParticle[NumActiveParticle] (host array of indices into P[], NULL = all) are walked, their
  * FullTreeGravAccel / Potential / AccelStore entries updated (the tree of mpg_dist_force_tree_full holds every particle) */
-int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
                                     double (*AccelStore)[3], double rho0);
 /* density() / hydro_force() as drop-in calls on the same table (after mpg_dist_force_tree_full on it): A holds HOST arrays in particle
  * order, as for mpg_density / mpg_hydro_force (the shim gathers SphP[P[i].PI].X into them); inputs are read, outputs written.
  * ActiveParticle[NumActiveParticle]: host array of indices into P[] (NULL = all), see mpg_dist_dev_density_active */
-int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
+/* BlackHoleOn of density() (density.c:234, density_haswork :521-530): when set, the own black holes that are not swallowed are targets
+ * of the following mpg_dist_(dev_)density calls next to the gas (Hsml, Density and DivVel of BHP); the smoothing lengths of both must
+ * lie within the domain margin.  Swallowed black holes and garbage carry type 7 in d_type (the host form reads the flag bits). */
+int mpg_dist_set_sph_options(mpg_dist *d, int BlackHoleOn);
+/* the largest smoothing length over all ranks at the end of the last mpg_dist_(dev_)density loop.  When that call failed because it
+ * exceeds the domain margin (the neighbours of such a particle are not all local), set the domain again with a margin above this
+ * value, rebuild the local tree and repeat the call: the inputs were not modified. */
+double mpg_dist_last_max_hsml(mpg_dist *d);
+/* PartManager->MaxPart for domain_check_memory_bound (domain.c:378-424): a decomposition that gives one task more particles is retried
+ * with the next policy (domain.c:199-201).  0 (default): no bound. */
+int mpg_dist_domain_set_maxpart(mpg_dist *d, int64_t MaxPart);
+/* the matter power spectrum of the last mpg_dist_(dev_)gravpm_force over all ranks (gravpm.c:110-118; powerspectrum_sum's
+ * MPI_Allreduce, powerspectrum.c:55-91).  Collective; arrays of Nmesh entries, *nonzero of which are filled on every rank. */
+int mpg_dist_gravpm_get_powerspectrum(mpg_dist *d, double BoxSize_in_MPC, double *kk, double *Power, int64_t *Nmodes, int *nonzero);
+int mpg_dist_density(mpg_dist *d, const mpg_particle_view *pv, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
                      int64_t NumActiveParticle, int update_hsml, int DoEgyDensity);
-int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
+int mpg_dist_hydro_force(mpg_dist *d, const mpg_particle_view *pv, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
                          int64_t NumActiveParticle);
 /* per-particle work of the last mpg_dist walk for the rank's own particles (device pointer, n_own floats, caller order):
  * the cost the next domain decomposition balances (mpg_dev_set_walk_cost) */
@@ -677,6 +691,9 @@ int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
 int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave);
 int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
 int mpg_set_walk_variant(mpg_engine *eng, int variant);
+/* list-construction kernel of the two-kernel walk (variant 6): 2 (default) one traversal per wave of 8 targets, 1 pairs of targets
+ * per group of 8 lanes, 0 one target per group.  All three take the reference's per-target decisions (gravshort-tree.c:198-241). */
+int mpg_set_walk_lists_mode(mpg_engine *eng, int mode);
 /* kernel in use (the explicit variant, or the default policy's pick: 6 for >= 65536 targets, else 1; 0 = no walk yet), kernel 6's current list capacity and
  * the number of targets its last walk handed to the fallback kernel (either output may be NULL) */
 int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsigned *last_overflow);

@@ -344,20 +344,23 @@ __global__ void __launch_bounds__(256) k_unpack_sph_mid(int64_t nr, const double
     curlvel[i] = r[5];
 }
 
+// density_haswork (density.c:521-530): gas, and with BlackHoleOn the black holes (swallowed ones carry type 7 here, like garbage)
 struct IsOwnGas {
     const uint8_t *type;
-    __host__ __device__ bool operator()(const int &i) const { return type[i] == 0; }
+    int bh;
+    __host__ __device__ bool operator()(const int &i) const { return type[i] == 0 || (bh && type[i] == 5); }
 };
 struct IsActiveGas {
     const uint8_t *type, *flag;
-    __host__ __device__ bool operator()(const int &i) const { return type[i] == 0 && flag[i] != 0; }
+    int bh;
+    __host__ __device__ bool operator()(const int &i) const { return (type[i] == 0 || (bh && type[i] == 5)) && flag[i] != 0; }
 };
 
-__global__ void __launch_bounds__(256) k_max_gas_hsml(int64_t n, const uint8_t *__restrict__ type, const double *__restrict__ hsml,
+__global__ void __launch_bounds__(256) k_max_gas_hsml(int64_t n, const uint8_t *__restrict__ type, const double *__restrict__ hsml, const int bh,
                                                       unsigned long long *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double h = (i < n && type[i] == 0) ? hsml[i] : 0.0;
+    double h = (i < n && (type[i] == 0 || (bh && type[i] == 5))) ? hsml[i] : 0.0;
     for(int off = 32; off > 0; off >>= 1)
         h = fmax(h, __shfl_down(h, off));
     if((threadIdx.x & 63) == 0 && h > 0)
@@ -570,6 +573,10 @@ struct mpg_dist {
     DevBuf<unsigned> err;
     HostBuf<double> htop;
     int64_t ntarg = 0, n_own_tree = -1;
+    bool grav_tree_valid = false; // the engine's tree is the gravity tree of mpg_dist_dev_force_tree_build (the SPH loops and FOF replace it)
+    double last_hmax = 0;         // largest smoothing length over all ranks after the last density loop
+    int blackholes = 0;           // BlackHoleOn of density(): the own non-swallowed black holes are targets of the density loop too
+    int64_t dom_max_part = 0;     // PartManager->MaxPart of domain_check_memory_bound (0: no bound)
     DevBuf<float> cost;
     // SPH loops on the local set: inputs and outputs over [own | ghosts]
     DevBuf<uint8_t> s_type, s_tbh, s_tbg;
@@ -1102,6 +1109,7 @@ int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_po
         d->ntarg = (int64_t)c;
         MPG_CHECK(d->ntarg == n_own, "mpg_dist: own particles missing from the local tree");
     }
+    d->grav_tree_valid = true;
     d->times[2] = now_ms() - t2;
     API_END
 }
@@ -1118,6 +1126,8 @@ int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_
     API_BEGIN
     MPG_CHECK(d && d_accel, "null argument");
     MPG_CHECK(d->n_own_tree >= 0, "mpg_dist_dev_grav_short_tree: mpg_dist_dev_force_tree_build first");
+    MPG_CHECK(d->grav_tree_valid, "mpg_dist_dev_grav_short_tree: the local tree was replaced since mpg_dist_dev_force_tree_build (the density loop "
+                                  "builds a gas tree, FOF a tree of the primary types): build the gravity tree again");
     MPG_CHECK(nactive >= 0 && nactive <= d->n_own_tree, "mpg_dist_dev_grav_short_tree_active: bad number of active particles");
     mpg_engine *e = d->eng;
     MPG_HIP(hipSetDevice(e->device));
@@ -1367,7 +1377,7 @@ int mpg_dist_dev_density(mpg_dist *d, int64_t n_own, const uint8_t *d_type, cons
 }
 
 // the loop's targets: the own gas (d_active == null) or the own gas among the listed particles, ascending
-static void sph_targets(mpg_dist *d, int64_t n_own, const int *d_active, int64_t nactive)
+static void sph_targets(mpg_dist *d, int64_t n_own, const int *d_active, int64_t nactive, const int bh)
 {
     hipStream_t st = d->eng->stream;
     d->gas.reserve((size_t)n_own + 1);
@@ -1385,16 +1395,16 @@ static void sph_targets(mpg_dist *d, int64_t n_own, const int *d_active, int64_t
         MPG_HIP(hipMemsetAsync(d->err.p, 0, sizeof(unsigned), st));
         MPG_HIP(hipMemsetAsync(d->actflag.p, 0, (size_t)n_own, st));
         hipLaunchKernelGGL(k_flag_list, dim3(nblk(nactive)), dim3(256), 0, st, nactive, d_active, (int)n_own, d->actflag.p, d->err.p);
-        const IsActiveGas pred{d->s_type.p, d->actflag.p};
+        const IsActiveGas pred{d->s_type.p, d->actflag.p, bh};
         MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, pred, st));
         d->tmp.reserve(tb + 16);
         MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, pred, st));
         MPG_HIP(hipMemcpyAsync(&bad, d->err.p, sizeof(bad), hipMemcpyDeviceToHost, st));
     }
     else {
-        MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
+        MPG_HIP(rocprim::select(nullptr, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p, bh}, st));
         d->tmp.reserve(tb + 16);
-        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p}, st));
+        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->gas.p, d->scount.p, (size_t)n_own, IsOwnGas{d->s_type.p, bh}, st));
     }
     unsigned long long c = 0;
     MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
@@ -1436,10 +1446,11 @@ int mpg_dist_dev_density_active(mpg_dist *d, int64_t n_own, const uint8_t *d_typ
     exchange_rows(d, pl, d->sendbuf.p, d->recvbuf.p, false, 128);
     if(pl.nrecv > 0)
         hipLaunchKernelGGL(k_unpack_sph_in, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const double *)d->recvbuf.p, loc, n_own);
-    // the gas tree of the local set (force_tree_rebuild_mask(GASMASK), run.c:466)
+    // the gas tree of the local set (force_tree_rebuild_mask(GASMASK), run.c:466); it REPLACES the gravity tree in the engine
+    d->grav_tree_valid = false;
     MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, d->s_type.p, d->box) == 0, mpg_last_error());
     MPG_CHECK(mpg_dev_force_tree_rebuild_mask(e, 1, 0) == 0, mpg_last_error());
-    sph_targets(d, n_own, d_active, nactive);
+    sph_targets(d, n_own, d_active, nactive, d->blackholes);
     if(d_active && n_own > 0) {
         // a sub-step: the inactive own particles keep the results of their last density loop, which the hydro loop of this sub-step
         // reads and their owners hand to the ghosts (the reference leaves SphP of inactive particles alone)
@@ -1476,18 +1487,19 @@ int mpg_dist_dev_density_active(mpg_dist *d, int64_t n_own, const uint8_t *d_typ
     L.hydroacc_out = d->s_out[7].p;
     L.dtentropy_out = d->s_out[8].p;
     L.maxsignalvel = d->s_out[9].p;
-    MPG_CHECK(mpg_dev_density(e, &L, T, d->gas.p, d->ngas, update_hsml, DoEgyDensity, 0) == 0, mpg_last_error());
+    MPG_CHECK(mpg_dev_density(e, &L, T, d->gas.p, d->ngas, update_hsml, DoEgyDensity, d->blackholes) == 0, mpg_last_error());
     // every neighbour within a smoothing length must be local: the largest one against the domain margin
     d->scount.reserve(4);
     MPG_HIP(hipMemsetAsync(d->scount.p, 0, sizeof(unsigned long long), st));
     if(n_own > 0)
-        hipLaunchKernelGGL(k_max_gas_hsml, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d->s_type.p, d->s_in[0].p, d->scount.p);
+        hipLaunchKernelGGL(k_max_gas_hsml, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d->s_type.p, d->s_in[0].p, d->blackholes, d->scount.p);
     unsigned long long hb = 0;
     MPG_HIP(hipMemcpyAsync(&hb, d->scount.p, sizeof(hb), hipMemcpyDeviceToHost, st));
     sync(d);
     double hmax;
     memcpy(&hmax, &hb, sizeof(double));
     allreduce_host_f64(d, &hmax, 1, 1);
+    d->last_hmax = hmax;
     MPG_CHECK(hmax <= d->margin, "mpg_dist_dev_density: the largest smoothing length exceeds the domain margin (mpg_dist_set_domain with a larger one)");
     // own rows out
     auto out = [&](double *dst, const double *src, int w) {
@@ -1552,7 +1564,7 @@ int mpg_dist_dev_hydro_force_active(mpg_dist *d, int64_t n_own, const mpg_sph_ar
     L.hydroacc_out = d->s_out[7].p;
     L.dtentropy_out = d->s_out[8].p;
     L.maxsignalvel = d->s_out[9].p;
-    sph_targets(d, n_own, d_active, nactive);
+    sph_targets(d, n_own, d_active, nactive, 0); // (hydro_force: gas only, hydra.c:193)
     if(d_active && n_own > 0) { // (inactive particles keep their HydroAccel / DtEntropy / MaxSignalVel)
         MPG_HIP(hipMemcpyAsync(L.hydroacc_out, A->hydroacc_out, (size_t)3 * n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
         MPG_HIP(hipMemcpyAsync(L.dtentropy_out, A->dtentropy_out, (size_t)n_own * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1789,6 +1801,14 @@ int mpg_dist_domain_decompose(mpg_dist *d, int64_t n, const double *d_pos, const
                          tcounts.data(), e->domain, st);
         sync(d);
         allreduce_i64(d, fcounts.data(), nleaves, 0);
+        if(d->dom_max_part > 0 && i < 15) {
+            // domain_check_memory_bound (domain.c:378-424): a task that would hold more than MaxPart particles sends the loop to the
+            // next policy ("Still try an exchange if this is the last policy", domain.c:199-201)
+            std::vector<int64_t> load = tcounts;
+            allreduce_i64(d, load.data(), nt, 0);
+            if(*std::max_element(load.begin(), load.end()) > d->dom_max_part)
+                continue;
+        }
         d->dom_policy = i;
         d->dom_tree.assign((const mpg_topnode *)tree.data(), (const mpg_topnode *)tree.data() + size);
         d->dom_size = size;
@@ -2036,6 +2056,7 @@ int mpg_dist_dev_fof_fof(mpg_dist *d, int64_t n_own, const double *d_pos, const 
     if(pl.nrecv > 0)
         hipLaunchKernelGGL(k_unpack_idtype, dim3(nblk(pl.nrecv)), dim3(256), 0, st, pl.nrecv, (const IdRow *)d->recvbuf.p, d->f_id.p + n_own,
                            d->f_type.p + n_own);
+    d->grav_tree_valid = false; // (the tree of the primary types replaces the gravity tree in the engine)
     MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, d->f_type.p, d->box) == 0, mpg_last_error());
     e->tree.build(nl, d->lpos.p, d->lmass.p, d->f_type.p, par->FOFPrimaryLinkTypes, d->box, st, &e->timer, nullptr);
     e->tree_allocated = true;
@@ -2390,7 +2411,12 @@ const uint8_t *stage_types(mpg_dist *d, const mpg_particle_view *P)
     uint8_t *t = ty.data();
     parallel_for(n, [=](int64_t lo, int64_t hi) {
         for(int64_t i = lo; i < hi; i++)
+        {
             t[i] = V.off_type >= 0 ? (uint8_t)(*(const uint8_t *)(b + i * V.stride + V.off_type) & 7) : (uint8_t)1;
+            // garbage and swallowed black holes are no targets and no neighbours (density.c:521-530, forcetree.c:357-365): type 7
+            if(V.off_flags >= 0 && (*(const uint8_t *)(b + i * V.stride + V.off_flags) & 3))
+                t[i] = 7;
+        }
     });
     d->o_u8[0].reserve((size_t)n + 1);
     if(n > 0)
@@ -2411,6 +2437,46 @@ static const int *stage_active(mpg_dist *d, const int *ActiveParticle, int64_t n
     if(n > 0)
         MPG_HIP(hipMemcpy(d->o_act.p, ActiveParticle, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     return d->o_act.p;
+}
+
+int mpg_dist_set_sph_options(mpg_dist *d, int BlackHoleOn)
+{
+    API_BEGIN
+    MPG_CHECK(d, "null argument");
+    d->blackholes = BlackHoleOn != 0;
+    API_END
+}
+
+double mpg_dist_last_max_hsml(mpg_dist *d) { return d ? d->last_hmax : 0; }
+
+int mpg_dist_domain_set_maxpart(mpg_dist *d, int64_t MaxPart)
+{
+    API_BEGIN
+    MPG_CHECK(d && MaxPart >= 0, "null argument");
+    d->dom_max_part = MaxPart;
+    API_END
+}
+
+/* measure_power_spectrum + powerspectrum_sum over the ranks (gravpm.c:110-118, powerspectrum.c:55-91): every rank binned the k_y rows of
+ * its slab during mpg_dist_(dev_)gravpm_force; the raw sums (Power, k, Norm, mode counts) are all-reduced as the reference's
+ * MPI_Allreduce does, then normalised.  Collective; every rank gets the spectrum. */
+int mpg_dist_gravpm_get_powerspectrum(mpg_dist *d, double BoxSize_in_MPC, double *kk, double *Power, int64_t *Nmodes, int *nonzero)
+{
+    API_BEGIN
+    MPG_CHECK(d && kk && Power && Nmodes && nonzero, "null argument");
+    mpg_engine *e = d->eng;
+    MPG_CHECK(e->pm.nmesh > 0 && e->pm.ps_valid, "power spectrum: no PM step has been run with the measurement on");
+    MPG_HIP(hipSetDevice(e->device));
+    const size_t nb = (size_t)e->pm.nmesh;
+    std::vector<double> acc(2 * nb + 1);
+    std::vector<int64_t> modes(nb);
+    MPG_HIP(hipMemcpyAsync(acc.data(), e->pm.ps_acc.p, (2 * nb + 1) * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    MPG_HIP(hipMemcpyAsync(modes.data(), e->pm.ps_modes.p, nb * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+    sync(d);
+    allreduce_host_f64(d, acc.data(), (int64_t)(2 * nb + 1), 0);
+    allreduce_i64(d, modes.data(), (int64_t)nb, 0);
+    MPG_CHECK(mpg_powerspectrum_sum((int)nb, acc.data(), modes.data(), BoxSize_in_MPC, kk, Power, Nmodes, nonzero) == 0, mpg_last_error());
+    API_END
 }
 
 int mpg_dist_density(mpg_dist *d, const mpg_particle_view *P, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *ActiveParticle,
@@ -2501,6 +2567,7 @@ extern "C" int mpg_dist_dev_grav_short_tree_active_tree(mpg_dist *d, int64_t n_a
         at += cnt[r];
     }
     sync(d); // (`all` is read by the copies)
+    d->grav_tree_valid = false;
     MPG_CHECK(mpg_dev_bind_particles(e, ntot, d->lpos.p, d->lmass.p, nullptr, d->box) == 0, mpg_last_error());
     MPG_CHECK(mpg_dev_force_tree_build(e, 63) == 0, mpg_last_error());
     e->full_particle_tree = false; // (force_tree_active_moments, forcetree.c:129-148: P[].Potential and FullTreeGravAccel are not this walk's)

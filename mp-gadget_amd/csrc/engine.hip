@@ -1914,6 +1914,14 @@ int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsig
     API_END
 }
 
+int mpg_set_walk_lists_mode(mpg_engine *eng, int mode)
+{
+    API_BEGIN
+    MPG_CHECK(eng && mode >= 0 && mode <= 2, "walk lists mode must be 0 (one target per group), 1 (pairs) or 2 (one traversal per wave)");
+    eng->w3.split_lists_mode = mode;
+    API_END
+}
+
 int mpg_set_walk_variant(mpg_engine *eng, int variant)
 {
     API_BEGIN

@@ -28,6 +28,7 @@
 // NEAREST() per pair as partmanager.h:99 does.
 #include "grav_walk.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mpg {
 
@@ -427,7 +428,10 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists(const TreeView tv, cons
 //
 // the reference's tests for one node and one target (shall_we_discard_node / shall_we_open_node, gravshort-tree.c:198-241);
 // MODE as in walk_target; special: the root or one of its children (exact images for both the centre and the centre of mass)
-template <int MODE>
+// EAGER (k_walk_lists8): every comparison is evaluated by every lane and the outcomes are combined with & and | - the short-circuit
+// form makes hipcc guard single compares with exec-mask regions (3 scalar instructions to skip one vector compare) - and the
+// Barnes-Hut switch is folded into aold by the caller (aold = +inf: "mass l^2 > r^4 aold" is false for every r, NaN at r = 0 included)
+template <int MODE, bool EAGER = false>
 __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &g, const Src4 &mom, const bool special,
                                            const bool any_special /* wave-uniform */, const double eff,
                                            const double l2, const double inside, const double ml2, const double px, const double py,
@@ -476,8 +480,14 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
         }
     }
     const double r2 = dx * dx + dy * dy + dz * dz;
-    discard = (r2 > gp.rcut2) && (cmax > eff);
-    open = ((!gp.use_bh) && (ml2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cmax < inside);
+    if(EAGER) {
+        discard = (r2 > gp.rcut2) & (cmax > eff);
+        open = (ml2 > r2 * r2 * aold) | (l2 > r2 * gp.bhangle2) | (cmax < inside);
+    }
+    else {
+        discard = (r2 > gp.rcut2) && (cmax > eff);
+        open = ((!gp.use_bh) && (ml2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cmax < inside);
+    }
 }
 
 // state of one target of a pair (group-uniform except wrap_lane)
@@ -720,6 +730,298 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists2(const TreeView tv, con
     }
 }
 
+// ---- list construction with ONE traversal per wave: 8 targets share a frontier, one node per lane ---------------------------------
+// k_walk_lists / k_walk_lists2 spend two thirds of their instructions on bookkeeping that is repeated per group of 8 lanes and step
+// (ballot -> group mask -> prefix count -> predicated append, five times per step) and leave half of their lanes idle (a step tests
+// the <= 8 children of ONE node with 8 lanes).  Here the 64 lanes of a wave hold 64 DIFFERENT pending nodes of the union of the walks
+// of the wave's 8 targets (tree-order neighbours: leaf-mates mostly), popped from a wave-shared frontier in LDS whose entries carry
+// the mask of the targets that reached the node.  The wave then loops over its targets: target t's position and opening parameter
+// are wave-uniform (scalar registers), every lane applies the reference's two tests to ITS node for target t
+// (gravshort-tree.c:198-241; node_tests above, unchanged), and the three outcomes are wave-wide ballots: the leaf / node entries
+// of target t are appended by all lanes at once (position = count + v_mbcnt of the ballot: 2 instructions for 64 nodes instead of
+// ~10 per 8), the counts advance by s_bcnt1, the push mask of a lane collects the targets that open its node.  After the 8 targets
+// the opened internal nodes' children go back to the frontier (one entry per child: a prefix sum over the lanes by four ballots).
+// Per target the set of nodes tested and the outcome of every test are exactly those of its own walk (a node reaches the frontier
+// with bit t set iff target t opened its parent), only the ORDER of the list entries differs from k_walk_lists' (so the sums of
+// k_walk_eval differ by rounding between the two list kernels; the interaction counters are equal).
+// List layout of this kernel (CONTIG in k_walk_eval): target t of chunk u owns lists[(u * 8 + t) * cap ...], leaf entries from 0 up,
+// node entries from cap - 1 down - the 64 lanes of an append write one contiguous run.
+constexpr int QCAP = 1024; // frontier entries per wave (node index 4 B + target mask 1 B); a wave that would exceed it hands its targets to the fallback
+
+__device__ __forceinline__ unsigned mbcnt64(const unsigned long long b)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+}
+
+// the 8 targets of a wave: list lengths and counters are wave-uniform (scalar registers); positions and opening parameters sit in
+// LDS (s_tgt: [t][4] doubles) and are read back with a wave-uniform address per target - as scalars they overflowed the SGPR file
+// (8 x 8 registers) and every use cost a v_readlane
+struct WaveTargets {
+    int nleaf[8], nnode[8];
+    unsigned c_vis[8], c_used[8];
+};
+
+// returns false on an internal error (loop guard)
+template <bool COUNT, int MODE, bool O32>
+__device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ q_node,
+                                           unsigned char *__restrict__ q_mask, const double *__restrict__ s_tgt, const int cap, const int lane,
+                                           const unsigned live0, WaveTargets &T, unsigned &overflowed, bool &wrapped, unsigned (&c_pp)[8],
+                                           const unsigned guard_max, unsigned *__restrict__ ctl, unsigned &st_a, unsigned &st_al)
+{
+    unsigned live = live0; // targets still walking (wave-uniform)
+    int sp = 0;            // frontier entries (wave-uniform)
+    if(live) {
+        if(lane == 0) {
+            q_node[0] = 0u; // the root
+            q_mask[0] = (unsigned char)live;
+        }
+        sp = 1;
+    }
+    unsigned guard = 0;
+    unsigned long long wmask = 0;
+    int maxused = 0; // longest pair of lists among the wave's targets (wave-uniform)
+    while(sp > 0 && live) {
+        if(++guard > guard_max) {
+            if(lane == 0)
+                atomicExch(&ctl[1], 1u);
+            return false;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n = sp < 64 ? sp : 64;
+        const bool valid = lane < n;
+        // (idle lanes read entry 0, which always holds a node index: no exec-mask regions around the two reads)
+        const int qi = valid ? sp - 1 - lane : 0;
+        const unsigned my = q_node[qi];
+        const unsigned mask = valid ? ((unsigned)q_mask[qi] & live) : 0u;
+        sp -= n;
+        const NodeGeo g = ld<O32>(tv.geoB, my);
+        const Src4 mom = ld<O32>(tv.momB, my);
+        const NodeLinkB lk = ld<O32>(tv.linkB, my);
+        const double eff = fma(0.5, g.len, gp.rcut);
+        const double l2 = g.len * g.len;
+        const double inside = 0.6 * g.len;
+        const double ml2 = mom.m * l2;
+        const bool special = MODE != 0 && valid && my <= 8u;
+        const bool any_special = MODE != 0 && any_lane(special);
+        const bool isleaf = lk.pcount > 0, isint = lk.pcount <= 0 && lk.nchild > 0;
+        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+        unsigned openmask = 0;
+        if(COUNT) {
+            st_a++;
+            st_al += (unsigned)n;
+        }
+        // One pass over the wave's targets.  A target gains at most 64 entries per pass (one per lane): only when some list is that
+        // close to its capacity are the appends CHECKED one by one; the common pass has no branch but the two predicated stores.
+        auto pass = [&](auto checked_tag) {
+            constexpr bool CHECKED = decltype(checked_tag)::value;
+#pragma unroll
+            for(int t = 0; t < 8; t++) {
+                const bool act = (mask & (1u << t)) != 0u; // (no lane for a target that overflowed, is absent or did not open the parent)
+                // (measured: 28 % of the passes over a target find no lane with its bit - the entries popped late in a walk belong to
+                // few of the 8 targets - so the test pays for its two scalar instructions)
+                if(!any_lane(act))
+                    continue;
+                // (one address for the wave: a broadcast read.  The empty asm hides from hipcc that the 8 reads are the same in every
+                // pass of the walk: hoisted out of the loop they would hold 64 registers)
+                unsigned ot = 4u * t;
+                asm volatile("" : "+v"(ot));
+                const double4 tg = *(const double4 *)(s_tgt + ot);
+                bool d, o, w;
+                node_tests<MODE, true>(gp, g, mom, special, any_special, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, d, o, w);
+                const bool keep = act & !d;
+                const bool b_node = keep & !o;
+                const bool b_leaf = keep & o & isleaf;
+                const unsigned long long bl = __builtin_amdgcn_ballot_w64(b_leaf), bn = __builtin_amdgcn_ballot_w64(b_node);
+                const int kl = __builtin_popcountll(bl), kn = __builtin_popcountll(bn);
+                if(CHECKED && T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
+                    overflowed |= 1u << t;
+                    live &= ~(1u << t);
+                    continue;
+                }
+                unsigned *__restrict__ Lt = Lw + (unsigned)(t * cap); // (wave-uniform base)
+                if(b_leaf) // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
+                    st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, (unsigned)T.nleaf[t])), ent_val);
+                if(b_node)
+                    st32(Lt, (unsigned)(cap - 1 - T.nnode[t]) - mbcnt64(bn), my);
+                T.nleaf[t] += kl;
+                T.nnode[t] += kn;
+                maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
+                openmask |= (keep & o & isint) ? (1u << t) : 0u;
+                // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children
+                if(MODE == 1 || (MODE == 2 && any_special))
+                    wmask |= __builtin_amdgcn_ballot_w64(w & (b_leaf | b_node));
+                if(COUNT) {
+                    T.c_vis[t] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+                    T.c_used[t] += (unsigned)kn;
+                    c_pp[t] += b_leaf ? (unsigned)lk.pcount : 0u;
+                }
+                // (the 8 targets' tests are independent: left alone, hipcc interleaves them and runs out of registers)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if(maxused + 64 > cap)
+            pass(std::true_type{});
+        else
+            pass(std::false_type{});
+        // the children of the opened internal nodes: one frontier entry per child, mask = the targets that opened the parent
+        const bool pushing = openmask != 0u;
+        const unsigned long long bp = __builtin_amdgcn_ballot_w64(pushing);
+        if(bp != 0ull) {
+            const unsigned nm1 = (unsigned)(lk.nchild - 1); // 0..7
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 1u)), b1 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 2u)),
+                                     b2 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 4u));
+            const int total = __builtin_popcountll(bp) + __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+            if(sp + total > QCAP) { // (a pathological tree) every target still walking goes to the fallback
+                overflowed |= live;
+                live = 0;
+                break;
+            }
+            if(pushing) {
+                const unsigned at = (unsigned)sp + mbcnt64(bp) + mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2);
+#pragma unroll
+                for(unsigned c = 0; c < 8; c++)
+                    if(c <= nm1) {
+                        q_node[at + c] = (unsigned)lk.firstchild + c;
+                        q_mask[at + c] = (unsigned char)openmask;
+                    }
+            }
+            sp += total;
+        }
+    }
+    wrapped = wmask != 0ull;
+    return true;
+}
+
+// one wave = one chunk of k_walk_eval (8 consecutive targets)
+template <bool COUNT, bool FASTWRAP, bool O32, int BLK>
+__global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
+                                                      int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
+                                                      unsigned *__restrict__ ctl, int *__restrict__ ovf)
+{
+    __shared__ unsigned s_qnode[4 * QCAP];
+    __shared__ unsigned char s_qmask[4 * QCAP];
+    __shared__ __attribute__((aligned(32))) double s_tgt4[4 * 8 * 4];
+    set_wave_prio(io.list_prio);
+    const int lane = threadIdx.x & 63;
+    unsigned *q_node = s_qnode + (threadIdx.x >> 6) * QCAP;
+    unsigned char *q_mask = s_qmask + (threadIdx.x >> 6) * QCAP;
+    double *s_tgt = s_tgt4 + (threadIdx.x >> 6) * 32;
+    const unsigned nchunks = (unsigned)((nslots + 7) / 8);
+    const ChunkIter it(nchunks);
+    const unsigned guard_max = (unsigned)min((long long)(8ll * (tv.nnodes + 1024)), 0x7fffffffll);
+    const double face = gp.rcut + 0.002 * gp.box;
+    unsigned long long n_pp = 0, n_vis = 0, n_used = 0;
+    unsigned st_a = 0, st_al = 0;
+
+    for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
+        // lane t < 8 fetches target t; the values are then made wave-uniform
+        const int64_t rel = (int64_t)chunk * 8 + (lane & 7);
+        const bool tvalid = lane < 8 && rel < nslots;
+        int ci = -1;
+        double vx = 0, vy = 0, vz = 0, vaold = 0;
+        if(tvalid) {
+            const int64_t slot = slot0 + rel;
+            ci = io.targets ? io.targets[slot] : tv.order[slot];
+            vx = io.pos[3 * (int64_t)ci + 0];
+            vy = io.pos[3 * (int64_t)ci + 1];
+            vz = io.pos[3 * (int64_t)ci + 2];
+            double old = 0;
+            if(io.oldacc)
+                old = io.oldacc[ci];
+            else if(io.prev_accel) { // grav_get_abs_accel, gravshort.h:70-80
+                double s2 = 0;
+                for(int j = 0; j < 3; j++) {
+                    const double a = io.prev_accel[3 * (int64_t)ci + j] + (io.gravpm ? io.gravpm[3 * (int64_t)ci + j] : 0.0);
+                    s2 += a * a;
+                }
+                old = sqrt(s2) / gp.G;
+            }
+            // (Barnes-Hut walk: the relative criterion "mass l^2 > r^4 aold" must never hold - node_tests<., EAGER>)
+            vaold = gp.use_bh ? __builtin_inf() : gp.errtol * old;
+        }
+        const bool near_face = tvalid && (fmin(fmin(vx, vy), vz) < face || fmax(fmax(vx, vy), vz) > gp.box - face);
+        const unsigned live0 = (unsigned)(__builtin_amdgcn_ballot_w64(tvalid) & 0xffull);
+        WaveTargets T;
+        unsigned c_pp[8];
+        __builtin_amdgcn_wave_barrier(); // (the previous chunk's reads of s_tgt are done: LDS operations of a wave complete in order)
+        if(lane < 8)
+            *(double4 *)(s_tgt + 4 * lane) = make_double4(vx, vy, vz, vaold);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for(int t = 0; t < 8; t++) {
+            T.nleaf[t] = T.nnode[t] = 0;
+            T.c_vis[t] = T.c_used[t] = 0u;
+            c_pp[t] = 0u;
+        }
+        unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8;
+        unsigned overflowed = 0;
+        bool wrapped = false; // (one flag for the wave: k_walk_eval takes NEAREST() for a whole chunk anyway)
+        bool ok;
+        if(FASTWRAP) {
+            if(!any_lane(near_face))
+                ok = walk_wave8<COUNT, 2, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+            else
+                ok = walk_wave8<COUNT, 1, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+        }
+        else
+            ok = walk_wave8<COUNT, 0, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+        if(!ok)
+            return;
+        int nl = 0, nn = 0;
+#pragma unroll
+        for(int t = 0; t < 8; t++)
+            if(lane == t) {
+                nl = T.nleaf[t];
+                nn = T.nnode[t];
+            }
+        if(tvalid) {
+            const bool overflow = (overflowed >> lane) & 1u;
+            // the work this target causes in the two kernels: 8 lanes per leaf entry and 1 per node entry in the evaluation, and about
+            // as many node tests as it has entries in the list construction (k_walk_lists / k_walk_lists2 count 8 per traversal step
+            // instead; the measure only has to be proportional to the time spent: domain.c:611)
+            if(io.cost)
+                io.cost[ci] = (float)(8 * (overflow ? cap : nl) + nn + 3 * (nl + nn));
+            if(overflow) {
+                counts[rel] = make_int2(-1, 0);
+                ovf[atomicAdd(&ctl[0], 1u)] = ci;
+            }
+            else {
+                counts[rel] = make_int2(nl | (wrapped ? (1 << 30) : 0), nn);
+                if((unsigned)(nl + nn) > ctl[2])
+                    atomicMax(&ctl[2], (unsigned)(nl + nn));
+            }
+        }
+        if(COUNT) {
+#pragma unroll
+            for(int t = 0; t < 8; t++)
+                if(!((overflowed >> t) & 1u)) { // an overflowed target is walked again, and counted, by the fallback kernel
+                    n_pp += c_pp[t]; // (per lane; summed over the wave below)
+                    if(lane == 0) {
+                        n_vis += T.c_vis[t];
+                        n_used += T.c_used[t];
+                    }
+                }
+        }
+    }
+    if(COUNT) {
+        unsigned long long c0 = n_pp, c1 = n_vis, c2 = n_used, c3 = lane == 0 ? st_a : 0u, c4 = lane == 0 ? st_al : 0u;
+        for(int off = 32; off > 0; off >>= 1) {
+            c0 += __shfl_down(c0, off);
+            c1 += __shfl_down(c1, off);
+            c2 += __shfl_down(c2, off);
+            c3 += __shfl_down(c3, off);
+            c4 += __shfl_down(c4, off);
+        }
+        if(lane == 0) {
+            atomicAdd(&io.counters[0], c0);
+            atomicAdd(&io.counters[1], c1);
+            atomicAdd(&io.counters[2], c2);
+            atomicAdd(&io.counters[3], c3);
+            atomicAdd(&io.counters[4], c4);
+        }
+    }
+}
+
 // The two list loops of one group (8 lanes, lane s <-> source s of a leaf entry / entry r0 + s of the node list).
 // WRAP: take NEAREST() per pair (partmanager.h:99); otherwise plain differences (bit-identical where no image is wrapped).
 //
@@ -729,7 +1031,8 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists2(const TreeView tv, con
 // source (short leaf, list exhausted) reads a zero-mass padding record behind the tree's source array instead: its pair
 // evaluates to exactly zero, so the accumulators are updated unconditionally (a conditional update makes hipcc keep a
 // renamed copy of the four accumulators per unrolled stage).
-template <bool POT, bool WRAP, bool O32>
+// CONTIG: the lists of group g start at L + g * cap and are contiguous (k_walk_lists8); otherwise the interleaved layout above.
+template <bool POT, bool WRAP, bool O32, bool CONTIG>
 __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
                                            const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
                                            const double py, const double pz, const double *__restrict__ s_wtab,
@@ -758,15 +1061,17 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // two source buffers (A, B) used alternately: while one pair is evaluated the other buffer's load is in flight.  The
         // stage loop is deliberately not unrolled beyond that: every unrolled stage carries its own copy of the (rare)
         // softened branch, and those copies are what drives register pressure and code size.
-        const unsigned ls = (unsigned)(gshift + s);
-        unsigned ent = (s < nleaf) ? ld<true>(L, ls) : empty;
-        unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, 64u + ls) : empty;
+        // index of leaf entry e0 + s (e0 a multiple of 8)
+        const unsigned ls = CONTIG ? (unsigned)((gshift >> 3) * cap + s) : (unsigned)(gshift + s);
+#define MPG_LEAF_AT(E0) (CONTIG ? ls + (unsigned)(E0) : (((unsigned)(E0) >> 3) << 6) + ls)
+        unsigned ent = (s < nleaf) ? ld<true>(L, MPG_LEAF_AT(0)) : empty;
+        unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(8)) : empty;
         Src4 A, B;
         MPG_LOAD(ent, 0, A);
         for(int e0 = 0;; e0 += 8) {
             if(!any_lane(e0 < nleaf))
                 break;
-            const unsigned ent_nn = (e0 + 16 + s < nleaf) ? ld<true>(L, (((unsigned)(e0 + 16) >> 3) << 6) + ls) : empty;
+            const unsigned ent_nn = (e0 + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e0 + 16)) : empty;
 #pragma unroll 1
             for(int j = 0; j < 8; j += 2) {
                 MPG_LOAD(ent, j + 1, B);
@@ -782,15 +1087,17 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
     // ---- node entries (level-order indices): lane s takes entry r0 + s; entries two batches ahead, moments one
     if(any_lane(nnode > 0)) {
         const unsigned NONE = (unsigned)tv.nnodes; // a zero-mass padding record behind the moments (TreeBuilder::make_level_order)
-        const unsigned top = (((unsigned)(cap - 8) >> 3) << 6) + (unsigned)(gshift + 7 - s);
-        unsigned ne = (s < nnode) ? ld<true>(L, top) : NONE;
-        unsigned ne_n = (8 + s < nnode) ? ld<true>(L, top - 64u) : NONE;
+        // index of node entry r0 + s counted from the top of the list (r0 a multiple of 8)
+        const unsigned top = CONTIG ? (unsigned)((gshift >> 3) * cap + cap - 1 - s) : (((unsigned)(cap - 8) >> 3) << 6) + (unsigned)(gshift + 7 - s);
+#define MPG_NODE_AT(R0) (CONTIG ? top - (unsigned)(R0) : top - (((unsigned)(R0) >> 3) << 6))
+        unsigned ne = (s < nnode) ? ld<true>(L, MPG_NODE_AT(0)) : NONE;
+        unsigned ne_n = (8 + s < nnode) ? ld<true>(L, MPG_NODE_AT(8)) : NONE;
         Src4 sc = ld<O32>(tv.momB, ne);
         for(int r0 = 0;; r0 += 8) {
             if(!any_lane(r0 < nnode))
                 break;
             ne = ne_n;
-            ne_n = (r0 + 16 + s < nnode) ? ld<true>(L, top - (((unsigned)(r0 + 16) >> 3) << 6)) : NONE;
+            ne_n = (r0 + 16 + s < nnode) ? ld<true>(L, MPG_NODE_AT(r0 + 16)) : NONE;
             const Src4 sc_n = ld<O32>(tv.momB, ne);
             MPG_EVAL(sc);
             sc = sc_n;
@@ -798,9 +1105,11 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
     }
 #undef MPG_LOAD
 #undef MPG_EVAL
+#undef MPG_LEAF_AT
+#undef MPG_NODE_AT
 }
 
-template <bool POT, bool FASTWRAP, bool O32, int BLK>
+template <bool POT, bool FASTWRAP, bool O32, bool CONTIG, int BLK>
 __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
                                                     const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
 {
@@ -850,9 +1159,9 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
         const unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8; // wave-uniform
         double ax = 0, ay = 0, az = 0, pot = 0;
         if(!FASTWRAP || any_lane(wrapped)) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
-            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, true, O32, CONTIG>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         else
-            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, false, O32, CONTIG>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         // reduce the partial sums over the 8 lanes of the group
         for(int off = 1; off < 8; off <<= 1) {
             ax += __shfl_xor(ax, off);
@@ -909,21 +1218,20 @@ int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_p
 template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
-    // resident 256-thread blocks per CU each kernel is compiled for (= waves per SIMD: 512 VGPRs / that many).  Experiment knobs
-    // MPG_LISTS_BLOCKS (6 | 8) and MPG_EVAL_BLOCKS (4 | 5 | 6); the defaults are the measured best (profiles/r02b_walk_knobs.txt)
-    static const int lists_blk_env = getenv("MPG_LISTS_BLOCKS") ? atoi(getenv("MPG_LISTS_BLOCKS")) : 0;
-    static const int eval_blk = getenv("MPG_EVAL_BLOCKS") ? atoi(getenv("MPG_EVAL_BLOCKS")) : MPG_EVAL_BLOCKS;
-    // MPG_LISTS_PAIR: 1 (default) two targets per group of 8 lanes (k_walk_lists2; its stack entries hold 27-bit node indices, larger
-    // trees take the other kernel), 0 one (k_walk_lists).  Measured at 256^3, ms per step, pair / single: Zel'dovich 97.9 / 100.2,
-    // S-grid 82.0 / 83.7, clustered 177.5 / 187.1 (same lists, bit-identical results)
-    static const int pair_env = getenv("MPG_LISTS_PAIR") ? atoi(getenv("MPG_LISTS_PAIR")) : 1;
-    const bool pair = pair_env != 0 && tv.nnodes < (1ll << 27);
-    const int lists_blk = lists_blk_env ? lists_blk_env : (pair ? 5 : 6); // (the pair kernel: 5 waves per SIMD, 96 VGPRs; measured best)
-    auto kl = pair ? (lists_blk == 4   ? k_walk_lists2<COUNT, FASTWRAP, O32, 4>
-                      : lists_blk == 5 ? k_walk_lists2<COUNT, FASTWRAP, O32, 5>
-                                       : k_walk_lists2<COUNT, FASTWRAP, O32, 6>)
-                   : (lists_blk == 8 ? k_walk_lists<COUNT, FASTWRAP, O32, 8> : k_walk_lists<COUNT, FASTWRAP, O32, 6>);
-    auto ke = eval_blk == 4 ? k_walk_eval<POT, FASTWRAP, O32, 4> : (eval_blk == 5 ? k_walk_eval<POT, FASTWRAP, O32, 5> : k_walk_eval<POT, FASTWRAP, O32, 6>);
+    // List construction: ws.split_lists_mode 2 (default) one traversal per wave of 8 targets (k_walk_lists8), 1 pairs of targets per
+    // group of 8 lanes (k_walk_lists2; its stack entries hold 27-bit node indices), 0 one target per group (k_walk_lists).  Modes 0
+    // and 1 write the same lists entry for entry (bit-identical results); mode 2 writes the same entries in another order and in the
+    // contiguous layout.  MPG_LISTS_MODE overrides (experiments; read once per process).
+    static const int mode_env = getenv("MPG_LISTS_MODE") ? atoi(getenv("MPG_LISTS_MODE")) : -1;
+    int mode = mode_env >= 0 ? mode_env : ws.split_lists_mode;
+    if(mode == 1 && tv.nnodes >= (1ll << 27))
+        mode = 0;
+    const bool pair = mode == 1, contig = mode == 2;
+    static const int l8_blk = getenv("MPG_LISTS8_BLOCKS") ? atoi(getenv("MPG_LISTS8_BLOCKS")) : 6; // resident blocks per CU k_walk_lists8 is compiled for
+    auto kl = contig ? (l8_blk == 4 ? k_walk_lists8<COUNT, FASTWRAP, O32, 4> : l8_blk == 5 ? k_walk_lists8<COUNT, FASTWRAP, O32, 5> : k_walk_lists8<COUNT, FASTWRAP, O32, 6>)
+              : pair ? k_walk_lists2<COUNT, FASTWRAP, O32, 5>
+                     : k_walk_lists<COUNT, FASTWRAP, O32, 6>;
+    auto ke = contig ? k_walk_eval<POT, FASTWRAP, O32, true, MPG_EVAL_BLOCKS> : k_walk_eval<POT, FASTWRAP, O32, false, MPG_EVAL_BLOCKS>;
     const int cap = ws.split_cap;
     // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
     int64_t slice = (int64_t)(ws.split_bytes / ((size_t)cap * sizeof(unsigned))) / 2048 * 2048;

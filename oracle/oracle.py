@@ -41,9 +41,10 @@ def _vp(a):
 class Oracle:
     """One loaded oracle library (strict or the reference-flags 'fast' build)."""
 
-    def __init__(self, fast=False):
+    def __init__(self, fast=False, lib_path=None):
+        """lib_path: another build of the same sources (tests/test_hydro_physics.py loads deliberately mutated copies)"""
         build()
-        path = os.path.join(_BUILD, "liboracle_fast.so" if fast else "liboracle.so")
+        path = lib_path or os.path.join(_BUILD, "liboracle_fast.so" if fast else "liboracle.so")
         L = self.lib = C.CDLL(path)
         L.ot_build.restype = C.c_void_p
         L.ot_build.argtypes = [C.c_int64, _dp, _fp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]

@@ -14,12 +14,13 @@
 #include "forcetree.h"   /* ForceTree */
 #include "domain.h"      /* DomainDecomp, struct topnode_data / topleaf_data */
 #include "partmanager.h" /* P, PartManager */
-#include "timestep.h"    /* ActiveParticles */
+#include "timestep.h"    /* ActiveParticles, get_atime */
 #include "walltime.h"
 #include "utils/endrun.h"
 #include "utils/mymalloc.h"
 #include <mpgadget_hip.h>
 #include "mpg_mpi_comm.h"
+#include "mpg_shim.h"
 
 _Static_assert(sizeof(struct particle_data) == 160 && __builtin_offsetof(struct particle_data, GravPM) == 88 &&
                __builtin_offsetof(struct particle_data, FullTreeGravAccel) == 64 && __builtin_offsetof(struct particle_data, Potential) == 152,
@@ -31,11 +32,20 @@ static mpg_engine *E;
 static mpg_dist *D;
 static MPI_Comm Comm;
 static int NTask = 1;
-static int64_t Epoch;
-static const DomainDecomp *DomainOfD; /* the decomposition D was told about */
-static int NTopLeavesOfD;
 
-static void ck(int rc)
+/* ---- what the library was last told (mpg_shim.h) ---- */
+static int64_t Epoch;              /* particle-table epoch handed to mpg_set_particle_epoch */
+static inttime_t TableTi = -1;     /* (Ti_Current, &P[0], NumPart) of that epoch */
+static const void *TableBase;
+static int64_t TableNumPart = -1;
+static int TableDirty = 1;         /* mpg_shim_particles_changed() */
+static DomainDecomp *Domain;       /* the run's decomposition object */
+static uint64_t DomainHash;        /* of what mpg_dist_set_domain last received ... */
+static double DomainMargin;        /* ... with this margin */
+static int64_t DistTreeEpoch = -1; /* epoch of the local tree + ghost plan inside the library (NTask > 1) */
+
+#define ck mpg_shim_ck
+void mpg_shim_ck(int rc)
 {
     if(rc)
         endrun(5, "mpgadget_hip: %s\n", mpg_last_error());
@@ -61,14 +71,103 @@ static mpg_engine *eng(void)
     return E;
 }
 
-mpg_engine *mpg_shim_engine(void) { return eng(); } /* sph-hip.c shares the rank's engine */
-mpg_dist *mpg_shim_dist(void) { return eng(), D; }  /* ... and its multi-rank state (NULL with one rank) */
+mpg_engine *mpg_shim_engine(void) { return eng(); }
+mpg_dist *mpg_shim_dist(void) { return eng(), D; }
+int mpg_shim_ntask(void) { return eng(), NTask; }
 
-static mpg_particle_view view(void)
+mpg_particle_view mpg_shim_view(void)
 {
     mpg_particle_view v;
     mpg_particle_view_reference_layout(&v, P, PartManager->NumPart);
     return v;
+}
+#define view mpg_shim_view
+
+void mpg_shim_set_domain(DomainDecomp *ddecomp) { Domain = ddecomp; }
+void mpg_shim_particles_changed(void) { TableDirty = 1; }
+void mpg_shim_dist_tree_replaced(void) { DistTreeEpoch = -1; }
+double mpg_shim_margin(void) { return DomainMargin; }
+
+/* FNV-1a over what mpg_dist_set_domain reads: the decomposition is rewritten in place by every domain_decompose_full (run.c:422,434),
+ * so neither the pointer nor NTopLeaves says whether it changed */
+static uint64_t domain_hash(const DomainDecomp *dd)
+{
+    uint64_t h = 1469598103934665603ull;
+    int i;
+#define MIX(x) (h = (h ^ (uint64_t)(x)) * 1099511628211ull)
+    MIX(dd->NTopNodes);
+    MIX(dd->NTopLeaves);
+    for(i = 0; i < dd->NTopNodes; i++) {
+        MIX(dd->TopNodes[i].StartKey);
+        MIX(dd->TopNodes[i].Shift);
+        MIX(dd->TopNodes[i].Daughter);
+        MIX(dd->TopNodes[i].Daughter < 0 ? dd->TopNodes[i].Leaf : -1);
+    }
+    for(i = 0; i < dd->NTopLeaves; i++)
+        MIX(dd->TopLeaves[i].Task);
+#undef MIX
+    return h;
+}
+
+static void push_domain(double BoxSize, double margin)
+{
+    const DomainDecomp *dd = Domain;
+    mpg_topnode *tn = (mpg_topnode *)mymalloc("mpg_topnodes", dd->NTopNodes * sizeof(mpg_topnode));
+    int *task = (int *)mymalloc("mpg_leaftask", dd->NTopLeaves * sizeof(int));
+    int i;
+    for(i = 0; i < dd->NTopNodes; i++) {
+        memset(&tn[i], 0, sizeof(tn[i]));
+        tn[i].StartKey = dd->TopNodes[i].StartKey;
+        tn[i].Shift = dd->TopNodes[i].Shift;
+        tn[i].Daughter = dd->TopNodes[i].Daughter;
+        tn[i].Leaf = dd->TopNodes[i].Daughter < 0 ? dd->TopNodes[i].Leaf : -1;
+    }
+    for(i = 0; i < dd->NTopLeaves; i++)
+        task[i] = dd->TopLeaves[i].Task;
+    ck(mpg_dist_set_domain(D, BoxSize, tn, dd->NTopNodes, task, dd->NTopLeaves, margin, 0));
+    myfree(task);
+    myfree(tn);
+}
+
+void mpg_shim_sync(inttime_t Ti_Current, double Time, double BoxSize, double margin_want)
+{
+    eng();
+    /* ---- the particle table ---- */
+    if(Ti_Current < 0 && TableTi >= 0 && Time == get_atime(TableTi))
+        Ti_Current = TableTi; /* gravpm_force of the step whose density() / grav_short_tree() already came by (run.c:356,522) */
+    if(TableDirty || Ti_Current < 0 || Ti_Current != TableTi || TableBase != (const void *)P || TableNumPart != PartManager->NumPart) {
+        Epoch++;
+        TableTi = Ti_Current;
+        TableBase = (const void *)P;
+        TableNumPart = PartManager->NumPart;
+        TableDirty = 0;
+    }
+    ck(mpg_set_particle_epoch(E, Epoch));
+    /* ---- the decomposition (several ranks) ---- */
+    if(NTask > 1) {
+        if(!Domain)
+            endrun(5, "mpgadget_hip: no DomainDecomp known yet: call mpg_shim_set_domain(ddecomp) after domain_decompose_full\n");
+        const uint64_t h = domain_hash(Domain);
+        /* every rank must take the same decision: the margin wanted is the largest over the ranks */
+        double m = margin_want;
+        MPI_Allreduce(MPI_IN_PLACE, &m, 1, MPI_DOUBLE, MPI_MAX, Comm);
+        if(m <= 0)
+            m = DomainMargin; /* a caller without a range of its own (hydro_force after density, set_init_hsml) keeps what is in force */
+        if(m > 0 && (h != DomainHash || m > DomainMargin)) {
+            push_domain(BoxSize, m);
+            DomainHash = h;
+            DomainMargin = m;
+            DistTreeEpoch = -1; /* the ghost plan belongs to the old need-map */
+        }
+    }
+}
+
+void mpg_shim_dist_tree(const mpg_particle_view *v)
+{
+    if(DistTreeEpoch == Epoch)
+        return;
+    ck(mpg_dist_force_tree_full(D, v));
+    DistTreeEpoch = Epoch;
 }
 
 /* the clocks the reference charges on this path, fed from the engine's per-phase device times */
@@ -98,55 +197,32 @@ void gravpm_init_periodic(PetaPM *pm, double BoxSize, double Asmth, int Nmesh, d
  * gravity path is never given to petapm_init here, so petapm_destroy on it finds priv == NULL plans... the maintainer guards
  * runtests.c:204,222 with `if(pm->priv)`; the device mesh is released by mpg_petapm_destroy when the engine is destroyed. */
 
-/* tell the library about the decomposition the particles were exchanged by (domain_decompose_full ran before this step) */
-static void sync_domain(DomainDecomp *ddecomp, double BoxSize, double Rcut)
-{
-    if(DomainOfD == ddecomp && NTopLeavesOfD == ddecomp->NTopLeaves)
-        return;
-    mpg_topnode *tn = (mpg_topnode *)mymalloc("mpg_topnodes", ddecomp->NTopNodes * sizeof(mpg_topnode));
-    int *task = (int *)mymalloc("mpg_leaftask", ddecomp->NTopLeaves * sizeof(int));
-    int i;
-    for(i = 0; i < ddecomp->NTopNodes; i++) {
-        memset(&tn[i], 0, sizeof(tn[i]));
-        tn[i].StartKey = ddecomp->TopNodes[i].StartKey;
-        tn[i].Shift = ddecomp->TopNodes[i].Shift;
-        tn[i].Daughter = ddecomp->TopNodes[i].Daughter;
-        tn[i].Leaf = ddecomp->TopNodes[i].Daughter < 0 ? ddecomp->TopNodes[i].Leaf : -1;
-    }
-    for(i = 0; i < ddecomp->NTopLeaves; i++)
-        task[i] = ddecomp->TopLeaves[i].Task;
-    ck(mpg_dist_set_domain(D, BoxSize, tn, ddecomp->NTopNodes, task, ddecomp->NTopLeaves, Rcut, 0));
-    myfree(task);
-    myfree(tn);
-    DomainOfD = ddecomp;
-    NTopLeavesOfD = ddecomp->NTopLeaves;
-}
-
 void gravpm_force(PetaPM *pm, DomainDecomp *ddecomp, Cosmology *CP, double Time, double UnitLength_in_cm, const char *PowerOutputDir,
                   double TimeIC)
 {
     (void)CP;
-    (void)UnitLength_in_cm;
     (void)TimeIC;
-    mpg_particle_view v = view();
     walltime_measure("/Misc");
-    /* P[] has just been exchanged / drifted: one upload of Pos / Mass serves the three calls of this step (run.c:522-548) */
-    ck(mpg_set_particle_epoch(eng(), ++Epoch));
+    mpg_shim_set_domain(ddecomp);
+    const struct gravshort_tree_params tp = get_gravshort_treepar();
+    /* one upload of Pos / Mass serves the calls of this step (run.c:472-548); Ti_Current is not an argument here: matched through Time */
+    mpg_shim_sync(-1, Time, pm->BoxSize, tp.Rcut * pm->Asmth * pm->CellSize);
+    mpg_particle_view v = view();
     if(NTask == 1)
         ck(mpg_gravpm_force(eng(), &v)); /* writes P[i].GravPM, accumulates P[i].Potential */
-    else {
-        const struct gravshort_tree_params tp = get_gravshort_treepar();
-        sync_domain(ddecomp, pm->BoxSize, tp.Rcut * pm->Asmth * pm->CellSize);
+    else
         ck(mpg_dist_gravpm_force(D, &v));
-    }
     charge_pm_clocks();
-    /* the matter power spectrum gravpm_force saves on every PM step (gravpm.c:110-118) */
-    if(PowerOutputDir && NTask == 1) {
+    /* the matter power spectrum gravpm_force saves on every PM step (gravpm.c:110-118): summed over the ranks, written by rank 0 */
+    if(PowerOutputDir) {
         double *kk = (double *)mymalloc("pk", 2 * pm->Nmesh * sizeof(double)), *pw = kk + pm->Nmesh;
         int64_t *nm = (int64_t *)mymalloc("pkn", pm->Nmesh * sizeof(int64_t));
-        int nonzero = 0;
-        ck(mpg_gravpm_get_powerspectrum(eng(), pm->BoxSize * UnitLength_in_cm / 3.085678e24, kk, pw, nm, &nonzero));
-        int rank;
+        int nonzero = 0, rank;
+        const double BoxSize_in_MPC = pm->BoxSize * UnitLength_in_cm / 3.085678e24; /* CM_PER_MPC, gravpm.c:112 */
+        if(NTask == 1)
+            ck(mpg_gravpm_get_powerspectrum(eng(), BoxSize_in_MPC, kk, pw, nm, &nonzero));
+        else
+            ck(mpg_dist_gravpm_get_powerspectrum(D, BoxSize_in_MPC, kk, pw, nm, &nonzero));
         MPI_Comm_rank(MPI_COMM_WORLD, &rank);
         if(rank == 0)
             ck(mpg_powerspectrum_save(PowerOutputDir, "powerspectrum", Time, 1.0, nonzero, kk, pw, nm));
@@ -183,26 +259,30 @@ double FORCE_SOFTENING(void) { return mpg_force_softening(eng()); }
  * force_tree_full(). */
 void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, MyFloat (*AccelStore)[3], double rho0, inttime_t Ti_Current)
 {
-    (void)Ti_Current;
-    mpg_particle_view v = view();
     if(!tree->moments_computed_flag)
         endrun(2, "Gravtree called before tree moments computed!\n");
     walltime_measure("/Misc");
+    const struct gravshort_tree_params tp = get_gravshort_treepar();
+    /* (run.c calls density() / hydro_force() and, on PM steps, gravpm_force() before this with the same Ti_Current: same epoch, one
+     * upload; a redecomposition on a non-PM step - extradomain or needfull, run.c:417-435 - is seen here through the hash) */
+    mpg_shim_sync(Ti_Current, 0, tree->BoxSize, tp.Rcut * pm->Asmth * pm->CellSize);
+    mpg_particle_view v = view();
     if(NTask == 1) {
         ck(mpg_force_tree_rebuild_mask(eng(), &v, tree->BoxSize, tree->mask));
         ck(mpg_grav_short_tree(eng(), &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
     }
     else {
-        (void)pm;
         if(!tree->full_particle_tree_flag) {
             /* hierarchical_gravity_accelerations: the tree of force_tree_active_moments holds the active particles only; the library
              * gathers that (small) set on every rank and builds its tree itself, results in AccelStore */
             if(!AccelStore)
                 endrun(5, "mpgadget_hip: a walk on an active-only tree needs AccelStore\n");
             ck(mpg_dist_grav_short_tree_active_tree(D, &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
+            mpg_shim_dist_tree_replaced();
         }
         else {
-            ck(mpg_dist_force_tree_full(D, &v));
+            /* the gravity tree of this table: built once per epoch unless an SPH loop has replaced it in the meantime */
+            mpg_shim_dist_tree(&v);
             ck(mpg_dist_grav_short_tree_active(D, &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
         }
     }
@@ -226,9 +306,11 @@ void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, My
 void grav_short_pair(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, double Rcut, double rho0)
 {
     (void)pm;
-    mpg_particle_view v = view();
-    if(NTask > 1)
+    if(mpg_shim_ntask() > 1)
         endrun(5, "mpgadget_hip: grav_short_pair is a single-rank test helper (runtests.c)\n");
+    mpg_shim_particles_changed(); /* (no Ti_Current here: runtests.c moves nothing between its calls, but it may have read a snapshot) */
+    mpg_shim_sync(-1, -1, tree->BoxSize, 0);
+    mpg_particle_view v = view();
     ck(mpg_force_tree_rebuild_mask(eng(), &v, tree->BoxSize, tree->mask));
     ck(mpg_grav_short_pair(eng(), &v, act->ActiveParticle, act->NumActiveParticle, Rcut, rho0));
     walltime_measure("/Tree/Pairwise");

@@ -1,0 +1,40 @@
+/* libgadget/mpg_shim.h -- what gravity-hip.c and sph-hip.c share: the rank's engine, its multi-rank state, the error check, and the
+ * bookkeeping that tells the library WHEN the rank's particle table or the domain decomposition changed.
+ *
+ * The reference calls its force modules in a fixed order per step (run.c:392-548): drift + domain_decompose_full / domain_maintain,
+ * then density() and hydro_force() (run.c:472,489), then gravpm_force() on PM steps (run.c:522) and force_tree_full() +
+ * grav_short_tree() (run.c:546-547); at start-up set_init_hsml() and density() run before any gravity (init.c).  None of these
+ * calls says "P[] moved since you last saw it", and ddecomp is rewritten IN PLACE by every domain_decompose_full (run.c:422,434),
+ * usually with the same NTopLeaves.  So every entry point of the shim starts with mpg_shim_sync():
+ *   - the particle table is identified by (Ti_Current, &P[0], NumPart): a new key is a new epoch for the engine's upload cache
+ *     (mpg_set_particle_epoch) and invalidates the local tree / ghost plan of the multi-rank path;
+ *   - the decomposition is identified by a hash over TopNodes (StartKey, Shift, Daughter, Leaf) and TopLeaves[].Task, recomputed on
+ *     every call (a few thousand entries): a new hash, or a margin that grew, goes to mpg_dist_set_domain.
+ * A maintainer who prefers explicit hooks calls mpg_shim_particles_changed() after anything else that moves or reorders P[]
+ * within one Ti_Current (fof_fof's exchange, a restart) and mpg_shim_set_domain() once with the run's DomainDecomp. */
+#ifndef MPG_SHIM_H
+#define MPG_SHIM_H
+#include "domain.h"
+#include "timebinmgr.h"
+#include <mpgadget_hip.h>
+
+mpg_engine *mpg_shim_engine(void);  /* the rank's engine (created on first use; one rank = one GPU) */
+mpg_dist *mpg_shim_dist(void);      /* its multi-rank state, NULL with one rank */
+int mpg_shim_ntask(void);
+void mpg_shim_ck(int rc);           /* endrun(5, mpg_last_error()) on a non-zero return code */
+
+/* the DomainDecomp of this run (run.c keeps one object for the whole run); gravpm_force() and set_init_hsml() also pass it */
+void mpg_shim_set_domain(DomainDecomp *ddecomp);
+/* P[] was moved / reordered / resized by something the shim cannot see */
+void mpg_shim_particles_changed(void);
+/* Start of every entry point.  Ti_Current < 0: not known to the caller (gravpm_force: matched through Time = get_atime(Ti)).
+ * margin_want: the interaction range this call needs covered by ghosts (Rcut in length units; the largest smoothing length for the
+ * SPH loops); the domain is (re-)set when the decomposition changed or the margin in force is smaller. */
+void mpg_shim_sync(inttime_t Ti_Current, double Time, double BoxSize, double margin_want);
+/* NTask > 1: the local tree + ghost plan of the current table (mpg_dist_force_tree_full once per epoch) */
+void mpg_shim_dist_tree(const mpg_particle_view *v);
+/* ... and its invalidation by the SPH loops / FOF, which replace the gravity tree inside the library */
+void mpg_shim_dist_tree_replaced(void);
+double mpg_shim_margin(void); /* the ghost margin in force (0: no domain handed over yet) */
+mpg_particle_view mpg_shim_view(void);
+#endif

@@ -27,15 +27,22 @@
 #include "utils/endrun.h"
 #include "utils/mymalloc.h"
 #include <mpgadget_hip.h>
+#include "mpg_shim.h" /* the rank's engine / multi-rank state, mpg_shim_sync, mpg_shim_ck (gravity-hip.c) */
 
-extern mpg_engine *mpg_shim_engine(void); /* gravity-hip.c: the rank's engine */
-extern mpg_dist *mpg_shim_dist(void);     /* gravity-hip.c: the rank's multi-rank state, NULL with one rank */
+#define ck mpg_shim_ck
 
-/* the multi-rank density loop serves gas only */
-static void need_no_bh(int BlackHoleOn)
+/* the largest smoothing length of the density loop's targets on this rank: the ghosts must cover it (mpg_shim_sync takes the
+ * maximum over the ranks).  The loop may still grow Hsml beyond the margin chosen from it (void gas): density() then repeats
+ * the call with the margin the library reports (mpg_dist_last_max_hsml). */
+static double max_target_hsml(int BlackHoleOn)
 {
-    if(BlackHoleOn)
-        endrun(5, "mpgadget_hip: the multi-rank density loop does not serve black holes\n");
+    double h = 0;
+    int64_t i;
+    #pragma omp parallel for reduction(max : h)
+    for(i = 0; i < PartManager->NumPart; i++)
+        if(!P[i].IsGarbage && !P[i].Swallowed && (P[i].Type == 0 || (BlackHoleOn && P[i].Type == 5)) && P[i].Hsml > h)
+            h = P[i].Hsml;
+    return h;
 }
 
 void mpg_shim_set_densitypar(const struct density_params *dp)
@@ -136,19 +143,18 @@ static void release(struct sph_host *H)
     myfree(H->block);
 }
 
-static mpg_particle_view view(void)
-{
-    mpg_particle_view v;
-    mpg_particle_view_reference_layout(&v, P, PartManager->NumPart);
-    return v;
-}
+#define view mpg_shim_view
 
 void set_init_hsml(ForceTree *tree, DomainDecomp *ddecomp, const double MeanGasSeparation)
 {
-    (void)ddecomp;
     struct sph_host H;
-    mpg_particle_view v = view();
     int64_t i;
+    mpg_shim_set_domain(ddecomp);
+    /* init.c:setup_smoothinglengths calls this once at start-up, before any force: a fresh epoch.  The estimate is local arithmetic
+     * on the node sizes of the rank's own gas tree (density.c:57-73: no neighbour search), so one rank's form serves any NTask */
+    mpg_shim_particles_changed();
+    mpg_shim_sync(-1, -1, tree->BoxSize, 0);
+    mpg_particle_view v = view();
     gather(&H);
     ck(mpg_set_init_hsml(mpg_shim_engine(), &v, tree->BoxSize, &H.A, MeanGasSeparation));
     #pragma omp parallel for
@@ -156,6 +162,7 @@ void set_init_hsml(ForceTree *tree, DomainDecomp *ddecomp, const double MeanGasS
         if(P[i].Type == 0 || P[i].Type == 5)
             P[i].Hsml = H.A.hsml[i];
     release(&H);
+    mpg_shim_particles_changed(); /* (the engine now holds this table under an epoch that gravity must not reuse blindly: Hsml changed) */
 }
 
 void density(const ActiveParticles *act, int update_hsml, int DoEgyDensity, int BlackHoleOn, const DriftKickTimes times, Cosmology *CP,
@@ -164,15 +171,32 @@ void density(const ActiveParticles *act, int update_hsml, int DoEgyDensity, int 
     (void)SPH_predicted; /* the engine keeps its own prediction cache (density.c:75-100) */
     struct sph_host H;
     mpg_sph_times t;
-    mpg_particle_view v = view();
     int64_t i;
     walltime_measure("/Misc");
+    /* density() is the FIRST force call of a step (run.c:472, and of the start-up: init.c): the table may just have been drifted
+     * and exchanged, the decomposition rewritten */
+    mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, mpg_shim_dist() ? 1.26 * max_target_hsml(BlackHoleOn) : 0);
+    mpg_particle_view v = view();
     gather(&H);
     fill_times(&t, &times, CP, 0);
     walltime_measure("/SPH/Density/Init");
     if(mpg_shim_dist()) {
-        need_no_bh(BlackHoleOn);
-        ck(mpg_dist_density(mpg_shim_dist(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml, DoEgyDensity));
+        int attempt;
+        ck(mpg_dist_set_sph_options(mpg_shim_dist(), BlackHoleOn));
+        for(attempt = 0;; attempt++) {
+            /* own particles + ghosts of this table: the local set the gas tree is built from (mpg_dist_force_tree_full once per epoch) */
+            mpg_shim_dist_tree(&v);
+            const int rc = mpg_dist_density(mpg_shim_dist(), &v, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml, DoEgyDensity);
+            mpg_shim_dist_tree_replaced(); /* (the gas tree took the place of the gravity tree inside the library) */
+            if(rc == 0)
+                break;
+            /* a smoothing length outgrew the ghost margin (collective: every rank sees the same all-reduced maximum): wider margin,
+             * new ghosts, same inputs */
+            const double hmax = mpg_dist_last_max_hsml(mpg_shim_dist());
+            if(attempt >= 3 || !(hmax > mpg_shim_margin()))
+                ck(rc); /* (another failure, or no convergence: endrun with the library's message) */
+            mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, 1.26 * hmax);
+        }
     }
     else
         ck(mpg_density(mpg_shim_engine(), &v, tree->BoxSize, &H.A, &t, act->ActiveParticle, act->NumActiveParticle, update_hsml,
@@ -217,12 +241,14 @@ void hydro_force(const ActiveParticles *act, const double atime, struct sph_pred
                  Cosmology *CP, const ForceTree *const tree)
 {
     (void)SPH_predicted;
-    (void)tree;
     struct sph_host H;
     mpg_sph_times t;
-    mpg_particle_view v = view();
     int64_t i;
     walltime_measure("/Misc");
+    /* hydro_force() follows density() of the same step on the same table (run.c:472-489): same epoch, and for several ranks the
+     * local set, gas tree and ghost columns the density loop left in the library (mpg_dist_hydro_force checks that it is so) */
+    mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, 0);
+    mpg_particle_view v = view();
     gather(&H);
     fill_times(&t, &times, CP, atime);
     walltime_measure("/SPH/Hydro/Init");

@@ -78,6 +78,30 @@ def test_mpi_comm_shim_compiles():
     assert r.returncode == 0, r.stderr
 
 
+def test_reference_side_shim_compiles(tmp_path):
+    """shim/gravity-hip.c and shim/sph-hip.c - the files a maintainer adds inside the reference tree - go through gcc's front end
+    against the reference's OWN headers and include/mpgadget_hip.h: every call matches a prototype (implicit declarations are errors),
+    every reference type and field they touch exists, no identifier of the C-ABI header collides with a reference macro (the header
+    once named a parameter `P`, which partmanager.h:88 defines as PartManager->Base).  gravity.h / density.h pull in <pfft.h> and
+    <gsl/gsl_interp.h>, which this image lacks: two throw-away headers holding only the typedef NAMES those includes need are
+    written into tmp_path so the parser gets past them.  -fsyntax-only: nothing is built, linked, run or used as an oracle, and
+    nothing of it stays in the repository.  Runs where /root/reference and an <mpi.h> exist (this container); skipped elsewhere."""
+    import shutil
+    import subprocess
+    ref = "/root/reference/libgadget"
+    mpi = "/opt/conda/include"
+    if not os.path.isdir(ref) or not os.path.exists(os.path.join(mpi, "mpi.h")) or not shutil.which("gcc"):
+        pytest.skip("needs the reference headers, an mpi.h and gcc")
+    (tmp_path / "gsl").mkdir()
+    (tmp_path / "pfft.h").write_text("#include <stddef.h>\n#include <mpi.h>\ntypedef double pfft_complex[2];\ntypedef struct pfft_plan_s *pfft_plan;\n")
+    (tmp_path / "gsl" / "gsl_interp.h").write_text("typedef struct gsl_interp gsl_interp;\ntypedef struct gsl_interp_accel gsl_interp_accel;\n")
+    for src in ("gravity-hip.c", "sph-hip.c", "mpg_mpi_comm.c"):
+        r = subprocess.run(["gcc", "-std=gnu11", "-fopenmp", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                            "-I", str(tmp_path), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim"), "-I", mpi,
+                            "-I", ref, "-I", os.path.dirname(ref), os.path.join(ROOT, "shim", src)], capture_output=True, text=True)
+        assert r.returncode == 0, src + "\n" + r.stderr[-3000:]
+
+
 def test_stale_library_is_refused(monkeypatch):
     """The library carries the hash of the sources it was built from (mpg_build_stamp, build.py); the host side refuses one that does
     not match the tree instead of running old kernels silently."""

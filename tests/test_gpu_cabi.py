@@ -81,3 +81,70 @@ def test_c_caller_ranks_against_oracle(tmp_path, orc):
     for nt in (2, 4):
         _run(exe, "ranks", table, p, e, n, nmesh, box, nt)
     _run(exe, "ranks_host", table, p, e, n, nmesh, box, 4)
+
+
+def _pk_line(out):
+    for ln in out.splitlines():
+        if ln.startswith("pk:"):
+            t = ln.split()
+            return int(t[2]), int(t[4]), float(t[6]), float(t[8])
+    raise AssertionError("no pk: line in\n" + out)
+
+
+@pytest.mark.gpu
+def test_c_caller_power_spectrum_does_not_depend_on_ranks(tmp_path):
+    """gravpm_force saves the matter power spectrum on every PM step (gravpm.c:110-118).  One rank: mpg_gravpm_get_powerspectrum;
+    several: every rank bins the k_y rows of its slab and mpg_dist_gravpm_get_powerspectrum all-reduces the raw sums
+    (powerspectrum_sum's MPI_Allreduce, powerspectrum.c:55-91): bins, mode counts and sum P N equal to the one-rank result."""
+    pkg = importlib.import_module("mp-gadget_amd")
+    exe = build(tmp_path)
+    table = os.path.join(ROOT, "mp-gadget_amd", "data", "shortrange_force_kernels.f64")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "grav_sgrid16.npz"))
+    pos, mass, box = pkg.ics.s_grid(16)
+    p, e = _write_case(tmp_path, "sgrid16", pos, g["GravPM"], g["Accel2"])
+    one = _pk_line(_run(exe, "single", table, p, e, 16, 32, box))
+    assert one[0] > 4 and one[1] > 1000 and one[2] > 0
+    for nt in (2, 4):
+        pk = _pk_line(_run(exe, "ranks_host", table, p, e, 16, 32, box, nt))
+        assert pk[:2] == one[:2], (nt, pk, one)
+        assert abs(pk[2] / one[2] - 1) < 1e-9 and abs(pk[3] / one[3] - 1) < 1e-12, (nt, pk, one)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bh", [0, 1])
+def test_c_caller_sph_loops_against_oracle(tmp_path, orc, bh):
+    """density() -> hydro_force() as shim/sph-hip.c issues them, from C on 160-byte records + host mpg_sph_arrays: 1 rank
+    (mpg_density / mpg_hydro_force) and 2 / 4 forked ranks (mpg_dist_force_tree_full / mpg_dist_density / mpg_dist_hydro_force; the
+    first margin is too small on purpose: the retry through mpg_dist_last_max_hsml runs) against the CPU oracle; bh = 1 adds black
+    holes as density targets (density_haswork, density.c:521-530), which the multi-rank loop refused in round 2; a gravity walk on
+    the gas tree the density loop leaves behind must be refused."""
+    from oracle import oracle as O
+    pkg = importlib.import_module("mp-gadget_amd")
+    exe = build(tmp_path)
+    n = 18
+    pos, mass, box = pkg.ics.s_zel(n, box=8.0)
+    N = len(pos)
+    rng = np.random.RandomState(11)
+    typ = np.zeros(N, np.int32)
+    typ[rng.choice(N, N // 6, replace=False)] = 1            # dark matter: not in the gas tree
+    if bh:
+        typ[rng.choice(np.flatnonzero(typ == 1), 40, replace=False)] = 5
+    vel = rng.standard_normal((N, 3))
+    ent = 1.0 + 0.5 * rng.random_sample(N)
+    h0 = np.full(N, 2.0 * box / n)
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., 1, 0.006)
+    O.sph_set_softening(orc, 2.8 * (box / np.cbrt(N)) / 30.)
+    A = O.SphArrays(pos, mass, type=typ, hsml=h0, vel=vel, entropy=ent)
+    to = O.sph_times(atime=1.0, hubble=0.1)
+    tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    O.sph_density(orc, tr, dp, A, to, BlackHoleOn=bh)
+    tr.calc_moments()
+    O.sph_hydro_force(orc, tr, dp, O.HydroParams(0, 100.0, 0.75), A, to)
+    inp = np.column_stack([pos, typ.astype(float), vel, ent, h0, mass.astype(float)])
+    exp = np.column_stack([A.hsml, A.density, A.hydroacc_out, A.dtentropy_out])
+    pi, pe = str(tmp_path / "sph.in"), str(tmp_path / "sph.expect")
+    inp.astype("<f8").tofile(pi)
+    exp.astype("<f8").tofile(pe)
+    for nt in (1, 2, 4):
+        r = subprocess.run([exe, "sph", pi, pe, str(N), str(box), str(nt), str(bh), "1"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "PASS sph %d" % nt in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])

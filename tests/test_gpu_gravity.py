@@ -169,25 +169,36 @@ def test_walk_parity(pkg, engine, orc, ic, n, nmesh):
 
 
 @pytest.mark.parametrize("ic,n", [("s_clust", 48), ("s_zel", 40)])
-def test_pair_list_kernel_is_bit_identical(tmp_path, ic, n):
-    """k_walk_lists2 (MPG_LISTS_PAIR=1: two tree-order neighbours per group of 8 lanes share one traversal) writes, per target, the lists
-    k_walk_lists writes: accelerations, potentials and the per-target walk cost of three steps (Barnes-Hut walk, list-capacity
-    adaptation with overflowing targets on the clustered set, relative criterion) are equal bit for bit.  (The knob is read once per
-    process: two processes.)"""
+def test_list_kernels_agree(tmp_path, ic, n):
+    """The three list-construction kernels of the two-kernel walk (MPG_LISTS_MODE 0: one target per group of 8 lanes, 1: two tree-order
+    neighbours per group share one traversal, 2: the 8 targets of a wave share one frontier with one node per lane) take the same
+    per-target decisions.  Modes 0 and 1 write the same lists entry for entry: accelerations, potentials and the per-target walk
+    cost of three steps (Barnes-Hut walk, list-capacity adaptation with overflowing targets on the clustered set, relative criterion)
+    are equal bit for bit.  Mode 2 writes the same entries in another order: sums agree to rounding, and its per-target cost
+    (a measure of work for the domain decomposition) is proportional to that of modes 0 / 1.
+    (The knob is read once per process: three processes.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for pr in ("0", "1"):
-        out = str(tmp_path / ("pair%s.npz" % pr))
+    for mode in ("0", "1", "2"):
+        out = str(tmp_path / ("mode%s.npz" % mode))
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), out, ic, str(n)], capture_output=True, text=True,
-                           timeout=600, env=dict(os.environ, MPG_LISTS_PAIR=pr))
+                           timeout=600, env=dict(os.environ, MPG_LISTS_MODE=mode))
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(out))
-    assert set(res[0].files) == set(res[1].files) and len(res[0].files) == 9
+    assert set(res[0].files) == set(res[1].files) == set(res[2].files) and len(res[0].files) == 9
     for k in res[0].files:
         assert np.array_equal(res[0][k], res[1][k]), k
     assert np.abs(res[0]["acc2"]).max() > 0 and res[0]["cost2"].min() > 0
+    for step in range(3):
+        a0, a2 = res[0]["acc%d" % step], res[2]["acc%d" % step]
+        assert np.abs(a2 - a0).max() <= 1e-12 * np.abs(a0).mean() + 1e-13 * np.abs(a0).max(), step
+        p0, p2 = res[0]["pot%d" % step], res[2]["pot%d" % step]
+        assert np.abs(p2 - p0).max() <= 1e-12 * np.abs(p0).mean(), step
+        # the per-target work measure of mode 2 counts node tests by list entries instead of traversal steps: proportional, not equal
+        c0, c2 = res[0]["cost%d" % step], res[2]["cost%d" % step]
+        assert c2.min() > 0 and 0.6 < np.median(c2 / c0) < 1.6 and np.corrcoef(c0, c2)[0, 1] > 0.9, step
 
 
 @pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (5, 512), (6, 512), (6, 40)])

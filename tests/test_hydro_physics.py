@@ -1,0 +1,280 @@
+"""hydro_force() pinned by PHYSICS, since no reference vector can exist (the reference holds none and hydra.c cannot be built here).
+
+tests/sph_paper.py states the SPH equations from the publications (Springel & Hernquist 2002, Springel 2005, Hopkins 2013, Price
+2012) and from the comoving-variable physics - NOT from hydra.c - and evaluates them by brute force over all pairs.  Here
+
+  * the CPU oracle (oracle/sph_oracle.c, the line-by-line restatement) and the HIP kernels (-m gpu) must agree with it to rounding:
+    both SPH formulations, two kernels, a = 1 and a cosmological epoch (a = 0.5 with Hubble flow: fac_mu, hubble_a2 and fac_vsic_fix
+    all differ from 1), the bound on the viscous force on and off;
+  * three closed-form states gate the sign and the amplitude independently of sph_paper.py as well: a sinusoidal entropy
+    perturbation on a lattice gives HydroAccel = -grad P / rho; the pair sums conserve energy, sum m v.a + sum m du/dt = 0, with
+    du/dt rebuilt from the density-loop outputs; a uniformly converging flow heats every particle;
+  * MUTATIONS of the restatement - a wrong power of a in fac_mu, rr1 / rr2 exchanged, the viscosity prefactor doubled, the grad-h
+    factor of the neighbour taken from the target, the Hubble term dropped - are compiled into a scratch copy of the oracle and must
+    each make a gate fail: the gates see what they are meant to see.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sph_paper import GAMMA, sph_paper
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gas_state(pkg, n=9, seed=5, box=6.0):
+    """A disordered gas: Zel'dovich-displaced lattice, random velocities, entropies between 1 and 1.5."""
+    pos, mass, box = pkg.ics.s_zel(n, box=box)
+    rng = np.random.RandomState(seed)
+    N = len(pos)
+    mass = (mass * (1.0 + 0.2 * rng.random_sample(N))).astype(np.float32)
+    vel = 0.6 * rng.standard_normal((N, 3))
+    ent = 1.0 + 0.5 * rng.random_sample(N)
+    return pos, mass, vel, ent, box
+
+
+CASES = [
+    # formulation, kernel, atime, hubble, dlna of every particle (0: the bound on the viscous force is off)
+    ("density", 1, 1.0, 0.1, 0.0),
+    ("density", 2, 0.5, 0.3, 0.0),
+    ("density", 1, 0.5, 0.3, 0.02),
+    ("pressure", 1, 1.0, 0.1, 0.0),
+    ("pressure", 2, 0.5, 0.3, 0.02),
+]
+
+
+def oracle_loops(orc, pos, mass, vel, ent, box, formulation, kernel, atime, hubble, dlna, alpha=0.75, h0=None):
+    """density() then hydro_force() of the restatement; every particle is gas, active, in time bin 0 with no pending kicks, so that
+    predicted quantities equal the current ones (the prediction formulas are plain arithmetic and covered by the parity tests)."""
+    N = len(pos)
+    pe = 1 if formulation == "pressure" else 0
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., kernel, 0.006)
+    O.sph_set_softening(orc, 1e-3)
+    A = O.SphArrays(pos, mass, hsml=np.full(N, 2.2 * box / round(N ** (1 / 3.))) if h0 is None else h0, vel=vel, entropy=ent)
+    to = O.sph_times(atime=atime, hubble=hubble, dloga_bin=[dlna] + [0.0] * 46)
+    tr = orc.tree(pos, mass, box, type=np.zeros(N, np.int32), hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+    O.sph_density(orc, tr, dp, A, to, DoEgyDensity=pe)
+    tr.calc_moments()
+    O.sph_hydro_force(orc, tr, dp, O.HydroParams(pe, 100.0, alpha), A, to)
+    return A
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max()
+
+
+def gate_paper(F, ref, formulation, tol=2e-10):
+    """F: fields of an implementation (attributes), ref: sph_paper's.  Raises AssertionError naming the first field that differs."""
+    assert rel(F.density, ref["density"]) <= tol, "Density"
+    assert rel(F.divvel, ref["divvel"]) <= tol, "DivVel"
+    assert rel(F.curlvel, ref["curlvel"]) <= tol, "CurlVel"
+    if formulation == "pressure":
+        assert rel(F.egywtdensity, ref["egywtdensity"]) <= tol, "EgyWtDensity"
+        assert rel(F.dhsmlegyfac, ref["dhsmlegy"]) <= 10 * tol, "DhsmlEgyDensityFactor"
+    else:
+        assert rel(F.dhsmlegyfac, ref["dhsml"]) <= tol, "DhsmlDensityFactor"
+    assert rel(F.hydroacc_out, ref["hydroacc"]) <= tol, "HydroAccel"
+    assert rel(F.dtentropy_out, ref["dtentropy"]) <= tol, "DtEntropy"
+    assert rel(F.maxsignalvel, ref["maxsignalvel"]) <= 1e-12, "MaxSignalVel"
+
+
+def gate_energy(F, mass, vel, ent, atime, hubble, formulation):
+    """Pair sums conserve energy (SH02 section 2.2: the equations follow from a Lagrangian).  In comoving variables, per unit of the
+    common factor a^(-3(gamma-1)):  sum_i m_i u_i . HydroAccel_i  +  sum_i m_i [ P_i / eom_i^2 d(eom_i)/dt' + eom^(gamma-1)/(gamma-1) dA/dt' ] = 0
+    with the adiabatic rate rebuilt from the density loop's own outputs.  Density formulation: d rho_i/dt' = -rho_i f_i DivVel_i ...
+    only when the Hubble flow does no work on the pair terms, so this gate runs at hubble -> 0 (the caller passes a small H and the
+    viscous heating converted back with it)."""
+    m = mass.astype(float)
+    rho = F.density
+    if formulation == "density":
+        P = ent * rho ** GAMMA
+        adiabatic = -(m * P / rho * F.dhsmlegyfac * F.divvel).sum()     # sum m (P/rho^2) f d rho/dt, d rho/dt = -rho DivVel (per f)
+    else:
+        return  # (the pressure-entropy form conserves sum m A^(1/gamma) y^(gamma-1) / (gamma-1): gated through sph_paper only)
+    work = (m[:, None] * vel * F.hydroacc_out).sum()
+    heat = (m * rho ** (GAMMA - 1) / (GAMMA - 1) * F.dtentropy_out * hubble * atime ** 2).sum()   # dA/dln a -> the bracketed sum
+    scale = np.abs(m[:, None] * vel * F.hydroacc_out).sum()
+    assert abs(work + adiabatic + heat) <= 1e-9 * scale, ("energy", work, adiabatic, heat)
+
+
+@pytest.mark.parametrize("formulation,kernel,atime,hubble,dlna", CASES)
+def test_oracle_hydro_matches_the_published_equations(pkg, orc, formulation, kernel, atime, hubble, dlna):
+    pos, mass, vel, ent, box = gas_state(pkg)
+    A = oracle_loops(orc, pos, mass, vel, ent, box, formulation, kernel, atime, hubble, dlna)
+    ref = sph_paper(pos, mass, vel, ent, A.hsml, box, atime, hubble, 0.75, kernel, formulation, dlna=np.full(len(pos), dlna) if dlna else None)
+    assert (ref["dtentropy"] > 0).mean() > 0.5 and np.abs(ref["hydroacc"]).max() > 0      # a state with shocks and pressure forces
+    gate_paper(A, ref, formulation)
+
+
+def test_oracle_hydro_conserves_energy(pkg, orc):
+    """sum m u.a + sum m du/dt = 0 over the pair sums, viscosity included (its work reappears as heat), bound off, H -> 0."""
+    pos, mass, vel, ent, box = gas_state(pkg, seed=8)
+    A = oracle_loops(orc, pos, mass, vel, ent, box, "density", 1, 1.0, 1e-9, 0.0)
+    gate_energy(A, mass, vel, ent, 1.0, 1e-9, "density")
+
+
+def lattice_state(n, box, eps_entropy=0.0, v_converge=0.0):
+    g = (np.arange(n) + 0.5) * box / n
+    pos = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    N = len(pos)
+    k = 2 * np.pi / box
+    ent = 1.0 + eps_entropy * np.sin(k * pos[:, 0])
+    vel = np.zeros((N, 3))
+    vel[:, 0] = -v_converge * np.sin(k * pos[:, 0])       # converging towards x = 0 (and box), diverging around box / 2
+    return pos, np.ones(N, np.float32), vel, ent
+
+
+def gate_pressure_gradient(run, n=16, box=8.0, eps=0.02):
+    """A cubic lattice of equal-mass gas (uniform density rho0 = N / box^3) with entropy A(x) = 1 + eps sin(kx): the force per unit
+    mass must be -grad P / rho = -rho0^(gamma-1) eps k cos(kx) along x, zero across - sign, amplitude (the kernel smooths a mode of
+    wavelength 16 spacings by a few per cent) and phase."""
+    pos, mass, vel, ent = lattice_state(n, box, eps_entropy=eps)
+    F = run(pos, mass, vel, ent, box)
+    k = 2 * np.pi / box
+    rho0 = len(pos) / box ** 3
+    assert rel(F.density, np.full(len(pos), rho0)) < 0.02
+    expect = -rho0 ** (GAMMA - 1) * eps * k * np.cos(k * pos[:, 0])
+    a = F.hydroacc_out
+    amp = (a[:, 0] * expect).sum() / (expect ** 2).sum()         # least-squares amplitude of the expected pattern
+    assert 0.9 < amp < 1.02, ("amplitude", amp)
+    assert np.abs(a[:, 0] - amp * expect).max() < 0.02 * np.abs(expect).max(), "phase / shape"
+    assert np.abs(a[:, 1:]).max() < 1e-10 * np.abs(expect).max(), "transverse"
+
+
+def gate_converging_flow(run, n=16, box=8.0, v0=0.5):
+    """u_x = -v0 sin(kx) on the same lattice: where the flow converges (x near 0) the viscosity must act - entropy production > 0,
+    signal velocity above 2 c; where it diverges (x near box/2) there is none - dA/dt = 0 exactly, signal velocity = 2 c; the viscous
+    force opposes the compression, and momentum is conserved."""
+    pos, mass, vel, ent = lattice_state(n, box, v_converge=v0)
+    F = run(pos, mass, vel, ent, box)
+    x = pos[:, 0]
+    conv = (x < 0.1 * box) | (x > 0.9 * box)
+    div = np.abs(x - 0.5 * box) < 0.1 * box
+    rho0 = len(pos) / box ** 3
+    c = np.sqrt(GAMMA * rho0 ** (GAMMA - 1))
+    assert F.dtentropy_out[conv].min() > 0 and np.all(F.dtentropy_out[div] == 0), "entropy production"
+    assert F.maxsignalvel[conv].min() > 2.0 * c * (1 + 1e-3) and rel(F.maxsignalvel[div], np.full(div.sum(), 2 * c)) < 0.02, "signal velocity"
+    # the viscous force decelerates the inflow: on the left of the convergence point (x > 0.9 box, u_x > 0) it points to -x
+    left = x > 0.9 * box
+    assert np.all(F.hydroacc_out[left, 0] < 0) and np.all(F.hydroacc_out[(x < 0.1 * box), 0] > 0), "direction of the viscous force"
+    assert np.abs(F.hydroacc_out.sum(0)).max() < 1e-9 * np.abs(F.hydroacc_out).sum(), "momentum"
+
+
+def test_oracle_closed_form_states(pkg, orc):
+    run = lambda pos, mass, vel, ent, box: oracle_loops(orc, pos, mass, vel, ent, box, "density", 1, 1.0, 0.1, 0.0)
+    gate_pressure_gradient(run)
+    gate_converging_flow(run)
+    run_pe = lambda pos, mass, vel, ent, box: oracle_loops(orc, pos, mass, vel, ent, box, "pressure", 1, 1.0, 0.1, 0.0)
+    gate_pressure_gradient(run_pe)
+
+
+# ---- mutations of the restatement: every one must trip a gate ---------------------------------------------------------------------
+MUTATIONS = {
+    "fac_mu: wrong power of a": ("const double fac_mu = pow(atime, 3 * (GAMMA - 1) / 2) / atime;",
+                                 "const double fac_mu = pow(atime, 3 * (GAMMA - 1) / 2);"),
+    "viscosity prefactor doubled": ("visc = 0.25 * HP->ArtBulkViscConst", "visc = 0.5 * HP->ArtBulkViscConst"),
+    "rr1 / rr2 exchanged": ("rr1 = IEgyRho / IDensity;\n                        rr2 = eomdensity / density_j;",
+                            "rr2 = IEgyRho / IDensity;\n                        rr1 = eomdensity / density_j;"),
+    "neighbour's grad-h factor taken from the target": ("p_over_rho2_j * A->dhsmlegyfac[other] * dwk_j * rr2", "p_over_rho2_j * IDhsml * dwk_j * rr2"),
+    "Hubble flow dropped from the approach velocity": ("const double vdotr2 = vdotr + hubble_a2 * rsq;", "const double vdotr2 = vdotr;"),
+    "bound on the viscous force: wrong power of a": ("const double fac_vsic_fix = hubble * pow(atime, 3 * GAMMA_MINUS1);",
+                                                     "const double fac_vsic_fix = hubble * pow(atime, GAMMA_MINUS1);"),
+    "entropy rate: density exponent": ("(GAMMA_MINUS1 / (hubble_a2 * pow(A->density[i], GAMMA_MINUS1)))", "(GAMMA_MINUS1 / (hubble_a2 * pow(A->density[i], GAMMA)))"),
+}
+
+
+def mutated_oracle(tmp_path, name):
+    old, new = MUTATIONS[name]
+    d = tmp_path / ("mut_%d" % (abs(hash(name)) % 10 ** 8))
+    d.mkdir()
+    srcs = ["gravtree_oracle.c", "sph_oracle.c", "timestep_oracle.c", "fof_oracle.c", "oracle_tree.h"]
+    for f in srcs:
+        shutil.copy(os.path.join(ROOT, "oracle", f), str(d / f))
+    txt = (d / "sph_oracle.c").read_text()
+    assert txt.count(old) == 1, ("mutation target not found exactly once", name)
+    (d / "sph_oracle.c").write_text(txt.replace(old, new))
+    lib = str(d / "liboracle_mut.so")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-std=gnu11", "-fPIC", "-shared", "-Wno-unused-function", "-o", lib] +
+                          [str(d / f) for f in srcs if f.endswith(".c")] + ["-lm"])
+    return O.Oracle(lib_path=lib)
+
+
+def all_gates(pkg, orc):
+    pos, mass, vel, ent, box = gas_state(pkg)
+    for formulation, kernel, atime, hubble, dlna in CASES:
+        A = oracle_loops(orc, pos, mass, vel, ent, box, formulation, kernel, atime, hubble, dlna)
+        ref = sph_paper(pos, mass, vel, ent, A.hsml, box, atime, hubble, 0.75, kernel, formulation, dlna=np.full(len(pos), dlna) if dlna else None)
+        gate_paper(A, ref, formulation)
+    A = oracle_loops(orc, pos, mass, vel, ent, box, "density", 1, 1.0, 1e-9, 0.0)
+    gate_energy(A, mass, vel, ent, 1.0, 1e-9, "density")
+    run = lambda pos, mass, vel, ent, box: oracle_loops(orc, pos, mass, vel, ent, box, "density", 1, 1.0, 0.1, 0.0)
+    gate_pressure_gradient(run)
+    gate_converging_flow(run)
+
+
+@pytest.mark.parametrize("name", sorted(MUTATIONS))
+def test_gates_catch_mutations_of_the_restatement(pkg, tmp_path, name):
+    mut = mutated_oracle(tmp_path, name)
+    with pytest.raises(AssertionError):
+        all_gates(pkg, mut)
+
+
+def test_gates_pass_on_the_unmutated_restatement(pkg, orc):
+    all_gates(pkg, orc)
+
+
+# ---- the HIP kernels against the same gates ------------------------------------------------------------------------------------------
+class _Fields:
+    pass
+
+
+def engine_loops(pkg, pos, mass, vel, ent, box, formulation, kernel, atime, hubble, dlna, alpha=0.75):
+    import torch
+    from test_gpu_sph import gpu_arrays, make_times
+    N = len(pos)
+    pe = 1 if formulation == "pressure" else 0
+    eng = pkg.Engine(0)
+    try:
+        eng.set_gravshort_treepar(FractionalGravitySoftening=1.0)
+        eng.gravshort_set_softenings(1e-3 / 2.8)
+        eng.set_densitypar(1.0, 2.0, 2.0, 99999., kernel, 0.006)
+        eng.set_hydropar(pe, 100.0, alpha)
+        h0 = np.full(N, 2.2 * box / round(N ** (1 / 3.)))
+        a, keep = gpu_arrays(torch, pos, mass, np.zeros(N, np.int32), h0, vel, ent)
+        eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
+        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+        t = make_times(pkg, atime=atime, hubble=hubble, dloga_bin=[dlna] + [0.0] * 46)
+        eng.dev_density(a, t, DoEgyDensity=pe)
+        eng.dev_force_tree_calc_hmax()
+        eng.dev_hydro_force(a, t)
+        eng.synchronize()
+        F = _Fields()
+        for k in ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel", "hydroacc_out", "dtentropy_out", "maxsignalvel"):
+            setattr(F, k, a[k].cpu().numpy())
+        return F
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("formulation,kernel,atime,hubble,dlna", CASES)
+def test_gpu_hydro_matches_the_published_equations(pkg, formulation, kernel, atime, hubble, dlna):
+    pos, mass, vel, ent, box = gas_state(pkg)
+    F = engine_loops(pkg, pos, mass, vel, ent, box, formulation, kernel, atime, hubble, dlna)
+    ref = sph_paper(pos, mass, vel, ent, F.hsml, box, atime, hubble, 0.75, kernel, formulation, dlna=np.full(len(pos), dlna) if dlna else None)
+    gate_paper(F, ref, formulation)
+
+
+@pytest.mark.gpu
+def test_gpu_hydro_closed_form_states_and_energy(pkg):
+    run = lambda pos, mass, vel, ent, box: engine_loops(pkg, pos, mass, vel, ent, box, "density", 1, 1.0, 0.1, 0.0)
+    gate_pressure_gradient(run)
+    gate_converging_flow(run)
+    pos, mass, vel, ent, box = gas_state(pkg, seed=8)
+    F = engine_loops(pkg, pos, mass, vel, ent, box, "density", 1, 1.0, 1e-9, 0.0)
+    gate_energy(F, mass, vel, ent, 1.0, 1e-9, "density")

@@ -1,5 +1,5 @@
 """Accelerations / potentials / per-target walk cost of three force steps (two-kernel walk) written to an .npz: run once with
-MPG_LISTS_PAIR=0 and once with 1 and compare bit for bit (tools/r02_pair.sh).  usage: pair_check.py out.npz ic n"""
+MPG_LISTS_MODE=0, 1 and 2 and compare (tests/test_gpu_gravity.py::test_list_kernels_agree).  usage: pair_check.py out.npz ic n"""
 import ctypes as C
 import importlib, os, sys
 import numpy as np

@@ -33,10 +33,10 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     walks, cur = [], None
     for r in rows:
         nm = r["Kernel_Name"]
-        w = "k_walk_lists<" in nm or "k_walk_lists2<" in nm or "k_walk_eval<" in nm
+        w = "k_walk_lists<" in nm or "k_walk_lists2<" in nm or "k_walk_lists8<" in nm or "k_walk_eval<" in nm
         if w:
             if cur is None:
-                cur = dict(t0=int(r["Start_Timestamp"]), t1=0, count=("k_walk_lists<true" in nm or "k_walk_lists2<true" in nm), n=0)
+                cur = dict(t0=int(r["Start_Timestamp"]), t1=0, count=("k_walk_lists<true" in nm or "k_walk_lists2<true" in nm or "k_walk_lists8<true" in nm), n=0)
             cur["t1"] = max(cur["t1"], int(r["End_Timestamp"]))
             cur["n"] += 1
         elif cur is not None and "rocclr" not in nm and "k_grav_walk" not in nm:
