@@ -6,10 +6,11 @@ run.c:522-548): gravpm_force (CIC deposit, 5 FFTs, transfers, readout) + force_t
 + grav_short_tree (short-range walk with the relative opening criterion, OldAcc from the previous step).
 Inputs are resident in HBM when the timed region starts.
 
-N = 1 : 256^3 dark-matter particles, Nmesh = 512 (BASELINE.json configs[1]), S-grid synthetic ICs.
-N > 1 : weak scaling, ~256^3 particles per GPU (n = 320 / 400 / 512 per dimension for N = 2 / 4 / 8, Nmesh = 2n).
-        Every rank holds the particle set; targets are sharded over ranks as contiguous tree-order (Morton) ranges
-        and the accelerations are exchanged with one RCCL all-gather per step.
+N = 1 : 256^3 dark-matter particles, Nmesh = 512 (BASELINE.json configs[1]), Zel'dovich-displaced synthetic ICs.
+N > 1 : weak scaling, ~256^3 particles per GPU (n = 320 / 400 / 512 per dimension for N = 2 / 4 / 8, Nmesh = 2n): particles on the
+        owners of their Peano-Hilbert TopLeaves, PM by shipping particles to x-slabs, ghost import, all-reduced top of the tree
+        (the library's choreography, csrc/dist.hip); the line carries `parity_check`, the forces of sampled
+        particles against the one-GPU path.
 
 One JSON line is printed by rank 0 (contract of the task statement), with `roofline` for the dominant kernel
 (the short-range walk; HIP events on the engine stream inside the timed region) and `cpu_baseline` (the oracle
@@ -137,6 +138,549 @@ def host_path_steps(pkg, eng, pos, mass, box, steps=3):
                     "rate is `value`" % N}
 
 
+def resident_path_steps(pkg, eng, pos, mass, box, steps=3):
+    """The drop-in calls in the device-resident mode (mpg_resident_begin): the same three host-pointer calls on the same 160-byte records,
+    but the table stays in HBM between them (one upload, timed separately); the host fetches FullTreeGravAccel when a module of its own
+    needs it (timed separately)."""
+    P = pkg.make_particles(pos, mass)
+    N = len(pos)
+    t0 = time.perf_counter()
+    eng.resident_begin(P, box)
+    t_begin = time.perf_counter() - t0
+    ts = []
+    for it in range(steps + 2):
+        t0 = time.perf_counter()
+        eng.gravpm_force(P)
+        eng.force_tree_full(P, box)
+        eng.grav_short_tree(P)
+        eng.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    eng.resident_fetch(P, eng.FIELD_ACCEL)
+    t_fetch = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng.resident_end(P)
+    t_end = time.perf_counter() - t0
+    tot = float(np.mean(ts[2:]))
+    return {"ms_per_step": round(1e3 * tot, 2), "particles_per_s": N / tot, "upload_once_ms": round(1e3 * t_begin, 1),
+            "fetch_accel_ms": round(1e3 * t_fetch, 1), "end_fetch_all_ms": round(1e3 * t_end, 1),
+            "mean_abs_accel": float(np.abs(P["FullTreeGravAccel"]).mean()),
+            "note": "mpg_resident_begin once, then mpg_gravpm_force + mpg_force_tree_full + mpg_grav_short_tree on the same %d records per step "
+                    "with the table resident in HBM (drift / kicks through mpg_dev_* on mpg_resident_arrays); fetch_accel_ms = "
+                    "mpg_resident_fetch(FullTreeGravAccel) into P[] on demand" % N}
+
+
+def configure_gravity(eng, args, box, n, nmesh):
+    eng.use_torch_stream()
+    eng.set_walk_threshold(args.thresh)
+    eng.set_walk_variant(args.variant)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,
+                              FractionalGravitySoftening=1. / 30.)
+    eng.gravshort_set_softenings(box / n)
+
+
+def walk_traffic(pkg, N, ic, variant):
+    """HBM bytes per walk from the committed PMC passes (tools/prof.sh -> profiles/walk_traffic.json), valid only for the library
+    they were taken with: the file carries the build stamp (mpg_build_stamp) of that library, and a line produced by another build
+    reports no traffic instead of a stale one."""
+    tpath = os.path.join(ROOT, "profiles", "walk_traffic.json")
+    if not os.path.exists(tpath) or N != 256 ** 3:
+        return None, "no PMC summary committed for this configuration"
+    tj = json.load(open(tpath))
+    stamp = pkg.engine.load_library().mpg_build_stamp().decode()
+    if tj.get("build_stamp") != stamp:
+        return None, ("profiles/walk_traffic.json was measured with library build %s, this run uses %s: re-run tools/prof.sh"
+                      % (str(tj.get("build_stamp"))[:12], stamp[:12]))
+    e = tj.get("by_ic", {}).get(ic, {}).get(str(variant))
+    if not e:
+        return None, "no PMC summary committed for this input set"
+    return e["hbm_bytes_per_launch"], "bytes per walk (%s) from %s; library build %s" % (e["kernel"], e["method"], stamp[:12])
+
+
+def substep_measure(pkg, torch, eng, N, acc, prev, gravpm, pot, dev, fracs=(1. / 8, 1. / 64, 1. / 512), reps=3):
+    """SURVEY 8(d) metric (ii), the short-range-only step, as production runs spend most of their walks (timestep.c:296-599): an
+    ActiveParticle list of N f randomly chosen particles (a) on the tree of ALL particles (the sub-steps of run.c:392-470: tree build +
+    walk of the active ones) and (b) on a tree of the active particles only (force_tree_active_moments, the hierarchical gravity
+    levels).  Times per call in ms (device-resident), active particles per second for (a)."""
+    g = torch.Generator(device=dev).manual_seed(99)
+    out = {}
+    for f in fracs:
+        na = max(int(N * f), 1)
+        act = torch.randperm(N, device=dev, generator=g)[:na].sort().values.to(torch.int32).contiguous()
+        res = {}
+        for name, full in (("all_particle_tree", True), ("active_only_tree", False)):
+            def one():
+                if full:
+                    eng.dev_force_tree_build()
+                else:
+                    eng.dev_force_tree_active_moments(act)
+                eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot if full else None, active=act)
+            one()
+            torch.cuda.synchronize()
+            eng.walk_events_collect()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                one()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / reps
+            wms, wl = eng.walk_events_collect()
+            res[name] = {"ms_per_substep": round(1e3 * el, 3), "walk_ms": round(wms / max(wl, 1), 3), "walk_kernel": eng.walk_choice()[0],
+                         "active_per_s": na / el}
+        out["1/%d" % round(1 / f)] = dict(active=na, **res)
+    eng.dev_force_tree_build()      # leave the tree of all particles in place
+    return out
+
+
+FLOP_PER_DENSITY_NGB, FLOP_PER_HYDRO_PAIR, FLOP_PER_CANDIDATE = 60, 120, 8   # DESIGN 3.4: flop-equivalents of density_ngbiter / hydro_ngbiter / one distance test
+
+
+def hydro_measure(pkg, torch, args, dev, n=128, steps=3, PE=0):
+    """BASELINE configs[2] (2 x n^3 DM + gas, density-entropy SPH): ms per force step (gravity + gas tree + density + hmax + hydro) and
+    the two SPH kernels graded against the fp64 vector peak (their neighbour arithmetic is what the reference requires; the gathers are
+    served by L2)."""
+    nmesh = 2 * n
+    pos, mass, typ, box = hydro_ics(pkg, n)
+    N = len(pos)
+    f8 = torch.float64
+    d_pos, d_mass, d_type = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
+    eng = pkg.Engine(dev.index or 0)
+    eng.use_torch_stream()
+    eng.set_walk_variant(args.variant)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
+    eng.set_gravshort_treepar(TreeUseBH=2)
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(PE, 100.0, 0.75)
+    eng.dev_bind_particles(d_pos, d_mass, box, type=d_type)
+    z1 = lambda: torch.zeros(N, dtype=f8, device=dev)
+    z3 = lambda: torch.zeros(N, 3, dtype=f8, device=dev)
+    a = dict(hsml=z1(), dthsml=z1(), vel=z3(), entropy=torch.ones(N, dtype=f8, device=dev), density=z1(), egywtdensity=z1(),
+             dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(), hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
+    gravpm, acc, prev, pot = z3(), z3(), z3(), z1()
+    t = pkg.SphTimes()
+    t.atime, t.hubble = 0.1, 0.1
+    for i in range(47):
+        t.dloga_bin[i] = 0.01
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK + pkg.engine.BHMASK, with_moments=True)
+    eng.dev_set_init_hsml(a, box / n)
+    iters = []
+
+    def step():
+        nonlocal acc, prev
+        eng.dev_gravpm_force(gravpm, pot)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+        eng.dev_density(a, t, DoEgyDensity=PE)
+        iters.append(eng.sph_stats()["iterations"])
+        eng.dev_force_tree_calc_hmax()
+        eng.dev_hydro_force(a, t)
+
+    for _ in range(max(args.warmup, 2)):      # (the first density loop converges Hsml from set_init_hsml's estimate: several passes)
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # untimed pass with events around the phases
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+    ev[0].record()
+    eng.dev_gravpm_force(gravpm, pot)
+    eng.dev_force_tree_build()
+    eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+    ev[1].record()
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    ev[2].record()
+    eng.dev_density(a, t, DoEgyDensity=PE)
+    sd = eng.sph_stats()
+    ev[3].record()
+    eng.dev_force_tree_calc_hmax()
+    ev[4].record()
+    eng.dev_hydro_force(a, t)
+    sh = eng.sph_stats()
+    ev[5].record()
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    ngas = n ** 3
+    b_dens = sd["targets"] * 128 + sd["candidates"] * 28 + sd["interactions"] * 32
+    b_hyd = ngas * 176 + sh["candidates"] * 36 + sh["interactions"] * 100
+
+    def roof(kernel, flops, b, t_ms, note):
+        ach = flops / (t_ms * 1e-3) / 1e12
+        return {"bound": "fp64_valu", "kernel": kernel, "achieved": ach, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TF,
+                "traffic": None, "flop_per_launch": flops, "algorithmic_bytes_per_launch": b,
+                "algorithmic_bytes_over_hbm_peak": b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": t_ms, "note": note}
+    out = {"ms_per_step": 1e3 * el / steps, "particles_per_s": N * steps / el, "particles": N, "steps": steps,
+           "workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
+           "density_iterations": iters[-steps:],
+           "roofline": roof("k_density", sd["interactions"] * FLOP_PER_DENSITY_NGB + sd["candidates"] * FLOP_PER_CANDIDATE, b_dens, ms[2],
+                            "one density() incl. queue set-up, predictions and every Hsml pass; flops = %d x N_ngb + %d x N_cand (%d neighbours, %d "
+                            "candidates, %d target visits); algorithmic bytes (SURVEY 8(d) B_dens) are served by L2, not HBM: their ratio to the "
+                            "HBM peak is reported, not graded" % (FLOP_PER_DENSITY_NGB, FLOP_PER_CANDIDATE, sd["interactions"], sd["candidates"], sd["targets"])),
+           "roofline_hydro": roof("k_hydro", sh["interactions"] * FLOP_PER_HYDRO_PAIR + sh["candidates"] * FLOP_PER_CANDIDATE, b_hyd, ms[4],
+                                  "flops = %d x N_pair + %d x N_cand (%d pairs, %d candidates); B_hyd as SURVEY 8(d)"
+                                  % (FLOP_PER_HYDRO_PAIR, FLOP_PER_CANDIDATE, sh["interactions"], sh["candidates"])),
+           "phases_ms": {"gravity_pm_tree_walk": round(ms[0], 3), "gas_tree": round(ms[1], 3), "density": round(ms[2], 3),
+                         "hmax": round(ms[3], 3), "hydro": round(ms[4], 3)}}
+    eng.close()
+    del d_pos, d_mass, d_type, a, gravpm, acc, prev, pot
+    torch.cuda.empty_cache()
+    return out
+
+
+def hydro_bench(pkg, torch, args, dev):
+    """--workload hydro: BASELINE.json configs[2] as its own line"""
+    n = args.n or 128
+    PE = 1 if args.sph == "pe" else 0
+    h = hydro_measure(pkg, torch, args, dev, n=n, steps=args.steps, PE=PE)
+    out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": h["particles_per_s"], "unit": "particles/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": h["workload"], "particles": h["particles"], "density_iterations": h["density_iterations"]},
+           "roofline": h["roofline"], "roofline_hydro": h["roofline_hydro"], "phases_ms": h["phases_ms"]}
+    emit(out)
+    return out
+
+
+def parity_check_ranks(pkg, torch, dist, args, dev, rank, world, host_pos, host_mass, box, n, nmesh, own_ids, loc, dforce, eng, nsample=2048):
+    """The multi-rank force step checks itself (the reference's runs do, through run_gravity_test, runtests.c:89-232): nsample own
+    particles, spread over the ranks, are recomputed on ONE GPU (rank 0) from the whole particle set through the single-GPU path the
+    parity tests pin to the oracle - PM of all particles, tree of all particles, walk of the sampled targets with the SAME opening
+    input (the previous step's acceleration of those particles as the ranks hold it) - and compared with what the ranks computed:
+    GravPM and the short-range acceleration of the last step, and the interaction counters of a walk restricted to the sample
+    (pair interactions, nodes visited, nodes used: equal when every rank took the reference's decisions on its local tree).
+    Untimed; collective."""
+    n_own = int(own_ids.shape[0])
+    k = max(nsample // world, 1)
+    sel = torch.linspace(0, max(n_own - 1, 0), steps=min(k, n_own), device=dev).long().unique()
+    ns = int(sel.shape[0])
+    # counters of the N-rank walk restricted to the sample (same tree as the last step: build, then walk the sample with counting on)
+    eng.set_instrumentation(False, True)
+    acc_s = torch.zeros_like(loc["acc"])
+    dforce.force_tree_build(loc["pos"], loc["mass"])
+    dforce.grav_short_tree(acc_s, prev_accel=loc["prev"], gravpm=loc["gravpm"], active=sel.to(torch.int32).contiguous())
+    cnt = eng.walk_counters()
+    eng.set_instrumentation(False, False)
+    c_n = torch.tensor([cnt["pp"], cnt["nodes_visited"], cnt["nodes_used"]], dtype=torch.int64, device=dev)
+    dist.all_reduce(c_n)
+    # (the restricted walk repeats the step's values to rounding: the order of a target's list entries depends on its wave-mates)
+    same_walk = float((acc_s[sel] - loc["acc"][sel]).abs().max() / loc["acc"][sel].abs().mean().clamp_min(1e-300)) if ns else 0.0
+    # the sample's rows to rank 0: id, prev accel (the opening input), GravPM, acceleration
+    rows = torch.cat([own_ids[sel].double()[:, None], loc["prev"][sel], loc["gravpm"][sel], loc["acc"][sel]], dim=1)
+    pad = torch.zeros(k, 10, dtype=torch.float64, device=dev)
+    pad[:ns] = rows
+    cntv = torch.tensor([ns], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(cntv) for _ in range(world)]
+    allr = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(allc, cntv)
+    dist.all_gather(allr, pad)
+    res = None
+    if rank == 0:
+        got = torch.cat([allr[r][:int(allc[r].item())] for r in range(world)])
+        ids = got[:, 0].long()
+        N = len(host_pos)
+        e1 = pkg.Engine(dev.index or 0)
+        e1.use_torch_stream()
+        configure_gravity(e1, args, box, n, nmesh)
+        e1.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=0, Rcut=6.0,
+                                 FractionalGravitySoftening=1. / 30.)
+        p1, m1 = torch.from_numpy(host_pos).to(dev), torch.from_numpy(host_mass).to(dev)
+        e1.dev_bind_particles(p1, m1, box)
+        g1 = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+        a1 = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+        pv = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+        pv[ids] = got[:, 1:4]
+        e1.dev_gravpm_force(g1, None)
+        e1.dev_force_tree_build()
+        e1.set_instrumentation(False, True)
+        order = torch.argsort(ids)
+        tg = ids[order].to(torch.int32).contiguous()
+        e1.dev_grav_short_tree(a1, prev_accel=pv, gravpm=g1, active=tg)
+        torch.cuda.synchronize()
+        c1 = e1.walk_counters()
+        d_pm = (g1[ids] - got[:, 4:7]).norm(dim=1) / g1[ids].norm(dim=1).mean()
+        an = a1[ids].norm(dim=1)
+        d_a = (a1[ids] - got[:, 7:10]).norm(dim=1) / an.clamp_min(1e-300)
+        cn = [int(x) for x in c_n.cpu()]
+        c1v = [c1["pp"], c1["nodes_visited"], c1["nodes_used"]]
+        res = {"n": int(ids.shape[0]), "max_rel": float(d_a.max()), "median_rel": float(d_a.median()),
+               "p999_rel": float(torch.quantile(d_a, 0.999)), "gravpm_max_rel_to_mean": float(d_pm.max()),
+               "worst_over_mean_accel": float(((a1[ids] - got[:, 7:10]).norm(dim=1)).max() / an.mean()),
+               "counters_equal": cn == c1v, "counters_ranks": cn, "counters_one_gpu": c1v, "restricted_walk_max_rel_rank0": same_walk,
+               "gate": "SURVEY 8(d): median <= 1e-12, 99.9 % <= 1e-9, no particle worse than 2 ErrTolForceAcc <|a|>; GravPM <= 1e-11 <|GravPM|>",
+               "reference": "the same particles recomputed on one GPU from all %d particles through the single-GPU path (pinned to the oracle "
+                            "by tests/test_gpu_gravity.py); opening input = the ranks' previous acceleration" % N}
+        res["ok"] = bool(res["median_rel"] <= 1e-12 and res["p999_rel"] <= 1e-9 and res["worst_over_mean_accel"] <= 2 * 0.002 and
+                         res["gravpm_max_rel_to_mean"] <= 1e-11 and res["counters_equal"])
+        e1.close()
+    return res
+
+
+def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
+    """N > 1 (or MPG_FORCE_MGPU: the same code in a one-rank group): weak scaling, ~256^3 particles per GPU, particles on the owners of
+    their Peano-Hilbert TopLeaves, everything through the library's choreography (mpg_dist_*, csrc/dist.hip) with the collectives on
+    RCCL (dist.py::TorchComm)."""
+    n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / (8 * world))) * 8 * world)
+    nmesh = 2 * n
+    pos, mass, box = getattr(pkg.ics, args.ic)(n)
+    N = len(pos)
+    eng = pkg.Engine(local_rank)
+    configure_gravity(eng, args, box, n, nmesh)
+    comm = pkg.dist.TorchComm(dev)
+    dforce = pkg.dist.DistForce(eng, comm)
+    rcut = 6.0 * 1.5 * box / nmesh                        # margin = Rcut * Asmth * cell size (gravshort-tree.c:102)
+    # domain_decompose_full + domain_exchange (untimed, SURVEY 8(d)): every rank starts from a contiguous share of the set
+    lo, hi = (N * rank) // world, (N * (rank + 1)) // world
+    sp = torch.from_numpy(pos[lo:hi]).to(dev)
+    sm = torch.from_numpy(mass[lo:hi]).to(dev)
+    sid = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    ntn, ntl = dforce.domain_decompose(sp, box, overdecomposition=args.overdecomp)
+    own_pos, own_mass, own_ids = dforce.domain_exchange(sp, sm, sid)
+    del sp, sm, sid
+    dforce.use_decomposition(box, rcut)
+    n_own = int(own_pos.shape[0])
+    tot = torch.tensor([n_own], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot)
+    assert int(tot.item()) == N, "the ranks' own sets do not add up to the particle set (%d of %d)" % (int(tot.item()), N)
+    if rank != 0 or args.no_parity_check:
+        del pos                                            # (rank 0 keeps the host copy for the parity tail)
+    z3 = lambda: torch.zeros(n_own, 3, dtype=torch.float64, device=dev)
+    loc = dict(pos=own_pos, mass=own_mass, acc=z3(), prev=z3(), gravpm=z3(), pot=torch.zeros(n_own, dtype=torch.float64, device=dev), steps=0)
+
+    def rank_sums(x):
+        """max over ranks / mean over ranks of a per-rank number"""
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = float(x)
+        dist.all_reduce(t)
+        return float(t.max() / t.mean())
+
+    def step():
+        loc["prev"], loc["acc"] = loc["acc"], loc["prev"]
+        # the first step has no previous acceleration: Barnes-Hut opening (TreeUseBH = 2), as the reference's first step
+        dforce.gravity_step(loc["pos"], loc["mass"], loc["acc"], loc["gravpm"], potential=loc["pot"], prev_accel=loc["prev"] if loc["steps"] else None)
+        loc["steps"] += 1
+
+    def rebalance():
+        """domain_decompose_full again, now with the work the last walk measured per particle as the cost the TopLeaves are balanced
+        by (domain.c:611), and the exchange of the particles with their last acceleration, which the relative criterion needs"""
+        nonlocal own_ids, n_own
+        cost = dforce.walk_cost(n_own)
+        loc["work_before"] = rank_sums(cost.sum().item())
+        loc["count_before"] = rank_sums(n_own)
+        dforce.domain_decompose(loc["pos"], box, overdecomposition=args.overdecomp, cost=cost)
+        p, m, ids, pa, pg = dforce.domain_exchange(loc["pos"], loc["mass"], own_ids, loc["acc"], loc["gravpm"])
+        own_ids, n_own = ids, int(p.shape[0])
+        dforce.use_decomposition(box, rcut)
+        loc.update(pos=p, mass=m, acc=pa.contiguous(), prev=torch.zeros_like(pa), gravpm=pg.contiguous(),
+                   pot=torch.zeros(n_own, dtype=torch.float64, device=dev))
+        step()
+        loc["work_after"] = rank_sums(dforce.walk_cost(n_own).sum().item())
+        loc["count_after"] = rank_sums(n_own)
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    step()          # set-up, not a step: first-use allocations, FFT plans, the list-capacity adaptation of the walk
+    if not args.no_rebalance:
+        step()      # (a walk with the relative criterion: its per-particle work is what the domains are balanced by)
+        rebalance()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.walk_events_collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    walk_ms, walk_launches = eng.walk_events_collect()
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    elapsed = float(dt.item())
+    # ---- untimed: phase times of one more step, interaction counters of another, then the self-check
+    tm_sum = None
+    eng.set_instrumentation(True, False)
+    step()
+    sync()
+    ph = eng.phase_times()
+    st, tm = dforce.stats(), dforce.times()
+    eng.set_instrumentation(False, True)
+    step()
+    sync()
+    cnt = eng.walk_counters()
+    eng.set_instrumentation(False, False)
+    eng.walk_events_collect()
+    parity = None
+    if not args.no_parity_check:
+        parity = parity_check_ranks(pkg, torch, dist, args, dev, rank, world, pos if rank == 0 else None, mass, box, n, nmesh, own_ids, loc, dforce, eng)
+    out = None
+    if rank == 0:
+        value = N * args.steps / elapsed
+        traffic, traffic_note = None, "per-rank walk; no PMC summary for multi-rank runs"
+        out = {
+            "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
+            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
+                                   "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
+                       "particles": N, "nmesh": nmesh,
+                       "parallelism": "%d GPUs: particles on the owners of their Peano-Hilbert TopLeaves (domain_decompose_full, %d TopLeaves); per step "
+                                      "{Pos, Mass} shipped to the x-slab PM (2 all-to-all transposes + neighbour planes) and {GravPM, Potential} back, "
+                                      "ghosts imported in whole level-La tree cells within Rcut of the rank's TopLeaves, top of the tree from an "
+                                      "all-reduce; choreography in the library (mpg_dist_*), collectives on RCCL" % (world, ntl),
+                       "ghost_fraction_rank0": round(st["ghosts"] / max(n_own, 1), 3), "decomposition_level_La": st["La"]},
+            "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
+            "phases_ms": {k: round(v, 3) for k, v in ph.items()},
+        }
+        out["roofline"]["note"] += "; rank 0's walk over its own particles (counters and events of rank 0)"
+        if "work_after" in loc:
+            out["config"]["load_balance"] = {
+                "walk_work_max_over_mean": round(loc["work_after"], 4), "particles_max_over_mean": round(loc["count_after"], 4),
+                "by_particle_number": {"walk_work_max_over_mean": round(loc["work_before"], 4),
+                                       "particles_max_over_mean": round(loc["count_before"], 4)},
+                "note": "TopLeaves dealt to the ranks by the walk work measured per particle; by_particle_number = the same step on the "
+                        "decomposition balanced by particle counts"}
+        out["phases_ms"].update({"dist_pm_ms": round(tm["pm"], 3), "dist_ghost_import_ms": round(tm["ghosts"], 3),
+                                 "dist_tree_and_top_ms": round(tm["tree"], 3), "dist_walk_ms": round(tm["walk"], 3),
+                                 "dist_exchange_bytes": st["exchange_bytes"], "dist_transpose_bytes": st["transpose_bytes"]})
+        if parity is not None:
+            out["parity_check"] = parity
+    dist.barrier()
+    dist.destroy_process_group()
+    dforce.close()
+    eng.close()
+    if out is not None:
+        emit(out)
+        if parity is not None and not parity["ok"]:
+            print("bench.py: the multi-rank forces FAILED the self-check against the one-GPU path: %s" % json.dumps(parity), file=sys.stderr, flush=True)
+            sys.exit(3)
+    return out
+
+
+def gravity_bench_single(pkg, torch, args, dev, local_rank):
+    """N = 1: BASELINE.json configs[1], the configuration the metric is quoted on."""
+    n = args.n or 256
+    nmesh = 2 * n
+    pos, mass, box = getattr(pkg.ics, args.ic)(n)
+    N = len(pos)
+    d_pos = torch.from_numpy(pos).to(dev)
+    d_mass = torch.from_numpy(mass).to(dev)
+    del pos
+    eng = pkg.Engine(local_rank)
+    configure_gravity(eng, args, box, n, nmesh)
+    eng.dev_bind_particles(d_pos, d_mass, box)
+    z3 = lambda: torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    gravpm, acc, prev, pot = z3(), z3(), z3(), torch.zeros(N, dtype=torch.float64, device=dev)
+
+    def step():
+        nonlocal acc, prev
+        eng.dev_gravpm_force(gravpm, pot)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+
+    step()          # set-up, not a step: first-use allocations, FFT plans, the list-capacity adaptation of the walk and the deposit's timing trial
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.walk_events_collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    walk_ms, walk_launches = eng.walk_events_collect()
+    # ---- untimed diagnostic passes: phase times of one more step, interaction counters of another (the counting builds of the
+    # walk kernels are slower: kept out of the phase times)
+    eng.set_instrumentation(True, False)
+    step()
+    torch.cuda.synchronize()
+    ph = eng.phase_times()
+    eng.set_instrumentation(False, True)
+    step()
+    torch.cuda.synchronize()
+    cnt = eng.walk_counters()
+    eng.set_instrumentation(False, False)
+    eng.walk_events_collect()
+    variant = eng.walk_choice()[0]
+    traffic, traffic_note = walk_traffic(pkg, N, args.ic, variant)
+    out = {
+        "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
+        "value": N * args.steps / elapsed, "unit": "particles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
+                               "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
+                   "particles": N, "nmesh": nmesh, "parallelism": "1 GPU"},
+        "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
+        "phases_ms": {k: round(v, 3) for k, v in ph.items()},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(), args.cpu_sample)
+    if not args.no_extras:
+        # untimed legs after `value`: the short-range-only sub-steps, the PCIe-inclusive drop-in path, the other input sets of
+        # SURVEY 8(d) at the same size, and BASELINE configs[2] (the gas configuration)
+        out["substeps"] = substep_measure(pkg, torch, eng, N, acc, prev, gravpm, pot, dev)
+        host_pos = d_pos.cpu().numpy()
+        out["host_path"] = host_path_steps(pkg, eng, host_pos, mass, box)
+        out["resident_path"] = resident_path_steps(pkg, eng, host_pos, mass, box)
+        del gravpm, acc, prev, pot, d_pos, d_mass, host_pos
+        torch.cuda.empty_cache()
+        out["other_inputs"] = {ic: quick_gravity_steps(pkg, torch, eng, ic, n, nmesh, dev)
+                               for ic in ("s_grid", "s_zel", "s_clust") if ic != args.ic}
+    eng.close()
+    if not args.no_extras:
+        torch.cuda.empty_cache()
+        out["hydro"] = hydro_measure(pkg, torch, args, dev, n=128 if n >= 128 else max(n // 2, 16))
+    emit(out)
+    return out
+
+
+def substep_bench(pkg, torch, args, dev, local_rank):
+    """--workload substep: SURVEY 8(d) metric (ii) as its own line (value = active particles per second at --active-frac on the tree of
+    all particles)."""
+    n = args.n or 256
+    nmesh = 2 * n
+    pos, mass, box = getattr(pkg.ics, args.ic)(n)
+    N = len(pos)
+    d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
+    eng = pkg.Engine(local_rank)
+    configure_gravity(eng, args, box, n, nmesh)
+    eng.dev_bind_particles(d_pos, d_mass, box)
+    z3 = lambda: torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    gravpm, acc, prev, pot = z3(), z3(), z3(), torch.zeros(N, dtype=torch.float64, device=dev)
+    for _ in range(3):      # Barnes-Hut first walk, list-capacity adaptation, one relative-criterion walk: OldAcc for the sub-steps
+        eng.dev_gravpm_force(gravpm, pot)
+        eng.dev_force_tree_build()
+        prev, acc = acc, prev
+        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
+    fr = sorted(set([args.active_frac, 1. / 8, 1. / 64, 1. / 512]), reverse=True)
+    res = substep_measure(pkg, torch, eng, N, acc, prev, gravpm, pot, dev, fracs=fr, reps=max(args.steps, 1))
+    key = "1/%d" % round(1 / args.active_frac)
+    r = res[key]["all_particle_tree"]
+    out = {"metric": "active particle-updates/sec (short-range-only sub-step: tree build + walk of the ActiveParticle list)",
+           "value": r["active_per_s"], "unit": "particles/s", "n_gpus": 1, "steps": max(args.steps, 1), "warmup": 1,
+           "ms_per_step": r["ms_per_substep"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%d^3 DM-only, sub-step with %s of the particles active (random), tree of all particles, relative criterion" % (n, key),
+                      "particles": N, "active": res[key]["active"]},
+           "roofline": {"bound": "fp64_valu", "kernel": {1: "k_grav_walk", 6: "k_walk_lists8 + k_walk_eval"}.get(r["walk_kernel"], "?"), "achieved": None,
+                        "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": None, "traffic": None, "avg_launch_ms": r["walk_ms"],
+                        "note": "sub-steps are bound by the tree build and the launch of a small walk, not by a roofline: see `substeps`"},
+           "substeps": res}
+    eng.close()
+    emit(out)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,25 +691,23 @@ def main():
     ap.add_argument("--ic", default="s_zel", choices=["s_grid", "s_zel", "s_clust"],
                     help="synthetic input set (SURVEY 8(d)); s_zel, the Zel'dovich-displaced grid, is the headline set")
     ap.add_argument("--no-extras", action="store_true",
-                    help="N = 1: skip the other_inputs (s_grid, s_clust) and host_path (PCIe-inclusive drop-in calls) legs")
+                    help="N = 1: skip the untimed legs (substeps, host_path, resident_path, other_inputs, hydro)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="N > 1: skip the untimed self-check of the forces against the one-GPU path")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--mgpu", choices=["peano", "domain", "slab", "replicated"], default="peano",
-                    help="N > 1: peano = particles on the owners of their Peano-Hilbert TopLeaves (the reference's domain_decompose_full), "
-                         "force step through the library's own choreography (mpg_dist_*, csrc/dist.hip); domain = x-slab domains with "
-                         "ghost import driven from Python (round 1); slab = particles replicated, slab PM and slab targets; replicated = "
-                         "everything but the walk targets replicated")
-    ap.add_argument("--overdecomp", type=int, default=8, help="peano: DomainOverDecompositionFactor (TopLeaves per rank and policy)")
+    ap.add_argument("--mgpu", default="peano", choices=["peano"], help="(kept for the command lines of round 2; the x-slab / replicated forms were retired)")
+    ap.add_argument("--overdecomp", type=int, default=8, help="DomainOverDecompositionFactor (TopLeaves per rank and policy)")
     ap.add_argument("--no-rebalance", action="store_true",
-                    help="peano: keep the decomposition by particle number (default: after two set-up steps the TopLeaves are dealt out "
+                    help="N > 1: keep the decomposition by particle number (default: after two set-up steps the TopLeaves are dealt out "
                          "again by the measured work per particle, domain.c:611)")
     ap.add_argument("--sph", default="auto", choices=["auto", "de", "pe"],
                     help="hydro workload: density-entropy (BASELINE configs[2]) or pressure-entropy SPH (configs[4]); auto: de on one GPU, pe on several")
-    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof", "domain"],
-                    help="gravity: BASELINE.json configs[1] (default, the headline metric); hydro: configs[2], 2 x n^3 DM+gas, "
-                         "adds gas tree + density + hmax + hydro force (single GPU, diagnostic line)")
+    ap.add_argument("--active-frac", type=float, default=1. / 64, help="substep workload: fraction of the particles that is active")
+    ap.add_argument("--workload", default="gravity", choices=["gravity", "hydro", "integrate", "fof", "domain", "substep"],
+                    help="gravity: BASELINE.json configs[1] (default, the headline metric; its line also carries the sub-steps and configs[2]); "
+                         "hydro: configs[2] / [4] as their own line; substep: the short-range-only step; integrate / fof / domain: SURVEY 8(f) rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,320 +730,28 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("MPG_DIST_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU in tests
+        backend = os.environ.get("MPG_DIST_BACKEND", "nccl")   # "gloo" lets several ranks share one GPU in tests
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
+    if args.workload in ("integrate", "fof", "domain", "substep") and world != 1:
+        raise SystemExit("--workload %s is a one-GPU line" % args.workload)
     if args.workload == "integrate":
-        if world != 1:
-            raise SystemExit("--workload integrate is single-GPU")
         return integrate_bench(pkg, torch, args, dev)
     if args.workload == "fof":
-        if world != 1:
-            raise SystemExit("--workload fof is single-GPU")
         return fof_bench(pkg, torch, args, dev)
     if args.workload == "domain":
-        if world != 1:
-            raise SystemExit("--workload domain is a one-rank line (tests/test_gpu_domain.py runs the decomposition on several ranks)")
         return domain_bench(pkg, torch, args, dev)
-    if multi and world == 1:
-        pkg.pm_slab.FORCE_COLLECTIVES = True
+    if args.workload == "substep":
+        return substep_bench(pkg, torch, args, dev, local_rank)
     if args.workload == "hydro":
-        if multi and args.mgpu == "peano":
+        if multi:
             return hydro_bench_peano(pkg, torch, dist, args, dev, rank, world)
-        if multi:
-            return hydro_bench_domain(pkg, torch, dist, args, dev, rank, world)
         return hydro_bench(pkg, torch, args, dev)
-    # weak scaling: about 256^3 particles per GPU; Nmesh = 2 n must be a multiple of the number of GPUs (x-slab PM)
-    n = args.n or {1: 256, 2: 320, 4: 400, 8: 512}.get(world, int(round(256 * world ** (1. / 3) / (8 * world))) * 8 * world)
-    nmesh = 2 * n
-    gen = getattr(pkg.ics, args.ic)
-    slabwise = multi and args.mgpu == "domain" and args.ic == "s_grid" and world > 1 and n % world == 0
-    if slabwise:
-        # every rank generates only the grid planes its slab can own: its n/world planes and one more on either side (the
-        # +-0.15 spacing jitter moves no particle further); the union over ranks is exactly s_grid(n)
-        lo, hi = rank * (n // world), (rank + 1) * (n // world)
-        parts = [pkg.ics.s_grid_planes(n, max(lo - 1, 0), min(hi + 1, n))]
-        if lo == 0:
-            parts.append(pkg.ics.s_grid_planes(n, n - 1, n))
-        if hi == n:
-            parts.append(pkg.ics.s_grid_planes(n, 0, 1))
-        pos = np.concatenate([p[0] for p in parts])
-        mass = np.concatenate([p[1] for p in parts])
-        box = parts[0][2]
-        N = n ** 3
-    else:
-        pos, mass, box = gen(n)
-        N = len(pos)
-    d_pos = torch.from_numpy(pos).to(dev)
-    d_mass = torch.from_numpy(mass).to(dev)
-    del pos
-    eng = pkg.Engine(local_rank)
-    eng.use_torch_stream()
-    eng.set_walk_threshold(args.thresh)
-    eng.set_walk_variant(args.variant)
-    eng.gravshort_fill_ntab(0, 1.5)
-    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
-    eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,
-                              FractionalGravitySoftening=1. / 30.)
-    eng.gravshort_set_softenings(box / n)
-    eng.dev_bind_particles(d_pos, d_mass, box)
-
-    NB = int(d_pos.shape[0])    # particles bound at set-up (all of them, except in the slab-wise domain mode)
-    gravpm = torch.zeros(NB, 3, dtype=torch.float64, device=dev)
-    acc = torch.zeros(NB, 3, dtype=torch.float64, device=dev)
-    prev = torch.zeros(NB, 3, dtype=torch.float64, device=dev)
-    pot = torch.zeros(NB, dtype=torch.float64, device=dev)
-    # N > 1: "slab" = x-slab PM (two all-to-all transposes per step) with the particles of the slab as
-    # PM-readout and walk targets; "replicated" = every rank does the whole PM, targets are contiguous tree-slot ranges
-    pm_ms = [0.0, 0]
-    if multi and args.mgpu == "domain":
-        rcut = 6.0 * 1.5 * box / nmesh                       # Rcut * Asmth * cell size (gravshort-tree.c:102)
-        dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut)
-        own = dom.select_own(d_pos)
-        own_pos, own_mass = d_pos[own].contiguous(), d_mass[own].contiguous()
-        n_own = int(own.shape[0])
-        tot = torch.tensor([n_own], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
-        assert int(tot.item()) == N, "the ranks' own sets do not add up to the particle set (%d of %d)" % (int(tot.item()), N)
-        del d_pos, d_mass, own, gravpm, acc, prev, pot      # from here on this rank holds its own particles and their ghosts only
-        torch.cuda.empty_cache()
-        spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        loc = {}                                             # arrays over [own | ghosts], sized on first use
-    elif multi and args.mgpu == "peano":
-        # domain_decompose_full + domain_exchange (untimed): every rank starts from a contiguous share of the set
-        share = slice((N * rank) // world, (N * (rank + 1)) // world)
-        pdom = pkg.domain_peano.PeanoDomain(eng, box, rank, world, overdecomposition=args.overdecomp)
-        sp, sm = d_pos[share].contiguous(), d_mass[share].contiguous()
-        pdom.decompose(sp)
-        own_pos, own_mass = pdom.exchange(sp, sm)
-        n_own = int(own_pos.shape[0])
-        tot = torch.tensor([n_own], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
-        assert int(tot.item()) == N, "the ranks' own sets do not add up to the particle set (%d of %d)" % (int(tot.item()), N)
-        del d_pos, d_mass, sp, sm, gravpm, acc, prev, pot
-        torch.cuda.empty_cache()
-        comm = pkg.dist.TorchComm(dev)
-        dforce = pkg.dist.DistForce(eng, comm)
-        dforce.set_domain(pdom, 6.0 * 1.5 * box / nmesh)      # margin = Rcut * Asmth * cell size (gravshort-tree.c:102)
-        z3 = lambda: torch.zeros(n_own, 3, dtype=torch.float64, device=dev)
-        loc = dict(acc=z3(), prev=z3(), gravpm=z3(), pot=torch.zeros(n_own, dtype=torch.float64, device=dev), steps=0)
-    elif multi and args.mgpu == "slab":
-        spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
-        tex = pkg.pm_slab.TargetExchange(world, dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    elif multi:
-        lo, hi = pkg.shard.slot_range(N, rank, world)
-        chunk = pkg.shard.chunk_size(N, world)
-        gbuf = torch.zeros(world * chunk, 3, dtype=torch.float64, device=dev)
-        sbuf = torch.zeros(chunk, 3, dtype=torch.float64, device=dev)
-
-    def step_domain():
-        lpos, lmass = dom.import_ghosts(own_pos, own_mass)
-        nl = int(lpos.shape[0])
-        if loc.get("n", -1) < nl:
-            z3 = lambda: torch.zeros(int(nl * 1.02) + 1024, 3, dtype=torch.float64, device=dev)
-            loc.update(n=int(nl * 1.02) + 1024, acc=z3(), prev=z3(), gravpm=z3(), pot=torch.zeros(int(nl * 1.02) + 1024, dtype=torch.float64, device=dev))
-        loc["pos"], loc["mass"] = lpos, lmass               # keep the bound arrays alive
-        eng.dev_bind_particles(lpos, lmass, box)
-        eng.dev_force_tree_build()
-        dom.set_global_top(n_own)
-        tg = dom.own_targets(n_own, nl)
-        ev0.record()
-        spm.force(tg, loc["gravpm"], loc["pot"])
-        ev1.record()
-        loc["prev"], loc["acc"] = loc["acc"], loc["prev"]
-        eng.dev_grav_short_tree(loc["acc"], prev_accel=loc["prev"], gravpm=loc["gravpm"], potential=loc["pot"], active=tg)
-        loc["ghost_fraction"] = nl / n_own - 1
-        eng.synchronize()
-        pm_ms[0] += ev0.elapsed_time(ev1)
-        pm_ms[1] += 1
-
-    def rank_sums(x):
-        """max over ranks / mean over ranks of a per-rank number"""
-        t = torch.zeros(world, dtype=torch.float64, device=dev)
-        t[rank] = float(x)
-        dist.all_reduce(t)
-        return float(t.max() / t.mean())
-
-    def rebalance_peano():
-        """domain_decompose_full again, now with the work the last walk measured per particle as the cost the TopLeaves are balanced
-        by, and the exchange of the particles (with their last acceleration, which the relative opening criterion needs)"""
-        nonlocal own_pos, own_mass, n_own
-        cost = dforce.walk_cost(n_own)
-        loc["work_before"] = rank_sums(cost.sum().item())
-        loc["count_before"] = rank_sums(n_own)
-        # what equal-volume x-slabs (the domains of round 1) would carry of the same work
-        slab = pkg.pm_slab.slab_of_cells(own_pos[:, 0], box / nmesh, nmesh, world)
-        w = torch.zeros(world, dtype=torch.float64, device=dev).index_add_(0, slab, cost.double())
-        dist.all_reduce(w)
-        loc["work_xslab"] = float(w.max() / w.mean())
-        pdom.decompose(own_pos, cost=cost)
-        own_pos, own_mass, pa, pg = pdom.exchange(own_pos, own_mass, loc["acc"], loc["gravpm"])
-        n_own = int(own_pos.shape[0])
-        dforce.set_domain(pdom, 6.0 * 1.5 * box / nmesh)
-        z3 = lambda: torch.zeros(n_own, 3, dtype=torch.float64, device=dev)
-        loc.update(acc=pa.contiguous(), prev=z3(), gravpm=pg.contiguous(), pot=torch.zeros(n_own, dtype=torch.float64, device=dev))
-        step_peano()
-        loc["work_after"] = rank_sums(dforce.walk_cost(n_own).sum().item())
-        loc["count_after"] = rank_sums(n_own)
-
-    def step_peano():
-        loc["prev"], loc["acc"] = loc["acc"], loc["prev"]
-        # the first step has no previous acceleration: Barnes-Hut opening (TreeUseBH = 2), as the reference's first step
-        dforce.gravity_step(own_pos, own_mass, loc["acc"], loc["gravpm"], potential=loc["pot"], prev_accel=loc["prev"] if loc["steps"] else None)
-        loc["steps"] += 1
-
-    def step():
-        nonlocal acc, prev
-        if multi and args.mgpu == "peano":
-            return step_peano()
-        if multi and args.mgpu == "domain":
-            return step_domain()
-        if not multi:
-            eng.dev_gravpm_force(gravpm, pot)
-            eng.dev_force_tree_build()
-            prev, acc = acc, prev
-            eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
-        elif args.mgpu == "slab":
-            eng.dev_force_tree_build()
-            tg = spm.targets(d_pos, eng.dev_tree_order(N, dev))
-            ev0.record()
-            spm.force(tg, gravpm, pot)
-            ev1.record()
-            prev, acc = acc, prev
-            eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=tg)
-            tex.exchange(acc, tg)
-            pm_ms[0] += ev0.elapsed_time(ev1)   # both events are complete: exchange() synchronised on the target counts
-            pm_ms[1] += 1
-        else:
-            eng.dev_gravpm_force(gravpm, pot)
-            eng.dev_force_tree_build()
-            prev, acc = acc, prev
-            optr = eng.dev_tree_order_ptr()
-            eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=optr + 4 * lo, nactive=hi - lo)
-            pkg.shard.exchange_results(acc, eng.dev_tree_order(N, dev), rank, world, sbuf, gbuf)
-
-    def sync():
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    step()          # set-up, not a step: first-use allocations, FFT plans, the list-capacity adaptation of the walk and the deposit's timing trial (engine.hip, pm.hip)
-    if multi and args.mgpu == "peano" and not args.no_rebalance:
-        step()      # (a walk with the relative criterion: its per-particle work is what the domains are balanced by)
-        rebalance_peano()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    eng.walk_events_collect()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    t1 = time.perf_counter()
-    walk_ms, walk_launches = eng.walk_events_collect()
-    dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if multi:
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    elapsed = float(dt.item())
-
-    # ---- untimed diagnostic passes: phase times of one more step, interaction counters of another (the counting builds of the
-    # walk kernels are slower: kept out of the phase times)
-    eng.set_instrumentation(True, False)
-    step()
-    sync()
-    ph = eng.phase_times()
-    eng.set_instrumentation(False, True)
-    step()
-    sync()
-    cnt = eng.walk_counters()
-    eng.set_instrumentation(False, False)
-    eng.walk_events_collect()
-    if os.environ.get("MPG_BENCH_DEBUG") and rank == 0:
-        if multi and args.mgpu in ("domain", "peano"):
-            a, b, g = loc["acc"][:n_own], loc["prev"][:n_own], loc["gravpm"][:n_own]
-        else:
-            a, b, g = acc, prev, gravpm
-        nrm = lambda t: float(t.norm(dim=1).mean())
-        print("debug: mean |acc| %.6e |prev| %.6e |gravpm| %.6e |prev+gravpm| %.6e |acc+gravpm| %.6e" % (nrm(a), nrm(b), nrm(g), nrm(b + g), nrm(a + g)), flush=True)
-
-    out = None
-    if rank == 0:
-        value = N * args.steps / elapsed
-        traffic, traffic_note = None, "no PMC summary committed for this configuration"
-        tpath = os.path.join(ROOT, "profiles", "walk_traffic.json")
-        variant = eng.walk_choice()[0]
-        if os.path.exists(tpath) and N == 256 ** 3 and world == 1:
-            tj = json.load(open(tpath)).get("by_ic", {}).get(args.ic, {}).get(str(variant))
-            if tj:
-                traffic = tj["hbm_bytes_per_launch"]
-                traffic_note = "bytes per walk (%s) from %s" % (tj["kernel"], tj["method"])
-        out = {
-            "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
-            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d^3 DM-only TreePM force step, Nmesh=%d, %s ICs, all particles active, relative opening "
-                                   "criterion (ErrTolForceAcc 0.002), TreeRcut 6, Asmth 1.5" % (n, nmesh, args.ic),
-                       "particles": N, "nmesh": nmesh, "parallelism": "1 GPU" if world == 1 else
-                       ("%d GPUs: particles on the owners of their Peano-Hilbert TopLeaves (domain_decompose_full, %d TopLeaves); per step "
-                        "{Pos, Mass} shipped to the x-slab PM (2 all-to-all transposes + neighbour planes) and {GravPM, Potential} back, "
-                        "ghosts imported in whole level-La tree cells within Rcut of the rank's TopLeaves, top of the tree from an "
-                        "all-reduce; choreography in the library (mpg_dist_*), collectives on RCCL" % (world, pdom.NTopLeaves)
-                        if args.mgpu == "peano" else
-                        "%d GPUs: particles distributed in x-slab domains, ghosts imported in whole tree-cell columns within Rcut "
-                        "(one personalised exchange per step), top of the tree from an all-reduce, x-slab PM (2 all-to-all "
-                        "transposes + ghost planes per step); nothing replicated or all-gathered" % world if args.mgpu == "domain" else
-                        "%d GPUs: x-slab PM (2 all-to-all transposes + ghost planes per step), slab particles as targets, tree "
-                        "replicated, one all-gather of accelerations" % world if args.mgpu == "slab" else
-                        "targets sharded over %d GPUs (tree-order ranges), PM and tree replicated, all-gather of accelerations" % world)},
-            "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
-            "phases_ms": {k: round(v, 3) for k, v in ph.items()},
-        }
-        if pm_ms[1]:
-            out["phases_ms"]["pm_slab_total_incl_collectives"] = round(pm_ms[0] / pm_ms[1], 3)
-        if multi and args.mgpu == "domain":
-            out["config"]["ghost_fraction_rank0"] = round(loc["ghost_fraction"], 3)
-        if multi and args.mgpu == "peano":
-            st, tm = dforce.stats(), dforce.times()
-            out["config"]["ghost_fraction_rank0"] = round(st["ghosts"] / max(n_own, 1), 3)
-            out["config"]["decomposition_level_La"] = st["La"]
-            out["config"]["own_particles_max_over_mean"] = round(float(pdom.task_loads.max() / pdom.task_loads.mean()), 4)
-            if "work_after" in loc:
-                out["config"]["load_balance"] = {
-                    "walk_work_max_over_mean": round(loc["work_after"], 4), "particles_max_over_mean": round(loc["count_after"], 4),
-                    "by_particle_number": {"walk_work_max_over_mean": round(loc["work_before"], 4),
-                                           "particles_max_over_mean": round(loc["count_before"], 4)},
-                    "x_slab_domains_walk_work_max_over_mean": round(loc["work_xslab"], 4),
-                    "note": "TopLeaves dealt to the ranks by measured walk work per particle (8 x leaf entries + nodes used + 8 x "
-                            "traversal steps); by_particle_number = the same step on the decomposition balanced by particle counts"}
-            out["phases_ms"].update({"dist_pm_ms": round(tm["pm"], 3), "dist_ghost_import_ms": round(tm["ghosts"], 3),
-                                     "dist_tree_and_top_ms": round(tm["tree"], 3), "dist_walk_ms": round(tm["walk"], 3),
-                                     "dist_exchange_bytes": st["exchange_bytes"], "dist_transpose_bytes": st["transpose_bytes"]})
-        if world == 1 and not multi and not args.no_cpu_baseline:    # (MPG_FORCE_MGPU frees the full arrays: no baseline leg)
-            out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(),
-                                               args.cpu_sample)
-        if world == 1 and not multi and not args.no_extras:
-            # the other input sets of SURVEY 8(d) at the same size, and the PCIe-inclusive drop-in path (untimed legs: after `value`)
-            host_pos = d_pos.cpu().numpy()
-            del gravpm, acc, prev, pot
-            out["host_path"] = host_path_steps(pkg, eng, host_pos, mass, box)
-            del d_pos, d_mass, host_pos
-            torch.cuda.empty_cache()
-            out["other_inputs"] = {ic: quick_gravity_steps(pkg, torch, eng, ic, n, nmesh, dev)
-                                   for ic in ("s_grid", "s_zel", "s_clust") if ic != args.ic}
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
-    eng.close()
-    if out is not None:
-        emit(out)
-    return out
+        return gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank)
+    return gravity_bench_single(pkg, torch, args, dev, local_rank)
 
 
 def integrate_bench(pkg, torch, args, dev):
@@ -689,103 +939,6 @@ def domain_bench(pkg, torch, args, dev):
     return out
 
 
-def hydro_bench(pkg, torch, args, dev):
-    """BASELINE.json configs[2]: 2 x n^3 (dark matter + gas), density-entropy SPH: one force step =
-    gravpm_force + force_tree_full + grav_short_tree (all particles) + force_tree_rebuild_mask(GAS) + density
-    + force_tree_calc_moments (hmax) + hydro_force  (run.c:466-548)."""
-    n = args.n or 128
-    nmesh = 2 * n
-    PE = 1 if args.sph == "pe" else 0
-    pos, mass, typ, box = hydro_ics(pkg, n)
-    N = len(pos)
-    f8 = torch.float64
-    d_pos, d_mass, d_type = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
-    eng = pkg.Engine(dev.index or 0)
-    eng.use_torch_stream()
-    eng.set_walk_variant(args.variant)
-    eng.gravshort_fill_ntab(0, 1.5)
-    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
-    eng.set_gravshort_treepar(TreeUseBH=2)
-    eng.gravshort_set_softenings(box / n)
-    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
-    eng.set_hydropar(PE, 100.0, 0.75)
-    eng.dev_bind_particles(d_pos, d_mass, box, type=d_type)
-    z1 = lambda: torch.zeros(N, dtype=f8, device=dev)
-    z3 = lambda: torch.zeros(N, 3, dtype=f8, device=dev)
-    a = dict(hsml=z1(), dthsml=z1(), vel=z3(), entropy=torch.ones(N, dtype=f8, device=dev), density=z1(), egywtdensity=z1(),
-             dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(), hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
-    gravpm, acc, prev, pot = z3(), z3(), z3(), z1()
-    t = pkg.SphTimes()
-    t.atime, t.hubble = 0.1, 0.1
-    for i in range(47):
-        t.dloga_bin[i] = 0.01
-    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK + pkg.engine.BHMASK, with_moments=True)
-    eng.dev_set_init_hsml(a, box / n)
-    iters = []
-
-    def step():
-        nonlocal acc, prev
-        eng.dev_gravpm_force(gravpm, pot)
-        eng.dev_force_tree_build()
-        prev, acc = acc, prev
-        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
-        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
-        eng.dev_density(a, t, DoEgyDensity=PE)
-        iters.append(eng.sph_stats()["iterations"])
-        eng.dev_force_tree_calc_hmax()
-        eng.dev_hydro_force(a, t)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    # ---- untimed diagnostic pass: per-phase times (events on the engine's stream) and the SPH kernels against SURVEY 8(d)'s bytes
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
-    ev[0].record()
-    eng.dev_gravpm_force(gravpm, pot)
-    eng.dev_force_tree_build()
-    eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot)
-    ev[1].record()
-    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
-    ev[2].record()
-    eng.dev_density(a, t, DoEgyDensity=PE)
-    sd = eng.sph_stats()
-    ev[3].record()
-    eng.dev_force_tree_calc_hmax()
-    ev[4].record()
-    eng.dev_hydro_force(a, t)
-    sh = eng.sph_stats()
-    ev[5].record()
-    torch.cuda.synchronize()
-    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
-    ngas = n ** 3
-    b_dens = sd["targets"] * 128 + sd["candidates"] * 28 + sd["interactions"] * 32
-    b_hyd = ngas * 176 + sh["candidates"] * 36 + sh["interactions"] * 100
-
-    def roof(kernel, b, t_ms, note):
-        ach = b / (t_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": b, "avg_launch_ms": t_ms, "note": note}
-    out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
-                      "particles": N, "density_iterations": iters[-args.steps:]},
-           "roofline": roof("k_density", b_dens, ms[2], "one density pass incl. queue set-up and predictions; B_dens = N_tgt*128 + N_cand*28 + "
-                            "N_ngb*32 (SURVEY 8(d)): %d targets, %d candidates, %d neighbours" % (sd["targets"], sd["candidates"], sd["interactions"])),
-           "roofline_hydro": roof("k_hydro", b_hyd, ms[4], "B_hyd = N_tgt*176 + N_cand*36 + N_pair*100: %d candidates, %d pairs"
-                                  % (sh["candidates"], sh["interactions"])),
-           "phases_ms": {"gravity_pm_tree_walk": round(ms[0], 3), "gas_tree": round(ms[1], 3), "density": round(ms[2], 3),
-                         "hmax": round(ms[3], 3), "hydro": round(ms[4], 3)}}
-    eng.close()
-    emit(out)
-    return out
-
-
 def hydro_ics(pkg, n):
     return pkg.ics.hydro_pair(n)
 
@@ -870,101 +1023,6 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
     return out
 
 
-def hydro_bench_domain(pkg, torch, dist, args, dev, rank, world):
-    """configs[2] weak-scaled over GPUs with the particles distributed: x-slab domains, ghosts within
-    max(Rcut, largest Hsml), gravity as in the DM-only bench, then gas tree -> density (own gas) -> the ghosts' SPH fields from
-    their owners -> hmax -> hydro_force (own gas)."""
-    n = args.n or {2: 160, 4: 200, 8: 256}.get(world, int(round(128 * world ** (1. / 3) / (4 * world))) * 4 * world)
-    nmesh = 2 * n
-    PE = 0 if args.sph == "de" else 1                        # configs[4]: pressure-entropy SPH on several GPUs
-    pos, mass, typ, box = hydro_ics(pkg, n)
-    N = len(pos)
-    f8 = dict(dtype=torch.float64, device=dev)
-    eng = pkg.Engine(dev.index or 0)
-    eng.use_torch_stream()
-    eng.set_walk_variant(args.variant)
-    eng.gravshort_fill_ntab(0, 1.5)
-    eng.gravpm_init_periodic(box, 1.5, nmesh, G)
-    eng.set_gravshort_treepar(TreeUseBH=2)
-    eng.gravshort_set_softenings(box / n)
-    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
-    eng.set_hydropar(PE, 100.0, 0.75)
-    rcut = 6.0 * 1.5 * box / nmesh
-    dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut, margin=6.0 * box / n)
-    g_pos = torch.from_numpy(pos).to(dev)
-    own = dom.select_own(g_pos)
-    n_own = int(own.shape[0])
-    o_pos, o_mass, o_typ = g_pos[own].contiguous(), torch.from_numpy(mass).to(dev)[own].contiguous(), torch.from_numpy(typ).to(dev)[own].contiguous()
-    del g_pos
-    o_vel, o_ent = torch.zeros(n_own, 3, **f8), torch.ones(n_own, **f8)
-    o_hsml = torch.full((n_own,), 2.0 * box / n, **f8)          # first pass converges it (untimed set-up step)
-    o_prev = torch.zeros(n_own, 3, **f8)
-    spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
-    t = pkg.SphTimes()
-    t.atime, t.hubble = 0.1, 0.1
-    for i in range(47):
-        t.dloga_bin[i] = 0.01
-    FIELDS = ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel")
-    keep = {}
-
-    def step():
-        nonlocal o_hsml, o_prev
-        lpos, lmass, ltyp, lvel, lent, lhsml = dom.import_ghosts(o_pos, o_mass, (o_typ, o_vel, o_ent, o_hsml))
-        nl = int(lpos.shape[0])
-        z1, z3 = (lambda: torch.zeros(nl, **f8)), (lambda: torch.zeros(nl, 3, **f8))
-        gravpm, acc, prev, pot = z3(), z3(), z3(), z1()
-        prev[:n_own] = o_prev
-        eng.dev_bind_particles(lpos, lmass, box, type=ltyp)
-        eng.dev_force_tree_build()
-        dom.set_global_top(n_own)
-        tg = dom.own_targets(n_own, nl)
-        spm.force(tg, gravpm, pot)
-        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gravpm, potential=pot, active=tg)
-        a = dict(hsml=lhsml, dthsml=z1(), vel=lvel, entropy=lent, density=z1(), egywtdensity=z1(), dhsmlegyfac=z1(), divvel=z1(), curlvel=z1(),
-                 hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
-        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
-        act = torch.nonzero(ltyp[:n_own] == 0).squeeze(1).to(torch.int32).contiguous()
-        eng.dev_density(a, t, active=act, DoEgyDensity=PE)
-        dom.check_hsml_margin(a["hsml"][:n_own])
-        for k, g in zip(FIELDS, dom.ghost_update_many([a[k][:n_own] for k in FIELDS])):
-            a[k][n_own:] = g
-        eng.dev_force_tree_calc_hmax()
-        eng.dev_hydro_force(a, t, active=act)
-        eng.synchronize()
-        o_hsml, o_prev = a["hsml"][:n_own].clone(), acc[:n_own].clone()
-        keep.update(arrays=(lpos, lmass, ltyp, a, acc), ghost_fraction=nl / n_own - 1, it=eng.sph_stats()["iterations"])
-
-    def sync():
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup + 1):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = torch.tensor([time.perf_counter() - t0], **f8)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    el = float(dt.item())
-    out = None
-    if rank == 0:
-        out = {"metric": "particle-updates/sec (gravity + SPH force step)", "value": N * args.steps / el, "unit": "particles/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
-                          "particles": N, "parallelism": "%d GPUs: particles distributed in x-slab domains with ghost import" % world,
-                          "ghost_fraction_rank0": round(keep["ghost_fraction"], 3), "density_iterations_last": keep["it"]}}
-    dist.barrier()
-    dist.destroy_process_group()
-    eng.close()
-    if out is not None:
-        emit(out)
-    return out
-
-
 def host_cpu_info():
     """(physical cores, logical cpus, model name) of this box from /proc/cpuinfo."""
     cores, model, logical = set(), "unknown", 0
@@ -987,62 +1045,169 @@ def host_cpu_info():
     return (len(cores) or os.cpu_count() or 1), (logical or os.cpu_count() or 1), model
 
 
-def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
-    """The CPU "port" (SURVEY 8(d) "CPU baseline timing"): the oracle built with the reference's flags (-O3 -ffast-math -fopenmp),
-    one process, OMP_NUM_THREADS = the physical cores this process may use, OMP_PROC_BIND=spread.  Bounded sample: the full tree
-    build + the short-range walk for `sample` targets that are CONTIGUOUS IN TREE (Morton) ORDER (the reference walks its
-    particles in Peano-Hilbert order, so neighbouring threads share nodes in cache), median of 3 walks after a warm-up, scaled to N;
-    the PM part (about 10 % of a reference step) is left out, which favours the CPU."""
-    phys, logical, model = host_cpu_info()
+def _numa_core_groups(nproc_hint=0):
+    """Physical cores of this box grouped for one worker process each: (first logical cpu of every physical core), sorted by socket /
+    NUMA node, cut into groups of ~16 cores that never straddle a socket (the reference runs as ranks x threads, README.rst:121)."""
+    cpus = {}
     try:
-        usable = len(os.sched_getaffinity(0))
+        proc = phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                proc = int(v)
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id":
+                core = int(v)
+                cpus.setdefault((phys, core), proc)
+    except OSError:
+        pass
+    try:
+        allowed = os.sched_getaffinity(0)
     except AttributeError:
-        usable = logical
-    threads = max(1, min(phys, usable))
-    # libgomp reads these when it is loaded (the oracle library is the first OpenMP user in this process)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    os.environ["OMP_PROC_BIND"] = "spread"
+        allowed = set(range(os.cpu_count() or 1))
+    cores = sorted((k, c) for k, c in cpus.items() if c in allowed)
+    if not cores:
+        cores = [((0, i), c) for i, c in enumerate(sorted(allowed))]
+    by_socket = {}
+    for (ph, _), c in cores:
+        by_socket.setdefault(ph, []).append(c)
+    groups = []
+    for ph in sorted(by_socket):
+        cs = by_socket[ph]
+        k = max(1, round(len(cs) / 16)) if not nproc_hint else max(1, nproc_hint // len(by_socket))
+        for i in range(k):
+            g = cs[len(cs) * i // k:len(cs) * (i + 1) // k]
+            if g:
+                groups.append(g)
+    return groups
+
+
+def _cpu_worker(rank, nproc, cpus, path, box, n, nmesh, lo, hi, q):
+    """One "rank" of the CPU baseline: pinned to its cores, it loads the particle set (first touch by its own threads: the pages land on
+    its NUMA node), builds the oracle's tree, and walks its contiguous share [lo, hi) of the Morton-ordered sample.  Also timed: the tree
+    of its own 1/nproc of the particles, which is what a rank of the reference builds (forcetree.c: local particles + top tree)."""
+    try:
+        os.sched_setaffinity(0, set(cpus))
+    except (AttributeError, OSError):
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(len(cpus))
+    os.environ["OMP_PROC_BIND"] = "close"
     os.environ["OMP_PLACES"] = "cores"
+    os.environ["OMP_WAIT_POLICY"] = "active"
+    sys.path.insert(0, ROOT)
     from oracle import oracle as O
     orc = O.Oracle(fast=True)
     orc.fill_ntab(0, 1.5)
+    d = np.load(path, mmap_mode="r")
+    pos = np.array(d["pos"])            # copies: first touch in this process
+    mass = np.array(d["mass"])
+    old = np.array(d["old"])
+    order = np.array(d["order"])
     N = len(pos)
+    # the tree a rank of the reference builds: its own share of the particles (a contiguous Morton range)
+    own = np.sort(order[N * rank // nproc:N * (rank + 1) // nproc])
+    t0 = time.perf_counter()
+    tr_own = orc.tree(np.ascontiguousarray(pos[own]), np.ascontiguousarray(mass[own]), box, father=False)
+    t_tree_own = time.perf_counter() - t0
+    del tr_own
     t0 = time.perf_counter()
     tr = orc.tree(pos, mass, box, father=False)
-    t_tree = time.perf_counter() - t0
+    t_tree_full = time.perf_counter() - t0
     par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
     par.TreeUseBH = 0
+    act = np.ascontiguousarray(order[lo:hi])
+    tr.grav_short_tree(par, oldacc=old, active=act[:min(len(act), 16384)])   # warm-up
+    q.put(("ready", rank))
+    walks, pp = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, c, _ = tr.grav_short_tree(par, oldacc=old, active=act)
+        walks.append(time.perf_counter() - t0)
+        pp = int(c[0])
+    q.put(("done", rank, walks, pp, t_tree_own, t_tree_full, orc.num_threads()))
+
+
+def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
+    """The CPU "port" (SURVEY 8(d) "CPU baseline timing"): the oracle built with the reference's flags (-O3 -ffast-math -fopenmp) on the
+    host cores of this box, as the reference runs on such a box: P processes x T threads (README.rst:121), each process pinned to a
+    group of cores of one socket with its data first-touched there.  Bounded sample: `sample` targets CONTIGUOUS IN MORTON ORDER
+    (the reference walks its particles in Peano-Hilbert order), cut into P contiguous shares; every process holds the tree of all
+    particles (so that the walk of its share is the reference's walk) and also times the tree of its own 1/P of the particles, the
+    tree a reference rank builds.  value = N / (tree of an own share + median walk time scaled from the sample to N); the PM part
+    (about 10 % of a reference step) is left out, which favours the CPU.  Round 2 ran ONE process over all cores with the arrays
+    first-touched by one thread: 12 % of the per-thread rate of the 8-thread calibration."""
+    import multiprocessing as mp
+    import tempfile
+    phys, logical, model = host_cpu_info()
+    groups = _numa_core_groups()
+    P = len(groups)
+    N = len(pos)
     old = np.sqrt((aold_vec ** 2).sum(1)) / G
     sample = min(sample, N)
-    # Morton order of the particles (10 bits per axis are enough to make consecutive targets neighbours)
-    q = np.minimum((pos / box * 1024).astype(np.int64), 1023)
+    q10 = np.minimum((pos / box * 1024).astype(np.int64), 1023)     # Morton order (10 bits per axis make consecutive targets neighbours)
 
     def spread(v):
         v = (v | (v << 16)) & 0x030000FF
         v = (v | (v << 8)) & 0x0300F00F
         v = (v | (v << 4)) & 0x030C30C3
         return (v | (v << 2)) & 0x09249249
-    morton = (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+    morton = (spread(q10[:, 0]) << 2) | (spread(q10[:, 1]) << 1) | spread(q10[:, 2])
     order = np.argsort(morton, kind="stable").astype(np.int32)
-    del q, morton
+    del q10, morton
     start = (N - sample) // 2
-    act = np.ascontiguousarray(order[start:start + sample])
-    tr.grav_short_tree(par, oldacc=old, active=act[:65536])   # warm-up
-    walks, pp = [], 0
-    for _ in range(3):
-        t0 = time.perf_counter()
-        _, _, c, _ = tr.grav_short_tree(par, oldacc=old, active=act)
-        walks.append(time.perf_counter() - t0)
-        pp = int(c[0])     # counters: (pair interactions, nodes visited, nodes used)
-    t_walk = float(np.median(walks))
-    t_full = t_tree + t_walk * N / sample
-    out = {"value": N / t_full, "unit": "particles/s", "cores": orc.num_threads(), "kind": "port",
-           "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "omp": "OMP_PROC_BIND=spread OMP_PLACES=cores",
-           "walk_s_median_of_3": round(t_walk, 3), "walk_s_all": [round(w, 3) for w in walks], "tree_build_s": round(t_tree, 3),
-           "sample": "oracle (gcc -O3 -ffast-math -fopenmp): tree build of all %d particles (%.2f s) + short-range walk of %d "
-                     "tree-ordered targets (median of 3: %.2f s, %d threads) scaled to N; PM excluded" % (N, t_tree, sample, t_walk, orc.num_threads())}
-    if pp:
-        out["pairs_per_s_per_thread"] = pp / t_walk / orc.num_threads()
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(shm, "mpg_cpu_baseline_%d.npz" % os.getpid())
+    np.savez(path, pos=pos, mass=mass, old=old, order=order)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = []
+    for r, cpus in enumerate(groups):
+        lo, hi = start + sample * r // P, start + sample * (r + 1) // P
+        procs.append(ctx.Process(target=_cpu_worker, args=(r, P, cpus, path, box, n, nmesh, lo, hi, q)))
+    t_all0 = time.perf_counter()
+    for p in procs:
+        p.start()
+    res, ready = {}, 0
+    try:
+        import queue as _queue
+        deadline = time.perf_counter() + 1800
+        while len(res) < P:
+            try:
+                m = q.get(timeout=5)
+            except _queue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs) or time.perf_counter() > deadline:
+                    raise RuntimeError("cpu_baseline: a worker process died (exit codes %s)" % [p.exitcode for p in procs])
+                continue
+            if m[0] == "done":
+                res[m[1]] = m[2:]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    t_total = time.perf_counter() - t_all0
+    walks = np.array([res[r][0] for r in range(P)])          # [P, 3] seconds
+    t_walk = float(np.median(walks.max(0)))                  # per repetition the slowest process; median over the three
+    pp = sum(res[r][1] for r in range(P))
+    threads = sum(res[r][4] for r in range(P))
+    t_tree_own = max(res[r][2] for r in range(P))
+    t_tree_full = max(res[r][3] for r in range(P))
+    t_full = t_tree_own + t_walk * N / sample
+    out = {"value": N / t_full, "unit": "particles/s", "cores": threads, "kind": "port", "processes": P,
+           "threads_per_process": [len(g) for g in groups], "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+           "omp": "per process: sched_setaffinity to its cores, OMP_PROC_BIND=close OMP_PLACES=cores", "walk_s_median_of_3": round(t_walk, 3),
+           "walk_s_all": [round(float(w), 3) for w in walks.max(0)], "tree_build_own_share_s": round(t_tree_own, 3),
+           "tree_build_all_particles_s": round(t_tree_full, 3), "wall_s": round(t_total, 1),
+           "pairs_per_s_per_thread": pp / t_walk / threads if pp else None,
+           "calibration_pairs_per_s_per_thread": 5.1e7,
+           "sample": "oracle (gcc -O3 -ffast-math -fopenmp), %d processes x %s threads pinned per socket: each builds the tree of all %d particles "
+                     "(%.2f s, set-up) and walks its share of %d Morton-ordered targets (median of 3 of the slowest process: %.2f s), scaled to N, "
+                     "plus the tree of an own 1/%d share (%.2f s); PM excluded" % (P, "/".join(str(len(g)) for g in groups[:2]) + ("/..." if P > 2 else ""),
+                                                                                      N, t_tree_full, sample, t_walk, P, t_tree_own)}
     return out
 
 

@@ -131,6 +131,37 @@ int mpg_dev_force_tree_active_moments(mpg_engine *eng, const int *d_active, int6
 int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
                         double (*AccelStore)[3], double rho0);
 
+/* ---- device-resident drop-in mode ------------------------------------------------------------------------------------------
+ * The host-pointer calls above upload Pos / Mass and download their results on every call, because the caller may have touched P[]
+ * in between (run.c:392-548 drifts, kicks and exchanges on the host).  A caller that lets the engine integrate as well
+ * (mpg_dev_drift_all_particles / mpg_dev_apply_pm_half_kick / mpg_dev_apply_half_kick, drift.c:18-102, timestep.c:873-1036, on the
+ * arrays of mpg_resident_arrays) declares its table RESIDENT: mpg_resident_begin uploads Pos, Mass, Type / flags, Vel,
+ * FullTreeGravAccel, GravPM and Potential once; from then on mpg_gravpm_force, mpg_force_tree_full / _rebuild_mask and
+ * mpg_grav_short_tree called with the same view run on the device copies and leave their results there (P[] on the host goes stale:
+ * AccelStore, when given, still receives its copy).  mpg_resident_fetch writes the named columns back into P[] for the host modules
+ * that read them, mpg_resident_push takes columns the host changed, mpg_resident_end fetches everything and leaves the mode.
+ * Anything that reorders or resizes P[] (domain_exchange, slots_gc) goes between _end and a new _begin. */
+#define MPG_FIELD_POS 1u
+#define MPG_FIELD_VEL 2u
+#define MPG_FIELD_ACCEL 4u     /* FullTreeGravAccel */
+#define MPG_FIELD_GRAVPM 8u
+#define MPG_FIELD_POTENTIAL 16u
+typedef struct mpg_resident_view {
+    int64_t n;
+    double *d_pos;            /* [n][3] */
+    float *d_mass;            /* [n] */
+    unsigned char *d_type;    /* [n] (7 = garbage / swallowed) */
+    double *d_vel;            /* [n][3] or NULL when the view had no Vel */
+    double *d_fulltree_accel; /* [n][3] */
+    double *d_gravpm;         /* [n][3] */
+    double *d_potential;      /* [n] */
+} mpg_resident_view;
+int mpg_resident_begin(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize);
+int mpg_resident_arrays(mpg_engine *eng, mpg_resident_view *out);
+int mpg_resident_fetch(mpg_engine *eng, const mpg_particle_view *pv, unsigned fields);
+int mpg_resident_push(mpg_engine *eng, const mpg_particle_view *pv, unsigned fields);
+int mpg_resident_end(mpg_engine *eng, const mpg_particle_view *pv);
+
 /* ---- device-resident entry points (inputs and outputs stay in HBM) ---------------------------- */
 /* Bind device arrays in the caller's particle order: pos[n][3] f64, mass[n] f32, type[n] u8 (NULL = all type 1).
  * The arrays must stay valid until the next bind. */
@@ -646,9 +677,11 @@ int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *pv, co
 /* density() / hydro_force() as drop-in calls on the same table (after mpg_dist_force_tree_full on it): A holds HOST arrays in particle
  * order, as for mpg_density / mpg_hydro_force (the shim gathers SphP[P[i].PI].X into them); inputs are read, outputs written.
  * ActiveParticle[NumActiveParticle]: host array of indices into P[] (NULL = all), see mpg_dist_dev_density_active */
-/* BlackHoleOn of density() (density.c:234, density_haswork :521-530): when set, the own black holes that are not swallowed are targets
- * of the following mpg_dist_(dev_)density calls next to the gas (Hsml, Density and DivVel of BHP); the smoothing lengths of both must
- * lie within the domain margin.  Swallowed black holes and garbage carry type 7 in d_type (the host form reads the flag bits). */
+/* BlackHoleOn of density() (density.c:234) for the following mpg_dist_(dev_)density calls.  The own black holes that are not swallowed
+ * are targets of the density loop next to the gas in any case (density_haswork, density.c:521-530: Hsml, Density and DivVel of BHP);
+ * BlackHoleOn gives them BlackHoleNgbFactor times the neighbours and caps their radius (density.c:598-600, 667-670).  The smoothing
+ * lengths of both must lie within the domain margin.  Swallowed black holes and garbage carry type 7 in d_type (the host form reads
+ * the flag bits). */
 int mpg_dist_set_sph_options(mpg_dist *d, int BlackHoleOn);
 /* the largest smoothing length over all ranks at the end of the last mpg_dist_(dev_)density loop.  When that call failed because it
  * exceeds the domain margin (the neighbours of such a particle are not all local), set the domain again with a margin above this

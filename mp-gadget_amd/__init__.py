@@ -6,9 +6,7 @@ or through the `mpgadget_amd()` helper of the repo-root conftest / bench.
 """
 from . import ics  # noqa: F401
 from . import engine  # noqa: F401
-from . import shard  # noqa: F401
-from . import pm_slab  # noqa: F401
-from . import domain  # noqa: F401
+from . import rows  # noqa: F401
 from . import domain_peano  # noqa: F401
 from . import dist  # noqa: F401
 from .engine import Engine, EngineError, PARTICLE_DTYPE, make_particles, SphTimes, KickFactors, DriftKickTimes  # noqa: F401

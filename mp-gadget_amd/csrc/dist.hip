@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) k_unpack_sph_mid(int64_t nr, const double
     curlvel[i] = r[5];
 }
 
-// density_haswork (density.c:521-530): gas, and with BlackHoleOn the black holes (swallowed ones carry type 7 here, like garbage)
+// density_haswork (density.c:521-530): gas and black holes (bh = 1; swallowed ones carry type 7 here, like garbage); hydro_haswork: gas
 struct IsOwnGas {
     const uint8_t *type;
     int bh;
@@ -1450,7 +1450,7 @@ int mpg_dist_dev_density_active(mpg_dist *d, int64_t n_own, const uint8_t *d_typ
     d->grav_tree_valid = false;
     MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, d->s_type.p, d->box) == 0, mpg_last_error());
     MPG_CHECK(mpg_dev_force_tree_rebuild_mask(e, 1, 0) == 0, mpg_last_error());
-    sph_targets(d, n_own, d_active, nactive, d->blackholes);
+    sph_targets(d, n_own, d_active, nactive, 1); // (black holes are density targets whatever BlackHoleOn says: density_haswork)
     if(d_active && n_own > 0) {
         // a sub-step: the inactive own particles keep the results of their last density loop, which the hydro loop of this sub-step
         // reads and their owners hand to the ghosts (the reference leaves SphP of inactive particles alone)
@@ -1492,7 +1492,7 @@ int mpg_dist_dev_density_active(mpg_dist *d, int64_t n_own, const uint8_t *d_typ
     d->scount.reserve(4);
     MPG_HIP(hipMemsetAsync(d->scount.p, 0, sizeof(unsigned long long), st));
     if(n_own > 0)
-        hipLaunchKernelGGL(k_max_gas_hsml, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d->s_type.p, d->s_in[0].p, d->blackholes, d->scount.p);
+        hipLaunchKernelGGL(k_max_gas_hsml, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d->s_type.p, d->s_in[0].p, 1, d->scount.p);
     unsigned long long hb = 0;
     MPG_HIP(hipMemcpyAsync(&hb, d->scount.p, sizeof(hb), hipMemcpyDeviceToHost, st));
     sync(d);

@@ -1155,6 +1155,11 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
     MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
     MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
     const int64_t n = P->n;
+    if(eng->resident && eng->res_base == P->base) { // resident mode: the table is the device's
+        MPG_CHECK(eng->res_n == n && eng->box == BoxSize && eng->d_pos == eng->s_pos.p,
+                  "resident mode: the particle table changed size, box or binding (mpg_resident_end / _begin around anything that reorders P[])");
+        return;
+    }
     // positions, masses and types of this very table are on the device already (mpg_set_particle_epoch)
     if(eng->host_epoch != 0 && eng->staged_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n &&
        eng->staged_box == BoxSize && eng->d_pos == eng->s_pos.p)
@@ -1226,6 +1231,11 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     MPG_CHECK(P->off_gravpm >= 0, "particle view needs GravPM");
     stage_particles(eng, P, eng->pm.box);
     const int64_t n = P->n;
+    if(eng->resident && eng->res_base == P->base) { // results stay in HBM: GravPM assigned, Potential accumulated (gravpm.c:499-501)
+        eng->pm.force(n, eng->d_pos, eng->d_mass, nullptr, eng->r_gravpm.p, eng->r_pot.p, eng->stream, &eng->timer);
+        mpg_err_slot().clear();
+        return 0;
+    }
     eng->s_gravpm.reserve(3 * (size_t)n + 1);
     const bool wantpot = P->off_potential >= 0;
     char *b = (char *)P->base;
@@ -1304,6 +1314,43 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     MPG_CHECK(P->n == eng->n, "grav_short_tree: particle table changed size since the tree was built");
     MPG_CHECK(P->off_accel >= 0 && P->off_gravpm >= 0, "particle view needs FullTreeGravAccel and GravPM");
     const int64_t n = P->n;
+    if(eng->resident && eng->res_base == P->base) {
+        // OldAcc from the resident FullTreeGravAccel + GravPM (grav_get_abs_accel, gravshort.h:70-80), results into the resident
+        // FullTreeGravAccel / Potential in place: a target's old value is read before its new one is written, and no walk reads
+        // another target's acceleration.  AccelStore (host) receives a copy when given (timestep.c:454-456).
+        const int *d_act = nullptr;
+        if(ActiveParticle) {
+            eng->s_active.reserve((size_t)NumActiveParticle + 1);
+            MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+            d_act = eng->s_active.p;
+        }
+        const bool full = eng->full_particle_tree;
+        double *out = eng->r_accel.p;
+        if(!full) { // (a tree of a subset: results go to AccelStore only, gravshort.h:54-66)
+            eng->s_accel.reserve(3 * (size_t)n + 1);
+            MPG_HIP(hipMemsetAsync(eng->s_accel.p, 0, 3 * n * sizeof(double), eng->stream));
+            out = eng->s_accel.p;
+        }
+        if(mpg_dev_grav_short_tree(eng, nullptr, eng->r_accel.p, eng->r_gravpm.p, d_act, NumActiveParticle, out, full ? eng->r_pot.p : nullptr, rho0))
+            throw Error(g_err);
+        if(AccelStore) {
+            eng->h_d2.reserve(3 * (size_t)n + 1);
+            double *ha = eng->h_d2.p;
+            MPG_HIP(hipMemcpyAsync(ha, out, 3 * n * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+            MPG_HIP(hipStreamSynchronize(eng->stream));
+            const int64_t m = ActiveParticle ? NumActiveParticle : n;
+            parallel_for(m, [=](int64_t lo, int64_t hi) {
+                for(int64_t k = lo; k < hi; k++) {
+                    const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+                    AccelStore[i][0] = ha[3 * i + 0];
+                    AccelStore[i][1] = ha[3 * i + 1];
+                    AccelStore[i][2] = ha[3 * i + 2];
+                }
+            });
+        }
+        mpg_err_slot().clear();
+        return 0;
+    }
     const char *b = (const char *)P->base;
     // fill: OldAcc = |FullTreeGravAccel + GravPM| / G (grav_short_copy, gravshort.h:82-86)
     eng->h_d3.reserve((size_t)n + 1);
@@ -1381,6 +1428,155 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                 put(ActiveParticle[k]);
         });
     }
+    API_END
+}
+
+/* ---- device-resident drop-in mode ------------------------------------------------------------------------------------------
+ * The host-pointer calls above move Pos / Mass up and GravPM / FullTreeGravAccel / Potential down on every call because the caller
+ * may have changed P[] in between: at 256^3 that is half of a step (bench.py host_path).  A caller that lets the engine integrate -
+ * mpg_dev_drift_all_particles, mpg_dev_apply_pm_half_kick, mpg_dev_apply_half_kick on the arrays of mpg_resident_arrays - declares
+ * the table resident: one upload, then gravpm_force / force_tree_* / grav_short_tree on the same mpg_particle_view run on the device
+ * copies and leave their results there; the host asks for the columns its other modules read (mpg_resident_fetch) and hands back
+ * what they changed (mpg_resident_push).  Anything that reorders or resizes P[] (domain exchange, garbage collection) goes between
+ * mpg_resident_end and a new mpg_resident_begin. */
+namespace {
+// one column of the AoS table <-> a device array of w doubles per particle
+void column_to_device(mpg_engine *eng, const mpg_particle_view &V, int64_t off, int w, double *dev)
+{
+    const int64_t n = V.n;
+    eng->h_d.reserve((size_t)w * n + 1);
+    double *h = eng->h_d.p;
+    const char *b = (const char *)V.base;
+    const int64_t stride = V.stride;
+    for(int c = 0; c < HOST_CHUNKS; c++) {
+        int64_t lo, hi;
+        chunk_range(n, c, lo, hi);
+        if(hi <= lo)
+            continue;
+        parallel_for(hi - lo, [=](int64_t a0, int64_t a1) {
+            for(int64_t i = lo + a0; i < lo + a1; i++)
+                for(int k = 0; k < w; k++)
+                    h[w * i + k] = ((const double *)(b + i * stride + off))[k];
+        });
+        MPG_HIP(hipMemcpyAsync(dev + w * lo, h + w * lo, (size_t)w * (hi - lo) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    }
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+}
+
+void column_to_host(mpg_engine *eng, const mpg_particle_view &V, int64_t off, int w, const double *dev)
+{
+    const int64_t n = V.n;
+    eng->h_d.reserve((size_t)w * n + 1);
+    double *h = eng->h_d.p;
+    char *b = (char *)V.base;
+    const int64_t stride = V.stride;
+    hipStream_t st = eng->stream;
+    download_chunks(
+        eng, n, [=](int64_t lo, int64_t hi) { MPG_HIP(hipMemcpyAsync(h + w * lo, dev + w * lo, (size_t)w * (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, st)); },
+        [=](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++)
+                for(int k = 0; k < w; k++)
+                    ((double *)(b + i * stride + off))[k] = h[w * i + k];
+        });
+}
+
+void resident_check(mpg_engine *eng, const mpg_particle_view *P)
+{
+    MPG_CHECK(eng && P, "null argument");
+    MPG_CHECK(eng->resident && eng->res_base == P->base && eng->res_n == P->n, "not the resident particle table (mpg_resident_begin first)");
+    MPG_HIP(hipSetDevice(eng->device));
+}
+} // namespace
+
+int mpg_resident_begin(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    MPG_CHECK(P->off_accel >= 0 && P->off_gravpm >= 0 && P->off_potential >= 0, "resident mode needs FullTreeGravAccel, GravPM and Potential in the view");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->resident = false;
+    eng->staged_epoch = -1; // (force the upload whatever epoch the caller declared)
+    stage_particles(eng, P, BoxSize);
+    const size_t n = (size_t)P->n;
+    eng->r_accel.reserve(3 * n + 3);
+    eng->r_gravpm.reserve(3 * n + 3);
+    eng->r_pot.reserve(n + 1);
+    column_to_device(eng, *P, P->off_accel, 3, eng->r_accel.p);
+    column_to_device(eng, *P, P->off_gravpm, 3, eng->r_gravpm.p);
+    column_to_device(eng, *P, P->off_potential, 1, eng->r_pot.p);
+    if(P->off_vel >= 0) {
+        eng->r_vel.reserve(3 * n + 3);
+        column_to_device(eng, *P, P->off_vel, 3, eng->r_vel.p);
+    }
+    eng->resident = true;
+    eng->res_base = P->base;
+    eng->res_n = P->n;
+    API_END
+}
+
+int mpg_resident_arrays(mpg_engine *eng, mpg_resident_view *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && out && eng->resident, "mpg_resident_arrays: no resident table");
+    out->n = eng->res_n;
+    out->d_pos = eng->s_pos.p;
+    out->d_mass = eng->s_mass.p;
+    out->d_type = eng->s_type.p;
+    out->d_vel = eng->r_vel.p;
+    out->d_fulltree_accel = eng->r_accel.p;
+    out->d_gravpm = eng->r_gravpm.p;
+    out->d_potential = eng->r_pot.p;
+    API_END
+}
+
+int mpg_resident_fetch(mpg_engine *eng, const mpg_particle_view *P, unsigned fields)
+{
+    API_BEGIN
+    resident_check(eng, P);
+    if(fields & MPG_FIELD_POS)
+        column_to_host(eng, *P, P->off_pos, 3, eng->s_pos.p);
+    if((fields & MPG_FIELD_VEL) && P->off_vel >= 0 && eng->r_vel.p)
+        column_to_host(eng, *P, P->off_vel, 3, eng->r_vel.p);
+    if(fields & MPG_FIELD_ACCEL)
+        column_to_host(eng, *P, P->off_accel, 3, eng->r_accel.p);
+    if(fields & MPG_FIELD_GRAVPM)
+        column_to_host(eng, *P, P->off_gravpm, 3, eng->r_gravpm.p);
+    if(fields & MPG_FIELD_POTENTIAL)
+        column_to_host(eng, *P, P->off_potential, 1, eng->r_pot.p);
+    API_END
+}
+
+int mpg_resident_push(mpg_engine *eng, const mpg_particle_view *P, unsigned fields)
+{
+    API_BEGIN
+    resident_check(eng, P);
+    if(fields & MPG_FIELD_POS) {
+        column_to_device(eng, *P, P->off_pos, 3, eng->s_pos.p);
+        eng->pm_queued = false;
+    }
+    if((fields & MPG_FIELD_VEL) && P->off_vel >= 0) {
+        eng->r_vel.reserve(3 * (size_t)P->n + 3);
+        column_to_device(eng, *P, P->off_vel, 3, eng->r_vel.p);
+    }
+    if(fields & MPG_FIELD_ACCEL)
+        column_to_device(eng, *P, P->off_accel, 3, eng->r_accel.p);
+    if(fields & MPG_FIELD_GRAVPM)
+        column_to_device(eng, *P, P->off_gravpm, 3, eng->r_gravpm.p);
+    if(fields & MPG_FIELD_POTENTIAL)
+        column_to_device(eng, *P, P->off_potential, 1, eng->r_pot.p);
+    API_END
+}
+
+int mpg_resident_end(mpg_engine *eng, const mpg_particle_view *P)
+{
+    API_BEGIN
+    resident_check(eng, P);
+    if(mpg_resident_fetch(eng, P, MPG_FIELD_POS | MPG_FIELD_VEL | MPG_FIELD_ACCEL | MPG_FIELD_GRAVPM | MPG_FIELD_POTENTIAL))
+        throw Error(g_err);
+    eng->resident = false;
+    eng->res_base = nullptr;
+    eng->res_n = -1;
+    eng->staged_epoch = -1;
     API_END
 }
 
@@ -1569,7 +1765,7 @@ int mpg_dev_density(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_time
     MPG_HIP(hipSetDevice(eng->device));
     const SphView v = make_sph_view(eng, A);
     eng->sph.density(eng->tree, v, *T, eng->denspar, 2.8 * eng->GravitySoftening, d_active, nactive, eng->n, update_hsml, DoEgyDensity,
-                     BlackHoleOn, eng->stream);
+                     BlackHoleOn, (eng->tree_mask & 32) != 0, eng->stream);
     API_END
 }
 

@@ -146,6 +146,12 @@ struct mpg_engine {
     // host path: what is staged (mpg_set_particle_epoch) and the events of the chunked downloads
     int64_t host_epoch = 0, staged_epoch = 0, staged_n = -1;
     const void *staged_base = nullptr;
+    // device-resident drop-in mode (mpg_resident_begin): the table at res_base lives in s_pos / s_mass / s_type and r_*; the host calls on
+    // that table move no particle data
+    bool resident = false;
+    const void *res_base = nullptr;
+    int64_t res_n = -1;
+    DevBuf<double> r_vel, r_accel, r_gravpm, r_pot;
     double staged_box = 0;
     hipEvent_t chunk_ev[8] = {};
 };

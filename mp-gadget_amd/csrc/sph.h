@@ -58,7 +58,8 @@ struct SphEngine {
     const uint8_t *mark_active(const int *d_active, int64_t nactive, int64_t n, hipStream_t st);
     // density(), density.c:234-355
     void density(TreeBuilder &tree, const SphView &A, const mpg_sph_times &T, const mpg_density_params &P, double force_softening,
-                 const int *d_active, int64_t nactive, int64_t n, int update_hsml, int DoEgyDensity, int BlackHoleOn, hipStream_t st);
+                 const int *d_active, int64_t nactive, int64_t n, int update_hsml, int DoEgyDensity, int BlackHoleOn, bool bh_in_tree,
+                 hipStream_t st);
     // set_init_hsml(), density.c:691-749
     void set_init_hsml(TreeBuilder &tree, const SphView &A, const mpg_density_params &P, double MeanGasSeparation, hipStream_t st);
     // the hmax half of force_tree_calc_moments after density (run.c:477)

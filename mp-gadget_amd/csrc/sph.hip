@@ -511,6 +511,30 @@ __global__ void __launch_bounds__(256) k_queue_treeorder(int64_t npart, const in
         queue[basepos + __popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
+// The black holes are targets of the density loop (density_haswork, density.c:521-530) but no neighbours: the search takes gas only
+// (density.c:438).  When the tree was built for gas alone (run.c:466 builds GASMASK | BHMASK only to reuse the tree for the mergers)
+// they are not among its particles, so they are appended to the queue from the particle table.  Type 7 = garbage / swallowed.
+__global__ void __launch_bounds__(256) k_queue_blackholes(int64_t n, const uint8_t *__restrict__ flags, const SphView A, const DensityCtl C, double box,
+                                                          int *__restrict__ queue, unsigned *__restrict__ nqueue)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool work = i < n && (!flags || flags[i]) && A.type && (A.type[i] & 7) == 5;
+    if(work) {
+        C.Right[i] = box;
+        C.NumNgb[i] = 0;
+        C.Left[i] = 0;
+    }
+    const unsigned long long m = ballot64(work);
+    unsigned basepos = 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    if(work && lane == leader)
+        basepos = atomicAdd(nqueue, (unsigned)__popcll(m));
+    basepos = __shfl(basepos, leader < 0 ? 0 : leader);
+    if(work)
+        queue[basepos + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+}
+
 // hsml of the gas particles of the tree in tree order (negative: does not contribute), for force_tree hmax
 __global__ void __launch_bounds__(256) k_hsml_treeorder(int64_t npart, const int *__restrict__ order, const SphView A, double *__restrict__ out)
 {
@@ -846,7 +870,8 @@ double sph_desnumngb(const mpg_density_params &P)
 }
 
 void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times &T, const mpg_density_params &P, double force_softening,
-                        const int *d_active, int64_t nactive, int64_t n, int update_hsml, int DoEgyDensity, int BlackHoleOn, hipStream_t st)
+                        const int *d_active, int64_t nactive, int64_t n, int update_hsml, int DoEgyDensity, int BlackHoleOn, bool bh_in_tree,
+                        hipStream_t st)
 {
     tree.ensure_level_order(st); // the cooperative walk uses the level-ordered copy of the tree
     const TreeView tv = tree.view();
@@ -856,8 +881,11 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
     right.reserve(n + 1);
     numngb.reserve(n + 1);
     entvarpred.reserve(n + 1);
-    queue_a.reserve(tv.npart + 1);
-    queue_b.reserve(tv.npart + 1);
+    // (targets: the gas of the tree, and the black holes, which a gas-only tree does not hold; BlackHoleOn only changes their
+    // neighbour number and caps their radius, density.c:598-600, 667-670)
+    const int64_t qcap = !bh_in_tree ? tv.npart + n : tv.npart;
+    queue_a.reserve(qcap + 1);
+    queue_b.reserve(qcap + 1);
     aux.reserve(tv.npart + 1);
     ctr.reserve(8);
     stats.reserve(8);
@@ -880,6 +908,8 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
     if(tv.npart > 0 && nact > 0)
         hipLaunchKernelGGL(k_queue_treeorder<true>, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, flags, A, C, tv.box, false,
                            queue_a.p, ctr.p);
+    if(!bh_in_tree && A.type && n > 0 && nact > 0)
+        hipLaunchKernelGGL(k_queue_blackholes, dim3(nblk(n)), dim3(256), 0, st, n, flags, A, C, tv.box, queue_a.p, ctr.p);
     unsigned nq = 0;
     MPG_HIP(hipMemcpyAsync(&nq, ctr.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipStreamSynchronize(st));

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import engine as E
-from . import pm_slab
+from . import rows
 
 
 class TopNode(C.Structure):
@@ -251,8 +251,8 @@ class PeanoDomain:
         assert sum(counts) == nlive
         if self.world == 1:
             return [c[order] for c in columns]
-        allc = pm_slab.count_matrix(counts, self.world, columns[0].device if dist.get_backend(self.group) == "nccl" else torch.device("cpu"), self.group)
-        return [pm_slab.exchange_rows(c[order].contiguous(), counts, self.world, self.group, allc) for c in columns]
+        allc = rows.count_matrix(counts, self.world, columns[0].device if dist.get_backend(self.group) == "nccl" else torch.device("cpu"), self.group)
+        return [rows.exchange_rows(c[order].contiguous(), counts, self.world, self.group, allc) for c in columns]
 
     def peano_order(self, pos, type=None):
         """The last step of domain_decompose_full (slots_gc_sorted, domain.c:238-241, slotsmanager.c:404-452): the permutation that

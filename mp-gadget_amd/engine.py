@@ -345,6 +345,34 @@ class Engine:
         self.lib.mpg_particle_view_reference_layout(C.byref(v), C.c_void_p(P.ctypes.data), C.c_int64(len(P)))
         return v
 
+    # device-resident drop-in mode (include/mpgadget_hip.h): the table P lives in HBM between mpg_resident_begin and _end; the host
+    # calls gravpm_force / force_tree_* / grav_short_tree on it move no particle data
+    FIELD_POS, FIELD_VEL, FIELD_ACCEL, FIELD_GRAVPM, FIELD_POTENTIAL = 1, 2, 4, 8, 16
+
+    def resident_begin(self, P, BoxSize):
+        v = self._view(P)
+        self._ck(self.lib.mpg_resident_begin(self.h, C.byref(v), C.c_double(BoxSize)))
+
+    def resident_fetch(self, P, fields):
+        v = self._view(P)
+        self._ck(self.lib.mpg_resident_fetch(self.h, C.byref(v), C.c_uint(fields)))
+
+    def resident_push(self, P, fields):
+        v = self._view(P)
+        self._ck(self.lib.mpg_resident_push(self.h, C.byref(v), C.c_uint(fields)))
+
+    def resident_end(self, P):
+        v = self._view(P)
+        self._ck(self.lib.mpg_resident_end(self.h, C.byref(v)))
+
+    def resident_arrays(self):
+        """device pointers of the resident columns (dict of ints; 0 = absent) and n"""
+        class RV(C.Structure):
+            _fields_ = [("n", C.c_int64)] + [(k, C.c_void_p) for k in ("d_pos", "d_mass", "d_type", "d_vel", "d_fulltree_accel", "d_gravpm", "d_potential")]
+        r = RV()
+        self._ck(self.lib.mpg_resident_arrays(self.h, C.byref(r)))
+        return {k: (getattr(r, k) or 0) for k, _ in RV._fields_}
+
     def gravpm_force(self, P):
         v = self._view(P)
         self._ck(self.lib.mpg_gravpm_force(self.h, C.byref(v)))

@@ -34,13 +34,13 @@
 /* the largest smoothing length of the density loop's targets on this rank: the ghosts must cover it (mpg_shim_sync takes the
  * maximum over the ranks).  The loop may still grow Hsml beyond the margin chosen from it (void gas): density() then repeats
  * the call with the margin the library reports (mpg_dist_last_max_hsml). */
-static double max_target_hsml(int BlackHoleOn)
+static double max_target_hsml(void)
 {
     double h = 0;
     int64_t i;
     #pragma omp parallel for reduction(max : h)
     for(i = 0; i < PartManager->NumPart; i++)
-        if(!P[i].IsGarbage && !P[i].Swallowed && (P[i].Type == 0 || (BlackHoleOn && P[i].Type == 5)) && P[i].Hsml > h)
+        if(!P[i].IsGarbage && !P[i].Swallowed && (P[i].Type == 0 || P[i].Type == 5) && P[i].Hsml > h)
             h = P[i].Hsml;
     return h;
 }
@@ -175,7 +175,7 @@ void density(const ActiveParticles *act, int update_hsml, int DoEgyDensity, int 
     walltime_measure("/Misc");
     /* density() is the FIRST force call of a step (run.c:472, and of the start-up: init.c): the table may just have been drifted
      * and exchanged, the decomposition rewritten */
-    mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, mpg_shim_dist() ? 1.26 * max_target_hsml(BlackHoleOn) : 0);
+    mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, mpg_shim_dist() ? 1.26 * max_target_hsml() : 0);
     mpg_particle_view v = view();
     gather(&H);
     fill_times(&t, &times, CP, 0);

@@ -619,7 +619,9 @@ static int run_sph(const char *in_path, const char *expect_path, int64_t N, doub
     for(int64_t i = 0; i < N; i++) {
         const int ty = (int)in[i].Type;
         const double *r = R + 6 * i, *x = expect + 6 * i;
-        if(ty == 0 || (bh && ty == 5)) {
+        if(ty == 5)
+            nbh++;
+        if(ty == 0 || ty == 5) { /* (black holes are density targets whatever BlackHoleOn says: density_haswork) */
             const double dh = fabs(r[0] / x[0] - 1);
             if(dh > 1e-12) { /* a target within an ulp of the NumNgb window's edge may take one iteration more or fewer (tests/test_gpu_sph.py) */
                 nloose++;
@@ -639,9 +641,7 @@ static int run_sph(const char *in_path, const char *expect_path, int64_t N, doub
             ee = fmax(ee, fabs(r[5] - x[5]));
             ne = fmax(ne, fabs(x[5]));
         }
-        else if(ty == 5)
-            nbh++;
-        else if(r[1] != 0 || r[2] != 0 || r[5] != 0)
+        else if(ty != 5 && (r[1] != 0 || r[2] != 0 || r[5] != 0))
             eh = 1;
     }
     printf("sph %d rank(s): gas %lld bh %lld loose-Hsml %lld  Hsml-out-of-bound %.2e  Density %.2e  HydroAccel %.2e  DtEntropy %.2e\n", nt,

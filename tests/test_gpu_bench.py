@@ -30,21 +30,52 @@ def test_default_workload_line():
     assert "workload" in j["config"] and "s_zel" in j["config"]["workload"]          # the headline set of SURVEY 8(d)
     r = j["roofline"]
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert j["cpu_baseline"]["physical_cores"] >= 1 and len(j["cpu_baseline"]["walk_s_all"]) == 3 and j["cpu_baseline"]["cpu_model"]
+    cb = j["cpu_baseline"]
+    assert cb["physical_cores"] >= 1 and len(cb["walk_s_all"]) == 3 and cb["cpu_model"] and cb["processes"] >= 1
+    assert cb["cores"] == sum(cb["threads_per_process"]) and cb["pairs_per_s_per_thread"] > 1e6 and cb["tree_build_own_share_s"] >= 0
     assert set(j["other_inputs"]) == {"s_grid", "s_clust"} and all(v["ms_per_step"] > 0 for v in j["other_inputs"].values())
     assert j["host_path"]["ms_per_step"] > 0 and set(j["host_path"]["calls_ms"]) == {"gravpm_force", "force_tree_full", "grav_short_tree"}
+    # the device-resident drop-in mode: the same calls without per-call transfers, and the same physics
+    rp = j["resident_path"]
+    assert 0 < rp["ms_per_step"] < j["host_path"]["ms_per_step"] and rp["mean_abs_accel"] > 0
+    # SURVEY 8(d) metric (ii): the short-range-only sub-steps, on the tree of all particles and on the tree of the active ones
+    assert set(j["substeps"]) == {"1/8", "1/64", "1/512"}
+    for v in j["substeps"].values():
+        assert v["all_particle_tree"]["ms_per_substep"] > 0 and v["active_only_tree"]["ms_per_substep"] > 0 and v["active"] >= 1
+    # BASELINE configs[2] in the default line, graded against the fp64 vector peak
+    h = j["hydro"]
+    assert h["ms_per_step"] > 0 and h["roofline"]["bound"] == "fp64_valu" and 0 < h["roofline"]["frac"] <= 1 and 0 < h["roofline_hydro"]["frac"] <= 1
 
 
-@pytest.mark.parametrize("mode", ["peano", "domain", "slab", "replicated"])
-def test_multi_gpu_paths_in_a_one_rank_group(mode):
-    j = run_bench(["--gpus", "1", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--mgpu", mode],
-                  env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29%03d" % (hash(mode) % 900 + 50)})
+def test_multi_gpu_path_in_a_one_rank_group_checks_itself():
+    """bench.py --gpus N runs the library's choreography and then checks its own forces: sampled particles recomputed on one GPU from
+    the whole set (parity_check in the line; a failed check exits non-zero)."""
+    j = run_bench(["--gpus", "1", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                  env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29171"})
     assert KEYS <= set(j) and j["value"] > 1e6
+    pc = j["parity_check"]
+    assert pc["ok"] and pc["counters_equal"] and pc["n"] >= 1024 and pc["median_rel"] <= 1e-12 and pc["gravpm_max_rel_to_mean"] <= 1e-11
+
+
+def test_multi_gpu_parity_check_on_four_ranks():
+    """... and on 4 ranks (gloo, sharing this GPU), clustered set, after the rebalancing exchange: the self-check the driver's 8-GPU
+    run carries (BASELINE configs[4]: "per-step force tolerance check")."""
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port",
+           "29874", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "48", "--ic", "s_clust", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    pc = j["parity_check"]
+    assert pc["ok"] and pc["counters_equal"] and pc["n"] >= 2000, pc
 
 
 def test_other_workloads():
     h = run_bench(["--workload", "hydro", "--size", "32", "--steps", "1", "--warmup", "0"])
-    assert KEYS <= set(h) and "roofline_hydro" in h
+    assert KEYS <= set(h) and "roofline_hydro" in h and h["roofline"]["bound"] == "fp64_valu"
+    sb = run_bench(["--workload", "substep", "--size", "64", "--steps", "2", "--active-frac", "0.125"])
+    assert KEYS <= set(sb) and sb["config"]["active"] == 64 ** 3 // 8 and sb["value"] > 0
     i = run_bench(["--workload", "integrate", "--size", "64", "--steps", "2", "--warmup", "1"])
     assert KEYS <= set(i) and i["roofline"]["frac"] > 0.05
     f = run_bench(["--workload", "fof", "--size", "64", "--steps", "1", "--warmup", "0"])
@@ -60,7 +91,7 @@ def test_c4_shape_through_rccl_at_full_per_gpu_size(ic):
     """BASELINE configs[3] (512^3 on 8 GPUs) as ONE rank sees it: 256^3 own particles, the distributed choreography of mpg_dist_*
     with every collective issued through RCCL (a one-rank group: MPG_FORCE_MGPU) on device buffers - the decomposition, the particle
     shipping of the PM, the transposes, the ghost import and the all-reduce of the top of the tree at their full per-GPU sizes."""
-    j = run_bench(["--gpus", "1", "--size", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--mgpu", "peano", "--ic", ic],
+    j = run_bench(["--gpus", "1", "--size", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ic", ic],
                   env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29871"})
     assert KEYS <= set(j) and j["value"] > 2e7 and j["config"]["particles"] == 256 ** 3
     assert j["roofline"]["pp_interactions_per_launch"] > 0 and j["phases_ms"]["dist_transpose_bytes"] > 2 * 512 ** 3 * 8
@@ -78,14 +109,14 @@ def test_c5_shape_through_rccl_at_full_per_gpu_size():
 
 def test_peano_domains_balance_the_walk_work_on_the_clustered_set():
     """4 ranks (gloo, sharing this GPU) on the strongly clustered set: the TopLeaves dealt out by the measured work per particle
-    (domain.c:611) even out the walk's work; equal-volume x-slabs (round 1's domains) and equal particle numbers do not."""
+    (domain.c:611) even out the walk's work; equal particle numbers do not."""
     env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port",
            "29873", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "64", "--ic", "s_clust", "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline", "--mgpu", "peano", "--overdecomp", "32"]
+           "--no-cpu-baseline", "--overdecomp", "32", "--no-parity-check"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     lb = j["config"]["load_balance"]
     assert lb["walk_work_max_over_mean"] < 1.15, lb
-    assert lb["x_slab_domains_walk_work_max_over_mean"] > 1.5 * lb["walk_work_max_over_mean"], lb
+    assert lb["by_particle_number"]["walk_work_max_over_mean"] > 1.3 * lb["walk_work_max_over_mean"], lb

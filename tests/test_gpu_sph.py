@@ -400,22 +400,3 @@ def _run_hydro(tmp_path, name, nproc, mode, port, host=False, every=0):
                "--master-port", str(port), script, out, "24"]
     run_ranks(cmd, env, out)
     return np.load(out)
-
-
-@keep_artifacts_on_failure
-def test_sph_ranks_match_one(tmp_path):
-    """SPH loops with the particles distributed over ranks (x-slab domains, ghosts within Rcut, the ghosts' SPH fields refreshed
-    from their owners between density and hydro): the same results as one GPU.  The local gas trees differ from the global
-    one, so the sums run in a different order: the usual SPH parity bounds apply."""
-    one = _run_hydro(tmp_path, "one.npz", 1, "single", 0)
-    gas = one["typ"] == 0
-    for name, nproc, port in (("d1.npz", 1, 0), ("d2.npz", 2, 29590), ("d4.npz", 4, 29591)):
-        d = _run_hydro(tmp_path, name, nproc, "domain", port)
-        same = assert_hsml_parity(d["hsml"][gas], one["hsml"][gas], 113.1)      # quintic spline, eta = 1: 4 pi/3 * 3^3
-        g = np.flatnonzero(gas)[same]
-        for k in ("density", "divvel", "curlvel", "dhsmlegyfac", "hydroacc_out", "dtentropy_out"):
-            r = rel(d[k][g], one[k][g])
-            if r > 1e-9:                                          # (say where: a rare failure has to be diagnosable from the log)
-                w = np.unravel_index(np.abs(d[k][g] - one[k][g]).argmax(), d[k][g].shape)
-                raise AssertionError((name, k, r, int(g[w[0]]), d[k][g][w], one[k][g][w], d["hsml"][g[w[0]]], one["hsml"][g[w[0]]]))
-        assert rel(d["maxsignalvel"][g], one["maxsignalvel"][g]) <= 1e-12, name

@@ -135,10 +135,9 @@ def test_distributed_evolution_matches_one_gpu(tmp_path):
         return np.load(out)
 
     one = run("one.npy", 1, "single", 0)
-    # x-slab domains driven from Python (round 1), then the library's own choreography on the Peano-Hilbert domains: decomposition,
-    # exchange, force, kicks, drift, domain_maintain + exchange (mpg_dist_*, csrc/dist.hip)
-    for name, nproc, port, mode in (("e2.npy", 2, 29595, "domain"), ("e4.npy", 4, 29596, "domain"), ("p1.npy", 1, 0, "peano"),
-                                    ("p2.npy", 2, 29597, "peano"), ("p4.npy", 4, 29598, "peano")):
+    # the library's own choreography on the Peano-Hilbert domains: decomposition, exchange, force, kicks, drift, domain_maintain +
+    # exchange (mpg_dist_*, csrc/dist.hip)
+    for name, nproc, port, mode in (("p1.npy", 1, 0, "peano"), ("p2.npy", 2, 29597, "peano"), ("p4.npy", 4, 29598, "peano")):
         d = run(name, nproc, mode, port)
         dp = np.abs(d[:, 0:3] - one[:, 0:3])
         dp = np.minimum(dp, np.abs(dp - np.abs(one[:, 0:3]).max()))       # (a particle sitting on the periodic seam)

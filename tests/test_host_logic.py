@@ -1,4 +1,4 @@
-"""Host-side logic that needs no GPU: synthetic IC generators and the target-sharding exchange (gloo, world_size 2)."""
+"""Host-side logic that needs no GPU: synthetic IC generators, the row exchange between ranks and the mpg_comm callbacks (gloo, world_size 2 - 4)."""
 import os
 import sys
 
@@ -49,139 +49,6 @@ def test_szel_and_sclust(pkg):
     assert q.shape == (512, 3) and q.min() >= 0 and q.max() <= b2
 
 
-def test_slot_ranges_partition(pkg):
-    for n in (0, 1, 7, 1000, 4097):
-        for w in (1, 2, 3, 8):
-            r = [pkg.shard.slot_range(n, k, w) for k in range(w)]
-            assert r[0][0] == 0 and r[-1][1] == n
-            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
-            assert max(h - l for l, h in r) <= pkg.shard.chunk_size(n, w)
-
-
-def _worker(rank, world, port, n, q):
-    sys.path.insert(0, ROOT)
-    import importlib
-    pkg = importlib.import_module("mp-gadget_amd")
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = torch.Generator().manual_seed(7)
-    order = torch.randperm(n, generator=g).to(torch.int32)          # same on every rank
-    truth = torch.randn(n, 3, dtype=torch.float64, generator=g)     # what a single rank would compute
-    lo, hi = pkg.shard.slot_range(n, rank, world)
-    vals = torch.full((n, 3), float("nan"), dtype=torch.float64)
-    mine = order[lo:hi].long()
-    vals[mine] = truth[mine]                                        # this rank "walked" only its own targets
-    pkg.shard.exchange_results(vals, order, rank, world)
-    q.put((rank, bool(torch.equal(vals, truth))))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("n", [1001, 64])
-def test_exchange_results_world2_gloo(n):
-    """N>1 path on CPU: two gloo ranks each own half of the tree-order slots; after the all-gather both hold the
-    single-rank answer bit for bit."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
-
-
-def _slab_worker(rank, world, port, q):
-    """Collectives and index logic of the slab-decomposed PM on CPU tensors (gloo): the all-to-all transpose of a toy
-    [x][y] array, the ring pass of ghost planes, slab ownership of particles and the per-target all-gather."""
-    sys.path.insert(0, ROOT)
-    import importlib
-    pkg = importlib.import_module("mp-gadget_amd")
-    S = pkg.pm_slab
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    ok = True
-    # transpose: rank r holds rows x in [r P, (r+1) P) of A[x][y]; after the all-to-all it holds columns y in its range, x slowest
-    M, P = 8, 8 // world
-    A = torch.arange(M * M, dtype=torch.float64).reshape(M, M)
-    mine = A[rank * P:(rank + 1) * P]                                    # [P][M]
-    send = torch.stack([mine[:, d * P:(d + 1) * P] for d in range(world)]).contiguous()   # [d][xl][yl]
-    recv = torch.empty_like(send)
-    S._all_to_all(recv.view(-1), send.view(-1), world)
-    ok &= bool(torch.equal(recv.reshape(M, P), A[:, rank * P:(rank + 1) * P]))
-    # the same through the piecewise path (calls above A2A_MAX_ELEMENTS elements are split: RCCL fails above 1 GiB)
-    keep, S.A2A_MAX_ELEMENTS = S.A2A_MAX_ELEMENTS, 5 * world
-    recv2 = torch.full_like(send, -1.0)
-    S._all_to_all(recv2.view(-1), send.view(-1), world)
-    S.A2A_MAX_ELEMENTS = keep
-    ok &= bool(torch.equal(recv2, recv))
-    # ghost planes of the potential: first 3 planes to the previous rank, last 2 to the next (the same rank when world == 2)
-    class _E:   # the exchange only needs the buffers
-        pass
-    spm = S.SlabPM.__new__(S.SlabPM)
-    spm.world, spm.rank, spm.group = world, rank, None
-    spm.ghost_send = torch.stack([torch.full((6,), 10.0 * rank + k, dtype=torch.float64) for k in range(5)])
-    spm.ghost_recv = torch.zeros_like(spm.ghost_send)
-    spm._ghost_planes()
-    nxt, prv = (rank + 1) % world, (rank - 1) % world
-    exp = [10.0 * nxt + 0, 10.0 * nxt + 1, 10.0 * nxt + 2, 10.0 * prv + 3, 10.0 * prv + 4]
-    ok &= bool(torch.equal(spm.ghost_recv[:, 0], torch.tensor(exp, dtype=torch.float64)))
-    # slab ownership incl. x == box (wraps to cell 0) and the per-target exchange
-    nmesh, box = 16, 4.0
-    gen = torch.Generator().manual_seed(3)
-    n = 1000
-    pos = torch.rand(n, 3, dtype=torch.float64, generator=gen) * box
-    pos[0, 0] = box
-    owner = S.slab_of_cells(pos[:, 0], box / nmesh, nmesh, world)
-    ok &= int(owner[0]) == 0 and int(owner.min()) >= 0 and int(owner.max()) < world
-    order = torch.randperm(n, generator=gen).to(torch.int32)
-    tg = order[owner[order.long()] == rank].contiguous()
-    truth = torch.randn(n, 3, dtype=torch.float64, generator=gen)
-    vals = torch.full((n, 3), float("nan"), dtype=torch.float64)
-    vals[tg.long()] = truth[tg.long()]
-    S.TargetExchange(world, torch.device("cpu")).exchange(vals, tg)
-    ok &= bool(torch.equal(vals, truth))
-    q.put((rank, ok))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_slab_pm_collectives_world2_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_slab_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
-
-
-def test_tree_columns_and_needed_sets(pkg):
-    """Index logic of the distributed-particle mode: tree_column replays the octree descent (root cell 1.001 Box around Box/2);
-    every rank's needed columns cover its slab widened by the margin, periodically."""
-    D = pkg.domain
-    box, La = 8.0, 3
-    x = torch.tensor([1e-9, 0.9959, 0.9961, 3.999, 4.001, 7.99, 8.0], dtype=torch.float64)
-    w, lo = 1.001 * box / 8, box / 2 - 0.5 * 1.001 * box
-    ref = torch.floor((x - lo) / w).to(torch.int64)
-    assert torch.equal(D.tree_column(x, box, La), ref)
-    need = D.needed_columns(box, 64, 4, La, margin=0.7)
-    assert need.shape == (4, 8)
-    for s in range(4):
-        for xx in np.linspace(s * 2.0 - 0.7, (s + 1) * 2.0 + 0.7, 50):
-            xx = float(np.mod(xx, box))
-            assert bool(need[s, int(np.floor((xx - lo) / w))]), (s, xx)
-    assert bool(need[0, 7]) and bool(need[3, 0])            # periodic neighbours across the box edge
-    assert not bool(need[0, 3]) and not bool(need[2, 0])
-
-
 def _domain_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import importlib
@@ -195,69 +62,19 @@ def _domain_worker(rank, world, port, q):
         c = 0 if d == rank else d + 1 + rank
         counts.append(c)
         rows.append(torch.full((c, 4), float(10 * rank + d), dtype=torch.float64))
-    got = pkg.pm_slab.exchange_rows(torch.cat(rows), counts, world)
+    got = pkg.rows.exchange_rows(torch.cat(rows), counts, world)
     exp = torch.cat([torch.full((0 if s == rank else rank + 1 + s, 4), float(10 * s + rank), dtype=torch.float64) for s in range(world)])
     q.put((rank, bool(torch.equal(got, exp))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ghost_exchange_world2_gloo():
+def test_row_exchange_world2_gloo():
+    """rows.exchange_rows (the MPI_Alltoallv of exchange.c as domain_peano.PeanoDomain.exchange issues it): uneven counts, gloo"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_domain_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
-
-
-def _migrate_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    import importlib
-    pkg = importlib.import_module("mp-gadget_amd")
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    box, nmesh = 8.0, 32
-    dom = pkg.domain.SlabDomain(None, box, nmesh, rank, world, torch.device("cpu"), rcut=1.0)
-    g = torch.Generator().manual_seed(11)
-    pos = torch.rand(3000, 3, dtype=torch.float64, generator=g) * box      # the same global set on every rank
-    ids = torch.arange(3000, dtype=torch.float64)
-    # 64-bit IDs as the reference's stars / black holes carry them: Generation in bits 56+ (not representable in a double),
-    # one byte-wide and one float32 column as well: every column must arrive bit for bit
-    big = (torch.arange(3000, dtype=torch.int64) * 2654435761 + 12345) | (torch.arange(3000, dtype=torch.int64) % 5 + 1 << 56) | 1
-    typ8 = (torch.arange(3000) % 6).to(torch.uint8)
-    m32 = torch.rand(3000, dtype=torch.float32, generator=g)
-    own = dom.select_own(pos)
-    p, i = pos[own].clone(), ids[own].clone()
-    p[:, 0] = torch.remainder(p[:, 0] + 1.7, box)                          # a "drift" that carries many particles across slab faces
-    p2, i2, big2, typ2, m2 = dom.migrate(p, (i, big[own].clone(), typ8[own].clone(), m32[own].clone()))
-    assert big2.dtype == torch.int64 and typ2.dtype == torch.uint8 and m2.dtype == torch.float32
-    okb = bool(torch.equal(big2, big[i2.long()]) and torch.equal(typ2, typ8[i2.long()]) and torch.equal(m2, m32[i2.long()]))
-    owner = pkg.pm_slab.slab_of_cells(p2[:, 0], box / nmesh, nmesh, world)
-    ok = bool((owner == rank).all())
-    # global check: every id exactly once, carried with its own position
-    cnt = torch.zeros(3000, dtype=torch.float64)
-    cnt[i2.long()] += 1
-    dist.all_reduce(cnt)
-    ok &= bool((cnt == 1).all())
-    exp = pos[i2.long()].clone()
-    exp[:, 0] = torch.remainder(exp[:, 0] + 1.7, box)
-    ok &= bool(torch.equal(exp, p2)) and okb
-    q.put((rank, ok))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_particle_migration_world2_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 35500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_migrate_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -274,7 +91,7 @@ def test_sgrid_planes_equal_slices_of_the_full_set(pkg):
         assert box2 == box and np.array_equal(part, full[a * n * n:b * n * n]) and len(m) == len(part)
 
 
-def _comm_worker(rank, world, port, q):
+def _comm_worker(rank, world, port, q, scale=1):
     """The mpg_comm callbacks of the multi-rank library path (mp-gadget_amd/dist.py::TorchComm) on host buffers over gloo: called
     through the C function pointers exactly as csrc/dist.hip calls them."""
     sys.path.insert(0, ROOT)
@@ -302,18 +119,27 @@ def _comm_worker(rank, world, port, q):
     r = np.zeros(world, dtype=np.int64)
     ok &= c.alltoall_i64(None, i64(s), i64(r)) == 0
     ok &= bool(np.array_equal(r, [100 * src + rank for src in range(world)]))
-    # alltoallv of bytes: rank r sends (r + d + 1) bytes of value 16 r + d to rank d, packed
-    sb = np.array([rank + d + 1 for d in range(world)], dtype=np.int64)
-    sd = np.concatenate([[0], np.cumsum(sb)[:-1]]).astype(np.int64)
-    rb = np.array([src + rank + 1 for src in range(world)], dtype=np.int64)
-    rd = np.concatenate([[0], np.cumsum(rb)[:-1]]).astype(np.int64)
-    send = np.concatenate([np.full(sb[d], 16 * rank + d, np.uint8) for d in range(world)])
-    want = np.concatenate([np.full(rb[src], 16 * src + rank, np.uint8) for src in range(world)])
-    for piece in (None, 2):      # 2: the exchange cut into pieces of 2 bytes per peer (the path of calls above A2A_MAX_BYTES)
+    # alltoallv of bytes: rank r sends scale (r + d + 1) bytes of value 16 r + d to rank d; scale 1: packed blocks, scale > 1:
+    # blocks with gaps of 3 bytes between them on both sides (displacements that are not the running sums)
+    gap = 0 if scale == 1 else 3
+    sb = np.array([scale * (rank + d + 1) for d in range(world)], dtype=np.int64)
+    sd = (np.concatenate([[0], np.cumsum(sb)[:-1]]) + gap * np.arange(world)).astype(np.int64)
+    rb = np.array([scale * (src + rank + 1) for src in range(world)], dtype=np.int64)
+    rd = (np.concatenate([[0], np.cumsum(rb)[:-1]]) + gap * np.arange(world)).astype(np.int64)
+    send = np.full(int(sd[-1] + sb[-1]), 255, np.uint8)
+    want = np.zeros(int(rd[-1] + rb[-1]), np.uint8)
+    for d in range(world):
+        send[sd[d]:sd[d] + sb[d]] = 16 * rank + d
+    for src in range(world):
+        want[rd[src]:rd[src] + rb[src]] = 16 * src + rank
+    # piece 2: the exchange cut into pieces of 2 bytes per peer (the path of calls above A2A_MAX_BYTES; RCCL returned garbage beyond
+    # 1 GiB per call in round 1).  With scale 3 and 3 - 4 ranks the largest block has 15 - 21 bytes: 8 - 11 pieces, the number being
+    # decided by the largest block of ANY rank while most blocks end earlier (empty trailing pieces)
+    for piece in (None, 2):
         keep = D.A2A_MAX_BYTES
         if piece:
             D.A2A_MAX_BYTES = piece * world
-        recv = np.zeros(int(rb.sum()), np.uint8)
+        recv = np.zeros(len(want), np.uint8)
         ok &= c.alltoallv(None, send.ctypes.data, i64(sb), i64(sd), recv.ctypes.data, i64(rb), i64(rd), 0) == 0
         D.A2A_MAX_BYTES = keep
         ok &= bool(np.array_equal(recv, want))
@@ -343,3 +169,19 @@ def test_mpg_comm_callbacks_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_mpg_comm_piecewise_alltoallv_gloo(world):
+    """TorchComm's piece-splitting of a large exchange with an artificially small limit: 3 and 4 gloo ranks, unequal blocks with gaps,
+    8 - 11 pieces per exchange (the first real multi-GPU RCCL run takes this path for every exchange above 512 MiB)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q, 3)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]

@@ -1,5 +1,5 @@
 """RCCL all_to_all_single in a one-rank group against the identity, for a list of element counts (float64): found the large-block
-failure that mp-gadget_amd/pm_slab.py:_all_to_all works around.  usage: python tools/a2a_selftest.py [n ...]"""
+failure that mp-gadget_amd/dist.py::TorchComm works around (A2A_MAX_BYTES).  usage: python tools/a2a_selftest.py [n ...]"""
 import os, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29533")
 torch.cuda.set_device(0)

@@ -1,7 +1,6 @@
-import os
-"""Run one sharded TreePM force step under torch.distributed and save rank 0's accelerations (used by
-tests/test_gpu_gravity.py::test_two_ranks_match_one).  Launch with torch.distributed.run; MPG_DIST_BACKEND=gloo lets the
-ranks share one GPU."""
+"""Run one TreePM force step - on one GPU (mode "single") or with the particles on the owners of their Peano-Hilbert TopLeaves through the
+library's choreography (mode "peano", csrc/dist.hip) - and save the whole set's accelerations, GravPM and potential from rank 0 (used by
+tests/test_gpu_gravity.py).  Launch with torch.distributed.run; MPG_DIST_BACKEND=gloo lets the ranks share one GPU."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,24 +37,18 @@ eng.dev_bind_particles(d_pos, d_mass, box)
 gravpm = torch.zeros(N, 3, dtype=torch.float64, device=dev)
 acc = torch.zeros_like(gravpm)
 old = torch.full((N,), 1e-7, dtype=torch.float64, device=dev)
-mode = os.environ.get("MPG_MGPU_MODE", "slab")
+mode = os.environ.get("MPG_MGPU_MODE", "peano")
+assert mode in ("single", "peano", "peano1"), mode
 pot = torch.zeros(N, dtype=torch.float64, device=dev)
 every = int(os.environ.get("MPG_ACTIVE_EVERY", "0"))     # > 0: a sub-step - only the particles with index % every == 0 are walked
-if world == 1 and mode not in ("slab1", "domain1", "peano1"):
+if world == 1 and mode != "peano1":
     eng.dev_gravpm_force(gravpm, pot)
     eng.dev_force_tree_build()
     act = torch.arange(0, N, every, dtype=torch.int32, device=dev) if every else None
     if every and os.environ.get("MPG_ACTIVE_TREE"):      # hierarchical gravity: the tree holds the active particles only
         eng.dev_force_tree_active_moments(act)
     eng.dev_grav_short_tree(acc, oldacc=old, active=act)
-elif mode == "replicated":
-    eng.dev_gravpm_force(gravpm, pot)
-    eng.dev_force_tree_build()
-    lo, hi = pkg.shard.slot_range(N, rank, world)
-    optr = eng.dev_tree_order_ptr()
-    eng.dev_grav_short_tree(acc, oldacc=old, active=optr + 4 * lo, nactive=hi - lo)
-    pkg.shard.exchange_results(acc, eng.dev_tree_order(N, dev), rank, world)
-elif mode.startswith("peano"):
+else:
     # the library's own choreography (csrc/dist.hip): particles on their Peano-Hilbert owners (domain_decompose_full + exchange),
     # PM by shipping particles to the x-slabs, ghosts in whole level-La cells around the rank's TopLeaves, global top of the tree
     DP = pkg.domain_peano
@@ -96,53 +89,14 @@ elif mode.startswith("peano"):
     both = torch.zeros(N, 7, **f8)
     both[oids] = torch.cat([ga, gg, gp[:, None]], dim=1)
     if grouped:
-        pkg.pm_slab.TargetExchange(world, dev).exchange(both, oids.to(torch.int32))
+        pkg.rows.TargetExchange(world, dev).exchange(both, oids.to(torch.int32))
     acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
     if rank == 0:
         print("peano: %s own %d times %s" % (df.stats(), n_own, df.times()), flush=True)
     df.close()
-elif mode.startswith("domain"):
-    # particles distributed: own = x-slab particles, ghosts imported in whole tree-cell columns, global top of the tree
-    rcut = 6.0 * 1.5 * box / (2 * n)
-    dom = pkg.domain.SlabDomain(eng, box, 2 * n, rank, world, dev, rcut)
-    own = dom.select_own(d_pos)
-    n_own = own.shape[0]
-    lpos, lmass = dom.import_ghosts(d_pos[own].contiguous(), d_mass[own].contiguous())
-    nl = lpos.shape[0]
-    eng.dev_bind_particles(lpos, lmass, box)
-    eng.dev_force_tree_build()
-    dom.set_global_top(n_own)
-    spm = pkg.pm_slab.SlabPM(eng, box, 2 * n, rank, world, dev)
-    tg = dom.own_targets(n_own, nl)
-    f8 = dict(dtype=torch.float64, device=dev)
-    gl, al, pl = torch.zeros(nl, 3, **f8), torch.zeros(nl, 3, **f8), torch.zeros(nl, **f8)
-    spm.force(tg, gl, pl)
-    eng.dev_grav_short_tree(al, oldacc=torch.full((nl,), 1e-7, **f8), active=tg)
-    both = torch.zeros(N, 7, **f8)
-    both[own] = torch.cat([al[:n_own], gl[:n_own], pl[:n_own, None]], dim=1)
-    pkg.pm_slab.TargetExchange(world, dev).exchange(both, own.to(torch.int32))
-    acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
-    if rank == 0:
-        print("domain: La %d, own %d, local %d (ghost fraction %.2f)" % (dom.La, n_own, nl, nl / n_own - 1), flush=True)
-else:
-    # slab-decomposed PM; PM readout and walk targets = the particles of this rank's x-slab
-    eng.dev_force_tree_build()
-    spm = pkg.pm_slab.SlabPM(eng, box, 2 * n, rank, world, dev)
-    tg = spm.targets(d_pos, eng.dev_tree_order(N, dev))
-    spm.force(tg, gravpm, pot)
-    eng.dev_grav_short_tree(acc, oldacc=old, active=tg)
-    ex = pkg.pm_slab.TargetExchange(world, dev)
-    both = torch.cat([acc, gravpm, pot[:, None]], dim=1)
-    ex.exchange(both, tg)
-    acc, gravpm, pot = both[:, 0:3].contiguous(), both[:, 3:6].contiguous(), both[:, 6].contiguous()
 # the matter power spectrum measured on the way (gravpm.c:331-382): rows of (k, P, Nmodes)
 mpc = box / 1000.0
-if world == 1 and mode not in ("slab1", "domain1", "peano1") or mode == "replicated":
-    ps = eng.gravpm_get_powerspectrum(2 * n, mpc)
-elif mode.startswith("peano"):
-    ps = None
-else:
-    ps = spm.power_spectrum(mpc)
+ps = eng.gravpm_get_powerspectrum(2 * n, mpc) if (world == 1 and mode != "peano1") else None
 torch.cuda.synchronize()
 if rank == 0:
     if ps is not None:

@@ -79,47 +79,14 @@ elif mode == "peano":
     final[o_id] = torch.cat([o_pos, o_vel, o_acc], dim=1)
     cnt = torch.tensor([o_pos.shape[0], moved], dtype=torch.int64, device=dev)
     if grouped:
-        pkg.pm_slab.TargetExchange(world, dev).exchange(final, o_id.to(torch.int32))
+        pkg.rows.TargetExchange(world, dev).exchange(final, o_id.to(torch.int32))
         dist.all_reduce(cnt)
     assert int(cnt[0].item()) == N, "particles lost or duplicated in the exchange"
     if rank == 0:
         print("peano evolution: %d particles changed owner over 3 steps" % int(cnt[1].item()), flush=True)
     df.close()
 else:
-    dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut=6.0 * 1.5 * box / nmesh)
-    spm = pkg.pm_slab.SlabPM(eng, box, nmesh, rank, world, dev)
-    g_pos = T(pos)
-    own = dom.select_own(g_pos)
-    o_id = own.to(torch.float64)
-    o_pos, o_mass, o_vel = g_pos[own].contiguous(), T(mass)[own].contiguous(), T(vel)[own].contiguous()
-    o_acc = torch.zeros(own.shape[0], 3, **f8)
-    for step in range(3):
-        n_own = o_pos.shape[0]
-        lpos, lmass = dom.import_ghosts(o_pos, o_mass)
-        nl = lpos.shape[0]
-        eng.dev_bind_particles(lpos, lmass, box)
-        eng.dev_force_tree_build()
-        dom.set_global_top(n_own)
-        tg = dom.own_targets(n_own, nl)
-        gpm, acc, prev = torch.zeros(nl, 3, **f8), torch.zeros(nl, 3, **f8), torch.zeros(nl, 3, **f8)
-        prev[:n_own] = o_acc
-        spm.force(tg, gpm, None)
-        eng.dev_grav_short_tree(acc, prev_accel=prev, gravpm=gpm, active=tg)
-        o_acc = acc[:n_own].contiguous()
-        o_gpm = gpm[:n_own].contiguous()
-        eng.dev_apply_pm_half_kick(o_vel, o_gpm, dt)
-        eng.dev_apply_half_kick(o_vel, o_acc, K)
-        eng.dev_drift_all_particles(o_pos, o_vel, dt, box)
-        eng.synchronize()
-        o_pos, o_mass, o_vel, o_acc, o_id = dom.migrate(o_pos, (o_mass, o_vel, o_acc, o_id))
-    final = torch.zeros(N, 9, **f8)
-    ids = o_id.long()
-    final[ids] = torch.cat([o_pos, o_vel, o_acc], dim=1)
-    pkg.pm_slab.TargetExchange(world, dev).exchange(final, ids.to(torch.int32))
-    cnt = torch.tensor([o_pos.shape[0]], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(cnt)
-    assert int(cnt.item()) == N, "particles lost or duplicated in migration"
+    raise SystemExit("mode must be single or peano (the x-slab domains of round 1 were retired)")
 torch.cuda.synchronize()
 if rank == 0:
     np.save(out, final.cpu().numpy())

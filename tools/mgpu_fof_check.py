@@ -74,7 +74,7 @@ else:
     grnr[o_idx] = g_own
     if world > 1:
         full = grnr.to(torch.float64).reshape(N, 1).contiguous()
-        pkg.pm_slab.TargetExchange(world, dev).exchange(full, o_idx.to(torch.int32))
+        pkg.rows.TargetExchange(world, dev).exchange(full, o_idx.to(torch.int32))
         grnr = full[:, 0].to(torch.int64)
         tabs = [None] * world
         dist.all_gather_object(tabs, Gh)

@@ -121,38 +121,13 @@ elif mode == "peano":
         full = torch.zeros((N,) + tuple(a[k].shape[1:]), **f8)
         full[o_ids] = a[k]
         if grouped:
-            pkg.pm_slab.TargetExchange(world, dev).exchange(full.reshape(N, -1), o_ids.to(torch.int32))
+            pkg.rows.TargetExchange(world, dev).exchange(full.reshape(N, -1), o_ids.to(torch.int32))
         res[k] = full
     if rank == 0:
         print("hydro peano: %s own %d" % (df.stats(), n_own), flush=True)
     df.close()
 else:
-    nmesh = 2 * n
-    dom = pkg.domain.SlabDomain(eng, box, nmesh, rank, world, dev, rcut=6.0 * 1.5 * box / nmesh, margin=6.0 * box / n)
-    own = dom.select_own(g_pos)
-    n_own = own.shape[0]
-    lpos, lmass, ltyp, lvel, lent, lhsml = dom.import_ghosts(g_pos[own].contiguous(), g_mass[own].contiguous(),
-                                                            (g_typ[own].contiguous(), g_vel[own].contiguous(), g_ent[own].contiguous(), g_hsml[own].contiguous()))
-    nl = lpos.shape[0]
-    a = arrays(nl, lhsml, lvel, lent)
-    eng.dev_bind_particles(lpos, lmass, box, type=ltyp)
-    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
-    act = torch.nonzero(ltyp[:n_own] == 0).squeeze(1).to(torch.int32).contiguous()    # own gas particles
-    eng.dev_density(a, t, active=act)
-    dom.check_hsml_margin(a["hsml"][:n_own])
-    for k, g in zip(FIELDS, dom.ghost_update_many([a[k][:n_own] for k in FIELDS])):   # the ghosts' new Hsml, Density, ... from their owners
-        a[k][n_own:] = g
-    eng.dev_force_tree_calc_hmax()
-    eng.dev_hydro_force(a, t, active=act)
-    res = {}
-    ex = pkg.pm_slab.TargetExchange(world, dev)
-    for k in FIELDS + ("hydroacc_out", "dtentropy_out", "maxsignalvel"):
-        full = torch.zeros((N,) + tuple(a[k].shape[1:]), **f8)
-        full[own] = a[k][:n_own]
-        ex.exchange(full.reshape(N, -1), own.to(torch.int32))
-        res[k] = full
-    if rank == 0:
-        print("hydro domain: La %d own %d local %d" % (dom.La, n_own, nl), flush=True)
+    raise SystemExit("mode must be single or peano (the x-slab domains of round 1 were retired)")
 torch.cuda.synchronize()
 if rank == 0:
     np.savez(out, typ=typ, **{k: v.cpu().numpy() for k, v in res.items()})

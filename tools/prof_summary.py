@@ -74,7 +74,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 # MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
 # wide (16 B/lane) coalesced read stream -> doubled.  Collected in separate --pmc passes (tools/prof.sh).
 import json
-WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists<", "k_walk_lists2<", "k_walk_eval<")}
+WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists<", "k_walk_lists2<", "k_walk_lists8<", "k_walk_eval<")}
 METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled "
           "(gfx950 correction for 16 B/lane reads, MI355X_MICROARCH.md section HBM); summed over the dispatches of one walk")
 
@@ -82,7 +82,7 @@ METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; K
 def is_count_build(kname):
     # the COUNT template flag (instrumented untimed pass) is the 2nd parameter of k_grav_walk*, the 1st of k_walk_lists
     targs = [a.strip() for a in kname.split("<")[-1].split(">")[0].split(",")]
-    if "k_walk_lists<" in kname or "k_walk_lists2<" in kname:
+    if "k_walk_lists<" in kname or "k_walk_lists2<" in kname or "k_walk_lists8<" in kname:
         return targs[0] == "true"
     if "k_walk_eval<" in kname:
         return False
@@ -107,7 +107,7 @@ for var, pats in WALK_KERNELS.items():
             if ndisp:
                 # dispatches of the first kernel of the group per walk: 1 for kernels 1 and 4, ceil(N / 2^21) slices for 6
                 per_walk = int(os.environ.get("MPG_SLICES_PER_WALK", "1")) if var == "6" else 1   # 256^3 is one slice (list capacity 1024)
-                first = len(ndisp[pats[0]]) + (len(ndisp["k_walk_lists2<"]) if var == "6" else 0)   # (either list kernel opens a walk)
+                first = len(ndisp[pats[0]]) + (len(ndisp["k_walk_lists2<"]) + len(ndisp["k_walk_lists8<"]) if var == "6" else 0)   # (any list kernel opens a walk)
                 walks[name] += first / per_walk
     if walks["FETCH_SIZE"] and walks["WRITE_SIZE"]:
         fb = 2 * 1024 * tot["FETCH_SIZE"] / walks["FETCH_SIZE"]
@@ -115,6 +115,19 @@ for var, pats in WALK_KERNELS.items():
         variants[var] = {"kernel": " + ".join(p_.rstrip("<") for p_ in pats), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                          "hbm_bytes_per_launch": fb + wb, "walks_profiled": walks["FETCH_SIZE"], "method": METHOD}
 if variants:
-    print("== walk traffic:", json.dumps(variants))
+    # the library these counters belong to and the input set: bench.py reports the traffic only for the same build (mpg_build_stamp)
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stamp, ic = None, None
+    try:
+        stamp = open(os.path.join(here, "mp-gadget_amd", "libmpgadget_hip.so.stamp")).read().strip()
+    except OSError:
+        pass
+    try:
+        line = [x for x in open(os.path.join(root, "bench_trace.json")) if x.startswith("{")][-1]
+        wl = json.loads(line)["config"]["workload"]
+        ic = [k for k in ("s_grid", "s_zel", "s_clust") if k in wl][0]
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
+    print("== walk traffic (%s, build %s):" % (ic, stamp), json.dumps(variants))
     with open(os.path.join(root, "walk_traffic.json"), "w") as fo:
-        json.dump({"variants": variants}, fo, indent=1)
+        json.dump({"build_stamp": stamp, "by_ic": {ic or "unknown": variants}}, fo, indent=1)
