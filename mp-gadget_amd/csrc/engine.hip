@@ -434,12 +434,15 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     int variant = eng->walk_variant;
     if(variant == 0) {
         // Default: the two-kernel walk (6) with the cooperative kernel (4) for the targets whose lists overflow; the lane-per-target
-        // kernel (1) for small target sets, where launch count matters more than lane use.  (This used to be decided by timing
+        // kernel (1) for small target sets (fewer than 4096), where launch count matters more than lane use.  (This used to be decided by timing
         // kernels 1, 4 and 6 on the first walk and every 64th.  On the measured sets - grid, Zel'dovich, clustered, 96^3 .. 256^3 -
         // kernel 6 now always wins, and the trial itself is unaffordable on clustered sets: 6.7 s for kernel 1 and 2 s for kernel 4
         // against 0.18 s for kernel 6 at 256^3; timing a sample of the targets instead misjudges kernel 6, whose fixed costs -
         // slices, two streams, the control-word read-back - weigh on a small sample.)
-        variant = io.ntargets >= 65536 ? 6 : 1;
+        // (round 3, with k_walk_lists8: 32 768 active targets of a 256^3 tree take 1.09 ms with kernel 6 against 4.6 ms with kernel 1;
+        // the threshold was 65 536 when the list kernels needed that many targets to fill the chip)
+        static const int64_t split_min = getenv("MPG_SPLIT_MIN_TARGETS") ? atoll(getenv("MPG_SPLIT_MIN_TARGETS")) : 4096;
+        variant = io.ntargets >= split_min ? 6 : 1;
         eng->walk_choice = variant;
         eng->walks_since_tune++;
     }

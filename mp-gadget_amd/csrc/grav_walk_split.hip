@@ -490,6 +490,61 @@ __device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &
     }
 }
 
+// The same tests with every comparison taken as a lane mask (k_walk_lists8).  The Barnes-Hut switch is folded into aold by the caller
+// (aold = +inf: "mass l^2 > r^4 aold" is false for every r, NaN at r = 0 included).
+template <int MODE>
+__device__ __forceinline__ void node_test_masks(const GravParams &gp, const NodeGeo &g, const Src4 &mom, const bool special,
+                                                const bool any_special /* wave-uniform */, const double eff, const double l2, const double inside,
+                                                const double ml2, const double px, const double py, const double pz, const double aold,
+                                                unsigned long long &m_discard, unsigned long long &m_open, unsigned long long &m_wrap)
+{
+    double dx, dy, dz, cmax;
+    m_wrap = 0ull;
+    if(MODE == 0) {
+        cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
+                    fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
+        dx = nearest_img(mom.x - px, gp.box, gp.invbox);
+        dy = nearest_img(mom.y - py, gp.box, gp.invbox);
+        dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
+    }
+    else {
+        if(MODE == 1) {
+            const double kx = rint((g.cx - px) * gp.invbox);
+            const double ky = rint((g.cy - py) * gp.invbox);
+            const double kz = rint((g.cz - pz) * gp.invbox);
+            const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
+            cmax = fmax(fmax(fabs(g.cx - qx), fabs(g.cy - qy)), fabs(g.cz - qz));
+            dx = mom.x - qx;
+            dy = mom.y - qy;
+            dz = mom.z - qz;
+            m_wrap = __builtin_amdgcn_ballot_w64(kx != 0.0) | __builtin_amdgcn_ballot_w64(ky != 0.0) | __builtin_amdgcn_ballot_w64(kz != 0.0);
+        }
+        else {
+            cmax = fmax(fmax(fabs(g.cx - px), fabs(g.cy - py)), fabs(g.cz - pz));
+            dx = mom.x - px;
+            dy = mom.y - py;
+            dz = mom.z - pz;
+        }
+        if(any_special) { // (the root and its children: exact images for the centre and the centre of mass, see walk_target)
+            const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
+            dx = special ? fma(-jx, gp.box, mom.x - px) : dx;
+            dy = special ? fma(-jy, gp.box, mom.y - py) : dy;
+            dz = special ? fma(-jz, gp.box, mom.z - pz) : dz;
+            const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(special);
+            m_wrap |= m_sp & (__builtin_amdgcn_ballot_w64(jx != 0.0) | __builtin_amdgcn_ballot_w64(jy != 0.0) | __builtin_amdgcn_ballot_w64(jz != 0.0));
+            if(MODE == 2) {
+                const double cm = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
+                                       fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
+                cmax = special ? cm : cmax;
+            }
+        }
+    }
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    // shall_we_discard_node / shall_we_open_node, gravshort-tree.c:198-241
+    m_discard = __builtin_amdgcn_ballot_w64(r2 > gp.rcut2) & __builtin_amdgcn_ballot_w64(cmax > eff);
+    m_open = __builtin_amdgcn_ballot_w64(ml2 > r2 * r2 * aold) | __builtin_amdgcn_ballot_w64(l2 > r2 * gp.bhangle2) | __builtin_amdgcn_ballot_w64(cmax < inside);
+}
+
 // state of one target of a pair (group-uniform except wrap_lane)
 struct PairTarget {
     double px, py, pz, aold;
@@ -803,35 +858,41 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const double ml2 = mom.m * l2;
         const bool special = MODE != 0 && valid && my <= 8u;
         const bool any_special = MODE != 0 && any_lane(special);
-        const bool isleaf = lk.pcount > 0, isint = lk.pcount <= 0 && lk.nchild > 0;
         const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
         unsigned openmask = 0;
         if(COUNT) {
             st_a++;
             st_al += (unsigned)n;
         }
-        // One pass over the wave's targets.  A target gains at most 64 entries per pass (one per lane): only when some list is that
-        // close to its capacity are the appends CHECKED one by one; the common pass has no branch but the two predicated stores.
+        // One pass over the wave's targets.  The outcome of every comparison is taken as a 64-bit LANE MASK (the ballot of a bare
+        // comparison is the comparison's own result register: no instruction) and the reference's boolean expressions are evaluated
+        // once per wave on those masks by the scalar unit; a mask comes back as the predicate of a store through inverse_ballot (it
+        // becomes the exec mask: no vector instruction either).  Written with per-lane booleans, hipcc materialised every && / || as
+        // v_cndmask / v_and chains: 45 - 50 vector instructions per pass where this form needs ~35.
+        // A target gains at most 64 entries per pass (one per lane): only when some list is that close to its capacity are the
+        // appends CHECKED one by one.
+        const unsigned long long m_leafnode = __builtin_amdgcn_ballot_w64(lk.pcount > 0);
+        const unsigned long long m_intnode = ~m_leafnode & __builtin_amdgcn_ballot_w64(lk.nchild > 0);
         auto pass = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
             for(int t = 0; t < 8; t++) {
-                const bool act = (mask & (1u << t)) != 0u; // (no lane for a target that overflowed, is absent or did not open the parent)
-                // (measured: 28 % of the passes over a target find no lane with its bit - the entries popped late in a walk belong to
-                // few of the 8 targets - so the test pays for its two scalar instructions)
-                if(!any_lane(act))
+                // (no lane for a target that overflowed, is absent or did not open the parent; measured: 28 % of the passes over a
+                // target find no lane with its bit - the entries popped late in a walk belong to few of the 8 targets)
+                const unsigned long long m_act = __builtin_amdgcn_ballot_w64((mask & (1u << t)) != 0u);
+                if(m_act == 0ull)
                     continue;
                 // (one address for the wave: a broadcast read.  The empty asm hides from hipcc that the 8 reads are the same in every
                 // pass of the walk: hoisted out of the loop they would hold 64 registers)
                 unsigned ot = 4u * t;
                 asm volatile("" : "+v"(ot));
                 const double4 tg = *(const double4 *)(s_tgt + ot);
-                bool d, o, w;
-                node_tests<MODE, true>(gp, g, mom, special, any_special, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, d, o, w);
-                const bool keep = act & !d;
-                const bool b_node = keep & !o;
-                const bool b_leaf = keep & o & isleaf;
-                const unsigned long long bl = __builtin_amdgcn_ballot_w64(b_leaf), bn = __builtin_amdgcn_ballot_w64(b_node);
+                unsigned long long m_discard, m_open, m_wrap;
+                node_test_masks<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
+                const unsigned long long keep = m_act & ~m_discard;
+                const unsigned long long bn = keep & ~m_open;              // used unopened
+                const unsigned long long bl = keep & m_open & m_leafnode;  // opened leaves
+                const unsigned long long bpush = keep & m_open & m_intnode;
                 const int kl = __builtin_popcountll(bl), kn = __builtin_popcountll(bn);
                 if(CHECKED && T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
                     overflowed |= 1u << t;
@@ -839,21 +900,21 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                     continue;
                 }
                 unsigned *__restrict__ Lt = Lw + (unsigned)(t * cap); // (wave-uniform base)
-                if(b_leaf) // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
+                if(__builtin_amdgcn_inverse_ballot_w64(bl)) // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
                     st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, (unsigned)T.nleaf[t])), ent_val);
-                if(b_node)
+                if(__builtin_amdgcn_inverse_ballot_w64(bn))
                     st32(Lt, (unsigned)(cap - 1 - T.nnode[t]) - mbcnt64(bn), my);
                 T.nleaf[t] += kl;
                 T.nnode[t] += kn;
                 maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
-                openmask |= (keep & o & isint) ? (1u << t) : 0u;
+                openmask |= __builtin_amdgcn_inverse_ballot_w64(bpush) ? (1u << t) : 0u;
                 // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children
                 if(MODE == 1 || (MODE == 2 && any_special))
-                    wmask |= __builtin_amdgcn_ballot_w64(w & (b_leaf | b_node));
+                    wmask |= m_wrap & (bl | bn);
                 if(COUNT) {
-                    T.c_vis[t] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+                    T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
                     T.c_used[t] += (unsigned)kn;
-                    c_pp[t] += b_leaf ? (unsigned)lk.pcount : 0u;
+                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl) ? (unsigned)lk.pcount : 0u;
                 }
                 // (the 8 targets' tests are independent: left alone, hipcc interleaves them and runs out of registers)
                 __builtin_amdgcn_sched_barrier(0);
