@@ -711,9 +711,8 @@ int mpg_dist_get_times(mpg_dist *d, double ms[8]);
 int mpg_dev_force_tree_set_min_leaf_level(mpg_engine *eng, int level);
 
 /* Tuning knobs of the walk; results do not depend on any of them.
- *   variant   0 = auto (default): time kernels 1, 4 and 6 once on a large walk and keep the fastest (re-tuned every 64 walks);
+ *   variant   0 = auto (default): kernel 6 for 4096 targets or more, kernel 1 below that;
  *             1 = lane-per-target while-while kernel (grav_walk.hip); 4 = group-cooperative list kernel (grav_walk_coop.hip);
- *             5 = shared-traversal kernel (grav_walk_shared.hip, experimental);
  *             6 = two kernels, list construction then evaluation (grav_walk_split.hip)
  *   threshold (kernel 1) the node phase keeps running while at least that many lanes of a wave still search (default 16)
  *   list capacity (kernels 4, 6) interaction-list entries per target (default 512): kernel 4 drains its lists when they are

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmpgadget_hip.so")
-SOURCES = ["tree_build.hip", "grav_walk.hip", "grav_walk_coop.hip", "grav_walk_shared.hip", "grav_walk_split.hip", "grav_pair_walk.hip", "pm.hip", "sph.hip", "timestep.hip", "peano.hip", "domain.hip", "fof.hip", "snapshot_io.hip", "engine.hip", "dist.hip"]
+SOURCES = ["tree_build.hip", "grav_walk.hip", "grav_walk_coop.hip", "grav_walk_split.hip", "grav_pair_walk.hip", "pm.hip", "sph.hip", "timestep.hip", "peano.hip", "domain.hip", "fof.hip", "snapshot_io.hip", "engine.hip", "dist.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

@@ -420,13 +420,11 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     const bool fastwrap = !getenv("MPG_NO_FASTWRAP") && (gp.rcut + 1.5 * maxleaf < 0.49 * gp.box) && (gp.rcut < 0.2 * gp.box);
     auto run_variant_io = [&](int v, const WalkIO &w) {
         if(v != 1)
-            eng->tree.ensure_level_order(eng->stream); // variants 4 and 5 walk the level-ordered copy of the tree
+            eng->tree.ensure_level_order(eng->stream); // variants 4 and 6 walk the level-ordered copy of the tree
         if(v == 1)
             launch_grav_walk(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
         else if(v == 6)
             launch_grav_walk_split(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->w3, eng->stream);
-        else if(v == 5)
-            launch_grav_walk_shared(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, eng->w3, eng->stream);
         else
             launch_grav_walk_coop(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->w3, eng->stream);
     };
@@ -2124,7 +2122,7 @@ int mpg_set_walk_lists_mode(mpg_engine *eng, int mode)
 int mpg_set_walk_variant(mpg_engine *eng, int variant)
 {
     API_BEGIN
-    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4 || variant == 5 || variant == 6), "walk variant must be 0 (auto), 1, 4, 5 or 6");
+    MPG_CHECK(eng && (variant == 0 || variant == 1 || variant == 4 || variant == 6), "walk variant must be 0 (auto), 1, 4 or 6");
     eng->walk_variant = variant;
     eng->walk_choice = 0;
     API_END

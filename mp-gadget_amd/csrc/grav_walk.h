@@ -62,9 +62,6 @@ struct WalkScratch {
 // fastwrap: the minimum-image wrap may be hoisted out of the pair loop (decided by the caller from Rcut, Box, leaf sizes)
 void launch_grav_walk_coop(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap,
                            WalkScratch &ws, hipStream_t st);
-// shared-traversal walk (grav_walk_shared.hip): the 8 targets of a wave share one tree traversal
-void launch_grav_walk_shared(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, WalkScratch &ws,
-                             hipStream_t st);
 // two-kernel walk (grav_walk_split.hip): list construction, then evaluation; overflowing targets fall back to launch_grav_walk
 void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const WalkIO &io, bool want_pot, bool count, bool fastwrap, int thresh,
                             WalkScratch &ws, hipStream_t st);

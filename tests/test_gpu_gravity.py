@@ -201,10 +201,10 @@ def test_list_kernels_agree(tmp_path, ic, n):
         assert c2.min() > 0 and 0.6 < np.median(c2 / c0) < 1.6 and np.corrcoef(c0, c2)[0, 1] > 0.9, step
 
 
-@pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (5, 512), (6, 512), (6, 40)])
+@pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (6, 512), (6, 40)])
 @pytest.mark.parametrize("ic,n,nmesh", [("s_grid", 24, 48), ("s_clust", 20, 40), ("s_zel", 24, 48)])
 def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
-    """Every walk kernel (lane-per-target 1, group-cooperative 4, shared traversal 5, two-kernel list/evaluate 6) takes the
+    """Every walk kernel (lane-per-target 1, group-cooperative 4, two-kernel list/evaluate 6) takes the
     reference's decisions per target: equal counters and accelerations against the oracle.  The small list capacities force
     kernel 4 to drain its lists mid-walk and kernel 6 to send overflowing targets to its fallback."""
     if ic == "s_clust":
