@@ -95,16 +95,70 @@ __global__ void __launch_bounds__(256) k_need_mask(int64_t n, const double *__re
     mask[i] = need[tree_cell(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], box, La)] & ~(1ull << me);
 }
 
-// rows per destination: one atomic per wave and destination
-__global__ void __launch_bounds__(256) k_count_dests(int64_t n, const unsigned long long *__restrict__ mask, int nt,
-                                                     unsigned long long *__restrict__ counts)
+// ---- send lists for all destinations in two passes (a stable multi-way split).  A row may go to several destinations (one bit per
+// rank in its mask); within a destination the rows keep their order, so the lists - and with them the order of the ghosts in the
+// receivers' arrays - do not depend on scheduling.  Tiles of 1024 consecutive rows: pass 1 counts the rows of every tile per
+// destination (tilecnt[d][tile]: an exclusive scan over that array, destinations back to back, IS the start of (d, tile) in the
+// concatenated lists) and adds the totals up (one global atomic per tile and destination: per WAVE and destination on the same 8
+// words it took 1.76 ms for 16.8 M rows); pass 2 ranks the rows of a tile by ballots and wave totals in LDS and writes the indices.
+// (Round 2: one rocprim::select pass over all rows PER DESTINATION.)
+constexpr int SPLIT_TILE = 1024;
+__global__ void __launch_bounds__(256) k_split_count(int64_t n, const unsigned long long *__restrict__ mask, int nt, int64_t ntiles,
+                                                     unsigned *__restrict__ tilecnt, unsigned long long *__restrict__ counts)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long m = i < n ? mask[i] : 0ull;
-    for(int d = 0; d < nt; d++) {
-        const unsigned long long b = __builtin_amdgcn_ballot_w64((m >> d) & 1ull);
-        if(b && (threadIdx.x & 63) == 0)
-            atomicAdd(&counts[d], (unsigned long long)__popcll(b));
+    __shared__ unsigned s_cnt[64];
+    if(threadIdx.x < 64)
+        s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SPLIT_TILE;
+    for(int j = 0; j < SPLIT_TILE / 256; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const unsigned long long m = i < n ? mask[i] : 0ull;
+        for(int d = 0; d < nt; d++) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64((m >> d) & 1ull);
+            if(b && (threadIdx.x & 63) == 0)
+                atomicAdd(&s_cnt[d], (unsigned)__popcll(b));
+        }
+    }
+    __syncthreads();
+    if(threadIdx.x < nt) {
+        const unsigned c = s_cnt[threadIdx.x];
+        tilecnt[(int64_t)threadIdx.x * ntiles + blockIdx.x] = c;
+        if(c)
+            atomicAdd(&counts[threadIdx.x], (unsigned long long)c);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_split_scatter(int64_t n, const unsigned long long *__restrict__ mask, int nt, int64_t ntiles,
+                                                       const unsigned *__restrict__ tilepos, int *__restrict__ idx)
+{
+    __shared__ unsigned s_base[64], s_w[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if(threadIdx.x < nt)
+        s_base[threadIdx.x] = tilepos[(int64_t)threadIdx.x * ntiles + blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SPLIT_TILE;
+    for(int j = 0; j < SPLIT_TILE / 256; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const unsigned long long m = i < n ? mask[i] : 0ull;
+        for(int d = 0; d < nt; d++) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64((m >> d) & 1ull);
+            if(lane == 0)
+                s_w[wave][d] = (unsigned)__popcll(b);
+        }
+        __syncthreads();
+        for(int d = 0; d < nt; d++) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64((m >> d) & 1ull);
+            if((m >> d) & 1ull) {
+                unsigned pos = s_base[d] + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+                for(int w = 0; w < wave; w++)
+                    pos += s_w[w][d];
+                idx[pos] = (int)i;
+            }
+        }
+        __syncthreads();
+        if(threadIdx.x < nt)
+            s_base[threadIdx.x] += s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -552,6 +606,7 @@ struct mpg_dist {
     DevBuf<unsigned long long> need; // [8^La] ranks that need the cell
     // work
     DevBuf<unsigned long long> mask, cnt;
+    DevBuf<unsigned> tilecnt, tilepos; // build_plan: rows per (destination, tile of 1024 rows) and their exclusive scan
     DevBuf<char> tmp;
     DevBuf<char> sendbuf, recvbuf;
     HostBuf<char> hsend, hrecv;
@@ -683,10 +738,19 @@ void build_plan(mpg_dist *d, Plan &pl, int64_t n, const unsigned long long *mask
     const int nt = d->nt;
     d->cnt.reserve(64);
     MPG_HIP(hipMemsetAsync(d->cnt.p, 0, 64 * sizeof(unsigned long long), st));
+    const int64_t ntiles = (n + SPLIT_TILE - 1) / SPLIT_TILE;
+    d->tilecnt.reserve((size_t)nt * ntiles + 1);
+    d->tilepos.reserve((size_t)nt * ntiles + 1);
     if(n > 0)
-        hipLaunchKernelGGL(k_count_dests, dim3(nblk(n)), dim3(256), 0, st, n, mask, nt, d->cnt.p);
+        hipLaunchKernelGGL(k_split_count, dim3((unsigned)ntiles), dim3(256), 0, st, n, mask, nt, ntiles, d->tilecnt.p, d->cnt.p);
     unsigned long long hc[64];
     MPG_HIP(hipMemcpyAsync(hc, d->cnt.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if(n > 0) { // (queued behind the count pass, before the host looks at the totals)
+        size_t tb = 0;
+        MPG_HIP(rocprim::exclusive_scan(nullptr, tb, d->tilecnt.p, d->tilepos.p, 0u, (size_t)nt * ntiles, rocprim::plus<unsigned>(), st));
+        d->tmp.reserve(tb + 16);
+        MPG_HIP(rocprim::exclusive_scan((void *)d->tmp.p, tb, d->tilecnt.p, d->tilepos.p, 0u, (size_t)nt * ntiles, rocprim::plus<unsigned>(), st));
+    }
     sync(d);
     pl.scnt.assign(nt, 0);
     pl.sdsp.assign(nt + 1, 0);
@@ -695,23 +759,13 @@ void build_plan(mpg_dist *d, Plan &pl, int64_t n, const unsigned long long *mask
         pl.sdsp[r + 1] = pl.sdsp[r] + pl.scnt[r];
     }
     pl.nsend = pl.sdsp[nt];
+    MPG_CHECK(pl.nsend < (1ll << 31), "mpg_dist: more than 2^31 rows in one exchange");
     pl.idx.reserve((size_t)pl.nsend + 1);
     pl.d_sdsp.reserve((size_t)nt + 1);
     std::vector<long long> dsp(pl.sdsp.begin(), pl.sdsp.end());
     MPG_HIP(hipMemcpyAsync(pl.d_sdsp.p, dsp.data(), (nt + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
-    if(n > 0) {
-        rocprim::counting_iterator<int> iota(0);
-        size_t tb = 0;
-        auto flags0 = rocprim::make_transform_iterator(mask, BitOf{0});
-        MPG_HIP(rocprim::select(nullptr, tb, iota, flags0, pl.idx.p, d->cnt.p, (size_t)n, st));
-        d->tmp.reserve(tb + 16);
-        for(int r = 0; r < nt; r++) {
-            if(pl.scnt[r] == 0)
-                continue;
-            auto flags = rocprim::make_transform_iterator(mask, BitOf{r});
-            MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, flags, pl.idx.p + pl.sdsp[r], d->cnt.p + 32, (size_t)n, st));
-        }
-    }
+    if(n > 0 && pl.nsend > 0)
+        hipLaunchKernelGGL(k_split_scatter, dim3((unsigned)ntiles), dim3(256), 0, st, n, mask, nt, ntiles, d->tilepos.p, pl.idx.p);
     sync(d); // (dsp is a host vector)
     pl.rcnt.assign(nt, 0);
     if(nt == 1 && !d->comm.alltoall_i64)

@@ -7,8 +7,11 @@
  * Pinning: the kernel functions are checked bit-for-bit against oracle/_ref (densitykernel.c compiled in place);
  * the density loop against the reference's known answers of libgadget/tests/test_density.c (mean Hsml 0.501747 +- 1e-4
  * on the 32^3 grid, cubic spline, eta = 1, MaxNumNgbDeviation = 2; stability under MaxNumNgbDeviation 0.5, :126-147).
- * hydra.c has no known answer in the reference's tests: parity "unpinned" beyond conservation properties
- * (tests/test_oracle_sph.py: pairwise antisymmetry of the momentum exchange).
+ * hydra.c has no known answer in the reference's tests and cannot be built here; since round 3 os_hydro_force (and the derived
+ * fields of os_density) are pinned by PHYSICS instead: tests/sph_paper.py states the SPH equations from the publications and the
+ * comoving-variable physics (not from hydra.c) and evaluates them over all pairs; tests/test_hydro_physics.py requires agreement to
+ * 2e-10 in both SPH formulations, at a = 1 and at a cosmological epoch, with and without the bound on the viscous force, adds
+ * closed-form states and an energy balance, and shows that seven deliberate mutations of this file each fail a gate.
  *
  * Single rank, trivial domain: export / ghost machinery (treewalk.c:325-793) is not restated.
  */

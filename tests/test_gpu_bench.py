@@ -119,4 +119,4 @@ def test_peano_domains_balance_the_walk_work_on_the_clustered_set():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     lb = j["config"]["load_balance"]
     assert lb["walk_work_max_over_mean"] < 1.15, lb
-    assert lb["by_particle_number"]["walk_work_max_over_mean"] > 1.3 * lb["walk_work_max_over_mean"], lb
+    assert lb["by_particle_number"]["walk_work_max_over_mean"] > 1.2 * lb["walk_work_max_over_mean"], lb
