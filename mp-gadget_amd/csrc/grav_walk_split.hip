@@ -812,7 +812,7 @@ __device__ __forceinline__ unsigned mbcnt64(const unsigned long long b)
 // LDS (s_tgt: [t][4] doubles) and are read back with a wave-uniform address per target - as scalars they overflowed the SGPR file
 // (8 x 8 registers) and every use cost a v_readlane
 struct WaveTargets {
-    int n[8]; // list entries so far
+    int nleaf[8], nnode[8];
     unsigned c_vis[8], c_used[8];
 };
 
@@ -834,7 +834,7 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
     }
     unsigned guard = 0;
     unsigned long long wmask = 0;
-    int maxused = 0; // longest list among the wave's targets (wave-uniform)
+    int maxused = 0; // longest pair of lists among the wave's targets (wave-uniform)
     while(sp > 0 && live) {
         if(++guard > guard_max) {
             if(lane == 0)
@@ -858,10 +858,7 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const double ml2 = mom.m * l2;
         const bool special = MODE != 0 && valid && my <= 8u;
         const bool any_special = MODE != 0 && any_lane(special);
-        // the two entries a node can contribute: its particles (an opened leaf) or its moments (used unopened), the latter as a
-        // "leaf" of one source at record mom_off + my of the source array
-        const unsigned ent_leaf = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-        const unsigned ent_node = ((unsigned)tv.mom_off + my) << 3;
+        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
         unsigned openmask = 0;
         if(COUNT) {
             st_a++;
@@ -896,27 +893,27 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 const unsigned long long bn = keep & ~m_open;              // used unopened
                 const unsigned long long bl = keep & m_open & m_leafnode;  // opened leaves
                 const unsigned long long bpush = keep & m_open & m_intnode;
-                const unsigned long long we = bl | bn;
-                const int k = __builtin_popcountll(we);
-                if(CHECKED && T.n[t] + k > cap) { // the list of target t is full: the fallback kernel walks it again
+                const int kl = __builtin_popcountll(bl), kn = __builtin_popcountll(bn);
+                if(CHECKED && T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
                     overflowed |= 1u << t;
                     live &= ~(1u << t);
                     continue;
                 }
                 unsigned *__restrict__ Lt = Lw + (unsigned)(t * cap); // (wave-uniform base)
-                // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
-                const unsigned val = __builtin_amdgcn_inverse_ballot_w64(bl) ? ent_leaf : ent_node;
-                if(__builtin_amdgcn_inverse_ballot_w64(we))
-                    st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(we >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)we, (unsigned)T.n[t])), val);
-                T.n[t] += k;
-                maxused = max(maxused, T.n[t]);
+                if(__builtin_amdgcn_inverse_ballot_w64(bl)) // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
+                    st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, (unsigned)T.nleaf[t])), ent_val);
+                if(__builtin_amdgcn_inverse_ballot_w64(bn))
+                    st32(Lt, (unsigned)(cap - 1 - T.nnode[t]) - mbcnt64(bn), my);
+                T.nleaf[t] += kl;
+                T.nnode[t] += kn;
+                maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
                 openmask |= __builtin_amdgcn_inverse_ballot_w64(bpush) ? (1u << t) : 0u;
                 // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children
                 if(MODE == 1 || (MODE == 2 && any_special))
                     wmask |= m_wrap & (bl | bn);
                 if(COUNT) {
                     T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
-                    T.c_used[t] += (unsigned)__builtin_popcountll(bn);
+                    T.c_used[t] += (unsigned)kn;
                     c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl) ? (unsigned)lk.pcount : 0u;
                 }
                 // (the 8 targets' tests are independent: left alone, hipcc interleaves them and runs out of registers)
@@ -1013,7 +1010,7 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, con
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for(int t = 0; t < 8; t++) {
-            T.n[t] = 0;
+            T.nleaf[t] = T.nnode[t] = 0;
             T.c_vis[t] = T.c_used[t] = 0u;
             c_pp[t] = 0u;
         }
@@ -1031,25 +1028,28 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, con
             ok = walk_wave8<COUNT, 0, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
         if(!ok)
             return;
-        int nl = 0;
+        int nl = 0, nn = 0;
 #pragma unroll
         for(int t = 0; t < 8; t++)
-            if(lane == t)
-                nl = T.n[t];
+            if(lane == t) {
+                nl = T.nleaf[t];
+                nn = T.nnode[t];
+            }
         if(tvalid) {
             const bool overflow = (overflowed >> lane) & 1u;
+            // the work this target causes in the two kernels: 8 lanes per leaf entry and 1 per node entry in the evaluation, and about
+            // as many node tests as it has entries in the list construction (k_walk_lists / k_walk_lists2 count 8 per traversal step
+            // instead; the measure only has to be proportional to the time spent: domain.c:611)
+            if(io.cost)
+                io.cost[ci] = (float)(8 * (overflow ? cap : nl) + nn + 3 * (nl + nn));
             if(overflow) {
-                // (k_walk_stream writes the work measure of the targets it evaluates; an overflowed one is at least as expensive as
-                // a full list of full leaves)
-                if(io.cost)
-                    io.cost[ci] = (float)(10 * cap);
                 counts[rel] = make_int2(-1, 0);
                 ovf[atomicAdd(&ctl[0], 1u)] = ci;
             }
             else {
-                counts[rel] = make_int2(nl | (wrapped ? (1 << 30) : 0), 0);
-                if((unsigned)nl > ctl[2])
-                    atomicMax(&ctl[2], (unsigned)nl);
+                counts[rel] = make_int2(nl | (wrapped ? (1 << 30) : 0), nn);
+                if((unsigned)(nl + nn) > ctl[2])
+                    atomicMax(&ctl[2], (unsigned)(nl + nn));
             }
         }
         if(COUNT) {

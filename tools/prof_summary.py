@@ -33,7 +33,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     walks, cur = [], None
     for r in rows:
         nm = r["Kernel_Name"]
-        w = "k_walk_lists<" in nm or "k_walk_lists2<" in nm or "k_walk_lists8<" in nm or "k_walk_eval<" in nm
+        w = "k_walk_lists<" in nm or "k_walk_lists2<" in nm or "k_walk_lists8<" in nm or "k_walk_eval<" in nm or "k_walk_stream<" in nm
         if w:
             if cur is None:
                 cur = dict(t0=int(r["Start_Timestamp"]), t1=0, count=("k_walk_lists<true" in nm or "k_walk_lists2<true" in nm or "k_walk_lists8<true" in nm), n=0)
@@ -47,7 +47,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     timed = [w for w in walks if not w["count"]]
     if timed:
         spans = [(w["t1"] - w["t0"]) / 1e6 for w in timed]
-        print("== walks (first k_walk_lists start .. last k_walk_eval end):", len(walks), "of which", len(timed), "without counters")
+        print("== walks (first list kernel start .. last evaluation kernel end):", len(walks), "of which", len(timed), "without counters")
         print("  span ms:", " ".join("%.2f" % x for x in spans), "  kernels per walk:", timed[-1]["n"])
         print("  steady state (last %d): %.3f ms per walk" % (min(len(spans), 2), sum(spans[-2:]) / len(spans[-2:])))
 
@@ -74,7 +74,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 # MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
 # wide (16 B/lane) coalesced read stream -> doubled.  Collected in separate --pmc passes (tools/prof.sh).
 import json
-WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists<", "k_walk_lists2<", "k_walk_lists8<", "k_walk_eval<")}
+WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists<", "k_walk_lists2<", "k_walk_lists8<", "k_walk_eval<", "k_walk_stream<")}
 METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled "
           "(gfx950 correction for 16 B/lane reads, MI355X_MICROARCH.md section HBM); summed over the dispatches of one walk")
 
@@ -84,7 +84,7 @@ def is_count_build(kname):
     targs = [a.strip() for a in kname.split("<")[-1].split(">")[0].split(",")]
     if "k_walk_lists<" in kname or "k_walk_lists2<" in kname or "k_walk_lists8<" in kname:
         return targs[0] == "true"
-    if "k_walk_eval<" in kname:
+    if "k_walk_eval<" in kname or "k_walk_stream<" in kname:
         return False
     return len(targs) > 1 and targs[1] == "true"
 
