@@ -57,7 +57,7 @@ def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
     tests of the traversal, which the reference also performs, are NOT counted as flops.  The HBM side is reported next to it:
     algorithmic bytes (SURVEY 8(d) B_walk), measured HBM traffic (PMC) as a fraction of the 8 TB/s peak, and their ratio."""
     variant, list_cap, list_ovf = eng.walk_choice()
-    kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 6: {"0": "k_walk_lists + k_walk_eval", "1": "k_walk_lists2 + k_walk_eval"}.get(os.environ.get("MPG_LISTS_MODE", "2"), "k_walk_lists8 + k_walk_eval"),
+    kernels = {1: "k_grav_walk", 4: "k_grav_walk_coop", 6: "k_walk_lists8 + k_walk_eval",
                7: "k_walk_leaf"}.get(variant, "?")
     t = walk_ms / max(walk_launches, 1) * 1e-3
     flops = (cnt["pp"] + cnt["nodes_used"]) * float(FLOP_PER_INTERACTION)

@@ -2111,11 +2111,11 @@ int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsig
     API_END
 }
 
-int mpg_set_walk_lists_mode(mpg_engine *eng, int mode)
+int mpg_set_walk_leaf_expand(mpg_engine *eng, int kx)
 {
     API_BEGIN
-    MPG_CHECK(eng && mode >= 0 && mode <= 2, "walk lists mode must be 0 (one target per group), 1 (pairs) or 2 (one traversal per wave)");
-    eng->w3.split_lists_mode = mode;
+    MPG_CHECK(eng && (kx == 0 || kx == 1 || kx == 2 || kx == 4), "walk leaf expansion must be 0, 1, 2 or 4 particles");
+    eng->w3.split_leaf_expand = kx;
     API_END
 }
 

@@ -5,27 +5,33 @@
 // separates the two activities -- it collects the particles of opened leaves in `ngblist` and evaluates them afterwards
 // (gravshort-tree.c:346-374) -- and so does this file, at kernel granularity:
 //
-//   k_walk_lists   8 lanes per target walk the level-ordered tree exactly as phase A of grav_walk_coop.hip does (LIFO of
-//                  child ranges in LDS, the 8 lanes test the <= 8 children of one opened node per step) and write, per
-//                  target, the opened leaves (4-byte entries: first particle << 3 | count-1) and the nodes used unopened
-//                  (4-byte level-order indices) to HBM.  No force arithmetic, no window tables.  (A lane-per-target
-//                  depth-first list builder was measured too: 64 lanes gathering 80-byte node records from 64 different
-//                  nodes is bound by the vector-memory pipe and is 15 % - 2.5x slower than this cooperative form.)
+//   k_walk_lists8  one traversal per wave of 8 targets (tree-order neighbours): the 64 lanes hold 64 different pending nodes of the
+//                  union of the 8 walks, the wave loops over its targets and every lane applies the reference's two tests to its
+//                  node for that target.  Written per target to HBM: the opened leaves with more than KX particles (4-byte entries:
+//                  first particle << 3 | count-1) and a list of SINGLE SOURCES (4-byte record numbers of the source array): the
+//                  nodes used unopened (record mom_off + level-order index: their moments) and the particles of the opened
+//                  leaves with <= KX particles, one entry each.  No force arithmetic, no window tables.
 //   k_walk_eval    8 lanes per target stream the target's lists: for a leaf entry lane s evaluates source s (one
-//                  coalesced 256-byte read per group), node entries are taken 8 at a time.  No traversal state: the
+//                  coalesced 256-byte read per group), single sources are taken 8 at a time.  No traversal state: the
 //                  kernel is a pure fp64 pair loop fed by sequential list reads.
 //
-// List layout: the 8 targets of a wave ("chunk") interleave their lists in blocks of 8 entries, so that one wave-wide
-// read or write of "the next 8 entries of every group" is one contiguous 256-byte segment:
-//     index(chunk, g, e) = chunk * cap * 8 + (e >> 3) * 64 + g * 8 + (e & 7)
-// Leaf entries grow up from e = 0, node entries down from e = cap-1.  A target whose lists would exceed `cap` is put on
-// an overflow list and handled afterwards by the lane-per-target kernel (grav_walk.hip), so `cap` bounds memory, not
+// Why small leaves are expanded (round 3): a leaf entry occupies the 8 lanes of a group for one pair evaluation whatever its
+// particle count, and the reference's tree (a cell is split as soon as it holds more than 8 particles) has MANY small leaves - on the
+// 256^3 Zel'dovich set 44 % of the leaves hold one particle, 22 % two, 22 % eight (mean 3.3; the clustered set: mean 2.7) - so with
+// one entry per leaf the evaluation ran 243 pair steps per wave of which 47 % of the lanes carried a source.  An opened leaf of c
+// particles IS c single sources (same records, same arithmetic), and 8 single sources fill a step: with KX = 2 the same lists take
+// 125 steps.  (KX = 8 would fill every lane but doubles the list bytes; the lists make a round trip through HBM.)
+//
+// List layout: target t of chunk u (the 8 targets of a wave) owns lists[(u * 8 + t) * cap ...]: leaf entries from 0 up, single
+// sources from cap - 1 down; the 64 lanes of an append write one contiguous run.  A target whose lists would exceed `cap` is put on
+// an overflow list and handled afterwards by the cooperative kernel (grav_walk_coop.hip), so `cap` bounds memory, not
 // correctness.  Targets are processed in slices of `slice` targets so the list area stays bounded (cap * 4 B each).
 //
 // Periodic wrap: with FASTWRAP (box large against Rcut and the leaves) a source range shares the periodic image of its
-// node; k_walk_lists records per target whether ANY of its entries lies on a wrapped image.  Targets without (all but a
+// node; k_walk_lists8 records per wave whether ANY of its entries lies on a wrapped image.  Waves without (all but a
 // surface layer Rcut thick) evaluate with plain differences, which is bit-identical to NEAREST() there; the others take
 // NEAREST() per pair as partmanager.h:99 does.
+// (Rounds 1-2 built the lists with 8 lanes per target - k_walk_lists, k_walk_lists2: DESIGN.md 3.2 - retired in round 3.)
 #include "grav_walk.h"
 #include <cstdlib>
 #include <type_traits>
@@ -37,8 +43,6 @@ namespace {
 #ifndef MPG_EVAL_BLOCKS
 #define MPG_EVAL_BLOCKS 6 // resident 256-thread blocks per CU the evaluation kernel is compiled for (80 VGPRs)
 #endif
-
-constexpr int STK = 160; // pending child ranges per group (LIFO): <= 7 per tree level + 8, 21 levels
 
 
 __device__ __forceinline__ double rsqrt_nr(double x)
@@ -164,332 +168,16 @@ struct ChunkIter {
     }
 };
 
-// One target's walk (8 lanes), lists written to L.  MODE: 0 NEAREST() per quantity (small boxes); 1 the node's periodic image
-// k = rint((c - p)/Box) is applied to the target (FASTWRAP); 2 plain differences, for targets farther than Rcut + Box/500 from
-// every face of the box.  MODE 2 is exact: a node that is not discarded has |c - p| <= Rcut + len/2 per axis on its nearest
-// image (its centre of mass lies inside it), which for such a target is the unwrapped image; and a node that is discarded
-// with nearest-image distances is discarded with the (larger or equal) unwrapped ones.  In modes 1 and 2 the centre of mass
-// of a node can sit on another image than its centre only if Rcut + len >= Box/2 (the root and its children, two steps per
-// target): those take NEAREST() for both, exactly as gravshort-tree.c:299-300 does.
-// Returns false on an internal error (loop guard / stack), which ends the kernel.
-template <bool COUNT, int MODE, bool O32>
-__device__ __forceinline__ bool walk_target(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ stack,
-                                            const int cap, const int lane, const int s, const int gshift, const bool valid, const double px,
-                                            const double py, const double pz, const double aold, const unsigned guard_max,
-                                            unsigned *__restrict__ ctl, int &nleaf, int &nnode, bool &wrapped, bool &overflow, unsigned &c_pp,
-                                            unsigned &c_vis, unsigned &c_used, unsigned &st_a, unsigned &st_al, unsigned &nsteps)
-{
-    const unsigned below = (1u << s) - 1u;
-    int sp = 0; // stack pointer (group-uniform)
-    if(valid) {
-        if(s == 0)
-            stack[0] = (0u << 4) | 1u; // the root
-        sp = 1;
-    }
-    unsigned guard = 0;
-    bool err = false, wrap_lane = false;
-    // One step per iteration, written without divergent control flow (the first form, an `act` code set in nested
-    // branches, cost ~25 register moves and three extra exec-mask regions per step): every lane computes the tests for
-    // "its" child (idle lanes recompute the root, a broadcast read), the outcomes are booleans, and only the three kinds
-    // of stores are predicated.
-    for(;;) {
-        if(sp > 0 && nleaf + nnode + 8 > cap) { // the next step might not fit: hand the target to the fallback kernel
-            overflow = true;
-            sp = 0;
-        }
-        const bool can = sp > 0;
-        if(!any_lane(can))
-            break;
-        if(++guard > guard_max || any_lane(sp + 8 > STK)) { // (one exit for both, so that the loop keeps a single latch)
-            err = true;
-            break;
-        }
-        nsteps += can ? 1u : 0u;
-        const unsigned range = can ? stack[sp - 1] : 0u;
-        const int nch = (int)(range & 15u);
-        const bool mine = s < nch; // false for every lane of a group that is not walking
-        const unsigned my = mine ? (range >> 4) + (unsigned)s : 0u;
-        const NodeGeo g = ld<O32>(tv.geoB, my);
-        const Src4 mom = ld<O32>(tv.momB, my);
-        const NodeLinkB lk = ld<O32>(tv.linkB, my);
-        // Both tests on the centre distances are tests on their LARGEST: "cdx > eff || cdy > eff || cdz > eff" is cmax > eff and
-        // "cdx < inside && cdy < inside && cdz < inside" is cmax < inside (no NaNs here).  Written with the three values, hipcc
-        // materialised each |.| in registers and chained five v_max_f64 plus three compares; this form is two v_max_f64 with |.|
-        // source modifiers and two compares (10 VALU instructions less per step of ~87).
-        double dx, dy, dz, cmax;
-        bool wr = false;
-        if(MODE == 0) {
-            cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
-                        fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
-            dx = nearest_img(mom.x - px, gp.box, gp.invbox);
-            dy = nearest_img(mom.y - py, gp.box, gp.invbox);
-            dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
-        }
-        else {
-            if(MODE == 1) {
-                // periodic image of this node relative to the target: k = rint((c - p)/Box) per axis
-                const double kx = rint((g.cx - px) * gp.invbox);
-                const double ky = rint((g.cy - py) * gp.invbox);
-                const double kz = rint((g.cz - pz) * gp.invbox);
-                const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
-                cmax = fmax(fmax(fabs(g.cx - qx), fabs(g.cy - qy)), fabs(g.cz - qz));
-                dx = mom.x - qx;
-                dy = mom.y - qy;
-                dz = mom.z - qz;
-                wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
-            }
-            else {
-                cmax = fmax(fmax(fabs(g.cx - px), fabs(g.cy - py)), fabs(g.cz - pz));
-                dx = mom.x - px;
-                dy = mom.y - py;
-                dz = mom.z - pz;
-            }
-            // the root and its children: with FASTWRAP (Rcut < 0.2 Box) they are the only nodes with len + Rcut > 0.49 Box, and in
-            // level order they are nodes 0 .. nchild(root) <= 8 (for a node beyond them the branch is exact too, only not needed).
-            // Idle lanes (which point at the root) stay out: they used to drag the wave through this branch on most steps.
-            if(mine && my <= 8u) {
-                const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
-                dx = fma(-jx, gp.box, mom.x - px);
-                dy = fma(-jy, gp.box, mom.y - py);
-                dz = fma(-jz, gp.box, mom.z - pz);
-                wr = wr || (jx != 0.0) || (jy != 0.0) || (jz != 0.0);
-                if(MODE == 2)
-                    cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
-                                fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
-            }
-        }
-        const double r2 = dx * dx + dy * dy + dz * dz;
-        // shall_we_discard_node, gravshort-tree.c:198-215
-        const double eff = fma(0.5, g.len, gp.rcut);
-        const bool discard = (r2 > gp.rcut2) && (cmax > eff);
-        // shall_we_open_node, gravshort-tree.c:220-241
-        const double l2 = g.len * g.len;
-        const double inside = 0.6 * g.len;
-        const bool open = ((!gp.use_bh) && (mom.m * l2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cmax < inside);
-        const bool keep = mine && !discard;
-        const bool b_node = keep && !open;                                   // used unopened: a 1-element source
-        const bool b_leaf = keep && open && lk.pcount > 0;                   // opened leaf
-        const bool b_push = keep && open && lk.pcount <= 0 && lk.nchild > 0; // opened internal node
-        // Leaf entries: one entry = one opened leaf (<= 8 consecutive particles in tree order), evaluated by the 8 lanes of the group
-        // in one pair step.  (Packing runs of adjacent opened leaves into full entries was built and measured twice - 117.9 against
-        // 113.6 ms per step with overlapped slices, 109.2 against 102.0 with one slice: two thirds of the leaves lie in the shell of
-        // the cut-off cube, where discards fragment the runs, and the list kernel pays more than the evaluation saves.  Removed in
-        // round 2; the code is in the history.)
-        const bool has_ent = b_leaf;
-        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-        const unsigned gm_leaf = (unsigned)((__builtin_amdgcn_ballot_w64(has_ent) >> gshift) & 0xffull);
-        const unsigned gm_node = (unsigned)((__builtin_amdgcn_ballot_w64(b_node) >> gshift) & 0xffull);
-        const unsigned gm_push = (unsigned)((__builtin_amdgcn_ballot_w64(b_push) >> gshift) & 0xffull);
-        if(has_ent) {
-            const unsigned e = (unsigned)(nleaf + __popc(gm_leaf & below));
-            st32(Lw, ((e >> 3) << 6) + (unsigned)gshift + (e & 7u), ent_val);
-        }
-        if(b_node) {
-            const unsigned e = (unsigned)(cap - 1 - (nnode + __popc(gm_node & below)));
-            st32(Lw, ((e >> 3) << 6) + (unsigned)gshift + (e & 7u), my);
-        }
-        if(b_push)
-            stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
-        // (all masks are zero for a group that is not walking)
-        nleaf += __popc(gm_leaf);
-        nnode += __popc(gm_node);
-        sp += __popc(gm_push) - (can ? 1 : 0);
-        if(MODE != 0)
-            wrap_lane = wrap_lane || (wr && (b_leaf || b_node));
-        if(COUNT) {
-            c_vis += mine ? 1u : 0u;
-            c_used += b_node ? 1u : 0u;
-            c_pp += b_leaf ? (unsigned)lk.pcount : 0u;
-            if(can && s == 0) {
-                st_a++;
-                st_al += nch;
-            }
-        }
-    }
-    if(err) {
-        if(lane == 0)
-            atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
-        return false;
-    }
-    if(MODE != 0) // an entry of this target lies on a wrapped image
-        wrapped = ((__builtin_amdgcn_ballot_w64(wrap_lane) >> gshift) & 0xffull) != 0;
-    return true;
-}
-
-// ctl words: [0] number of overflowed targets, [1] error flag (loop guard / stack), [2] longest list seen
-// counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] group steps [4] children tested
-template <bool COUNT, bool FASTWRAP, bool O32, int BLK>
-__global__ void __launch_bounds__(256, BLK) k_walk_lists(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
-                                                     int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
-                                                     unsigned *__restrict__ ctl, int *__restrict__ ovf)
-{
-    __shared__ unsigned s_stack[4 * 8 * STK];
-    set_wave_prio(io.list_prio);
-    const int lane = threadIdx.x & 63;
-    const int grp = lane >> 3, s = lane & 7;
-    const int gshift = grp * 8;
-    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * STK; // pending child ranges of this group: (first << 4) | count
-    const unsigned nchunks = (unsigned)((nslots + 7) / 8);
-    const ChunkIter it(nchunks);
-    const unsigned guard_max = (unsigned)min((long long)(64ll * (tv.nnodes + 1024)), 0x7fffffffll);
-    const double face = gp.rcut + 0.002 * gp.box; // MODE 2 margin (the root cell is 1.001 Box wide: + Box/2000, with slack)
-    unsigned n_pp = 0, n_vis = 0, n_used = 0, st_a = 0, st_al = 0;
-
-    for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
-        const int64_t rel = (int64_t)chunk * 8 + grp;
-        const bool valid = rel < nslots;
-        const int64_t slot = slot0 + rel;
-        int ci = -1;
-        double px = 0, py = 0, pz = 0, aold = 0;
-        if(valid) {
-            ci = io.targets ? io.targets[slot] : tv.order[slot];
-            px = io.pos[3 * (int64_t)ci + 0];
-            py = io.pos[3 * (int64_t)ci + 1];
-            pz = io.pos[3 * (int64_t)ci + 2];
-            double old = 0;
-            if(io.oldacc)
-                old = io.oldacc[ci];
-            else if(io.prev_accel) { // grav_get_abs_accel, gravshort.h:70-80
-                double s2 = 0;
-                for(int j = 0; j < 3; j++) {
-                    const double a = io.prev_accel[3 * (int64_t)ci + j] + (io.gravpm ? io.gravpm[3 * (int64_t)ci + j] : 0.0);
-                    s2 += a * a;
-                }
-                old = sqrt(s2) / gp.G;
-            }
-            aold = gp.errtol * old;
-        }
-        // (chunk is wave-uniform: a scalar base lets the list stores use 32-bit offsets)
-        unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8;
-        int nleaf = 0, nnode = 0; // entries in the two lists (group-uniform)
-        bool wrapped = false, overflow = false;
-        unsigned c_pp = 0, c_vis = 0, c_used = 0, nsteps = 0;
-        bool ok;
-        if(FASTWRAP) {
-            const bool near_face = valid && (fmin(fmin(px, py), pz) < face || fmax(fmax(px, py), pz) > gp.box - face);
-            if(!any_lane(near_face))
-                ok = walk_target<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
-                                           overflow, c_pp, c_vis, c_used, st_a, st_al, nsteps);
-            else
-                ok = walk_target<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped,
-                                           overflow, c_pp, c_vis, c_used, st_a, st_al, nsteps);
-        }
-        else
-            ok = walk_target<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, valid, px, py, pz, aold, guard_max, ctl, nleaf, nnode, wrapped, overflow,
-                                       c_pp, c_vis, c_used, st_a, st_al, nsteps);
-        if(!ok)
-            return;
-        if(io.cost && valid && s == 0) // (an overflowed target is at least as expensive as a full list)
-            io.cost[ci] = (float)(8 * (overflow ? cap : nleaf) + nnode + 8 * (int)nsteps);
-        if(valid && s == 0) {
-            if(overflow) {
-                counts[rel] = make_int2(-1, 0);
-                ovf[atomicAdd(&ctl[0], 1u)] = ci;
-            }
-            else {
-                counts[rel] = make_int2(nleaf | (wrapped ? (1 << 30) : 0), nnode);
-                if((unsigned)(nleaf + nnode) > ctl[2])
-                    atomicMax(&ctl[2], (unsigned)(nleaf + nnode));
-            }
-        }
-        if(COUNT && !overflow) { // an overflowed target is walked again, and counted, by the fallback kernel
-            n_pp += c_pp;
-            n_vis += c_vis;
-            n_used += c_used;
-        }
-    }
-    if(COUNT) {
-        unsigned long long c0 = n_pp, c1 = n_vis, c2 = n_used, c3 = st_a, c4 = st_al;
-        for(int off = 32; off > 0; off >>= 1) {
-            c0 += __shfl_down(c0, off);
-            c1 += __shfl_down(c1, off);
-            c2 += __shfl_down(c2, off);
-            c3 += __shfl_down(c3, off);
-            c4 += __shfl_down(c4, off);
-        }
-        if(lane == 0) {
-            atomicAdd(&io.counters[0], c0);
-            atomicAdd(&io.counters[1], c1);
-            atomicAdd(&io.counters[2], c2);
-            atomicAdd(&io.counters[3], c3);
-            atomicAdd(&io.counters[4], c4);
-        }
-    }
-}
-
-// ---- list construction for PAIRS of targets --------------------------------------------------------------------------------
-// The two targets of a pair are neighbours in tree order (leaf-mates, mostly), so their walks open almost the same nodes.  A group
-// of 8 lanes walks the UNION of the two walks: a stack entry carries a 2-bit mask of the targets that reached the node, lane s
-// loads child s once and applies the reference's tests to it for both targets, a child is pushed with the mask of the targets
-// that open it.  Restricted to one target the union walk visits that target's nodes in the order its own walk would (a depth-first
-// walk with a fixed child order), so each target's two lists are entry for entry what k_walk_lists writes.  What is shared per step:
-// the stack, the range decode, the three node loads and their address arithmetic, the loop control, and the four node-only
-// products of the tests; what is per target: 21 fp64 instructions and the two list appends.
+// ctl words: [0] number of overflowed targets, [1] error flag (loop guard / frontier), [2] longest list seen
+// counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] frontier pops [4] nodes popped
 //
-// the reference's tests for one node and one target (shall_we_discard_node / shall_we_open_node, gravshort-tree.c:198-241);
-// MODE as in walk_target; special: the root or one of its children (exact images for both the centre and the centre of mass)
-// EAGER (k_walk_lists8): every comparison is evaluated by every lane and the outcomes are combined with & and | - the short-circuit
-// form makes hipcc guard single compares with exec-mask regions (3 scalar instructions to skip one vector compare) - and the
-// Barnes-Hut switch is folded into aold by the caller (aold = +inf: "mass l^2 > r^4 aold" is false for every r, NaN at r = 0 included)
-template <int MODE, bool EAGER = false>
-__device__ __forceinline__ void node_tests(const GravParams &gp, const NodeGeo &g, const Src4 &mom, const bool special,
-                                           const bool any_special /* wave-uniform */, const double eff,
-                                           const double l2, const double inside, const double ml2, const double px, const double py,
-                                           const double pz, const double aold, bool &discard, bool &open, bool &wr)
-{
-    double dx, dy, dz, cmax; // (cmax: see walk_target)
-    wr = false;
-    if(MODE == 0) {
-        cmax = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
-                    fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
-        dx = nearest_img(mom.x - px, gp.box, gp.invbox);
-        dy = nearest_img(mom.y - py, gp.box, gp.invbox);
-        dz = nearest_img(mom.z - pz, gp.box, gp.invbox);
-    }
-    else {
-        if(MODE == 1) {
-            const double kx = rint((g.cx - px) * gp.invbox);
-            const double ky = rint((g.cy - py) * gp.invbox);
-            const double kz = rint((g.cz - pz) * gp.invbox);
-            const double qx = fma(kx, gp.box, px), qy = fma(ky, gp.box, py), qz = fma(kz, gp.box, pz);
-            cmax = fmax(fmax(fabs(g.cx - qx), fabs(g.cy - qy)), fabs(g.cz - qz));
-            dx = mom.x - qx;
-            dy = mom.y - qy;
-            dz = mom.z - qz;
-            wr = (kx != 0.0) || (ky != 0.0) || (kz != 0.0);
-        }
-        else {
-            cmax = fmax(fmax(fabs(g.cx - px), fabs(g.cy - py)), fabs(g.cz - pz));
-            dx = mom.x - px;
-            dy = mom.y - py;
-            dz = mom.z - pz;
-        }
-        // (see walk_target.  A wave-uniform branch around per-lane selects: written as `if(special)` the block was flattened into
-        // the step by hipcc)
-        if(any_special) {
-            const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
-            dx = special ? fma(-jx, gp.box, mom.x - px) : dx;
-            dy = special ? fma(-jy, gp.box, mom.y - py) : dy;
-            dz = special ? fma(-jz, gp.box, mom.z - pz) : dz;
-            wr = wr || (special && ((jx != 0.0) || (jy != 0.0) || (jz != 0.0)));
-            if(MODE == 2) {
-                const double cm = fmax(fmax(fabs(nearest_img(g.cx - px, gp.box, gp.invbox)), fabs(nearest_img(g.cy - py, gp.box, gp.invbox))),
-                                       fabs(nearest_img(g.cz - pz, gp.box, gp.invbox)));
-                cmax = special ? cm : cmax;
-            }
-        }
-    }
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    if(EAGER) {
-        discard = (r2 > gp.rcut2) & (cmax > eff);
-        open = (ml2 > r2 * r2 * aold) | (l2 > r2 * gp.bhangle2) | (cmax < inside);
-    }
-    else {
-        discard = (r2 > gp.rcut2) && (cmax > eff);
-        open = ((!gp.use_bh) && (ml2 > r2 * r2 * aold)) || (l2 > r2 * gp.bhangle2) || (cmax < inside);
-    }
-}
-
+// MODE of the node tests: 0 NEAREST() per quantity (small boxes); 1 the node's periodic image k = rint((c - p)/Box) is applied to the
+// target (FASTWRAP); 2 plain differences, for targets farther than Rcut + Box/500 from every face of the box.  MODE 2 is exact: a
+// node that is not discarded has |c - p| <= Rcut + len/2 per axis on its nearest image (its centre of mass lies inside it), which for
+// such a target is the unwrapped image; and a node that is discarded with nearest-image distances is discarded with the (larger or
+// equal) unwrapped ones.  In modes 1 and 2 the centre of mass of a node can sit on another image than its centre only if
+// Rcut + len >= Box/2 (the root and its children): those (`special`) take NEAREST() for both, exactly as gravshort-tree.c:299-300 does.
+//
 // The same tests with every comparison taken as a lane mask (k_walk_lists8).  The Barnes-Hut switch is folded into aold by the caller
 // (aold = +inf: "mass l^2 > r^4 aold" is false for every r, NaN at r = 0 included).
 template <int MODE>
@@ -525,7 +213,7 @@ __device__ __forceinline__ void node_test_masks(const GravParams &gp, const Node
             dy = mom.y - py;
             dz = mom.z - pz;
         }
-        if(any_special) { // (the root and its children: exact images for the centre and the centre of mass, see walk_target)
+        if(any_special) { // (the root and its children: exact images for the centre and the centre of mass, see above)
             const double jx = rint((mom.x - px) * gp.invbox), jy = rint((mom.y - py) * gp.invbox), jz = rint((mom.z - pz) * gp.invbox);
             dx = special ? fma(-jx, gp.box, mom.x - px) : dx;
             dy = special ? fma(-jy, gp.box, mom.y - py) : dy;
@@ -545,262 +233,16 @@ __device__ __forceinline__ void node_test_masks(const GravParams &gp, const Node
     m_open = __builtin_amdgcn_ballot_w64(ml2 > r2 * r2 * aold) | __builtin_amdgcn_ballot_w64(l2 > r2 * gp.bhangle2) | __builtin_amdgcn_ballot_w64(cmax < inside);
 }
 
-// state of one target of a pair (group-uniform except wrap_lane)
-struct PairTarget {
-    double px, py, pz, aold;
-    unsigned off;  // entry offset of the target's interleaved lists from the wave's list base: chunk half * cap * 8 + slot * 8
-    int nleaf, nnode;
-    unsigned nsteps, c_pp, c_vis, c_used;
-    bool wrap_lane, wrapped;
-};
-
-// stack entry: first child << 5 | (children - 1) << 2 | mask of the targets (needs nnodes < 2^27: checked by the launcher)
-template <bool COUNT, int MODE, bool O32>
-__device__ __forceinline__ bool walk_pair(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ stack,
-                                          const int cap, const int lane, const int s, const int gshift, const unsigned live0, PairTarget &A,
-                                          PairTarget &B, unsigned &overflowed, const unsigned guard_max, unsigned *__restrict__ ctl, unsigned &st_a,
-                                          unsigned &st_al)
-{
-    const unsigned below = (1u << s) - 1u;
-    unsigned live = live0; // targets still walking (bit 0: A, bit 1: B)
-    int sp = 0;
-    if(live) {
-        if(s == 0)
-            stack[0] = live; // the root: first 0, one "child"
-        sp = 1;
-    }
-    unsigned guard = 0, steps2 = 0;
-    bool err = false;
-    for(;;) {
-        const bool can = sp > 0;
-        if(!any_lane(can))
-            break;
-        if(++guard > guard_max || any_lane(sp + 8 > STK)) {
-            err = true;
-            break;
-        }
-        const unsigned range = can ? stack[sp - 1] : 0u;
-        unsigned m2 = range & live; // (live < 4)
-        // a target whose step might not fit its lists goes to the fallback kernel (the test k_walk_lists makes before each of a
-        // target's steps); its mate walks on, and the entries it leaves on the stack alone are popped unused
-        // (rare: a wave-uniform branch keeps the mask arithmetic off the common path)
-        if(any_lane(A.nleaf + A.nnode + 8 > cap || B.nleaf + B.nnode + 8 > cap)) {
-            const unsigned ov = (((A.nleaf + A.nnode + 8 > cap) ? 1u : 0u) | ((B.nleaf + B.nnode + 8 > cap) ? 2u : 0u)) & m2;
-            overflowed |= ov;
-            live &= ~ov;
-            m2 &= ~ov;
-        }
-        const int nch = m2 ? (int)((range >> 2) & 7u) + 1 : 0;
-        const bool mine = s < nch;
-        const unsigned my = mine ? (range >> 5) + (unsigned)s : 0u;
-        const NodeGeo g = ld<O32>(tv.geoB, my);
-        const Src4 mom = ld<O32>(tv.momB, my);
-        const NodeLinkB lk = ld<O32>(tv.linkB, my);
-        steps2 += (m2 & 1u) | ((m2 & 2u) << 15); // both targets' step counts in one word (A: low half, B: high half; < 2^16 each)
-        const double eff = fma(0.5, g.len, gp.rcut);
-        const double l2 = g.len * g.len;
-        const double inside = 0.6 * g.len;
-        const double ml2 = mom.m * l2;
-        const bool special = MODE != 0 && mine && my <= 8u;
-        const bool any_special = MODE != 0 && any_lane(special);
-        bool dA, oA, wA, dB, oB, wB;
-        node_tests<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, A.px, A.py, A.pz, A.aold, dA, oA, wA);
-        node_tests<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, B.px, B.py, B.pz, B.aold, dB, oB, wB);
-        const bool keepA = mine && (m2 & 1u) && !dA, keepB = mine && (m2 & 2u) && !dB;
-        const bool isleaf = lk.pcount > 0, isint = lk.pcount <= 0 && lk.nchild > 0;
-        const bool nodeA = keepA && !oA, nodeB = keepB && !oB;
-        const bool leafA = keepA && oA && isleaf, leafB = keepB && oB && isleaf;
-        const unsigned pushm = ((keepA && oA && isint) ? 1u : 0u) | ((keepB && oB && isint) ? 2u : 0u);
-        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-        const unsigned gm_leafA = (unsigned)((__builtin_amdgcn_ballot_w64(leafA) >> gshift) & 0xffull);
-        const unsigned gm_leafB = (unsigned)((__builtin_amdgcn_ballot_w64(leafB) >> gshift) & 0xffull);
-        const unsigned gm_nodeA = (unsigned)((__builtin_amdgcn_ballot_w64(nodeA) >> gshift) & 0xffull);
-        const unsigned gm_nodeB = (unsigned)((__builtin_amdgcn_ballot_w64(nodeB) >> gshift) & 0xffull);
-        const unsigned gm_push = (unsigned)((__builtin_amdgcn_ballot_w64(pushm != 0) >> gshift) & 0xffull);
-        if(leafA) {
-            const unsigned e = (unsigned)(A.nleaf + __popc(gm_leafA & below));
-            st32(Lw, A.off + ((e >> 3) << 6) + (e & 7u), ent_val);
-        }
-        if(leafB) {
-            const unsigned e = (unsigned)(B.nleaf + __popc(gm_leafB & below));
-            st32(Lw, B.off + ((e >> 3) << 6) + (e & 7u), ent_val);
-        }
-        if(nodeA) {
-            const unsigned e = (unsigned)(cap - 1 - (A.nnode + __popc(gm_nodeA & below)));
-            st32(Lw, A.off + ((e >> 3) << 6) + (e & 7u), my);
-        }
-        if(nodeB) {
-            const unsigned e = (unsigned)(cap - 1 - (B.nnode + __popc(gm_nodeB & below)));
-            st32(Lw, B.off + ((e >> 3) << 6) + (e & 7u), my);
-        }
-        if(pushm)
-            stack[sp - 1 + __popc(gm_push & below)] = ((unsigned)lk.firstchild << 5) | ((unsigned)(lk.nchild - 1) << 2) | pushm;
-        A.nleaf += __popc(gm_leafA);
-        B.nleaf += __popc(gm_leafB);
-        A.nnode += __popc(gm_nodeA);
-        B.nnode += __popc(gm_nodeB);
-        sp += __popc(gm_push) - (can ? 1 : 0);
-        if(MODE != 0) {
-            A.wrap_lane = A.wrap_lane || (wA && (leafA || nodeA));
-            B.wrap_lane = B.wrap_lane || (wB && (leafB || nodeB));
-        }
-        if(COUNT) {
-            A.c_vis += (mine && (m2 & 1u)) ? 1u : 0u;
-            B.c_vis += (mine && (m2 & 2u)) ? 1u : 0u;
-            A.c_used += nodeA ? 1u : 0u;
-            B.c_used += nodeB ? 1u : 0u;
-            A.c_pp += leafA ? (unsigned)lk.pcount : 0u;
-            B.c_pp += leafB ? (unsigned)lk.pcount : 0u;
-            if(m2 && s == 0) {
-                st_a++;
-                st_al += nch;
-            }
-        }
-    }
-    A.nsteps = steps2 & 0xffffu;
-    B.nsteps = steps2 >> 16;
-    if(err) {
-        if(lane == 0)
-            atomicExch(&ctl[1], (guard > guard_max) ? 1u : 4u);
-        return false;
-    }
-    if(MODE != 0) {
-        A.wrapped = ((__builtin_amdgcn_ballot_w64(A.wrap_lane) >> gshift) & 0xffull) != 0;
-        B.wrapped = ((__builtin_amdgcn_ballot_w64(B.wrap_lane) >> gshift) & 0xffull) != 0;
-    }
-    return true;
-}
-
-// one wave = 16 consecutive targets (two chunks of the list layout k_walk_eval reads): group g walks targets 2g and 2g + 1 of them
-template <bool COUNT, bool FASTWRAP, bool O32, int BLK>
-__global__ void __launch_bounds__(256, BLK) k_walk_lists2(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
-                                                      int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
-                                                      unsigned *__restrict__ ctl, int *__restrict__ ovf)
-{
-    __shared__ unsigned s_stack[4 * 8 * STK];
-    set_wave_prio(io.list_prio);
-    const int lane = threadIdx.x & 63;
-    const int grp = lane >> 3, s = lane & 7;
-    const int gshift = grp * 8;
-    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * STK;
-    const unsigned nunits = (unsigned)((nslots + 15) / 16);
-    const ChunkIter it(nunits);
-    const unsigned guard_max = (unsigned)min((long long)(64ll * (tv.nnodes + 1024)), 0x7fffffffll);
-    const double face = gp.rcut + 0.002 * gp.box;
-    unsigned n_pp = 0, n_vis = 0, n_used = 0, st_a = 0, st_al = 0;
-
-    for(unsigned unit = it.lo + it.first; unit < it.hi; unit += it.stride) {
-        PairTarget T[2];
-        int ci[2];
-        unsigned live = 0;
-        bool near_face = false;
-        const int64_t rel0 = (int64_t)unit * 16 + 2 * grp;
-#pragma unroll
-        for(int k = 0; k < 2; k++) {
-            PairTarget &t = T[k];
-            const int64_t rel = rel0 + k;
-            t.px = t.py = t.pz = t.aold = 0;
-            t.nleaf = t.nnode = 0;
-            t.nsteps = t.c_pp = t.c_vis = t.c_used = 0;
-            t.wrap_lane = t.wrapped = false;
-            t.off = (unsigned)(grp >> 2) * (unsigned)cap * 8u + (unsigned)(((2 * grp + k) & 7) * 8);
-            ci[k] = -1;
-            if(rel < nslots) {
-                live |= 1u << k;
-                const int64_t slot = slot0 + rel;
-                const int c = io.targets ? io.targets[slot] : tv.order[slot];
-                ci[k] = c;
-                t.px = io.pos[3 * (int64_t)c + 0];
-                t.py = io.pos[3 * (int64_t)c + 1];
-                t.pz = io.pos[3 * (int64_t)c + 2];
-                double old = 0;
-                if(io.oldacc)
-                    old = io.oldacc[c];
-                else if(io.prev_accel) { // grav_get_abs_accel, gravshort.h:70-80
-                    double s2 = 0;
-                    for(int j = 0; j < 3; j++) {
-                        const double a = io.prev_accel[3 * (int64_t)c + j] + (io.gravpm ? io.gravpm[3 * (int64_t)c + j] : 0.0);
-                        s2 += a * a;
-                    }
-                    old = sqrt(s2) / gp.G;
-                }
-                t.aold = gp.errtol * old;
-                near_face = near_face || fmin(fmin(t.px, t.py), t.pz) < face || fmax(fmax(t.px, t.py), t.pz) > gp.box - face;
-            }
-        }
-        unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)unit) * (size_t)cap * 16;
-        unsigned overflowed = 0;
-        bool ok;
-        if(FASTWRAP) {
-            if(!any_lane(near_face))
-                ok = walk_pair<COUNT, 2, O32>(tv, gp, L, stack, cap, lane, s, gshift, live, T[0], T[1], overflowed, guard_max, ctl, st_a, st_al);
-            else
-                ok = walk_pair<COUNT, 1, O32>(tv, gp, L, stack, cap, lane, s, gshift, live, T[0], T[1], overflowed, guard_max, ctl, st_a, st_al);
-        }
-        else
-            ok = walk_pair<COUNT, 0, O32>(tv, gp, L, stack, cap, lane, s, gshift, live, T[0], T[1], overflowed, guard_max, ctl, st_a, st_al);
-        if(!ok)
-            return;
-#pragma unroll
-        for(int k = 0; k < 2; k++) {
-            const PairTarget &t = T[k];
-            const bool valid = (live >> k) & 1u, overflow = (overflowed >> k) & 1u;
-            const int64_t rel = rel0 + k;
-            if(valid && s == 0) {
-                if(io.cost)
-                    io.cost[ci[k]] = (float)(8 * (overflow ? cap : t.nleaf) + t.nnode + 8 * (int)t.nsteps);
-                if(overflow) {
-                    counts[rel] = make_int2(-1, 0);
-                    ovf[atomicAdd(&ctl[0], 1u)] = ci[k];
-                }
-                else {
-                    counts[rel] = make_int2(t.nleaf | (t.wrapped ? (1 << 30) : 0), t.nnode);
-                    if((unsigned)(t.nleaf + t.nnode) > ctl[2])
-                        atomicMax(&ctl[2], (unsigned)(t.nleaf + t.nnode));
-                }
-            }
-            if(COUNT && !overflow) {
-                n_pp += t.c_pp;
-                n_vis += t.c_vis;
-                n_used += t.c_used;
-            }
-        }
-    }
-    if(COUNT) {
-        unsigned long long c0 = n_pp, c1 = n_vis, c2 = n_used, c3 = st_a, c4 = st_al;
-        for(int off = 32; off > 0; off >>= 1) {
-            c0 += __shfl_down(c0, off);
-            c1 += __shfl_down(c1, off);
-            c2 += __shfl_down(c2, off);
-            c3 += __shfl_down(c3, off);
-            c4 += __shfl_down(c4, off);
-        }
-        if(lane == 0) {
-            atomicAdd(&io.counters[0], c0);
-            atomicAdd(&io.counters[1], c1);
-            atomicAdd(&io.counters[2], c2);
-            atomicAdd(&io.counters[3], c3);
-            atomicAdd(&io.counters[4], c4);
-        }
-    }
-}
-
 // ---- list construction with ONE traversal per wave: 8 targets share a frontier, one node per lane ---------------------------------
-// k_walk_lists / k_walk_lists2 spend two thirds of their instructions on bookkeeping that is repeated per group of 8 lanes and step
-// (ballot -> group mask -> prefix count -> predicated append, five times per step) and leave half of their lanes idle (a step tests
-// the <= 8 children of ONE node with 8 lanes).  Here the 64 lanes of a wave hold 64 DIFFERENT pending nodes of the union of the walks
-// of the wave's 8 targets (tree-order neighbours: leaf-mates mostly), popped from a wave-shared frontier in LDS whose entries carry
-// the mask of the targets that reached the node.  The wave then loops over its targets: target t's position and opening parameter
-// are wave-uniform (scalar registers), every lane applies the reference's two tests to ITS node for target t
-// (gravshort-tree.c:198-241; node_tests above, unchanged), and the three outcomes are wave-wide ballots: the leaf / node entries
-// of target t are appended by all lanes at once (position = count + v_mbcnt of the ballot: 2 instructions for 64 nodes instead of
-// ~10 per 8), the counts advance by s_bcnt1, the push mask of a lane collects the targets that open its node.  After the 8 targets
-// the opened internal nodes' children go back to the frontier (one entry per child: a prefix sum over the lanes by four ballots).
+// The 64 lanes of a wave hold 64 DIFFERENT pending nodes of the union of the walks of the wave's 8 targets (tree-order neighbours:
+// leaf-mates mostly), popped from a wave-shared frontier in LDS whose entries carry the mask of the targets that reached the node.
+// The wave then loops over its targets: target t's position and opening parameter are wave-uniform, every lane applies the
+// reference's two tests to ITS node for target t (gravshort-tree.c:198-241; node_test_masks above), and the outcomes are lane
+// masks: the entries of target t are appended by all lanes at once (position = count + v_mbcnt of the mask), the counts advance by
+// s_bcnt1, the push mask of a lane collects the targets that open its node.  After the 8 targets the opened internal nodes' children
+// go back to the frontier (one entry per child: a prefix sum over the lanes by four ballots).
 // Per target the set of nodes tested and the outcome of every test are exactly those of its own walk (a node reaches the frontier
-// with bit t set iff target t opened its parent), only the ORDER of the list entries differs from k_walk_lists' (so the sums of
-// k_walk_eval differ by rounding between the two list kernels; the interaction counters are equal).
-// List layout of this kernel (CONTIG in k_walk_eval): target t of chunk u owns lists[(u * 8 + t) * cap ...], leaf entries from 0 up,
-// node entries from cap - 1 down - the 64 lanes of an append write one contiguous run.
+// with bit t set iff target t opened its parent); the ORDER of a target's list entries depends on its 7 wave-mates.
 constexpr int QCAP = 1024; // frontier entries per wave (node index 4 B + target mask 1 B); a wave that would exceed it hands its targets to the fallback
 
 __device__ __forceinline__ unsigned mbcnt64(const unsigned long long b)
@@ -817,7 +259,7 @@ struct WaveTargets {
 };
 
 // returns false on an internal error (loop guard)
-template <bool COUNT, int MODE, bool O32>
+template <bool COUNT, int MODE, bool O32, int KX>
 __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ q_node,
                                            unsigned char *__restrict__ q_mask, const double *__restrict__ s_tgt, const int cap, const int lane,
                                            const unsigned live0, WaveTargets &T, unsigned &overflowed, bool &wrapped, unsigned (&c_pp)[8],
@@ -859,6 +301,10 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const bool special = MODE != 0 && valid && my <= 8u;
         const bool any_special = MODE != 0 && any_lane(special);
         const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+        // the record of the source array a single-source entry of this lane's node names: the node's moments, or (an opened leaf of at
+        // most KX particles) its first particle
+        const bool small = KX > 0 && lk.pcount > 0 && lk.pcount <= KX;
+        const unsigned one_val = small ? (unsigned)lk.pstart : (unsigned)tv.mom_off + my;
         unsigned openmask = 0;
         if(COUNT) {
             st_a++;
@@ -869,10 +315,14 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         // once per wave on those masks by the scalar unit; a mask comes back as the predicate of a store through inverse_ballot (it
         // becomes the exec mask: no vector instruction either).  Written with per-lane booleans, hipcc materialised every && / || as
         // v_cndmask / v_and chains: 45 - 50 vector instructions per pass where this form needs ~35.
-        // A target gains at most 64 entries per pass (one per lane): only when some list is that close to its capacity are the
+        // A target gains at most 64 * max(KX, 1) entries per pass: only when some list is that close to its capacity are the
         // appends CHECKED one by one.
         const unsigned long long m_leafnode = __builtin_amdgcn_ballot_w64(lk.pcount > 0);
         const unsigned long long m_intnode = ~m_leafnode & __builtin_amdgcn_ballot_w64(lk.nchild > 0);
+        // leaves that are expanded into single sources, and the bit planes of their particle count - 1
+        const unsigned long long m_small = KX > 0 ? __builtin_amdgcn_ballot_w64(small) : 0ull;
+        const unsigned long long m_c0 = KX > 1 ? __builtin_amdgcn_ballot_w64(small && ((lk.pcount - 1) & 1)) : 0ull;
+        const unsigned long long m_c1 = KX > 2 ? __builtin_amdgcn_ballot_w64(small && ((lk.pcount - 1) & 2)) : 0ull;
         auto pass = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
@@ -891,9 +341,17 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 node_test_masks<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
                 const unsigned long long keep = m_act & ~m_discard;
                 const unsigned long long bn = keep & ~m_open;              // used unopened
-                const unsigned long long bl = keep & m_open & m_leafnode;  // opened leaves
+                const unsigned long long bo = keep & m_open & m_leafnode;  // opened leaves
                 const unsigned long long bpush = keep & m_open & m_intnode;
-                const int kl = __builtin_popcountll(bl), kn = __builtin_popcountll(bn);
+                const unsigned long long bl = bo & ~m_small;               // ... that get a leaf entry
+                const unsigned long long bx = bn | (bo & m_small);         // lanes with single-source entries: 1 + (count - 1) each
+                const unsigned long long q0 = bo & m_c0, q1 = bo & m_c1;
+                const int kl = __builtin_popcountll(bl);
+                int kn = __builtin_popcountll(bx);
+                if(KX > 1)
+                    kn += __builtin_popcountll(q0);
+                if(KX > 2)
+                    kn += 2 * __builtin_popcountll(q1);
                 if(CHECKED && T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
                     overflowed |= 1u << t;
                     live &= ~(1u << t);
@@ -902,25 +360,40 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 unsigned *__restrict__ Lt = Lw + (unsigned)(t * cap); // (wave-uniform base)
                 if(__builtin_amdgcn_inverse_ballot_w64(bl)) // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
                     st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, (unsigned)T.nleaf[t])), ent_val);
-                if(__builtin_amdgcn_inverse_ballot_w64(bn))
-                    st32(Lt, (unsigned)(cap - 1 - T.nnode[t]) - mbcnt64(bn), my);
+                {
+                    // single sources, from the top of the list down: entries of the lanes below this one
+                    unsigned below = mbcnt64(bx);
+                    if(KX > 1)
+                        below = __builtin_amdgcn_mbcnt_hi((unsigned)(q0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)q0, below));
+                    if(KX > 2)
+                        below += 2u * mbcnt64(q1);
+                    const unsigned at = (unsigned)(cap - 1 - T.nnode[t]) - below;
+                    if(__builtin_amdgcn_inverse_ballot_w64(bx))
+                        st32(Lt, at, one_val);
+                    if(KX > 1 && __builtin_amdgcn_inverse_ballot_w64(q0 | q1)) // count >= 2
+                        st32(Lt, at - 1u, one_val + 1u);
+                    if(KX > 2 && __builtin_amdgcn_inverse_ballot_w64(q1)) // count >= 3
+                        st32(Lt, at - 2u, one_val + 2u);
+                    if(KX > 2 && __builtin_amdgcn_inverse_ballot_w64(q0 & q1)) // count == 4
+                        st32(Lt, at - 3u, one_val + 3u);
+                }
                 T.nleaf[t] += kl;
                 T.nnode[t] += kn;
                 maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
                 openmask |= __builtin_amdgcn_inverse_ballot_w64(bpush) ? (1u << t) : 0u;
                 // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children
                 if(MODE == 1 || (MODE == 2 && any_special))
-                    wmask |= m_wrap & (bl | bn);
+                    wmask |= m_wrap & (bo | bn);
                 if(COUNT) {
                     T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
-                    T.c_used[t] += (unsigned)kn;
-                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl) ? (unsigned)lk.pcount : 0u;
+                    T.c_used[t] += (unsigned)__builtin_popcountll(bn);
+                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bo) ? (unsigned)lk.pcount : 0u;
                 }
                 // (the 8 targets' tests are independent: left alone, hipcc interleaves them and runs out of registers)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if(maxused + 64 > cap)
+        if(maxused + 64 * (KX > 1 ? KX : 1) > cap)
             pass(std::true_type{});
         else
             pass(std::false_type{});
@@ -954,8 +427,8 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
 }
 
 // one wave = one chunk of k_walk_eval (8 consecutive targets)
-template <bool COUNT, bool FASTWRAP, bool O32, int BLK>
-__global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
+template <bool COUNT, bool FASTWRAP, bool O32, int KX>
+__global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
                                                       int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
                                                       unsigned *__restrict__ ctl, int *__restrict__ ovf)
 {
@@ -997,7 +470,7 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, con
                 }
                 old = sqrt(s2) / gp.G;
             }
-            // (Barnes-Hut walk: the relative criterion "mass l^2 > r^4 aold" must never hold - node_tests<., EAGER>)
+            // (Barnes-Hut walk: the relative criterion "mass l^2 > r^4 aold" must never hold)
             vaold = gp.use_bh ? __builtin_inf() : gp.errtol * old;
         }
         const bool near_face = tvalid && (fmin(fmin(vx, vy), vz) < face || fmax(fmax(vx, vy), vz) > gp.box - face);
@@ -1020,12 +493,12 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, con
         bool ok;
         if(FASTWRAP) {
             if(!any_lane(near_face))
-                ok = walk_wave8<COUNT, 2, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+                ok = walk_wave8<COUNT, 2, O32, KX>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
             else
-                ok = walk_wave8<COUNT, 1, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+                ok = walk_wave8<COUNT, 1, O32, KX>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
         }
         else
-            ok = walk_wave8<COUNT, 0, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+            ok = walk_wave8<COUNT, 0, O32, KX>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
         if(!ok)
             return;
         int nl = 0, nn = 0;
@@ -1037,9 +510,9 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, con
             }
         if(tvalid) {
             const bool overflow = (overflowed >> lane) & 1u;
-            // the work this target causes in the two kernels: 8 lanes per leaf entry and 1 per node entry in the evaluation, and about
-            // as many node tests as it has entries in the list construction (k_walk_lists / k_walk_lists2 count 8 per traversal step
-            // instead; the measure only has to be proportional to the time spent: domain.c:611)
+            // the work this target causes in the two kernels: 8 lanes per leaf entry and 1 per single source in the evaluation, and about
+            // as many node tests as it has entries in the list construction (the measure only has to be proportional to the time
+            // spent: domain.c:611)
             if(io.cost)
                 io.cost[ci] = (float)(8 * (overflow ? cap : nl) + nn + 3 * (nl + nn));
             if(overflow) {
@@ -1092,8 +565,8 @@ __global__ void __launch_bounds__(256, BLK) k_walk_lists8(const TreeView tv, con
 // source (short leaf, list exhausted) reads a zero-mass padding record behind the tree's source array instead: its pair
 // evaluates to exactly zero, so the accumulators are updated unconditionally (a conditional update makes hipcc keep a
 // renamed copy of the four accumulators per unrolled stage).
-// CONTIG: the lists of group g start at L + g * cap and are contiguous (k_walk_lists8); otherwise the interleaved layout above.
-template <bool POT, bool WRAP, bool O32, bool CONTIG>
+// The lists of group g start at L + g * cap (layout: top of this file).
+template <bool POT, bool WRAP, bool O32>
 __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
                                            const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
                                            const double py, const double pz, const double *__restrict__ s_wtab,
@@ -1123,8 +596,8 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // stage loop is deliberately not unrolled beyond that: every unrolled stage carries its own copy of the (rare)
         // softened branch, and those copies are what drives register pressure and code size.
         // index of leaf entry e0 + s (e0 a multiple of 8)
-        const unsigned ls = CONTIG ? (unsigned)((gshift >> 3) * cap + s) : (unsigned)(gshift + s);
-#define MPG_LEAF_AT(E0) (CONTIG ? ls + (unsigned)(E0) : (((unsigned)(E0) >> 3) << 6) + ls)
+        const unsigned ls = (unsigned)((gshift >> 3) * cap + s);
+#define MPG_LEAF_AT(E0) (ls + (unsigned)(E0))
         unsigned ent = (s < nleaf) ? ld<true>(L, MPG_LEAF_AT(0)) : empty;
         unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(8)) : empty;
         Src4 A, B;
@@ -1145,21 +618,22 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
             ent_n = ent_nn;
         }
     }
-    // ---- node entries (level-order indices): lane s takes entry r0 + s; entries two batches ahead, moments one
+    // ---- single sources (records of the source array: node moments, particles of small leaves): lane s takes entry r0 + s; entries
+    // two batches ahead, records one
     if(any_lane(nnode > 0)) {
-        const unsigned NONE = (unsigned)tv.nnodes; // a zero-mass padding record behind the moments (TreeBuilder::make_level_order)
+        const unsigned NONE = zero_src;
         // index of node entry r0 + s counted from the top of the list (r0 a multiple of 8)
-        const unsigned top = CONTIG ? (unsigned)((gshift >> 3) * cap + cap - 1 - s) : (((unsigned)(cap - 8) >> 3) << 6) + (unsigned)(gshift + 7 - s);
-#define MPG_NODE_AT(R0) (CONTIG ? top - (unsigned)(R0) : top - (((unsigned)(R0) >> 3) << 6))
+        const unsigned top = (unsigned)((gshift >> 3) * cap + cap - 1 - s);
+#define MPG_NODE_AT(R0) (top - (unsigned)(R0))
         unsigned ne = (s < nnode) ? ld<true>(L, MPG_NODE_AT(0)) : NONE;
         unsigned ne_n = (8 + s < nnode) ? ld<true>(L, MPG_NODE_AT(8)) : NONE;
-        Src4 sc = ld<O32>(tv.momB, ne);
+        Src4 sc = ld<O32>(tv.src, ne);
         for(int r0 = 0;; r0 += 8) {
             if(!any_lane(r0 < nnode))
                 break;
             ne = ne_n;
             ne_n = (r0 + 16 + s < nnode) ? ld<true>(L, MPG_NODE_AT(r0 + 16)) : NONE;
-            const Src4 sc_n = ld<O32>(tv.momB, ne);
+            const Src4 sc_n = ld<O32>(tv.src, ne);
             MPG_EVAL(sc);
             sc = sc_n;
         }
@@ -1170,7 +644,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
 #undef MPG_NODE_AT
 }
 
-template <bool POT, bool FASTWRAP, bool O32, bool CONTIG, int BLK>
+template <bool POT, bool FASTWRAP, bool O32, int BLK>
 __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
                                                     const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
 {
@@ -1220,9 +694,9 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
         const unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8; // wave-uniform
         double ax = 0, ay = 0, az = 0, pot = 0;
         if(!FASTWRAP || any_lane(wrapped)) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
-            eval_lists<POT, true, O32, CONTIG>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         else
-            eval_lists<POT, false, O32, CONTIG>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
         // reduce the partial sums over the 8 lanes of the group
         for(int off = 1; off < 8; off <<= 1) {
             ax += __shfl_xor(ax, off);
@@ -1279,20 +753,13 @@ int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_p
 template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
-    // List construction: ws.split_lists_mode 2 (default) one traversal per wave of 8 targets (k_walk_lists8), 1 pairs of targets per
-    // group of 8 lanes (k_walk_lists2; its stack entries hold 27-bit node indices), 0 one target per group (k_walk_lists).  Modes 0
-    // and 1 write the same lists entry for entry (bit-identical results); mode 2 writes the same entries in another order and in the
-    // contiguous layout.  MPG_LISTS_MODE overrides (experiments; read once per process).
-    static const int mode_env = getenv("MPG_LISTS_MODE") ? atoi(getenv("MPG_LISTS_MODE")) : -1;
-    int mode = mode_env >= 0 ? mode_env : ws.split_lists_mode;
-    if(mode == 1 && tv.nnodes >= (1ll << 27))
-        mode = 0;
-    const bool pair = mode == 1, contig = mode == 2;
-    static const int l8_blk = getenv("MPG_LISTS8_BLOCKS") ? atoi(getenv("MPG_LISTS8_BLOCKS")) : 6; // resident blocks per CU k_walk_lists8 is compiled for
-    auto kl = contig ? (l8_blk == 4 ? k_walk_lists8<COUNT, FASTWRAP, O32, 4> : l8_blk == 5 ? k_walk_lists8<COUNT, FASTWRAP, O32, 5> : k_walk_lists8<COUNT, FASTWRAP, O32, 6>)
-              : pair ? k_walk_lists2<COUNT, FASTWRAP, O32, 5>
-                     : k_walk_lists<COUNT, FASTWRAP, O32, 6>;
-    auto ke = contig ? k_walk_eval<POT, FASTWRAP, O32, true, MPG_EVAL_BLOCKS> : k_walk_eval<POT, FASTWRAP, O32, false, MPG_EVAL_BLOCKS>;
+    // Leaves of at most KX particles are listed as single sources (top of this file): ws.split_leaf_expand (0, 1, 2 or 4; default 2),
+    // MPG_LEAF_EXPAND overrides (experiments; read once per process).  Counters and per-target interaction sets do not depend on it.
+    static const int kx_env = getenv("MPG_LEAF_EXPAND") ? atoi(getenv("MPG_LEAF_EXPAND")) : -1;
+    const int kx = kx_env >= 0 ? kx_env : ws.split_leaf_expand;
+    auto kl = kx <= 0 ? k_walk_lists8<COUNT, FASTWRAP, O32, 0> : kx == 1 ? k_walk_lists8<COUNT, FASTWRAP, O32, 1> : kx == 2 ? k_walk_lists8<COUNT, FASTWRAP, O32, 2>
+                                                                                                                      : k_walk_lists8<COUNT, FASTWRAP, O32, 4>;
+    auto ke = k_walk_eval<POT, FASTWRAP, O32, MPG_EVAL_BLOCKS>;
     const int cap = ws.split_cap;
     // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
     int64_t slice = (int64_t)(ws.split_bytes / ((size_t)cap * sizeof(unsigned))) / 2048 * 2048;
@@ -1333,8 +800,7 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         int2 *counts = ws.split_counts.p + (size_t)b * counts_sz;
         if(overlap && i >= 2)
             MPG_HIP(hipStreamWaitEvent(sl, ws.ev_eval[b], 0)); // the evaluation that read this buffer two slices ago is done
-        // (the pair kernel's waves take units of 16 targets)
-        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, pair ? (ns + 15) / 16 : nchunks, cpw)), dim3(256), 0, sl, tv, gp, io,
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks, cpw)), dim3(256), 0, sl, tv, gp, io,
                            lists, counts, cap, s0, ns, ws.ctr.p, ws.split_ovf.p);
         if(overlap) {
             MPG_HIP(hipEventRecord(ws.ev_lists[b], sl));
@@ -1357,8 +823,8 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
         return;
     MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
     ws.ctr.reserve(16);
-    // 32-bit byte offsets into the source and node arrays (32-byte records, padding included)?
-    const bool o32 = (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
+    // 32-bit byte offsets into the source and node arrays (32-byte records, both copies of the moments and the padding included)?
+    const bool o32 = (tv.npart + 2 * tv.nnodes + 64) * 32 < (1ll << 32);
 #define MPG_WS(P, C)                                                \
     do {                                                            \
         if(fastwrap) {                                              \

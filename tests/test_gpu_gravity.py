@@ -169,36 +169,29 @@ def test_walk_parity(pkg, engine, orc, ic, n, nmesh):
 
 
 @pytest.mark.parametrize("ic,n", [("s_clust", 48), ("s_zel", 40)])
-def test_list_kernels_agree(tmp_path, ic, n):
-    """The three list-construction kernels of the two-kernel walk (MPG_LISTS_MODE 0: one target per group of 8 lanes, 1: two tree-order
-    neighbours per group share one traversal, 2: the 8 targets of a wave share one frontier with one node per lane) take the same
-    per-target decisions.  Modes 0 and 1 write the same lists entry for entry: accelerations, potentials and the per-target walk
-    cost of three steps (Barnes-Hut walk, list-capacity adaptation with overflowing targets on the clustered set, relative criterion)
-    are equal bit for bit.  Mode 2 writes the same entries in another order: sums agree to rounding, and its per-target cost
-    (a measure of work for the domain decomposition) is proportional to that of modes 0 / 1.
-    (The knob is read once per process: three processes.)"""
+def test_leaf_expansion_levels_agree(tmp_path, ic, n):
+    """The two-kernel walk lists an opened leaf of at most KX particles as KX single sources instead of one leaf entry
+    (mpg_set_walk_leaf_expand; grav_walk_split.hip).  Whatever KX (0 = every leaf keeps its entry, 1, 2 = default, 4), the per-target
+    decisions are the reference's: interaction counters equal, accelerations and potentials of three steps (Barnes-Hut walk,
+    list-capacity adaptation with overflowing targets on the clustered set, relative criterion) equal to rounding (the order of
+    summation differs), and the per-target work measure handed to the domain decomposition stays proportional."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for mode in ("0", "1", "2"):
-        out = str(tmp_path / ("mode%s.npz" % mode))
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), out, ic, str(n)], capture_output=True, text=True,
-                           timeout=600, env=dict(os.environ, MPG_LISTS_MODE=mode))
-        assert r.returncode == 0, r.stderr[-2000:]
-        res.append(np.load(out))
-    assert set(res[0].files) == set(res[1].files) == set(res[2].files) and len(res[0].files) == 9
-    for k in res[0].files:
-        assert np.array_equal(res[0][k], res[1][k]), k
-    assert np.abs(res[0]["acc2"]).max() > 0 and res[0]["cost2"].min() > 0
+    out = str(tmp_path / "levels.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), out, ic, str(n)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = np.load(out)
+    assert len(res.files) == 4 * 3 * 4
     for step in range(3):
-        a0, a2 = res[0]["acc%d" % step], res[2]["acc%d" % step]
-        assert np.abs(a2 - a0).max() <= 1e-12 * np.abs(a0).mean() + 1e-13 * np.abs(a0).max(), step
-        p0, p2 = res[0]["pot%d" % step], res[2]["pot%d" % step]
-        assert np.abs(p2 - p0).max() <= 1e-12 * np.abs(p0).mean(), step
-        # the per-target work measure of mode 2 counts node tests by list entries instead of traversal steps: proportional, not equal
-        c0, c2 = res[0]["cost%d" % step], res[2]["cost%d" % step]
-        assert c2.min() > 0 and 0.6 < np.median(c2 / c0) < 1.6 and np.corrcoef(c0, c2)[0, 1] > 0.9, step
+        a0, p0, c0, n0 = (res["%s%d_k0" % (k, step)] for k in ("acc", "pot", "cost", "cnt"))
+        assert np.abs(a0).max() > 0 and c0.min() > 0 and n0.min() > 0
+        for kx in (1, 2, 4):
+            a, p_, c, n_ = (res["%s%d_k%d" % (k, step, kx)] for k in ("acc", "pot", "cost", "cnt"))
+            assert np.array_equal(n_, n0), (step, kx, n_, n0)
+            assert np.abs(a - a0).max() <= 1e-12 * np.abs(a0).mean() + 1e-13 * np.abs(a0).max(), (step, kx)
+            assert np.abs(p_ - p0).max() <= 1e-12 * np.abs(p0).mean(), (step, kx)
+            assert c.min() > 0 and 0.3 < np.median(c / c0) < 1.2 and np.corrcoef(c0, c)[0, 1] > 0.9, (step, kx)
 
 
 @pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (6, 512), (6, 40)])

@@ -33,10 +33,10 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     walks, cur = [], None
     for r in rows:
         nm = r["Kernel_Name"]
-        w = "k_walk_lists<" in nm or "k_walk_lists2<" in nm or "k_walk_lists8<" in nm or "k_walk_eval<" in nm or "k_walk_stream<" in nm
+        w = "k_walk_lists8<" in nm or "k_walk_eval<" in nm
         if w:
             if cur is None:
-                cur = dict(t0=int(r["Start_Timestamp"]), t1=0, count=("k_walk_lists<true" in nm or "k_walk_lists2<true" in nm or "k_walk_lists8<true" in nm), n=0)
+                cur = dict(t0=int(r["Start_Timestamp"]), t1=0, count=("k_walk_lists8<true" in nm), n=0)
             cur["t1"] = max(cur["t1"], int(r["End_Timestamp"]))
             cur["n"] += 1
         elif cur is not None and "rocclr" not in nm and "k_grav_walk" not in nm:
@@ -74,7 +74,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
 # MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
 # wide (16 B/lane) coalesced read stream -> doubled.  Collected in separate --pmc passes (tools/prof.sh).
 import json
-WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists<", "k_walk_lists2<", "k_walk_lists8<", "k_walk_eval<", "k_walk_stream<")}
+WALK_KERNELS = {"1": ("k_grav_walk<",), "4": ("k_grav_walk_coop<",), "6": ("k_walk_lists8<", "k_walk_eval<")}
 METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled "
           "(gfx950 correction for 16 B/lane reads, MI355X_MICROARCH.md section HBM); summed over the dispatches of one walk")
 
@@ -82,9 +82,9 @@ METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; K
 def is_count_build(kname):
     # the COUNT template flag (instrumented untimed pass) is the 2nd parameter of k_grav_walk*, the 1st of k_walk_lists
     targs = [a.strip() for a in kname.split("<")[-1].split(">")[0].split(",")]
-    if "k_walk_lists<" in kname or "k_walk_lists2<" in kname or "k_walk_lists8<" in kname:
+    if "k_walk_lists8<" in kname:
         return targs[0] == "true"
-    if "k_walk_eval<" in kname or "k_walk_stream<" in kname:
+    if "k_walk_eval<" in kname:
         return False
     return len(targs) > 1 and targs[1] == "true"
 
@@ -107,7 +107,7 @@ for var, pats in WALK_KERNELS.items():
             if ndisp:
                 # dispatches of the first kernel of the group per walk: 1 for kernels 1 and 4, ceil(N / 2^21) slices for 6
                 per_walk = int(os.environ.get("MPG_SLICES_PER_WALK", "1")) if var == "6" else 1   # 256^3 is one slice (list capacity 1024)
-                first = len(ndisp[pats[0]]) + (len(ndisp["k_walk_lists2<"]) + len(ndisp["k_walk_lists8<"]) if var == "6" else 0)   # (any list kernel opens a walk)
+                first = len(ndisp[pats[0]])   # (the list kernel opens a walk)
                 walks[name] += first / per_walk
     if walks["FETCH_SIZE"] and walks["WRITE_SIZE"]:
         fb = 2 * 1024 * tot["FETCH_SIZE"] / walks["FETCH_SIZE"]
