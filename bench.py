@@ -75,6 +75,8 @@ def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
          "walk_variant": variant, "list_capacity": list_cap, "targets_to_fallback_kernel": list_ovf,
          "children_per_node_step": round(cnt["node_lanes"] / max(cnt["node_steps"], 1), 2),
          "node_steps_per_launch": cnt["node_steps"], "node_lanes_per_launch": cnt["node_lanes"],
+         "leaf_entries_per_launch": cnt["int_steps"] if variant == 6 else None,
+         "node_entries_per_launch": cnt["int_lanes"] if variant == 6 else None,
          "note": "one launch = one short-range walk over all targets; the walk is bound by fp64 VALU issue (pairwise kernel with a "
                  "per-pair window-table lookup; MFMA does not apply), so frac = 38 flop x (N_pp + N_nodes_used) / t / 78.6 TFLOP/s; "
                  "hbm_measured_frac = PMC traffic / t / 8 TB/s; reuse = SURVEY 8(d) B_walk / PMC traffic"}

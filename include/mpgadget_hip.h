@@ -723,10 +723,6 @@ int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
 int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave);
 int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
 int mpg_set_walk_variant(mpg_engine *eng, int variant);
-/* two-kernel walk (variant 6): opened leaves of at most kx particles (0, 1, 2 = default, 4) enter a target's list of single sources
- * instead of its list of leaves.  The per-target decisions (gravshort-tree.c:198-241) and interaction sets do not depend on it; the
- * order of summation does. */
-int mpg_set_walk_leaf_expand(mpg_engine *eng, int kx);
 /* kernel in use (the explicit variant, or the default policy's pick: 6 for >= 4096 targets, else 1; 0 = no walk yet), kernel 6's current list capacity and
  * the number of targets its last walk handed to the fallback kernel (either output may be NULL) */
 int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsigned *last_overflow);

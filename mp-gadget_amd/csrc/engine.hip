@@ -2111,14 +2111,6 @@ int mpg_get_walk_choice(mpg_engine *eng, int *variant, int *list_capacity, unsig
     API_END
 }
 
-int mpg_set_walk_leaf_expand(mpg_engine *eng, int kx)
-{
-    API_BEGIN
-    MPG_CHECK(eng && (kx == 0 || kx == 1 || kx == 2 || kx == 4), "walk leaf expansion must be 0, 1, 2 or 4 particles");
-    eng->w3.split_leaf_expand = kx;
-    API_END
-}
-
 int mpg_set_walk_variant(mpg_engine *eng, int variant)
 {
     API_BEGIN

@@ -37,7 +37,6 @@ struct WalkScratch {
     DevBuf<int2> split_counts;    // [slice] {leaf entries | wrapped << 30, node entries} or {-1, 0}: overflowed
     DevBuf<int> split_ovf;        // caller indices of overflowed targets
     int split_cap = 512;          // list entries per target (multiple of 8)
-    int split_leaf_expand = 2;    // opened leaves of at most this many particles are listed as single sources (0, 1, 2, 4): grav_walk_split.hip
     int split_slice = 1 << 25;    // most targets per list-construction / evaluation kernel pair.  Measured at 256^3 Zel'dovich
                                   // (profiles/r02b_walk_knobs.txt): slices of 2^21 / 2^22 / 2^23 targets with the two kernels overlapped on
                                   // two streams 113.8 / 110.6 / 105.9 ms per step, the same slices one after the other 104.6 (2^22) /

@@ -7,23 +7,14 @@
 //
 //   k_walk_lists8  one traversal per wave of 8 targets (tree-order neighbours): the 64 lanes hold 64 different pending nodes of the
 //                  union of the 8 walks, the wave loops over its targets and every lane applies the reference's two tests to its
-//                  node for that target.  Written per target to HBM: the opened leaves with more than KX particles (4-byte entries:
-//                  first particle << 3 | count-1) and a list of SINGLE SOURCES (4-byte record numbers of the source array): the
-//                  nodes used unopened (record mom_off + level-order index: their moments) and the particles of the opened
-//                  leaves with <= KX particles, one entry each.  No force arithmetic, no window tables.
+//                  node for that target.  Written per target to HBM: the opened leaves (4-byte entries: first particle << 3 |
+//                  count-1) and the nodes used unopened (4-byte level-order indices).  No force arithmetic, no window tables.
 //   k_walk_eval    8 lanes per target stream the target's lists: for a leaf entry lane s evaluates source s (one
-//                  coalesced 256-byte read per group), single sources are taken 8 at a time.  No traversal state: the
+//                  coalesced 256-byte read per group), node entries are taken 8 at a time.  No traversal state: the
 //                  kernel is a pure fp64 pair loop fed by sequential list reads.
 //
-// Why small leaves are expanded (round 3): a leaf entry occupies the 8 lanes of a group for one pair evaluation whatever its
-// particle count, and the reference's tree (a cell is split as soon as it holds more than 8 particles) has MANY small leaves - on the
-// 256^3 Zel'dovich set 44 % of the leaves hold one particle, 22 % two, 22 % eight (mean 3.3; the clustered set: mean 2.7) - so with
-// one entry per leaf the evaluation ran 243 pair steps per wave of which 47 % of the lanes carried a source.  An opened leaf of c
-// particles IS c single sources (same records, same arithmetic), and 8 single sources fill a step: with KX = 2 the same lists take
-// 125 steps.  (KX = 8 would fill every lane but doubles the list bytes; the lists make a round trip through HBM.)
-//
-// List layout: target t of chunk u (the 8 targets of a wave) owns lists[(u * 8 + t) * cap ...]: leaf entries from 0 up, single
-// sources from cap - 1 down; the 64 lanes of an append write one contiguous run.  A target whose lists would exceed `cap` is put on
+// List layout: target t of chunk u (the 8 targets of a wave) owns lists[(u * 8 + t) * cap ...]: leaf entries from 0 up, node
+// entries from cap - 1 down; the 64 lanes of an append write one contiguous run.  A target whose lists would exceed `cap` is put on
 // an overflow list and handled afterwards by the cooperative kernel (grav_walk_coop.hip), so `cap` bounds memory, not
 // correctness.  Targets are processed in slices of `slice` targets so the list area stays bounded (cap * 4 B each).
 //
@@ -170,6 +161,7 @@ struct ChunkIter {
 
 // ctl words: [0] number of overflowed targets, [1] error flag (loop guard / frontier), [2] longest list seen
 // counters (COUNT builds): [0] pair interactions [1] nodes visited [2] nodes used unopened [3] frontier pops [4] nodes popped
+//                          [5] leaf entries written [6] node entries written
 //
 // MODE of the node tests: 0 NEAREST() per quantity (small boxes); 1 the node's periodic image k = rint((c - p)/Box) is applied to the
 // target (FASTWRAP); 2 plain differences, for targets farther than Rcut + Box/500 from every face of the box.  MODE 2 is exact: a
@@ -259,7 +251,7 @@ struct WaveTargets {
 };
 
 // returns false on an internal error (loop guard)
-template <bool COUNT, int MODE, bool O32, int KX>
+template <bool COUNT, int MODE, bool O32>
 __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ q_node,
                                            unsigned char *__restrict__ q_mask, const double *__restrict__ s_tgt, const int cap, const int lane,
                                            const unsigned live0, WaveTargets &T, unsigned &overflowed, bool &wrapped, unsigned (&c_pp)[8],
@@ -301,10 +293,6 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const bool special = MODE != 0 && valid && my <= 8u;
         const bool any_special = MODE != 0 && any_lane(special);
         const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
-        // the record of the source array a single-source entry of this lane's node names: the node's moments, or (an opened leaf of at
-        // most KX particles) its first particle
-        const bool small = KX > 0 && lk.pcount > 0 && lk.pcount <= KX;
-        const unsigned one_val = small ? (unsigned)lk.pstart : (unsigned)tv.mom_off + my;
         unsigned openmask = 0;
         if(COUNT) {
             st_a++;
@@ -315,14 +303,10 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         // once per wave on those masks by the scalar unit; a mask comes back as the predicate of a store through inverse_ballot (it
         // becomes the exec mask: no vector instruction either).  Written with per-lane booleans, hipcc materialised every && / || as
         // v_cndmask / v_and chains: 45 - 50 vector instructions per pass where this form needs ~35.
-        // A target gains at most 64 * max(KX, 1) entries per pass: only when some list is that close to its capacity are the
+        // A target gains at most 64 entries per pass (one per lane): only when some list is that close to its capacity are the
         // appends CHECKED one by one.
         const unsigned long long m_leafnode = __builtin_amdgcn_ballot_w64(lk.pcount > 0);
         const unsigned long long m_intnode = ~m_leafnode & __builtin_amdgcn_ballot_w64(lk.nchild > 0);
-        // leaves that are expanded into single sources, and the bit planes of their particle count - 1
-        const unsigned long long m_small = KX > 0 ? __builtin_amdgcn_ballot_w64(small) : 0ull;
-        const unsigned long long m_c0 = KX > 1 ? __builtin_amdgcn_ballot_w64(small && ((lk.pcount - 1) & 1)) : 0ull;
-        const unsigned long long m_c1 = KX > 2 ? __builtin_amdgcn_ballot_w64(small && ((lk.pcount - 1) & 2)) : 0ull;
         auto pass = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
@@ -341,17 +325,9 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 node_test_masks<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
                 const unsigned long long keep = m_act & ~m_discard;
                 const unsigned long long bn = keep & ~m_open;              // used unopened
-                const unsigned long long bo = keep & m_open & m_leafnode;  // opened leaves
+                const unsigned long long bl = keep & m_open & m_leafnode;  // opened leaves
                 const unsigned long long bpush = keep & m_open & m_intnode;
-                const unsigned long long bl = bo & ~m_small;               // ... that get a leaf entry
-                const unsigned long long bx = bn | (bo & m_small);         // lanes with single-source entries: 1 + (count - 1) each
-                const unsigned long long q0 = bo & m_c0, q1 = bo & m_c1;
-                const int kl = __builtin_popcountll(bl);
-                int kn = __builtin_popcountll(bx);
-                if(KX > 1)
-                    kn += __builtin_popcountll(q0);
-                if(KX > 2)
-                    kn += 2 * __builtin_popcountll(q1);
+                const int kl = __builtin_popcountll(bl), kn = __builtin_popcountll(bn);
                 if(CHECKED && T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
                     overflowed |= 1u << t;
                     live &= ~(1u << t);
@@ -360,40 +336,25 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 unsigned *__restrict__ Lt = Lw + (unsigned)(t * cap); // (wave-uniform base)
                 if(__builtin_amdgcn_inverse_ballot_w64(bl)) // position = entries so far + set bits below this lane (v_mbcnt accumulates onto its last operand)
                     st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, (unsigned)T.nleaf[t])), ent_val);
-                {
-                    // single sources, from the top of the list down: entries of the lanes below this one
-                    unsigned below = mbcnt64(bx);
-                    if(KX > 1)
-                        below = __builtin_amdgcn_mbcnt_hi((unsigned)(q0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)q0, below));
-                    if(KX > 2)
-                        below += 2u * mbcnt64(q1);
-                    const unsigned at = (unsigned)(cap - 1 - T.nnode[t]) - below;
-                    if(__builtin_amdgcn_inverse_ballot_w64(bx))
-                        st32(Lt, at, one_val);
-                    if(KX > 1 && __builtin_amdgcn_inverse_ballot_w64(q0 | q1)) // count >= 2
-                        st32(Lt, at - 1u, one_val + 1u);
-                    if(KX > 2 && __builtin_amdgcn_inverse_ballot_w64(q1)) // count >= 3
-                        st32(Lt, at - 2u, one_val + 2u);
-                    if(KX > 2 && __builtin_amdgcn_inverse_ballot_w64(q0 & q1)) // count == 4
-                        st32(Lt, at - 3u, one_val + 3u);
-                }
+                if(__builtin_amdgcn_inverse_ballot_w64(bn))
+                    st32(Lt, (unsigned)(cap - 1 - T.nnode[t]) - mbcnt64(bn), my);
                 T.nleaf[t] += kl;
                 T.nnode[t] += kn;
                 maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
                 openmask |= __builtin_amdgcn_inverse_ballot_w64(bpush) ? (1u << t) : 0u;
                 // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children
                 if(MODE == 1 || (MODE == 2 && any_special))
-                    wmask |= m_wrap & (bo | bn);
+                    wmask |= m_wrap & (bl | bn);
                 if(COUNT) {
                     T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
-                    T.c_used[t] += (unsigned)__builtin_popcountll(bn);
-                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bo) ? (unsigned)lk.pcount : 0u;
+                    T.c_used[t] += (unsigned)kn;
+                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl) ? (unsigned)lk.pcount : 0u;
                 }
                 // (the 8 targets' tests are independent: left alone, hipcc interleaves them and runs out of registers)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if(maxused + 64 * (KX > 1 ? KX : 1) > cap)
+        if(maxused + 64 > cap)
             pass(std::true_type{});
         else
             pass(std::false_type{});
@@ -427,7 +388,7 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
 }
 
 // one wave = one chunk of k_walk_eval (8 consecutive targets)
-template <bool COUNT, bool FASTWRAP, bool O32, int KX>
+template <bool COUNT, bool FASTWRAP, bool O32>
 __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
                                                       int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
                                                       unsigned *__restrict__ ctl, int *__restrict__ ovf)
@@ -444,7 +405,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const
     const ChunkIter it(nchunks);
     const unsigned guard_max = (unsigned)min((long long)(8ll * (tv.nnodes + 1024)), 0x7fffffffll);
     const double face = gp.rcut + 0.002 * gp.box;
-    unsigned long long n_pp = 0, n_vis = 0, n_used = 0;
+    unsigned long long n_pp = 0, n_vis = 0, n_used = 0, n_le = 0, n_se = 0;
     unsigned st_a = 0, st_al = 0;
 
     for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
@@ -493,12 +454,12 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const
         bool ok;
         if(FASTWRAP) {
             if(!any_lane(near_face))
-                ok = walk_wave8<COUNT, 2, O32, KX>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+                ok = walk_wave8<COUNT, 2, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
             else
-                ok = walk_wave8<COUNT, 1, O32, KX>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+                ok = walk_wave8<COUNT, 1, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
         }
         else
-            ok = walk_wave8<COUNT, 0, O32, KX>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+            ok = walk_wave8<COUNT, 0, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
         if(!ok)
             return;
         int nl = 0, nn = 0;
@@ -510,7 +471,7 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const
             }
         if(tvalid) {
             const bool overflow = (overflowed >> lane) & 1u;
-            // the work this target causes in the two kernels: 8 lanes per leaf entry and 1 per single source in the evaluation, and about
+            // the work this target causes in the two kernels: 8 lanes per leaf entry and 1 per node entry in the evaluation, and about
             // as many node tests as it has entries in the list construction (the measure only has to be proportional to the time
             // spent: domain.c:611)
             if(io.cost)
@@ -533,6 +494,8 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const
                     if(lane == 0) {
                         n_vis += T.c_vis[t];
                         n_used += T.c_used[t];
+                        n_le += (unsigned)T.nleaf[t];
+                        n_se += (unsigned)T.nnode[t];
                     }
                 }
         }
@@ -547,6 +510,8 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const
             c4 += __shfl_down(c4, off);
         }
         if(lane == 0) {
+            atomicAdd(&io.counters[5], n_le); // list entries written: leaves, nodes (lane 0 holds the wave's sums)
+            atomicAdd(&io.counters[6], n_se);
             atomicAdd(&io.counters[0], c0);
             atomicAdd(&io.counters[1], c1);
             atomicAdd(&io.counters[2], c2);
@@ -618,22 +583,21 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
             ent_n = ent_nn;
         }
     }
-    // ---- single sources (records of the source array: node moments, particles of small leaves): lane s takes entry r0 + s; entries
-    // two batches ahead, records one
+    // ---- node entries (level-order indices): lane s takes entry r0 + s; entries two batches ahead, moments one
     if(any_lane(nnode > 0)) {
-        const unsigned NONE = zero_src;
+        const unsigned NONE = (unsigned)tv.nnodes; // a zero-mass padding record behind the moments (TreeBuilder::make_level_order)
         // index of node entry r0 + s counted from the top of the list (r0 a multiple of 8)
         const unsigned top = (unsigned)((gshift >> 3) * cap + cap - 1 - s);
 #define MPG_NODE_AT(R0) (top - (unsigned)(R0))
         unsigned ne = (s < nnode) ? ld<true>(L, MPG_NODE_AT(0)) : NONE;
         unsigned ne_n = (8 + s < nnode) ? ld<true>(L, MPG_NODE_AT(8)) : NONE;
-        Src4 sc = ld<O32>(tv.src, ne);
+        Src4 sc = ld<O32>(tv.momB, ne);
         for(int r0 = 0;; r0 += 8) {
             if(!any_lane(r0 < nnode))
                 break;
             ne = ne_n;
             ne_n = (r0 + 16 + s < nnode) ? ld<true>(L, MPG_NODE_AT(r0 + 16)) : NONE;
-            const Src4 sc_n = ld<O32>(tv.src, ne);
+            const Src4 sc_n = ld<O32>(tv.momB, ne);
             MPG_EVAL(sc);
             sc = sc_n;
         }
@@ -753,13 +717,10 @@ int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_p
 template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
-    // Leaves of at most KX particles are listed as single sources (top of this file): ws.split_leaf_expand (0, 1, 2 or 4; default 2),
-    // MPG_LEAF_EXPAND overrides (experiments; read once per process).  Counters and per-target interaction sets do not depend on it.
-    static const int kx_env = getenv("MPG_LEAF_EXPAND") ? atoi(getenv("MPG_LEAF_EXPAND")) : -1;
-    const int kx = kx_env >= 0 ? kx_env : ws.split_leaf_expand;
-    auto kl = kx <= 0 ? k_walk_lists8<COUNT, FASTWRAP, O32, 0> : kx == 1 ? k_walk_lists8<COUNT, FASTWRAP, O32, 1> : kx == 2 ? k_walk_lists8<COUNT, FASTWRAP, O32, 2>
-                                                                                                                      : k_walk_lists8<COUNT, FASTWRAP, O32, 4>;
+    auto kl = k_walk_lists8<COUNT, FASTWRAP, O32>;
     auto ke = k_walk_eval<POT, FASTWRAP, O32, MPG_EVAL_BLOCKS>;
+    if(const char *e = getenv("MPG_LIST_CAP")) // experiment knob
+        ws.split_cap = atoi(e) / 8 * 8;
     const int cap = ws.split_cap;
     // targets per kernel pair: bounded by the list area (split_bytes), at least 64 Ki so that a launch still fills the chip
     int64_t slice = (int64_t)(ws.split_bytes / ((size_t)cap * sizeof(unsigned))) / 2048 * 2048;
@@ -823,8 +784,8 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
         return;
     MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
     ws.ctr.reserve(16);
-    // 32-bit byte offsets into the source and node arrays (32-byte records, both copies of the moments and the padding included)?
-    const bool o32 = (tv.npart + 2 * tv.nnodes + 64) * 32 < (1ll << 32);
+    // 32-bit byte offsets into the source and node arrays (32-byte records, padding included)?
+    const bool o32 = (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
 #define MPG_WS(P, C)                                                \
     do {                                                            \
         if(fastwrap) {                                              \

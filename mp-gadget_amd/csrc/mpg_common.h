@@ -104,8 +104,7 @@ struct TreeView {
     const int *order = nullptr;    // [npart] tree order -> caller index
     // level-ordered copy (root = 0, the children of a node are contiguous): geometry, moments, links, hmax
     const NodeGeo *geoB = nullptr;
-    const Src4 *momB = nullptr;  // = src + mom_off: record mom_off + i of the source array holds the moments of level-order node i
-    int64_t mom_off = 0;
+    const Src4 *momB = nullptr;
     const NodeLinkB *linkB = nullptr;
     const double *hmaxB = nullptr;
     double box = 0;

@@ -70,8 +70,7 @@ struct TreeBuilder {
     // level-ordered copy for the cooperative walk (children of a node contiguous)
     DevBuf<uint32_t> lvl_a, lvl_b, nid_a, nid_b, bfs_of_dfs;
     DevBuf<NodeGeo> geoB;
-    Src4 *momB = nullptr; // = src.p + mom_offset()
-    int64_t mom_offset() const { return npart + nnodes + 16; }
+    DevBuf<Src4> momB;
     DevBuf<NodeLinkB> linkB;
     DevBuf<double> hmaxB;
     bool has_bfs = false;

@@ -419,14 +419,12 @@ void TreeBuilder::make_level_order(hipStream_t st)
     nid_b.reserve(M + 1);
     bfs_of_dfs.reserve(M + 1);
     geoB.reserve(M + 16);
-    // the level-ordered moments live in the source array itself, behind the depth-first ones (build() reserved the room): one
-    // 29-bit index addresses a particle or a node's moments, which lets the walk's interaction lists hold both (grav_walk_split.hip)
-    momB = src.p + mom_offset();
+    momB.reserve(M + 16);
     linkB.reserve(M + 16);
     if(has_hmax)
         hmaxB.reserve(M + 16);
     // zero-mass padding records behind the moments (the evaluation kernel points idle lanes of its node loop at them)
-    MPG_HIP(hipMemsetAsync(momB + M, 0, 16 * sizeof(Src4), st));
+    MPG_HIP(hipMemsetAsync(momB.p + M, 0, 16 * sizeof(Src4), st));
     hipLaunchKernelGGL(k_node_levels, dim3(nblk(M)), dim3(256), 0, st, M, link.p, lvl_a.p, nid_a.p);
     size_t tb = 0;
     MPG_HIP(rocprim::radix_sort_pairs(nullptr, tb, lvl_a.p, lvl_b.p, nid_a.p, nid_b.p, (size_t)M, 0, 5, st));
@@ -434,7 +432,7 @@ void TreeBuilder::make_level_order(hipStream_t st)
     MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, lvl_a.p, lvl_b.p, nid_a.p, nid_b.p, (size_t)M, 0, 5, st));
     hipLaunchKernelGGL(k_invert_perm, dim3(nblk(M)), dim3(256), 0, st, M, nid_b.p, bfs_of_dfs.p);
     hipLaunchKernelGGL(k_build_level_order, dim3(nblk(M)), dim3(256), 0, st, M, npart, nid_b.p, bfs_of_dfs.p, geo.p, link.p, src.p,
-                       has_hmax ? hmax.p : (const double *)nullptr, geoB.p, momB, linkB.p, has_hmax ? hmaxB.p : (double *)nullptr);
+                       has_hmax ? hmax.p : (const double *)nullptr, geoB.p, momB.p, linkB.p, has_hmax ? hmaxB.p : (double *)nullptr);
     MPG_HIP(hipGetLastError());
     has_bfs = true;
 }
@@ -507,8 +505,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
         minleaflevel = 0;
     }
     // padding records behind each array: the cooperative walk reads nodes no .. no+7 (those past the end are ignored)
-    // (the source array also has room for the level-ordered copy of the moments: make_level_order)
-    src.reserve(npart + 2 * (nnodes + 16));
+    src.reserve(npart + nnodes + 16);
     geo.reserve(nnodes + 16);
     link.reserve(nnodes + 16);
     // the padding records of the source array are zero-mass sources at the origin (grav_walk_split.hip points idle lanes at them)
@@ -675,8 +672,7 @@ TreeView TreeBuilder::view() const
     v.order = (const int *)idx_b.p;
     if(has_bfs) {
         v.geoB = geoB.p;
-        v.momB = momB;
-        v.mom_off = mom_offset();
+        v.momB = momB.p;
         v.linkB = linkB.p;
         v.hmaxB = has_hmax ? hmaxB.p : nullptr;
     }

@@ -256,9 +256,6 @@ class Engine:
         self._ck(self.lib.mpg_get_walk_choice(self.h, C.byref(v), C.byref(cap), C.byref(ovf)))
         return v.value, cap.value, ovf.value
 
-    def set_walk_leaf_expand(self, kx):
-        self._ck(self.lib.mpg_set_walk_leaf_expand(self.h, int(kx)))
-
     def set_walk_list_capacity(self, cap):
         self._ck(self.lib.mpg_set_walk_list_capacity(self.h, int(cap)))
 

@@ -168,32 +168,6 @@ def test_walk_parity(pkg, engine, orc, ic, n, nmesh):
     engine.set_instrumentation(False, False)
 
 
-@pytest.mark.parametrize("ic,n", [("s_clust", 48), ("s_zel", 40)])
-def test_leaf_expansion_levels_agree(tmp_path, ic, n):
-    """The two-kernel walk lists an opened leaf of at most KX particles as KX single sources instead of one leaf entry
-    (mpg_set_walk_leaf_expand; grav_walk_split.hip).  Whatever KX (0 = every leaf keeps its entry, 1, 2 = default, 4), the per-target
-    decisions are the reference's: interaction counters equal, accelerations and potentials of three steps (Barnes-Hut walk,
-    list-capacity adaptation with overflowing targets on the clustered set, relative criterion) equal to rounding (the order of
-    summation differs), and the per-target work measure handed to the domain decomposition stays proportional."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / "levels.npz")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pair_check.py"), out, ic, str(n)], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    res = np.load(out)
-    assert len(res.files) == 4 * 3 * 4
-    for step in range(3):
-        a0, p0, c0, n0 = (res["%s%d_k0" % (k, step)] for k in ("acc", "pot", "cost", "cnt"))
-        assert np.abs(a0).max() > 0 and c0.min() > 0 and n0.min() > 0
-        for kx in (1, 2, 4):
-            a, p_, c, n_ = (res["%s%d_k%d" % (k, step, kx)] for k in ("acc", "pot", "cost", "cnt"))
-            assert np.array_equal(n_, n0), (step, kx, n_, n0)
-            assert np.abs(a - a0).max() <= 1e-12 * np.abs(a0).mean() + 1e-13 * np.abs(a0).max(), (step, kx)
-            assert np.abs(p_ - p0).max() <= 1e-12 * np.abs(p0).mean(), (step, kx)
-            assert c.min() > 0 and 0.3 < np.median(c / c0) < 1.2 and np.corrcoef(c0, c)[0, 1] > 0.9, (step, kx)
-
-
 @pytest.mark.parametrize("variant,cap", [(1, 512), (4, 512), (4, 48), (6, 512), (6, 40)])
 @pytest.mark.parametrize("ic,n,nmesh", [("s_grid", 24, 48), ("s_clust", 20, 40), ("s_zel", 24, 48)])
 def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
