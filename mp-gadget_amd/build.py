@@ -17,6 +17,10 @@ LIB = os.path.join(HERE, "libmpgadget_hip.so")
 SOURCES = ["tree_build.hip", "grav_walk.hip", "grav_walk_coop.hip", "grav_walk_split.hip", "grav_pair_walk.hip", "pm.hip", "sph.hip", "timestep.hip", "peano.hip", "domain.hip", "fof.hip", "snapshot_io.hip", "engine.hip", "dist.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# experiments (-DMPG_EXP_...): MPG_EXTRA_FLAGS="file.hip:-Dx -Dy" applies to one source, MPG_EXTRA_FLAGS="-Dx" to all; part of the
+# build stamp like every flag
+_EXTRA = os.environ.get("MPG_EXTRA_FLAGS", "")
+_EXTRA_FILE, _EXTRA = (_EXTRA.split(":", 1) if ".hip:" in _EXTRA else ("", _EXTRA))
 
 
 def _headers():
@@ -36,7 +40,7 @@ def _sha(paths, extra=""):
 
 def source_stamp():
     """the stamp a library built from the sources of this tree carries"""
-    return _sha([os.path.join(CSRC, s) for s in SOURCES] + _headers(), " ".join(FLAGS))[:32]
+    return _sha([os.path.join(CSRC, s) for s in SOURCES] + _headers(), " ".join(FLAGS) + os.environ.get("MPG_EXTRA_FLAGS", ""))[:32]
 
 
 def _read(path):
@@ -54,9 +58,10 @@ def build(force=False, verbose=False):
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        want = _sha([s] + headers, " ".join(FLAGS))
+        flags = FLAGS + (_EXTRA.split() if _EXTRA_FILE in ("", src) else [])
+        want = _sha([s] + headers, " ".join(flags))
         if force or not os.path.exists(o) or _read(o + ".hash") != want:
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -83,23 +83,29 @@ __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const 
 {
     // apply_accn_to_output, gravshort-tree.c:158-193
     const double r2 = dx * dx + dy * dy + dz * dz;
-    const double rinv = rsqrt_nr(fmax(r2, 1e-180)); // the clamp keeps m * rinv^3 finite for r = 0
-    const double r = r2 * rinv; // exactly 0 for the self interaction
-    // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
-    // the table's last row, which holds zeros
-    const double ti = r * gp.inv_cell_dx;
+    // (no clamp of r2 on the common path: for r2 = 0 - the self interaction - and below ~1e-300 rinv is not finite, and the softened
+    // branch, which such a pair always takes and which overwrites fac and facpot, puts r = 0 in its place)
+    const double rinv = rsqrt_nr(r2);
+    double r = r2 * rinv;
     const double mr = s.m * rinv;
     double fac = mr * rinv * rinv;
     double facpot = -mr;
-    if(r2 < gp.h * gp.h) // rare (the self interaction, close encounters): kept out of line so that its divisions and
-        softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot); // constants do not occupy registers in the pair loop
+    if(r2 < gp.h * gp.h) { // rare (the self interaction, close encounters): kept out of line so that its divisions and
+        if(!(rinv < 1e150))  // constants do not occupy registers in the pair loop
+            r = 0.0;
+        softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot);
+    }
+    // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
+    // the table's last row, which holds zeros
+    const double ti = r * gp.inv_cell_dx;
     // row t holds {T[t], T[t+1] - T[t]} (the difference of two floats is exact in double): T[t] + (i - t) (T[t+1] - T[t]) is the
     // interpolation of gravity.c:63 up to one rounding.  (i - t) = fract(i) exactly for i >= 0.
     const int t = min((int)ti, NTAB - 1);
     const double w1 = __builtin_amdgcn_fract(ti);
     // two tables of 16-byte rows, {T, dT} of the force, then (with POT) {T, dT} of the potential NTAB rows further on: both reads are
     // issued together.  (One 32-byte row holding both put every force read on one half of the LDS banks and every potential read on
-    // the other half; with 16-byte rows the random rows of a wave's 64 lanes spread over all banks.)
+    // the other half; with 16-byte rows the random rows of a wave's 64 lanes spread over all banks.  Round 3 also measured rows of four
+    // floats {F[t], F[t+1], P[t], P[t+1]} - one 16-byte read per pair, six more conversions: no change.)
     const double *__restrict__ row = wtab + t * 2;
     const double2 f = *(const double2 *)row;
     double2 p = f;
@@ -538,10 +544,18 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
                                            double &ax, double &ay, double &az, double &pot)
 {
     const unsigned empty = (zero_src << 3) | 7u; // a full "leaf" of zero-mass padding records
-#define MPG_LOAD(ENT, J, SV)                                                                \
-    {                                                                                       \
-        const unsigned ej_ = (unsigned)__shfl((int)(ENT), gshift + (J));                    \
-        SV = ld<O32>(tv.src, (s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src); \
+    // source s of leaf entry J of the current batch.  O32: byte offsets formed directly (first particle * 32 = (entry & ~7) << 2)
+    const unsigned s32 = (unsigned)s * 32u, zoff = zero_src * 32u;
+#define MPG_LOAD(ENT, J, SV)                                                                    \
+    {                                                                                           \
+        const unsigned ej_ = (unsigned)__shfl((int)(ENT), gshift + (J));                        \
+        if(O32) {                                                                               \
+            unsigned off_; /* (first particle + s) * 32: hipcc forms (e << 2) & ~31 and a separate add */ \
+            asm("v_and_b32 %0, -8, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(off_) : "v"(ej_), "v"(s32)); \
+            SV = *(const Src4 *)((const char *)tv.src + (size_t)(((unsigned)s <= (ej_ & 7u)) ? off_ : zoff)); \
+        }                                                                                       \
+        else                                                                                    \
+            SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
     }
 #define MPG_EVAL(SV)                                                              \
     {                                                                             \
