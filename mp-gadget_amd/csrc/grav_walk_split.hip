@@ -265,16 +265,121 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
 {
     unsigned live = live0; // targets still walking (wave-uniform)
     int sp = 0;            // frontier entries (wave-uniform)
-    if(live) {
-        if(lane == 0) {
-            q_node[0] = 0u; // the root
-            q_mask[0] = (unsigned char)live;
-        }
-        sp = 1;
-    }
     unsigned guard = 0;
     unsigned long long wmask = 0;
     int maxused = 0; // longest pair of lists among the wave's targets (wave-uniform)
+
+    // the children of the nodes a pass opened: one frontier entry per child, mask = the targets that opened the parent.  Returns false
+    // if the frontier would overflow (a pathological tree): every target still walking goes to the fallback.
+    auto push_children = [&](const bool pushing, const NodeLinkB &lk, const unsigned openmask) -> bool {
+        const unsigned long long bp = __builtin_amdgcn_ballot_w64(pushing);
+        if(bp == 0ull)
+            return true;
+        const unsigned nm1 = (unsigned)(lk.nchild - 1); // 0..7
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 1u)), b1 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 2u)),
+                                 b2 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 4u));
+        const int total = __builtin_popcountll(bp) + __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+        if(sp + total > QCAP) {
+            overflowed |= live;
+            live = 0;
+            return false;
+        }
+        if(pushing) {
+            const unsigned at = (unsigned)sp + mbcnt64(bp) + mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2);
+#pragma unroll
+            for(unsigned c = 0; c < 8; c++)
+                if(c <= nm1) {
+                    q_node[at + c] = (unsigned)lk.firstchild + c;
+                    q_mask[at + c] = (unsigned char)openmask;
+                }
+        }
+        sp += total;
+        return true;
+    };
+
+    // ---- the top of the tree: the root, then its children, then - as long as the wave's targets open ONE node of a level - that node's
+    // children, with ONE pass per level over (node, target) pairs: lane = 8 * target + node.  (Popped from the frontier like every
+    // other node, the root filled 1 lane and its children 8 of a pop that costs 8 target passes whatever it holds: 2 to 3 of the ~21
+    // pops of a wave at 256^3.  Written as a branch of the main loop instead - any pop of <= 8 nodes - the same code made hipcc spill
+    // 36 vector registers in the passes per target: 79 ms per walk against 70.)  The root and its children are also the only nodes that
+    // can need exact periodic images for the centre and the centre of mass separately (`special`: Rcut + len >= Box / 2 needs len >=
+    // Box / 2, FASTWRAP has Rcut < 0.2 Box), so the passes of the main loop below do without that branch.
+    {
+        const int tc = lane & 7, tt = lane >> 3;
+        unsigned tmask = live; // targets that reach the nodes of this level (wave-uniform)
+        unsigned first = 0u;
+        int nch = 1;
+        for(int level = 0; tmask != 0u; level++) {
+            const bool valid = tc < nch && ((tmask >> tt) & 1u);
+            const unsigned my = first + (unsigned)(tc < nch ? tc : 0);
+            const NodeGeo g = ld<O32>(tv.geoB, my);
+            const Src4 mom = ld<O32>(tv.momB, my);
+            const NodeLinkB lk = ld<O32>(tv.linkB, my);
+            const double4 tg = *(const double4 *)(s_tgt + 4 * tt);
+            const double eff = fma(0.5, g.len, gp.rcut);
+            const double l2 = g.len * g.len;
+            const bool special = MODE != 0 && valid && level < 2;
+            unsigned long long m_discard, m_open, m_wrap;
+            node_test_masks<MODE>(gp, g, mom, special, MODE != 0 && level < 2, eff, l2, 0.6 * g.len, mom.m * l2, tg.x, tg.y, tg.z, tg.w, m_discard,
+                                  m_open, m_wrap);
+            const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(valid);
+            const unsigned long long m_leafnode = __builtin_amdgcn_ballot_w64(lk.pcount > 0);
+            const unsigned long long m_intnode = ~m_leafnode & __builtin_amdgcn_ballot_w64(lk.nchild > 0);
+            const unsigned long long keep = m_valid & ~m_discard;
+            const unsigned long long bn = keep & ~m_open, bl = keep & m_open & m_leafnode;
+            unsigned long long bpush = keep & m_open & m_intnode;
+            if(COUNT) {
+                st_a++;
+                st_al += (unsigned)nch;
+            }
+            if(COUNT || (bn | bl) != 0ull) { // (list entries this high in the tree: small trees, or coarse nodes far from the targets)
+                const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+#pragma unroll
+                for(int t = 0; t < 8; t++) {
+                    const unsigned long long grp = 0xffull << (8 * t);
+                    const unsigned long long bl_t = bl & grp, bn_t = bn & grp;
+                    const int kl = __builtin_popcountll(bl_t), kn = __builtin_popcountll(bn_t);
+                    if(T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
+                        overflowed |= 1u << t;
+                        live &= ~(1u << t);
+                        bpush &= ~grp;
+                        continue;
+                    }
+                    unsigned *__restrict__ Lt = Lw + (unsigned)(t * cap);
+                    if(__builtin_amdgcn_inverse_ballot_w64(bl_t))
+                        st32(Lt, __builtin_amdgcn_mbcnt_hi((unsigned)(bl_t >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl_t, (unsigned)T.nleaf[t])), ent_val);
+                    if(__builtin_amdgcn_inverse_ballot_w64(bn_t))
+                        st32(Lt, (unsigned)(cap - 1 - T.nnode[t]) - mbcnt64(bn_t), my);
+                    T.nleaf[t] += kl;
+                    T.nnode[t] += kn;
+                    maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
+                    if(COUNT) {
+                        T.c_vis[t] += (unsigned)__builtin_popcountll(m_valid & grp);
+                        T.c_used[t] += (unsigned)kn;
+                        c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl_t) ? (unsigned)lk.pcount : 0u;
+                    }
+                }
+            }
+            if(MODE != 0)
+                wmask |= m_wrap & (bl | bn);
+            // the targets that opened node tc (the same in every lane with this tc); lanes 0..7 - target group 0 - hold one lane per node
+            unsigned om = 0;
+#pragma unroll
+            for(int t = 0; t < 8; t++)
+                om |= (unsigned)((bpush >> (8 * t + tc)) & 1ull) << t;
+            const unsigned long long m_opened = __builtin_amdgcn_ballot_w64(lane < 8 && om != 0u);
+            if(__builtin_popcountll(m_opened) == 1) { // one node opened: its children are the next level
+                const int src = __builtin_ctzll(m_opened);
+                tmask = (unsigned)__builtin_amdgcn_readlane((int)om, src);
+                first = (unsigned)__builtin_amdgcn_readlane(lk.firstchild, src);
+                nch = __builtin_amdgcn_readlane(lk.nchild, src);
+            }
+            else {
+                push_children(lane < 8 && om != 0u, lk, om);
+                tmask = 0u;
+            }
+        }
+    }
     while(sp > 0 && live) {
         if(++guard > guard_max) {
             if(lane == 0)
@@ -296,8 +401,6 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const double l2 = g.len * g.len;
         const double inside = 0.6 * g.len;
         const double ml2 = mom.m * l2;
-        const bool special = MODE != 0 && valid && my <= 8u;
-        const bool any_special = MODE != 0 && any_lane(special);
         const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
         unsigned openmask = 0;
         if(COUNT) {
@@ -328,7 +431,7 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 asm volatile("" : "+v"(ot));
                 const double4 tg = *(const double4 *)(s_tgt + ot);
                 unsigned long long m_discard, m_open, m_wrap;
-                node_test_masks<MODE>(gp, g, mom, special, any_special, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
+                node_test_masks<MODE>(gp, g, mom, false, false, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
                 const unsigned long long keep = m_act & ~m_discard;
                 const unsigned long long bn = keep & ~m_open;              // used unopened
                 const unsigned long long bl = keep & m_open & m_leafnode;  // opened leaves
@@ -348,8 +451,8 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 T.nnode[t] += kn;
                 maxused = max(maxused, T.nleaf[t] + T.nnode[t]);
                 openmask |= __builtin_amdgcn_inverse_ballot_w64(bpush) ? (1u << t) : 0u;
-                // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children
-                if(MODE == 1 || (MODE == 2 && any_special))
+                // an entry on a wrapped periodic image: MODE 2 can meet one only among the root and its children (the top passes above)
+                if(MODE == 1)
                     wmask |= m_wrap & (bl | bn);
                 if(COUNT) {
                     T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
@@ -364,30 +467,8 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
             pass(std::true_type{});
         else
             pass(std::false_type{});
-        // the children of the opened internal nodes: one frontier entry per child, mask = the targets that opened the parent
-        const bool pushing = openmask != 0u;
-        const unsigned long long bp = __builtin_amdgcn_ballot_w64(pushing);
-        if(bp != 0ull) {
-            const unsigned nm1 = (unsigned)(lk.nchild - 1); // 0..7
-            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 1u)), b1 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 2u)),
-                                     b2 = __builtin_amdgcn_ballot_w64(pushing && (nm1 & 4u));
-            const int total = __builtin_popcountll(bp) + __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
-            if(sp + total > QCAP) { // (a pathological tree) every target still walking goes to the fallback
-                overflowed |= live;
-                live = 0;
-                break;
-            }
-            if(pushing) {
-                const unsigned at = (unsigned)sp + mbcnt64(bp) + mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2);
-#pragma unroll
-                for(unsigned c = 0; c < 8; c++)
-                    if(c <= nm1) {
-                        q_node[at + c] = (unsigned)lk.firstchild + c;
-                        q_mask[at + c] = (unsigned char)openmask;
-                    }
-            }
-            sp += total;
-        }
+        if(!push_children(openmask != 0u, lk, openmask))
+            break;
     }
     wrapped = wmask != 0ull;
     return true;
