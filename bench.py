@@ -557,6 +557,7 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
                         "decomposition balanced by particle counts"}
         out["phases_ms"].update({"dist_pm_ms": round(tm["pm"], 3), "dist_ghost_import_ms": round(tm["ghosts"], 3),
                                  "dist_tree_and_top_ms": round(tm["tree"], 3), "dist_walk_ms": round(tm["walk"], 3),
+                                 "dist_tree_build_beside_pm_ms": round(tm["tree_beside_pm"], 3),
                                  "dist_exchange_bytes": st["exchange_bytes"], "dist_transpose_bytes": st["transpose_bytes"]})
         if parity is not None:
             out["parity_check"] = parity

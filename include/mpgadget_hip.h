@@ -704,7 +704,9 @@ const float *mpg_dist_walk_cost(mpg_dist *d);
  * [3] decomposition level La, [4] bytes sent in personalised exchanges, [5] bytes sent in transposes */
 int mpg_dist_get_stats(mpg_dist *d, int64_t stats[8]);
 /* phase times of the last step in ms (host clock around stream synchronisations): [0] PM shipping + slab PM, [1] ghost import,
- * [2] tree build + global top, [3] walk */
+ * [2] tree build + global top, [3] walk.  After mpg_dist_gravity_step, which builds the local tree on a second stream beside the PM
+ * step (MPG_DIST_NO_OVERLAP=1: one after the other): [0] PM with the tree build beside it, [2] global top + targets, [4] the tree build
+ * on its own stream */
 int mpg_dist_get_times(mpg_dist *d, double ms[8]);
 /* cells of the tree above this level are kept internal (never leaves) by the next tree builds; 0 restores forcetree.c's rule.
  * Used by the distributed step; exposed for tests. */

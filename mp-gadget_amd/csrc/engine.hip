@@ -304,6 +304,17 @@ int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int
     API_END
 }
 
+// tree of the bound particles + moments on the given stream (csrc/dist.hip: beside the PM step, from a second host thread)
+void engine_tree_build_on(mpg_engine *eng, int mask, hipStream_t st)
+{
+    eng->pm_queued = false;
+    eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, st, nullptr);
+    eng->tree.calc_moments(nullptr, st, nullptr);
+    eng->tree_allocated = true;
+    eng->tree_mask = mask;
+    eng->full_particle_tree = (eng->tree.npart == eng->n);
+}
+
 int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
 {
     API_BEGIN

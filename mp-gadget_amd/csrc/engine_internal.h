@@ -156,7 +156,15 @@ struct mpg_engine {
     hipEvent_t chunk_ev[8] = {};
 };
 
+extern "C" void engine_tree_build_on(mpg_engine *eng, int mask, hipStream_t st); // engine.hip
+
 #define API_BEGIN try {
+#define API_END_NORETURN             \
+    }                                \
+    catch(const std::exception &e) { \
+        mpg_err_slot() = e.what();   \
+        return 1;                    \
+    }
 #define API_END                      \
     }                                \
     catch(const std::exception &e) { \

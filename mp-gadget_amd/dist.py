@@ -355,7 +355,7 @@ class DistForce:
     def times(self):
         t = (C.c_double * 8)()
         self._ck(self.lib.mpg_dist_get_times(self.h, t))
-        return dict(pm=t[0], ghosts=t[1], tree=t[2], walk=t[3])
+        return dict(pm=t[0], ghosts=t[1], tree=t[2], walk=t[3], tree_beside_pm=t[4])
 
     def close(self):
         if self.h:
