@@ -49,6 +49,7 @@ struct SphEngine {
     DevBuf<uint8_t> active_flags;
     DevBuf<Aux4> aux;
     DevBuf<HydroSrc> hsrc;
+    DevBuf<double> hsml_t; // the sources' smoothing lengths in tree order (hydro distance tests)
     DevBuf<unsigned> ctr;
     DevBuf<unsigned long long> stats;
     bool hmax_pending = false;

@@ -607,7 +607,7 @@ __device__ __forceinline__ double pressure_pred(double eom, double entvar) // Pr
 // per-source record of the hydro loop (tree order); every field is a function of the source particle alone
 __global__ void __launch_bounds__(256) k_hydro_prepare(int64_t npart, const int *__restrict__ order, const SphView A, const mpg_sph_times T,
                                                        const mpg_hydro_params HP, const double *__restrict__ entvarpred, double fac_mu,
-                                                       HydroSrc *__restrict__ hs)
+                                                       HydroSrc *__restrict__ hs, double *__restrict__ hsml_t)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(k >= npart)
@@ -630,6 +630,7 @@ __global__ void __launch_bounds__(256) k_hydro_prepare(int64_t npart, const int 
     o.dhsml = A.dhsmlegyfac[ci];
     o.dloga = T.dloga_bin[bin];
     hs[k] = o;
+    hsml_t[k] = o.hsml; // (the distance tests read the smoothing lengths alone: 8 bytes per candidate instead of a line of the 96-byte records)
 }
 
 // the target-side constants of hydro_ngbiter
@@ -716,7 +717,8 @@ __device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, cons
 
 // hydro_force loop: group-cooperative walk with the symmetric cull (see k_density)
 __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_hydro_params HP,
-                                               const HydroCtl C, const HydroSrc *__restrict__ hs, const int *__restrict__ slot_of,
+                                               const HydroCtl C, const HydroSrc *__restrict__ hs, const double *__restrict__ hsml_t,
+                                               const int *__restrict__ slot_of,
                                                const int *__restrict__ targets, int64_t ntargets, unsigned long long *__restrict__ stats,
                                                unsigned *__restrict__ err)
 {
@@ -794,7 +796,7 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
             bool keep = false;
             if(s < pc) {
                 n_cand++;
-                keep = hydro_test(tv.src[ps + s], hs[ps + s].hsml, t, kernel_i, C, tv.box);
+                keep = hydro_test(tv.src[ps + s], hsml_t[ps + s], t, kernel_i, C, tv.box);
                 n_pair += keep ? 1u : 0u;
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
@@ -992,6 +994,7 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
     MPG_CHECK(tree.has_hmax && tv.hmax && tv.hmaxB, "Hydro called before hmax computed"); // hydra.c:172-173
     MPG_CHECK(entvarpred.p != nullptr, "hydro_force needs the predicted entropies of density()");
     hsrc.reserve(tv.npart + 1);
+    hsml_t.reserve(tv.npart + 1);
     slot_of.reserve(n + 1);
     stats.reserve(8);
     HydroCtl C;
@@ -1003,7 +1006,7 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
     MPG_HIP(hipMemsetAsync(stats.p, 0, 8 * sizeof(unsigned long long), st));
     if(tv.npart > 0) {
         hipLaunchKernelGGL(k_slot_of, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, slot_of.p);
-        hipLaunchKernelGGL(k_hydro_prepare, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, A, T, HP, entvarpred.p, C.fac_mu, hsrc.p);
+        hipLaunchKernelGGL(k_hydro_prepare, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, A, T, HP, entvarpred.p, C.fac_mu, hsrc.p, hsml_t.p);
     }
     // work queue: the active gas particles in tree order
     queue_a.reserve(tv.npart + 1);
@@ -1018,7 +1021,7 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
         MPG_HIP(hipStreamSynchronize(st));
     }
     if(nt > 0)
-        hipLaunchKernelGGL(k_hydro, dim3(nblk(nt, 32)), dim3(256), 0, st, tv, A, T, HP, C, hsrc.p, slot_of.p, queue_a.p, (int64_t)nt, stats.p,
+        hipLaunchKernelGGL(k_hydro, dim3(nblk(nt, 32)), dim3(256), 0, st, tv, A, T, HP, C, hsrc.p, hsml_t.p, slot_of.p, queue_a.p, (int64_t)nt, stats.p,
                            ctr.p + 7);
     MPG_HIP(hipGetLastError());
     unsigned long long hs[2] = {0, 0};

@@ -15,7 +15,7 @@ PY
 tail -2 $R/gpurun_out/r3w/bench_$1.err | cut -c1-200
 }
 run base ""
-run SPH_WALKONLY "sph.hip:-DMPG_EXP_SPH_WALKONLY"
-run SPH_NOEVAL "sph.hip:-DMPG_EXP_SPH_NOEVAL"
+
+
 cp /tmp/lib_orig.so $R/mp-gadget_amd/libmpgadget_hip.so
 find $R/gpurun_out/r3w -name "*kernel_trace.csv" -delete
