@@ -724,6 +724,9 @@ int mpg_set_walk_threshold(mpg_engine *eng, int thresh);
  * chunks_per_wave = 0 uses persistent grids, > 0 that many 8-target chunks per wave (default 2) */
 int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave);
 int mpg_set_walk_list_capacity(mpg_engine *eng, int cap);
+/* kernel 6: on != 0 takes the kernels' 64-bit-offset variants whatever the array sizes (default: only when the source and node arrays exceed
+ * 4 GiB, i.e. from about 512^3 particles in one tree); results do not depend on it */
+int mpg_set_walk_offsets64(mpg_engine *eng, int on);
 int mpg_set_walk_variant(mpg_engine *eng, int variant);
 /* kernel in use (the explicit variant, or the default policy's pick: 6 for >= 4096 targets, else 1; 0 = no walk yet), kernel 6's current list capacity and
  * the number of targets its last walk handed to the fallback kernel (either output may be NULL) */

@@ -2093,6 +2093,14 @@ int mpg_set_walk_split_mode(mpg_engine *eng, int overlap, int chunks_per_wave)
     API_END
 }
 
+int mpg_set_walk_offsets64(mpg_engine *eng, int on)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->w3.split_offsets64 = on != 0;
+    API_END
+}
+
 int mpg_set_walk_threshold(mpg_engine *eng, int thresh)
 {
     API_BEGIN

@@ -46,6 +46,7 @@ struct WalkScratch {
     unsigned split_last_overflow = 0, split_last_maxlen = 0;
     bool split_overlap = false;       // true: build the lists of slice k+1 on a second stream while slice k is evaluated (two list areas);
                                       // the default of round 1, measured slower than serial slices in round 2 (see split_slice)
+    bool split_offsets64 = false;     // take the 64-bit-offset variants of the kernels whatever the array sizes (tests: the forms a 512^3 tree needs)
     int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)
     hipStream_t split_stream = nullptr;
     hipEvent_t ev_lists[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_begin = nullptr;

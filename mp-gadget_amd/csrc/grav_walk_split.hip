@@ -880,7 +880,7 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
     MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
     ws.ctr.reserve(16);
     // 32-bit byte offsets into the source and node arrays (32-byte records, padding included)?
-    const bool o32 = (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
+    const bool o32 = !ws.split_offsets64 && (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
 #define MPG_WS(P, C)                                                \
     do {                                                            \
         if(fastwrap) {                                              \

@@ -262,6 +262,9 @@ class Engine:
     def set_walk_split_mode(self, overlap=True, chunks_per_wave=2):
         self._ck(self.lib.mpg_set_walk_split_mode(self.h, int(bool(overlap)), int(chunks_per_wave)))
 
+    def set_walk_offsets64(self, on):
+        self._ck(self.lib.mpg_set_walk_offsets64(self.h, int(bool(on))))
+
     def set_walk_threshold(self, thresh):
         self._ck(self.lib.mpg_set_walk_threshold(self.h, int(thresh)))
 

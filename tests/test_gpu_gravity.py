@@ -204,6 +204,38 @@ def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
     assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
 
 
+@pytest.mark.parametrize("ic", ["s_zel", "s_grid"])
+def test_walk_64bit_offset_kernels(pkg, engine, orc, ic):
+    """The two-kernel walk has variants with 64-bit offsets into the source / node arrays, taken when those exceed 4 GiB (512^3 particles in
+    one tree: BASELINE configs[3] on one GPU); mpg_set_walk_offsets64 selects them at a size the oracle can check.  Same decisions, same
+    results."""
+    n, nmesh = 24, 48
+    pos, mass, box = getattr(pkg.ics, ic)(n)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    gpm_o, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    a_ref, p_ref, c_ref, _ = tr.grav_short_tree(par, oldacc=np.sqrt((gpm_o ** 2).sum(1)) / G, want_pot=True)
+    P = pkg.make_particles(pos, mass)
+    P["GravPM"] = gpm_o
+    P["FullTreeGravAccel"] = 0.0
+    try:
+        engine.set_walk_variant(6)
+        engine.set_walk_offsets64(True)
+        engine.set_instrumentation(False, True)
+        engine.force_tree_full(P, box)
+        engine.grav_short_tree(P)
+        c = engine.walk_counters()
+    finally:
+        engine.set_walk_variant(0)
+        engine.set_walk_offsets64(False)
+        engine.set_instrumentation(False, False)
+    assert (c["pp"], c["nodes_visited"], c["nodes_used"]) == tuple(c_ref)
+    assert_accel_parity(P["FullTreeGravAccel"], a_ref)
+    assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
+
+
 @pytest.mark.parametrize("name", ["grav_sgrid16", "grav_sclust12"])
 def test_committed_oracle_vectors(pkg, engine, name):
     """The committed vectors of tests/golden/grav_*.npz are outputs of the ORACLE (make_golden.py), frozen at the state in which it
