@@ -304,16 +304,22 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         if(ballot64(overflow) != 0)
             break;
         // ---- phase B: every group takes its next leaf; lane s <-> particle s
+        // (the candidate of the NEXT leaf is requested before this one is tested: an iteration is a dependent LDS read -> gather -> test ->
+        // LDS append chain, and 4 waves per SIMD do not hide the gather's latency.  Lanes beyond the leaf's count read its first particle.)
+        unsigned e = (0 < nl) ? llist[0] : 0u;
+        int ps = (int)(e >> 4), pc = (int)(e & 15u);
+        Src4 cand = tv.src[ps + (s < pc ? s : 0)];
         for(int it = 0;; it++) {
             const bool has = it < nl;
             if(ballot64(has) == 0)
                 break;
-            const unsigned e = has ? llist[it] : 0u;
-            const int ps = (int)(e >> 4), pc = (int)(e & 15u);
+            const unsigned e_n = (it + 1 < nl) ? llist[it + 1] : 0u;
+            const int ps_n = (int)(e_n >> 4), pc_n = (int)(e_n & 15u);
+            const Src4 cand_n = tv.src[ps_n + (s < pc_n ? s : 0)];
             bool keep = false;
             if(s < pc) {
                 n_cand++;
-                keep = density_test(tv.src[ps + s], px, py, pz, h2, kern.HH, tv.box, n_int);
+                keep = density_test(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
             if(ballot64(cnt >= 16) != 0) {
@@ -323,6 +329,9 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                     cnt = cbuf_pop8(cbuf, cnt, s);
                 }
             }
+            cand = cand_n;
+            ps = ps_n;
+            pc = pc_n;
         }
         if(ballot64(sp > 0) == 0)
             break;
@@ -716,7 +725,7 @@ __device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, cons
 }
 
 // hydro_force loop: group-cooperative walk with the symmetric cull (see k_density)
-__global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_hydro_params HP,
+__global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_hydro_params HP,
                                                const HydroCtl C, const HydroSrc *__restrict__ hs, const double *__restrict__ hsml_t,
                                                const int *__restrict__ slot_of,
                                                const int *__restrict__ targets, int64_t ntargets, unsigned long long *__restrict__ stats,
@@ -787,16 +796,23 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
         if(ballot64(overflow) != 0)
             break;
         // ---- phase B: every group takes its next leaf; lane s <-> particle s
+        // (the candidate of the next leaf is requested before this one is tested: see k_density)
+        unsigned e = (0 < nl) ? llist[0] : 0u;
+        int ps = (int)(e >> 4), pc = (int)(e & 15u);
+        Src4 cand = tv.src[ps + (s < pc ? s : 0)];
+        double cand_h = hsml_t[ps + (s < pc ? s : 0)];
         for(int it = 0;; it++) {
             const bool has = it < nl;
             if(ballot64(has) == 0)
                 break;
-            const unsigned e = has ? llist[it] : 0u;
-            const int ps = (int)(e >> 4), pc = (int)(e & 15u);
+            const unsigned e_n = (it + 1 < nl) ? llist[it + 1] : 0u;
+            const int ps_n = (int)(e_n >> 4), pc_n = (int)(e_n & 15u);
+            const Src4 cand_n = tv.src[ps_n + (s < pc_n ? s : 0)];
+            const double cand_hn = hsml_t[ps_n + (s < pc_n ? s : 0)];
             bool keep = false;
             if(s < pc) {
                 n_cand++;
-                keep = hydro_test(tv.src[ps + s], hsml_t[ps + s], t, kernel_i, C, tv.box);
+                keep = hydro_test(cand, cand_h, t, kernel_i, C, tv.box);
                 n_pair += keep ? 1u : 0u;
             }
             cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
@@ -807,6 +823,10 @@ __global__ void __launch_bounds__(256) k_hydro(const TreeView tv, const SphView 
                     cnt = cbuf_pop8(cbuf, cnt, s);
                 }
             }
+            cand = cand_n;
+            cand_h = cand_hn;
+            ps = ps_n;
+            pc = pc_n;
         }
         if(ballot64(sp > 0) == 0)
             break;
