@@ -104,4 +104,52 @@ __device__ __forceinline__ unsigned walk_step(const TreeView &tv, unsigned *stac
     return can ? gm_leaf : 0u;
 }
 
+// Two child ranges per step (round 3, the SPH loops): the search is a chain of dependent steps - LDS pop -> node loads -> cull ->
+// ballots -> LDS push, ~57 per wave of 8 targets in the hydro loop and 45 % of that kernel's time (cycle counters) - whose
+// latency 4 waves per SIMD do not hide; taking the two topmost ranges of the LIFO at once halves the number of sequential steps for
+// the same node tests.  Lane s tests child s of both ranges.  The leaves opened go to the group's list, first those of the upper range.
+// Returns the new number of list entries.
+template <bool SYM>
+__device__ __forceinline__ int walk_step2(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
+                                          const double hsml, const double px, const double py, const double pz, unsigned *llist, int nl, bool &overflow)
+{
+    const bool can = valid_more;
+    const bool can2 = can && sp > 1;
+    const unsigned r1 = can ? stack[sp - 1] : 0u, r2 = can2 ? stack[sp - 2] : 0u;
+    const int n1 = (int)(r1 & 15u), n2 = (int)(r2 & 15u);
+    const bool t1 = s < n1, t2 = s < n2;
+    // (lanes without a child read node 0: no exec-mask regions around the loads, both nodes' loads are issued together)
+    const int my1 = t1 ? (int)(r1 >> 4) + s : 0, my2 = t2 ? (int)(r2 >> 4) + s : 0;
+    const NodeGeo g1 = tv.geoB[my1], g2 = tv.geoB[my2];
+    const NodeLinkB k1 = tv.linkB[my1], k2 = tv.linkB[my2];
+    const double h1 = SYM ? tv.hmaxB[my1] : 0.0, h2 = SYM ? tv.hmaxB[my2] : 0.0;
+    const double invbox = 1.0 / tv.box;
+    const bool in1 = t1 && !cull_node(g1, h1, hsml, px, py, pz, tv.box, invbox);
+    const bool in2 = t2 && !cull_node(g2, h2, hsml, px, py, pz, tv.box, invbox);
+    const bool leaf1 = in1 && k1.pcount > 0, leaf2 = in2 && k2.pcount > 0;
+    const bool push1 = in1 && k1.pcount <= 0 && k1.nchild > 0, push2 = in2 && k2.pcount <= 0 && k2.nchild > 0;
+    const unsigned gl1 = (unsigned)((ballot64(leaf1) >> gshift) & 0xffull), gl2 = (unsigned)((ballot64(leaf2) >> gshift) & 0xffull);
+    const unsigned gp1 = (unsigned)((ballot64(push1) >> gshift) & 0xffull), gp2 = (unsigned)((ballot64(push2) >> gshift) & 0xffull);
+    const unsigned below = (1u << s) - 1u;
+    const int base = sp - (can ? 1 : 0) - (can2 ? 1 : 0);
+    const int np1 = __popc(gp1), np2 = __popc(gp2);
+    if(can && base + np1 + np2 > SPH_STK)
+        overflow = true;
+    else {
+        // the lower range's children below the upper range's: the search stays depth-first in the upper range
+        if(push2)
+            stack[base + __popc(gp2 & below)] = ((unsigned)k2.firstchild << 4) | (unsigned)k2.nchild;
+        if(push1)
+            stack[base + np2 + __popc(gp1 & below)] = ((unsigned)k1.firstchild << 4) | (unsigned)k1.nchild;
+    }
+    if(can)
+        sp = base + np1 + np2;
+    if(leaf1)
+        llist[nl + __popc(gl1 & below)] = ((unsigned)k1.pstart << 4) | (unsigned)k1.pcount;
+    const int nl1 = nl + (can ? __popc(gl1) : 0);
+    if(leaf2)
+        llist[nl1 + __popc(gl2 & below)] = ((unsigned)k2.pstart << 4) | (unsigned)k2.pcount;
+    return nl1 + (can ? __popc(gl2) : 0);
+}
+
 } // namespace mpg

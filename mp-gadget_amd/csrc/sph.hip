@@ -292,12 +292,10 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
         for(;;) {
-            const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            int lps, lpc;
-            const unsigned gm = walk_step<false>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, lps, lpc, overflow);
-            nl = llist_push(llist, nl, gm, lps, lpc, s);
+            nl = walk_step2<false>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
             if(ballot64(overflow) != 0)
                 break;
         }
@@ -784,12 +782,10 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
         for(;;) {
-            const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            int lps, lpc;
-            const unsigned gm = walk_step<true>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, lps, lpc, overflow);
-            nl = llist_push(llist, nl, gm, lps, lpc, s);
+            nl = walk_step2<true>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
             if(ballot64(overflow) != 0)
                 break;
         }
