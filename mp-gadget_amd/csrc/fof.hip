@@ -121,12 +121,10 @@ __global__ void __launch_bounds__(256) k_fof_walk(const TreeView tv, const doubl
     for(;;) {
         int nl = 0;
         for(;;) { // phase A: walk; opened leaves go to the group's list
-            const bool go = sp > 0 && nl + 8 <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            int lps, lpc;
-            const unsigned gm = walk_step<false>(tv, stack, sp, go, s, gshift, radius, px, py, pz, lps, lpc, overflow);
-            nl = llist_push(llist, nl, gm, lps, lpc, s);
+            nl = walk_stepk<false, 2>(tv, stack, sp, go, s, gshift, radius, px, py, pz, llist, nl, overflow); // (two child ranges per step: ngb_walk.h)
             if(ballot64(overflow) != 0)
                 break;
         }

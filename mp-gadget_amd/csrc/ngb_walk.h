@@ -41,17 +41,10 @@ __device__ __forceinline__ bool cull_node(const NodeGeo &g, double hm, double hs
 // pass over 2.1 M targets against the figures in DESIGN.md section 3.4.)
 constexpr int SPH_STK = 160; // pending child ranges per group: <= 7 per level + 8, 21 levels
 
-// The walk and the leaf work are separated in time so that the 8 groups of a wave stay in step: phase A walks (walk_step) and
+// The walk and the leaf work are separated in time so that the 8 groups of a wave stay in step: phase A walks (walk_stepk) and
 // only records the opened leaves in a per-group list in LDS; phase B lets every group take its next leaf per iteration.
 // (Interleaving them made every group wait while one group tested the leaves it had just opened.)
-constexpr int SPH_LCAP = 120; // leaf entries per group; phase A pauses when a group may not fit 8 more
-
-__device__ __forceinline__ int llist_push(unsigned *llist, int nl, const unsigned gm_leaf, const int lps, const int lpc, const int s)
-{
-    if(lpc > 0)
-        llist[nl + __popc(gm_leaf & ((1u << s) - 1u))] = ((unsigned)lps << 4) | (unsigned)lpc;
-    return nl + __popc(gm_leaf);
-}
+constexpr int SPH_LCAP = 120; // leaf entries per group; phase A pauses when a group may not fit 8 more per child range of a step
 
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -60,96 +53,75 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
-// One cooperative walk step shared by both loops: pops a child range, culls, pushes; returns in (leaf_ps, leaf_pc) the leaf
-// this lane opened (pc = 0: none) and the group's mask of lanes that opened one.  SYM: symmetric search radius
-// max(node hmax, Hsml) (hydro); otherwise Hsml (density).
-template <bool SYM>
-__device__ __forceinline__ unsigned walk_step(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
-                                              const double hsml, const double px, const double py, const double pz, int &leaf_ps, int &leaf_pc,
-                                              bool &overflow)
-{
-    const bool can = valid_more;
-    const unsigned range = can ? stack[sp - 1] : 0u;
-    const int first = (int)(range >> 4), nch = (int)(range & 15u);
-    int act = 0;
-    unsigned pushval = 0;
-    leaf_pc = 0;
-    leaf_ps = 0;
-    if(can && s < nch) {
-        const int my = first + s;
-        const NodeGeo g = tv.geoB[my];
-        const NodeLinkB lk = tv.linkB[my];
-        const double hm = SYM ? tv.hmaxB[my] : 0.0;
-        if(!cull_node(g, hm, hsml, px, py, pz, tv.box, 1.0 / tv.box)) {
-            if(lk.pcount > 0) {
-                act = 1;
-                leaf_ps = lk.pstart;
-                leaf_pc = lk.pcount;
-            }
-            else if(lk.nchild > 0) {
-                act = 3;
-                pushval = ((unsigned)lk.firstchild << 4) | (unsigned)lk.nchild;
-            }
-        }
-    }
-    const unsigned gm_leaf = (unsigned)((ballot64(act == 1) >> gshift) & 0xffull);
-    const unsigned gm_push = (unsigned)((ballot64(act == 3) >> gshift) & 0xffull);
-    const unsigned below = (1u << s) - 1u;
-    if(can && sp - 1 + __popc(gm_push) > SPH_STK)
-        overflow = true;
-    else if(act == 3)
-        stack[sp - 1 + __popc(gm_push & below)] = pushval;
-    if(can)
-        sp += __popc(gm_push) - 1;
-    return can ? gm_leaf : 0u;
-}
-
-// Two child ranges per step (round 3, the SPH loops): the search is a chain of dependent steps - LDS pop -> node loads -> cull ->
+// One cooperative search step: pops child ranges, culls, pushes; SYM: symmetric search radius max(node hmax, Hsml) (hydro);
+// otherwise Hsml (density, FOF, the pair-wise gravity check).  K child ranges per step (round 3; rounds 1-2 took one): the search is a
+// chain of dependent steps - LDS pop -> node loads -> cull ->
 // ballots -> LDS push, ~57 per wave of 8 targets in the hydro loop and 45 % of that kernel's time (cycle counters) - whose
-// latency 4 waves per SIMD do not hide; taking the two topmost ranges of the LIFO at once halves the number of sequential steps for
-// the same node tests.  Lane s tests child s of both ranges.  The leaves opened go to the group's list, first those of the upper range.
+// latency 4 waves per SIMD do not hide; taking the K topmost ranges of the LIFO at once divides the number of sequential steps
+// for the same node tests.  Lane s tests child s of every range.  The leaves opened go to the group's list, first those of the upper ranges.
 // Returns the new number of list entries.
-template <bool SYM>
-__device__ __forceinline__ int walk_step2(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
+template <bool SYM, int K>
+__device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
                                           const double hsml, const double px, const double py, const double pz, unsigned *llist, int nl, bool &overflow)
 {
     const bool can = valid_more;
-    const bool can2 = can && sp > 1;
-    const unsigned r1 = can ? stack[sp - 1] : 0u, r2 = can2 ? stack[sp - 2] : 0u;
-    const int n1 = (int)(r1 & 15u), n2 = (int)(r2 & 15u);
-    const bool t1 = s < n1, t2 = s < n2;
-    // (lanes without a child read node 0: no exec-mask regions around the loads, both nodes' loads are issued together)
-    const int my1 = t1 ? (int)(r1 >> 4) + s : 0, my2 = t2 ? (int)(r2 >> 4) + s : 0;
-    const NodeGeo g1 = tv.geoB[my1], g2 = tv.geoB[my2];
-    const NodeLinkB k1 = tv.linkB[my1], k2 = tv.linkB[my2];
-    const double h1 = SYM ? tv.hmaxB[my1] : 0.0, h2 = SYM ? tv.hmaxB[my2] : 0.0;
     const double invbox = 1.0 / tv.box;
-    const bool in1 = t1 && !cull_node(g1, h1, hsml, px, py, pz, tv.box, invbox);
-    const bool in2 = t2 && !cull_node(g2, h2, hsml, px, py, pz, tv.box, invbox);
-    const bool leaf1 = in1 && k1.pcount > 0, leaf2 = in2 && k2.pcount > 0;
-    const bool push1 = in1 && k1.pcount <= 0 && k1.nchild > 0, push2 = in2 && k2.pcount <= 0 && k2.nchild > 0;
-    const unsigned gl1 = (unsigned)((ballot64(leaf1) >> gshift) & 0xffull), gl2 = (unsigned)((ballot64(leaf2) >> gshift) & 0xffull);
-    const unsigned gp1 = (unsigned)((ballot64(push1) >> gshift) & 0xffull), gp2 = (unsigned)((ballot64(push2) >> gshift) & 0xffull);
     const unsigned below = (1u << s) - 1u;
-    const int base = sp - (can ? 1 : 0) - (can2 ? 1 : 0);
-    const int np1 = __popc(gp1), np2 = __popc(gp2);
-    if(can && base + np1 + np2 > SPH_STK)
+    unsigned r[K];
+    int my[K];
+    bool tst[K];
+#pragma unroll
+    for(int k = 0; k < K; k++) { // range k: the k-th entry from the top of the LIFO
+        r[k] = (can && sp > k) ? stack[sp - 1 - k] : 0u;
+        tst[k] = s < (int)(r[k] & 15u);
+        my[k] = tst[k] ? (int)(r[k] >> 4) + s : 0; // (lanes without a child read node 0: no exec-mask regions, all loads issued together)
+    }
+    NodeGeo g[K];
+    NodeLinkB lk[K];
+    double hm[K];
+#pragma unroll
+    for(int k = 0; k < K; k++) {
+        g[k] = tv.geoB[my[k]];
+        lk[k] = tv.linkB[my[k]];
+        hm[k] = SYM ? tv.hmaxB[my[k]] : 0.0;
+    }
+    unsigned gl[K], gp[K];
+    bool leaf[K], push[K];
+#pragma unroll
+    for(int k = 0; k < K; k++) {
+        const bool in = tst[k] && !cull_node(g[k], hm[k], hsml, px, py, pz, tv.box, invbox);
+        leaf[k] = in && lk[k].pcount > 0;
+        push[k] = in && lk[k].pcount <= 0 && lk[k].nchild > 0;
+        gl[k] = (unsigned)((ballot64(leaf[k]) >> gshift) & 0xffull);
+        gp[k] = (unsigned)((ballot64(push[k]) >> gshift) & 0xffull);
+    }
+    const int taken = can ? (sp < K ? sp : K) : 0;
+    const int base = sp - taken;
+    int npush = 0;
+#pragma unroll
+    for(int k = 0; k < K; k++)
+        npush += __popc(gp[k]);
+    if(can && base + npush > SPH_STK)
         overflow = true;
     else {
-        // the lower range's children below the upper range's: the search stays depth-first in the upper range
-        if(push2)
-            stack[base + __popc(gp2 & below)] = ((unsigned)k2.firstchild << 4) | (unsigned)k2.nchild;
-        if(push1)
-            stack[base + np2 + __popc(gp1 & below)] = ((unsigned)k1.firstchild << 4) | (unsigned)k1.nchild;
+        // the children of the lower ranges below those of the upper ones: the search stays depth-first in the topmost range
+        int at = base;
+#pragma unroll
+        for(int k = K - 1; k >= 0; k--) {
+            if(push[k])
+                stack[at + __popc(gp[k] & below)] = ((unsigned)lk[k].firstchild << 4) | (unsigned)lk[k].nchild;
+            at += __popc(gp[k]);
+        }
     }
     if(can)
-        sp = base + np1 + np2;
-    if(leaf1)
-        llist[nl + __popc(gl1 & below)] = ((unsigned)k1.pstart << 4) | (unsigned)k1.pcount;
-    const int nl1 = nl + (can ? __popc(gl1) : 0);
-    if(leaf2)
-        llist[nl1 + __popc(gl2 & below)] = ((unsigned)k2.pstart << 4) | (unsigned)k2.pcount;
-    return nl1 + (can ? __popc(gl2) : 0);
+        sp = base + npush;
+#pragma unroll
+    for(int k = 0; k < K; k++) {
+        if(leaf[k])
+            llist[nl + __popc(gl[k] & below)] = ((unsigned)lk[k].pstart << 4) | (unsigned)lk[k].pcount;
+        nl += can ? __popc(gl[k]) : 0;
+    }
+    return nl;
 }
 
 } // namespace mpg

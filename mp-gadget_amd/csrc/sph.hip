@@ -154,6 +154,10 @@ __global__ void __launch_bounds__(256) k_sph_predict(int64_t npart, const int *_
 
 
 
+#ifndef SPH_WALK_K
+#define SPH_WALK_K 2 // child ranges per search step (walk_stepk, ngb_walk.h)
+#endif
+
 struct DensAcc {
     double EgyRho = 0, DhsmlEgy = 0, Rho = 0, DhsmlDensity = 0, Ngb = 0, Div = 0, Rot0 = 0, Rot1 = 0, Rot2 = 0, G0 = 0, G1 = 0, G2 = 0;
 };
@@ -292,10 +296,10 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
         for(;;) {
-            const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_step2<false>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
+            nl = walk_stepk<false, SPH_WALK_K>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
             if(ballot64(overflow) != 0)
                 break;
         }
@@ -782,10 +786,10 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
         for(;;) {
-            const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_step2<true>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
+            nl = walk_stepk<true, SPH_WALK_K>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
             if(ballot64(overflow) != 0)
                 break;
         }
