@@ -165,7 +165,7 @@ struct DensAcc {
 // Candidate handling is split in two so that the expensive part runs with full lanes: every candidate of an opened leaf
 // gets the distance test (treewalk.c:1218-1232; cheap, ~1/3 pass), the survivors are compacted into a small per-group
 // buffer in LDS, and the kernel evaluation (density_ngbiter / hydro_ngbiter) is run 8 survivors at a time.
-constexpr int SPH_CBUF = 24; // survivor slots per group: evaluation triggers when any group of the wave holds >= 16
+constexpr int SPH_CBUF = 32; // survivor slots per group (a ring: a power of two); an evaluation is triggered when any group of the wave holds >= 16
 
 // distance test of density: returns whether the kernel evaluation is needed; counts the reference's "ninteractions"
 __device__ __forceinline__ bool density_test(const Src4 s, const double px, const double py, const double pz, const double h2, const double HH,
@@ -216,33 +216,15 @@ __device__ __forceinline__ void density_eval(const Src4 s, const Aux4 o, const d
     }
 }
 
-// appends this lane's survivor (if any) to the group's buffer; returns the new (group-uniform) fill level
-__device__ __forceinline__ int cbuf_push(int *cbuf, int cnt, const bool keep, const int sidx, const int s, const int gshift)
+// The survivor buffer of a group is a ring of SPH_CBUF slots (head, cnt group-uniform: no entries are moved after an evaluation).
+// Appends this lane's survivor (if any); returns the new fill level.
+__device__ __forceinline__ int cbuf_push(int *cbuf, const int head, int cnt, const bool keep, const int sidx, const int s, const int gshift)
 {
     const unsigned gm = (unsigned)((ballot64(keep) >> gshift) & 0xffull);
     if(keep)
-        cbuf[cnt + __popc(gm & ((1u << s) - 1u))] = sidx;
+        cbuf[(head + cnt + __popc(gm & ((1u << s) - 1u))) & (SPH_CBUF - 1)] = sidx;
     return cnt + __popc(gm);
 }
-
-
-// after the first 8 survivors were evaluated: move the rest to the front
-__device__ __forceinline__ int cbuf_pop8(int *cbuf, int cnt, const int s)
-{
-    const int rest = cnt - 8;
-    int v0 = 0, v1 = 0;
-    if(s < rest)
-        v0 = cbuf[8 + s];
-    if(8 + s < rest)
-        v1 = cbuf[16 + s];
-    if(s < rest)
-        cbuf[s] = v0;
-    if(8 + s < rest)
-        cbuf[8 + s] = v1;
-    return rest;
-}
-
-
 
 // One density pass over the current queue: treewalk_visit_nolist_ngbiter + density_ngbiter + density_reduce +
 // density_postprocess + density_check_neighbours.  Targets that are not done are appended to `redo`.
@@ -259,7 +241,7 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
     int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
     unsigned *llist = s_llist + ((threadIdx.x >> 6) * 8 + grp) * SPH_LCAP;
-    int cnt = 0; // survivors waiting in cbuf (group-uniform)
+    int cnt = 0, head = 0; // survivors waiting in the group's ring buffer, its first slot (group-uniform)
     const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
     const bool valid = q < nqueue;
     unsigned n_int = 0, n_cand = 0;
@@ -323,12 +305,13 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
                 n_cand++;
                 keep = density_test(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
             }
-            cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
+            cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
             if(ballot64(cnt >= 16) != 0) {
                 if(cnt >= 8) {
-                    const int sidx = cbuf[s];
+                    const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
                     density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
-                    cnt = cbuf_pop8(cbuf, cnt, s);
+                    head = (head + 8) & (SPH_CBUF - 1);
+                    cnt -= 8;
                 }
             }
             cand = cand_n;
@@ -345,10 +328,11 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
     }
     while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
         if(s < cnt) {
-            const int sidx = cbuf[s];
+            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
             density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
         }
-        cnt = cnt > 8 ? cbuf_pop8(cbuf, cnt, s) : 0;
+        head = (head + 8) & (SPH_CBUF - 1);
+        cnt = cnt > 8 ? cnt - 8 : 0;
     }
     // sum over the 8 lanes of the group
     a.EgyRho = group_sum(a.EgyRho);
@@ -741,7 +725,7 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
     int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
     unsigned *llist = s_llist + ((threadIdx.x >> 6) * 8 + grp) * SPH_LCAP;
-    int cnt = 0; // survivors waiting in cbuf (group-uniform)
+    int cnt = 0, head = 0; // survivors waiting in the group's ring buffer, its first slot (group-uniform)
     const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
     const bool valid = q < ntargets; // the queue holds gas particles only (hydro_haswork)
     unsigned n_cand = 0, n_pair = 0;
@@ -815,12 +799,13 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
                 keep = hydro_test(cand, cand_h, t, kernel_i, C, tv.box);
                 n_pair += keep ? 1u : 0u;
             }
-            cnt = cbuf_push(cbuf, cnt, keep, ps + s, s, gshift);
+            cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
             if(ballot64(cnt >= 16) != 0) {
                 if(cnt >= 8) {
-                    const int sidx = cbuf[s];
+                    const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
                     hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
-                    cnt = cbuf_pop8(cbuf, cnt, s);
+                    head = (head + 8) & (SPH_CBUF - 1);
+                    cnt -= 8;
                 }
             }
             cand = cand_n;
@@ -838,10 +823,11 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
     }
     while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
         if(s < cnt) {
-            const int sidx = cbuf[s];
+            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
             hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
         }
-        cnt = cnt > 8 ? cbuf_pop8(cbuf, cnt, s) : 0;
+        head = (head + 8) & (SPH_CBUF - 1);
+        cnt = cnt > 8 ? cnt - 8 : 0;
     }
     a.Acc0 = group_sum(a.Acc0);
     a.Acc1 = group_sum(a.Acc1);

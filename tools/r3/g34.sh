@@ -15,7 +15,7 @@ for r in list(csv.DictReader(open("$R/gpurun_out/r3w/trace_$1/trace_kernel_stats
 PY
 }
 run base ""
-run K3 "sph.hip:-DSPH_WALK_K=3"
-run K4 "sph.hip:-DSPH_WALK_K=4"
+
+
 cp /tmp/lib_orig.so $R/mp-gadget_amd/libmpgadget_hip.so
 find $R/gpurun_out/r3w -name "*kernel_trace.csv" -delete
