@@ -1,6 +1,6 @@
-"""cpu_baseline experiments on the GPU box's host: python tools/r3/cb_test.py n log2(sample) [groups like 1x8, 8x16]"""
+"""cpu_baseline experiments on the GPU box's host: python tools/cpu_baseline_threads.py n log2(sample) [groups like 1x8, 8x16]"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import importlib, numpy as np
 import bench
