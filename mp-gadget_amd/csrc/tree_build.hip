@@ -36,13 +36,25 @@ __device__ __forceinline__ int cpl_levels(uint64_t a, uint64_t b)
 }
 
 // include: optional byte per particle, 0 = leave out (the active-particle trees of force_tree_active_moments)
-__global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restrict__ pos, const uint8_t *__restrict__ type, int mask,
-                                              const uint8_t *__restrict__ include, double box, uint64_t *__restrict__ keys,
-                                              uint32_t *__restrict__ idx, unsigned long long *__restrict__ nexcluded)
+// the particles a tree holds: the types of the mask (forcetree.c:357-365), and of those the ones flagged in `include` if given
+struct TreeMember {
+    const uint8_t *type, *include;
+    int mask;
+    __device__ bool operator()(const uint32_t i) const
+    {
+        const int ty = type ? (type[i] & 7) : 1;
+        return (((1 << ty) & mask) != 0) && (!include || include[i]);
+    }
+};
+
+// octant path of particle idx[k] (all particles in caller order when idx is null, in which case idx is written too)
+__global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restrict__ pos, const uint32_t *__restrict__ members, double box,
+                                              uint64_t *__restrict__ keys, uint32_t *__restrict__ idx)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= n)
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
         return;
+    const int64_t i = members ? (int64_t)members[k] : k;
     const double x = pos[3 * i + 0], y = pos[3 * i + 1], z = pos[3 * i + 2];
     double cx = box / 2., cy = box / 2., cz = box / 2.;
     double len = box * 1.001;
@@ -57,14 +69,9 @@ __global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restric
         cz += bz ? q : -q;
         len *= 0.5;
     }
-    const int ty = type ? (type[i] & 7) : 1;
-    const bool in = (((1 << ty) & mask) != 0) && (!include || include[i]);
-    if(!in) {
-        key = ~0ull;
-        atomicAdd(nexcluded, 1ull);
-    }
-    keys[i] = key;
-    idx[i] = (uint32_t)i;
+    keys[k] = key;
+    if(!members)
+        idx[k] = (uint32_t)i;
 }
 
 __global__ void __launch_bounds__(256) k_gather_src(int64_t n, const uint32_t *__restrict__ order, const double *__restrict__ pos,
@@ -454,23 +461,38 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     idx_b.reserve(n + 1);
     flags.reserve(8);
     MPG_HIP(hipMemsetAsync(flags.p, 0, 8 * sizeof(int64_t), st));
-    unsigned long long *d_nexcl = (unsigned long long *)(flags.p + 4);
+    unsigned long long *d_nmemb = (unsigned long long *)(flags.p + 4);
     int *d_flags = (int *)flags.p;
-    if(n > 0)
-        hipLaunchKernelGGL(k_keys, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_type, mask, d_include, box, keys_a.p, idx_a.p, d_nexcl);
+    // A tree of a subset (a type mask, an include list: the gas tree of the SPH loops, the trees of the active particles of the
+    // hierarchical gravity levels) first compacts its members' indices and computes and sorts keys for those alone.  (Rounds 1-2 gave the
+    // other particles the key ~0 and counted them with one same-address atomic each: 3.2 ms for the keys of a 32 768-particle tree in a
+    // 256^3 table, plus the sort of all 2^24 keys.)
+    npart = n;
+    const bool subset = n > 0 && (d_type != nullptr || d_include != nullptr);
+    if(subset) {
+        rocprim::counting_iterator<uint32_t> iota(0);
+        const TreeMember member{d_type, d_include, mask};
+        size_t sb = 0;
+        MPG_HIP(rocprim::select(nullptr, sb, iota, idx_a.p, d_nmemb, (size_t)n, member, st));
+        tmp.reserve(sb + 16);
+        MPG_HIP(rocprim::select((void *)tmp.p, sb, iota, idx_a.p, d_nmemb, (size_t)n, member, st));
+        unsigned long long nm = 0;
+        MPG_HIP(hipMemcpyAsync(&nm, d_nmemb, sizeof(nm), hipMemcpyDeviceToHost, st));
+        MPG_HIP(hipStreamSynchronize(st));
+        npart = (int64_t)nm;
+    }
+    if(npart > 0)
+        hipLaunchKernelGGL(k_keys, dim3(nblk(npart)), dim3(256), 0, st, npart, d_pos, subset ? (const uint32_t *)idx_a.p : (const uint32_t *)nullptr, box, keys_a.p,
+                           idx_a.p);
     if(tm)
         tm->lap(st, &tm->t.tree_keys);
-    // --- sort
+    // --- sort (stable: particles with equal keys stay in caller order)
     size_t tmpbytes = 0;
-    if(n > 0) {
-        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)n, 0, 64, st));
+    if(npart > 0) {
+        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, 0, 64, st));
         tmp.reserve(tmpbytes + 16);
-        MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)n, 0, 64, st));
+        MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, 0, 64, st));
     }
-    unsigned long long nexcl = 0;
-    MPG_HIP(hipMemcpyAsync(&nexcl, d_nexcl, sizeof(nexcl), hipMemcpyDeviceToHost, st));
-    MPG_HIP(hipStreamSynchronize(st));
-    npart = n - (int64_t)nexcl;
     if(tm)
         tm->lap(st, &tm->t.tree_sort);
     // --- leaf levels, node numbering
