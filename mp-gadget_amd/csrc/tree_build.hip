@@ -486,22 +486,29 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
                            idx_a.p);
     if(tm)
         tm->lap(st, &tm->t.tree_keys);
-    // --- sort (stable: particles with equal keys stay in caller order)
-    size_t tmpbytes = 0;
-    if(npart > 0) {
-        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, 0, 64, st));
-        tmp.reserve(tmpbytes + 16);
-        MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, 0, 64, st));
-    }
-    if(tm)
-        tm->lap(st, &tm->t.tree_sort);
-    // --- leaf levels, node numbering
+    // --- sort (stable: particles with equal keys stay in caller order), leaf levels, node numbering.
+    // A tree whose leaves all lie at level <= 10 is fully determined by the top 30 bits of the keys: when the previous tree built here was
+    // that shallow, only those bits are sorted (4 radix passes instead of 8) and the leaf levels found are checked - a level-10 cell with
+    // more than 8 particles shows up as a leaf level > 10, and the sort is then done again on all bits.  (Within a leaf the particles
+    // are then in caller order instead of key order: the node set and every decision are the same, sums differ by rounding.)
+    static const bool full_sort_only = getenv("MPG_TREE_FULL_SORT") != nullptr;
+    bool short_sort = !full_sort_only && maxlevel > 0 && maxlevel <= 9;
+    constexpr int SHORT_LEVELS = 10;
     leaflevel.reserve(npart + 1);
     cnt.reserve(npart + 1);
     base.reserve(npart + 1);
     int hflags[3] = {0, 0, 0};
     uint32_t lastbase = 0, lastcnt = 0;
-    if(npart > 0) {
+    for(;;) {
+        if(npart == 0)
+            break;
+        const unsigned begin_bit = short_sort ? (unsigned)(3 * (MAXLEVEL - SHORT_LEVELS)) : 0u;
+        size_t tmpbytes = 0;
+        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, begin_bit, 64, st));
+        tmp.reserve(tmpbytes + 16);
+        MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, begin_bit, 64, st));
+        if(tm)
+            tm->lap(st, &tm->t.tree_sort);
         const int64_t nwaves = (int64_t)nblk(npart) * 4;
         wave_ext.reserve((size_t)nwaves);
         hipLaunchKernelGGL(k_leaflevel, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, d_flags, wave_ext.p, force_internal_above);
@@ -514,6 +521,14 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
         MPG_HIP(hipMemcpyAsync(&lastbase, base.p + (npart - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         MPG_HIP(hipMemcpyAsync(&lastcnt, cnt.p + (npart - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         MPG_HIP(hipStreamSynchronize(st));
+        if(short_sort && (hflags[1] > SHORT_LEVELS || hflags[0] != 0)) { // deeper than the bits sorted: all bits
+            short_sort = false;
+            MPG_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), st));
+            continue;
+        }
+        break;
+    }
+    if(npart > 0) {
         MPG_CHECK(hflags[0] == 0, "tree build: more than 8 particles share one 2^-21 cell (coincident particles; the reference "
                                   "aborts here too, forcetree.c:393-412)");
         nnodes = (int64_t)lastbase + lastcnt;
