@@ -58,6 +58,7 @@ struct TreeBuilder {
 
     DevBuf<uint64_t> keys_a, keys_b;
     DevBuf<uint32_t> idx_a, idx_b; // idx_b: tree order -> caller index
+    DevBuf<uint32_t> hi_a, hi_b, pos_a, pos_b; // short sort: top key bits and positions (tree_build.hip)
     DevBuf<uint8_t> leaflevel;
     DevBuf<uint32_t> cnt, base;
     DevBuf<int64_t> flags;

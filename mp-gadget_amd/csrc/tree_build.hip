@@ -74,6 +74,27 @@ __global__ void __launch_bounds__(256) k_keys(int64_t n, const double *__restric
         idx[k] = (uint32_t)i;
 }
 
+// the top bits of the keys as 32-bit keys, and the positions they are sorted with
+__global__ void __launch_bounds__(256) k_key_tops(int64_t n, const uint64_t *__restrict__ keys, int shift, uint32_t *__restrict__ hi, uint32_t *__restrict__ pos)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    hi[k] = (uint32_t)(keys[k] >> shift);
+    pos[k] = (uint32_t)k;
+}
+
+__global__ void __launch_bounds__(256) k_apply_order(int64_t n, const uint32_t *__restrict__ pos, const uint64_t *__restrict__ keys_in,
+                                                     const uint32_t *__restrict__ idx_in, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ idx_out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k >= n)
+        return;
+    const uint32_t p = pos[k];
+    keys_out[k] = keys_in[p];
+    idx_out[k] = idx_in[p];
+}
+
 __global__ void __launch_bounds__(256) k_gather_src(int64_t n, const uint32_t *__restrict__ order, const double *__restrict__ pos,
                                                     const float *__restrict__ mass, Src4 *__restrict__ src)
 {
@@ -487,12 +508,13 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     if(tm)
         tm->lap(st, &tm->t.tree_keys);
     // --- sort (stable: particles with equal keys stay in caller order), leaf levels, node numbering.
-    // A tree whose leaves all lie at level <= 10 is fully determined by the top 30 bits of the keys: when the previous tree built here was
-    // that shallow, only those bits are sorted (4 radix passes instead of 8) and the leaf levels found are checked - a level-10 cell with
-    // more than 8 particles shows up as a leaf level > 10, and the sort is then done again on all bits.  (Within a leaf the particles
-    // are then in caller order instead of key order: the node set and every decision are the same, sums differ by rounding.)
+    // A tree whose leaves all lie at level <= 10 is fully determined by the top 30 bits of the keys: those bits are sorted first (4 radix
+    // passes instead of 8) and the leaf levels found are the check - a level-10 cell with more than 8 particles shows up as a leaf level
+    // > 10, and the sort is then done again on all bits (a clustered set: 4 passes lost).  Within a leaf of a shallow tree the particles
+    // are in caller order instead of key order: the node set and every decision are the same, sums differ by rounding.  The attempt is
+    // made for EVERY tree, whatever the builder built before: the particle order is a function of the particle set alone.
     static const bool full_sort_only = getenv("MPG_TREE_FULL_SORT") != nullptr;
-    bool short_sort = !full_sort_only && maxlevel > 0 && maxlevel <= 9;
+    bool short_sort = !full_sort_only;
     constexpr int SHORT_LEVELS = 10;
     leaflevel.reserve(npart + 1);
     cnt.reserve(npart + 1);
@@ -502,11 +524,25 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     for(;;) {
         if(npart == 0)
             break;
-        const unsigned begin_bit = short_sort ? (unsigned)(3 * (MAXLEVEL - SHORT_LEVELS)) : 0u;
         size_t tmpbytes = 0;
-        MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, begin_bit, 64, st));
-        tmp.reserve(tmpbytes + 16);
-        MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, begin_bit, 64, st));
+        if(short_sort) {
+            // (the top 30 bits as 32-bit keys of their own, sorted with their position: rocprim 4.2's radix_sort_pairs returns wrong
+            // results - mismatched pairs - for begin_bit > 0 below a few million elements, measured with tools/sort_bits_check.hip)
+            hi_a.reserve(npart + 1);
+            hi_b.reserve(npart + 1);
+            pos_a.reserve(npart + 1);
+            pos_b.reserve(npart + 1);
+            hipLaunchKernelGGL(k_key_tops, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_a.p, 3 * (MAXLEVEL - SHORT_LEVELS), hi_a.p, pos_a.p);
+            MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, hi_a.p, hi_b.p, pos_a.p, pos_b.p, (size_t)npart, 0, 3 * SHORT_LEVELS, st));
+            tmp.reserve(tmpbytes + 16);
+            MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, hi_a.p, hi_b.p, pos_a.p, pos_b.p, (size_t)npart, 0, 3 * SHORT_LEVELS, st));
+            hipLaunchKernelGGL(k_apply_order, dim3(nblk(npart)), dim3(256), 0, st, npart, pos_b.p, keys_a.p, idx_a.p, keys_b.p, idx_b.p);
+        }
+        else {
+            MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, 0, 64, st));
+            tmp.reserve(tmpbytes + 16);
+            MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmpbytes, keys_a.p, keys_b.p, idx_a.p, idx_b.p, (size_t)npart, 0, 64, st));
+        }
         if(tm)
             tm->lap(st, &tm->t.tree_sort);
         const int64_t nwaves = (int64_t)nblk(npart) * 4;
