@@ -130,15 +130,20 @@ __global__ void __launch_bounds__(256) k_fof_walk(const TreeView tv, const doubl
         }
         if(ballot64(overflow) != 0)
             break;
-        for(int it = 0;; it++) { // phase B: every group takes its next leaf; lane s <-> particle s
+        // phase B: every group takes its next leaf; lane s <-> particle s.  (The particle of the NEXT leaf is requested before this one
+        // is tested, as in the SPH loops: sph.hip.  Lanes beyond a leaf's count read its first particle.)
+        unsigned e = (0 < nl) ? llist[0] : 0u;
+        int ps = (int)(e >> 4), pc = (int)(e & 15u);
+        Src4 o = tv.src[ps + (s < pc ? s : 0)];
+        for(int it = 0;; it++) {
             const bool has = it < nl;
             if(ballot64(has) == 0)
                 break;
-            const unsigned e = has ? llist[it] : 0u;
-            const int ps = (int)(e >> 4), pc = (int)(e & 15u);
+            const unsigned e_n = (it + 1 < nl) ? llist[it + 1] : 0u;
+            const int ps_n = (int)(e_n >> 4), pc_n = (int)(e_n & 15u);
+            const Src4 o_n = tv.src[ps_n + (s < pc_n ? s : 0)];
             if(s < pc) {
                 const int j = ps + s;
-                const Src4 o = tv.src[j];
                 const double d0 = nearest_img(px - o.x, tv.box, 1.0 / tv.box);
                 const double d1 = nearest_img(py - o.y, tv.box, 1.0 / tv.box);
                 const double d2 = nearest_img(pz - o.z, tv.box, 1.0 / tv.box);
@@ -154,6 +159,9 @@ __global__ void __launch_bounds__(256) k_fof_walk(const TreeView tv, const doubl
                     }
                 }
             }
+            o = o_n;
+            ps = ps_n;
+            pc = pc_n;
         }
         if(ballot64(sp > 0) == 0)
             break;

@@ -70,9 +70,12 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
     unsigned r[K];
     int my[K];
     bool tst[K];
+    // (more than one range only while the LIFO has room for all their children: a depth-first search with one range per step needs at
+    // most 7 entries per tree level + 8, which is what SPH_STK is sized for; K ranges at once could need up to K times that)
+    const int take = (SPH_STK - sp >= 7 * K) ? K : 1;
 #pragma unroll
     for(int k = 0; k < K; k++) { // range k: the k-th entry from the top of the LIFO
-        r[k] = (can && sp > k) ? stack[sp - 1 - k] : 0u;
+        r[k] = (can && sp > k && k < take) ? stack[sp - 1 - k] : 0u;
         tst[k] = s < (int)(r[k] & 15u);
         my[k] = tst[k] ? (int)(r[k] >> 4) + s : 0; // (lanes without a child read node 0: no exec-mask regions, all loads issued together)
     }
@@ -95,7 +98,7 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
         gl[k] = (unsigned)((ballot64(leaf[k]) >> gshift) & 0xffull);
         gp[k] = (unsigned)((ballot64(push[k]) >> gshift) & 0xffull);
     }
-    const int taken = can ? (sp < K ? sp : K) : 0;
+    const int taken = can ? (sp < take ? sp : take) : 0;
     const int base = sp - taken;
     int npush = 0;
 #pragma unroll
