@@ -310,6 +310,11 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         unsigned first = 0u;
         int nch = 1;
         for(int level = 0; tmask != 0u; level++) {
+            if(level > 64) { // (a corrupt tree: the loop guard of the main loop, for the chain of single opened nodes)
+                if(lane == 0)
+                    atomicExch(&ctl[1], 1u);
+                return false;
+            }
             const bool valid = tc < nch && ((tmask >> tt) & 1u);
             const unsigned my = first + (unsigned)(tc < nch ? tc : 0);
             const NodeGeo g = ld<O32>(tv.geoB, my);
