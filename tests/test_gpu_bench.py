@@ -47,14 +47,19 @@ def test_default_workload_line():
     assert h["ms_per_step"] > 0 and h["roofline"]["bound"] == "fp64_valu" and 0 < h["roofline"]["frac"] <= 1 and 0 < h["roofline_hydro"]["frac"] <= 1
 
 
-def test_multi_gpu_path_in_a_one_rank_group_checks_itself():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_multi_gpu_path_in_a_one_rank_group_checks_itself(overlap):
     """bench.py --gpus N runs the library's choreography and then checks its own forces: sampled particles recomputed on one GPU from
-    the whole set (parity_check in the line; a failed check exits non-zero)."""
-    j = run_bench(["--gpus", "1", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
-                  env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29171"})
+    the whole set (parity_check in the line; a failed check exits non-zero).  mpg_dist_gravity_step builds the local tree on a second
+    thread and stream beside the PM step; MPG_DIST_NO_OVERLAP=1 runs the phases one after the other: both forms pass the same check."""
+    env = {"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29171" if overlap else "29172"}
+    if not overlap:
+        env["MPG_DIST_NO_OVERLAP"] = "1"
+    j = run_bench(["--gpus", "1", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env)
     assert KEYS <= set(j) and j["value"] > 1e6
     pc = j["parity_check"]
     assert pc["ok"] and pc["counters_equal"] and pc["n"] >= 1024 and pc["median_rel"] <= 1e-12 and pc["gravpm_max_rel_to_mean"] <= 1e-11
+    assert (j["phases_ms"]["dist_tree_build_beside_pm_ms"] > 0) == overlap
 
 
 def test_multi_gpu_parity_check_on_four_ranks():
