@@ -378,6 +378,21 @@ int mpg_dev_set_walk_cost(mpg_engine *eng, float *d_cost)
     API_END
 }
 
+// OldAcc = |FullTreeGravAccel + GravPM| / G of every particle (grav_get_abs_accel, gravshort.h:70-80), the arithmetic of the walk kernels
+__global__ void __launch_bounds__(256) k_oldacc(int64_t n, const double *__restrict__ prev, const double *__restrict__ gravpm, double G,
+                                                double *__restrict__ old)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if(i >= n)
+        return;
+    double s2 = 0;
+    for(int j = 0; j < 3; j++) {
+        const double a = prev[3 * i + j] + (gravpm ? gravpm[3 * i + j] : 0.0);
+        s2 += a * a;
+    }
+    old[i] = sqrt(s2) / G;
+}
+
 int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm,
                             const int *d_active, int64_t nactive, double *d_accel, double *d_potential, double rho0)
 {
@@ -386,6 +401,16 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     MPG_HIP(hipSetDevice(eng->device));
     MPG_CHECK(eng->tree_allocated && eng->tree.has_moments, "Gravtree called before tree moments computed!"); // gravshort-tree.c:113-114
     const GravParams gp = make_gp(eng, rho0);
+    if(!d_oldacc && d_prev_accel && d_prev_accel == d_accel) {
+        // Results written in place over the previous acceleration (resident mode, mpg_dist callers): the two-kernel walk may run its
+        // list pass a second time with longer lists after the evaluation has stored new values for the targets that fitted, and the
+        // fallback kernels run after it, so the opening input is taken once, before any kernel of this walk writes.
+        eng->w_old.reserve((size_t)eng->n + 1);
+        hipLaunchKernelGGL(k_oldacc, dim3((unsigned)((eng->n + 255) / 256)), dim3(256), 0, eng->stream, eng->n, d_prev_accel, d_gravpm, gp.G,
+                           eng->w_old.p);
+        d_oldacc = eng->w_old.p;
+        d_prev_accel = nullptr;
+    }
     WalkIO io;
     io.targets = d_active;
     if(d_active)
@@ -1516,7 +1541,8 @@ int mpg_resident_begin(mpg_engine *eng, const mpg_particle_view *P, double BoxSi
     column_to_device(eng, *P, P->off_accel, 3, eng->r_accel.p);
     column_to_device(eng, *P, P->off_gravpm, 3, eng->r_gravpm.p);
     column_to_device(eng, *P, P->off_potential, 1, eng->r_pot.p);
-    if(P->off_vel >= 0) {
+    eng->res_has_vel = P->off_vel >= 0;
+    if(eng->res_has_vel) {
         eng->r_vel.reserve(3 * n + 3);
         column_to_device(eng, *P, P->off_vel, 3, eng->r_vel.p);
     }
@@ -1534,7 +1560,7 @@ int mpg_resident_arrays(mpg_engine *eng, mpg_resident_view *out)
     out->d_pos = eng->s_pos.p;
     out->d_mass = eng->s_mass.p;
     out->d_type = eng->s_type.p;
-    out->d_vel = eng->r_vel.p;
+    out->d_vel = eng->res_has_vel ? eng->r_vel.p : nullptr; // (a buffer left by an earlier session is not this table's Vel)
     out->d_fulltree_accel = eng->r_accel.p;
     out->d_gravpm = eng->r_gravpm.p;
     out->d_potential = eng->r_pot.p;
@@ -1547,7 +1573,7 @@ int mpg_resident_fetch(mpg_engine *eng, const mpg_particle_view *P, unsigned fie
     resident_check(eng, P);
     if(fields & MPG_FIELD_POS)
         column_to_host(eng, *P, P->off_pos, 3, eng->s_pos.p);
-    if((fields & MPG_FIELD_VEL) && P->off_vel >= 0 && eng->r_vel.p)
+    if((fields & MPG_FIELD_VEL) && P->off_vel >= 0 && eng->res_has_vel)
         column_to_host(eng, *P, P->off_vel, 3, eng->r_vel.p);
     if(fields & MPG_FIELD_ACCEL)
         column_to_host(eng, *P, P->off_accel, 3, eng->r_accel.p);
@@ -1569,6 +1595,7 @@ int mpg_resident_push(mpg_engine *eng, const mpg_particle_view *P, unsigned fiel
     if((fields & MPG_FIELD_VEL) && P->off_vel >= 0) {
         eng->r_vel.reserve(3 * (size_t)P->n + 3);
         column_to_device(eng, *P, P->off_vel, 3, eng->r_vel.p);
+        eng->res_has_vel = true;
     }
     if(fields & MPG_FIELD_ACCEL)
         column_to_device(eng, *P, P->off_accel, 3, eng->r_accel.p);
@@ -1586,6 +1613,7 @@ int mpg_resident_end(mpg_engine *eng, const mpg_particle_view *P)
     if(mpg_resident_fetch(eng, P, MPG_FIELD_POS | MPG_FIELD_VEL | MPG_FIELD_ACCEL | MPG_FIELD_GRAVPM | MPG_FIELD_POTENTIAL))
         throw Error(g_err);
     eng->resident = false;
+    eng->res_has_vel = false;
     eng->res_base = nullptr;
     eng->res_n = -1;
     eng->staged_epoch = -1;

@@ -126,6 +126,7 @@ struct mpg_engine {
     DevBuf<uint8_t> h_sph_u8[2];
     // staging for the host (AoS) path
     DevBuf<double> s_pos, s_accel, s_gravpm, s_pot, s_prev, s_old;
+    DevBuf<double> w_old; // OldAcc of a walk that writes over its own opening input (mpg_dev_grav_short_tree)
     DevBuf<float> s_mass;
     DevBuf<uint8_t> s_type;
     DevBuf<int> s_active;
@@ -148,7 +149,7 @@ struct mpg_engine {
     const void *staged_base = nullptr;
     // device-resident drop-in mode (mpg_resident_begin): the table at res_base lives in s_pos / s_mass / s_type and r_*; the host calls on
     // that table move no particle data
-    bool resident = false;
+    bool resident = false, res_has_vel = false;
     const void *res_base = nullptr;
     int64_t res_n = -1;
     DevBuf<double> r_vel, r_accel, r_gravpm, r_pot;

@@ -489,6 +489,9 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     // other particles the key ~0 and counted them with one same-address atomic each: 3.2 ms for the keys of a 32 768-particle tree in a
     // 256^3 table, plus the sort of all 2^24 keys.)
     npart = n;
+    // (without a type array every particle counts as type 1, as TreeMember does: a mask without that bit selects nothing)
+    if(!d_type && (mask & 2) == 0)
+        npart = n = 0;
     const bool subset = n > 0 && (d_type != nullptr || d_include != nullptr);
     if(subset) {
         rocprim::counting_iterator<uint32_t> iota(0);

@@ -1,7 +1,7 @@
 /* libgadget/gravity-hip.c -- the reference's gravity entry points forwarded to libmpgadget_hip.so.
  *
- * Replaces gravpm.o, gravshort-tree.o and gravity.o in the link of libgadget; forcetree.o, treewalk.o and
- * petapm.o stay for the 14 other tree walks and MP-GenIC.  Compiled inside the reference tree with its own headers:
+ * Replaces gravpm.o, gravshort-tree.o and gravity.o in the link of libgadget; forcetree.o (with its five constructors
+ * renamed: forcetree-hip.c takes their place), treewalk.o and petapm.o stay for the 14 other tree walks and MP-GenIC.  Compiled inside the reference tree with its own headers:
  *     $(CC) $(OPTIMIZE) -I$(MPGADGET_HIP)/include -c gravity-hip.c mpg_mpi_comm.c          link: -lmpgadget_hip
  * (This container cannot compile it - gravity.h pulls in pfft.h and GSL, SURVEY 8(c) - so everything that does not need a
  * reference type lives behind the C-ABI, where tests/c/test_cabi.c exercises it with the same call sequence.)
@@ -254,9 +254,9 @@ void gravshort_set_softenings(double MeanSeparation) { ck(mpg_gravshort_set_soft
 /* (blackhole.c, density.c, timestep.c and run.c read the softening through this) */
 double FORCE_SOFTENING(void) { return mpg_force_softening(eng()); }
 
-/* The CPU ForceTree stays the property of forcetree.c (the other walks use it); the device tree of the gravity path is built
- * here, when grav_short_tree is entered with a tree whose moments are valid - the point where run.c:546-547 has just called
- * force_tree_full(). */
+/* The ForceTree handed in is a descriptor: with forcetree-hip.c in the link force_tree_full() / force_tree_active_moments() build
+ * nothing on the host (the reference's OpenMP build took 10 x this whole step), they record mask and active list; the device tree of
+ * the gravity path is built here, where Ti_Current says whether this step's upload of the table is still valid (run.c:546-547). */
 void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, MyFloat (*AccelStore)[3], double rho0, inttime_t Ti_Current)
 {
     if(!tree->moments_computed_flag)
@@ -268,7 +268,13 @@ void grav_short_tree(const ActiveParticles *act, PetaPM *pm, ForceTree *tree, My
     mpg_shim_sync(Ti_Current, 0, tree->BoxSize, tp.Rcut * pm->Asmth * pm->CellSize);
     mpg_particle_view v = view();
     if(NTask == 1) {
-        ck(mpg_force_tree_rebuild_mask(eng(), &v, tree->BoxSize, tree->mask));
+        /* the device tree this ForceTree stands for (forcetree-hip.c): the tree of the active particles of a hierarchical gravity level
+         * (force_tree_active_moments, timestep.c:287), or the tree of all particles of the mask */
+        const struct mpg_deferred_tree *dt = mpg_shim_deferred_tree(tree);
+        if(dt && dt->kind == MPG_TREE_ACTIVE && dt->ActiveParticle)
+            ck(mpg_force_tree_active_moments(eng(), &v, tree->BoxSize, dt->ActiveParticle, dt->NumActiveParticle, dt->HybridNuTracer));
+        else
+            ck(mpg_force_tree_rebuild_mask(eng(), &v, tree->BoxSize, tree->mask));
         ck(mpg_grav_short_tree(eng(), &v, act->ActiveParticle, act->NumActiveParticle, AccelStore, rho0));
     }
     else {

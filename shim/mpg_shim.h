@@ -16,6 +16,7 @@
 #define MPG_SHIM_H
 #include "domain.h"
 #include "timebinmgr.h"
+#include "forcetree.h"
 #include <mpgadget_hip.h>
 
 mpg_engine *mpg_shim_engine(void);  /* the rank's engine (created on first use; one rank = one GPU) */
@@ -35,6 +36,24 @@ void mpg_shim_sync(inttime_t Ti_Current, double Time, double BoxSize, double mar
 void mpg_shim_dist_tree(const mpg_particle_view *v);
 /* ... and its invalidation by the SPH loops / FOF, which replace the gravity tree inside the library */
 void mpg_shim_dist_tree_replaced(void);
+/* ---- trees that exist only on the device (forcetree-hip.c) ----
+ * The constructors of forcetree.h record what was asked for; the consumers in gravity-hip.c / sph-hip.c build the device tree from the
+ * record.  mpg_shim_deferred_tree: the record of a tree that has no host nodes (NULL: an ordinary host tree).  mpg_shim_host_tree: build
+ * the host tree now (before the first host module that receives it allocates anything); mpg_shim_require_host_tree: the guard at the top
+ * of treewalk_run. */
+enum { MPG_TREE_FULL = 1, MPG_TREE_ACTIVE = 2, MPG_TREE_MASK = 3 };
+struct mpg_deferred_tree {
+    const ForceTree *tree;       /* the caller's object (key) */
+    DomainDecomp *ddecomp;
+    int kind, mask, HybridNuTracer, alloc_father, moments_wanted, materialised;
+    const int *ActiveParticle;   /* MPG_TREE_ACTIVE: the list the tree is built from (NULL: all) */
+    int64_t NumActiveParticle;
+    const char *EmergencyOutputDir;
+    struct NODE root;            /* what tree->Nodes[tree->firstnode] reads while the tree is deferred */
+};
+const struct mpg_deferred_tree *mpg_shim_deferred_tree(const ForceTree *tree);
+void mpg_shim_host_tree(ForceTree *tree);
+void mpg_shim_require_host_tree(const ForceTree *tree, const char *walk);
 double mpg_shim_margin(void); /* the ghost margin in force (0: no domain handed over yet) */
 mpg_particle_view mpg_shim_view(void);
 #endif

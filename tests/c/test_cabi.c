@@ -5,6 +5,10 @@
  *       the drop-in (host pointer) calls on an array of 160-byte `struct particle_data` records: mpg_gravpm_force,
  *       mpg_force_tree_full, mpg_grav_short_tree (twice: Barnes-Hut opening, then the relative criterion, test_gravity.c:211-213);
  *       P[].GravPM and P[].FullTreeGravAccel against the committed vectors of tests/golden/ (expect = GravPM[n][3], Accel2[n][3]).
+ *   test_cabi run <table.f64> <pos.f64> <expect.f64> n nmesh box <expect_active.f64>
+ *       one rank in run.c's order with shim/forcetree-hip.c in the link ("Tree constructors"): the tree constructors
+ *       only record mask / active list, no host tree exists anywhere; PM step (run.c:522-548), a refused walk after force_tree_free,
+ *       and one level of the hierarchical loop (timestep.c:287-289: tree of every third particle, results in AccelStore only).
  *   test_cabi ranks|ranks_host <table.f64> <pos.f64> <expect.f64> n nmesh box NTask
  *       NTask processes (fork; the collectives of mpg_comm are implemented on a shared-memory segment with a process-shared
  *       barrier - what MPI_Allreduce / MPI_Alltoall / MPI_Alltoallv would do), every one with its own engine on GPU 0.
@@ -156,6 +160,94 @@ static int run_single(const double *table, const double *pos, const double *expe
         return 1;
     }
     printf("PASS single\n");
+    return 0;
+}
+
+/* ---- one rank, the order of run.c with shim/forcetree-hip.c in the link: the tree constructors only record what was asked for, no
+ * host tree exists at any point, the consumer builds the device tree from the record ----------------------------------------- */
+enum { TREE_NONE = 0, TREE_FULL = 1, TREE_ACTIVE = 2 };
+struct tree_record { /* what forcetree-hip.c keeps per ForceTree (shim/mpg_shim.h: struct mpg_deferred_tree) */
+    int kind, mask, HybridNuTracer;
+    const int *ActiveParticle;
+    int64_t NumActiveParticle;
+};
+/* grav_short_tree of shim/gravity-hip.c, NTask == 1 */
+static int shim_grav_short_tree(mpg_engine *e, const mpg_particle_view *v, double box, const struct tree_record *t, const int *act, int64_t nact,
+                                double (*AccelStore)[3])
+{
+    if(t->kind == TREE_NONE)
+        return mpg_grav_short_tree(e, v, act, nact, AccelStore, 0.0); /* (must fail: "Gravtree called before tree moments computed") */
+    if(t->kind == TREE_ACTIVE && t->ActiveParticle)
+        CK(mpg_force_tree_active_moments(e, v, box, t->ActiveParticle, t->NumActiveParticle, t->HybridNuTracer));
+    else
+        CK(mpg_force_tree_rebuild_mask(e, v, box, t->mask));
+    return mpg_grav_short_tree(e, v, act, nact, AccelStore, 0.0);
+}
+
+static int run_order(const double *table, const double *pos, const double *expect, const char *expect_active_path, int n, int nmesh, double box)
+{
+    const int64_t N = (int64_t)n * n * n;
+    struct particle_data *P = calloc(N, sizeof(struct particle_data));
+    for(int64_t i = 0; i < N; i++) {
+        memcpy(P[i].Pos, pos + 3 * i, 3 * sizeof(double));
+        P[i].Mass = 1.0f;
+        P[i].Type = 1;
+        P[i].ID = (uint64_t)i;
+    }
+    mpg_engine *e = make_engine(table, box, n, nmesh);
+    mpg_particle_view v;
+    mpg_particle_view_reference_layout(&v, P, N);
+    int64_t epoch = 1;
+    CK(mpg_set_particle_epoch(e, epoch)); /* mpg_shim_sync: one upload serves the calls of this step */
+    /* ---- a PM step, run.c:522-548 ---- */
+    CK(mpg_gravpm_force(e, &v));
+    struct tree_record Tree = {TREE_FULL, 63, 0, NULL, 0};   /* force_tree_full(&Tree, ...): recorded, nothing built */
+    CK(shim_grav_short_tree(e, &v, box, &Tree, NULL, 0, NULL));
+    Tree = (struct tree_record){TREE_NONE, 0, 0, NULL, 0};    /* force_tree_free(&Tree) */
+    CK(mpg_force_tree_free(e));
+    if(shim_grav_short_tree(e, &v, box, &Tree, NULL, 0, NULL) == 0) {
+        printf("FAIL a walk after force_tree_free was not refused\n");
+        return 1;
+    }
+    /* second walk of the start-up sequence (relative criterion; test_gravity.c:211-213) */
+    Tree = (struct tree_record){TREE_FULL, 63, 0, NULL, 0};
+    CK(shim_grav_short_tree(e, &v, box, &Tree, NULL, 0, NULL));
+    CK(mpg_force_tree_free(e));
+    double *gpm = malloc(3 * N * sizeof(double)), *acc = malloc(3 * N * sizeof(double));
+    for(int64_t i = 0; i < N; i++)
+        for(int k = 0; k < 3; k++) {
+            gpm[3 * i + k] = P[i].GravPM[k];
+            acc[3 * i + k] = P[i].FullTreeGravAccel[k];
+        }
+    const double e_pm = relerr(gpm, expect, 3 * N), e_tr = relerr(acc, expect + 3 * N, 3 * N);
+    printf("run: N %lld  GravPM err %.3e  FullTreeGravAccel err %.3e\n", (long long)N, e_pm, e_tr);
+    /* ---- a level of the hierarchical gravity loop, timestep.c:287-289: force_tree_active_moments(&Tree, subact) records the list;
+     * grav_short_tree walks the tree of those particles for those particles into AccelStore and leaves P[] alone (gravshort.h:57-67) ---- */
+    int64_t nact = 0;
+    int *act = malloc(N * sizeof(int));
+    for(int64_t i = 0; i < N; i += 3)
+        act[nact++] = (int)i;
+    double *exa = read_f64(expect_active_path, 3 * (size_t)nact);
+    double(*store)[3] = calloc(N, sizeof(double[3]));
+    Tree = (struct tree_record){TREE_ACTIVE, 63, 0, act, nact};
+    CK(shim_grav_short_tree(e, &v, box, &Tree, act, nact, store));
+    CK(mpg_force_tree_free(e));
+    double *got = malloc(3 * nact * sizeof(double));
+    int touched = 0;
+    for(int64_t k = 0; k < nact; k++)
+        for(int j = 0; j < 3; j++)
+            got[3 * k + j] = store[act[k]][j];
+    for(int64_t i = 0; i < N; i++)
+        for(int k = 0; k < 3; k++)
+            touched |= (P[i].FullTreeGravAccel[k] != acc[3 * i + k]);
+    const double e_act = relerr(got, exa, 3 * nact);
+    printf("run: active-only tree of %lld particles  AccelStore err %.3e  P[] touched %d\n", (long long)nact, e_act, touched);
+    mpg_engine_destroy(e);
+    if(!(e_pm < 1e-10 && e_tr < 1e-10 && e_act < 1e-10 && !touched)) {
+        printf("FAIL\n");
+        return 1;
+    }
+    printf("PASS run\n");
     return 0;
 }
 
@@ -729,5 +821,7 @@ int main(int argc, char **argv)
     double *table = read_f64(argv[2], 512 * 5), *pos = read_f64(argv[3], 3 * N), *expect = read_f64(argv[4], 6 * N);
     if(!strcmp(argv[1], "single"))
         return run_single(table, pos, expect, n, nmesh, box);
+    if(!strcmp(argv[1], "run"))
+        return run_order(table, pos, expect, argv[8], n, nmesh, box);
     return run_ranks(table, pos, expect, n, nmesh, box, argc > 8 ? atoi(argv[8]) : 2, !strcmp(argv[1], "ranks_host"));
 }

@@ -95,11 +95,23 @@ def test_reference_side_shim_compiles(tmp_path):
     (tmp_path / "gsl").mkdir()
     (tmp_path / "pfft.h").write_text("#include <stddef.h>\n#include <mpi.h>\ntypedef double pfft_complex[2];\ntypedef struct pfft_plan_s *pfft_plan;\n")
     (tmp_path / "gsl" / "gsl_interp.h").write_text("typedef struct gsl_interp gsl_interp;\ntypedef struct gsl_interp_accel gsl_interp_accel;\n")
-    for src in ("gravity-hip.c", "sph-hip.c", "mpg_mpi_comm.c"):
+    for src in ("gravity-hip.c", "sph-hip.c", "forcetree-hip.c", "mpg_mpi_comm.c"):
         r = subprocess.run(["gcc", "-std=gnu11", "-fopenmp", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
                             "-I", str(tmp_path), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim"), "-I", mpi,
                             "-I", ref, "-I", os.path.dirname(ref), os.path.join(ROOT, "shim", src)], capture_output=True, text=True)
         assert r.returncode == 0, src + "\n" + r.stderr[-3000:]
+    # forcetree.c with its five constructors renamed (the flags INTEGRATION.md gives for forcetree.o): still parses, defines the cpu_*
+    # names forcetree-hip.c calls and no longer the public ones (preprocessor output only: nothing is compiled)
+    names = ["force_tree_full", "force_tree_rebuild_mask", "force_tree_active_moments", "force_tree_calc_moments", "force_tree_free"]
+    flags = ["-D%s=cpu_%s" % (n, n) for n in names]
+    assert all(f in open(os.path.join(ROOT, "INTEGRATION.md")).read() for f in flags)
+    base = ["gcc", "-std=gnu11", "-fopenmp", "-I", str(tmp_path), "-I", mpi, "-I", ref, "-I", os.path.dirname(ref)] + flags
+    r = subprocess.run(base + ["-fsyntax-only", os.path.join(ref, "forcetree.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    pre = subprocess.run(base + ["-E", os.path.join(ref, "forcetree.c")], capture_output=True, text=True).stdout
+    for n in names:
+        assert re.search(r"^cpu_%s\s*\(" % n, pre, flags=re.M) or re.search(r"\bvoid\s+cpu_%s\s*\(" % n, pre), n
+        assert not re.search(r"(?<!cpu_)\b%s\s*\(" % n, pre), n
 
 
 def test_stale_library_is_refused(monkeypatch):

@@ -62,6 +62,36 @@ def test_c_caller_single_and_ranks_against_golden(tmp_path):
 
 
 @pytest.mark.gpu
+def test_c_caller_run_order_without_host_tree(tmp_path, orc):
+    """run.c's order with shim/forcetree-hip.c in the link: force_tree_full / force_tree_active_moments record, the consumer builds the
+    device tree (no struct NODE array on the host at any point).  PM step against the oracle; one hierarchical-gravity level - the tree
+    of every third particle walked for those particles, sources restricted to them, results in AccelStore, P[] untouched -
+    against the oracle's tree of that subset with the same opening input."""
+    from oracle import oracle as O
+    pkg = importlib.import_module("mp-gadget_amd")
+    exe = build(tmp_path)
+    table = os.path.join(ROOT, "mp-gadget_amd", "data", "shortrange_force_kernels.f64")
+    n, nmesh = 24, 48
+    pos, mass, box = pkg.ics.s_zel(n)
+    gpm, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 1
+    a1, _, _, _ = tr.grav_short_tree(par, oldacc=np.sqrt((gpm ** 2).sum(1)) / G)
+    par.TreeUseBH = 0
+    a2, _, _, _ = tr.grav_short_tree(par, oldacc=np.sqrt(((a1 + gpm) ** 2).sum(1)) / G)
+    act = np.arange(0, len(pos), 3)
+    tra = orc.tree(pos[act], mass[act], box)
+    old = np.sqrt(((a2 + gpm) ** 2).sum(1)) / G
+    aa, _, _, _ = tra.grav_short_tree(par, oldacc=old[act])
+    p, e = _write_case(tmp_path, "szel24", pos, gpm, a2)
+    ea = str(tmp_path / "szel24.active")
+    aa.astype("<f8").tofile(ea)
+    out = _run(exe, "run", table, p, e, n, nmesh, box, ea)
+    assert "PASS run" in out
+
+
+@pytest.mark.gpu
 def test_c_caller_ranks_against_oracle(tmp_path, orc):
     """a set large enough for a real decomposition level (Rcut = 9 of 64 mesh cells: La = 2), Zel'dovich-displaced: 2 and 4 C ranks"""
     from oracle import oracle as O

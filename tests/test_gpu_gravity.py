@@ -204,6 +204,45 @@ def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
     assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
 
 
+def test_resident_walk_in_place_with_list_retry(pkg, engine, orc):
+    """in resident mode the walk writes FullTreeGravAccel over its own opening input.  The two-kernel walk runs
+    its list pass again with longer lists when more than a fifth of the targets overflow - after the evaluation has already stored new
+    accelerations for the targets that fitted - so the opening input is now taken once, before the first kernel (k_oldacc).  A capacity
+    of 16 entries forces such retries; results must equal the host path's (separate buffers) and the oracle's."""
+    n, nmesh = 24, 48
+    pos, mass, box = pkg.ics.s_zel(n)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    gpm_o, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    rng = np.random.RandomState(5)
+    prev = 1e-3 * np.abs(gpm_o).mean() * rng.standard_normal(gpm_o.shape)   # a previous acceleration unlike the new one
+    a_ref, _, _, _ = tr.grav_short_tree(par, oldacc=np.sqrt(((prev + gpm_o) ** 2).sum(1)) / G)
+    res = {}
+    try:
+        engine.set_walk_variant(6)
+        for mode in ("host", "resident"):
+            P = pkg.make_particles(pos, mass)
+            P["GravPM"] = gpm_o
+            P["FullTreeGravAccel"] = prev
+            engine.set_walk_list_capacity(16)
+            if mode == "resident":
+                engine.resident_begin(P, box)
+            engine.force_tree_full(P, box)
+            engine.grav_short_tree(P)
+            assert engine.walk_choice()[1] > 16     # the retry ran
+            if mode == "resident":
+                engine.resident_end(P)
+            res[mode] = P["FullTreeGravAccel"].copy()
+    finally:
+        engine.set_walk_variant(0)
+        engine.set_walk_list_capacity(512)
+    assert_accel_parity(res["host"], a_ref)
+    assert_accel_parity(res["resident"], a_ref)
+    assert np.abs(res["resident"] - res["host"]).max() <= 1e-12 * np.abs(a_ref).mean()
+
+
 @pytest.mark.parametrize("ic", ["s_zel", "s_grid"])
 def test_walk_64bit_offset_kernels(pkg, engine, orc, ic):
     """The two-kernel walk has variants with 64-bit offsets into the source / node arrays, taken when those exceed 4 GiB (512^3 particles in
