@@ -428,6 +428,28 @@ def parity_check_ranks(pkg, torch, dist, args, dev, rank, world, host_pos, host_
     return res
 
 
+def make_comm(pkg, torch, dist, args, dev, eng):
+    """The communicator the multi-rank step runs on: the library's native RCCL communicator (csrc/rccl_comm.hip: ncclSend / ncclRecv /
+    ncclAllReduce on the engine's stream, no Python in any collective), bootstrapped through the launcher's torch.distributed group and
+    checked once with its self-test.  Should it fail on ANY rank, all ranks fall back to the torch.distributed callbacks and the line says so."""
+    note = "torch.distributed callbacks (dist.py::TorchComm)"
+    if args.comm == "rccl" and dist.get_backend() == "nccl":
+        comm, ok, err = None, 1, ""
+        try:
+            comm = pkg.dist.RcclComm(eng.lib, dev, selftest_bytes=1 << 20)
+        except Exception as e:      # noqa: BLE001 - whatever went wrong, every rank must learn of it
+            ok, err = 0, repr(e)
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            return comm, "native RCCL communicator of the library (mpg_rccl_*: ncclGroupStart + ncclSend / ncclRecv per peer, ncclAllReduce, " \
+                         "on the engine's stream; RCCL %d)" % comm.stats()["rccl_version"]
+        if comm is not None:
+            comm.close()
+        note = "torch.distributed callbacks (the native RCCL communicator failed on some rank: %s)" % (err or "another rank")
+    return pkg.dist.TorchComm(dev), note
+
+
 def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
     """N > 1 (or MPG_FORCE_MGPU: the same code in a one-rank group): weak scaling, ~256^3 particles per GPU, particles on the owners of
     their Peano-Hilbert TopLeaves, everything through the library's choreography (mpg_dist_*, csrc/dist.hip) with the collectives on
@@ -438,7 +460,7 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
     N = len(pos)
     eng = pkg.Engine(local_rank)
     configure_gravity(eng, args, box, n, nmesh)
-    comm = pkg.dist.TorchComm(dev)
+    comm, comm_note = make_comm(pkg, torch, dist, args, dev, eng)
     dforce = pkg.dist.DistForce(eng, comm)
     rcut = 6.0 * 1.5 * box / nmesh                        # margin = Rcut * Asmth * cell size (gravshort-tree.c:102)
     # domain_decompose_full + domain_exchange (untimed): every rank starts from a contiguous share of the set
@@ -543,6 +565,7 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
                                       "{Pos, Mass} shipped to the x-slab PM (2 all-to-all transposes + neighbour planes) and {GravPM, Potential} back, "
                                       "ghosts imported in whole level-La tree cells within Rcut of the rank's TopLeaves, top of the tree from an "
                                       "all-reduce; choreography in the library (mpg_dist_*), collectives on RCCL" % (world, ntl),
+                       "communicator": comm_note,
                        "ghost_fraction_rank0": round(st["ghosts"] / max(n_own, 1), 3), "decomposition_level_La": st["La"]},
             "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
             "phases_ms": {k: round(v, 3) for k, v in ph.items()},
@@ -561,9 +584,13 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
                                  "dist_exchange_bytes": st["exchange_bytes"], "dist_transpose_bytes": st["transpose_bytes"]})
         if parity is not None:
             out["parity_check"] = parity
+    if out is not None and hasattr(comm, "stats"):
+        out["config"]["communicator_calls"] = comm.stats()
     dist.barrier()
     dist.destroy_process_group()
     dforce.close()
+    if hasattr(comm, "close"):
+        comm.close()
     eng.close()
     if out is not None:
         emit(out)
@@ -705,6 +732,8 @@ def main():
     ap.add_argument("--thresh", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--mgpu", default="peano", choices=["peano"], help="(kept for the command lines of round 2; the x-slab / replicated forms were retired)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: the library's native RCCL communicator (default) or the torch.distributed callbacks of rounds 2-3")
     ap.add_argument("--overdecomp", type=int, default=8, help="DomainOverDecompositionFactor (TopLeaves per rank and policy)")
     ap.add_argument("--no-rebalance", action="store_true",
                     help="N > 1: keep the decomposition by particle number (default: after two set-up steps the TopLeaves are dealt out "
@@ -970,7 +999,8 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
     eng.gravshort_set_softenings(box / n)
     eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
     eng.set_hydropar(PE, 100.0, 0.75)
-    df = pkg.dist.DistForce(eng, pkg.dist.TorchComm(dev))
+    comm, comm_note = make_comm(pkg, torch, dist, args, dev, eng)
+    df = pkg.dist.DistForce(eng, comm)
     share = slice((N * rank) // world, (N * (rank + 1)) // world)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a[share])).to(dev)
     s_pos = T(pos)
@@ -1020,10 +1050,13 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
                "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
                           "particles": N, "parallelism": "%d GPUs: particles on the owners of their Peano-Hilbert TopLeaves, choreography in the library "
                                                          "(mpg_dist_*), collectives on RCCL" % world,
+                          "communicator": comm_note,
                           "ghost_fraction_rank0": round(st["ghosts"] / max(n_own, 1), 3), "density_iterations_last": eng.sph_stats()["iterations"]}}
     dist.barrier()
     dist.destroy_process_group()
     df.close()
+    if hasattr(comm, "close"):
+        comm.close()
     eng.close()
     if out is not None:
         emit(out)

@@ -579,7 +579,32 @@ typedef struct mpg_comm {
     /* MPI_Alltoallv of bytes */
     int (*alltoallv)(void *ctx, const void *send, const int64_t *sendbytes, const int64_t *sdispls, void *recv, const int64_t *recvbytes,
                      const int64_t *rdispls, int on_device);
+    /* Optional (NULL: every call blocks until its data has arrived, as MPI does).  A communicator whose device-buffer collectives are
+     * stream-ordered work (RCCL) sets bind_stream: mpg_dist_create calls it once with the engine's hipStream_t.  From then on a callback
+     * that is handed device pointers ENQUEUES on that stream and returns at once, and the library does not synchronise around it:
+     * kernels and collectives of a force step run back to back.  Calls with host pointers stay blocking. */
+    int (*bind_stream)(void *ctx, void *hip_stream);
 } mpg_comm;
+
+/* ---- mpg_comm on a native RCCL communicator (csrc/rccl_comm.hip) --------------------------------------------------------------
+ * Stands where the reference has MPI on this path: the query export / import of the tree walks (treewalk.c:586-655: MPI_Alltoall of
+ * counts, MPI_Isend / MPI_Irecv per peer) and the PM mesh exchanges (petapm.c:751,815,869: MPI_Alltoallv) become ncclGroupStart +
+ * ncclSend / ncclRecv per peer + ncclGroupEnd and ncclAllReduce on the engine's stream, device memory to device memory over xGMI.
+ * librccl is opened at run time (the library does not link it).  Bootstrap: rank 0 obtains the 128-byte id, the CALLER hands it to
+ * every rank (MPI_Bcast: shim/mpg_rccl_mpi.c; torch.distributed: bench.py; shared memory: tests/c/test_cabi.c), then every rank calls
+ * mpg_rccl_create (collective: ncclCommInitRank) on ITS device and passes the callbacks of mpg_rccl_comm to mpg_dist_create.
+ * mpg_rccl_selftest runs every collective once on a known pattern (collective) and fails if a byte differs. */
+#define MPG_RCCL_ID_BYTES 128
+typedef struct mpg_rccl mpg_rccl;
+int mpg_rccl_available(void);                 /* 1 if librccl could be opened */
+int mpg_rccl_get_unique_id(void *id128);
+int mpg_rccl_create(mpg_rccl **out, int ThisTask, int NTask, const void *id128, int device);
+int mpg_rccl_comm(mpg_rccl *r, mpg_comm *out);
+int mpg_rccl_selftest(mpg_rccl *r, int64_t bytes_per_peer);
+/* calls3: allreduce, alltoall_i64, alltoallv calls so far; bytes sent to OTHER ranks; the RCCL version code (any may be NULL) */
+int mpg_rccl_stats(mpg_rccl *r, int64_t *calls3, int64_t *bytes_sent, int *version);
+const char *mpg_rccl_last_error(mpg_rccl *r); /* detail of the last failed callback */
+void mpg_rccl_destroy(mpg_rccl *r);
 
 typedef struct mpg_dist mpg_dist;
 /* eng: configured as for one rank (mpg_gravpm_init_periodic with the GLOBAL Nmesh, tables, tree parameters, softening);

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmpgadget_hip.so")
-SOURCES = ["tree_build.hip", "grav_walk.hip", "grav_walk_coop.hip", "grav_walk_split.hip", "grav_pair_walk.hip", "pm.hip", "sph.hip", "timestep.hip", "peano.hip", "domain.hip", "fof.hip", "snapshot_io.hip", "engine.hip", "dist.hip"]
+SOURCES = ["tree_build.hip", "grav_walk.hip", "grav_walk_coop.hip", "grav_walk_split.hip", "grav_pair_walk.hip", "pm.hip", "sph.hip", "timestep.hip", "peano.hip", "domain.hip", "fof.hip", "snapshot_io.hip", "engine.hip", "dist.hip", "rccl_comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # experiments (-DMPG_EXP_...): MPG_EXTRA_FLAGS="file.hip:-Dx -Dy" applies to one source, MPG_EXTRA_FLAGS="-Dx" to all; part of the
@@ -81,7 +81,7 @@ def build(force=False, verbose=False):
         so = os.path.join(OBJ, "build_stamp.o")
         subprocess.check_call(["gcc", "-O1", "-fPIC", "-c", sc, "-o", so])
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [so] + \
-              ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+              ["-L/opt/rocm/lib", "-lhipfft", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -600,6 +600,10 @@ struct mpg_dist {
     mpg_engine *eng = nullptr;
     mpg_comm comm{};
     int me = 0, nt = 1;
+    // the communicator runs device-buffer collectives as work on the engine's stream (mpg_comm.bind_stream: RCCL): no host
+    // synchronisation before or after them
+    bool stream_ordered = false;
+    hipStream_t bound_stream = nullptr;
     // domain
     double box = 0, margin = 0;
     int La = 0;
@@ -686,6 +690,15 @@ void sync(mpg_dist *d) { MPG_HIP(hipStreamSynchronize(d->eng->stream)); }
 
 void cb(int rc, const char *what) { MPG_CHECK(rc == 0, std::string("mpg_comm callback failed: ") + what); }
 
+// a stream-ordered communicator follows the engine's stream (mpg_use_stream may have replaced it since mpg_dist_create)
+void follow_stream(mpg_dist *d)
+{
+    if(d->stream_ordered && d->bound_stream != d->eng->stream) {
+        cb(d->comm.bind_stream(d->comm.ctx, (void *)d->eng->stream), "bind_stream");
+        d->bound_stream = d->eng->stream;
+    }
+}
+
 // alltoallv of bytes between device buffers (staged through pinned host memory unless the communicator takes device pointers)
 void a2av(mpg_dist *d, const void *dsend, const std::vector<int64_t> &sb, const std::vector<int64_t> &sd, void *drecv,
           const std::vector<int64_t> &rb, const std::vector<int64_t> &rd, int64_t stot, int64_t rtot)
@@ -699,7 +712,9 @@ void a2av(mpg_dist *d, const void *dsend, const std::vector<int64_t> &sb, const 
     }
     MPG_CHECK(d->comm.alltoallv, "mpg_comm: alltoallv callback missing");
     if(d->comm.device_buffers) {
-        sync(d);
+        follow_stream(d);
+        if(!d->stream_ordered)
+            sync(d); // (a blocking communicator works outside the stream: what it sends must be complete)
         cb(d->comm.alltoallv(d->comm.ctx, dsend, sb.data(), sd.data(), drecv, rb.data(), rd.data(), 1), "alltoallv");
         return;
     }
@@ -972,6 +987,38 @@ int64_t import_ghosts(mpg_dist *d, int64_t n, const double *pos, const float *ma
 }
 
 // moments of the nodes above level La from the sums over all ranks (tree_build.hip, "the top of the tree from global sums")
+// levels La-2 .. 0 of the global top from the all-reduced sums of level La-1 (4 doubles per cell, children consecutive in octant-path
+// numbering), laid out level 0 first as k_top_set reads them; the all-reduced particle counts are checked on the way: a cell above
+// the decomposition level is internal on every rank whatever it holds locally, and the global tree agrees only if it holds more than
+// NMAXCHILD particles in all.  One block: the levels depend on each other and the whole top is a few thousand cells.
+__global__ void __launch_bounds__(1024) k_top_levels(int La, const double *__restrict__ fine, const double *__restrict__ cnt, double *__restrict__ all,
+                                                     unsigned *__restrict__ err)
+{
+    const size_t nfine = (size_t)1 << (3 * (La - 1));
+    size_t off = 0;
+    for(int l = 0; l < La - 1; l++)
+        off += (size_t)1 << (3 * l);
+    for(size_t c = threadIdx.x; c < nfine; c += blockDim.x) {
+        const double k = cnt[c];
+        if(!(k == 0 || k > NMAXCHILD))
+            atomicOr(err, 1u);
+        for(int j = 0; j < 4; j++)
+            all[(off + c) * 4 + j] = fine[c * 4 + j];
+    }
+    for(int l = La - 2; l >= 0; l--) {
+        __syncthreads();
+        const size_t nc = (size_t)1 << (3 * l), coff = off;
+        off -= nc;
+        for(size_t c = threadIdx.x; c < nc; c += blockDim.x)
+            for(int j = 0; j < 4; j++) {
+                double sum = 0.0; // (children added in octant order, as the host loop of rounds 2-3 did: same bits)
+                for(int k = 0; k < 8; k++)
+                    sum += all[(coff + 8 * c + k) * 4 + j];
+                all[(off + c) * 4 + j] = sum;
+            }
+    }
+}
+
 void global_top(mpg_dist *d, int64_t n_own)
 {
     mpg_engine *e = d->eng;
@@ -981,41 +1028,29 @@ void global_top(mpg_dist *d, int64_t n_own)
     size_t ntot = 0;
     for(int l = 0; l < La; l++)
         ntot += (size_t)1 << (3 * l);
-    d->top.reserve(std::max(nfine * 5, ntot * 4) + 8);
+    // [nfine * 4 sums | nfine counts | ntot * 4 levels]
+    d->top.reserve(nfine * 5 + ntot * 4 + 8);
     e->tree.top_partial(La, n_own, d->top.p, st);
-    double *cnt = d->top.p + nfine * 4;
+    double *cnt = d->top.p + nfine * 4, *all = d->top.p + nfine * 5;
     MPG_HIP(hipMemsetAsync(cnt, 0, nfine * sizeof(double), st));
     if(e->tree.npart > 0)
         hipLaunchKernelGGL(k_top_counts, dim3(nblk(e->tree.npart)), dim3(256), 0, st, e->tree.npart, e->tree.keys_b.p, e->tree.idx_b.p, n_own,
                            3 * (MAXLEVEL - (La - 1)), cnt);
-    d->htop.reserve(std::max(nfine * 5, ntot * 4) + 8);
-    MPG_HIP(hipMemcpyAsync(d->htop.p, d->top.p, nfine * 5 * sizeof(double), hipMemcpyDeviceToHost, st));
-    sync(d);
-    allreduce_host_f64(d, d->htop.p, (int64_t)(nfine * 5), 0);
-    // a cell above the decomposition level is internal here whatever it holds; the global tree agrees only if it holds more
-    // than NMAXCHILD particles in all
-    for(size_t c = 0; c < nfine; c++) {
-        const double k = d->htop.p[nfine * 4 + c];
-        MPG_CHECK(k == 0 || k > NMAXCHILD, "mpg_dist: a cell above the decomposition level holds <= 8 particles in all (use a coarser level La)");
+    follow_stream(d);
+    if(d->stream_ordered) // (RCCL: the all-reduce is the next piece of work on the stream)
+        cb(d->comm.allreduce(d->comm.ctx, d->top.p, (int64_t)(nfine * 5), 0, 0, 1), "allreduce");
+    else if(!(d->nt == 1 && !d->comm.allreduce)) {
+        d->htop.reserve(nfine * 5 + 8);
+        MPG_HIP(hipMemcpyAsync(d->htop.p, d->top.p, nfine * 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+        sync(d);
+        allreduce_host_f64(d, d->htop.p, (int64_t)(nfine * 5), 0);
+        MPG_HIP(hipMemcpyAsync(d->top.p, d->htop.p, nfine * 5 * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    // levels La-1 .. 0 by summing the 8 children (consecutive in octant-path numbering), laid out level 0 first
-    std::vector<double> lev(d->htop.p, d->htop.p + nfine * 4), all(ntot * 4);
-    size_t off = ntot;
-    for(int l = La - 1; l >= 0; l--) {
-        const size_t nc = (size_t)1 << (3 * l);
-        off -= nc;
-        std::copy(lev.begin(), lev.begin() + nc * 4, all.begin() + off * 4);
-        if(l > 0) {
-            std::vector<double> up(nc / 8 * 4, 0.0);
-            for(size_t c = 0; c < nc; c++)
-                for(int j = 0; j < 4; j++)
-                    up[(c >> 3) * 4 + j] += lev[c * 4 + j];
-            lev.swap(up);
-        }
-    }
-    std::copy(all.begin(), all.end(), d->htop.p);
-    MPG_HIP(hipMemcpyAsync(d->top.p, d->htop.p, ntot * 4 * sizeof(double), hipMemcpyHostToDevice, st));
-    e->tree.top_set(La, d->top.p, st); // (synchronises: htop may be reused afterwards)
+    // the checks of this phase raise bits of d->err[1..2]; tree_finish reads them with the target count (no wait here)
+    d->err.reserve(8);
+    MPG_HIP(hipMemsetAsync(d->err.p + 1, 0, 2 * sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_top_levels, dim3(1), dim3(1024), 0, st, La, (const double *)d->top.p, (const double *)cnt, all, d->err.p + 1);
+    e->tree.top_set(La, all, st, (int *)(d->err.p + 2));
 }
 
 } // namespace
@@ -1032,6 +1067,14 @@ int mpg_dist_create(mpg_dist **out, mpg_engine *eng, const mpg_comm *comm)
     d->comm = *comm;
     d->me = comm->ThisTask;
     d->nt = comm->NTask;
+    if(comm->bind_stream && comm->device_buffers) {
+        if(comm->bind_stream(comm->ctx, (void *)eng->stream) != 0) {
+            delete d;
+            throw Error("mpg_comm: bind_stream failed");
+        }
+        d->stream_ordered = true;
+        d->bound_stream = eng->stream;
+    }
     *out = d;
     API_END
 }
@@ -1163,9 +1206,19 @@ static void tree_finish(mpg_dist *d, int64_t n_own, int64_t nl)
         MPG_HIP(rocprim::select((void *)d->tmp.p, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, IsOwn{(int)n_own}, st));
         unsigned long long c = 0;
         MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        unsigned ef[2] = {0, 0};
+        MPG_HIP(hipMemcpyAsync(ef, d->err.p + 1, sizeof(ef), hipMemcpyDeviceToHost, st));
         sync(d);
+        MPG_CHECK(ef[0] == 0, "mpg_dist: a cell above the decomposition level holds <= 8 particles in all (use a coarser level La)");
+        MPG_CHECK(ef[1] == 0, "domain decomposition: a cell above the decomposition level holds <= 8 local particles (use a coarser level)");
         d->ntarg = (int64_t)c;
         MPG_CHECK(d->ntarg == n_own, "mpg_dist: own particles missing from the local tree");
+    }
+    else {
+        unsigned ef[2] = {0, 0};
+        MPG_HIP(hipMemcpyAsync(ef, d->err.p + 1, sizeof(ef), hipMemcpyDeviceToHost, st));
+        sync(d);
+        MPG_CHECK(ef[0] == 0 && ef[1] == 0, "mpg_dist: a cell above the decomposition level holds <= 8 particles (use a coarser level La)");
     }
     d->grav_tree_valid = true;
 }

@@ -88,7 +88,8 @@ struct TreeBuilder {
     void make_level_order(hipStream_t st);
     // domain-decomposed runs: own-particle sums of the level-(La-1) cells / moments of the nodes above level La from global sums
     void top_partial(int La, int64_t n_own, double *d_out, hipStream_t st);
-    void top_set(int La, const double *d_sums, hipStream_t st);
+    // d_flag_later: a zeroed device word the kernel raises instead of the check + synchronisation here (the caller reads it later)
+    void top_set(int La, const double *d_sums, hipStream_t st, int *d_flag_later = nullptr);
     void ensure_level_order(hipStream_t st);
     TreeView view() const;
 };

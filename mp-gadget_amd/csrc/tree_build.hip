@@ -723,9 +723,15 @@ void TreeBuilder::top_partial(int La, int64_t n_own, double *d_out, hipStream_t 
     MPG_HIP(hipGetLastError());
 }
 
-void TreeBuilder::top_set(int La, const double *d_sums, hipStream_t st)
+void TreeBuilder::top_set(int La, const double *d_sums, hipStream_t st, int *d_flag_later)
 {
     MPG_CHECK(La >= 1 && La <= 8 && has_moments, "top_set: needs a tree with moments and a level in [1, 8]");
+    if(d_flag_later) { // the caller reads the flag (already zeroed) with its next read-back: nothing waits here
+        hipLaunchKernelGGL(k_top_set, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, La, link.p, keys_b.p, d_sums, src.p, d_flag_later);
+        MPG_HIP(hipGetLastError());
+        has_bfs = false;
+        return;
+    }
     int *d_flag = (int *)flags.p;
     MPG_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_top_set, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, La, link.p, keys_b.p, d_sums, src.p, d_flag);

@@ -21,9 +21,12 @@ A2AV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.P
                       C.POINTER(C.c_int64), C.c_int)
 
 
+BIND_STREAM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
 class MpgComm(C.Structure):     # mpg_comm, include/mpgadget_hip.h
     _fields_ = [("ctx", C.c_void_p), ("ThisTask", C.c_int), ("NTask", C.c_int), ("device_buffers", C.c_int),
-                ("allreduce", ALLREDUCE_FN), ("alltoall_i64", A2A_I64_FN), ("alltoallv", A2AV_FN)]
+                ("allreduce", ALLREDUCE_FN), ("alltoall_i64", A2A_I64_FN), ("alltoallv", A2AV_FN), ("bind_stream", BIND_STREAM_FN)]
 
 
 class _DevMem:
@@ -129,6 +132,60 @@ class TorchComm:
         return self._guard(go)
 
 
+class RcclComm:
+    """mpg_comm on the library's NATIVE RCCL communicator (csrc/rccl_comm.hip): ncclSend / ncclRecv / ncclAllReduce on the engine's
+    stream, no Python frame in any collective.  Python's only part is the bootstrap: rank 0's ncclUniqueId reaches the other ranks
+    through the torch.distributed group the launcher set up (any backend)."""
+
+    def __init__(self, lib, device, group=None, selftest_bytes=0):
+        self.lib, self.device, self.errors = lib, device, []
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        lib.mpg_rccl_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.mpg_rccl_comm.argtypes = [C.c_void_p, C.POINTER(MpgComm)]
+        lib.mpg_rccl_selftest.argtypes = [C.c_void_p, C.c_int64]
+        lib.mpg_rccl_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        lib.mpg_rccl_destroy.argtypes = [C.c_void_p]
+        lib.mpg_rccl_destroy.restype = None
+        lib.mpg_rccl_last_error.argtypes = [C.c_void_p]
+        lib.mpg_rccl_last_error.restype = C.c_char_p
+        idb = (C.c_char * 128)()
+        ok = 1
+        if self.rank == 0:
+            ok = 0 if lib.mpg_rccl_get_unique_id(idb) else 1
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.tensor([ok] + list(idb.raw), dtype=torch.int32, device=device if on_gpu else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        t = t.cpu()
+        if int(t[0]) != 1:
+            raise E.EngineError("RCCL: rank 0 could not create a unique id: " + lib.mpg_last_error().decode())
+        idb.raw = bytes(int(v) for v in t[1:])
+        self.h = C.c_void_p()
+        dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        if lib.mpg_rccl_create(C.byref(self.h), self.rank, self.world, idb, int(dev_index)):
+            raise E.EngineError("RCCL: " + lib.mpg_last_error().decode())
+        if selftest_bytes >= 0 and lib.mpg_rccl_selftest(self.h, C.c_int64(selftest_bytes)):
+            msg = lib.mpg_last_error().decode()
+            self.close()
+            raise E.EngineError("RCCL self-test: " + msg)
+        self.struct = MpgComm()
+        if lib.mpg_rccl_comm(self.h, C.byref(self.struct)):
+            raise E.EngineError("RCCL: " + lib.mpg_last_error().decode())
+        self.on_device = True
+
+    def stats(self):
+        calls, sent, ver = (C.c_int64 * 3)(), C.c_int64(0), C.c_int(0)
+        self.lib.mpg_rccl_stats(self.h, calls, C.byref(sent), C.byref(ver))
+        return dict(allreduce=calls[0], alltoall_i64=calls[1], alltoallv=calls[2], bytes_sent=sent.value, rccl_version=ver.value)
+
+    def last_error(self):
+        return (self.lib.mpg_rccl_last_error(self.h) or b"").decode() if self.h else ""
+
+    def close(self):
+        if self.h:
+            self.lib.mpg_rccl_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class LocalComm:
     """one rank, no process group: NULL callbacks (the library then copies locally)"""
 
@@ -169,6 +226,8 @@ class DistForce:
             msg = self.lib.mpg_last_error().decode()
             if self.comm.errors:
                 msg += " | callback: " + "; ".join(self.comm.errors[-3:])
+            if hasattr(self.comm, "last_error") and self.comm.last_error():
+                msg += " | RCCL: " + self.comm.last_error()
             raise E.EngineError(msg)
 
     def set_domain(self, dom, margin, La=0):

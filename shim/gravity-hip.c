@@ -9,6 +9,7 @@
  * One rank = one GPU.  NTask == 1: the host-pointer calls.  NTask > 1: the mpg_dist_* calls on the rank's own P[] with the
  * domain of ddecomp and MPI as the communicator (mpg_mpi_comm.c) - collective, as the functions they replace. */
 #include <mpi.h>
+#include <stdlib.h>
 #include <string.h>
 #include "gravity.h"     /* PetaPM, struct gravshort_tree_params, prototypes of everything defined here */
 #include "forcetree.h"   /* ForceTree */
@@ -30,6 +31,7 @@ extern const double shortrange_force_kernels[][5]; /* libgadget/shortrange-kerne
 
 static mpg_engine *E;
 static mpg_dist *D;
+static mpg_rccl *Rccl;
 static MPI_Comm Comm;
 static int NTask = 1;
 
@@ -64,7 +66,13 @@ static mpg_engine *eng(void)
         MPI_Comm_free(&shm);
         ck(mpg_engine_create(&E, local));
         if(NTask > 1) {
-            mpg_comm c = mpg_mpi_comm(&Comm);
+            /* the exchanges of the force step on RCCL over xGMI (mpg_rccl_mpi.c) unless MPG_SHIM_COMM=mpi or RCCL cannot be opened:
+             * then MPI with host staging (mpg_mpi_comm.c) */
+            mpg_comm c;
+            const char *want = getenv("MPG_SHIM_COMM");
+            if((want && !strcmp(want, "mpi")) || mpg_rccl_mpi_comm(Comm, local, &Rccl, &c) != 0)
+                c = mpg_mpi_comm(&Comm);
+            message(0, "mpgadget_hip: collectives of the force step on %s\n", Rccl ? "RCCL (device buffers, stream-ordered)" : "MPI (host staging)");
             ck(mpg_dist_create(&D, E, &c));
         }
     }

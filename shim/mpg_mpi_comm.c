@@ -2,6 +2,7 @@
 #include "mpg_mpi_comm.h"
 #include <limits.h>
 #include <stdlib.h>
+#include <string.h>
 
 static int cb_allreduce(void *ctx, void *buf, int64_t count, int dtype, int op, int on_device)
 {
@@ -60,6 +61,7 @@ static int cb_alltoallv(void *ctx, const void *send, const int64_t *sb, const in
 mpg_comm mpg_mpi_comm(MPI_Comm *comm)
 {
     mpg_comm m;
+    memset(&m, 0, sizeof(m)); /* (bind_stream = NULL: MPI calls block) */
     m.ctx = comm;
     MPI_Comm_rank(*comm, &m.ThisTask);
     MPI_Comm_size(*comm, &m.NTask);

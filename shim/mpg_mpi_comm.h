@@ -7,4 +7,7 @@
 #include <mpgadget_hip.h>
 /* `comm` must stay valid as long as the returned struct is in use (its address is the callback context) */
 mpg_comm mpg_mpi_comm(MPI_Comm *comm);
+/* mpg_rccl_mpi.c: the native RCCL communicator with MPI as its bootstrap (one MPI_Bcast of the unique id).  Collective over comm;
+ * returns non-zero ON EVERY RANK when RCCL is unavailable or its self-test fails on any rank (the caller then uses mpg_mpi_comm). */
+int mpg_rccl_mpi_comm(MPI_Comm comm, int device, mpg_rccl **out, mpg_comm *c);
 #endif

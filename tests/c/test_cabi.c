@@ -344,6 +344,21 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
     alarm(300); /* a rank that dies leaves its peers at a barrier: do not hang the test */
     struct ctx cx = {S, me, nt};
     mpg_comm comm = {&cx, me, nt, 0, cb_allreduce, cb_alltoall_i64, cb_alltoallv};
+    /* MPG_TEST_COMM=rccl: the library's native RCCL communicator instead (mpg_rccl_*, csrc/rccl_comm.hip), bootstrapped as a C caller
+     * does it - rank 0's unique id handed to every rank (here: one rank; RCCL refuses several ranks on one GPU), mpg_rccl_create, the
+     * self-test, the callbacks.  Collectives then run on the engine's stream with device pointers, no host staging. */
+    mpg_rccl *RC = NULL;
+    if(getenv("MPG_TEST_COMM") && !strcmp(getenv("MPG_TEST_COMM"), "rccl")) {
+        if(nt != 1) {
+            fprintf(stderr, "FAIL RCCL refuses several ranks on one GPU: NTask must be 1 with MPG_TEST_COMM=rccl\n");
+            exit(1);
+        }
+        char id[MPG_RCCL_ID_BYTES];
+        CK(mpg_rccl_get_unique_id(id));
+        CK(mpg_rccl_create(&RC, me, nt, id, 0));
+        CK(mpg_rccl_selftest(RC, 0));
+        CK(mpg_rccl_comm(RC, &comm));
+    }
     mpg_engine *e = make_engine(table, box, n, nmesh);
     /* the domain: the root of the Peano-Hilbert key space cut into its 8 cells, cell k owned by task k % NTask
      * (struct topnode_data, domain.h:12-18: StartKey, Shift, Daughter, Leaf) */
@@ -527,9 +542,20 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
             R[6 * ids[k] + 3 + j] = acc[3 * k + j];
         }
     printf("rank %d of %d: own %lld ghosts %lld local %lld La %lld\n", me, nt, (long long)n_own, (long long)st[0], (long long)st[2], (long long)st[3]);
+    if(RC) {
+        int64_t calls[3], sent = 0;
+        int ver = 0;
+        CK(mpg_rccl_stats(RC, calls, &sent, &ver));
+        printf("rccl: version %d allreduce %lld alltoall_i64 %lld alltoallv %lld\n", ver, (long long)calls[0], (long long)calls[1], (long long)calls[2]);
+        if(calls[0] < 1 || calls[2] < 4) {
+            fprintf(stderr, "FAIL the collectives did not go through the RCCL communicator\n");
+            exit(1);
+        }
+    }
     fflush(stdout);
     mpg_dist_destroy(D);
     mpg_engine_destroy(e);
+    mpg_rccl_destroy(RC);
     pthread_barrier_wait(&S->bar);
 }
 

@@ -60,6 +60,28 @@ def test_multi_gpu_path_in_a_one_rank_group_checks_itself(overlap):
     pc = j["parity_check"]
     assert pc["ok"] and pc["counters_equal"] and pc["n"] >= 1024 and pc["median_rel"] <= 1e-12 and pc["gravpm_max_rel_to_mean"] <= 1e-11
     assert (j["phases_ms"]["dist_tree_build_beside_pm_ms"] > 0) == overlap
+    # the collectives ran on the library's native RCCL communicator (csrc/rccl_comm.hip), not through Python callbacks
+    assert j["config"]["communicator"].startswith("native RCCL"), j["config"]["communicator"]
+    cc = j["config"]["communicator_calls"]
+    assert cc["alltoallv"] > 0 and cc["allreduce"] > 0 and cc["alltoall_i64"] > 0 and cc["rccl_version"] > 20000
+
+
+@pytest.mark.parametrize("mode", ["self_through_rccl", "torch_callbacks"])
+def test_multi_gpu_path_communicator_variants(mode):
+    """self_through_rccl: MPG_RCCL_SELF=1 sends the rank's own block through ncclSend / ncclRecv as well (on real peers only the other
+    ranks' blocks travel that way, the own block is a device copy), with pieces of 64 KiB so that every block is cut: on a one-GPU box
+    this is what exercises the grouped send / receive path with data.  torch_callbacks: the torch.distributed callbacks of rounds 2-3
+    (--comm torch) still pass the same self-check."""
+    env = {"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29173"}
+    args = ["--gpus", "1", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    if mode == "self_through_rccl":
+        env.update(MPG_RCCL_SELF="1", MPG_RCCL_PIECE="65536")
+    else:
+        args += ["--comm", "torch"]
+    j = run_bench(args, env=env)
+    pc = j["parity_check"]
+    assert pc["ok"] and pc["counters_equal"] and pc["median_rel"] <= 1e-12, pc
+    assert j["config"]["communicator"].startswith("native RCCL" if mode == "self_through_rccl" else "torch.distributed")
 
 
 def test_multi_gpu_parity_check_on_four_ranks():

@@ -92,6 +92,28 @@ def test_c_caller_run_order_without_host_tree(tmp_path, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("self_through_rccl", [0, 1])
+def test_c_caller_native_rccl_communicator(tmp_path, self_through_rccl):
+    """The library's native RCCL communicator from C (mpg_rccl_get_unique_id / _create / _selftest / _comm): a one-rank group - RCCL
+    refuses several ranks on one GPU - drives the whole multi-rank choreography with stream-ordered collectives on device pointers
+    (domain decomposition + exchange, PM particle shipping and transposes, ghost import, all-reduced top of the tree) and, through the
+    host drop-in forms, the staged path; results against the committed golden vectors.  self_through_rccl = 1 sends the rank's own
+    blocks through ncclSend / ncclRecv in 4 KiB pieces, i.e. runs the grouped send / receive code with data."""
+    pkg = importlib.import_module("mp-gadget_amd")
+    exe = build(tmp_path)
+    table = os.path.join(ROOT, "mp-gadget_amd", "data", "shortrange_force_kernels.f64")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "grav_sgrid16.npz"))
+    pos, mass, box = pkg.ics.s_grid(16)
+    p, e = _write_case(tmp_path, "sgrid16", pos, g["GravPM"], g["Accel2"])
+    env = dict(os.environ, MPG_TEST_COMM="rccl")
+    if self_through_rccl:
+        env.update(MPG_RCCL_SELF="1", MPG_RCCL_PIECE="4096")
+    for mode in ("ranks", "ranks_host"):
+        r = subprocess.run([exe, mode, table, p, e, "16", "32", str(box), "1"], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "PASS ranks 1" in r.stdout and "rccl: version" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
 def test_c_caller_ranks_against_oracle(tmp_path, orc):
     """a set large enough for a real decomposition level (Rcut = 9 of 64 mesh cells: La = 2), Zel'dovich-displaced: 2 and 4 C ranks"""
     from oracle import oracle as O
