@@ -647,6 +647,13 @@ int mpg_dist_gravity_step(mpg_dist *d, int64_t n_own, const double *d_pos, const
  *   force_tree_full (forcetree.h:115)    -> ghost import, local tree with the global top
  *   grav_short_tree (gravity.h:40)       -> accelerations of all own particles (and the tree potential, assigned) */
 int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, double *d_gravpm, double *d_potential);
+/* Garbage and swallowed particles among the own rows (P[].IsGarbage, P[].Swallowed: star formation and black-hole mergers leave them in
+ * the table until the next domain_decompose_full collects them).  The reference skips them in place in every loop of this path
+ * (treewalk.c:234, forcetree.c:806, gravpm.c:176-179); so do the mpg_dist_dev_* calls that follow on a table of n_own rows: such rows are
+ * shipped nowhere, are not in the local tree, are no targets; their GravPM is zeroed, their other outputs are left alone.
+ * d_garbage: n_own device bytes (non-zero = skip) or NULL for none; stays in force until the next call.  The host forms
+ * (mpg_dist_gravpm_force, ...) read the flag byte of the particle view themselves. */
+int mpg_dist_dev_set_garbage(mpg_dist *d, int64_t n_own, const unsigned char *d_garbage);
 int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass);
 int mpg_dist_dev_grav_short_tree(mpg_dist *d, const double *d_oldacc, const double *d_prev_accel, const double *d_gravpm, double *d_accel,
                                  double *d_potential, double rho0);

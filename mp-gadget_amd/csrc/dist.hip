@@ -55,15 +55,16 @@ __device__ __forceinline__ void pm_owners(double x, double cellsize, int nmesh, 
     o1 = wrapi(ix + 1, nmesh) / P;
 }
 
+// skip (may be null): garbage and swallowed particles take no part in the force (gravpm.c:176-179, forcetree.c:806): they go nowhere
 __global__ void __launch_bounds__(256) k_pm_mask(int64_t n, const double *__restrict__ pos, double cellsize, int nmesh, int P,
-                                                 unsigned long long *__restrict__ mask)
+                                                 const unsigned char *__restrict__ skip, unsigned long long *__restrict__ mask)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
         return;
     int o0, o1;
     pm_owners(pos[3 * i], cellsize, nmesh, P, o0, o1);
-    mask[i] = (1ull << o0) | (1ull << o1);
+    mask[i] = (skip && skip[i]) ? 0ull : ((1ull << o0) | (1ull << o1));
 }
 
 // level-La tree cell of a position by the reference's own floating-point descent (forcetree.c get_subnode, as k_keys of
@@ -88,12 +89,29 @@ __device__ __forceinline__ unsigned tree_cell(double x, double y, double z, doub
 }
 
 __global__ void __launch_bounds__(256) k_need_mask(int64_t n, const double *__restrict__ pos, double box, int La,
-                                                   const unsigned long long *__restrict__ need, int me, unsigned long long *__restrict__ mask)
+                                                   const unsigned long long *__restrict__ need, int me, const unsigned char *__restrict__ skip,
+                                                   unsigned long long *__restrict__ mask)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
         return;
-    mask[i] = need[tree_cell(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], box, La)] & ~(1ull << me);
+    mask[i] = (skip && skip[i]) ? 0ull : (need[tree_cell(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], box, La)] & ~(1ull << me));
+}
+
+// types of the local set [own | ghosts] when the own rows hold garbage: 7 (no bit of any tree mask) for those, 1 otherwise
+__global__ void __launch_bounds__(256) k_local_types(int64_t nl, int64_t n_own, const unsigned char *__restrict__ skip, uint8_t *__restrict__ type)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < nl)
+        type[i] = (i < n_own && skip[i]) ? 7 : 1;
+}
+
+__global__ void __launch_bounds__(256) k_count_nonzero(int64_t n, const unsigned char *__restrict__ b, unsigned long long *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && b[i] != 0);
+    if((threadIdx.x & 63) == 0 && m)
+        atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
 // ---- send lists for all destinations in two passes (a stable multi-way split).  A row may go to several destinations (one bit per
@@ -634,6 +652,11 @@ struct mpg_dist {
     DevBuf<unsigned> err;
     HostBuf<double> htop;
     int64_t ntarg = 0, n_own_tree = -1;
+    // garbage / swallowed particles among the own rows (mpg_dist_dev_set_garbage): flags over n_skip_rows rows, n_skip of them set
+    const unsigned char *d_skip = nullptr;
+    int64_t n_skip = 0, n_skip_rows = -1;
+    DevBuf<uint8_t> ltype, o_skip;
+    const unsigned char *skip_for(int64_t n) const { return (n_skip > 0 && n == n_skip_rows) ? d_skip : nullptr; }
     bool grav_tree_valid = false; // the engine's tree is the gravity tree of mpg_dist_dev_force_tree_build (the SPH loops and FOF replace it)
     double last_hmax = 0;         // largest smoothing length over all ranks after the last density loop
     int blackholes = 0;           // BlackHoleOn of density(): the own non-swallowed black holes are targets of the density loop too
@@ -678,6 +701,7 @@ struct mpg_dist {
     DevBuf<float> o_mass;
     std::vector<double> hbuf;
     std::vector<float> hbuf_f;
+    std::vector<uint8_t> hbuf_b;
     int64_t o_n = -1;
     DevBuf<int> o_act;        // ActiveParticle of the host drop-in walk
     DevBuf<double> o_sph[17]; // the double-valued fields of mpg_sph_arrays over the own particles (host SPH path)
@@ -881,7 +905,7 @@ void pm_step(mpg_dist *d, int64_t n, const double *pos, const float *mass, doubl
     const int nmesh = pm.nmesh, P = nmesh / d->nt;
     d->mask.reserve((size_t)n + 1);
     if(n > 0)
-        hipLaunchKernelGGL(k_pm_mask, dim3(nblk(n)), dim3(256), 0, st, n, pos, pm.cellsize, nmesh, P, d->mask.p);
+        hipLaunchKernelGGL(k_pm_mask, dim3(nblk(n)), dim3(256), 0, st, n, pos, pm.cellsize, nmesh, P, d->skip_for(n), d->mask.p);
     build_plan(d, d->pm, n, d->mask.p);
     Plan &pl = d->pm;
     d->sendbuf.reserve((size_t)32 * pl.nsend + 32);
@@ -962,7 +986,7 @@ int64_t import_ghosts(mpg_dist *d, int64_t n, const double *pos, const float *ma
     hipStream_t st = d->eng->stream;
     d->mask.reserve((size_t)n + 1);
     if(n > 0)
-        hipLaunchKernelGGL(k_need_mask, dim3(nblk(n)), dim3(256), 0, st, n, pos, d->box, d->La, d->need.p, d->me, d->mask.p);
+        hipLaunchKernelGGL(k_need_mask, dim3(nblk(n)), dim3(256), 0, st, n, pos, d->box, d->La, d->need.p, d->me, d->skip_for(n), d->mask.p);
     build_plan(d, d->ghost, n, d->mask.p);
     Plan &pl = d->ghost;
     d->sendbuf.reserve((size_t)32 * pl.nsend + 32);
@@ -1154,6 +1178,31 @@ int mpg_dist_set_domain(mpg_dist *d, double BoxSize, const mpg_topnode *TopNodes
     API_END
 }
 
+int mpg_dist_dev_set_garbage(mpg_dist *d, int64_t n_own, const unsigned char *d_garbage)
+{
+    API_BEGIN
+    MPG_CHECK(d && n_own >= 0, "null argument");
+    MPG_HIP(hipSetDevice(d->eng->device));
+    d->d_skip = nullptr;
+    d->n_skip = 0;
+    d->n_skip_rows = -1;
+    if(d_garbage && n_own > 0) {
+        hipStream_t st = d->eng->stream;
+        d->scount.reserve(4);
+        MPG_HIP(hipMemsetAsync(d->scount.p, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_count_nonzero, dim3(nblk(n_own)), dim3(256), 0, st, n_own, d_garbage, d->scount.p);
+        unsigned long long c = 0;
+        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        sync(d);
+        if(c > 0) {
+            d->d_skip = d_garbage;
+            d->n_skip = (int64_t)c;
+            d->n_skip_rows = n_own;
+        }
+    }
+    API_END
+}
+
 int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, const float *d_mass, double *d_gravpm, double *d_potential)
 {
     API_BEGIN
@@ -1164,6 +1213,8 @@ int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, c
     MPG_CHECK(n_own < (1ll << 31), "mpg_dist: too many particles on one rank");
     MPG_CHECK(e->pm.box == d->box, "mpg_dist: BoxSize of the mesh differs from the domain's");
     d->stats[4] = d->stats[5] = 0;
+    if(d->skip_for(n_own)) // (gravpm.c:88-92 zeroes GravPM of every particle; the readout then reaches the live ones only)
+        MPG_HIP(hipMemsetAsync(d_gravpm, 0, (size_t)3 * n_own * sizeof(double), e->stream));
     sync(d);
     const double t0 = now_ms();
     pm_step(d, n_own, d_pos, d_mass, d_gravpm, d_potential);
@@ -1174,10 +1225,16 @@ int mpg_dist_dev_gravpm_force(mpg_dist *d, int64_t n_own, const double *d_pos, c
 
 // The three phases of the local tree: ghosts (collective), build (no collective: may run on another stream beside the PM), global top
 // + targets (collective).
-static void tree_build_local(mpg_dist *d, int64_t nl, hipStream_t st)
+static void tree_build_local(mpg_dist *d, int64_t n_own, int64_t nl, hipStream_t st)
 {
     mpg_engine *e = d->eng;
-    MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, nullptr, d->box) == 0, mpg_last_error());
+    const uint8_t *ltype = nullptr;
+    if(d->skip_for(n_own)) { // garbage among the own rows: type 7 keeps them out of the tree (forcetree.c:806)
+        d->ltype.reserve((size_t)nl + 1);
+        hipLaunchKernelGGL(k_local_types, dim3(nblk(nl)), dim3(256), 0, st, nl, n_own, d->d_skip, d->ltype.p);
+        ltype = d->ltype.p;
+    }
+    MPG_CHECK(mpg_dev_bind_particles(e, nl, d->lpos.p, d->lmass.p, ltype, d->box) == 0, mpg_last_error());
     e->tree.force_internal_above = d->La;
     try {
         engine_tree_build_on(e, 63, st);
@@ -1212,7 +1269,7 @@ static void tree_finish(mpg_dist *d, int64_t n_own, int64_t nl)
         MPG_CHECK(ef[0] == 0, "mpg_dist: a cell above the decomposition level holds <= 8 particles in all (use a coarser level La)");
         MPG_CHECK(ef[1] == 0, "domain decomposition: a cell above the decomposition level holds <= 8 local particles (use a coarser level)");
         d->ntarg = (int64_t)c;
-        MPG_CHECK(d->ntarg == n_own, "mpg_dist: own particles missing from the local tree");
+        MPG_CHECK(d->ntarg == n_own - (d->skip_for(n_own) ? d->n_skip : 0), "mpg_dist: own particles missing from the local tree");
     }
     else {
         unsigned ef[2] = {0, 0};
@@ -1238,7 +1295,7 @@ int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_po
     sync(d);
     const double t2 = now_ms();
     d->times[1] = t2 - t1;
-    tree_build_local(d, nl, e->stream);
+    tree_build_local(d, n_own, nl, e->stream);
     tree_finish(d, n_own, nl);
     d->times[2] = now_ms() - t2;
     d->times[4] = 0;
@@ -1288,7 +1345,9 @@ int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_
             MPG_HIP(hipMemcpyAsync(&bad, d->err.p, sizeof(bad), hipMemcpyDeviceToHost, st));
             sync(d);
             MPG_CHECK(bad == 0, "mpg_dist_dev_grav_short_tree_active: an active index is not an own particle");
-            MPG_CHECK((int64_t)c == nactive, "mpg_dist_dev_grav_short_tree_active: the active list holds duplicates");
+            // (garbage on the active list is skipped in place, treewalk.c:234: it is not in the tree, hence not among the targets)
+            MPG_CHECK((int64_t)c == nactive || (d->n_skip > 0 && (int64_t)c < nactive && (int64_t)c >= nactive - d->n_skip),
+                      "mpg_dist_dev_grav_short_tree_active: the active list holds duplicates");
             ntarg = (int64_t)c;
         }
         targets = d->act_targets.p;
@@ -1338,6 +1397,8 @@ int mpg_dist_gravity_step(mpg_dist *d, int64_t n_own, const double *d_pos, const
         MPG_CHECK(n_own < (1ll << 31), "mpg_dist: too many particles on one rank");
         MPG_CHECK(e->pm.box == d->box, "mpg_dist: BoxSize of the mesh differs from the domain's");
         d->stats[4] = d->stats[5] = 0;
+        if(d->skip_for(n_own))
+            MPG_HIP(hipMemsetAsync(d_gravpm, 0, (size_t)3 * n_own * sizeof(double), e->stream));
         sync(d);
         const double t0 = now_ms();
         const int64_t nl = import_ghosts(d, n_own, d_pos, d_mass);
@@ -1352,7 +1413,7 @@ int mpg_dist_gravity_step(mpg_dist *d, int64_t n_own, const double *d_pos, const
             try {
                 MPG_HIP(hipSetDevice(e->device));
                 const double ta = now_ms();
-                tree_build_local(d, nl, d->tree_stream);
+                tree_build_local(d, n_own, nl, d->tree_stream);
                 MPG_HIP(hipStreamSynchronize(d->tree_stream));
                 t_tree = now_ms() - ta;
             }
@@ -1400,8 +1461,14 @@ void stage_own(mpg_dist *d, const mpg_particle_view *P)
     const char *b = (const char *)P->base;
     double *hd = d->hbuf.data();
     float *hf = d->hbuf_f.data();
+    // IsGarbage (bit 0) and Swallowed (bit 1) of the flag byte (partmanager.h:24-44): such particles stay where they are in P[] and are
+    // skipped in place by every loop of this path (treewalk.c:234, forcetree.c:806, gravpm.c:176-179) - after star formation and black
+    // hole mergers every sub-step sees some until the next domain_decompose_full collects them
+    d->hbuf_b.resize((size_t)n + 1);
+    uint8_t *hb = d->hbuf_b.data();
     std::vector<int> bad(64, 0);
     parallel_for(n, [=, &bad](int64_t lo, int64_t hi) {
+        int any = 0;
         for(int64_t i = lo; i < hi; i++) {
             const char *rec = b + i * V.stride;
             const double *pp = (const double *)(rec + V.off_pos);
@@ -1409,12 +1476,19 @@ void stage_own(mpg_dist *d, const mpg_particle_view *P)
             hd[3 * i + 1] = pp[1];
             hd[3 * i + 2] = pp[2];
             hf[i] = *(const float *)(rec + V.off_mass);
-            if(V.off_flags >= 0 && (*(const uint8_t *)(rec + V.off_flags) & 1))
-                bad[0] = 1;
+            hb[i] = (V.off_flags >= 0 && (*(const uint8_t *)(rec + V.off_flags) & 3)) ? 1 : 0;
+            any |= hb[i];
         }
+        if(any)
+            bad[0] = 1;
     });
-    // (a PM step follows domain_decompose_full, which has collected the garbage: domain.c:238-241)
-    MPG_CHECK(!bad[0], "mpg_dist: P[] holds garbage particles (run the domain decomposition / slots_gc first)");
+    if(bad[0]) {
+        d->o_skip.reserve((size_t)n + 1);
+        MPG_HIP(hipMemcpyAsync(d->o_skip.p, hb, (size_t)n, hipMemcpyHostToDevice, st));
+        MPG_CHECK(mpg_dist_dev_set_garbage(d, n, d->o_skip.p) == 0, mpg_last_error());
+    }
+    else
+        MPG_CHECK(mpg_dist_dev_set_garbage(d, n, nullptr) == 0, mpg_last_error());
     d->o_pos.reserve(3 * (size_t)n + 3);
     d->o_mass.reserve((size_t)n + 1);
     d->o_gravpm.reserve(3 * (size_t)n + 3);
@@ -1539,9 +1613,12 @@ int mpg_dist_grav_short_tree_active(mpg_dist *d, const mpg_particle_view *P, con
     }
     sync(d);
     const int64_t m = ActiveParticle ? NumActiveParticle : n;
+    const uint8_t *dead = (d->n_skip > 0 && (int64_t)d->hbuf_b.size() > n) ? d->hbuf_b.data() : nullptr; // (flags of this table: stage_own)
     parallel_for(m, [=](int64_t lo, int64_t hi) {
         for(int64_t k = lo; k < hi; k++) {
             const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            if(dead && dead[i])
+                continue; // garbage / swallowed: not walked, nothing to write (treewalk.c:234)
             double *a = (double *)(b + i * V.stride + V.off_accel);
             for(int j = 0; j < 3; j++) {
                 a[j] = ha[3 * i + j];
@@ -2793,10 +2870,22 @@ extern "C" int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_parti
     API_BEGIN
     MPG_CHECK(d && P && AccelStore, "null argument (the walk on an active-only tree returns its result in AccelStore)");
     MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0 && P->off_accel >= 0 && P->off_gravpm >= 0, "particle view needs Pos, Mass, FullTreeGravAccel, GravPM");
-    const int64_t n = ActiveParticle ? NumActiveParticle : P->n;
-    MPG_CHECK(n >= 0 && n <= P->n, "bad NumActiveParticle");
+    const int64_t nlist = ActiveParticle ? NumActiveParticle : P->n;
+    MPG_CHECK(nlist >= 0 && nlist <= P->n, "bad NumActiveParticle");
     MPG_HIP(hipSetDevice(d->eng->device));
     hipStream_t st = d->eng->stream;
+    // the live members of the list (garbage and swallowed particles are skipped in place: treewalk.c:234, forcetree.c:806)
+    std::vector<int64_t> live;
+    live.reserve((size_t)nlist);
+    for(int64_t k = 0; k < nlist; k++) {
+        const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+        MPG_CHECK(i >= 0 && i < P->n, "ActiveParticle index out of range");
+        if(P->off_flags >= 0 && (*((const uint8_t *)P->base + i * P->stride + P->off_flags) & 3))
+            continue;
+        live.push_back(i);
+    }
+    const int64_t n = (int64_t)live.size();
+    const int64_t *lv = live.data();
     std::vector<double> hp(3 * (size_t)n + 3), ho((size_t)n + 1);
     std::vector<float> hm((size_t)n + 1);
     const mpg_particle_view V = *P;
@@ -2806,7 +2895,7 @@ extern "C" int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_parti
     float *pm = hm.data();
     parallel_for(n, [=](int64_t lo, int64_t hi) {
         for(int64_t k = lo; k < hi; k++) {
-            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            const int64_t i = lv[k];
             const char *rec = b + i * V.stride;
             const double *x = (const double *)(rec + V.off_pos), *a = (const double *)(rec + V.off_accel), *g = (const double *)(rec + V.off_gravpm);
             double s2 = 0;
@@ -2836,7 +2925,7 @@ extern "C" int mpg_dist_grav_short_tree_active_tree(mpg_dist *d, const mpg_parti
     sync(d);
     parallel_for(n, [=](int64_t lo, int64_t hi) {
         for(int64_t k = lo; k < hi; k++) {
-            const int64_t i = ActiveParticle ? ActiveParticle[k] : k;
+            const int64_t i = lv[k];
             for(int j = 0; j < 3; j++)
                 AccelStore[i][j] = pp[3 * k + j];
         }

@@ -417,8 +417,10 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         io.ntargets = nactive;
     else {
         // ActiveParticle == NULL: all particles (timestep.c:77-84).  When the tree holds them all, walk in tree order.
-        MPG_CHECK(eng->tree.npart == eng->n, "grav_short_tree with ActiveParticle == NULL needs a tree of all particles "
-                                              "(pass the active list for masked trees)");
+        // (a tree of all types holds every LIVE particle: the garbage / swallowed records it leaves out are skipped by the reference's
+        // queue as well, treewalk.c:92-96,234)
+        MPG_CHECK(eng->tree.npart == eng->n || eng->full_particle_tree, "grav_short_tree with ActiveParticle == NULL needs a tree of all particles "
+                                                                         "(pass the active list for masked trees)");
         io.ntargets = eng->tree.npart;
     }
     io.pos = eng->d_pos;
@@ -1212,6 +1214,8 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
     float *hf = eng->h_f.p;
     uint8_t *hb = eng->h_b.p;
     const mpg_particle_view V = *P;
+    int any_dead_store[HOST_CHUNKS] = {};
+    int *any_dead = any_dead_store;
     for(int c = 0; c < HOST_CHUNKS; c++) {
         int64_t lo, hi;
         chunk_range(n, c, lo, hi);
@@ -1233,11 +1237,29 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
                         ty = 7;
                 }
                 hb[i] = ty;
+                if(ty == 7)
+                    any_dead[c] = 1;
             }
         });
         MPG_HIP(hipMemcpyAsync(eng->s_pos.p + 3 * lo, hd + 3 * lo, 3 * (hi - lo) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
         MPG_HIP(hipMemcpyAsync(eng->s_mass.p + lo, hf + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, eng->stream));
         MPG_HIP(hipMemcpyAsync(eng->s_type.p + lo, hb + lo, (hi - lo) * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
+    }
+    // garbage and swallowed particles are not deposited and receive no mesh force either (gravpm.c:176-179: region -2): the PM takes a
+    // live flag per particle when the table holds any
+    bool dead = false;
+    for(int c = 0; c < HOST_CHUNKS; c++)
+        dead = dead || any_dead[c];
+    eng->pm_live = nullptr;
+    if(dead) {
+        eng->s_live.reserve((size_t)n + 1);
+        MPG_HIP(hipStreamSynchronize(eng->stream)); // (the type bytes have left the staging buffer, which now takes the flags)
+        parallel_for(n, [=](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++)
+                hb[i] = hb[i] != 7;
+        });
+        MPG_HIP(hipMemcpyAsync(eng->s_live.p, hb, (size_t)n, hipMemcpyHostToDevice, eng->stream));
+        eng->pm_live = eng->s_live.p;
     }
     MPG_HIP(hipStreamSynchronize(eng->stream));
     eng->n = n;
@@ -1269,7 +1291,9 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     stage_particles(eng, P, eng->pm.box);
     const int64_t n = P->n;
     if(eng->resident && eng->res_base == P->base) { // results stay in HBM: GravPM assigned, Potential accumulated (gravpm.c:499-501)
-        eng->pm.force(n, eng->d_pos, eng->d_mass, nullptr, eng->r_gravpm.p, eng->r_pot.p, eng->stream, &eng->timer);
+        if(eng->pm_live) // (gravpm.c:88-92 zeroes GravPM of every particle; the readout reaches the live ones)
+            MPG_HIP(hipMemsetAsync(eng->r_gravpm.p, 0, 3 * (size_t)n * sizeof(double), eng->stream));
+        eng->pm.force(n, eng->d_pos, eng->d_mass, eng->pm_live, eng->r_gravpm.p, eng->r_pot.p, eng->stream, &eng->timer);
         mpg_err_slot().clear();
         return 0;
     }
@@ -1289,7 +1313,9 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
         });
         MPG_HIP(hipMemcpyAsync(eng->s_pot.p, hp, n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     }
-    eng->pm.force(n, eng->d_pos, eng->d_mass, nullptr, eng->s_gravpm.p, wantpot ? eng->s_pot.p : nullptr, eng->stream, &eng->timer);
+    if(eng->pm_live)
+        MPG_HIP(hipMemsetAsync(eng->s_gravpm.p, 0, 3 * (size_t)n * sizeof(double), eng->stream));
+    eng->pm.force(n, eng->d_pos, eng->d_mass, eng->pm_live, eng->s_gravpm.p, wantpot ? eng->s_pot.p : nullptr, eng->stream, &eng->timer);
     const double *dg = eng->s_gravpm.p, *dp = eng->s_pot.p;
     hipStream_t st = eng->stream;
     download_chunks(
@@ -1426,7 +1452,12 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     eng->h_d2.reserve(3 * (size_t)n + 1);
     double *ha = eng->h_d2.p, *hp = eng->h_d3.p; // (OldAcc has been uploaded: its staging buffer is free again)
     char *wb = (char *)P->base;
+    // (garbage / swallowed particles are no walk targets, treewalk.c:234: their fields stay as they are.  eng->h_b holds the live flags
+    // of the staged table whenever it has dead records: stage_particles)
+    const uint8_t *liveflag = eng->pm_live ? eng->h_b.p : nullptr;
     auto put = [=](int64_t i) {
+        if(liveflag && !liveflag[i])
+            return;
         if(AccelStore) {
             AccelStore[i][0] = ha[3 * i + 0];
             AccelStore[i][1] = ha[3 * i + 1];

@@ -128,7 +128,8 @@ struct mpg_engine {
     DevBuf<double> s_pos, s_accel, s_gravpm, s_pot, s_prev, s_old;
     DevBuf<double> w_old; // OldAcc of a walk that writes over its own opening input (mpg_dev_grav_short_tree)
     DevBuf<float> s_mass;
-    DevBuf<uint8_t> s_type;
+    DevBuf<uint8_t> s_type, s_live;
+    const uint8_t *pm_live = nullptr; // host path: 0 for garbage / swallowed particles when the staged table holds any (else null)
     DevBuf<int> s_active;
     DevBuf<unsigned> ts_flag;
     DevBuf<uint8_t> tree_incl; // particles included in an active-particle tree

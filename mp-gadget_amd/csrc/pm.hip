@@ -324,6 +324,8 @@ __global__ void __launch_bounds__(256) k_cic_readout(int64_t n, const double *__
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= n)
         return;
+    if(active && !active[i]) // garbage / swallowed: outside every region (gravpm.c:176-179), GravPM stays at the zero of gravpm.c:88-92
+        return;
     int ic[3];
     double res[3];
 #pragma unroll

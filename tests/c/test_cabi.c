@@ -451,20 +451,55 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
         CK(mpg_dist_use_decomposition(D, box, rcut, 0));
     double *acc = malloc(b3), *gpm = malloc(b3);
     if(host) {
-        /* the drop-in calls on this rank's table of 160-byte records, in run.c's order; twice (Barnes-Hut, then relative) */
-        struct particle_data *P = calloc(n_own + 1, sizeof(struct particle_data));
-        for(int64_t k = 0; k < n_own; k++) {
-            memcpy(P[k].Pos, opos + 3 * k, 3 * sizeof(double));
-            P[k].Mass = 1.0f;
-            P[k].Type = 1;
-            P[k].ID = (uint64_t)ids[k];
+        /* the drop-in calls on this rank's table of 160-byte records, in run.c's order; twice (Barnes-Hut, then relative).
+         * MPG_TEST_GARBAGE=<percent>: the table also holds that many garbage / swallowed records between the live ones (heavy, next to
+         * live particles: any leak into the mesh, a tree or a target list shows in the forces) - what P[] looks like in the sub-steps
+         * after star formation or a black-hole merger, until the next domain_decompose_full collects them.  The reference skips them
+         * in place (treewalk.c:234, forcetree.c:806, gravpm.c:176-179); the expected forces of the live particles do not change. */
+        const int gpct = getenv("MPG_TEST_GARBAGE") ? atoi(getenv("MPG_TEST_GARBAGE")) : 0;
+        const int64_t gevery = gpct > 0 ? 100 / gpct : 0;
+        const int64_t n_tab = n_own + (gevery ? n_own / gevery : 0);
+        struct particle_data *P = calloc(n_tab + 1, sizeof(struct particle_data));
+        int64_t *tab = malloc((n_own + 1) * sizeof(int64_t)); /* live particle k sits at P[tab[k]] */
+        unsigned char *dead = calloc(n_tab + 1, 1);
+        {
+            int64_t t = 0;
+            for(int64_t k = 0; k < n_own; k++) {
+                if(gevery && k % gevery == gevery - 1) {
+                    memcpy(P[t].Pos, opos + 3 * k, 3 * sizeof(double));
+                    P[t].Pos[0] += 1e-3 * box / n;
+                    P[t].Mass = 50.0f;
+                    P[t].ID = (uint64_t)(N + t);
+                    if((k / gevery) & 1) { /* a swallowed black hole (partmanager.h:33-37: Swallowed is bit 1 of the flag byte) */
+                        P[t].Type = 5;
+                        P[t].flags[0] = 2;
+                    }
+                    else { /* IsGarbage: bit 0 */
+                        P[t].Type = 1;
+                        P[t].flags[0] = 1;
+                    }
+                    P[t].GravPM[0] = 7.0; /* (must come back zeroed: gravpm.c:88-92) */
+                    P[t].FullTreeGravAccel[1] = 9.0; /* (must come back untouched) */
+                    dead[t++] = 1;
+                }
+                tab[k] = t;
+                memcpy(P[t].Pos, opos + 3 * k, 3 * sizeof(double));
+                P[t].Mass = 1.0f;
+                P[t].Type = 1;
+                P[t].ID = (uint64_t)ids[k];
+                t++;
+            }
+            if(t != n_tab) {
+                fprintf(stderr, "FAIL table construction\n");
+                exit(1);
+            }
         }
         mpg_particle_view v;
-        mpg_particle_view_reference_layout(&v, P, n_own);
-        double *prev = malloc((3 * n_own + 3) * sizeof(double));
+        mpg_particle_view_reference_layout(&v, P, n_tab);
+        double *prev = malloc((3 * n_tab + 3) * sizeof(double));
         for(int it = 0; it < 2; it++) {
-            for(int64_t k = 0; k < n_own; k++)
-                memcpy(prev + 3 * k, P[k].FullTreeGravAccel, 3 * sizeof(double));
+            for(int64_t t = 0; t < n_tab; t++)
+                memcpy(prev + 3 * t, P[t].FullTreeGravAccel, 3 * sizeof(double));
             CK(mpg_dist_gravpm_force(D, &v));
             if(it == 0) { /* gravpm.c:110-118 on several ranks: the slab sums all-reduced, the same spectrum on every rank */
                 double *kk = malloc(2 * nmesh * sizeof(double)), *pw = kk + nmesh, sp = 0;
@@ -485,20 +520,29 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
         }
         for(int64_t k = 0; k < n_own; k++)
             for(int j = 0; j < 3; j++) {
-                gpm[3 * k + j] = P[k].GravPM[j];
-                acc[3 * k + j] = P[k].FullTreeGravAccel[j];
+                gpm[3 * k + j] = P[tab[k]].GravPM[j];
+                acc[3 * k + j] = P[tab[k]].FullTreeGravAccel[j];
             }
-        /* a sub-step on the same tree: every third particle active (mpg_dist_grav_short_tree_active), P[] put back to what the second
-         * walk saw.  The active particles must get that walk's accelerations bit for bit (same tree, same OldAcc, same lists), in P[]
-         * and in AccelStore; the others keep what they had. */
+        for(int64_t t = 0; t < n_tab; t++)
+            if(dead[t] && !(P[t].GravPM[0] == 0.0 && P[t].GravPM[1] == 0.0 && P[t].FullTreeGravAccel[1] == 9.0 && P[t].FullTreeGravAccel[0] == 0.0)) {
+                fprintf(stderr, "rank %d: FAIL a garbage record was given a force (GravPM %g, accel %g %g)\n", me, P[t].GravPM[0],
+                        P[t].FullTreeGravAccel[0], P[t].FullTreeGravAccel[1]);
+                S->substep_bad = 1;
+                break;
+            }
+        /* a sub-step on the same tree: every third record active (mpg_dist_grav_short_tree_active; garbage on the list is skipped in
+         * place), P[] put back to what the second walk saw.  The active particles must get that walk's accelerations (same tree, same
+         * OldAcc, same lists), in P[] and in AccelStore; the others keep what they had. */
         {
             int64_t nact = 0, nbad = 0;
-            int *act = malloc((n_own + 1) * sizeof(int));
-            double(*store)[3] = calloc(n_own + 1, sizeof(*store));
-            for(int64_t k = 0; k < n_own; k++) {
-                memcpy(P[k].FullTreeGravAccel, prev + 3 * k, 3 * sizeof(double));
-                if(k % 3 == 0)
-                    act[nact++] = (int)k;
+            int *act = malloc((n_tab + 1) * sizeof(int));
+            double(*store)[3] = calloc(n_tab + 1, sizeof(*store));
+            double *full = malloc((3 * n_tab + 3) * sizeof(double)); /* the second walk's result per record */
+            for(int64_t t = 0; t < n_tab; t++) {
+                memcpy(full + 3 * t, P[t].FullTreeGravAccel, 3 * sizeof(double));
+                memcpy(P[t].FullTreeGravAccel, prev + 3 * t, 3 * sizeof(double));
+                if(t % 3 == 0)
+                    act[nact++] = (int)t;
             }
             CK(mpg_dist_grav_short_tree_active(D, &v, act, nact, store, 0.0));
             /* (the inactive particles keep what they had, bit for bit; the active ones get the full walk's accelerations to rounding:
@@ -507,13 +551,14 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
             double amax = 0;
             for(int64_t k = 0; k < 3 * n_own; k++)
                 amax = fmax(amax, fabs(acc[k]));
-            for(int64_t k = 0; k < n_own; k++) {
-                const double *want = (k % 3 == 0) ? acc + 3 * k : prev + 3 * k;
+            for(int64_t t = 0; t < n_tab; t++) {
+                const int walked = (t % 3 == 0) && !dead[t];
+                const double *want = walked ? full + 3 * t : prev + 3 * t;
                 for(int j = 0; j < 3; j++) {
-                    const double tol = (k % 3 == 0) ? 1e-13 * amax : 0.0;
-                    if(!(fabs(P[k].FullTreeGravAccel[j] - want[j]) <= tol))
+                    const double tol = walked ? 1e-13 * amax : 0.0;
+                    if(!(fabs(P[t].FullTreeGravAccel[j] - want[j]) <= tol))
                         nbad++;
-                    if(k % 3 == 0 ? !(fabs(store[k][j] - want[j]) <= tol) : store[k][j] != 0)
+                    if(walked ? !(fabs(store[t][j] - want[j]) <= tol) : store[t][j] != 0)
                         nbad++;
                 }
             }
@@ -523,7 +568,12 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
             }
             free(act);
             free(store);
+            free(full);
         }
+        if(gevery && me == 0)
+            printf("garbage: %lld of %lld records of rank 0 are garbage / swallowed\n", (long long)(n_tab - n_own), (long long)n_tab);
+        free(tab);
+        free(dead);
         free(prev);
         free(P);
     }

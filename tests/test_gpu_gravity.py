@@ -123,6 +123,45 @@ def test_pm_parity(pkg, engine, n, nmesh):
     assert np.abs(P["Potential"] - (pot + 0.25)).max() <= 1e-11 * np.abs(pot).mean()
 
 
+def test_host_path_skips_garbage_in_place(pkg, engine, orc):
+    """Garbage and swallowed black holes stay in P[] until the next domain_decompose_full; the reference skips them in place: not
+    deposited, no mesh force (gravpm.c:176-179: GravPM stays at the zero of gravpm.c:88-92), not in the tree (forcetree.c:806), no walk
+    targets (treewalk.c:234).  3 % heavy dead records between the live ones: the live particles get the oracle's forces of the live set
+    alone, the dead records come back with GravPM = 0 and their FullTreeGravAccel untouched."""
+    n, nmesh = 16, 32
+    pos, mass, box = pkg.ics.s_zel(n)
+    N = len(pos)
+    rng = np.random.RandomState(3)
+    dead_src = np.sort(rng.choice(N, N // 33, replace=False))
+    npos = np.insert(pos, dead_src, pos[dead_src] + 1e-3 * box / n, axis=0)
+    nmass = np.insert(mass, dead_src, np.float32(50.0))
+    is_dead = np.zeros(len(npos), bool)
+    is_dead[dead_src + np.arange(len(dead_src))] = True
+    assert np.array_equal(npos[~is_dead], pos)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    P = pkg.make_particles(npos, nmass)
+    di = np.flatnonzero(is_dead)
+    P["Flags"][di[0::2]] = 1                      # IsGarbage
+    P["Flags"][di[1::2]] = 2                      # Swallowed ...
+    P["Type"][di[1::2]] = 5                       # ... black holes
+    P["GravPM"][di] = 7.0
+    P["FullTreeGravAccel"][di] = 9.0
+    engine.set_particle_epoch(0)
+    engine.gravpm_force(P)
+    engine.force_tree_full(P, box)
+    assert engine.tree_stats().NumParticles == N
+    engine.grav_short_tree(P)
+    gpm, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = 0
+    a_ref, _, _, _ = tr.grav_short_tree(par, oldacc=np.sqrt((gpm ** 2).sum(1)) / G)
+    live = ~is_dead
+    assert np.abs(P["GravPM"][live] - gpm).max() <= 1e-11 * np.abs(gpm).mean()
+    assert_accel_parity(P["FullTreeGravAccel"][live], a_ref)
+    assert np.all(P["GravPM"][di] == 0.0) and np.all(P["FullTreeGravAccel"][di] == 9.0)
+
+
 def test_pm_linearity_and_momentum(pkg, engine):
     """Size-independent properties: the PM force is linear in the masses and conserves momentum (sum m a = 0)."""
     n, nmesh = 24, 48
