@@ -979,6 +979,101 @@ def hydro_ics(pkg, n):
     return pkg.ics.hydro_pair(n)
 
 
+def parity_check_hydro_ranks(pkg, torch, dist, args, dev, rank, world, host, box, n, PE, own_ids, o_pos, o_mass, o_typ, a, t, df, eng, nsample=2048):
+    """The multi-rank SPH step checks itself (BASELINE configs[4]: "per-step force tolerance check"; the reference's own gate is
+    check_densities, test_density.c:87-142).  One more density() + hydro_force() on the ranks from the smoothing lengths they hold;
+    rank 0 then repeats the two loops on ONE GPU over the WHOLE particle set from the same starting smoothing lengths, through the
+    single-GPU path the parity tests pin to the oracle, and compares nsample gas targets spread over the ranks: Hsml (1e-12), Density and
+    HydroAccel / DtEntropy (1e-10, for >= 99.9 % of the sample: a target whose neighbour number sits within rounding of the edge of the
+    accepted window may take one pass more or fewer), and the loop counters summed over the ranks (target visits,
+    neighbour interactions).  Untimed; collective."""
+    f8 = dict(dtype=torch.float64, device=dev)
+    n_own = int(own_ids.shape[0])
+    hs_in = a["hsml"].clone()
+    df.force_tree_build(o_pos, o_mass)
+    df.density(o_typ, a, t, DoEgyDensity=PE)
+    sd = eng.sph_stats()
+    df.hydro_force(n_own, a, t)
+    sh = eng.sph_stats()
+    c_n = torch.tensor([sd["iterations"], sd["targets"], sd["interactions"], sh["targets"], sh["interactions"]], dtype=torch.int64, device=dev)
+    it_max = c_n[:1].clone()
+    dist.all_reduce(it_max, op=dist.ReduceOp.MAX)
+    dist.all_reduce(c_n)
+    gas = torch.nonzero(o_typ == 0).squeeze(1)
+    k = max(nsample // world, 1)
+    sel = gas[torch.linspace(0, max(int(gas.shape[0]) - 1, 0), steps=min(k, int(gas.shape[0])), device=dev).long().unique()] if gas.shape[0] else gas
+    ns = int(sel.shape[0])
+    rows = torch.cat([own_ids[sel].double()[:, None], a["hsml"][sel][:, None], a["density"][sel][:, None], a["hydroacc_out"][sel],
+                      a["dtentropy_out"][sel][:, None]], dim=1) if ns else torch.zeros(0, 7, **f8)
+    pad = torch.zeros(k, 7, **f8)
+    pad[:ns] = rows
+    nmax = torch.tensor([n_own], dtype=torch.int64, device=dev)
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+    hin = torch.zeros(int(nmax.item()), 2, **f8)                     # (id, starting Hsml) of every own particle
+    hin[:n_own, 0] = own_ids.double()
+    hin[:n_own, 1] = hs_in
+    cntv = torch.tensor([ns, n_own], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(cntv) for _ in range(world)]
+    allr = [torch.zeros_like(pad) for _ in range(world)]
+    allh = [torch.zeros_like(hin) for _ in range(world)]
+    dist.all_gather(allc, cntv)
+    dist.all_gather(allr, pad)
+    dist.all_gather(allh, hin)
+    res = None
+    if rank == 0:
+        pos, mass, typ = host
+        N = len(pos)
+        got = torch.cat([allr[r][:int(allc[r][0].item())] for r in range(world)])
+        ids = got[:, 0].long()
+        h0 = torch.zeros(N, **f8)
+        for r in range(world):
+            m = int(allc[r][1].item())
+            h0[allh[r][:m, 0].long()] = allh[r][:m, 1]
+        del allh
+        e1 = pkg.Engine(dev.index or 0)
+        e1.use_torch_stream()
+        e1.gravshort_fill_ntab(0, 1.5)
+        e1.gravpm_init_periodic(box, 1.5, 2 * n, G)
+        e1.gravshort_set_softenings(box / n)
+        e1.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+        e1.set_hydropar(PE, 100.0, 0.75)
+        p1, m1, t1 = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
+        e1.dev_bind_particles(p1, m1, box, type=t1)
+        z1, z3 = (lambda: torch.zeros(N, **f8)), (lambda: torch.zeros(N, 3, **f8))
+        a1 = dict(hsml=h0, dthsml=z1(), vel=z3(), entropy=torch.ones(N, **f8), density=z1(), egywtdensity=z1(), dhsmlegyfac=z1(), divvel=z1(),
+                  curlvel=z1(), hydroacc_out=z3(), dtentropy_out=z1(), maxsignalvel=z1())
+        e1.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+        e1.dev_density(a1, t, DoEgyDensity=PE)
+        s1d = e1.sph_stats()
+        e1.dev_force_tree_calc_hmax()
+        e1.dev_hydro_force(a1, t)
+        s1h = e1.sph_stats()
+        torch.cuda.synchronize()
+        rel = lambda x, y, sc: ((x - y).abs() / sc) if x.dim() == 1 else ((x - y).norm(dim=1) / sc)
+        d_h = rel(a1["hsml"][ids], got[:, 1], a1["hsml"][ids])
+        d_rho = rel(a1["density"][ids], got[:, 2], a1["density"][ids])
+        d_acc = rel(a1["hydroacc_out"][ids], got[:, 3:6], a1["hydroacc_out"][ids].norm(dim=1).mean().clamp_min(1e-300))
+        d_dte = rel(a1["dtentropy_out"][ids], got[:, 6], a1["dtentropy_out"][ids].abs().mean().clamp_min(1e-300))
+        frac = lambda d, tol: float((d <= tol).double().mean())
+        cn = [int(x) for x in c_n.cpu()]
+        c1 = [s1d["targets"], s1d["interactions"], s1h["targets"], s1h["interactions"]]
+        close = lambda x, y: abs(x - y) <= 1e-5 * max(abs(y), 1)
+        res = {"n": int(ids.shape[0]), "hsml_frac_within_1e-12": frac(d_h, 1e-12), "hsml_max_rel": float(d_h.max()),
+               "density_frac_within_1e-10": frac(d_rho, 1e-10), "hydroaccel_frac_within_1e-10": frac(d_acc, 1e-10),
+               "dtentropy_frac_within_1e-10": frac(d_dte, 1e-10), "density_passes_ranks_max": int(it_max.item()), "density_passes_one_gpu": s1d["iterations"],
+               "counters_ranks": cn[1:], "counters_one_gpu": c1, "counters_equal": cn[1:] == c1,
+               "counters": "[density target visits, density neighbours, hydro targets, hydro pairs], summed over the ranks",
+               "gate": "Hsml within 1e-12, Density / HydroAccel / DtEntropy within 1e-10 for >= 99.9 % of the sample, Hsml of every sampled "
+                       "target within the reference's bound (1e-3, test_density.c:203), counters within 1e-5 of the one-GPU loops'",
+               "reference": "the same gas targets recomputed on one GPU from all %d particles and the same starting smoothing lengths through the "
+                            "single-GPU loops (pinned to the oracle by tests/test_gpu_sph.py)" % N}
+        res["ok"] = bool(res["hsml_frac_within_1e-12"] >= 0.999 and res["density_frac_within_1e-10"] >= 0.999 and
+                         res["hydroaccel_frac_within_1e-10"] >= 0.999 and res["dtentropy_frac_within_1e-10"] >= 0.999 and res["hsml_max_rel"] <= 1e-3 and
+                         all(close(x, y) for x, y in zip(cn[1:], c1)))
+        e1.close()
+    return res
+
+
 def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
     """configs[2] / [4] weak-scaled over GPUs on the reference's decomposition, everything through the library's choreography
     (mpg_dist_*, csrc/dist.hip): domain_decompose_full + exchange (untimed), then per step gravity (PM by particle shipping, ghost
@@ -1005,8 +1100,10 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a[share])).to(dev)
     s_pos = T(pos)
     df.domain_decompose(s_pos, box, overdecomposition=args.overdecomp)
-    o_pos, o_mass, o_typ = df.domain_exchange(s_pos, T(mass), T(typ))
+    o_pos, o_mass, o_typ, own_ids = df.domain_exchange(s_pos, T(mass), T(typ), torch.arange(N, dtype=torch.int64, device=dev)[share].contiguous())
     n_own = int(o_pos.shape[0])
+    host = (pos, mass, typ) if (rank == 0 and not args.no_parity_check) else None
+    del pos
     df.use_decomposition(box, max(6.0 * 1.5 * box / nmesh, 6.0 * box / n))       # margin: Rcut and the largest smoothing length
     z1, z3 = (lambda: torch.zeros(n_own, **f8)), (lambda: torch.zeros(n_own, 3, **f8))
     a = dict(hsml=torch.full((n_own,), 2.0 * box / n, **f8), dthsml=z1(), vel=z3(), entropy=torch.ones(n_own, **f8), density=z1(), egywtdensity=z1(),
@@ -1041,6 +1138,9 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
     dt = torch.tensor([time.perf_counter() - t0], **f8)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     el = float(dt.item())
+    parity = None
+    if not args.no_parity_check:
+        parity = parity_check_hydro_ranks(pkg, torch, dist, args, dev, rank, world, host, box, n, PE, own_ids, o_pos, o_mass, o_typ, a, t, df, eng)
     out = None
     if rank == 0:
         st = df.stats()
@@ -1059,7 +1159,12 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
         comm.close()
     eng.close()
     if out is not None:
+        if parity is not None:
+            out["parity_check"] = parity
         emit(out)
+        if parity is not None and not parity["ok"]:
+            print("bench.py: the multi-rank SPH loops FAILED the self-check against the one-GPU path: %s" % json.dumps(parity), file=sys.stderr, flush=True)
+            sys.exit(3)
     return out
 
 

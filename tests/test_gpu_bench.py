@@ -132,6 +132,25 @@ def test_c5_shape_through_rccl_at_full_per_gpu_size():
                   env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29872"})
     assert KEYS - {"roofline"} <= set(j) and j["config"]["particles"] == 2 * 128 ** 3 and "pressure-entropy" in j["config"]["workload"]
     assert j["value"] > 5e6
+    pc = j["parity_check"]        # the line checks its own SPH results against the one-GPU loops (configs[4]: "per-step force tolerance check")
+    assert pc["ok"] and pc["n"] >= 1024 and pc["hsml_frac_within_1e-12"] >= 0.999 and pc["hydroaccel_frac_within_1e-10"] >= 0.999, pc
+
+
+@pytest.mark.parametrize("sph", ["pe", "de"])
+def test_multi_gpu_hydro_parity_check_on_four_ranks(sph):
+    """bench.py --workload hydro --gpus 4 (gloo ranks sharing this GPU): after the timed steps the ranks' density() + hydro_force() are
+    repeated on ONE GPU over the whole set from the same starting smoothing lengths and sampled gas targets compared (Hsml 1e-12,
+    Density / HydroAccel / DtEntropy 1e-10, loop counters); a failed check exits with code 3.  Both SPH formulations."""
+    env = dict(os.environ, MPG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port",
+           "29875" if sph == "pe" else "29876", os.path.join(ROOT, "bench.py"), "--workload", "hydro", "--gpus", "4", "--size", "32", "--sph", sph,
+           "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    pc = j["parity_check"]
+    assert pc["ok"] and pc["n"] >= 1500 and pc["hsml_max_rel"] <= 1e-3, pc
+    assert pc["counters_equal"] or all(abs(x - y) <= 1e-5 * y for x, y in zip(pc["counters_ranks"], pc["counters_one_gpu"])), pc
 
 
 def test_peano_domains_balance_the_walk_work_on_the_clustered_set():
