@@ -258,6 +258,9 @@ int mpg_dev_density(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_time
                     int update_hsml, int DoEgyDensity, int BlackHoleOn);
 /* force_tree_calc_moments after density (run.c:477): propagates the leaf hmax of the final Hsml up the gas tree */
 int mpg_dev_force_tree_calc_hmax(mpg_engine *eng);
+/* force_update_hmax (forcetree.h:113, forcetree.c:1290-1340): the hmax moments of the current (gas) tree from the smoothing lengths in
+ * d_hsml[n] (caller order; only gas and black holes count), without a density loop before it (test_forcetree.c:257-292) */
+int mpg_dev_force_update_hmax(mpg_engine *eng, const double *d_hsml);
 /* hydro_force, libgadget/hydra.c:153-245 (needs density() and the hmax moments of the same tree) */
 int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive);
 /* Host-pointer forms of the four calls above: `P` supplies Pos / Mass / Type / flags (the reference AoS table), `A` holds HOST

@@ -1849,6 +1849,20 @@ int mpg_dev_force_tree_calc_hmax(mpg_engine *eng)
     API_END
 }
 
+int mpg_dev_force_update_hmax(mpg_engine *eng, const double *d_hsml)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_hsml && eng->tree_allocated, "force_update_hmax: no tree or no Hsml");
+    MPG_HIP(hipSetDevice(eng->device));
+    SphView v{};
+    v.type = eng->d_type;
+    v.hsml = const_cast<double *>(d_hsml);
+    eng->sph.hsml_view = v;
+    eng->sph.hmax_pending = true;
+    eng->sph.calc_hmax(eng->tree, eng->stream);
+    API_END
+}
+
 int mpg_dev_hydro_force(mpg_engine *eng, const mpg_sph_arrays *A, const mpg_sph_times *T, const int *d_active, int64_t nactive)
 {
     API_BEGIN

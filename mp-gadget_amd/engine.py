@@ -596,8 +596,14 @@ class Engine:
         self._ck(self.lib.mpg_dev_density(self.h, C.byref(a), C.byref(times), _ptr(active), C.c_int64(nact), int(update_hsml),
                                           int(DoEgyDensity), int(BlackHoleOn)))
 
-    def dev_force_tree_calc_hmax(self):
-        self._ck(self.lib.mpg_dev_force_tree_calc_hmax(self.h))
+    def dev_force_tree_calc_hmax(self, hsml=None):
+        """hmax moments of the gas tree: from the arrays of the last density() (run.c:477), or - force_update_hmax - from `hsml`"""
+        if hsml is None:
+            self._ck(self.lib.mpg_dev_force_tree_calc_hmax(self.h))
+        else:
+            self._keep["hmax_hsml"] = hsml
+            self.lib.mpg_dev_force_update_hmax.argtypes = [C.c_void_p, C.c_void_p]
+            self._ck(self.lib.mpg_dev_force_update_hmax(self.h, C.c_void_p(hsml.data_ptr())))
 
     def dev_hydro_force(self, arrays, times, active=None):
         a = self._sph_arrays(arrays)

@@ -116,6 +116,67 @@ def test_reference_density_known_answer_on_gpu(pkg, orc, kind, dev, tol):
     gas &= same
     assert rel(a["density"].cpu().numpy()[gas], A.density[gas]) <= 1e-10
     assert rel(a["dhsmlegyfac"].cpu().numpy()[gas], A.dhsmlegyfac[gas]) <= 1e-10
+    # check_densities (test_density.c:35-53) and the reference's stability gate (test_density.c:126-147): with MaxNumNgbDeviation made
+    # 0.5 a second density() on the same tree must leave every Hsml within MaxNumNgbDeviation / DesNumNgb of the first
+    assert np.all(np.isfinite(h)) and h.min() >= 0.006 and h.max() <= box
+    d1 = a["density"].cpu().numpy()[typ == 0]
+    assert np.all(np.isfinite(d1)) and np.all(d1 > 0)
+    eng.set_densitypar(1.0, 0.5, 2.0, 99999., pkg.engine.DENSITY_KERNEL_CUBIC_SPLINE, 0.006)
+    eng.dev_density(a, t)
+    eng.synchronize()
+    h2 = a["hsml"].cpu().numpy()
+    assert np.abs(h / h2 - 1).max() < 0.5 / (4.188790204786 * 8.0)
+    eng.close()
+
+
+def test_reference_gas_tree_hmax_known_answer_on_gpu(pkg, orc):
+    """test_forcetree.c:257-292,325 (do_tree_mask_hmax_update_test on the 128^3 lattice in a box of 8): gas with Hsml = Box / 128 x a
+    uniform deviate, force_update_hmax, then check_hmax - every particle lies inside every node above it and pokes beyond no such node's
+    faces by more than that node's hmax - and the known answer `root hmax >= 0.0584` (the largest excess of Pos + Hsml over the faces of a
+    particle's leaf, carried up the tree; < 1/16 = the largest Hsml).  The deviates are gsl_rng_mt19937's (oracle/mt19937.py; the
+    reference draws from its RandTable: any uniform set gives the bound).  GPU tree against the same checks and against the oracle's root."""
+    import torch
+    from oracle.mt19937 import GslMT19937
+    n, box = 128, 8.0
+    N = n ** 3
+    i = np.arange(N)
+    pos = np.stack([(box / n) * (i // n // n), (box / n) * ((i // n) % n), (box / n) * (i % n)], axis=1).astype(np.float64)
+    rng = GslMT19937(23)
+    hsml = (box / n) * rng.uniform(N)
+    mass = np.ones(N, np.float32)
+    typ = np.zeros(N, np.uint8)
+    eng = pkg.Engine(0)
+    a, keep = gpu_arrays(torch, pos, mass, typ, hsml, np.zeros((N, 3)), np.ones(N))
+    eng.dev_bind_particles(keep["pos"], keep["mass"], box, type=keep["type"])
+    eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+    eng.dev_force_tree_calc_hmax(hsml=a["hsml"])
+    eng.synchronize()
+    st = eng.tree_stats()
+    assert st.NumParticles == N
+    assert 0.0584 <= st.root_hmax < box / n
+    ex = eng.tree_export()
+    order = ex["order"]
+    # check_hmax: walk from every leaf up to the root
+    nn = len(ex["level"])
+    father = np.full(nn, -1, np.int64)
+    stack = []
+    for j in range(nn):                                  # depth-first pre-order: the father is the last node of a lower level
+        while stack and ex["level"][stack[-1]] >= ex["level"][j]:
+            stack.pop()
+        father[j] = stack[-1] if stack else -1
+        stack.append(j)
+    leaf = np.flatnonzero(ex["pcount"] > 0)
+    node_of = np.empty(N, np.int64)
+    for j in leaf[:: max(len(leaf) // 20000, 1)]:        # a sample of the leaves (all particles of each)
+        p = order[ex["pstart"][j]:ex["pstart"][j] + ex["pcount"][j]]
+        k = j
+        while k >= 0:
+            d = np.abs(pos[p] - ex["center"][k])
+            assert np.all(d <= ex["len"][k] / 2)
+            assert np.all((d + hsml[p, None] - ex["len"][k] / 2).max(1) <= ex["hmax"][k] + 1e-5) and ex["hmax"][k] >= 0
+            k = father[k]
+    tr = orc.tree(pos, mass, box, type=typ, hsml=hsml, mask=1, moments=True)
+    assert abs(st.root_hmax / tr.export()["hmax"][0] - 1) <= 1e-13
     eng.close()
 
 

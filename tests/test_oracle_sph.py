@@ -108,6 +108,25 @@ def test_reference_mean_hsml_known_answer(orc, kind, expected, tol):
     assert np.abs(h1 / A.hsml - 1).max() < 0.5 / desnumngb
 
 
+def test_reference_root_hmax_known_answer(orc):
+    """test_forcetree.c:257-292,325: the gas tree of the 128^3 lattice in a box of 8 with Hsml = Box / 128 x a uniform deviate must have
+    `root hmax >= 0.0584`.  A node's hmax is the largest amount by which Pos + Hsml of a particle pokes beyond the faces of its LEAF
+    (forcetree.c:947-966, 1290-1316), carried up unchanged (forcetree.c:1051-1052): a particle within 0.004 of a leaf face with a deviate
+    near 1 gives 1/16 - 0.004, and no particle can give more than its Hsml < 1/16.  (The deviates here are gsl_rng_mt19937's; the
+    reference draws from its RandTable: with 2 M particles any uniform set gives the bound.)  Pins the hmax definition of the restatement
+    to the reference's own number within 7 %."""
+    from oracle.mt19937 import GslMT19937
+    n, box = 128, 8.0
+    N = n ** 3
+    i = np.arange(N)
+    pos = np.stack([(box / n) * (i // n // n), (box / n) * ((i // n) % n), (box / n) * (i % n)], axis=1).astype(np.float64)
+    hsml = (box / n) * GslMT19937(23).uniform(N)
+    # (no hydro-active flags: every particle's excess enters at the build, which is what force_update_hmax does for all of them)
+    tr = orc.tree(pos, np.ones(N, np.float32), box, type=np.zeros(N, np.uint8), hsml=hsml, mask=1, moments=True)
+    h = tr.export()["hmax"][0]
+    assert 0.0584 <= h < box / n, h
+
+
 def test_hydro_momentum_conservation(pkg, orc):
     """hydra.c has no known answer in the reference's tests.  The pair force of hydro_ngbiter is antisymmetric under
     i <-> j when both are active with the same time bin, so sum_i m_i a_i vanishes to round-off."""
