@@ -226,114 +226,13 @@ __device__ __forceinline__ int cbuf_push(int *cbuf, const int head, int cnt, con
     return cnt + __popc(gm);
 }
 
-// One density pass over the current queue: treewalk_visit_nolist_ngbiter + density_ngbiter + density_reduce +
-// density_postprocess + density_check_neighbours.  Targets that are not done are appended to `redo`.
-__global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_density_params P,
-                                                 const DensityCtl C, const Aux4 *__restrict__ aux, const int *__restrict__ queue,
-                                                 int64_t nqueue, int *__restrict__ redo, unsigned *__restrict__ nredo,
-                                                 unsigned long long *__restrict__ stats, unsigned *__restrict__ err)
+// The end of a density pass for one target (the 8 lanes of its group hold partial sums): density_reduce + density_postprocess +
+// density_check_neighbours (density.c:374-409, 532-689), the append of an unfinished target to `redo`, the pass statistics.
+__device__ __forceinline__ void density_finish(const TreeView &tv, const SphView &A, const mpg_density_params &P, const DensityCtl &C, DensAcc &a,
+                                               const bool valid, const int s, const int lane, const int i, const int ty, const double hsml,
+                                               int *__restrict__ redo, unsigned *__restrict__ nredo, unsigned long long *__restrict__ stats,
+                                               const unsigned n_int, const unsigned n_cand)
 {
-    __shared__ unsigned s_stack[4 * 8 * SPH_STK];
-    __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
-    __shared__ unsigned s_llist[4 * 8 * SPH_LCAP];
-    const int lane = threadIdx.x & 63;
-    const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
-    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
-    int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
-    unsigned *llist = s_llist + ((threadIdx.x >> 6) * 8 + grp) * SPH_LCAP;
-    int cnt = 0, head = 0; // survivors waiting in the group's ring buffer, its first slot (group-uniform)
-    const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
-    const bool valid = q < nqueue;
-    unsigned n_int = 0, n_cand = 0;
-    int i = 0, ty = 0;
-    double px = 0, py = 0, pz = 0, hsml = 0;
-    double ivel[3] = {0, 0, 0};
-    if(valid) {
-        i = queue[q];
-        ty = A.type ? (A.type[i] & 7) : 0;
-        px = A.pos[3 * (int64_t)i];
-        py = A.pos[3 * (int64_t)i + 1];
-        pz = A.pos[3 * (int64_t)i + 2];
-        if(ty != 0) { // density_copy, density.c:357-372
-            ivel[0] = A.vel[3 * (int64_t)i];
-            ivel[1] = A.vel[3 * (int64_t)i + 1];
-            ivel[2] = A.vel[3 * (int64_t)i + 2];
-        }
-        else
-            vel_pred(A, T, i, ivel);
-        hsml = A.hsml[i];
-    }
-    const DKernel kern = kernel_init(valid ? hsml : 1.0, C.ktype);
-    const double kvol = NORM_COEFF * p3(kern.H);
-    const double h2 = hsml * hsml;
-    DensAcc a;
-    int sp = 0;
-    if(valid) {
-        if(s == 0)
-            stack[0] = (0u << 4) | 1u; // the root
-        sp = 1;
-    }
-    bool overflow = false;
-    for(;;) {
-        // ---- phase A: walk; opened leaves go to the group's list
-        int nl = 0;
-        for(;;) {
-            const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
-            if(ballot64(go) == 0)
-                break;
-            nl = walk_stepk<false, SPH_WALK_K>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
-            if(ballot64(overflow) != 0)
-                break;
-        }
-        if(ballot64(overflow) != 0)
-            break;
-        // ---- phase B: every group takes its next leaf; lane s <-> particle s
-        // (the candidate of the NEXT leaf is requested before this one is tested: an iteration is a dependent LDS read -> gather -> test ->
-        // LDS append chain, and 4 waves per SIMD do not hide the gather's latency.  Lanes beyond the leaf's count read its first particle.)
-        unsigned e = (0 < nl) ? llist[0] : 0u;
-        int ps = (int)(e >> 4), pc = (int)(e & 15u);
-        Src4 cand = tv.src[ps + (s < pc ? s : 0)];
-        for(int it = 0;; it++) {
-            const bool has = it < nl;
-            if(ballot64(has) == 0)
-                break;
-            const unsigned e_n = (it + 1 < nl) ? llist[it + 1] : 0u;
-            const int ps_n = (int)(e_n >> 4), pc_n = (int)(e_n & 15u);
-            const Src4 cand_n = tv.src[ps_n + (s < pc_n ? s : 0)];
-            bool keep = false;
-            if(s < pc) {
-                n_cand++;
-                keep = density_test(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
-            }
-            cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
-            if(ballot64(cnt >= 16) != 0) {
-                if(cnt >= 8) {
-                    const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
-                    density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
-                    head = (head + 8) & (SPH_CBUF - 1);
-                    cnt -= 8;
-                }
-            }
-            cand = cand_n;
-            ps = ps_n;
-            pc = pc_n;
-        }
-        if(ballot64(sp > 0) == 0)
-            break;
-    }
-    if(ballot64(overflow) != 0) {
-        if(lane == 0)
-            atomicExch(err, 1u);
-        return;
-    }
-    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
-        if(s < cnt) {
-            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
-            density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
-        }
-        head = (head + 8) & (SPH_CBUF - 1);
-        cnt = cnt > 8 ? cnt - 8 : 0;
-    }
     // sum over the 8 lanes of the group
     a.EgyRho = group_sum(a.EgyRho);
     a.DhsmlEgy = group_sum(a.DhsmlEgy);
@@ -465,6 +364,117 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         atomicAdd(&stats[0], c_int);
         atomicAdd(&stats[1], c_cand);
     }
+}
+
+// One density pass over the current queue: treewalk_visit_nolist_ngbiter + density_ngbiter + density_reduce +
+// density_postprocess + density_check_neighbours.  Targets that are not done are appended to `redo`.
+__global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_density_params P,
+                                                 const DensityCtl C, const Aux4 *__restrict__ aux, const int *__restrict__ queue,
+                                                 int64_t nqueue, int *__restrict__ redo, unsigned *__restrict__ nredo,
+                                                 unsigned long long *__restrict__ stats, unsigned *__restrict__ err)
+{
+    __shared__ unsigned s_stack[4 * 8 * SPH_STK];
+    __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
+    __shared__ unsigned s_llist[4 * 8 * SPH_LCAP];
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
+    unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
+    int *cbuf = s_cbuf + ((threadIdx.x >> 6) * 8 + grp) * SPH_CBUF;
+    unsigned *llist = s_llist + ((threadIdx.x >> 6) * 8 + grp) * SPH_LCAP;
+    int cnt = 0, head = 0; // survivors waiting in the group's ring buffer, its first slot (group-uniform)
+    const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + grp;
+    const bool valid = q < nqueue;
+    unsigned n_int = 0, n_cand = 0;
+    int i = 0, ty = 0;
+    double px = 0, py = 0, pz = 0, hsml = 0;
+    double ivel[3] = {0, 0, 0};
+    if(valid) {
+        i = queue[q];
+        ty = A.type ? (A.type[i] & 7) : 0;
+        px = A.pos[3 * (int64_t)i];
+        py = A.pos[3 * (int64_t)i + 1];
+        pz = A.pos[3 * (int64_t)i + 2];
+        if(ty != 0) { // density_copy, density.c:357-372
+            ivel[0] = A.vel[3 * (int64_t)i];
+            ivel[1] = A.vel[3 * (int64_t)i + 1];
+            ivel[2] = A.vel[3 * (int64_t)i + 2];
+        }
+        else
+            vel_pred(A, T, i, ivel);
+        hsml = A.hsml[i];
+    }
+    const DKernel kern = kernel_init(valid ? hsml : 1.0, C.ktype);
+    const double kvol = NORM_COEFF * p3(kern.H);
+    const double h2 = hsml * hsml;
+    DensAcc a;
+    int sp = 0;
+    if(valid) {
+        if(s == 0)
+            stack[0] = (0u << 4) | 1u; // the root
+        sp = 1;
+    }
+    bool overflow = false;
+    for(;;) {
+        // ---- phase A: walk; opened leaves go to the group's list
+        int nl = 0;
+        for(;;) {
+            const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
+            if(ballot64(go) == 0)
+                break;
+            nl = walk_stepk<false, SPH_WALK_K>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
+            if(ballot64(overflow) != 0)
+                break;
+        }
+        if(ballot64(overflow) != 0)
+            break;
+        // ---- phase B: every group takes its next leaf; lane s <-> particle s
+        // (the candidate of the NEXT leaf is requested before this one is tested: an iteration is a dependent LDS read -> gather -> test ->
+        // LDS append chain, and 4 waves per SIMD do not hide the gather's latency.  Lanes beyond the leaf's count read its first particle.)
+        unsigned e = (0 < nl) ? llist[0] : 0u;
+        int ps = (int)(e >> 4), pc = (int)(e & 15u);
+        Src4 cand = tv.src[ps + (s < pc ? s : 0)];
+        for(int it = 0;; it++) {
+            const bool has = it < nl;
+            if(ballot64(has) == 0)
+                break;
+            const unsigned e_n = (it + 1 < nl) ? llist[it + 1] : 0u;
+            const int ps_n = (int)(e_n >> 4), pc_n = (int)(e_n & 15u);
+            const Src4 cand_n = tv.src[ps_n + (s < pc_n ? s : 0)];
+            bool keep = false;
+            if(s < pc) {
+                n_cand++;
+                keep = density_test(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
+            }
+            cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
+            if(ballot64(cnt >= 16) != 0) {
+                if(cnt >= 8) {
+                    const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
+                    density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
+                    head = (head + 8) & (SPH_CBUF - 1);
+                    cnt -= 8;
+                }
+            }
+            cand = cand_n;
+            ps = ps_n;
+            pc = pc_n;
+        }
+        if(ballot64(sp > 0) == 0)
+            break;
+    }
+    if(ballot64(overflow) != 0) {
+        if(lane == 0)
+            atomicExch(err, 1u);
+        return;
+    }
+    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
+        if(s < cnt) {
+            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
+            density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
+        }
+        head = (head + 8) & (SPH_CBUF - 1);
+        cnt = cnt > 8 ? cnt - 8 : 0;
+    }
+    density_finish(tv, A, P, C, a, valid, s, lane, i, ty, hsml, redo, nredo, stats, n_int, n_cand);
 }
 
 // marks the active particles (caller indices) in a byte map
@@ -710,6 +720,36 @@ __device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, cons
     a.DtEntropy += 0.5 * hfc_visc * vdotr2;
 }
 
+// The end of the hydro loop for one target: hydro_reduce (assign) + hydro_postprocess (hydra.c:279-294, 514-528) and the statistics.
+__device__ __forceinline__ void hydro_finish(const SphView &A, const HydroCtl &C, HydroAcc &a, const HydroTarget &t, const bool valid, const int s,
+                                             const int lane, const int i, unsigned long long *__restrict__ stats, const unsigned n_cand,
+                                             const unsigned n_pair)
+{
+    a.Acc0 = group_sum(a.Acc0);
+    a.Acc1 = group_sum(a.Acc1);
+    a.Acc2 = group_sum(a.Acc2);
+    a.DtEntropy = group_sum(a.DtEntropy);
+    for(int off = 1; off < 8; off <<= 1)
+        a.MaxSignalVel = fmax(a.MaxSignalVel, __shfl_xor(a.MaxSignalVel, off));
+    if(valid && s == 0) {
+        // hydro_reduce (assign) + hydro_postprocess, hydra.c:279-294, 514-528
+        A.hydroacc_out[3 * (int64_t)i] = a.Acc0;
+        A.hydroacc_out[3 * (int64_t)i + 1] = a.Acc1;
+        A.hydroacc_out[3 * (int64_t)i + 2] = a.Acc2;
+        A.maxsignalvel[i] = a.MaxSignalVel;
+        A.dtentropy_out[i] = a.DtEntropy * (SPH_GAMMA_MINUS1 / (C.hubble_a2 * pow(t.IDensity, SPH_GAMMA_MINUS1)));
+    }
+    unsigned long long c_cand = n_cand, c_pair = n_pair;
+    for(int off = 32; off > 0; off >>= 1) {
+        c_cand += __shfl_down(c_cand, off);
+        c_pair += __shfl_down(c_pair, off);
+    }
+    if(lane == 0 && stats) {
+        atomicAdd(&stats[0], c_cand);
+        atomicAdd(&stats[1], c_pair);
+    }
+}
+
 // hydro_force loop: group-cooperative walk with the symmetric cull (see k_density)
 __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_hydro_params HP,
                                                const HydroCtl C, const HydroSrc *__restrict__ hs, const double *__restrict__ hsml_t,
@@ -829,29 +869,7 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
         head = (head + 8) & (SPH_CBUF - 1);
         cnt = cnt > 8 ? cnt - 8 : 0;
     }
-    a.Acc0 = group_sum(a.Acc0);
-    a.Acc1 = group_sum(a.Acc1);
-    a.Acc2 = group_sum(a.Acc2);
-    a.DtEntropy = group_sum(a.DtEntropy);
-    for(int off = 1; off < 8; off <<= 1)
-        a.MaxSignalVel = fmax(a.MaxSignalVel, __shfl_xor(a.MaxSignalVel, off));
-    if(valid && s == 0) {
-        // hydro_reduce (assign) + hydro_postprocess, hydra.c:279-294, 514-528
-        A.hydroacc_out[3 * (int64_t)i] = a.Acc0;
-        A.hydroacc_out[3 * (int64_t)i + 1] = a.Acc1;
-        A.hydroacc_out[3 * (int64_t)i + 2] = a.Acc2;
-        A.maxsignalvel[i] = a.MaxSignalVel;
-        A.dtentropy_out[i] = a.DtEntropy * (SPH_GAMMA_MINUS1 / (C.hubble_a2 * pow(t.IDensity, SPH_GAMMA_MINUS1)));
-    }
-    unsigned long long c_cand = n_cand, c_pair = n_pair;
-    for(int off = 32; off > 0; off >>= 1) {
-        c_cand += __shfl_down(c_cand, off);
-        c_pair += __shfl_down(c_pair, off);
-    }
-    if(lane == 0 && stats) {
-        atomicAdd(&stats[0], c_cand);
-        atomicAdd(&stats[1], c_pair);
-    }
+    hydro_finish(A, C, a, t, valid, s, lane, i, stats, n_cand, n_pair);
 }
 
 __global__ void __launch_bounds__(256) k_slot_of(int64_t npart, const int *__restrict__ order, int *__restrict__ slot_of)
