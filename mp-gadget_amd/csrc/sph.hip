@@ -116,6 +116,24 @@ __device__ __forceinline__ double kernel_dwk(const DKernel &k, int type, double 
     return k.dWknorm * (type == 0 ? dwk_q<0>(q) : (type == 1 ? dwk_q<1>(q) : dwk_q<2>(q)));
 }
 
+#ifndef SPH_EXACT_DIV
+#define SPH_FAST_DIV // round 4: the quotients and the square root of the pair evaluations by reciprocals (k_hydro 10.1 -> 9.6 ms)
+#endif
+// 1 / x and 1 / sqrt(x) to within an ulp: v_rcp_f64 / v_rsq_f64 and Newton steps instead of the ~30-instruction IEEE division and
+// square-root expansions (the reference itself is built with -ffast-math).  x > 0 and finite.
+__device__ __forceinline__ double rcp_fast(const double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ double rsqrt_fast(const double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
 // SPH_VelPred, density.c:91-100
 __device__ __forceinline__ void vel_pred(const SphView &A, const mpg_sph_times &T, int64_t i, double v[3])
 {
@@ -190,7 +208,12 @@ __device__ __forceinline__ void density_eval(const Src4 s, const Aux4 o, const d
     const double d1 = nearest_img(py - s.y, box, 1.0 / box);
     const double d2 = nearest_img(pz - s.z, box, 1.0 / box);
     const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
+#ifdef SPH_FAST_DIV
+    const double rinv_d = r2 > 0 ? rsqrt_fast(r2) : 0.0;
+    const double r = r2 * rinv_d;
+#else
     const double r = sqrt(r2);
+#endif
     const double u = r * kern.Hinv;
     const double wk = kernel_wk(kern, C.ktype, u);
     a.Ngb += wk * kvol;
@@ -204,7 +227,11 @@ __device__ __forceinline__ void density_eval(const Src4 s, const Aux4 o, const d
         a.DhsmlEgy += mass_j * o.w * density_dW;
     }
     if(r > 0) {
+#ifdef SPH_FAST_DIV
+        const double fac = mass_j * dwk * rinv_d;
+#else
         const double fac = mass_j * dwk / r;
+#endif
         const double dv0 = ivel[0] - o.x, dv1 = ivel[1] - o.y, dv2 = ivel[2] - o.z;
         a.Div += -fac * (d0 * dv0 + d1 * dv1 + d2 * dv2);
         a.Rot0 += fac * (dv1 * d2 - d1 * dv2); // crossproduct(dv, dist), densitykernel.h:63-76
@@ -671,9 +698,31 @@ __device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, cons
     const double d1 = nearest_img(t.py - s.y, box, 1.0 / box);
     const double d2 = nearest_img(t.pz - s.z, box, 1.0 / box);
     const double rsq = d0 * d0 + d1 * d1 + d2 * d2;
+#ifdef SPH_FAST_DIV
+    // (rsq > 0: hydro_test; the quotients of this function by reciprocals - see rcp_fast)
+    const double rinv = rsqrt_fast(rsq);
+    const double r = rsq * rinv;
+    DKernel kernel_j;
+    kernel_j.H = o.hsml;
+    kernel_j.HH = o.hsml * o.hsml;
+    kernel_j.Hinv = rcp_fast(o.hsml);
+    kernel_j.support = ksupport(C.ktype);
+    {
+        const double hinv = kernel_j.Hinv * kernel_j.support;
+        kernel_j.Wknorm = ksigma3(C.ktype) * p3(hinv);
+        kernel_j.dWknorm = kernel_j.Wknorm * hinv;
+    }
+    const double inv_eom_j = rcp_fast(o.eomdensity);
+    const double p_over_rho2_j = o.pressure * inv_eom_j * inv_eom_j;
+#define SPH_DIV_R(x) ((x) * rinv)
+#define SPH_DIV(x, y) ((x) * rcp_fast(y))
+#else
     const DKernel kernel_j = kernel_init(o.hsml, C.ktype);
     const double r = sqrt(rsq);
     const double p_over_rho2_j = o.pressure / (o.eomdensity * o.eomdensity);
+#define SPH_DIV_R(x) ((x) / r)
+#define SPH_DIV(x, y) ((x) / (y))
+#endif
     const double soundspeed_j = o.soundspeed;
     const double vsig = t.soundspeed_i + soundspeed_j;
     if(vsig > a.MaxSignalVel)
@@ -685,35 +734,35 @@ __device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, cons
     const double dwk_j = kernel_dwk(kernel_j, C.ktype, r * kernel_j.Hinv);
     double visc = 0;
     if(vdotr2 < 0) { // Gadget-2 eqs. 13-14, hydra.c:435-462
-        const double mu_ij = C.fac_mu * vdotr2 / r;
+        const double mu_ij = SPH_DIV_R(C.fac_mu * vdotr2);
         const double rho_ij = 0.5 * (t.IDensity + o.density);
         double vs = t.soundspeed_i + soundspeed_j;
         vs -= 3 * mu_ij;
         if(vs > a.MaxSignalVel)
             a.MaxSignalVel = vs;
-        visc = 0.25 * HP.ArtBulkViscConst * vs * (-mu_ij) / rho_ij * (t.IF1 + o.f2);
+        visc = SPH_DIV(0.25 * HP.ArtBulkViscConst * vs * (-mu_ij), rho_ij) * (t.IF1 + o.f2);
         const double dloga = 2 * fmax(me.dloga, o.dloga);
         if(dloga > 0 && (dwk_i + dwk_j) < 0) {
             if((t.IMass + s.m) > 0)
-                visc = fmin(visc, 0.5 * C.fac_vsic_fix * vdotr2 / (0.5 * (t.IMass + s.m) * (dwk_i + dwk_j) * r * dloga));
+                visc = fmin(visc, SPH_DIV(0.5 * C.fac_vsic_fix * vdotr2, 0.5 * (t.IMass + s.m) * (dwk_i + dwk_j) * r * dloga));
         }
     }
-    const double hfc_visc = 0.5 * s.m * visc * (dwk_i + dwk_j) / r;
+    const double hfc_visc = SPH_DIV_R(0.5 * s.m * visc * (dwk_i + dwk_j));
     double hfc = hfc_visc;
     double rr1 = 1, rr2 = 1;
     if(HP.DensityIndependentSphOn) {
         rr1 = 0, rr2 = 0;
-        hfc += s.m * (dwk_i * t.p_over_rho2_i * o.entvarpred / me.entvarpred + dwk_j * p_over_rho2_j * me.entvarpred / o.entvarpred) / r;
+        hfc += SPH_DIV_R(s.m * (SPH_DIV(dwk_i * t.p_over_rho2_i * o.entvarpred, me.entvarpred) + SPH_DIV(dwk_j * p_over_rho2_j * me.entvarpred, o.entvarpred)));
         if(HP.DensityContrastLimit >= 0) {
-            rr1 = t.IEgyRho / t.IDensity;
-            rr2 = o.eomdensity / o.density;
+            rr1 = SPH_DIV(t.IEgyRho, t.IDensity);
+            rr2 = SPH_DIV(o.eomdensity, o.density);
             if(HP.DensityContrastLimit > 0) {
                 rr1 = fmin(rr1, HP.DensityContrastLimit);
                 rr2 = fmin(rr2, HP.DensityContrastLimit);
             }
         }
     }
-    hfc += s.m * (t.p_over_rho2_i * me.dhsml * dwk_i * rr1 + p_over_rho2_j * o.dhsml * dwk_j * rr2) / r;
+    hfc += SPH_DIV_R(s.m * (t.p_over_rho2_i * me.dhsml * dwk_i * rr1 + p_over_rho2_j * o.dhsml * dwk_j * rr2));
     a.Acc0 += -hfc * d0;
     a.Acc1 += -hfc * d1;
     a.Acc2 += -hfc * d2;
