@@ -32,7 +32,10 @@ namespace mpg {
 namespace {
 
 #ifndef MPG_EVAL_BLOCKS
-#define MPG_EVAL_BLOCKS 6 // resident 256-thread blocks per CU the evaluation kernel is compiled for (80 VGPRs)
+// resident 256-thread blocks per CU the evaluation kernel is compiled for.  4 (128 VGPRs) since round 4: the instantiation with the
+// potential spills 8 registers there (50 at 6 blocks / 80 VGPRs: 15 GB of scratch writes per walk at 256^3) and the walk is 1.5 ms faster
+// (69.2 -> 67.7 ms); round 3 had measured 4, 5 and 6 blocks as equal before the list kernel changed
+#define MPG_EVAL_BLOCKS 4
 #endif
 
 
