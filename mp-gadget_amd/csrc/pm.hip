@@ -436,6 +436,59 @@ __global__ void __launch_bounds__(256) k_gradient3(int nmesh, double scale, cons
     gz[ip] = -(c1 * (pz[wrap(iz + 1, nmesh)] - pz[wrap(iz - 1, nmesh)]) - c2 * (pz[wrap(iz + 2, nmesh)] - pz[wrap(iz - 2, nmesh)])) * scale;
 }
 
+// readout_potential + readout_force_x/y/z (gravpm.c:491-510, petapm.c:1106-1144) in ONE pass without force meshes (round 4): the force at
+// a CIC corner is the 4-point difference of the potential there (k_gradient_axis above: the reference's force_transfer in real space), so
+// a particle gathers, per corner, the potential and its 12 stencil neighbours straight from the potential mesh and differences on the
+// fly.  104 gathers per particle instead of 32 - but from ONE mesh, with the z neighbours in the same cache line and the lanes of a wave
+// (particles come in some spatial order: Peano-Hilbert after a domain decomposition, lattice order in initial conditions) sharing lines -
+// and the gradient pass with its 3 x Nmesh^3 stores (4.3 GB moved at Nmesh = 512) is gone: gradient 1.5 ms + four read-outs 1.6 ms ->
+// 1.2 ms at 256^3 / 512^3, PM 9.9 -> 7.9 ms.  Same stencil expression, weights and corner order as k_gradient3 + k_cic_readout.
+// (Measured against it and not kept, profiles/r04a_experiments: the potential staged in LDS tiles of 16^3 cells + halo, 74 KB per block,
+// with the particles grouped by tile first - 2.0 ms + 0.5 ms for the grouping; the same gathers in tile order - 1.6 + 0.5 ms.)
+__global__ void __launch_bounds__(256) k_cic_readout_stencil(int64_t n, const double *__restrict__ pos, const uint8_t *__restrict__ active,
+                                                             double cellsize, int nmesh, double scale, const double *__restrict__ phi,
+                                                             double *__restrict__ gravpm, double *__restrict__ potential)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    if(active && !active[i]) // garbage / swallowed: outside every region (gravpm.c:176-179)
+        return;
+    size_t wi[3][6]; // wrapped cell indices ic-2 .. ic+3 per axis, times the axis stride
+    double res[3];
+    const size_t stride[3] = {(size_t)nmesh * nmesh, (size_t)nmesh, 1};
+#pragma unroll
+    for(int k = 0; k < 3; k++) {
+        const double tmp = pos[3 * i + k] / cellsize;
+        const double fl = floor(tmp);
+        res[k] = tmp - fl;
+        const int c = wrap((int)fl, nmesh);
+#pragma unroll
+        for(int j = 0; j < 6; j++)
+            wi[k][j] = (size_t)wrap(c - 2 + j, nmesh) * stride[k];
+    }
+    const double c1 = 2.0 / 3.0, c2 = 1.0 / 12.0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for(int cc = 0; cc < 8; cc++) { // corner order and weight products as in k_cic_readout: bit 0 -> x, bit 1 -> y, bit 2 -> z
+        const int ox = cc & 1, oy = (cc >> 1) & 1, oz = (cc >> 2) & 1;
+        double w = 1.0;
+        w *= ox ? res[0] : (1 - res[0]);
+        w *= oy ? res[1] : (1 - res[1]);
+        w *= oz ? res[2] : (1 - res[2]);
+        const size_t bx = wi[0][2 + ox], by = wi[1][2 + oy], bz = wi[2][2 + oz];
+        a0 += w * phi[bx + by + bz];
+        a1 += w * (-(c1 * (phi[wi[0][3 + ox] + by + bz] - phi[wi[0][1 + ox] + by + bz]) - c2 * (phi[wi[0][4 + ox] + by + bz] - phi[wi[0][0 + ox] + by + bz])) * scale);
+        a2 += w * (-(c1 * (phi[bx + wi[1][3 + oy] + bz] - phi[bx + wi[1][1 + oy] + bz]) - c2 * (phi[bx + wi[1][4 + oy] + bz] - phi[bx + wi[1][0 + oy] + bz])) * scale);
+        a3 += w * (-(c1 * (phi[bx + by + wi[2][3 + oz]] - phi[bx + by + wi[2][1 + oz]]) - c2 * (phi[bx + by + wi[2][4 + oz]] - phi[bx + by + wi[2][0 + oz]])) * scale);
+    }
+    if(potential)
+        potential[i] += a0;
+    gravpm[3 * i + 0] = a1;
+    gravpm[3 * i + 1] = a2;
+    gravpm[3 * i + 2] = a3;
+}
+
 static inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
 void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream_t st)
@@ -620,13 +673,24 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
             tm->lap(st, &t);
             t_fft += t;
         }
+        static const bool one_pass = !(getenv("MPG_PM_GRADIENT_PASSES") && getenv("MPG_PM_GRADIENT_PASSES")[0] == '3');
+        static const bool stencil = one_pass && !(getenv("MPG_PM_STENCIL") && getenv("MPG_PM_STENCIL")[0] == '0');
+        if(stencil) { // potential and forces in one read-out pass straight from the potential mesh (k_cic_readout_stencil)
+            if(n > 0)
+                hipLaunchKernelGGL(k_cic_readout_stencil, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, (double)nmesh / box,
+                                   (const double *)real.p, d_gravpm, d_potential);
+            if(tm) {
+                tm->lap(st, &t);
+                t_ro += t;
+            }
+        }
+        else {
         if(n > 0 && d_potential)
             hipLaunchKernelGGL(k_cic_readout, dim3(nblk(n)), dim3(256), 0, st, n, d_pos, d_active, cellsize, nmesh, real.p, 3, d_potential);
         if(tm) {
             tm->lap(st, &t);
             t_ro += t;
         }
-        static const bool one_pass = !(getenv("MPG_PM_GRADIENT_PASSES") && getenv("MPG_PM_GRADIENT_PASSES")[0] == '3');
         if(one_pass) { // the Fourier buffers are free now (Z2D consumed rho_k): they hold two of the three force meshes
             grad_z.reserve(nreal);
             double *g[3] = {work_k.p, rho_k.p, grad_z.p};
@@ -656,6 +720,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
                     t_ro += t;
                 }
             }
+        }
     }
     else
         for(int f = 0; f < 4; f++) {
@@ -963,6 +1028,64 @@ void PMesh::slab_inverse_c(const double *recvB, double *ghost_send, hipStream_t 
     MPG_HIP(hipGetLastError());
 }
 
+// k_cic_readout_stencil for a slab: potential and forces of the listed targets in one pass from the slab's potential, which is stored with
+// two ghost planes below plane 0 and planes P .. P+2 above (x is not wrapped: the neighbours' planes are there; y and z wrap)
+__global__ void __launch_bounds__(256) k_cic_readout_slab_stencil(int64_t nt, const int *__restrict__ targets, const double *__restrict__ pos,
+                                                                  double cellsize, int nmesh, int x0, int P, double scale,
+                                                                  const double *__restrict__ phi /* plane -2 first */, double *__restrict__ gravpm,
+                                                                  double *__restrict__ potential, unsigned *__restrict__ err)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(t >= nt)
+        return;
+    const int64_t i = targets[t];
+    size_t wi[3][6];
+    double res[3];
+    const size_t stride[3] = {(size_t)nmesh * nmesh, (size_t)nmesh, 1};
+    {
+        const double tmp = pos[3 * i] / cellsize;
+        const double fl = floor(tmp);
+        res[0] = tmp - fl;
+        const int px = wrap((int)fl, nmesh) - x0;
+        if(px < 0 || px >= P) { // the caller's target list is not this rank's slab
+            atomicExch(err, 1u);
+            return;
+        }
+#pragma unroll
+        for(int j = 0; j < 6; j++)
+            wi[0][j] = (size_t)(px + j) * stride[0]; // (px - 2 + j) + 2 ghost planes
+    }
+#pragma unroll
+    for(int k = 1; k < 3; k++) {
+        const double tmp = pos[3 * i + k] / cellsize;
+        const double fl = floor(tmp);
+        res[k] = tmp - fl;
+        const int c = wrap((int)fl, nmesh);
+#pragma unroll
+        for(int j = 0; j < 6; j++)
+            wi[k][j] = (size_t)wrap(c - 2 + j, nmesh) * stride[k];
+    }
+    const double c1 = 2.0 / 3.0, c2 = 1.0 / 12.0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for(int cc = 0; cc < 8; cc++) {
+        const int ox = cc & 1, oy = (cc >> 1) & 1, oz = (cc >> 2) & 1;
+        double w = ox ? res[0] : (1 - res[0]);
+        w *= oy ? res[1] : (1 - res[1]);
+        w *= oz ? res[2] : (1 - res[2]);
+        const size_t bx = wi[0][2 + ox], by = wi[1][2 + oy], bz = wi[2][2 + oz];
+        a0 += w * phi[bx + by + bz];
+        a1 += w * (-(c1 * (phi[wi[0][3 + ox] + by + bz] - phi[wi[0][1 + ox] + by + bz]) - c2 * (phi[wi[0][4 + ox] + by + bz] - phi[wi[0][0 + ox] + by + bz])) * scale);
+        a2 += w * (-(c1 * (phi[bx + wi[1][3 + oy] + bz] - phi[bx + wi[1][1 + oy] + bz]) - c2 * (phi[bx + wi[1][4 + oy] + bz] - phi[bx + wi[1][0 + oy] + bz])) * scale);
+        a3 += w * (-(c1 * (phi[bx + by + wi[2][3 + oz]] - phi[bx + by + wi[2][1 + oz]]) - c2 * (phi[bx + by + wi[2][4 + oz]] - phi[bx + by + wi[2][0 + oz]])) * scale);
+    }
+    if(potential)
+        potential[i] += a0;
+    gravpm[3 * i + 0] = a1;
+    gravpm[3 * i + 1] = a2;
+    gravpm[3 * i + 2] = a3;
+}
+
 void PMesh::slab_readout(const double *ghost_recv, const int *targets, int64_t nt, const double *d_pos, double *d_gravpm, double *d_potential,
                          hipStream_t st)
 {
@@ -976,11 +1099,19 @@ void PMesh::slab_readout(const double *ghost_recv, const int *targets, int64_t n
     MPG_HIP(hipMemcpyAsync(phi0 + (size_t)slab.P * plane, ghost_recv, 3 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
     MPG_HIP(hipMemcpyAsync(slab.phi.p, ghost_recv + 3 * plane, 2 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
     const int x0 = slab.rank * slab.P;
+    static const bool stencil = !(getenv("MPG_PM_STENCIL") && getenv("MPG_PM_STENCIL")[0] == '0');
+    if(stencil) {
+        if(nt > 0)
+            hipLaunchKernelGGL(k_cic_readout_slab_stencil, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, x0, slab.P,
+                               (double)nmesh / box, (const double *)slab.phi.p, d_gravpm, d_potential, flag.p);
+    }
+    else {
     if(nt > 0 && d_potential)
         hipLaunchKernelGGL(k_cic_readout_slab, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, x0, slab.P, phi0, 3, d_potential,
                            flag.p);
+    }
     const size_t ncell = (size_t)(slab.P + 1) * plane; // planes 0 .. P: the CIC readout reaches one plane beyond the slab
-    for(int axis = 0; axis < 3 && nt > 0; axis++) {
+    for(int axis = 0; axis < 3 && nt > 0 && !stencil; axis++) {
         hipLaunchKernelGGL(k_gradient_axis, dim3(nblk(ncell)), dim3(256), 0, st, nmesh, slab.P + 1, axis, (double)nmesh / box, slab.phi.p,
                            slab.force.p, 2);
         hipLaunchKernelGGL(k_cic_readout_slab, dim3(nblk(nt)), dim3(256), 0, st, nt, targets, d_pos, cellsize, nmesh, x0, slab.P, slab.force.p, axis,
