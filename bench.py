@@ -122,22 +122,27 @@ def host_path_steps(pkg, eng, pos, mass, box, steps=3):
     N = len(pos)
     ts = []
     for it in range(steps + 2):
+        # what shim/gravity-hip.c does at every entry point (mpg_shim_sync): one table epoch per step, so that Pos / Mass / Type go up
+        # once per step and not once per call (rounds 1-3 timed three uploads per step here)
+        eng.set_particle_epoch(it + 1)
         t0 = time.perf_counter()
         eng.gravpm_force(P)
         t1 = time.perf_counter()
-        eng.force_tree_full(P, box)
+        eng.force_tree_full(P, box)      # (with shim/forcetree-hip.c this is the whole cost of run.c:546: no host tree is built)
         t2 = time.perf_counter()
         eng.grav_short_tree(P)
         t3 = time.perf_counter()
         ts.append((t1 - t0, t2 - t1, t3 - t2))
+    eng.set_particle_epoch(0)
     ts = np.array(ts[2:])      # the first two steps allocate the pinned staging and run the Barnes-Hut walk
     tot = ts.sum(1).mean()
     return {"ms_per_step": round(1e3 * tot, 2), "particles_per_s": N / tot,
             "calls_ms": {"gravpm_force": round(1e3 * ts[:, 0].mean(), 2), "force_tree_full": round(1e3 * ts[:, 1].mean(), 2),
                          "grav_short_tree": round(1e3 * ts[:, 2].mean(), 2)},
             "note": "mpg_gravpm_force + mpg_force_tree_full + mpg_grav_short_tree on %d 160-byte particle_data records in pageable host "
-                    "memory (H2D of Pos/Mass, D2H of GravPM/FullTreeGravAccel/Potential, packing on host threads); the device-resident "
-                    "rate is `value`" % N}
+                    "memory, one table epoch per step as the shim declares it (one H2D of Pos/Mass per step, OldAcc up, GravPM / "
+                    "FullTreeGravAccel / Potential down, packing on host threads) = the force part of run.c:522-548 with shim/ in the link, "
+                    "no host tree anywhere; the device-resident rate is `value`" % N}
 
 
 def resident_path_steps(pkg, eng, pos, mass, box, steps=3):
@@ -199,6 +204,23 @@ def walk_traffic(pkg, N, ic, variant):
     if not e:
         return None, "no PMC summary committed for this input set"
     return e["hbm_bytes_per_launch"], "bytes per walk (%s) from %s; library build %s" % (e["kernel"], e["method"], stamp[:12])
+
+
+def sph_traffic(pkg, n, kernel):
+    """HBM bytes per full launch of k_density / k_hydro from the committed PMC passes (tools/prof.sh -> profiles/sph_traffic.json), for
+    the library build they were taken with only (see walk_traffic)."""
+    tpath = os.path.join(ROOT, "profiles", "sph_traffic.json")
+    if not os.path.exists(tpath) or n != 128:
+        return None, "no PMC summary committed for this configuration"
+    tj = json.load(open(tpath))
+    stamp = pkg.engine.load_library().mpg_build_stamp().decode()
+    if tj.get("build_stamp") != stamp:
+        return None, "profiles/sph_traffic.json was measured with library build %s, this run uses %s: re-run tools/prof.sh" % (
+            str(tj.get("build_stamp"))[:12], stamp[:12])
+    e = tj.get("kernels", {}).get(kernel)
+    if not e:
+        return None, "kernel not in the PMC summary"
+    return e["hbm_bytes_per_launch"], "bytes per full launch from %s; library build %s" % (e["method"], stamp[:12])
 
 
 def substep_measure(pkg, torch, eng, N, acc, prev, gravpm, pot, dev, fracs=(1. / 8, 1. / 64, 1. / 512), reps=3):
@@ -315,8 +337,9 @@ def hydro_measure(pkg, torch, args, dev, n=128, steps=3, PE=0):
 
     def roof(kernel, flops, b, t_ms, note):
         ach = flops / (t_ms * 1e-3) / 1e12
+        traffic, tnote = sph_traffic(pkg, n, kernel)
         return {"bound": "fp64_valu", "kernel": kernel, "achieved": ach, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TF,
-                "traffic": None, "flop_per_launch": flops, "algorithmic_bytes_per_launch": b,
+                "traffic": traffic, "traffic_note": tnote, "flop_per_launch": flops, "algorithmic_bytes_per_launch": b,
                 "algorithmic_bytes_over_hbm_peak": b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": t_ms, "note": note}
     out = {"ms_per_step": 1e3 * el / steps, "particles_per_s": N * steps / el, "particles": N, "steps": steps,
            "workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),

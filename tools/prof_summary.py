@@ -18,7 +18,7 @@ def short(name):
     return name[:70]
 
 
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True) + glob.glob(os.path.join(root, "trace_hydro", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel stats:", os.path.relpath(f, root))
     rows = list(csv.DictReader(open(f)))
     for r in rows[:14]:
@@ -131,3 +131,30 @@ if variants:
     print("== walk traffic (%s, build %s):" % (ic, stamp), json.dumps(variants))
     with open(os.path.join(root, "walk_traffic.json"), "w") as fo:
         json.dump({"build_stamp": stamp, "by_ic": {ic or "unknown": variants}}, fo, indent=1)
+
+
+# ---- HBM traffic of the SPH kernels (bench.py --workload hydro) for its roofline.traffic ---------------------------------------------
+# The largest dispatch of each kernel is a full launch (all gas targets); the Hsml iteration's later passes are smaller and are left out.
+try:
+    stamp = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mp-gadget_amd", "libmpgadget_hip.so.stamp")).read().strip()
+except OSError:
+    stamp = None
+sph = {}
+for kern in ("k_density", "k_hydro"):
+    val = {}
+    for name, sub in (("FETCH_SIZE", "pmc_hydro_fetch"), ("WRITE_SIZE", "pmc_hydro_write")):
+        per = defaultdict(float)
+        for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == name and short(r["Kernel_Name"]) == kern:
+                    per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        if per:
+            full = sorted(per.values())[-3:]          # the full launches (one per step) are the largest
+            val[name] = sum(full) / len(full)
+    if len(val) == 2:
+        fb, wb = 2 * 1024 * val["FETCH_SIZE"], 1024 * val["WRITE_SIZE"]
+        sph[kern] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb, "method": METHOD.replace("summed over the dispatches of one walk", "mean of the three largest dispatches (full launches)")}
+if sph:
+    print("== SPH traffic (build %s):" % stamp, json.dumps(sph))
+    with open(os.path.join(root, "sph_traffic.json"), "w") as fo:
+        json.dump({"build_stamp": stamp, "kernels": sph}, fo, indent=1)
