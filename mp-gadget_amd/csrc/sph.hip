@@ -49,61 +49,28 @@ __device__ __forceinline__ DKernel kernel_init(double H, int type) // densityker
     return k;
 }
 
+// The kernel polynomials of densitykernel.c:24-90 without branches on q: every term (c - q)^n of the reference's piecewise form is taken
+// of max(c - q, 0), which is the term where the reference has it and an exact zero (added or subtracted last, in the reference's order:
+// the sums' bits do not change) where it has not.  The lanes of a wave hold neighbours at all distances: with three branches the wave ran
+// all three bodies one after the other (round 4: the SPH kernels are issue-bound, profiles/r04a_experiments).
+__device__ __forceinline__ double pos_part(double x) { return fmax(x, 0.0); }
 template <int TYPE> __device__ __forceinline__ double wk_q(double q) // densitykernel.c:24-90
 {
-    if(TYPE == 0) {
-        if(q < 1.0)
-            return 0.25 * p3(2 - q) - p3(1 - q);
-        if(q < 2.0)
-            return 0.25 * p3(2 - q);
-        return 0.0;
-    }
-    else if(TYPE == 1) {
-        if(q < 1.0)
-            return p5(3 - q) - 6 * p5(2 - q) + 15 * p5(1 - q);
-        if(q < 2.0)
-            return p5(3 - q) - 6 * p5(2 - q);
-        if(q < 3.0)
-            return p5(3 - q);
-        return 0.0;
-    }
-    else {
-        if(q < 0.5)
-            return p4(2.5 - q) - 5 * p4(1.5 - q) + 10 * p4(0.5 - q);
-        if(q < 1.5)
-            return p4(2.5 - q) - 5 * p4(1.5 - q);
-        if(q < 2.5)
-            return p4(2.5 - q);
-        return 0.0;
-    }
+    if(TYPE == 0)
+        return 0.25 * p3(pos_part(2 - q)) - p3(pos_part(1 - q));
+    else if(TYPE == 1)
+        return p5(pos_part(3 - q)) - 6 * p5(pos_part(2 - q)) + 15 * p5(pos_part(1 - q));
+    else
+        return p4(pos_part(2.5 - q)) - 5 * p4(pos_part(1.5 - q)) + 10 * p4(pos_part(0.5 - q));
 }
 template <int TYPE> __device__ __forceinline__ double dwk_q(double q)
 {
-    if(TYPE == 0) {
-        if(q < 1.0)
-            return -0.25 * 3 * p2(2 - q) + 3 * p2(1 - q);
-        if(q < 2.0)
-            return -0.25 * 3 * p2(2 - q);
-        return 0.0;
-    }
-    else if(TYPE == 1) {
-        if(q < 1.0)
-            return -5 * p4(3 - q) + 30 * p4(2 - q) - 75 * p4(1 - q);
-        if(q < 2.0)
-            return -5 * p4(3 - q) + 30 * p4(2 - q);
-        if(q < 3.0)
-            return -5 * p4(3 - q);
-        return 0.0;
-    }
-    else {
-        if(q < 0.5)
-            return -4 * p3(2.5 - q) + 20 * p3(1.5 - q) - 40 * p3(0.5 - q);
-        if(q < 1.5)
-            return -4 * p3(2.5 - q) + 20 * p3(1.5 - q);
-        if(q < 2.5)
-            return -4 * p3(2.5 - q);
-        return 0.0;
-    }
+    if(TYPE == 0)
+        return -0.25 * 3 * p2(pos_part(2 - q)) + 3 * p2(pos_part(1 - q));
+    else if(TYPE == 1)
+        return -5 * p4(pos_part(3 - q)) + 30 * p4(pos_part(2 - q)) - 75 * p4(pos_part(1 - q));
+    else
+        return -4 * p3(pos_part(2.5 - q)) + 20 * p3(pos_part(1.5 - q)) - 40 * p3(pos_part(0.5 - q));
 }
 __device__ __forceinline__ double kernel_wk(const DKernel &k, int type, double u)
 {
