@@ -37,6 +37,9 @@ namespace {
 // (69.2 -> 67.7 ms); round 3 had measured 4, 5 and 6 blocks as equal before the list kernel changed
 #define MPG_EVAL_BLOCKS 4
 #endif
+#ifndef MPG_EVAL_BLOCKS_LONG
+#define MPG_EVAL_BLOCKS_LONG 6
+#endif
 
 
 __device__ __forceinline__ double rsqrt_nr(double x)
@@ -821,7 +824,10 @@ template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
     auto kl = k_walk_lists8<COUNT, FASTWRAP, O32>;
-    auto ke = k_walk_eval<POT, FASTWRAP, O32, MPG_EVAL_BLOCKS>;
+    // 4 resident blocks per CU (128 registers, hardly a spill) where the lists are short - the evaluation is then bound by instruction issue -
+    // and 6 (80 registers) where they are long (a clustered set: the list capacity has grown to >= 4096 entries), where it waits for memory and
+    // the waves count: 256^3 clustered 148 -> 127 ms per walk with 6, Zel'dovich 69.2 -> 67.7 with 4
+    auto ke = ws.split_cap >= 4096 ? k_walk_eval<POT, FASTWRAP, O32, MPG_EVAL_BLOCKS_LONG> : k_walk_eval<POT, FASTWRAP, O32, MPG_EVAL_BLOCKS>;
     if(const char *e = getenv("MPG_LIST_CAP")) // experiment knob
         ws.split_cap = atoi(e) / 8 * 8;
     const int cap = ws.split_cap;

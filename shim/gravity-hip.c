@@ -191,19 +191,46 @@ static void charge_pm_clocks(void)
     walltime_add("/PMgrav/readout", 1e-3 * t.pm_readout);  /* petapm.c:355 */
 }
 
+/* gravpm_init_periodic -> petapm_init (gravpm.c:51-54, petapm.c:105-223).  The mesh, the plans and the pencil layout live in the
+ * engine; the PetaPM object keeps what its other readers use (BoxSize, Asmth, Nmesh, G, CellSize: gravshort-tree.c:102, timestep.c,
+ * run.c) and everything petapm_destroy (petapm.c:225-232: runtests.c:204,222 call it on this object) releases, so that it can stay as it
+ * is in petapm.o (MP-GenIC and the reionisation PM use that file): the communicator it frees is a duplicate made here, Mesh2Task[0] is
+ * allocated where petapm_init allocates it (the same place in the allocator's stack: petapm.c:122), the two plans are NULL
+ * (pfft_destroy_plan returns on a null plan).  The regions describe the whole mesh on rank 0's terms: nothing on the device path reads
+ * them (the x-slab layout of the multi-rank PM is the library's own). */
 void gravpm_init_periodic(PetaPM *pm, double BoxSize, double Asmth, int Nmesh, double G)
 {
+    int i, NTaskHere;
+    memset(pm, 0, sizeof(*pm));
     pm->BoxSize = BoxSize;
     pm->Asmth = Asmth;
     pm->Nmesh = Nmesh;
     pm->G = G;
     pm->CellSize = BoxSize / Nmesh;
+    pm->comm = MPI_COMM_WORLD;
+    MPI_Comm_size(MPI_COMM_WORLD, &NTaskHere);
+    pm->Mesh2Task[0] = (int *)mymalloc2("Mesh2Task", 2 * sizeof(int) * Nmesh);
+    pm->Mesh2Task[1] = pm->Mesh2Task[0] + Nmesh;
+    for(i = 0; i < Nmesh; i++) { /* x-planes in NTask slabs (the library's decomposition), y undivided */
+        pm->Mesh2Task[0][i] = (int)(((int64_t)i * NTaskHere) / Nmesh);
+        pm->Mesh2Task[1][i] = 0;
+    }
+    MPI_Comm_dup(MPI_COMM_WORLD, &pm->priv->comm_cart_2d);
+    pm->NTask2d[0] = NTaskHere;
+    pm->NTask2d[1] = 1;
+    MPI_Comm_rank(MPI_COMM_WORLD, &pm->ThisTask2d[0]);
+    pm->ThisTask2d[1] = 0;
+    pm->priv->plan_forw = NULL;
+    pm->priv->plan_back = NULL;
+    pm->priv->fftsize = 0;
+    for(i = 0; i < 3; i++) {
+        pm->real_space_region.offset[i] = 0;
+        pm->real_space_region.size[i] = Nmesh;
+        pm->fourier_space_region.offset[i] = 0;
+        pm->fourier_space_region.size[i] = i == 2 ? Nmesh / 2 + 1 : Nmesh;
+    }
     ck(mpg_gravpm_init_periodic(eng(), BoxSize, Asmth, Nmesh, G));
 }
-
-/* petapm_module_init / petapm_destroy stay with petapm.o (MP-GenIC and the reionisation PM use it): the PetaPM object of the
- * gravity path is never given to petapm_init here, so petapm_destroy on it finds priv == NULL plans... the maintainer guards
- * runtests.c:204,222 with `if(pm->priv)`; the device mesh is released by mpg_petapm_destroy when the engine is destroyed. */
 
 void gravpm_force(PetaPM *pm, DomainDecomp *ddecomp, Cosmology *CP, double Time, double UnitLength_in_cm, const char *PowerOutputDir,
                   double TimeIC)
