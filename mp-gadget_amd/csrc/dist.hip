@@ -603,6 +603,7 @@ __global__ void __launch_bounds__(256) k_lookup_grnr(int64_t n, const unsigned l
 struct Plan { // one personalised exchange: who gets which of my rows, and what I get
     DevBuf<int> idx;
     DevBuf<long long> d_sdsp;
+    HostBuf<long long> h_sdsp;
     std::vector<int64_t> scnt, rcnt, sdsp, rdsp; // rows
     int64_t nsend = 0, nrecv = 0;
 };
@@ -657,6 +658,8 @@ struct mpg_dist {
     int64_t n_skip = 0, n_skip_rows = -1;
     DevBuf<uint8_t> ltype, o_skip;
     const unsigned char *skip_for(int64_t n) const { return (n_skip > 0 && n == n_skip_rows) ? d_skip : nullptr; }
+    HostBuf<unsigned long long> chk; // [0] own particles found in the local tree, [1] the two flags of the global top (pinned: read back without a wait)
+    bool chk_pending = false;
     bool grav_tree_valid = false; // the engine's tree is the gravity tree of mpg_dist_dev_force_tree_build (the SPH loops and FOF replace it)
     double last_hmax = 0;         // largest smoothing length over all ranks after the last density loop
     int blackholes = 0;           // BlackHoleOn of density(): the own non-swallowed black holes are targets of the density loop too
@@ -803,11 +806,12 @@ void build_plan(mpg_dist *d, Plan &pl, int64_t n, const unsigned long long *mask
     MPG_CHECK(pl.nsend < (1ll << 31), "mpg_dist: more than 2^31 rows in one exchange");
     pl.idx.reserve((size_t)pl.nsend + 1);
     pl.d_sdsp.reserve((size_t)nt + 1);
-    std::vector<long long> dsp(pl.sdsp.begin(), pl.sdsp.end());
-    MPG_HIP(hipMemcpyAsync(pl.d_sdsp.p, dsp.data(), (nt + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+    pl.h_sdsp.reserve((size_t)nt + 1); // (pinned, owned by the plan: the copy needs no wait; the next build_plan of this plan starts with one)
+    for(int r = 0; r <= nt; r++)
+        pl.h_sdsp.p[r] = (long long)pl.sdsp[r];
+    MPG_HIP(hipMemcpyAsync(pl.d_sdsp.p, pl.h_sdsp.p, (nt + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
     if(n > 0 && pl.nsend > 0)
         hipLaunchKernelGGL(k_split_scatter, dim3((unsigned)ntiles), dim3(256), 0, st, n, mask, nt, ntiles, d->tilepos.p, pl.idx.p);
-    sync(d); // (dsp is a host vector)
     pl.rcnt.assign(nt, 0);
     if(nt == 1 && !d->comm.alltoall_i64)
         pl.rcnt[0] = pl.scnt[0];
@@ -952,23 +956,30 @@ void pm_step(mpg_dist *d, int64_t n, const double *pos, const float *mass, doubl
         }
         a2av(d, d->gsend.p, sb, sd, d->grecv.p, rb, rd, 5 * pb, 5 * pb);
     }
-    // targets: the received particles whose base cell is mine
-    int64_t ntarg = 0;
+    // the received particles whose base cell is mine are read out (the kernel tells: no target list, no count read back - round 4)
     if(nr > 0) {
-        hipLaunchKernelGGL(k_flag_slab_targets, dim3(nblk(nr)), dim3(256), 0, st, nr, d->spos.p, pm.cellsize, nmesh, P, d->me, d->sflag.p);
-        rocprim::counting_iterator<int> iota(0);
-        size_t tb = 0;
-        MPG_HIP(rocprim::select(nullptr, tb, iota, d->sflag.p, d->starg.p, d->scount.p, (size_t)nr, st));
-        d->tmp.reserve(tb + 16);
-        MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->sflag.p, d->starg.p, d->scount.p, (size_t)nr, st));
-        unsigned long long c = 0;
-        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
-        sync(d);
-        ntarg = (int64_t)c;
         MPG_HIP(hipMemsetAsync(d->sgrav.p, 0, (size_t)3 * nr * sizeof(double), st));
         MPG_HIP(hipMemsetAsync(d->spot.p, 0, (size_t)nr * sizeof(double), st));
     }
-    pm.slab_readout(d->grecv.p, d->starg.p, ntarg, d->spos.p, d->sgrav.p, d->spot.p, st);
+    static const bool stencil_rows = !(getenv("MPG_PM_STENCIL") && getenv("MPG_PM_STENCIL")[0] == '0');
+    if(stencil_rows)
+        pm.slab_readout_rows(d->grecv.p, nr, d->spos.p, d->sgrav.p, d->spot.p, st);
+    else {
+        int64_t ntarg = 0;
+        if(nr > 0) {
+            hipLaunchKernelGGL(k_flag_slab_targets, dim3(nblk(nr)), dim3(256), 0, st, nr, d->spos.p, pm.cellsize, nmesh, P, d->me, d->sflag.p);
+            rocprim::counting_iterator<int> iota(0);
+            size_t tb = 0;
+            MPG_HIP(rocprim::select(nullptr, tb, iota, d->sflag.p, d->starg.p, d->scount.p, (size_t)nr, st));
+            d->tmp.reserve(tb + 16);
+            MPG_HIP(rocprim::select((void *)d->tmp.p, tb, iota, d->sflag.p, d->starg.p, d->scount.p, (size_t)nr, st));
+            unsigned long long c = 0;
+            MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
+            sync(d);
+            ntarg = (int64_t)c;
+        }
+        pm.slab_readout(d->grecv.p, d->starg.p, ntarg, d->spos.p, d->sgrav.p, d->spot.p, st);
+    }
     // results back along the same lists
     if(nr > 0)
         hipLaunchKernelGGL(k_pack_results, dim3(nblk(nr)), dim3(256), 0, st, nr, d->sgrav.p, d->spot.p, (RRow *)d->recvbuf.p);
@@ -1246,6 +1257,18 @@ static void tree_build_local(mpg_dist *d, int64_t n_own, int64_t nl, hipStream_t
     e->tree.force_internal_above = 0;
 }
 
+// the deferred checks of tree_finish; call after a synchronisation of the engine's stream
+static void tree_checks(mpg_dist *d)
+{
+    if(!d->chk_pending)
+        return;
+    d->chk_pending = false;
+    const unsigned *ef = (const unsigned *)&d->chk.p[1];
+    MPG_CHECK(ef[0] == 0, "mpg_dist: a cell above the decomposition level holds <= 8 particles in all (use a coarser level La)");
+    MPG_CHECK(ef[1] == 0, "domain decomposition: a cell above the decomposition level holds <= 8 local particles (use a coarser level)");
+    MPG_CHECK((int64_t)d->chk.p[0] == d->ntarg, "mpg_dist: own particles missing from the local tree");
+}
+
 static void tree_finish(mpg_dist *d, int64_t n_own, int64_t nl)
 {
     mpg_engine *e = d->eng;
@@ -1261,22 +1284,20 @@ static void tree_finish(mpg_dist *d, int64_t n_own, int64_t nl)
         MPG_HIP(rocprim::select(nullptr, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, IsOwn{(int)n_own}, st));
         d->tmp.reserve(tb + 16);
         MPG_HIP(rocprim::select((void *)d->tmp.p, tb, e->tree.idx_b.p, (int *)d->targets.p, d->scount.p, (size_t)e->tree.npart, IsOwn{(int)n_own}, st));
-        unsigned long long c = 0;
-        MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
-        unsigned ef[2] = {0, 0};
-        MPG_HIP(hipMemcpyAsync(ef, d->err.p + 1, sizeof(ef), hipMemcpyDeviceToHost, st));
-        sync(d);
-        MPG_CHECK(ef[0] == 0, "mpg_dist: a cell above the decomposition level holds <= 8 particles in all (use a coarser level La)");
-        MPG_CHECK(ef[1] == 0, "domain decomposition: a cell above the decomposition level holds <= 8 local particles (use a coarser level)");
-        d->ntarg = (int64_t)c;
-        MPG_CHECK(d->ntarg == n_own - (d->skip_for(n_own) ? d->n_skip : 0), "mpg_dist: own particles missing from the local tree");
+        // every own live particle is in the local tree, so the number of targets is known; the count the selection found and the flags of
+        // the global top travel to pinned memory behind it and are checked at the next point the host waits anyway (tree_checks)
+        d->ntarg = n_own - (d->skip_for(n_own) ? d->n_skip : 0);
+        d->chk.reserve(4);
+        d->chk.p[0] = ~0ull;
+        MPG_HIP(hipMemcpyAsync(&d->chk.p[0], d->scount.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     else {
-        unsigned ef[2] = {0, 0};
-        MPG_HIP(hipMemcpyAsync(ef, d->err.p + 1, sizeof(ef), hipMemcpyDeviceToHost, st));
-        sync(d);
-        MPG_CHECK(ef[0] == 0 && ef[1] == 0, "mpg_dist: a cell above the decomposition level holds <= 8 particles (use a coarser level La)");
+        d->chk.reserve(4);
+        d->chk.p[0] = 0;
     }
+    d->chk.p[1] = 0;
+    MPG_HIP(hipMemcpyAsync(&d->chk.p[1], d->err.p + 1, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    d->chk_pending = true;
     d->grav_tree_valid = true;
 }
 
@@ -1297,6 +1318,8 @@ int mpg_dist_dev_force_tree_build(mpg_dist *d, int64_t n_own, const double *d_po
     d->times[1] = t2 - t1;
     tree_build_local(d, n_own, nl, e->stream);
     tree_finish(d, n_own, nl);
+    sync(d); // (this entry point stands alone - the SPH loops and FOF follow it as well as the walk: its checks are made here)
+    tree_checks(d);
     d->times[2] = now_ms() - t2;
     d->times[4] = 0;
     API_END
@@ -1320,6 +1343,7 @@ int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_
     mpg_engine *e = d->eng;
     MPG_HIP(hipSetDevice(e->device));
     sync(d);
+    tree_checks(d);
     const double t3 = now_ms();
     // the walk's targets: the own particles in tree order, or those of them the caller lists as active (ActiveParticle of the
     // sub-steps, run.c:392-470: the tree holds every particle, a subset is walked)

@@ -69,6 +69,7 @@ struct PMesh {
     void slab_inverse_c(const double *recvB, double *ghost_send, hipStream_t st);
     // ghost_recv[5][Nmesh^2] = the next rank's first 3 planes, then the previous rank's last 2; forces by differencing the
     // potential, CIC readout for `nt` targets (caller indices) that lie in the slab
+    void slab_readout_rows(const double *ghost_recv, int64_t nrows, const double *d_pos, double *d_gravpm, double *d_potential, hipStream_t st);
     void slab_readout(const double *ghost_recv, const int *targets, int64_t nt, const double *d_pos, double *d_gravpm, double *d_potential,
                       hipStream_t st);
 };

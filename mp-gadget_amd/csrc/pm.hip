@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(256) k_cic_readout_slab_stencil(int64_t nt, co
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if(t >= nt)
         return;
-    const int64_t i = targets[t];
+    const int64_t i = targets ? targets[t] : t; // (no list: every row whose base cell lies in the slab is a target, the others are skipped)
     size_t wi[3][6];
     double res[3];
     const size_t stride[3] = {(size_t)nmesh * nmesh, (size_t)nmesh, 1};
@@ -1047,8 +1047,9 @@ __global__ void __launch_bounds__(256) k_cic_readout_slab_stencil(int64_t nt, co
         const double fl = floor(tmp);
         res[0] = tmp - fl;
         const int px = wrap((int)fl, nmesh) - x0;
-        if(px < 0 || px >= P) { // the caller's target list is not this rank's slab
-            atomicExch(err, 1u);
+        if(px < 0 || px >= P) { // not this rank's slab: an error in a caller's target list
+            if(targets)
+                atomicExch(err, 1u);
             return;
         }
 #pragma unroll
@@ -1084,6 +1085,21 @@ __global__ void __launch_bounds__(256) k_cic_readout_slab_stencil(int64_t nt, co
     gravpm[3 * i + 0] = a1;
     gravpm[3 * i + 1] = a2;
     gravpm[3 * i + 2] = a3;
+}
+
+// slab_readout for ALL rows of d_pos whose base cell lies in the slab (the rows a rank received for its slab: a particle whose CIC cloud
+// straddles two slabs was shipped to both, its base cell's owner reads it out); nothing is read back: no target list, no count
+void PMesh::slab_readout_rows(const double *ghost_recv, int64_t nrows, const double *d_pos, double *d_gravpm, double *d_potential, hipStream_t st)
+{
+    MPG_CHECK(slab.ready, "pm_slab: not initialised");
+    const size_t plane = (size_t)nmesh * nmesh;
+    double *phi0 = slab.phi.p + 2 * plane;
+    MPG_HIP(hipMemcpyAsync(phi0 + (size_t)slab.P * plane, ghost_recv, 3 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MPG_HIP(hipMemcpyAsync(slab.phi.p, ghost_recv + 3 * plane, 2 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if(nrows > 0)
+        hipLaunchKernelGGL(k_cic_readout_slab_stencil, dim3(nblk(nrows)), dim3(256), 0, st, nrows, (const int *)nullptr, d_pos, cellsize, nmesh,
+                           slab.rank * slab.P, slab.P, (double)nmesh / box, (const double *)slab.phi.p, d_gravpm, d_potential, (unsigned *)nullptr);
+    MPG_HIP(hipGetLastError());
 }
 
 void PMesh::slab_readout(const double *ghost_recv, const int *targets, int64_t nt, const double *d_pos, double *d_gravpm, double *d_potential,
