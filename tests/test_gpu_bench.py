@@ -124,6 +124,19 @@ def test_c4_shape_through_rccl_at_full_per_gpu_size(ic):
     assert j["roofline"]["pp_interactions_per_launch"] > 0 and j["phases_ms"]["dist_transpose_bytes"] > 2 * 512 ** 3 * 8
 
 
+def test_c4_whole_particle_set_on_one_gpu():
+    """BASELINE configs[3]'s WHOLE particle set (512^3 particles, Nmesh 1024) on the one GPU: 288 GB hold the set, its 1024^3 mesh and
+    the walk lists; the walk runs its 64-bit-offset kernels (source and node arrays beyond 4 GiB) and slices its list area.  One timed
+    step; the line's counters must be those of a 512^3 Zel'dovich walk (about 700 pair interactions and 200 nodes used per target)
+    and the rate that of the 256^3 run.  (this run was the builder's, not part of -m gpu.)"""
+    j = run_bench(["--size", "512", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"])   # (the warm-up step sizes the walk's lists)
+    assert KEYS <= set(j) and j["config"]["particles"] == 512 ** 3 and j["config"]["nmesh"] == 1024
+    r = j["roofline"]
+    assert j["value"] > 1.2e8 and 0.08 < r["frac"] <= 1
+    assert 400 < r["pp_interactions_per_launch"] / 512 ** 3 < 1200 and 100 < r["nodes_used_per_launch"] / 512 ** 3 < 400
+    assert r["targets_per_launch"] == 512 ** 3 and r["walk_variant"] == 6
+
+
 def test_c5_shape_through_rccl_at_full_per_gpu_size():
     """BASELINE configs[4] (2 x 256^3 pressure-entropy hydro on 8 GPUs) as ONE rank sees it: 2 x 128^3 own particles, gravity + the
     distributed SPH loops (ghost import, the ghosts' SPH fields refreshed from their owners between density and hydro) with the
