@@ -137,6 +137,17 @@ def test_c4_whole_particle_set_on_one_gpu():
     assert r["targets_per_launch"] == 512 ** 3 and r["walk_variant"] == 6
 
 
+def test_c5_whole_particle_set_on_one_gpu():
+    """BASELINE configs[4]'s WHOLE particle set (2 x 256^3 DM + gas, pressure-entropy SPH) on the one GPU: gravity, gas tree, density,
+    hmax, hydro force of 16.8 M gas particles; one Hsml pass per step once converged, about 110 neighbours per gas particle (quintic
+    kernel, eta = 1)."""
+    j = run_bench(["--workload", "hydro", "--size", "256", "--sph", "pe", "--steps", "1", "--warmup", "1"])
+    assert j["config"]["particles"] == 2 * 256 ** 3 and "pressure-entropy" in j["config"]["workload"] and j["value"] > 4e7
+    assert j["config"]["density_iterations"][-1] == 1
+    ngb = int(j["roofline"]["note"].split("(")[1].split(" neighbours")[0]) / 256 ** 3
+    assert 90 < ngb < 130, ngb
+
+
 def test_c5_shape_through_rccl_at_full_per_gpu_size():
     """BASELINE configs[4] (2 x 256^3 pressure-entropy hydro on 8 GPUs) as ONE rank sees it: 2 x 128^3 own particles, gravity + the
     distributed SPH loops (ghost import, the ghosts' SPH fields refreshed from their owners between density and hydro) with the
