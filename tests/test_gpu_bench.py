@@ -144,7 +144,8 @@ def test_c5_whole_particle_set_on_one_gpu():
     j = run_bench(["--workload", "hydro", "--size", "256", "--sph", "pe", "--steps", "1", "--warmup", "1"])
     assert j["config"]["particles"] == 2 * 256 ** 3 and "pressure-entropy" in j["config"]["workload"] and j["value"] > 4e7
     assert j["config"]["density_iterations"][-1] == 1
-    ngb = int(j["roofline"]["note"].split("(")[1].split(" neighbours")[0]) / 256 ** 3
+    import re
+    ngb = int(re.search(r"\((\d+) neighbours", j["roofline"]["note"]).group(1)) / 256 ** 3
     assert 90 < ngb < 130, ngb
 
 
