@@ -121,27 +121,19 @@ namespace {
         }                                                                             \
     } while(0)
 
-// one block of `bytes` to / from `peer`, in pieces: 8-byte words when everything is 8-byte aligned (counts stay far below 2^31 words)
+// one block of `bytes` to / from `peer`, in pieces of at most r->piece bytes.  Always as bytes (ncclChar): a send and its matching receive
+// must agree on datatype and count, and the two sides of a block know nothing of each other's alignment; for point-to-point transfers
+// the datatype only scales the count.
 int send_block(mpg_rccl *r, const char *p, size_t bytes, int peer)
 {
-    for(size_t o = 0; o < bytes; o += r->piece) {
-        const size_t n = std::min(r->piece, bytes - o);
-        if(((uintptr_t)(p + o) | n) % 8 == 0)
-            NCCL_TRY(r, api().Send(p + o, n / 8, ncclUint64, peer, r->comm, r->stream));
-        else
-            NCCL_TRY(r, api().Send(p + o, n, ncclChar, peer, r->comm, r->stream));
-    }
+    for(size_t o = 0; o < bytes; o += r->piece)
+        NCCL_TRY(r, api().Send(p + o, std::min(r->piece, bytes - o), ncclChar, peer, r->comm, r->stream));
     return 0;
 }
 int recv_block(mpg_rccl *r, char *p, size_t bytes, int peer)
 {
-    for(size_t o = 0; o < bytes; o += r->piece) {
-        const size_t n = std::min(r->piece, bytes - o);
-        if(((uintptr_t)(p + o) | n) % 8 == 0)
-            NCCL_TRY(r, api().Recv(p + o, n / 8, ncclUint64, peer, r->comm, r->stream));
-        else
-            NCCL_TRY(r, api().Recv(p + o, n, ncclChar, peer, r->comm, r->stream));
-    }
+    for(size_t o = 0; o < bytes; o += r->piece)
+        NCCL_TRY(r, api().Recv(p + o, std::min(r->piece, bytes - o), ncclChar, peer, r->comm, r->stream));
     return 0;
 }
 
