@@ -88,7 +88,12 @@ struct alignas(16) NodeLink {
 
 // Node links of the level-ordered ("children contiguous") copy of the tree used by the cooperative walk.
 struct alignas(16) NodeLinkB {
-    int firstchild; // level-order index of the first child (-1 for a leaf); the children are firstchild .. firstchild+nchild-1
+    // internal node: level-order index of the first child; the children are firstchild .. firstchild+nchild-1.
+    // LEAF: which opened leaves among its SIBLINGS may be listed as one run of <= 8 particles by the neighbour search (ngb_walk.h,
+    // walk_stepk<MERGE>; sibling leaves are contiguous in tree order): bits 0-3 the particle count of this child's pair (children 2j,
+    // 2j+1 of the parent), bits 4-7 of its quad, bits 8-11 of all children - each 0 unless every existing child of the set is a leaf,
+    // there are at least two, and they hold <= 8 particles together
+    int firstchild;
     int nchild;     // 1..8 occupied octants (0 for a leaf)
     int pstart;     // first particle (tree order) below this node
     int pcount;     // >0: leaf with that many particles; 0: internal node

@@ -12,23 +12,50 @@ namespace mpg {
 __device__ __forceinline__ unsigned long long ballot64(const bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
 __device__ __forceinline__ double nearest_img(double x, double box, double invbox) { return x - box * rint(x * invbox); }
+// WRAP = false: plain differences, for the targets of a wave that all lie farther from every face of the box than their search radius
+// (interior_wave below).  Exact, not approximate: a node / particle that the nearest-image form keeps has |d| <= radius + len < Box / 2 per
+// axis on the unwrapped image for such a target (rint(d / Box) = 0: NEAREST() returns d itself), and one whose unwrapped |d| exceeds Box / 2
+// on an axis lies, on its nearest image, beyond the face the target is `radius` away from, plus its own half length: culled by both forms.
+template <bool WRAP> __device__ __forceinline__ double near_img(double x, double box, double invbox) { return WRAP ? x - box * rint(x * invbox) : x; }
+
+// Do all targets of this wave (lanes with `valid`) lie farther than their search radius from every face of the box?  (Box / 500 of margin
+// as in the gravity walk's MODE 2, and radius < Box / 4 so that "beyond Box / 2" implies "culled" for every node below the root.)
+__device__ __forceinline__ bool interior_wave(const bool valid, const double px, const double py, const double pz, const double radius, const double box)
+{
+    const double face = radius + 0.002 * box;
+    const bool out = valid && (!(radius < 0.25 * box) || fmin(fmin(px, py), pz) < face || fmax(fmax(px, py), pz) > box - face);
+    return ballot64(out) == 0ull;
+}
 
 // cull_node, treewalk.c:1015-1042 (hm = 0: asymmetric search radius Hsml; symmetric: max(node hmax, Hsml))
+template <bool WRAP = true>
 __device__ __forceinline__ bool cull_node(const NodeGeo &g, double hm, double hsml, double px, double py, double pz, double box, double invbox)
 {
+#ifdef NGB_CULL_BRANCHY // (the reference's form, with its early returns: experiment switch)
     double dist = fmax(hm, hsml) + 0.5 * g.len;
-    const double dx = nearest_img(g.cx - px, box, invbox);
+    const double dx = near_img<WRAP>(g.cx - px, box, invbox);
     if(dx > dist || dx < -dist)
         return true;
-    const double dy = nearest_img(g.cy - py, box, invbox);
+    const double dy = near_img<WRAP>(g.cy - py, box, invbox);
     if(dy > dist || dy < -dist)
         return true;
-    const double dz = nearest_img(g.cz - pz, box, invbox);
+    const double dz = near_img<WRAP>(g.cz - pz, box, invbox);
     if(dz > dist || dz < -dist)
         return true;
     const double r2 = dx * dx + dy * dy + dz * dz;
     dist += FACT1 * g.len;
     return r2 > dist * dist;
+#else
+    // (without the early returns of the reference: |d| > dist on any axis is max |d| > dist, and the wave's lanes never agree on an exit)
+    const double dist = fmax(hm, hsml) + 0.5 * g.len;
+    const double dx = near_img<WRAP>(g.cx - px, box, invbox);
+    const double dy = near_img<WRAP>(g.cy - py, box, invbox);
+    const double dz = near_img<WRAP>(g.cz - pz, box, invbox);
+    const double cmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double d2 = dist + FACT1 * g.len;
+    return (cmax > dist) | (r2 > d2 * d2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -60,7 +87,14 @@ __device__ __forceinline__ double group_sum(double v)
 // latency 4 waves per SIMD do not hide; taking the K topmost ranges of the LIFO at once divides the number of sequential steps
 // for the same node tests.  Lane s tests child s of every range.  The leaves opened go to the group's list, first those of the upper ranges.
 // Returns the new number of list entries.
-template <bool SYM, int K>
+// MERGE (round 4): opened leaves of one child range whose particles are contiguous in tree order (siblings: the children of a split cell
+// hold one or two particles each, gas leaves 2.7 on average) are joined into one list entry of <= 8 particles, so that the candidate tests
+// of phase B run on fuller lanes (k_density 8.4 -> 7.5 ms, k_hydro 9.5 -> 8.8 at 2 x 128^3).  Which sets of siblings fit one entry is a
+// property of the tree (a leaf's NodeLinkB::firstchild, written with the level-ordered copy): all children, a quad or a pair; a set is joined when every
+// existing child of it was opened by this target, its first lane emitting the run.  The candidates are those of the opened leaves and no
+// others, so the reference's counters are unchanged.  (First form: the lanes compared start / count / contiguity with their neighbours
+// s ^ 1, s ^ 2, s ^ 4 at run time - 65 vector instructions per child range against ~20.)
+template <bool SYM, int K, bool MERGE = false, bool WRAP = true>
 __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
                                           const double hsml, const double px, const double py, const double pz, unsigned *llist, int nl, bool &overflow)
 {
@@ -88,13 +122,28 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
         lk[k] = tv.linkB[my[k]];
         hm[k] = SYM ? tv.hmaxB[my[k]] : 0.0;
     }
-    unsigned gl[K], gp[K];
+    unsigned gl[K], gp[K], ent[K];
     bool leaf[K], push[K];
 #pragma unroll
     for(int k = 0; k < K; k++) {
-        const bool in = tst[k] && !cull_node(g[k], hm[k], hsml, px, py, pz, tv.box, invbox);
+        const bool in = tst[k] && !cull_node<WRAP>(g[k], hm[k], hsml, px, py, pz, tv.box, invbox);
         leaf[k] = in && lk[k].pcount > 0;
         push[k] = in && lk[k].pcount <= 0 && lk[k].nchild > 0;
+        ent[k] = ((unsigned)lk[k].pstart << 4) | (unsigned)lk[k].pcount;
+        if(MERGE) {
+            const unsigned h = leaf[k] ? (unsigned)lk[k].firstchild : 0u; // (a leaf's merge hints: NodeLinkB)
+            const unsigned m = (unsigned)((ballot64(leaf[k]) >> gshift) & 0xffull); // the children this target opened as leaves
+            const unsigned x = m ^ ((1u << (r[k] & 15u)) - 1u);                      // existing children that are not among them
+            const unsigned sq = (h >> 4) & 15u, sp = h & 15u;
+            unsigned pcm = leaf[k] ? (unsigned)lk[k].pcount : 0u;
+            pcm = (sp != 0u && (x & (3u << (s & 6))) == 0u) ? ((s & 1) == 0 ? sp : 0u) : pcm;
+            pcm = (sq != 0u && (x & (15u << (s & 4))) == 0u) ? ((s & 3) == 0 ? sq : 0u) : pcm;
+#ifdef NGB_MERGE_OCT // (all children as one run: cannot occur in a tree whose cells are split at their 9th particle)
+            pcm = (((h >> 8) & 15u) != 0u && x == 0u) ? (s == 0 ? ((h >> 8) & 15u) : 0u) : pcm;
+#endif
+            ent[k] = ((unsigned)lk[k].pstart << 4) | pcm;
+            leaf[k] = pcm != 0u;
+        }
         gl[k] = (unsigned)((ballot64(leaf[k]) >> gshift) & 0xffull);
         gp[k] = (unsigned)((ballot64(push[k]) >> gshift) & 0xffull);
     }
@@ -121,7 +170,7 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
 #pragma unroll
     for(int k = 0; k < K; k++) {
         if(leaf[k])
-            llist[nl + __popc(gl[k] & below)] = ((unsigned)lk[k].pstart << 4) | (unsigned)lk[k].pcount;
+            llist[nl + __popc(gl[k] & below)] = ent[k];
         nl += can ? __popc(gl[k]) : 0;
     }
     return nl;

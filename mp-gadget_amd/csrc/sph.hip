@@ -15,6 +15,7 @@
 #include "sph.h"
 #include "ngb_walk.h"
 #include <cmath>
+#include <type_traits>
 
 namespace mpg {
 
@@ -143,6 +144,10 @@ __global__ void __launch_bounds__(256) k_sph_predict(int64_t npart, const int *_
 #define SPH_WALK_K 2 // child ranges per search step (walk_stepk, ngb_walk.h)
 #endif
 
+#ifndef SPH_MERGE
+#define SPH_MERGE true // contiguous opened leaves of a child range joined into one list entry (walk_stepk, ngb_walk.h)
+#endif
+
 struct DensAcc {
     double EgyRho = 0, DhsmlEgy = 0, Rho = 0, DhsmlDensity = 0, Ngb = 0, Div = 0, Rot0 = 0, Rot1 = 0, Rot2 = 0, G0 = 0, G1 = 0, G2 = 0;
 };
@@ -153,13 +158,14 @@ struct DensAcc {
 constexpr int SPH_CBUF = 32; // survivor slots per group (a ring: a power of two); an evaluation is triggered when any group of the wave holds >= 16
 
 // distance test of density: returns whether the kernel evaluation is needed; counts the reference's "ninteractions"
+template <bool WRAP>
 __device__ __forceinline__ bool density_test(const Src4 s, const double px, const double py, const double pz, const double h2, const double HH,
                                              const double box, unsigned &n_int)
 {
     // the distance vector points to 'other': I.Pos - P[other].Pos (treewalk.c:1218-1225)
-    const double d0 = nearest_img(px - s.x, box, 1.0 / box);
-    const double d1 = nearest_img(py - s.y, box, 1.0 / box);
-    const double d2 = nearest_img(pz - s.z, box, 1.0 / box);
+    const double d0 = near_img<WRAP>(px - s.x, box, 1.0 / box);
+    const double d1 = near_img<WRAP>(py - s.y, box, 1.0 / box);
+    const double d2 = near_img<WRAP>(pz - s.z, box, 1.0 / box);
     const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
     if(r2 > h2)
         return false;
@@ -168,12 +174,13 @@ __device__ __forceinline__ bool density_test(const Src4 s, const double px, cons
 }
 
 // density_ngbiter for one neighbour inside the kernel, density.c:451-518
+template <bool WRAP>
 __device__ __forceinline__ void density_eval(const Src4 s, const Aux4 o, const double px, const double py, const double pz, const DKernel &kern,
                                              const double kvol, const double *ivel, const DensityCtl &C, const double box, DensAcc &a)
 {
-    const double d0 = nearest_img(px - s.x, box, 1.0 / box);
-    const double d1 = nearest_img(py - s.y, box, 1.0 / box);
-    const double d2 = nearest_img(pz - s.z, box, 1.0 / box);
+    const double d0 = near_img<WRAP>(px - s.x, box, 1.0 / box);
+    const double d1 = near_img<WRAP>(py - s.y, box, 1.0 / box);
+    const double d2 = near_img<WRAP>(pz - s.z, box, 1.0 / box);
     const double r2 = d0 * d0 + d1 * d1 + d2 * d2;
 #ifdef SPH_FAST_DIV
     const double rinv_d = r2 > 0 ? rsqrt_fast(r2) : 0.0;
@@ -362,7 +369,7 @@ __device__ __forceinline__ void density_finish(const TreeView &tv, const SphView
 
 // One density pass over the current queue: treewalk_visit_nolist_ngbiter + density_ngbiter + density_reduce +
 // density_postprocess + density_check_neighbours.  Targets that are not done are appended to `redo`.
-__global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_density_params P,
+__global__ void __launch_bounds__(256, 4) k_density(const TreeView tv, const SphView A, const mpg_sph_times T, const mpg_density_params P,
                                                  const DensityCtl C, const Aux4 *__restrict__ aux, const int *__restrict__ queue,
                                                  int64_t nqueue, int *__restrict__ redo, unsigned *__restrict__ nredo,
                                                  unsigned long long *__restrict__ stats, unsigned *__restrict__ err)
@@ -408,6 +415,9 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         sp = 1;
     }
     bool overflow = false;
+    // the search and the pair loops, with (WRAP) or without NEAREST(): see interior_wave, ngb_walk.h
+    auto loops = [&](auto wrap_tag) {
+    constexpr bool WRAP = decltype(wrap_tag)::value;
     for(;;) {
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
             const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<false, SPH_WALK_K>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
+            nl = walk_stepk<false, SPH_WALK_K, SPH_MERGE, WRAP>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
             if(ballot64(overflow) != 0)
                 break;
         }
@@ -437,13 +447,13 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
             bool keep = false;
             if(s < pc) {
                 n_cand++;
-                keep = density_test(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
+                keep = density_test<WRAP>(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
             }
             cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
             if(ballot64(cnt >= 16) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
-                    density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
+                    density_eval<WRAP>(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
                     head = (head + 8) & (SPH_CBUF - 1);
                     cnt -= 8;
                 }
@@ -455,18 +465,25 @@ __global__ void __launch_bounds__(256) k_density(const TreeView tv, const SphVie
         if(ballot64(sp > 0) == 0)
             break;
     }
+    if(ballot64(overflow) != 0)
+        return;
+    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
+        if(s < cnt) {
+            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
+            density_eval<WRAP>(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
+        }
+        head = (head + 8) & (SPH_CBUF - 1);
+        cnt = cnt > 8 ? cnt - 8 : 0;
+    }
+    };
+    if(interior_wave(valid, px, py, pz, hsml, tv.box))
+        loops(std::false_type{});
+    else
+        loops(std::true_type{});
     if(ballot64(overflow) != 0) {
         if(lane == 0)
             atomicExch(err, 1u);
         return;
-    }
-    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
-        if(s < cnt) {
-            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
-            density_eval(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
-        }
-        head = (head + 8) & (SPH_CBUF - 1);
-        cnt = cnt > 8 ? cnt - 8 : 0;
     }
     density_finish(tv, A, P, C, a, valid, s, lane, i, ty, hsml, redo, nredo, stats, n_int, n_cand);
 }
@@ -642,13 +659,14 @@ struct HydroAcc {
 };
 
 // symmetric distance test (treewalk.c:1218-1232) and the pair condition of hydro_ngbiter (hydra.c:330-338): is this a pair?
+template <bool WRAP>
 __device__ __forceinline__ bool hydro_test(const Src4 s, const double hsml_j, const HydroTarget &t, const DKernel &kernel_i, const HydroCtl &C,
                                            const double box)
 {
     const double hh = fmax(hsml_j, t.me.hsml);
-    const double d0 = nearest_img(t.px - s.x, box, 1.0 / box);
-    const double d1 = nearest_img(t.py - s.y, box, 1.0 / box);
-    const double d2 = nearest_img(t.pz - s.z, box, 1.0 / box);
+    const double d0 = near_img<WRAP>(t.px - s.x, box, 1.0 / box);
+    const double d1 = near_img<WRAP>(t.py - s.y, box, 1.0 / box);
+    const double d2 = near_img<WRAP>(t.pz - s.z, box, 1.0 / box);
     const double rsq = d0 * d0 + d1 * d1 + d2 * d2;
     if(rsq > hh * hh)
         return false;
@@ -657,13 +675,14 @@ __device__ __forceinline__ bool hydro_test(const Src4 s, const double hsml_j, co
 }
 
 // hydro_ngbiter for one pair, hydra.c:296-512
+template <bool WRAP>
 __device__ __forceinline__ void hydro_eval(const Src4 s, const HydroSrc &o, const HydroTarget &t, const DKernel &kernel_i, const HydroCtl &C,
                                            const mpg_hydro_params &HP, const double box, HydroAcc &a)
 {
     const HydroSrc &me = t.me;
-    const double d0 = nearest_img(t.px - s.x, box, 1.0 / box);
-    const double d1 = nearest_img(t.py - s.y, box, 1.0 / box);
-    const double d2 = nearest_img(t.pz - s.z, box, 1.0 / box);
+    const double d0 = near_img<WRAP>(t.px - s.x, box, 1.0 / box);
+    const double d1 = near_img<WRAP>(t.py - s.y, box, 1.0 / box);
+    const double d2 = near_img<WRAP>(t.pz - s.z, box, 1.0 / box);
     const double rsq = d0 * d0 + d1 * d1 + d2 * d2;
 #ifdef SPH_FAST_DIV
     // (rsq > 0: hydro_test; the quotients of this function by reciprocals - see rcp_fast)
@@ -822,6 +841,8 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
         sp = 1;
     }
     bool overflow = false;
+    auto loops = [&](auto wrap_tag) { // (see k_density)
+    constexpr bool WRAP = decltype(wrap_tag)::value;
     for(;;) {
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
@@ -829,7 +850,11 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
             const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<true, SPH_WALK_K>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
+            nl = walk_stepk<true, SPH_WALK_K, SPH_MERGE, WRAP>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
+#ifdef SPH_HIST
+            if(lane == 0)
+                atomicAdd(&stats[7], 1ull);
+#endif
             if(ballot64(overflow) != 0)
                 break;
         }
@@ -850,16 +875,22 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
             const Src4 cand_n = tv.src[ps_n + (s < pc_n ? s : 0)];
             const double cand_hn = hsml_t[ps_n + (s < pc_n ? s : 0)];
             bool keep = false;
+#ifdef SPH_HIST // experiment: list entries by particle count (1-2, 3-4, 5-6, 7-8), phase-B iterations and walk steps per wave
+            if(s == 0 && has)
+                atomicAdd(&stats[2 + (pc - 1) / 2], 1ull);
+            if(lane == 0)
+                atomicAdd(&stats[6], 1ull);
+#endif
             if(s < pc) {
                 n_cand++;
-                keep = hydro_test(cand, cand_h, t, kernel_i, C, tv.box);
+                keep = hydro_test<WRAP>(cand, cand_h, t, kernel_i, C, tv.box);
                 n_pair += keep ? 1u : 0u;
             }
             cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
             if(ballot64(cnt >= 16) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
-                    hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
+                    hydro_eval<WRAP>(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
                     head = (head + 8) & (SPH_CBUF - 1);
                     cnt -= 8;
                 }
@@ -872,18 +903,26 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
         if(ballot64(sp > 0) == 0)
             break;
     }
+    if(ballot64(overflow) != 0)
+        return;
+    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
+        if(s < cnt) {
+            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
+            hydro_eval<WRAP>(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
+        }
+        head = (head + 8) & (SPH_CBUF - 1);
+        cnt = cnt > 8 ? cnt - 8 : 0;
+    }
+    };
+    // symmetric search: the radius of a cull is max(node hmax, Hsml) <= max(root hmax, Hsml)
+    if(interior_wave(valid, t.px, t.py, t.pz, fmax(t.me.hsml, tv.hmaxB[0]), tv.box))
+        loops(std::false_type{});
+    else
+        loops(std::true_type{});
     if(ballot64(overflow) != 0) {
         if(lane == 0)
             atomicExch(err, 1u);
         return;
-    }
-    while(ballot64(cnt > 0) != 0) { // drain the survivor buffers
-        if(s < cnt) {
-            const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
-            hydro_eval(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
-        }
-        head = (head + 8) & (SPH_CBUF - 1);
-        cnt = cnt > 8 ? cnt - 8 : 0;
     }
     hydro_finish(A, C, a, t, valid, s, lane, i, stats, n_cand, n_pair);
 }
@@ -1069,6 +1108,14 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
     MPG_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipMemcpyAsync(&e, ctr.p + 7, sizeof(e), hipMemcpyDeviceToHost, st));
     MPG_HIP(hipStreamSynchronize(st));
+#ifdef SPH_HIST
+    {
+        unsigned long long h8[8];
+        MPG_HIP(hipMemcpy(h8, stats.p, sizeof(h8), hipMemcpyDeviceToHost));
+        fprintf(stderr, "SPH_HIST hydro: targets %lld cand %llu pairs %llu entries[1-2,3-4,5-6,7-8] %llu %llu %llu %llu waveiters %llu wavesteps %llu\n", (long long)nt,
+                h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7]);
+    }
+#endif
     MPG_CHECK(e == 0, "hydro_force: neighbour-search stack overflow (tree deeper than the walk supports)");
     last_candidates = (int64_t)hs[0];
     last_interactions = (int64_t)hs[1];

@@ -411,13 +411,40 @@ __global__ void __launch_bounds__(256) k_build_level_order(int64_t nnodes, int64
     if(lk.pcount == 0 && j + 1 < nnodes) {
         o.firstchild = (int)bfs_of_dfs[j + 1];
         int c = (int)j + 1, n = 0;
+        int pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // particles of child n if it is a leaf
         do {
+            pc[n] = link[c].pcount;
             n++;
             c = link[c].sibling;
         } while(c != lk.sibling && n < 8);
         o.nchild = n;
+        // the merge hints of the leaves among the children (NodeLinkB::firstchild of a leaf): sets of sibling leaves that fit one list
+        // entry of the neighbour search.  (A leaf's own thread below writes its other three words only.)
+        auto run = [&](const int c0, const int c1) -> unsigned { // children c0 .. c1-1: their particle count if they can be joined
+            int sum = 0, have = 0;
+            for(int k = c0; k < c1 && k < n; k++) {
+                if(pc[k] <= 0)
+                    return 0u;
+                sum += pc[k];
+                have++;
+            }
+            return (have >= 2 && sum <= 8) ? (unsigned)sum : 0u;
+        };
+        const unsigned oct = run(0, 8);
+        for(int k = 0; k < n; k++)
+            if(pc[k] > 0)
+                linkB[o.firstchild + k].firstchild = (int)(run(k & 6, (k & 6) + 2) | (run(k & 4, (k & 4) + 4) << 4) | (oct << 8));
     }
-    linkB[i] = o;
+    if(lk.pcount > 0 && i > 0) { // a leaf below the root: its first word is its parent's to write
+        linkB[i].nchild = 0;
+        linkB[i].pstart = o.pstart;
+        linkB[i].pcount = o.pcount;
+    }
+    else {
+        if(lk.pcount > 0)
+            o.firstchild = 0; // (the root as a leaf: no siblings)
+        linkB[i] = o;
+    }
     if(hmaxB)
         hmaxB[i] = hmax ? hmax[j] : 0.0;
 }

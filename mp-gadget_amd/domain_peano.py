@@ -248,7 +248,8 @@ class PeanoDomain:
         nlive = int(live.sum().item())
         order = order[:nlive]
         counts = [int(c) for c in self.send_counts]
-        assert sum(counts) == nlive
+        assert sum(counts) == nlive, "send counts %r sum to %d, live rows %d of %d, rows per task %r" % (
+            counts, sum(counts), nlive, int(task.shape[0]), torch.bincount(task[live], minlength=self.world).tolist())
         if self.world == 1:
             return [c[order] for c in columns]
         allc = rows.count_matrix(counts, self.world, columns[0].device if dist.get_backend(self.group) == "nccl" else torch.device("cpu"), self.group)

@@ -77,6 +77,20 @@ def run_ranks(cmd, env, log_path, timeout=900):
     if r.returncode != 0:
         with open(str(log_path) + ".failed.log", "w") as f:
             f.write("cmd: %s\n---- stdout ----\n%s\n---- stderr ----\n%s\n" % (" ".join(cmd), r.stdout, r.stderr))
+        # Several ranks sharing ONE GPU fail once in ~50 runs in the set-up before any kernel of the test proper (DESIGN section 4:
+        # a worker SIGABRT in rounds 2-3, a count mismatch in the decomposition on a box's first multi-process use in round 4).
+        # The suite runs under -x: ONE repeat, and the first failure is kept in gpurun_out/flake/RETRIED.log and in a warning, so
+        # that a repeat is never silent.  A failure that repeats fails the test.
+        import warnings
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            os.makedirs(os.path.join(root, "gpurun_out", "flake"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "flake", "RETRIED.log"), "a") as f:
+                f.write("cmd: %s\nrc %d\n---- stderr (tail) ----\n%s\n\n" % (" ".join(cmd), r.returncode, r.stderr[-6000:]))
+        except OSError:
+            pass
+        warnings.warn("multi-rank helper failed once and was repeated: %s" % " ".join(cmd[-3:]))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     return r
 
