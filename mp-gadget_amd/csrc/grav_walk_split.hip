@@ -25,6 +25,8 @@
 // (Rounds 1-2 built the lists with 8 lanes per target - k_walk_lists, k_walk_lists2: DESIGN.md 3.2 - retired in round 3.)
 #include "grav_walk.h"
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 #include <type_traits>
 
 namespace mpg {
@@ -41,6 +43,10 @@ namespace {
 #define MPG_EVAL_BLOCKS_LONG 6
 #endif
 
+
+#ifdef MPG_LEAF_HIST
+__device__ unsigned long long g_leaf_hist[16];
+#endif
 
 __device__ __forceinline__ double rsqrt_nr(double x)
 {
@@ -469,6 +475,10 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                     T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
                     T.c_used[t] += (unsigned)kn;
                     c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl) ? (unsigned)lk.pcount : 0u;
+#ifdef MPG_LEAF_HIST // experiment: opened leaves by particle count
+                    if(__builtin_amdgcn_inverse_ballot_w64(bl))
+                        atomicAdd(&g_leaf_hist[lk.pcount], 1ull);
+#endif
                 }
                 // (the 8 targets' tests are independent: left alone, hipcc interleaves them and runs out of registers)
                 __builtin_amdgcn_sched_barrier(0);
@@ -870,8 +880,18 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         int2 *counts = ws.split_counts.p + (size_t)b * counts_sz;
         if(overlap && i >= 2)
             MPG_HIP(hipStreamWaitEvent(sl, ws.ev_eval[b], 0)); // the evaluation that read this buffer two slices ago is done
+        // MPG_SPLIT_TIME=1: the two kernels timed one by one with HIP events (a diagnostic: two host waits per slice)
+        static const bool split_time = getenv("MPG_SPLIT_TIME") != nullptr;
+        hipEvent_t te[3] = {nullptr, nullptr, nullptr};
+        if(split_time) {
+            for(auto &e : te)
+                MPG_HIP(hipEventCreate(&e));
+            MPG_HIP(hipEventRecord(te[0], sl));
+        }
         hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks, cpw)), dim3(256), 0, sl, tv, gp, io,
                            lists, counts, cap, s0, ns, ws.ctr.p, ws.split_ovf.p);
+        if(split_time)
+            MPG_HIP(hipEventRecord(te[1], sl));
         if(overlap) {
             MPG_HIP(hipEventRecord(ws.ev_lists[b], sl));
             MPG_HIP(hipStreamWaitEvent(st, ws.ev_lists[b], 0));
@@ -880,6 +900,16 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
                            ns);
         if(overlap)
             MPG_HIP(hipEventRecord(ws.ev_eval[b], st));
+        if(split_time) {
+            MPG_HIP(hipEventRecord(te[2], st));
+            MPG_HIP(hipEventSynchronize(te[2]));
+            float ml = 0, me = 0;
+            MPG_HIP(hipEventElapsedTime(&ml, te[0], te[1]));
+            MPG_HIP(hipEventElapsedTime(&me, te[1], te[2]));
+            fprintf(stderr, "SPLIT_TIME targets %lld lists %.3f ms eval %.3f ms\n", (long long)ns, ml, me);
+            for(auto &e : te)
+                MPG_HIP(hipEventDestroy(e));
+        }
     }
     MPG_HIP(hipGetLastError());
 }
@@ -924,6 +954,18 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
         MPG_HIP(hipMemcpyAsync(ctl, ws.ctr.p, sizeof(ctl), hipMemcpyDeviceToHost, st));
         MPG_HIP(hipStreamSynchronize(st));
         MPG_CHECK(ctl[1] == 0, "short-range walk (list construction) aborted by its loop guard (corrupt tree?)");
+#ifdef MPG_LEAF_HIST
+        if(count) {
+            unsigned long long h[16];
+            MPG_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_leaf_hist), sizeof(h)));
+            fprintf(stderr, "LEAF_HIST targets %lld opened leaves by count 1..8:", (long long)io.ntargets);
+            for(int k = 1; k <= 8; k++)
+                fprintf(stderr, " %llu", h[k]);
+            fprintf(stderr, "\n");
+            memset(h, 0, sizeof(h));
+            MPG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_hist), h, sizeof(h)));
+        }
+#endif
         // More than a fifth of the targets did not fit their lists (the first walk of a clustered set with the initial capacity):
         // walking them all with the fallback kernel costs seconds (256^3 clustered set: 3.3 s), a second pass of this kernel with
         // four times the capacity a fraction of one.  (Not when the interaction counters are on: they would count twice.)
