@@ -155,7 +155,12 @@ struct DensAcc {
 // Candidate handling is split in two so that the expensive part runs with full lanes: every candidate of an opened leaf
 // gets the distance test (treewalk.c:1218-1232; cheap, ~1/3 pass), the survivors are compacted into a small per-group
 // buffer in LDS, and the kernel evaluation (density_ngbiter / hydro_ngbiter) is run 8 survivors at a time.
-constexpr int SPH_CBUF = 32; // survivor slots per group (a ring: a power of two); an evaluation is triggered when any group of the wave holds >= 16
+#ifndef SPH_TRIG
+// survivors in some group of the wave that trigger an evaluation (<= SPH_CBUF - 8: the next append must fit).  24 since round 4 (16 before): the
+// later the trigger, the more of the wave's 8 groups hold a full 8 survivors when it comes (k_hydro 8.4 -> 7.9 ms; k_density unchanged; 8: 10.2)
+#define SPH_TRIG 24
+#endif
+constexpr int SPH_CBUF = 32; // survivor slots per group (a ring: a power of two)
 
 // distance test of density: returns whether the kernel evaluation is needed; counts the reference's "ninteractions"
 template <bool WRAP>
@@ -450,7 +455,7 @@ __global__ void __launch_bounds__(256, 4) k_density(const TreeView tv, const Sph
                 keep = density_test<WRAP>(cand, px, py, pz, h2, kern.HH, tv.box, n_int);
             }
             cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
-            if(ballot64(cnt >= 16) != 0) {
+            if(ballot64(cnt >= SPH_TRIG) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
                     density_eval<WRAP>(tv.src[sidx], aux[sidx], px, py, pz, kern, kvol, ivel, C, tv.box, a);
@@ -887,7 +892,7 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
                 n_pair += keep ? 1u : 0u;
             }
             cnt = cbuf_push(cbuf, head, cnt, keep, ps + s, s, gshift);
-            if(ballot64(cnt >= 16) != 0) {
+            if(ballot64(cnt >= SPH_TRIG) != 0) {
                 if(cnt >= 8) {
                     const int sidx = cbuf[(head + s) & (SPH_CBUF - 1)];
                     hydro_eval<WRAP>(tv.src[sidx], hs[sidx], t, kernel_i, C, HP, tv.box, a);
