@@ -41,6 +41,7 @@ static inttime_t TableTi = -1;     /* (Ti_Current, &P[0], NumPart) of that epoch
 static const void *TableBase;
 static int64_t TableNumPart = -1;
 static int TableDirty = 1;         /* mpg_shim_particles_changed() */
+static uint64_t TableSample;      /* table_sample_hash() of the table the epoch was declared for */
 static DomainDecomp *Domain;       /* the run's decomposition object */
 static uint64_t DomainHash;        /* of what mpg_dist_set_domain last received ... */
 static double DomainMargin;        /* ... with this margin */
@@ -117,6 +118,28 @@ static uint64_t domain_hash(const DomainDecomp *dd)
     return h;
 }
 
+/* FNV-1a over the IDs and positions of 64 records spread over the table: a reorder or an exchange inside one
+ * Ti_Current that keeps &P[0] and NumPart (the second domain_decompose_full of the first step, fof_fof's exchange) changes it; a caller
+ * that knows can still say so at once with mpg_shim_particles_changed() */
+static uint64_t table_sample_hash(void)
+{
+    uint64_t h = 1469598103934665603ull;
+    const int64_t n = PartManager->NumPart, stride = n > 64 ? n / 64 : 1;
+    int64_t i;
+    int k;
+#define MIX(x) (h = (h ^ (uint64_t)(x)) * 1099511628211ull)
+    for(i = 0; i < n; i += stride) {
+        MIX(P[i].ID);
+        for(k = 0; k < 3; k++) {
+            uint64_t b;
+            memcpy(&b, &P[i].Pos[k], sizeof(b));
+            MIX(b);
+        }
+    }
+#undef MIX
+    return h;
+}
+
 static void push_domain(double BoxSize, double margin)
 {
     const DomainDecomp *dd = Domain;
@@ -143,12 +166,20 @@ void mpg_shim_sync(inttime_t Ti_Current, double Time, double BoxSize, double mar
     /* ---- the particle table ---- */
     if(Ti_Current < 0 && TableTi >= 0 && Time == get_atime(TableTi))
         Ti_Current = TableTi; /* gravpm_force of the step whose density() / grav_short_tree() already came by (run.c:356,522) */
-    if(TableDirty || Ti_Current < 0 || Ti_Current != TableTi || TableBase != (const void *)P || TableNumPart != PartManager->NumPart) {
-        Epoch++;
-        TableTi = Ti_Current;
-        TableBase = (const void *)P;
-        TableNumPart = PartManager->NumPart;
-        TableDirty = 0;
+    {
+        const uint64_t sample = table_sample_hash();
+        int changed = TableDirty || Ti_Current < 0 || Ti_Current != TableTi || TableBase != (const void *)P || TableNumPart != PartManager->NumPart ||
+                      sample != TableSample;
+        if(NTask > 1) /* (the ghost plan and the local trees are rebuilt collectively: every rank takes the same decision) */
+            MPI_Allreduce(MPI_IN_PLACE, &changed, 1, MPI_INT, MPI_MAX, Comm);
+        if(changed) {
+            Epoch++;
+            TableTi = Ti_Current;
+            TableBase = (const void *)P;
+            TableNumPart = PartManager->NumPart;
+            TableSample = sample;
+            TableDirty = 0;
+        }
     }
     ck(mpg_set_particle_epoch(E, Epoch));
     /* ---- the decomposition (several ranks) ---- */
