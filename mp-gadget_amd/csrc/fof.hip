@@ -26,6 +26,10 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#ifndef FOF_MERGE
+#define FOF_MERGE true // sibling leaves that a target opens together as one list entry (walk_stepk<MERGE>, ngb_walk.h)
+#endif
+
 namespace mpg {
 
 namespace {
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(256) k_fof_walk(const TreeView tv, const doubl
             const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<false, 2>(tv, stack, sp, go, s, gshift, radius, px, py, pz, llist, nl, overflow); // (two child ranges per step: ngb_walk.h)
+            nl = walk_stepk<false, 2, FOF_MERGE>(tv, stack, sp, go, s, gshift, radius, px, py, pz, llist, nl, overflow); // (two child ranges per step, sibling leaves joined: ngb_walk.h)
             if(ballot64(overflow) != 0)
                 break;
         }
