@@ -1456,8 +1456,10 @@ int mpg_dist_gravity_step(mpg_dist *d, int64_t n_own, const double *d_pos, const
             perr = ex.what();
         }
         worker.join();
-        MPG_CHECK(perr.empty(), perr);
-        MPG_CHECK(werr.empty(), werr);
+        // (both failures are reported; ADVICE round 3.  The invariant the two threads rely on: tree_build_local touches the engine's tree,
+        // its particle binding (eng->n, d_pos, tree_mask) and d->tree_stream only, pm_step touches the mesh, the slab buffers, the
+        // communicator and eng->stream only, and neither reads what the other writes before the join above.)
+        MPG_CHECK(perr.empty() && werr.empty(), perr.empty() ? werr : (werr.empty() ? perr : perr + " | and the tree build beside it: " + werr));
         const double t2 = now_ms();
         d->times[0] = t2 - t1; // PM with the tree build beside it
         d->times[4] = t_tree;  // ... of which the tree build took this long on its stream
