@@ -433,6 +433,15 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         // appends CHECKED one by one.
         const unsigned long long m_leafnode = __builtin_amdgcn_ballot_w64(lk.pcount > 0);
         const unsigned long long m_intnode = ~m_leafnode & __builtin_amdgcn_ballot_w64(lk.nchild > 0);
+#ifndef MPG_NO_SINGLES_AS_NODES
+        // An OPENED leaf of one particle is listed with the nodes (round 4): its moment record is that particle (centre of mass = its position
+        // to a rounding, the same softening: apply_accn_to_output treats both alike), and there it shares an evaluation step with 7 other
+        // sources instead of taking one alone - 201 M of the 1916 M opened leaves per walk at 256^3 (a cell split at its 9th particle leaves
+        // children of one or two).  The decision stays the reference's and is counted as such (a pair interaction, not a node used).
+        const unsigned long long m_single = __builtin_amdgcn_ballot_w64(lk.pcount == 1);
+#else
+        const unsigned long long m_single = 0ull;
+#endif
         auto pass = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
@@ -450,8 +459,10 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 unsigned long long m_discard, m_open, m_wrap;
                 node_test_masks<MODE>(gp, g, mom, false, false, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
                 const unsigned long long keep = m_act & ~m_discard;
-                const unsigned long long bn = keep & ~m_open;              // used unopened
-                const unsigned long long bl = keep & m_open & m_leafnode;  // opened leaves
+                const unsigned long long bn0 = keep & ~m_open;              // used unopened
+                const unsigned long long bl0 = keep & m_open & m_leafnode;  // opened leaves
+                const unsigned long long bn = bn0 | (bl0 & m_single);       // ... entries of the node list (with the opened one-particle leaves)
+                const unsigned long long bl = bl0 & ~m_single;              // ... entries of the leaf list
                 const unsigned long long bpush = keep & m_open & m_intnode;
                 const int kl = __builtin_popcountll(bl), kn = __builtin_popcountll(bn);
                 if(CHECKED && T.nleaf[t] + T.nnode[t] + kl + kn > cap) { // the lists of target t are full: the fallback kernel walks it again
@@ -473,8 +484,8 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                     wmask |= m_wrap & (bl | bn);
                 if(COUNT) {
                     T.c_vis[t] += (unsigned)__builtin_popcountll(m_act);
-                    T.c_used[t] += (unsigned)kn;
-                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl) ? (unsigned)lk.pcount : 0u;
+                    T.c_used[t] += (unsigned)__builtin_popcountll(bn0);
+                    c_pp[t] += __builtin_amdgcn_inverse_ballot_w64(bl0) ? (unsigned)lk.pcount : 0u;
 #ifdef MPG_LEAF_HIST // experiment: opened leaves by particle count
                     if(__builtin_amdgcn_inverse_ballot_w64(bl))
                         atomicAdd(&g_leaf_hist[lk.pcount], 1ull);
