@@ -58,6 +58,22 @@ __device__ __forceinline__ bool cull_node(const NodeGeo &g, double hm, double hs
 #endif
 }
 
+// The same test with its two comparisons taken as lane masks (walk_stepk): the ballot of a bare comparison is the comparison's own result
+// register, and the boolean algebra of the step runs once per wave on the scalar unit (as in k_walk_lists8).  Written with per-lane
+// booleans, hipcc materialised every `a && b` that went into a ballot as v_cndmask 0/1 + v_cmp again.
+template <bool WRAP>
+__device__ __forceinline__ unsigned long long cull_mask(const NodeGeo &g, double hm, double hsml, double px, double py, double pz, double box, double invbox)
+{
+    const double dist = fmax(hm, hsml) + 0.5 * g.len;
+    const double dx = near_img<WRAP>(g.cx - px, box, invbox);
+    const double dy = near_img<WRAP>(g.cy - py, box, invbox);
+    const double dz = near_img<WRAP>(g.cz - pz, box, invbox);
+    const double cmax = fmax(fmax(fabs(dx), fabs(dy)), fabs(dz));
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double d2 = dist + FACT1 * g.len;
+    return __builtin_amdgcn_ballot_w64(cmax > dist) | __builtin_amdgcn_ballot_w64(r2 > d2 * d2);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Group-cooperative neighbour search (both SPH loops).  A wave is 8 groups of 8 lanes; a group owns ONE target and walks
 // the level-ordered copy of the tree (children of a node contiguous): one step pops a child range from the group's LIFO in
@@ -123,29 +139,37 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
         hm[k] = SYM ? tv.hmaxB[my[k]] : 0.0;
     }
     unsigned gl[K], gp[K], ent[K];
-    bool leaf[K], push[K];
+    unsigned long long m_leaf[K], m_push[K]; // lane masks: the children opened as leaves / whose own children are pushed
 #pragma unroll
     for(int k = 0; k < K; k++) {
+#ifndef NGB_NO_MASKS
+        const unsigned long long m_in = __builtin_amdgcn_ballot_w64(tst[k]) & ~cull_mask<WRAP>(g[k], hm[k], hsml, px, py, pz, tv.box, invbox);
+        const unsigned long long m_pc = __builtin_amdgcn_ballot_w64(lk[k].pcount > 0);
+        m_leaf[k] = m_in & m_pc;
+        m_push[k] = m_in & ~m_pc & __builtin_amdgcn_ballot_w64(lk[k].nchild > 0);
+#else // (experiment switch: per-lane booleans, as until round 4)
         const bool in = tst[k] && !cull_node<WRAP>(g[k], hm[k], hsml, px, py, pz, tv.box, invbox);
-        leaf[k] = in && lk[k].pcount > 0;
-        push[k] = in && lk[k].pcount <= 0 && lk[k].nchild > 0;
+        m_leaf[k] = ballot64(in && lk[k].pcount > 0);
+        m_push[k] = ballot64(in && lk[k].pcount <= 0 && lk[k].nchild > 0);
+#endif
         ent[k] = ((unsigned)lk[k].pstart << 4) | (unsigned)lk[k].pcount;
         if(MERGE) {
-            const unsigned h = leaf[k] ? (unsigned)lk[k].firstchild : 0u; // (a leaf's merge hints: NodeLinkB)
-            const unsigned m = (unsigned)((ballot64(leaf[k]) >> gshift) & 0xffull); // the children this target opened as leaves
-            const unsigned x = m ^ ((1u << (r[k] & 15u)) - 1u);                      // existing children that are not among them
+            const bool lf = __builtin_amdgcn_inverse_ballot_w64(m_leaf[k]);
+            const unsigned h = lf ? (unsigned)lk[k].firstchild : 0u;                  // (a leaf's merge hints: NodeLinkB)
+            const unsigned m = (unsigned)((m_leaf[k] >> gshift) & 0xffull);           // the children this target opened as leaves
+            const unsigned x = m ^ ((1u << (r[k] & 15u)) - 1u);                       // existing children that are not among them
             const unsigned sq = (h >> 4) & 15u, sp = h & 15u;
-            unsigned pcm = leaf[k] ? (unsigned)lk[k].pcount : 0u;
+            unsigned pcm = lf ? (unsigned)lk[k].pcount : 0u;
             pcm = (sp != 0u && (x & (3u << (s & 6))) == 0u) ? ((s & 1) == 0 ? sp : 0u) : pcm;
             pcm = (sq != 0u && (x & (15u << (s & 4))) == 0u) ? ((s & 3) == 0 ? sq : 0u) : pcm;
 #ifdef NGB_MERGE_OCT // (all children as one run: cannot occur in a tree whose cells are split at their 9th particle)
             pcm = (((h >> 8) & 15u) != 0u && x == 0u) ? (s == 0 ? ((h >> 8) & 15u) : 0u) : pcm;
 #endif
             ent[k] = ((unsigned)lk[k].pstart << 4) | pcm;
-            leaf[k] = pcm != 0u;
+            m_leaf[k] = __builtin_amdgcn_ballot_w64(pcm != 0u);
         }
-        gl[k] = (unsigned)((ballot64(leaf[k]) >> gshift) & 0xffull);
-        gp[k] = (unsigned)((ballot64(push[k]) >> gshift) & 0xffull);
+        gl[k] = (unsigned)((m_leaf[k] >> gshift) & 0xffull);
+        gp[k] = (unsigned)((m_push[k] >> gshift) & 0xffull);
     }
     const int taken = can ? (sp < take ? sp : take) : 0;
     const int base = sp - taken;
@@ -160,7 +184,7 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
         int at = base;
 #pragma unroll
         for(int k = K - 1; k >= 0; k--) {
-            if(push[k])
+            if(__builtin_amdgcn_inverse_ballot_w64(m_push[k]))
                 stack[at + __popc(gp[k] & below)] = ((unsigned)lk[k].firstchild << 4) | (unsigned)lk[k].nchild;
             at += __popc(gp[k]);
         }
@@ -169,7 +193,7 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
         sp = base + npush;
 #pragma unroll
     for(int k = 0; k < K; k++) {
-        if(leaf[k])
+        if(__builtin_amdgcn_inverse_ballot_w64(m_leaf[k]))
             llist[nl + __popc(gl[k] & below)] = ent[k];
         nl += can ? __popc(gl[k]) : 0;
     }
