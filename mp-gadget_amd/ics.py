@@ -128,6 +128,44 @@ def s_clust(n, box=8.0, seed=0):
     return pos, np.ones(N, dtype=np.float32), box
 
 
+ZEL_TORCH_MIN = 320  # s_zel: grids from this size on are displaced on the GPU when one is there (tests and golden sets are smaller)
+
+
+def _zel_positions_torch(n, wn, box, rms_disp, index):
+    """s_zel's displacement field and positions with torch.fft on the current GPU; None without torch / a GPU"""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+    except ImportError:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f8 = torch.float64
+    sp = box / n
+    dk = torch.fft.rfftn(torch.from_numpy(wn).to(dev))
+    k1 = torch.fft.fftfreq(n, 1.0 / n, dtype=f8, device=dev)
+    kz = torch.arange(n // 2 + 1, dtype=f8, device=dev)
+    K = (k1[:, None, None], k1[None, :, None], kz[None, None, :])
+    k2 = K[0] * K[0] + K[1] * K[1] + K[2] * K[2]
+    k2[0, 0, 0] = 1.0
+    dk = dk * k2 ** (index / 4.0)
+    dk[0, 0, 0] = 0
+    pos = torch.empty(n ** 3, 3, dtype=f8, device=dev)
+    for a in range(3):
+        pos[:, a] = torch.fft.irfftn(1j * K[a] / k2 * dk, s=(n, n, n), dim=(0, 1, 2)).reshape(-1)
+    del dk, k2
+    pos *= rms_disp / torch.sqrt(torch.mean(pos ** 2))
+    idx = torch.arange(n ** 3, dtype=torch.int64, device=dev)
+    for a, q in enumerate((idx // (n * n), (idx // n) % n, idx % n)):
+        pos[:, a] = torch.remainder((q.to(f8) + 0.5 + pos[:, a]) * sp, box)
+    del idx
+    pos[pos <= 0] += box   # positions live in (0, Box] (drift.c:76-79)
+    out = pos.cpu().numpy()
+    del pos
+    torch.cuda.empty_cache()
+    return out
+
+
 def s_zel(n, box=None, seed=181170, rms_disp=0.5, index=-2.0):
     """Zel'dovich displaced grid: x = q + psi(q), psi_k = i k/k^2 delta_k, delta_k Gaussian with P(k) ~ k^index,
     normalised so the per-axis rms displacement is `rms_disp` grid spacings."""
@@ -136,6 +174,13 @@ def s_zel(n, box=None, seed=181170, rms_disp=0.5, index=-2.0):
     sp = box / n
     rng = np.random.RandomState(seed)
     wn = rng.standard_normal((n, n, n))
+    if n >= ZEL_TORCH_MIN:
+        # the sets of the multi-GPU lines (320^3 ... 512^3, generated by EVERY rank) and of --size 512: the same construction with the
+        # transforms on this process's GPU (numpy's single-threaded FFTs take minutes at 512^3; 8 ranks of a node do them side by side).
+        # Same white noise, same formulas; the positions differ from the numpy form by the rounding of another FFT.
+        pos = _zel_positions_torch(n, wn, box, rms_disp, index)
+        if pos is not None:
+            return pos, np.ones(n ** 3, dtype=np.float32), box
     dk = np.fft.rfftn(wn)
     k1 = np.fft.fftfreq(n, 1.0 / n)
     kz = np.arange(n // 2 + 1, dtype=np.float64)
