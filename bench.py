@@ -1328,8 +1328,8 @@ def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
     group of cores of one socket with its data first-touched there.  Bounded sample: `sample` targets CONTIGUOUS IN MORTON ORDER
     (the reference walks its particles in Peano-Hilbert order), cut into P contiguous shares; every process holds the tree of all
     particles (so that the walk of its share is the reference's walk) and also times the tree of its own 1/P of the particles, the
-    tree a reference rank builds.  value = N / (tree of an own share + median walk time scaled from the sample to N + the five 3-D FFTs of
-    the PM step on the same cores); the rest of the PM part (CIC, transfer functions) is left out, which favours the CPU.  Round 2 ran ONE process over all cores with the arrays
+    tree a reference rank builds.  value = N / (tree of an own share + median walk time scaled from the sample to N + one whole
+    gravpm_force on the same cores: oracle/pm_oracle.c's loops + pocketfft).  Round 2 ran ONE process over all cores with the arrays
     first-touched by one thread: 12 % of the per-thread rate of the 8-thread calibration."""
     import multiprocessing as mp
     import tempfile
@@ -1389,27 +1389,29 @@ def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
     threads = sum(res[r][4] for r in range(P))
     t_tree_own = max(res[r][2] for r in range(P))
     t_tree_full = max(res[r][3] for r in range(P))
-    # the long-range part on the same cores: the five 3-D transforms of one gravpm_force (1 r2c + 4 c2r: potential and three force
-    # components, gravpm.c:32-39, petapm.c:319-357) on the Nmesh^3 mesh, by pocketfft (C++, scipy.fft) with one worker per core the
-    # container may use.  The reference runs them through PFFT on MPI ranks; its CIC deposit / read-out, the transfer functions and the
-    # pencil exchanges are NOT timed here (no C restatement of petapm.c exists: oracle.py's PM is numpy), which favours the CPU.
-    t_pm_fft = None
+    # the long-range part on the same cores: one whole gravpm_force (gravpm.c:61-119) on the Nmesh^3 mesh - CIC deposit, potential
+    # transfer, the three force transfers and the four read-outs as OpenMP loops (oracle/pm_oracle.c, the reference's flags), the five
+    # 3-D transforms (1 r2c + 4 c2r, petapm.c:319-357) by pocketfft (C++, scipy.fft) with one worker per core the container may use.
+    # The reference runs the transforms through PFFT on MPI ranks with pencil exchanges either side; those exchanges are not part of
+    # a one-process run, which favours the CPU.  Two runs, the second is taken (the first touches the mesh pages).
+    t_pm, pm_parts, t_pm_fft = None, None, None
     try:
-        import scipy.fft as sfft
-        rng = np.random.RandomState(1)
-        mesh = rng.random_sample((nmesh, nmesh, nmesh))
-        t0 = time.perf_counter()
-        fk = sfft.rfftn(mesh, workers=threads)
-        for _ in range(4):
-            back = sfft.irfftn(fk, s=mesh.shape, workers=threads)
-        t_pm_fft = time.perf_counter() - t0
-        del mesh, fk, back
-    except Exception:      # noqa: BLE001 - no scipy: the leg is reported as absent, the value then excludes the PM as in rounds 1-3
-        t_pm_fft = None
-    t_full = t_tree_own + t_walk * N / sample + (t_pm_fft or 0.0)
-    out = {"value": N / t_full, "pm_fft_s": None if t_pm_fft is None else round(t_pm_fft, 3),
-           "pm_note": "value includes the five 3-D FFTs of a PM step (pocketfft, %d workers); CIC deposit / read-out and transfer functions of the "
-                      "CPU side are not timed" % threads, "unit": "particles/s", "cores": threads, "kind": "port", "processes": P, "cgroup_cpu_limit": cgroup_cpu_limit(),
+        from oracle import oracle as O
+        orc_f = O.Oracle(fast=True)
+        for _ in range(2):
+            pm_parts = {}
+            O.gravpm_force_c(orc_f, pos, mass, box, nmesh, 1.5, G, want_potential=True, workers=threads, timings=pm_parts)
+        t_pm = float(sum(pm_parts.values()))
+        t_pm_fft = pm_parts["fft"]
+    except Exception as e:      # noqa: BLE001 - no scipy: the leg is reported as absent, the value then excludes the PM as in rounds 1-3
+        sys.stderr.write("cpu_baseline: PM leg failed (%s)\n" % e)
+        t_pm = None
+    t_full = t_tree_own + t_walk * N / sample + (t_pm or 0.0)
+    out = {"value": N / t_full, "pm_s": None if t_pm is None else round(t_pm, 3), "pm_fft_s": None if t_pm_fft is None else round(t_pm_fft, 3),
+           "pm_parts_s": None if pm_parts is None else {k: round(v, 3) for k, v in pm_parts.items()},
+           "pm_note": "value includes one whole gravpm_force on the CPU side: CIC deposit, transfer functions and the four read-outs as OpenMP "
+                      "loops (oracle/pm_oracle.c, %d threads) + the five 3-D FFTs by pocketfft (%d workers)" % (threads, threads),
+           "unit": "particles/s", "cores": threads, "kind": "port", "processes": P, "cgroup_cpu_limit": cgroup_cpu_limit(),
            "threads_per_process": [len(g) for g in groups], "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
            "omp": "per process: sched_setaffinity to its cores, OMP_PROC_BIND=close OMP_PLACES=cores", "walk_s_median_of_3": round(t_walk, 3),
            "walk_s_all": [round(float(w), 3) for w in walks.max(0)], "tree_build_own_share_s": round(t_tree_own, 3),
@@ -1421,7 +1423,7 @@ def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
            "value_if_all_physical_cores": (N / t_full) * phys / max(threads, 1),
            "sample": "oracle (gcc -O3 -ffast-math -fopenmp), %d processes x %s threads pinned per socket: each builds the tree of all %d particles "
                      "(%.2f s, set-up) and walks its share of %d Morton-ordered targets (median of 3 of the slowest process: %.2f s), scaled to N, "
-                     "plus the tree of an own 1/%d share (%.2f s), plus the PM step's five FFTs (pm_fft_s)" % (P, "/".join(str(len(g)) for g in groups[:2]) + ("/..." if P > 2 else ""),
+                     "plus the tree of an own 1/%d share (%.2f s), plus one whole PM step (pm_s)" % (P, "/".join(str(len(g)) for g in groups[:2]) + ("/..." if P > 2 else ""),
                                                                                       N, t_tree_full, sample, t_walk, P, t_tree_own)}
     return out
 

@@ -289,6 +289,75 @@ def gravpm_force(pos, mass, box, nmesh, Asmth=1.5, G=43.0071, want_potential=Tru
     return out, potential
 
 
+def _pm_bind(orc):
+    """pm_oracle.c's entry points on an Oracle's library (bound on first use: the deliberately mutated copies of
+    tests/test_hydro_physics.py are built without that file)"""
+    L = orc.lib
+    if not getattr(L, "_pm_bound", False):
+        L.pmo_cic_deposit.argtypes = [C.c_int64, _dp, _dp, C.c_void_p, C.c_double, C.c_int, _dp]
+        L.pmo_readout.argtypes = [C.c_int64, _dp, C.c_double, C.c_int, _dp, C.c_double, C.c_void_p, C.c_int]
+        L.pmo_potential_transfer.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.pmo_force_transfer.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        for f in ("pmo_cic_deposit", "pmo_readout", "pmo_potential_transfer", "pmo_force_transfer"):
+            getattr(L, f).restype = None
+        L._pm_bound = True
+    return L
+
+
+def gravpm_force_c(orc, pos, mass, box, nmesh, Asmth=1.5, G=43.0071, want_potential=True, workers=None, timings=None):
+    """gravpm_force (gravpm.c:61-119) for one rank with the particle <-> mesh loops and the Fourier sweeps in C + OpenMP
+    (pm_oracle.c) and the five transforms by pocketfft (scipy.fft, `workers` threads) where the reference calls PFFT.
+    Same result as gravpm_force() above (tests/test_oracle_pm.py); `timings`, a dict, receives the seconds of each part -
+    bench.py's cpu_baseline times the long-range step of the CPU side with it."""
+    import time
+    import scipy.fft as sfft
+    L = _pm_bind(orc)
+    pos = np.ascontiguousarray(pos, np.float64)
+    m64 = np.ascontiguousarray(mass, np.float64)
+    n = len(pos)
+    workers = workers or orc.num_threads()
+    tm = {"deposit": 0.0, "fft": 0.0, "transfer": 0.0, "readout": 0.0}
+
+    def lap(key, t0):
+        tm[key] += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rho = np.zeros((nmesh,) * 3)
+    L.pmo_cic_deposit(n, pos, m64, None, box, nmesh, rho.reshape(-1))
+    lap("deposit", t0)
+    t0 = time.perf_counter()
+    pot_k = sfft.rfftn(rho, workers=workers)
+    lap("fft", t0)
+    del rho
+    t0 = time.perf_counter()
+    L.pmo_potential_transfer(nmesh, box, Asmth, G, pot_k.ctypes.data_as(C.c_void_p))
+    lap("transfer", t0)
+    n3 = float(nmesh) ** 3            # PFFT's c2r is unnormalised, pocketfft's divides by Nmesh^3
+    out = np.zeros((n, 3))
+    potential = None
+    if want_potential:
+        t0 = time.perf_counter()
+        mesh = sfft.irfftn(pot_k, s=(nmesh,) * 3, workers=workers)
+        lap("fft", t0)
+        t0 = time.perf_counter()
+        potential = np.zeros(n)
+        L.pmo_readout(n, pos, box, nmesh, mesh.reshape(-1), n3, potential.ctypes.data_as(C.c_void_p), 1)
+        lap("readout", t0)
+    fk = np.empty_like(pot_k)
+    for d in range(3):
+        t0 = time.perf_counter()
+        L.pmo_force_transfer(nmesh, box, d, pot_k.ctypes.data_as(C.c_void_p), fk.ctypes.data_as(C.c_void_p))
+        lap("transfer", t0)
+        t0 = time.perf_counter()
+        mesh = sfft.irfftn(fk, s=(nmesh,) * 3, workers=workers)
+        lap("fft", t0)
+        t0 = time.perf_counter()
+        L.pmo_readout(n, pos, box, nmesh, mesh.reshape(-1), n3, C.c_void_p(out.ctypes.data + 8 * d), 3)
+        lap("readout", t0)
+    if timings is not None:
+        timings.update(tm)
+    return out, potential
+
+
 def pm_power_spectrum(pos, mass, box, nmesh, BoxSize_in_MPC):
     """The matter power spectrum gravpm_force measures on the PM mesh: measure_power_spectrum + powerspectrum_add_mode
     (gravpm.c:331-382) per Fourier cell, then powerspectrum_sum (powerspectrum.c:55-91).  Returns (kk, Power, Nmodes) with empty

@@ -536,6 +536,8 @@ def test_full_size_256_properties(pkg, orc, ic):
         only one of the two targets keeps the other's leaf (cube cut at Rcut + len/2, gravshort-tree.c:198-215), where
         the window has already suppressed the force by >1e4: |sum_i a_i| <= 1e-6 sum_i |a_i|;
       * PM momentum conservation: sum_i m_i GravPM_i = 0;
+      * GravPM of ALL 16.8 M particles against the CPU long-range step at the same size (oracle/pm_oracle.c's loops and sweeps +
+        pocketfft on the 512^3 mesh): 1e-10 of the mean |GravPM|;
       * 2048 random targets agree with the oracle walking the oracle-built tree of all 16.8 M particles."""
     import torch
     clk = phase_clock("full_size_256[%s]" % ic)
@@ -574,6 +576,10 @@ def test_full_size_256_properties(pkg, orc, ic):
     st = eng.tree_stats()
     assert st.NumParticles == N and abs(st.root_mass - N) < 1e-6
     clk.mark("checks")
+    gc, _ = O.gravpm_force_c(orc, pos, mass, box, nmesh, 1.5, G, want_potential=False)
+    clk.mark("oracle PM, all particles")
+    assert np.abs(g - gc).max() <= 1e-10 * np.abs(gc).mean()
+    del gc
     tr = orc.tree(pos, mass, box, father=False)
     clk.mark("oracle tree")
     assert tr.numnodes >= st.numnodes
