@@ -26,6 +26,10 @@
  *       mpg_dist_hydro_force (gas and, with BlackHoleOn, black holes as density targets).  in = [N][10] Pos, Type, Vel, Entropy,
  *       Hsml, Mass; expect = [N][6] Hsml, Density, HydroAccel, DtEntropy from the CPU oracle.  Also checks that a gravity walk
  *       after the SPH loops is refused until the gravity tree is rebuilt (the density loop replaces the tree in the library).
+ * Built with -DMPG_TEST_MPI and shim/mpg_mpi_comm.c + shim/mpg_rccl_mpi.c in the link (tests/test_gpu_cabi.py::test_c_caller_real_mpi),
+ * `ranks` / `ranks_host` run under mpiexec instead: one MPI process per rank, the collectives are the shim's MPI_Allreduce /
+ * MPI_Alltoall / MPI_Alltoallv on host buffers (mpg_mpi_comm, what shim/gravity-hip.c hands to the library), or with MPG_TEST_COMM=rccl
+ * and one process the RCCL communicator bootstrapped by the shim's MPI_Bcast (mpg_rccl_mpi_comm); rank 0 assembles and checks.
  * Exit code 0 and a last line "PASS ..." on success. */
 #define _GNU_SOURCE
 #include <math.h>
@@ -39,6 +43,9 @@
 #include <unistd.h>
 
 #include "mpgadget_hip.h"
+#ifdef MPG_TEST_MPI
+#include "mpg_mpi_comm.h" /* shim/ */
+#endif
 
 /* the four HIP runtime calls a device-resident caller needs (declared here so that plain gcc compiles this file) */
 extern int hipMalloc(void **p, size_t n);
@@ -348,6 +355,26 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
      * does it - rank 0's unique id handed to every rank (here: one rank; RCCL refuses several ranks on one GPU), mpg_rccl_create, the
      * self-test, the callbacks.  Collectives then run on the engine's stream with device pointers, no host staging. */
     mpg_rccl *RC = NULL;
+#ifdef MPG_TEST_MPI
+    /* real MPI processes: the shim's communicator (shim/mpg_mpi_comm.c), or - one process - its RCCL bootstrap (shim/mpg_rccl_mpi.c) */
+    static MPI_Comm world;
+    world = MPI_COMM_WORLD;
+    comm = mpg_mpi_comm(&world);
+    if(comm.ThisTask != me || comm.NTask != nt) {
+        fprintf(stderr, "FAIL mpg_mpi_comm reports task %d of %d, expected %d of %d\n", comm.ThisTask, comm.NTask, me, nt);
+        exit(1);
+    }
+    if(getenv("MPG_TEST_COMM") && !strcmp(getenv("MPG_TEST_COMM"), "rccl")) {
+        if(nt != 1) {
+            fprintf(stderr, "FAIL RCCL refuses several ranks on one GPU: one MPI process with MPG_TEST_COMM=rccl\n");
+            exit(1);
+        }
+        if(mpg_rccl_mpi_comm(world, 0, &RC, &comm)) {
+            fprintf(stderr, "FAIL mpg_rccl_mpi_comm\n");
+            exit(1);
+        }
+    }
+#else
     if(getenv("MPG_TEST_COMM") && !strcmp(getenv("MPG_TEST_COMM"), "rccl")) {
         if(nt != 1) {
             fprintf(stderr, "FAIL RCCL refuses several ranks on one GPU: NTask must be 1 with MPG_TEST_COMM=rccl\n");
@@ -359,6 +386,7 @@ static void rank_main(struct shm *S, int me, int nt, const double *table, const 
         CK(mpg_rccl_selftest(RC, 0));
         CK(mpg_rccl_comm(RC, &comm));
     }
+#endif
     mpg_engine *e = make_engine(table, box, n, nmesh);
     /* the domain: the root of the Peano-Hilbert key space cut into its 8 cells, cell k owned by task k % NTask
      * (struct topnode_data, domain.h:12-18: StartKey, Shift, Daughter, Leaf) */
@@ -842,6 +870,28 @@ static int run_ranks(const double *table, const double *pos, const double *expec
     pthread_barrierattr_t ba;
     pthread_barrierattr_init(&ba);
     pthread_barrierattr_setpshared(&ba, PTHREAD_PROCESS_SHARED);
+    int bad = 0;
+#ifdef MPG_TEST_MPI
+    /* this process IS one rank; the segment is private to it (the barrier counts one), the results are summed onto rank 0 (every
+     * particle is written by its owner only, the others hold zeros) */
+    int me = 0, size = 1;
+    MPI_Comm_rank(MPI_COMM_WORLD, &me);
+    MPI_Comm_size(MPI_COMM_WORLD, &size);
+    if(size != nt) {
+        fprintf(stderr, "FAIL NTask %d but mpiexec started %d processes\n", nt, size);
+        return 1;
+    }
+    pthread_barrier_init(&S->bar, &ba, 1u);
+    rank_main(S, me, nt, table, pos, n, nmesh, box, host);
+    MPI_Allreduce(MPI_IN_PLACE, &S->substep_bad, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+    if(6 * N > 2000000000) {
+        fprintf(stderr, "FAIL result too large for one MPI_Reduce\n");
+        return 1;
+    }
+    MPI_Reduce(me == 0 ? MPI_IN_PLACE : (void *)shm_result(S), shm_result(S), (int)(6 * N), MPI_DOUBLE, MPI_SUM, 0, MPI_COMM_WORLD);
+    if(me != 0)
+        return 0;
+#else
     pthread_barrier_init(&S->bar, &ba, (unsigned)nt);
     pid_t pids[MAXT];
     for(int r = 0; r < nt; r++) { /* (fork before anything touches the HIP runtime) */
@@ -851,13 +901,13 @@ static int run_ranks(const double *table, const double *pos, const double *expec
             _exit(0);
         }
     }
-    int bad = 0;
     for(int r = 0; r < nt; r++) {
         int status = 0;
         waitpid(pids[r], &status, 0);
         if(!WIFEXITED(status) || WEXITSTATUS(status) != 0)
             bad = 1;
     }
+#endif
     if(bad) {
         printf("FAIL a rank exited with an error\n");
         return 1;
@@ -874,6 +924,9 @@ static int run_ranks(const double *table, const double *pos, const double *expec
             acc[3 * i + j] = R[6 * i + 3 + j];
         }
     const double e_pm = relerr(gpm, expect, 3 * N), e_tr = relerr(acc, expect + 3 * N, 3 * N);
+#ifdef MPG_TEST_MPI
+    printf("MPI processes, collectives by %s\n", getenv("MPG_TEST_COMM") && !strcmp(getenv("MPG_TEST_COMM"), "rccl") ? "RCCL (bootstrapped by shim/mpg_rccl_mpi.c)" : "shim/mpg_mpi_comm.c");
+#endif
     printf("ranks %d (%s): N %lld  GravPM err %.3e  acceleration err %.3e\n", nt, host ? "host tables" : "device arrays", (long long)N, e_pm, e_tr);
     if(!(e_pm < 1e-10 && e_tr < 1e-10)) {
         printf("FAIL\n");
@@ -899,5 +952,14 @@ int main(int argc, char **argv)
         return run_single(table, pos, expect, n, nmesh, box);
     if(!strcmp(argv[1], "run"))
         return run_order(table, pos, expect, argv[8], n, nmesh, box);
+#ifdef MPG_TEST_MPI
+    MPI_Init(&argc, &argv);
+    const int rc = run_ranks(table, pos, expect, n, nmesh, box, argc > 8 ? atoi(argv[8]) : 2, !strcmp(argv[1], "ranks_host"));
+    if(rc)
+        MPI_Abort(MPI_COMM_WORLD, rc);
+    MPI_Finalize();
+    return rc;
+#else
     return run_ranks(table, pos, expect, n, nmesh, box, argc > 8 ? atoi(argv[8]) : 2, !strcmp(argv[1], "ranks_host"));
+#endif
 }

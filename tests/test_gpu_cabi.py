@@ -26,6 +26,52 @@ def build(tmp_path):
     return exe
 
 
+MPI_ROOT = os.environ.get("MPG_MPI_ROOT", "/opt/conda")     # this image carries MPICH 3.3.2 there (no MPI on the default paths)
+
+
+def build_mpi(tmp_path):
+    """The same C caller as real MPI processes: -DMPG_TEST_MPI, with shim/mpg_mpi_comm.c and shim/mpg_rccl_mpi.c - the files a
+    maintainer adds to libgadget - compiled and LINKED against the image's MPI.  libmpi is linked by path and found at run time through
+    a directory of links that holds it and its two private dependencies only (an rpath on the MPI's whole lib directory would put that
+    tree's libstdc++ in front of the one the HIP runtime was built with).  Returns (exe, mpiexec) or skips."""
+    inc, libmpi, mpiexec = os.path.join(MPI_ROOT, "include"), os.path.join(MPI_ROOT, "lib", "libmpi.so.12"), os.path.join(MPI_ROOT, "bin", "mpiexec")
+    if not (os.path.exists(os.path.join(inc, "mpi.h")) and os.path.exists(libmpi) and os.path.exists(mpiexec)):
+        pytest.skip("no MPI in this image")
+    links = tmp_path / "mpilib"
+    links.mkdir(exist_ok=True)
+    for f in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+        src = os.path.join(MPI_ROOT, "lib", f)
+        if os.path.exists(src) and not os.path.lexists(str(links / f)):
+            os.symlink(src, str(links / f))
+    exe = str(tmp_path / "test_cabi_mpi")
+    lib = os.path.join(ROOT, "mp-gadget_amd")
+    shim = os.path.join(ROOT, "shim")
+    cmd = ["gcc", "-O2", "-std=gnu11", "-Wall", "-Werror", "-DMPG_TEST_MPI", "-I", os.path.join(ROOT, "include"), "-I", shim, "-I", inc,
+           os.path.join(ROOT, "tests", "c", "test_cabi.c"), os.path.join(shim, "mpg_mpi_comm.c"), os.path.join(shim, "mpg_rccl_mpi.c"), "-o", exe,
+           "-L", lib, "-lmpgadget_hip", libmpi, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-lm",
+           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + str(links)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe, mpiexec
+
+
+def _mpirun(mpiexec, nt, exe, *args, env_extra=None):
+    env = dict(os.environ, MPICH_INTERFACE_HOSTNAME="127.0.0.1")      # (the box's hostname may not resolve)
+    env.update(env_extra or {})
+    r = subprocess.run([mpiexec, "-launcher", "fork", "-hosts", "127.0.0.1", "-n", str(nt), exe] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "PASS" in r.stdout.splitlines()[-1], (r.stdout[-3000:], r.stderr[-3000:])
+    return r.stdout
+
+
+def test_c_program_builds_with_the_shim_communicators_against_mpi(tmp_path):
+    """shim/mpg_mpi_comm.c and shim/mpg_rccl_mpi.c compile without a warning and link, with the C caller, against the image's MPI
+    and the library (CPU: the build only; the runs are test_c_caller_real_mpi)."""
+    importlib.import_module("__graft_entry__").build()
+    exe, _ = build_mpi(tmp_path)
+    assert os.path.exists(exe)
+
+
 def test_c_program_builds_against_the_header(tmp_path):
     """gcc compiles the C caller against include/mpgadget_hip.h (a C header: no C++ in the signatures) and links every symbol it
     uses from the library."""
@@ -43,6 +89,28 @@ def _run(exe, *args):
     r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PASS" in r.stdout.splitlines()[-1], (r.stdout[-3000:], r.stderr[-3000:])
     return r.stdout
+
+
+@pytest.mark.gpu
+def test_c_caller_real_mpi(tmp_path):
+    """The multi-rank C-ABI under a REAL MPI: mpiexec starts 2 / 4 processes of the C caller, every collective the library asks for goes
+    through shim/mpg_mpi_comm.c (MPI_Allreduce / MPI_Alltoall / MPI_Alltoallv on host buffers: the library stages through pinned memory)
+    - the device-array form with the library's own domain decomposition and exchange, and the host-table drop-in form with a sub-step -
+    against the committed vectors.  One process then takes the RCCL communicator through the shim's bootstrap (one MPI_Bcast of the
+    unique id, shim/mpg_rccl_mpi.c) and must have sent its collectives through RCCL."""
+    pkg = importlib.import_module("mp-gadget_amd")
+    exe, mpiexec = build_mpi(tmp_path)
+    table = os.path.join(ROOT, "mp-gadget_amd", "data", "shortrange_force_kernels.f64")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "grav_sgrid16.npz"))
+    pos, mass, box = pkg.ics.s_grid(16)
+    p, e = _write_case(tmp_path, "sgrid16", pos, g["GravPM"], g["Accel2"])
+    for nt in (2, 4):
+        out = _mpirun(mpiexec, nt, exe, "ranks", table, p, e, 16, 32, box, nt)
+        assert "PASS ranks %d" % nt in out and "collectives by shim/mpg_mpi_comm.c" in out
+    out = _mpirun(mpiexec, 2, exe, "ranks_host", table, p, e, 16, 32, box, 2)
+    assert "PASS ranks 2" in out
+    out = _mpirun(mpiexec, 1, exe, "ranks", table, p, e, 16, 32, box, 1, env_extra={"MPG_TEST_COMM": "rccl"})
+    assert "bootstrapped by shim/mpg_rccl_mpi.c" in out and "rccl: version" in out
 
 
 @pytest.mark.gpu
