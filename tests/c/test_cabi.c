@@ -648,6 +648,11 @@ static void sph_rank(struct shm *S, int me, int nt, const struct sph_in *in, dou
     alarm(300);
     struct ctx cx = {S, me, nt};
     mpg_comm comm = {&cx, me, nt, 0, cb_allreduce, cb_alltoall_i64, cb_alltoallv};
+#ifdef MPG_TEST_MPI
+    static MPI_Comm world;
+    world = MPI_COMM_WORLD;
+    comm = mpg_mpi_comm(&world); /* shim/mpg_mpi_comm.c */
+#endif
     mpg_engine *e = NULL;
     CK(mpg_engine_create(&e, 0));
     const double meansep = box / cbrt((double)N);
@@ -788,6 +793,21 @@ static int run_sph(const char *in_path, const char *expect_path, int64_t N, doub
     pthread_barrierattr_t ba;
     pthread_barrierattr_init(&ba);
     pthread_barrierattr_setpshared(&ba, PTHREAD_PROCESS_SHARED);
+    int bad = 0;
+#ifdef MPG_TEST_MPI
+    int me = 0, size = 1; /* (as run_ranks: this process is one rank, rank 0 collects) */
+    MPI_Comm_rank(MPI_COMM_WORLD, &me);
+    MPI_Comm_size(MPI_COMM_WORLD, &size);
+    if(size != nt || 6 * N > 2000000000) {
+        fprintf(stderr, "FAIL NTask %d but mpiexec started %d processes (or the result does not fit one MPI_Reduce)\n", nt, size);
+        return 1;
+    }
+    pthread_barrier_init(&S->bar, &ba, 1u);
+    sph_rank(S, me, nt, in, box, bh, kernel);
+    MPI_Reduce(me == 0 ? MPI_IN_PLACE : (void *)shm_result(S), shm_result(S), (int)(6 * N), MPI_DOUBLE, MPI_SUM, 0, MPI_COMM_WORLD);
+    if(me != 0)
+        return 0;
+#else
     pthread_barrier_init(&S->bar, &ba, (unsigned)nt);
     pid_t pids[MAXT];
     for(int r = 0; r < nt; r++) {
@@ -797,13 +817,13 @@ static int run_sph(const char *in_path, const char *expect_path, int64_t N, doub
             _exit(0);
         }
     }
-    int bad = 0;
     for(int r = 0; r < nt; r++) {
         int status = 0;
         waitpid(pids[r], &status, 0);
         if(!WIFEXITED(status) || WEXITSTATUS(status) != 0)
             bad = 1;
     }
+#endif
     if(bad) {
         printf("FAIL a rank exited with an error\n");
         return 1;
@@ -938,8 +958,18 @@ static int run_ranks(const double *table, const double *pos, const double *expec
 
 int main(int argc, char **argv)
 {
-    if(argc >= 9 && !strcmp(argv[1], "sph"))
+    if(argc >= 9 && !strcmp(argv[1], "sph")) {
+#ifdef MPG_TEST_MPI
+        MPI_Init(&argc, &argv);
+        const int rc = run_sph(argv[2], argv[3], atoll(argv[4]), atof(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
+        if(rc)
+            MPI_Abort(MPI_COMM_WORLD, rc);
+        MPI_Finalize();
+        return rc;
+#else
         return run_sph(argv[2], argv[3], atoll(argv[4]), atof(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
+#endif
+    }
     if(argc < 8) {
         fprintf(stderr, "usage: %s single|ranks|ranks_host table.f64 pos.f64 expect.f64 n nmesh box [NTask]\n       %s sph in.f64 expect.f64 N box NTask BlackHoleOn kernel\n", argv[0], argv[0]);
         return 2;

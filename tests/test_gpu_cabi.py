@@ -255,7 +255,8 @@ def test_c_caller_sph_loops_against_oracle(tmp_path, orc, bh):
     (mpg_density / mpg_hydro_force) and 2 / 4 forked ranks (mpg_dist_force_tree_full / mpg_dist_density / mpg_dist_hydro_force; the
     first margin is too small on purpose: the retry through mpg_dist_last_max_hsml runs) against the CPU oracle; bh = 1 adds black
     holes as density targets (density_haswork, density.c:521-530), which the multi-rank loop refused in round 2; a gravity walk on
-    the gas tree the density loop leaves behind must be refused."""
+    the gas tree the density loop leaves behind must be refused.  With bh = 1 the 2- and 4-rank runs are repeated as real MPI processes
+    (mpiexec, -DMPG_TEST_MPI) when the image has an MPI."""
     from oracle import oracle as O
     pkg = importlib.import_module("mp-gadget_amd")
     exe = build(tmp_path)
@@ -286,3 +287,8 @@ def test_c_caller_sph_loops_against_oracle(tmp_path, orc, bh):
     for nt in (1, 2, 4):
         r = subprocess.run([exe, "sph", pi, pe, str(N), str(box), str(nt), str(bh), "1"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "PASS sph %d" % nt in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    if bh:      # ... and as real MPI processes, the collectives of the SPH loops (ghost import with Hsml margins, the retry) through shim/mpg_mpi_comm.c
+        exe_mpi, mpiexec = build_mpi(tmp_path)
+        for nt in (2, 4):
+            out = _mpirun(mpiexec, nt, exe_mpi, "sph", pi, pe, N, box, nt, bh, 1)
+            assert "PASS sph %d" % nt in out
