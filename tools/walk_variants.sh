@@ -6,7 +6,7 @@ cd $ROOT
 for f in "$@"; do
     if [ -n "$f" ]; then export MPG_EXTRA_FLAGS="grav_walk_split.hip:$f"; else unset MPG_EXTRA_FLAGS; fi
     python mp-gadget_amd/build.py > /dev/null 2>&1 || echo "build failed: $f"
-    python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+    python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-} 2>/dev/null | tail -1 | python -c "
 import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('[%s] step %.2f ms  frac %.4f  walk %s  leaf entries %s' % ('$f', j['ms_per_step'], r['frac'], j.get('phases_ms',{}).get('walk'), r.get('leaf_entries_per_launch')))"
 done
 unset MPG_EXTRA_FLAGS
