@@ -1322,6 +1322,23 @@ def _cpu_worker(rank, nproc, cpus, path, box, n, nmesh, lo, hi, q):
     q.put(("done", rank, walks, pp, t_tree_own, t_tree_full, orc.num_threads()))
 
 
+def _cpu_pm_worker(pos, mass, box, nmesh, threads, q):
+    """The long-range step of the CPU baseline in a process of its own (the -ffast-math build of the oracle switches the thread that loads it to
+    flush-to-zero arithmetic: kept out of the bench process).  Two runs, the second is reported (the first touches the mesh pages)."""
+    try:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        sys.path.insert(0, ROOT)
+        from oracle import oracle as O
+        orc = O.Oracle(fast=True)
+        parts = {}
+        for _ in range(2):
+            parts = {}
+            O.gravpm_force_c(orc, pos, mass, box, nmesh, 1.5, G, want_potential=True, workers=threads, timings=parts)
+        q.put(("pm", parts))
+    except Exception as e:      # noqa: BLE001 - reported by the parent
+        q.put(("pm_failed", repr(e)))
+
+
 def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
     """The CPU "port" (SURVEY 8(d) "CPU baseline timing"): the oracle built with the reference's flags (-O3 -ffast-math -fopenmp) on the
     host cores of this box, as the reference runs on such a box: P processes x T threads (README.rst:121), each process pinned to a
@@ -1393,17 +1410,20 @@ def cpu_baseline(pkg, pos, mass, box, n, nmesh, aold_vec, sample):
     # transfer, the three force transfers and the four read-outs as OpenMP loops (oracle/pm_oracle.c, the reference's flags), the five
     # 3-D transforms (1 r2c + 4 c2r, petapm.c:319-357) by pocketfft (C++, scipy.fft) with one worker per core the container may use.
     # The reference runs the transforms through PFFT on MPI ranks with pencil exchanges either side; those exchanges are not part of
-    # a one-process run, which favours the CPU.  Two runs, the second is taken (the first touches the mesh pages).
+    # a one-process run, which favours the CPU.  In a process of its own (_cpu_pm_worker).
     t_pm, pm_parts, t_pm_fft = None, None, None
     try:
-        from oracle import oracle as O
-        orc_f = O.Oracle(fast=True)
-        for _ in range(2):
-            pm_parts = {}
-            O.gravpm_force_c(orc_f, pos, mass, box, nmesh, 1.5, G, want_potential=True, workers=threads, timings=pm_parts)
+        qpm = ctx.Queue()
+        ppm = ctx.Process(target=_cpu_pm_worker, args=(pos, mass, box, nmesh, threads, qpm))
+        ppm.start()
+        m = qpm.get(timeout=900)
+        ppm.join(timeout=60)
+        if m[0] != "pm":
+            raise RuntimeError(m[1])
+        pm_parts = m[1]
         t_pm = float(sum(pm_parts.values()))
         t_pm_fft = pm_parts["fft"]
-    except Exception as e:      # noqa: BLE001 - no scipy: the leg is reported as absent, the value then excludes the PM as in rounds 1-3
+    except Exception as e:      # noqa: BLE001 - no scipy / a failed worker: the leg is reported as absent, the value then excludes the PM as in rounds 1-3
         sys.stderr.write("cpu_baseline: PM leg failed (%s)\n" % e)
         t_pm = None
     t_full = t_tree_own + t_walk * N / sample + (t_pm or 0.0)

@@ -3,6 +3,7 @@ gravpm.c:383-517) against oracle.py's numpy restatement of the same functions, w
 reference's test_gravity.c bounds.  CPU only."""
 import ctypes as C
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -24,9 +25,7 @@ def _set(n, box, seed, clump=False):
     return pos, mass
 
 
-@pytest.mark.parametrize("fast", [False, True])
-@pytest.mark.parametrize("nmesh,clump", [(16, False), (32, True), (24, True)])
-def test_c_pm_matches_the_numpy_restatement(nmesh, clump, fast):
+def _check(nmesh, clump, fast):
     box = 1000.0
     pos, mass = _set(3000, box, nmesh, clump)
     orc = O.Oracle(fast=fast)
@@ -38,6 +37,19 @@ def test_c_pm_matches_the_numpy_restatement(nmesh, clump, fast):
     assert np.abs(a1 - a0).max() / sa < tol
     assert np.abs(p1 - p0).max() / sp < tol
     assert set(tm) == {"deposit", "fft", "transfer", "readout"} and all(v >= 0 for v in tm.values())
+
+
+@pytest.mark.parametrize("nmesh,clump", [(16, False), (32, True), (24, True)])
+def test_c_pm_matches_the_numpy_restatement(nmesh, clump):
+    _check(nmesh, clump, False)
+
+
+def test_c_pm_of_the_reference_flags_build():
+    """liboracle_fast.so (-O3 -ffast-math -fopenmp: what bench.py's cpu_baseline times).  In a process of its own: loading a -ffast-math
+    library switches the loading thread to flush-to-zero arithmetic, which must not leak into the other tests of this process."""
+    code = "import sys; sys.path.insert(0, %r); import tests.test_oracle_pm as t; [t._check(n, c, True) for n, c in ((16, False), (32, True), (24, True))]; print('fast ok')" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "fast ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_c_deposit_and_readout_piecewise():
