@@ -103,9 +103,20 @@ __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const 
     double fac = mr * rinv * rinv;
     double facpot = -mr;
     if(r2 < gp.h * gp.h) { // rare (the self interaction, close encounters): kept out of line so that its divisions and
-        if(!(rinv < 1e150))  // constants do not occupy registers in the pair loop
-            r = 0.0;
-        softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot);
+                           // constants do not occupy registers in the pair loop
+#ifndef MPG_NO_SELF_FAST
+        if(r2 == 0.0) { // the self interaction, once per target and so in ~6 % of a wave's pair steps: the spline's inner branch at u = 0
+            r = 0.0;    // (bit for bit: c0 + 0 and c3 + 0), from literals - softened_pair's constant fetches are dependent vector loads whose
+            fac = s.m * gp.h3inv * 10.666666666667; // waits also drain the prefetched source records
+            facpot = s.m * gp.hinv * -2.8;
+        }
+        else
+#endif
+        {
+            if(!(rinv < 1e150))
+                r = 0.0;
+            softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot);
+        }
     }
     // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
     // the table's last row, which holds zeros
