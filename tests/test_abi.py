@@ -78,6 +78,33 @@ def test_mpi_comm_shim_compiles():
     assert r.returncode == 0, r.stderr
 
 
+def test_shim_mpi_communicator_runs(tmp_path):
+    """shim/mpg_mpi_comm.c under a REAL MPI on the CPU (tests/c/test_mpi_comm.c, mpiexec -n 1 / 3 / 4): all-reduce (double / int64, sum /
+    max, a count beyond INT_MAX refused), the all-to-all of counts, and the byte all-to-all-v on ragged, empty and gapped blocks - also
+    with a displacement beyond 2^31 bytes, where the shim switches every rank to 8-byte units, and a block those units cannot express.
+    (The same file carries the library's collectives on the GPU box: tests/test_gpu_cabi.py::test_c_caller_real_mpi.)"""
+    import shutil
+    import subprocess
+    root = os.environ.get("MPG_MPI_ROOT", "/opt/conda")
+    inc, libmpi, mpiexec = os.path.join(root, "include"), os.path.join(root, "lib", "libmpi.so.12"), os.path.join(root, "bin", "mpiexec")
+    if not (os.path.exists(os.path.join(inc, "mpi.h")) and os.path.exists(libmpi) and os.path.exists(mpiexec) and shutil.which("gcc")):
+        pytest.skip("no MPI in this image")
+    links = tmp_path / "mpilib"
+    links.mkdir()
+    for f in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):     # libmpi and its private dependencies only (tests/test_gpu_cabi.py)
+        if os.path.exists(os.path.join(root, "lib", f)):
+            os.symlink(os.path.join(root, "lib", f), str(links / f))
+    exe = str(tmp_path / "test_mpi_comm")
+    r = subprocess.run(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim"),
+                        "-I", inc, os.path.join(ROOT, "tests", "c", "test_mpi_comm.c"), os.path.join(ROOT, "shim", "mpg_mpi_comm.c"), "-o", exe,
+                        libmpi, "-Wl,-rpath," + str(links)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, MPICH_INTERFACE_HOSTNAME="127.0.0.1")
+    for nt in (1, 3, 4):
+        r = subprocess.run([mpiexec, "-launcher", "fork", "-hosts", "127.0.0.1", "-n", str(nt), exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and ("PASS mpg_mpi_comm on %d MPI processes" % nt) in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_reference_side_shim_compiles(tmp_path):
     """shim/gravity-hip.c and shim/sph-hip.c - the files a maintainer adds inside the reference tree - go through gcc's front end
     against the reference's OWN headers and include/mpgadget_hip.h: every call matches a prototype (implicit declarations are errors),
