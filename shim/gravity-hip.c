@@ -22,6 +22,8 @@
 #include <mpgadget_hip.h>
 #include "mpg_mpi_comm.h"
 #include "mpg_shim.h"
+#include "mpg_shim_epoch.h"
+#include <stddef.h>
 
 _Static_assert(sizeof(struct particle_data) == 160 && __builtin_offsetof(struct particle_data, GravPM) == 88 &&
                __builtin_offsetof(struct particle_data, FullTreeGravAccel) == 64 && __builtin_offsetof(struct particle_data, Potential) == 152,
@@ -36,12 +38,9 @@ static MPI_Comm Comm;
 static int NTask = 1;
 
 /* ---- what the library was last told (mpg_shim.h) ---- */
-static int64_t Epoch;              /* particle-table epoch handed to mpg_set_particle_epoch */
-static inttime_t TableTi = -1;     /* (Ti_Current, &P[0], NumPart) of that epoch */
-static const void *TableBase;
-static int64_t TableNumPart = -1;
-static int TableDirty = 1;         /* mpg_shim_particles_changed() */
-static uint64_t TableSample;      /* table_sample_hash() of the table the epoch was declared for */
+static struct mpg_table_key Table = MPG_TABLE_KEY_INIT; /* the particle-table epoch handed to mpg_set_particle_epoch and the
+                                                         * (Ti_Current, &P[0], NumPart, sample hash) it was declared for (mpg_shim_epoch.h) */
+#define Epoch (Table.epoch)
 static DomainDecomp *Domain;       /* the run's decomposition object */
 static uint64_t DomainHash;        /* of what mpg_dist_set_domain last received ... */
 static double DomainMargin;        /* ... with this margin */
@@ -93,7 +92,7 @@ mpg_particle_view mpg_shim_view(void)
 #define view mpg_shim_view
 
 void mpg_shim_set_domain(DomainDecomp *ddecomp) { Domain = ddecomp; }
-void mpg_shim_particles_changed(void) { TableDirty = 1; }
+void mpg_shim_particles_changed(void) { Table.dirty = 1; }
 void mpg_shim_dist_tree_replaced(void) { DistTreeEpoch = -1; }
 double mpg_shim_margin(void) { return DomainMargin; }
 
@@ -118,26 +117,12 @@ static uint64_t domain_hash(const DomainDecomp *dd)
     return h;
 }
 
-/* FNV-1a over the IDs and positions of 64 records spread over the table: a reorder or an exchange inside one
- * Ti_Current that keeps &P[0] and NumPart (the second domain_decompose_full of the first step, fof_fof's exchange) changes it; a caller
- * that knows can still say so at once with mpg_shim_particles_changed() */
+/* the sample hash of mpg_shim_epoch.h over P[]: a reorder or an exchange inside one Ti_Current that keeps &P[0] and NumPart
+ * changes it; a caller that knows can still say so at once with mpg_shim_particles_changed() */
 static uint64_t table_sample_hash(void)
 {
-    uint64_t h = 1469598103934665603ull;
-    const int64_t n = PartManager->NumPart, stride = n > 64 ? n / 64 : 1;
-    int64_t i;
-    int k;
-#define MIX(x) (h = (h ^ (uint64_t)(x)) * 1099511628211ull)
-    for(i = 0; i < n; i += stride) {
-        MIX(P[i].ID);
-        for(k = 0; k < 3; k++) {
-            uint64_t b;
-            memcpy(&b, &P[i].Pos[k], sizeof(b));
-            MIX(b);
-        }
-    }
-#undef MIX
-    return h;
+    return mpg_table_sample_hash(P, sizeof(struct particle_data), PartManager->NumPart, offsetof(struct particle_data, ID),
+                                 offsetof(struct particle_data, Pos));
 }
 
 static void push_domain(double BoxSize, double margin)
@@ -164,22 +149,15 @@ void mpg_shim_sync(inttime_t Ti_Current, double Time, double BoxSize, double mar
 {
     eng();
     /* ---- the particle table ---- */
-    if(Ti_Current < 0 && TableTi >= 0 && Time == get_atime(TableTi))
-        Ti_Current = TableTi; /* gravpm_force of the step whose density() / grav_short_tree() already came by (run.c:356,522) */
+    if(Ti_Current < 0 && Table.ti >= 0 && Time == get_atime((inttime_t)Table.ti))
+        Ti_Current = (inttime_t)Table.ti; /* gravpm_force of the step whose density() / grav_short_tree() already came by (run.c:356,522) */
     {
         const uint64_t sample = table_sample_hash();
-        int changed = TableDirty || Ti_Current < 0 || Ti_Current != TableTi || TableBase != (const void *)P || TableNumPart != PartManager->NumPart ||
-                      sample != TableSample;
+        int changed = mpg_table_key_differs(&Table, Ti_Current, (const void *)P, PartManager->NumPart, sample);
         if(NTask > 1) /* (the ghost plan and the local trees are rebuilt collectively: every rank takes the same decision) */
             MPI_Allreduce(MPI_IN_PLACE, &changed, 1, MPI_INT, MPI_MAX, Comm);
-        if(changed) {
-            Epoch++;
-            TableTi = Ti_Current;
-            TableBase = (const void *)P;
-            TableNumPart = PartManager->NumPart;
-            TableSample = sample;
-            TableDirty = 0;
-        }
+        if(changed)
+            mpg_table_key_take(&Table, Ti_Current, (const void *)P, PartManager->NumPart, sample);
     }
     ck(mpg_set_particle_epoch(E, Epoch));
     /* ---- the decomposition (several ranks) ---- */

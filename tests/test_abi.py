@@ -78,6 +78,22 @@ def test_mpi_comm_shim_compiles():
     assert r.returncode == 0, r.stderr
 
 
+def test_shim_epoch_bookkeeping(tmp_path):
+    """shim/mpg_shim_epoch.h - when mpg_shim_sync declares a new particle-table epoch - compiled and RUN on 160-byte records
+    (tests/c/test_shim_epoch.c): one epoch per step, a new one for a new Ti_Current, moved / reordered / resized / relocated tables,
+    the explicit hook, callers without a Ti_Current; and the documented limit of the 64-record sample."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "test_shim_epoch")
+    r = subprocess.run(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "shim"),
+                        os.path.join(ROOT, "tests", "c", "test_shim_epoch.c"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("PASS"), r.stdout[-2000:]
+
+
 def test_shim_mpi_communicator_runs(tmp_path):
     """shim/mpg_mpi_comm.c under a REAL MPI on the CPU (tests/c/test_mpi_comm.c, mpiexec -n 1 / 3 / 4): all-reduce (double / int64, sum /
     max, a count beyond INT_MAX refused), the all-to-all of counts, and the byte all-to-all-v on ragged, empty and gapped blocks - also
