@@ -451,6 +451,36 @@ def parity_check_ranks(pkg, torch, dist, args, dev, rank, world, host_pos, host_
     return res
 
 
+def ranks_roofline(pkg, torch, dist, dev, rank, world, eng, cnt, walk_ms, walk_launches, n_own, ghosts, ic):
+    """Every rank's walk against the two ceilings (collective; the same arithmetic as walk_roofline): fp64 vector issue from the
+    rank's own counters and HIP events, and HBM - `hbm_measured_frac` where a PMC summary of this build exists: the bytes per list
+    entry measured on one GPU (profiles/walk_traffic.json) x the rank's list entries / its walk time / 8 TB/s (PMC counters cannot be
+    collected inside a timed multi-process run; the per-entry figure is what the one-GPU passes measured for the same kernels)."""
+    t = walk_ms / max(walk_launches, 1) * 1e-3
+    flops = (cnt["pp"] + cnt["nodes_used"]) * float(FLOP_PER_INTERACTION)
+    entries = float(cnt["int_steps"] + cnt["int_lanes"])
+    row = torch.tensor([t * 1e3, flops, entries, float(n_own), float(ghosts), float(torch.cuda.current_device()),
+                        float(cnt["pp"]), float(cnt["nodes_used"])], dtype=torch.float64, device=dev)
+    rows = [torch.zeros_like(row) for _ in range(world)]
+    dist.all_gather(rows, row)
+    rows = torch.stack(rows).cpu().numpy()
+    per_entry, note = None, "no PMC summary of this library build: hbm_measured_frac null"
+    tpath = os.path.join(ROOT, "profiles", "walk_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        e = tj.get("by_ic", {}).get(ic, {}).get("6")
+        if tj.get("build_stamp") == pkg.engine.load_library().mpg_build_stamp().decode() and e and e.get("list_entries_per_launch"):
+            per_entry = e["hbm_bytes_per_launch"] / e["list_entries_per_launch"]
+            note = "HBM bytes per list entry (%.1f B) from the one-GPU PMC passes of this build x the rank's entries" % per_entry
+    tt = np.maximum(rows[:, 0] * 1e-3, 1e-12)
+    return {"walk_ms": [round(float(x), 3) for x in rows[:, 0]],
+            "frac": [round(float(x), 4) for x in rows[:, 1] / tt / 1e12 / FP64_VALU_PEAK_TF],
+            "hbm_measured_frac": [round(float(x), 4) for x in rows[:, 2] * per_entry / tt / 1e9 / HBM_PEAK_GBS] if per_entry else None,
+            "hbm_note": note,
+            "own_particles": [int(x) for x in rows[:, 3]], "ghosts": [int(x) for x in rows[:, 4]], "device": [int(x) for x in rows[:, 5]],
+            "pp_interactions": [int(x) for x in rows[:, 6]], "nodes_used": [int(x) for x in rows[:, 7]]}
+
+
 def make_comm(pkg, torch, dist, args, dev, eng):
     """The communicator the multi-rank step runs on: the library's native RCCL communicator (csrc/rccl_comm.hip: ncclSend / ncclRecv /
     ncclAllReduce on the engine's stream, no Python in any collective), bootstrapped through the launcher's torch.distributed group and
@@ -569,6 +599,10 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
     cnt = eng.walk_counters()
     eng.set_instrumentation(False, False)
     eng.walk_events_collect()
+    per_rank = ranks_roofline(pkg, torch, dist, dev, rank, world, eng, cnt, walk_ms, walk_launches, n_own, st["ghosts"], args.ic)
+    rccl = comm.info() if hasattr(comm, "info") else None
+    if rccl is not None and rccl["nranks"] != world:
+        raise SystemExit("bench.py: RCCL reports %d ranks in the communicator, the launcher started %d" % (rccl["nranks"], world))
     parity = None
     if not args.no_parity_check:
         parity = parity_check_ranks(pkg, torch, dist, args, dev, rank, world, pos if rank == 0 else None, mass, box, n, nmesh, own_ids, loc, dforce, eng)
@@ -593,7 +627,10 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
             "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
             "phases_ms": {k: round(v, 3) for k, v in ph.items()},
         }
-        out["roofline"]["note"] += "; rank 0's walk over its own particles (counters and events of rank 0)"
+        out["roofline"]["note"] += "; rank 0's walk over its own particles (counters and events of rank 0); per_rank = the same of every rank"
+        out["roofline"]["per_rank"] = per_rank
+        out["config"]["rccl_ranks"] = rccl["nranks"] if rccl is not None else None     # ncclCommCount of the library's communicator
+        out["config"]["devices"] = per_rank["device"]
         if "work_after" in loc:
             out["config"]["load_balance"] = {
                 "walk_work_max_over_mean": round(loc["work_after"], 4), "particles_max_over_mean": round(loc["count_after"], 4),
@@ -738,6 +775,34 @@ def substep_bench(pkg, torch, args, dev, local_rank):
     return out
 
 
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks from here (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1 at a free port) and pass their exit code on.  Refuses - exit code 2, nothing printed on stdout -
+    when the box shows fewer than N GPUs: an N-GPU command must never produce a line measured on fewer.  (MPG_DIST_BACKEND=gloo, the
+    tests' way of putting several ranks on one GPU, lifts that check: the line then says `communicator: torch.distributed`.)"""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("MPG_DIST_BACKEND", "nccl")
+    if ndev < 1 or (backend == "nccl" and ndev < ngpus):
+        print("bench.py: --gpus %d needs %d visible GPUs, this box shows %d (HIP_VISIBLE_DEVICES=%s): refusing to run - no line is "
+              "printed rather than one measured on fewer GPUs" % (ngpus, ngpus, ndev, os.environ.get("HIP_VISIBLE_DEVICES", "unset")),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: --gpus %d without a launcher: starting %d ranks (%s backend, %d GPUs visible)" % (ngpus, ngpus, backend, ndev),
+          file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -769,18 +834,28 @@ def main():
                          "hydro: configs[2] / [4] as their own line; substep: the short-range-only step; integrate / fof / domain: SURVEY 8(f) rows")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain process (`python bench.py --gpus N`, no launcher): the ranks are launched from here, one per GPU -
+        # never a one-GPU line under an N-GPU command
+        return self_launch(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE %d != --gpus %d (the launcher's rank count and --gpus must agree)" % (world, args.gpus))
 
     pkg = importlib.import_module("mp-gadget_amd")
     import torch
     import torch.distributed as dist
 
+    ndev = torch.cuda.device_count()
     if os.environ.get("MPG_DIST_BACKEND", "nccl") != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % max(ndev, 1)
+    elif local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own: %d device(s) visible; RCCL needs one GPU per rank"
+                         % (rank, local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # MPG_FORCE_MGPU=1: run the multi-GPU code path (collectives included) in a one-rank group - a single-GPU box can then
@@ -1173,7 +1248,7 @@ def hydro_bench_peano(pkg, torch, dist, args, dev, rank, world):
                "config": {"workload": "2x%d^3 DM+gas TreePM + %s SPH force step, Nmesh=%d, s_zel ICs, quintic kernel" % (n, "pressure-entropy" if PE else "density-entropy", nmesh),
                           "particles": N, "parallelism": "%d GPUs: particles on the owners of their Peano-Hilbert TopLeaves, choreography in the library "
                                                          "(mpg_dist_*), collectives on RCCL" % world,
-                          "communicator": comm_note,
+                          "communicator": comm_note, "rccl_ranks": comm.info()["nranks"] if hasattr(comm, "info") else None,
                           "ghost_fraction_rank0": round(st["ghosts"] / max(n_own, 1), 3), "density_iterations_last": eng.sph_stats()["iterations"]}}
     dist.barrier()
     dist.destroy_process_group()

@@ -606,6 +606,8 @@ int mpg_rccl_comm(mpg_rccl *r, mpg_comm *out);
 int mpg_rccl_selftest(mpg_rccl *r, int64_t bytes_per_peer);
 /* calls3: allreduce, alltoall_i64, alltoallv calls so far; bytes sent to OTHER ranks; the RCCL version code (any may be NULL) */
 int mpg_rccl_stats(mpg_rccl *r, int64_t *calls3, int64_t *bytes_sent, int *version);
+/* what RCCL reports for the communicator: ncclCommCount, ncclCommUserRank, and the HIP device it was created on (any may be NULL) */
+int mpg_rccl_comm_info(mpg_rccl *r, int *nranks, int *rank, int *device);
 const char *mpg_rccl_last_error(mpg_rccl *r); /* detail of the last failed callback */
 void mpg_rccl_destroy(mpg_rccl *r);
 

@@ -379,12 +379,15 @@ int mpg_dev_set_walk_cost(mpg_engine *eng, float *d_cost)
 }
 
 // OldAcc = |FullTreeGravAccel + GravPM| / G of every particle (grav_get_abs_accel, gravshort.h:70-80), the arithmetic of the walk kernels
-__global__ void __launch_bounds__(256) k_oldacc(int64_t n, const double *__restrict__ prev, const double *__restrict__ gravpm, double G,
-                                                double *__restrict__ old)
+// (rows: the targets of the walk, or all n when the list is NULL - only the targets' rows of prev / gravpm are read: under mpg_dist the
+// engine is bound to own + ghost rows while the caller's arrays hold the own rows only)
+__global__ void __launch_bounds__(256) k_oldacc(int64_t n, const int *__restrict__ list, const double *__restrict__ prev,
+                                                const double *__restrict__ gravpm, double G, double *__restrict__ old)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if(i >= n)
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if(k >= n)
         return;
+    const int64_t i = list ? (int64_t)list[k] : k;
     double s2 = 0;
     for(int j = 0; j < 3; j++) {
         const double a = prev[3 * i + j] + (gravpm ? gravpm[3 * i + j] : 0.0);
@@ -405,9 +408,13 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         // Results written in place over the previous acceleration (resident mode, mpg_dist callers): the two-kernel walk may run its
         // list pass a second time with longer lists after the evaluation has stored new values for the targets that fitted, and the
         // fallback kernels run after it, so the opening input is taken once, before any kernel of this walk writes.
+        // Taken for the walk's TARGETS only: with an active list the caller's arrays need not hold eng->n rows (mpg_dist binds the engine
+        // to own + ghost particles and passes arrays of the own rows; its targets are own rows).
+        const int64_t nrows = d_active ? nactive : eng->n;
         eng->w_old.reserve((size_t)eng->n + 1);
-        hipLaunchKernelGGL(k_oldacc, dim3((unsigned)((eng->n + 255) / 256)), dim3(256), 0, eng->stream, eng->n, d_prev_accel, d_gravpm, gp.G,
-                           eng->w_old.p);
+        if(nrows > 0)
+            hipLaunchKernelGGL(k_oldacc, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, eng->stream, nrows, d_active, d_prev_accel, d_gravpm,
+                               gp.G, eng->w_old.p);
         d_oldacc = eng->w_old.p;
         d_prev_accel = nullptr;
     }

@@ -34,6 +34,9 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;           // optional: a failed callback leaves peers with enqueued work
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -72,6 +75,9 @@ RcclApi &api()
         a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
+        a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
+        a.CommAbort = (decltype(a.CommAbort))dlsym(a.handle, "ncclCommAbort");
         a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
         a.Send = (decltype(a.Send))sym("ncclSend");
         a.Recv = (decltype(a.Recv))sym("ncclRecv");
@@ -100,6 +106,7 @@ struct mpg_rccl {
     std::string error;
     int64_t calls[3] = {0, 0, 0};   // allreduce, alltoall_i64, alltoallv
     int64_t bytes_sent = 0;
+    bool dead = false;              // a collective failed half-way: the communicator was aborted (fail_fatal)
 };
 
 namespace {
@@ -124,6 +131,19 @@ namespace {
 // one block of `bytes` to / from `peer`, in pieces of at most r->piece bytes.  Always as bytes (ncclChar): a send and its matching receive
 // must agree on datatype and count, and the two sides of a block know nothing of each other's alignment; for point-to-point transfers
 // the datatype only scales the count.
+// A callback that fails after some ranks have enqueued their side of a collective cannot be repaired locally: the peers' matching
+// operations would wait for ever.  The communicator is aborted (ncclCommAbort: pending operations of every rank of it end with an
+// error) and every later call on it fails at once - a failed collective is fatal for the job, as an MPI error is in the reference.
+int fail_fatal(mpg_rccl *r)
+{
+    if(r->comm && api().CommAbort) {
+        api().CommAbort(r->comm);
+        r->comm = nullptr;
+    }
+    r->dead = true;
+    return 1;
+}
+
 int send_block(mpg_rccl *r, const char *p, size_t bytes, int peer)
 {
     for(size_t o = 0; o < bytes; o += r->piece)
@@ -141,6 +161,10 @@ int recv_block(mpg_rccl *r, char *p, size_t bytes, int peer)
 int a2av_device(mpg_rccl *r, const char *send, const int64_t *sb, const int64_t *sd, char *recv, const int64_t *rb, const int64_t *rd)
 {
     const int nt = r->nt, me = r->me;
+    if(r->dead) {
+        r->error = "the communicator was aborted after a failed collective";
+        return 1;
+    }
     if(!r->self_through_rccl) {
         if(sb[me] != rb[me]) {
             r->error = "alltoallv: the rank's own block has different send and receive sizes";
@@ -162,12 +186,12 @@ int a2av_device(mpg_rccl *r, const char *send, const int64_t *sb, const int64_t 
         if((to != me || r->self_through_rccl) && sb[to] > 0)
             if(send_block(r, send + sd[to], (size_t)sb[to], to)) {
                 api().GroupEnd();
-                return 1;
+                return fail_fatal(r);
             }
         if((from != me || r->self_through_rccl) && rb[from] > 0)
             if(recv_block(r, recv + rd[from], (size_t)rb[from], from)) {
                 api().GroupEnd();
-                return 1;
+                return fail_fatal(r);
             }
     }
     NCCL_TRY(r, api().GroupEnd());
@@ -184,7 +208,23 @@ int finish(mpg_rccl *r, bool block)
 int cb_bind_stream(void *ctx, void *hip_stream)
 {
     mpg_rccl *r = (mpg_rccl *)ctx;
-    r->stream = (hipStream_t)hip_stream;
+    hipStream_t next = (hipStream_t)hip_stream;
+    if(next != r->stream) {
+        // collectives still pending on the stream used so far must precede anything enqueued on the new one (RCCL orders the
+        // operations of one communicator by their stream: two streams need an edge between them)
+        HIP_TRY(r, hipSetDevice(r->device));
+        hipEvent_t ev;
+        HIP_TRY(r, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, r->stream);
+        if(e == hipSuccess)
+            e = hipStreamWaitEvent(next, ev, 0);
+        (void)hipEventDestroy(ev);
+        if(e != hipSuccess) {
+            r->error = std::string("bind_stream: ") + hipGetErrorString(e);
+            return 1;
+        }
+    }
+    r->stream = next;
     r->bound = true;
     return 0;
 }
@@ -195,6 +235,10 @@ int cb_allreduce(void *ctx, void *buf, int64_t count, int dtype, int op, int on_
     r->calls[0]++;
     if(count <= 0)
         return 0;
+    if(r->dead) {
+        r->error = "the communicator was aborted after a failed collective";
+        return 1;
+    }
     HIP_TRY(r, hipSetDevice(r->device));
     const ncclDataType_t ty = dtype ? ncclInt64 : ncclDouble;
     const ncclRedOp_t red = op ? ncclMax : ncclSum;
@@ -303,7 +347,12 @@ int mpg_rccl_create(mpg_rccl **out, int ThisTask, int NTask, const void *id128, 
         delete r;
         throw mpg::Error(msg);
     }
-    MPG_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
+    const hipError_t se = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking);
+    if(se != hipSuccess) {
+        api().CommDestroy(r->comm);
+        delete r;
+        throw mpg::Error(std::string("mpg_rccl_create: hipStreamCreateWithFlags: ") + hipGetErrorString(se));
+    }
     r->stream = r->own_stream;
     *out = r;
     API_END
@@ -322,6 +371,26 @@ int mpg_rccl_comm(mpg_rccl *r, mpg_comm *out)
     out->alltoall_i64 = cb_alltoall_i64;
     out->alltoallv = cb_alltoallv;
     out->bind_stream = cb_bind_stream;
+    API_END
+}
+
+int mpg_rccl_comm_info(mpg_rccl *r, int *nranks, int *rank, int *device)
+{
+    API_BEGIN
+    MPG_CHECK(r, "null argument");
+    MPG_CHECK(r->comm, "the communicator was aborted after a failed collective");
+    // what RCCL itself says the communicator spans (ncclCommCount / ncclCommUserRank), not what the caller passed to mpg_rccl_create
+    int n = -1, me = -1;
+    ncclResult_t res = api().CommCount(r->comm, &n);
+    MPG_CHECK(res == ncclSuccess, std::string("ncclCommCount: ") + api().GetErrorString(res));
+    res = api().CommUserRank(r->comm, &me);
+    MPG_CHECK(res == ncclSuccess, std::string("ncclCommUserRank: ") + api().GetErrorString(res));
+    if(nranks)
+        *nranks = n;
+    if(rank)
+        *rank = me;
+    if(device)
+        *device = r->device;
     API_END
 }
 

@@ -144,6 +144,7 @@ class RcclComm:
         lib.mpg_rccl_comm.argtypes = [C.c_void_p, C.POINTER(MpgComm)]
         lib.mpg_rccl_selftest.argtypes = [C.c_void_p, C.c_int64]
         lib.mpg_rccl_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        lib.mpg_rccl_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mpg_rccl_destroy.argtypes = [C.c_void_p]
         lib.mpg_rccl_destroy.restype = None
         lib.mpg_rccl_last_error.argtypes = [C.c_void_p]
@@ -176,6 +177,13 @@ class RcclComm:
         calls, sent, ver = (C.c_int64 * 3)(), C.c_int64(0), C.c_int(0)
         self.lib.mpg_rccl_stats(self.h, calls, C.byref(sent), C.byref(ver))
         return dict(allreduce=calls[0], alltoall_i64=calls[1], alltoallv=calls[2], bytes_sent=sent.value, rccl_version=ver.value)
+
+    def info(self):
+        """what RCCL itself reports for the communicator: ncclCommCount, ncclCommUserRank, the HIP device"""
+        n, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        if self.lib.mpg_rccl_comm_info(self.h, C.byref(n), C.byref(r), C.byref(d)):
+            raise E.EngineError("RCCL: " + self.lib.mpg_last_error().decode())
+        return dict(nranks=n.value, rank=r.value, device=d.value)
 
     def last_error(self):
         return (self.lib.mpg_rccl_last_error(self.h) or b"").decode() if self.h else ""

@@ -98,6 +98,36 @@ def test_multi_gpu_parity_check_on_four_ranks():
     assert pc["ok"] and pc["counters_equal"] and pc["n"] >= 2000, pc
 
 
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as a PLAIN command (no torchrun, no WORLD_SIZE - the shape of the driver's N = 1 command): bench.py
+    launches the two ranks itself.  With the default backend it must REFUSE on this one-GPU box (exit code 2, no JSON line: an N-GPU
+    command never prints a line measured on fewer GPUs); with MPG_DIST_BACKEND=gloo (ranks sharing the GPU) it prints `n_gpus: 2`
+    with a green parity_check and one roofline entry per rank."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPG_DIST_BACKEND", "MPG_FORCE_MGPU")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 2, (r.returncode, r.stderr[-2000:])
+        assert "needs 2 visible GPUs" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")], (r.stdout[-500:], r.stderr[-500:])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, MPG_DIST_BACKEND="gloo"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["config"]["particles"] == 64 ** 3
+    assert j["parity_check"]["ok"] and j["parity_check"]["counters_equal"], j["parity_check"]
+    pr = j["roofline"]["per_rank"]
+    assert len(pr["walk_ms"]) == 2 and len(pr["frac"]) == 2 and sum(pr["own_particles"]) == 64 ** 3 and all(0 < f <= 1 for f in pr["frac"])
+    assert j["config"]["communicator"].startswith("torch.distributed") and j["config"]["rccl_ranks"] is None
+    # a launcher whose rank count disagrees with --gpus is an error, not a line
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in r.stderr
+
+
+def test_one_rank_rccl_group_reports_the_communicator_rccl_sees():
+    j = run_bench(["--gpus", "1", "--size", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env={"MPG_FORCE_MGPU": "1", "MASTER_PORT": "29174"})
+    assert j["config"]["rccl_ranks"] == 1 and j["n_gpus"] == 1 and len(j["roofline"]["per_rank"]["walk_ms"]) == 1
+
+
 def test_other_workloads():
     h = run_bench(["--workload", "hydro", "--size", "32", "--steps", "1", "--warmup", "0"])
     assert KEYS <= set(h) and "roofline_hydro" in h and h["roofline"]["bound"] == "fp64_valu"

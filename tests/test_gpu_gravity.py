@@ -495,6 +495,21 @@ def test_peano_domain_ranks_match_one(tmp_path, ic):
 
 
 @keep_artifacts_on_failure
+def test_peano_domain_walk_in_place_on_ranks(tmp_path):
+    """mpg_dist_gravity_step with prev_accel aliased to accel (the resident caller's FullTreeGravAccel) on 1 and 3 ranks: the opening
+    input is taken for the walk's targets only - the engine is bound to own + ghost rows, the caller's arrays hold the own rows - and the
+    result equals the walk into a separate array (asserted inside the tool on every rank) and the one-GPU second step."""
+    n = 36
+    env = {"MPG_INPLACE": "1"}
+    for name, nproc, port in (("p1.npy", 1, 0), ("p3.npy", 3, 29612)):
+        d = _run_mgpu(tmp_path, name, nproc, "peano" if nproc > 1 else "peano1", port, ic="s_clust", n=n, env_extra=env)
+        if nproc == 1:
+            one = d
+        assert np.abs(d[:, 0:3]).min() > 0
+        assert_accel_parity(d[:, 0:3], one[:, 0:3])
+
+
+@keep_artifacts_on_failure
 def test_peano_domain_substep_active_subset(tmp_path):
     """A sub-step on several ranks (run.c:392-470 without the hierarchical trees): the tree holds every particle, every fifth one is
     active and walked (mpg_dist_dev_grav_short_tree_active).  The active particles get the accelerations of the one-GPU sub-step,

@@ -185,3 +185,22 @@ def test_mpg_comm_piecewise_alltoallv_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_bench_gpus_n_refuses_without_n_gpus():
+    """`python bench.py --gpus 2` as a plain command on a box that shows fewer than 2 GPUs (here: none) exits with code 2 and prints no
+    JSON line - it never falls through to a one-GPU measurement.  A launcher whose WORLD_SIZE disagrees with
+    --gpus is refused as well."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs the command asks for")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MPG_DIST_BACKEND", "MPG_FORCE_MGPU")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "32", "--steps", "1", "--warmup", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1500:])
+    assert "needs 2 visible GPUs" in r.stderr
+    assert not [x for x in r.stdout.splitlines() if x.startswith("{")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE 4 != --gpus 2" in r.stderr

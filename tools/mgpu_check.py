@@ -86,6 +86,19 @@ else:
         df.grav_short_tree(ga, oldacc=torch.full((n_own,), 1e-7, **f8), active=act)
     else:
         df.gravity_step(opos, omass, ga, gg, potential=gp, oldacc=torch.full((n_own,), 1e-7, **f8))
+        if os.environ.get("MPG_INPLACE"):
+            # a second step with the relative criterion's input taken from the last acceleration, once into a separate array and once
+            # IN PLACE (prev_accel aliased to accel, as a resident caller keeps FullTreeGravAccel): the same values.  The engine is bound
+            # to own + ghost rows here while these arrays hold the own rows only (the in-place OldAcc pass read eng->n rows).
+            sep, gp2 = torch.zeros_like(ga), torch.zeros_like(gp)
+            df.gravity_step(opos, omass, sep, gg, potential=gp2, prev_accel=ga)
+            inp = ga.clone()
+            df.gravity_step(opos, omass, inp, gg, potential=gp2, prev_accel=inp)
+            torch.cuda.synchronize()
+            err = float((inp - sep).abs().max() / sep.abs().mean())
+            print("rank %d in-place walk vs separate arrays: %.3e" % (rank, err), flush=True)
+            assert err <= 1e-12, err
+            ga = inp
     both = torch.zeros(N, 7, **f8)
     both[oids] = torch.cat([ga, gg, gp[:, None]], dim=1)
     if grouped:

@@ -124,8 +124,13 @@ if variants:
         pass
     try:
         line = [x for x in open(os.path.join(root, "bench_trace.json")) if x.startswith("{")][-1]
-        wl = json.loads(line)["config"]["workload"]
+        jl = json.loads(line)
+        wl = jl["config"]["workload"]
         ic = [k for k in ("s_grid", "s_zel", "s_clust") if k in wl][0]
+        # list entries of one walk (leaf + node entries): bench.py prices the ranks of a multi-GPU run per entry
+        rf = jl.get("roofline", {})
+        if "6" in variants and rf.get("leaf_entries_per_launch") and rf.get("node_entries_per_launch"):
+            variants["6"]["list_entries_per_launch"] = rf["leaf_entries_per_launch"] + rf["node_entries_per_launch"]
     except (OSError, IndexError, KeyError, ValueError):
         pass
     print("== walk traffic (%s, build %s):" % (ic, stamp), json.dumps(variants))
