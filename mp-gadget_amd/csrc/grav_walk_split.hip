@@ -57,11 +57,26 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 }
 
 // Softened branch of apply_accn_to_output, gravshort-tree.c:168-185 (Gadget-2 spline, constants as truncated there).
-// Rare (the self interaction, close encounters).  Its constants live in constant memory and are fetched inside the branch
-// (the empty asm keeps hipcc from hoisting the fetches out of the pair loop, where they would occupy ~30 registers), and
-// the divisions are v_rcp_f64 + Newton steps (<= 1 ulp from the quotient) instead of the 40-instruction IEEE expansion.
+// Rare (close encounters; the self interaction takes the literals in pair_force).  Its 13 constants must not occupy registers in the
+// pair loop, so they are produced INSIDE the branch.  Rounds 1-4 fetched them from constant memory through a laundered pointer, which
+// hipcc turned into flat_load + s_waitcnt vmcnt(0): two (inner spline branch) to five (outer) serialised memory round trips per
+// softened pair step, each wait also draining the prefetched source records - a softened step cost ~10 ordinary ones, and a clustered
+// set has them.  Now every constant is two s_mov_b32 of literals into a scalar register pair, emitted by a volatile asm at the point
+// of use (volatile: not hoisted out of the branch): no memory access, no wait.  (MPG_SPLINE_CONSTMEM restores the loads.)
+// The divisions are v_rcp_f64 + Newton steps (<= 1 ulp from the quotient) instead of the 40-instruction IEEE expansion.
+#ifdef MPG_SPLINE_CONSTMEM
 __constant__ double SPLINE_C[13] = {10.666666666667, 32.0, 38.4,  -2.8, 5.333333333333, 6.4, 9.6,
                                     21.333333333333, 48.0, 0.066666666667, -3.2, -16.0, 2.133333333333};
+#endif
+
+template <unsigned long long BITS>
+__device__ __forceinline__ double scalar_literal()
+{
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((unsigned)(BITS & 0xffffffffull)), "i"((unsigned)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define MPG_K(x) scalar_literal<__builtin_bit_cast(unsigned long long, (double)(x))>()
 
 __device__ __forceinline__ double rcp_nr(double x)
 {
@@ -72,10 +87,11 @@ __device__ __forceinline__ double rcp_nr(double x)
 
 __device__ __forceinline__ void softened_pair(const double r, const double m, const double hinv, const double h3inv, double &fac, double &facpot)
 {
-    const double *c = SPLINE_C;
-    asm volatile("" : "+s"(c));
     const double u = r * hinv;
     double wpk;
+#ifdef MPG_SPLINE_CONSTMEM
+    const double *c = SPLINE_C;
+    asm volatile("" : "+s"(c));
     if(u < 0.5) {
         fac = m * h3inv * (c[0] + u * u * (c[1] * u - c[2]));
         wpk = c[3] + u * u * (c[4] + u * u * (c[5] * u - c[6]));
@@ -85,6 +101,19 @@ __device__ __forceinline__ void softened_pair(const double r, const double m, co
         fac = m * h3inv * (c[7] - c[8] * u + c[2] * u * u - c[0] * u * u * u - c[9] * (iu * iu * iu));
         wpk = c[10] + c[9] * iu + u * u * (c[0] + u * (c[11] + u * (c[6] - c[12] * u)));
     }
+#else
+    if(u < 0.5) {
+        fac = m * h3inv * (MPG_K(10.666666666667) + u * u * (MPG_K(32.0) * u - MPG_K(38.4)));
+        wpk = MPG_K(-2.8) + u * u * (MPG_K(5.333333333333) + u * u * (MPG_K(6.4) * u - MPG_K(9.6)));
+    }
+    else {
+        const double iu = rcp_nr(u);
+        fac = m * h3inv * (MPG_K(21.333333333333) - MPG_K(48.0) * u + MPG_K(38.4) * u * u - MPG_K(10.666666666667) * u * u * u -
+                           MPG_K(0.066666666667) * (iu * iu * iu));
+        wpk = MPG_K(-3.2) + MPG_K(0.066666666667) * iu +
+              u * u * (MPG_K(10.666666666667) + u * (MPG_K(-16.0) + u * (MPG_K(9.6) - MPG_K(2.133333333333) * u)));
+    }
+#endif
     facpot = m * hinv * wpk;
 }
 
@@ -654,23 +683,47 @@ __global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const
 // The two list loops of one group (8 lanes, lane s <-> source s of a leaf entry / entry r0 + s of the node list).
 // WRAP: take NEAREST() per pair (partmanager.h:99); otherwise plain differences (bit-identical where no image is wrapped).
 //
-// Leaf entries are fetched 8 per group at a time (one coalesced 256-byte read per wave), two batches ahead; sources are
-// requested two pair evaluations ahead of their use.  The scheduling barriers and the empty asm keep hipcc from
+// Leaf entries are fetched 8 per group at a time (one coalesced 256-byte read per wave: lane s takes entry e0 + s), one batch ahead of
+// their use, and staged in a per-group ring of 16 words in LDS; the pair loop reads the two entries of its next steps with ONE
+// ds_read2_b32 at a wave-uniform offset (all 8 lanes of a group read the same word: a broadcast).  Rounds 1-4 kept the batch in a
+// register and broadcast entry J with ds_bpermute per pair: v_and_or + v_cndmask + v_lshlrev + ds_bpermute + s_waitcnt lgkmcnt(0) in
+// front of EVERY source load - 3 vector and 1 LDS instruction more per pair step than this form, with the LDS latency exposed.
+// Sources are requested two pair evaluations ahead of their use.  The scheduling barriers and the empty asm keep hipcc from
 // interleaving or sinking the (independent) pair evaluations, which would triple the live registers.  A lane without a
 // source (short leaf, list exhausted) reads a zero-mass padding record behind the tree's source array instead: its pair
 // evaluates to exactly zero, so the accumulators are updated unconditionally (a conditional update makes hipcc keep a
 // renamed copy of the four accumulators per unrolled stage).
 // The lists of group g start at L + g * cap (layout: top of this file).
+constexpr int RING_STRIDE = 17; // words per group: 16 used; the odd stride puts the 8 groups' words on different banks
+
 template <bool POT, bool WRAP, bool O32>
 __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
                                            const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
-                                           const double py, const double pz, const double *__restrict__ s_wtab,
+                                           const double py, const double pz, const double *__restrict__ s_wtab, unsigned *__restrict__ ring_g,
                                            double &ax, double &ay, double &az, double &pot)
 {
     const unsigned empty = (zero_src << 3) | 7u; // a full "leaf" of zero-mass padding records
-    // source s of leaf entry J of the current batch.  O32: byte offsets formed directly (first particle * 32 = (entry & ~7) << 2)
+    // source s of leaf entry EJ.  O32: byte offsets formed directly (first particle * 32 = (entry & ~7) << 2)
     const unsigned s32 = (unsigned)s * 32u, zoff = zero_src * 32u;
-#define MPG_LOAD(ENT, J, SV)                                                                    \
+    unsigned zoff_v = zoff;
+    asm volatile("" : "+v"(zoff_v));
+#define MPG_LOAD(EJ, SV)                                                                        \
+    {                                                                                           \
+        const unsigned ej_ = (EJ);                                                              \
+        if(O32) {                                                                               \
+            unsigned off_, cnt_; /* (first particle + s) * 32, or the padding record's offset for a lane beyond the leaf's particles; */ \
+            /* written out: hipcc forms (e << 2) & ~31 + a separate add, and moves the (scalar) padding offset into a register per use */ \
+            /* (v_cndmask reads vcc through the constant bus, which leaves no room for a scalar source: the offset is pinned in a VGPR) */ \
+            asm("v_and_b32 %0, -8, %2\n\tv_and_b32 %1, 7, %2\n\tv_lshl_add_u32 %0, %0, 2, %3\n\tv_cmp_le_u32 vcc, %4, %1\n\t" \
+                "v_cndmask_b32 %0, %5, %0, vcc"                                                  \
+                : "=&v"(off_), "=&v"(cnt_) : "v"(ej_), "v"(s32), "v"((unsigned)s), "v"(zoff_v) : "vcc"); \
+            SV = *(const Src4 *)((const char *)tv.src + (size_t)off_);                          \
+        }                                                                                       \
+        else                                                                                    \
+            SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
+    }
+#ifdef MPG_EVAL_BPERMUTE // rounds 1-4: the batch's entries in a register, entry J broadcast with ds_bpermute per pair (kept for same-box A/B runs)
+#define MPG_LOAD_BP(ENT, J, SV)                                                                    \
     {                                                                                           \
         const unsigned ej_ = (unsigned)__shfl((int)(ENT), gshift + (J));                        \
         if(O32) {                                                                               \
@@ -681,6 +734,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         else                                                                                    \
             SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
     }
+#endif
 #define MPG_EVAL(SV)                                                              \
     {                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                        \
@@ -701,25 +755,56 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // index of leaf entry e0 + s (e0 a multiple of 8)
         const unsigned ls = (unsigned)((gshift >> 3) * cap + s);
 #define MPG_LEAF_AT(E0) (ls + (unsigned)(E0))
+#ifdef MPG_EVAL_BPERMUTE
         unsigned ent = (s < nleaf) ? ld<true>(L, MPG_LEAF_AT(0)) : empty;
         unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(8)) : empty;
         Src4 A, B;
-        MPG_LOAD(ent, 0, A);
+        MPG_LOAD_BP(ent, 0, A);
         for(int e0 = 0;; e0 += 8) {
             if(!any_lane(e0 < nleaf))
                 break;
             const unsigned ent_nn = (e0 + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e0 + 16)) : empty;
 #pragma unroll 1
             for(int j = 0; j < 8; j += 2) {
-                MPG_LOAD(ent, j + 1, B);
+                MPG_LOAD_BP(ent, j + 1, B);
                 MPG_EVAL(A);
                 const unsigned en = (j + 2 < 8) ? ent : ent_n;
-                MPG_LOAD(en, (j + 2) & 7, A);
+                MPG_LOAD_BP(en, (j + 2) & 7, A);
                 MPG_EVAL(B);
             }
             ent = ent_n;
             ent_n = ent_nn;
         }
+#else
+        // batch 0 into ring slot 0, batch 1 requested.  (LDS operations of one wave complete in order; the wave barriers only keep
+        // hipcc from moving the ring's reads over its writes.)
+        __builtin_amdgcn_wave_barrier(); // (the previous chunk's reads of the ring are done)
+        ring_g[s] = (s < nleaf) ? ld<true>(L, MPG_LEAF_AT(0)) : empty;
+        unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(8)) : empty;
+        __builtin_amdgcn_wave_barrier();
+        unsigned eb = ring_g[1];
+        Src4 A, B;
+        MPG_LOAD(ring_g[0], A);
+        for(int e0 = 0;; e0 += 8) {
+            if(!any_lane(e0 < nleaf))
+                break;
+            // the next batch into the other half of the ring (its first entry is read in the last stage below), the one after requested
+            ring_g[((e0 + 8) & 8) + s] = ent_n;
+            ent_n = (e0 + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e0 + 16)) : empty;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for(int j = 0; j < 8; j += 2) {
+                MPG_LOAD(eb, B);
+                // entries e0 + j + 2 (the next A) and e0 + j + 3 (the next B): one ds_read2_b32, back before the evaluation of A ends
+                const unsigned *__restrict__ rr = ring_g + ((e0 + j + 2) & 15);
+                const unsigned ea = rr[0];
+                eb = rr[1];
+                MPG_EVAL(A);
+                MPG_LOAD(ea, A);
+                MPG_EVAL(B);
+            }
+        }
+#endif
     }
     // ---- node entries (level-order indices): lane s takes entry r0 + s; entries two batches ahead, moments one
     if(any_lane(nnode > 0)) {
@@ -741,6 +826,9 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         }
     }
 #undef MPG_LOAD
+#ifdef MPG_EVAL_BPERMUTE
+#undef MPG_LOAD_BP
+#endif
 #undef MPG_EVAL
 #undef MPG_LEAF_AT
 #undef MPG_NODE_AT
@@ -752,6 +840,7 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
 {
     constexpr int ROW = POT ? 4 : 2;
     __shared__ __attribute__((aligned(16))) double s_wtab[NTAB * ROW];
+    __shared__ unsigned s_ring[4 * 8 * RING_STRIDE]; // per wave and group: two batches of leaf entries (eval_lists)
     set_wave_prio(io.eval_prio);
     for(int i = threadIdx.x; i < NTAB; i += blockDim.x) {
         const bool last = i == NTAB - 1; // the row the clamp lands on: zeros
@@ -767,6 +856,7 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, s = lane & 7;
     const int gshift = grp * 8;
+    unsigned *__restrict__ ring_g = s_ring + ((threadIdx.x >> 6) * 8 + grp) * RING_STRIDE;
     const unsigned nchunks = (unsigned)((nslots + 7) / 8);
     const ChunkIter it(nchunks);
     const unsigned zero_src = (unsigned)(tv.npart + tv.nnodes); // zero-mass padding records (TreeBuilder::build)
@@ -796,9 +886,9 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
         const unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8; // wave-uniform
         double ax = 0, ay = 0, az = 0, pot = 0;
         if(!FASTWRAP || any_lane(wrapped)) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
-            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ring_g, ax, ay, az, pot);
         else
-            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ax, ay, az, pot);
+            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ring_g, ax, ay, az, pot);
         // reduce the partial sums over the 8 lanes of the group
         for(int off = 1; off < 8; off <<= 1) {
             ax += __shfl_xor(ax, off);

@@ -544,6 +544,18 @@ def test_peano_domain_hierarchical_active_tree(tmp_path):
 
 @pytest.mark.parametrize("ic", ["s_grid", "s_zel", "s_clust"])
 def test_full_size_256_properties(pkg, orc, ic):
+    _full_size_properties(pkg, orc, ic, 256)
+
+
+def test_c4_full_size_512_against_oracle(pkg, orc):
+    """BASELINE configs[3]'s WHOLE particle set (512^3 = 134 M particles, Nmesh 1024) on the one GPU, CHECKED against the oracle as the
+    256^3 sets are: GravPM of all 134 M particles against oracle/pm_oracle.c at Nmesh 1024 (<= 1e-10 of the mean) and 2048 sampled
+    targets against the oracle walking the oracle-built tree of all particles (assert_accel_parity) - the walk here runs its
+    64-bit-offset kernels and slices its list area (this run asserted counter ranges only)."""
+    _full_size_properties(pkg, orc, "s_zel", 512)
+
+
+def _full_size_properties(pkg, orc, ic, n):
     """256^3, Nmesh 512 (BASELINE configs[1]) on the device-resident path, on the three input sets of SURVEY 8(d) (the jittered grid,
     the Zel'dovich-displaced grid of the headline, the strongly clustered set): size-independent properties + a sampled oracle
     comparison.
@@ -555,8 +567,8 @@ def test_full_size_256_properties(pkg, orc, ic):
         pocketfft on the 512^3 mesh): 1e-10 of the mean |GravPM|;
       * 2048 random targets agree with the oracle walking the oracle-built tree of all 16.8 M particles."""
     import torch
-    clk = phase_clock("full_size_256[%s]" % ic)
-    n, nmesh = 256, 512
+    clk = phase_clock("full_size_%d[%s]" % (n, ic))
+    nmesh = 2 * n
     pos, mass, box = getattr(pkg.ics, ic)(n)
     clk.mark("ics")
     N = len(pos)
