@@ -785,24 +785,29 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         unsigned eb = ring_g[1];
         Src4 A, B;
         MPG_LOAD(ring_g[0], A);
-        for(int e0 = 0;; e0 += 8) {
-            if(!any_lane(e0 < nleaf))
-                break;
-            // the next batch into the other half of the ring (its first entry is read in the last stage below), the one after requested
-            ring_g[((e0 + 8) & 8) + s] = ent_n;
-            ent_n = (e0 + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e0 + 16)) : empty;
-            __builtin_amdgcn_wave_barrier();
+        // ONE loop over pairs of entries up to the longest leaf list of the wave's 8 targets (a loop over batches around a loop over
+        // the pairs of a batch made hipcc copy the four accumulators out and back at every batch: 8 v_mov_b64 per 8 pair steps; and
+        // whole batches ran up to 6 pair steps beyond the longest list)
+        int wmax = nleaf;
+        for(int off = 8; off < 64; off <<= 1)
+            wmax = max(wmax, __shfl_xor(wmax, off));
+        wmax = __builtin_amdgcn_readfirstlane(wmax);
 #pragma unroll 1
-            for(int j = 0; j < 8; j += 2) {
-                MPG_LOAD(eb, B);
-                // entries e0 + j + 2 (the next A) and e0 + j + 3 (the next B): one ds_read2_b32, back before the evaluation of A ends
-                const unsigned *__restrict__ rr = ring_g + ((e0 + j + 2) & 15);
-                const unsigned ea = rr[0];
-                eb = rr[1];
-                MPG_EVAL(A);
-                MPG_LOAD(ea, A);
-                MPG_EVAL(B);
+        for(int e = 0; e < wmax; e += 2) {
+            if((e & 7) == 0) { // (wave-uniform) the next batch into the other half of the ring - its first entry is read in the
+                               // last stage of this batch -, the one after that requested
+                ring_g[((e + 8) & 8) + s] = ent_n;
+                ent_n = (e + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e + 16)) : empty;
+                __builtin_amdgcn_wave_barrier();
             }
+            MPG_LOAD(eb, B);
+            // entries e + 2 (the next A) and e + 3 (the next B): one ds_read2_b32, back before the evaluation of A ends
+            const unsigned *__restrict__ rr = ring_g + ((e + 2) & 15);
+            const unsigned ea = rr[0];
+            eb = rr[1];
+            MPG_EVAL(A);
+            MPG_LOAD(ea, A);
+            MPG_EVAL(B);
         }
 #endif
     }
