@@ -162,6 +162,8 @@ int mpg_resident_fetch(mpg_engine *eng, const mpg_particle_view *pv, unsigned fi
 int mpg_resident_push(mpg_engine *eng, const mpg_particle_view *pv, unsigned fields);
 int mpg_resident_end(mpg_engine *eng, const mpg_particle_view *pv);
 
+/* (a gas run stays resident too: mpg_resident_sph_begin and the integrator calls further down, behind the types they take) */
+
 /* ---- device-resident entry points (inputs and outputs stay in HBM) ---------------------------- */
 /* Bind device arrays in the caller's particle order: pos[n][3] f64, mass[n] f32, type[n] u8 (NULL = all type 1).
  * The arrays must stay valid until the next bind. */
@@ -325,7 +327,7 @@ int mpg_dev_grav_short_pair(mpg_engine *eng, const int *d_active, int64_t nactiv
  * bit 1 Swallowed; may be NULL).  Results are bit-identical to the reference's loops (no FMA contraction).
  * Not carried: black-hole repositioning (drift.c:33-55) and the dynamic-friction / drag kicks of type 5 (timestep.c:1003-1010). */
 #define MPG_TIMEBINS 46 /* timebinmgr.h:8 */
-typedef struct {
+typedef struct mpg_kick_factors_s {
     double gravkick[MPG_TIMEBINS + 1];  /* get_exact_gravkick_factor(Ti_kick[bin], Ti_kick[bin] + dti/2); 0 for inactive bins */
     double hydrokick[MPG_TIMEBINS + 1]; /* get_exact_hydrokick_factor, same interval (timestep.c:878-890) */
     double dt_entr[MPG_TIMEBINS + 1];   /* dloga_from_dti(dti_from_timebin(bin) / 2, Ti_Current)  (timestep.c:917) */
@@ -351,6 +353,16 @@ int mpg_dev_apply_half_kick(mpg_engine *eng, int64_t n, const int *d_active, int
  * / |a_phys|), a_phys = (FullTreeGravAccel + GravPM) / a^2.  Uses the softening set by mpg_gravshort_set_softenings. */
 int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_gravaccel, const double *d_gravpm, double atime, double hubble,
                                    double ErrTolIntAccuracy, double *d_dloga);
+
+/* get_timestep_hydro_dloga (timestep.c:1076-1118) for every particle: gas takes the Courant criterion 2 CourantFac a Hsml / (fac3
+ * MaxSignalVel), fac3 = a^(3 (1 - GAMMA) / 2), or, when shorter, the Gadget-4 criterion on the change of the smoothing length CourantFac
+ * a^2 |Hsml / (DtHsml + 1e-20)|; a black hole the step of the bin above the shortest of its gas neighbours (d_bh_mintimebin = BHP().minTimeBin
+ * per particle and dloga_for_bin[b] = get_dloga_for_bin(b, Ti_Current), a host array of MPG_TIMEBINS + 1 entries; both NULL: no limiter);
+ * every other type dt = 1.  d_titype (may be NULL) receives enum TimeStepType (timestep.c:89-96: 0 ACCEL, 1 COURANT, 3 NEIGH, 4 HSML).
+ * d_type NULL: no gas; d_dthsml NULL: zero. */
+int mpg_dev_timestep_hydro_dloga(mpg_engine *eng, int64_t n, const unsigned char *d_type, const double *d_hsml, const double *d_dthsml,
+                                 const double *d_maxsignalvel, const unsigned char *d_bh_mintimebin, const double *dloga_for_bin, double atime,
+                                 double hubble, double CourantFac, double *d_dloga, unsigned char *d_titype);
 
 /* ---- hierarchical gravity (SplitGravityTimestepsOn, the default): the level loop of timestep.c:239-599 on
  * device-resident arrays.  Per level it builds the tree of the particles active at that level (force_tree_active_moments),
@@ -395,6 +407,59 @@ int mpg_dev_hierarchical_gravity_and_timesteps(mpg_engine *eng, const mpg_hiergr
 int mpg_dev_hierarchical_gravity_accelerations(mpg_engine *eng, const mpg_hiergrav_arrays *A, const int *d_active, int64_t NumActiveParticle,
                                                int64_t NumActiveGravity, mpg_drift_kick_times *times, double rho0, int HybridNuGrav,
                                                mpg_gravkick_fn gravkick, void *gravkick_ctx);
+/* find_hydro_timesteps (timestep.c:617-733), the assignment of the hydro time bins of the active gas / black-hole particles, in its two
+ * halves: the particle loop on the device (new bin from get_timestep_hydro_dloga through convert_timestep_to_ti and get_timebin_from_dti,
+ * never above the particle's gravity bin, written to TimeBinHydro when old and new bin are active), and - after the caller's MPI_Allreduce of
+ * the smallest bin and the counts, where it has ranks - the update of times->mintimebin (host).  Not carried: the dynamic-friction bins of the
+ * black holes (timestep.c:676-695).  Uses the particles bound with mpg_dev_bind_particles for n. */
+typedef struct {
+    const unsigned char *d_type;          /* P[].Type; NULL: no gas */
+    const unsigned char *d_flags;         /* bit 0 IsGarbage, bit 1 Swallowed; may be NULL */
+    const double *d_hsml, *d_dthsml;      /* P[].Hsml, P[].DtHsml (may be NULL: zero) */
+    const double *d_maxsignalvel;         /* SPHP().MaxSignalVel (hydro_force) */
+    const unsigned char *d_tb_grav;       /* P[].TimeBinGravity; NULL: no cap */
+    unsigned char *d_tb_hydro;            /* P[].TimeBinHydro, updated */
+    const unsigned char *d_bh_mintimebin; /* BHP().minTimeBin per particle, or NULL */
+} mpg_hydrostep_arrays;
+typedef struct {
+    int mTimeBin;               /* the smallest new bin among this rank's particles (MPG_TIMEBINS if it has none): MPI_MIN over the ranks */
+    int64_t ntitype[5];         /* particles by criterion: TI_ACCEL, TI_COURANT, TI_ACCRETE, TI_NEIGH, TI_HSML (MPI_SUM) */
+    int64_t badstepsizecount;   /* bin_hydro < 1 (MPI_SUM; the function's return value in the reference) */
+    int64_t badtimebins;        /* print_bad_timebin cases: dti <= 1 or > TIMEBASE */
+} mpg_hydrostep_result;
+int mpg_dev_find_hydro_timesteps(mpg_engine *eng, const mpg_hydrostep_arrays *A, const int *d_active, int64_t NumActiveParticle,
+                                 const mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,
+                                 double atime, double hubble, mpg_hydrostep_result *out);
+/* the tail of find_hydro_timesteps (timestep.c:709-733) with the all-reduced smallest bin: the rule for a bin without active particles,
+ * set_bh_first_timestep on the first step (d_type / d_tb_hydro of n particles; may be NULL when isFirstTimeStep == 0), times->mintimebin */
+int mpg_dev_hydro_timesteps_finish(mpg_engine *eng, int mTimeBin_global, int isFirstTimeStep, int64_t n, const unsigned char *d_type,
+                                   unsigned char *d_tb_hydro, mpg_drift_kick_times *times);
+/* A GAS run stays resident too (round 5).  mpg_resident_sph_begin, on a resident table, uploads every array of `A` (host arrays in
+ * particle order, as the host forms mpg_density / mpg_hydro_force take them) ONCE; its vel / gacc / gpm then alias the resident
+ * P[].Vel / FullTreeGravAccel / GravPM, and the *_in arrays of the velocity / entropy prediction alias the *_out arrays (SphP.HydroAccel,
+ * SphP.DtEntropy: one field each in the reference).  From then on mpg_density / mpg_hydro_force called with the same `A` run on the device
+ * copies and leave their results there, and the integrator between the force steps runs on the device as well:
+ *   mpg_resident_drift_all_particles   drift_all_particles (drift.c:84-102): Pos, and Hsml += DtHsml * ddrift for gas
+ *   mpg_resident_apply_pm_half_kick    apply_PM_half_kick (timestep.c:964-985)
+ *   mpg_resident_apply_half_kick       apply_half_kick (timestep.c:873-929): gravity kick, hydro kick, gas velocity limit, entropy
+ *   mpg_resident_find_hydro_timesteps  find_hydro_timesteps (timestep.c:617-733) on TimeBinHydro (both halves, one rank; several ranks:
+ *                                      mpg_dev_find_hydro_timesteps + the caller's MPI_Allreduce + mpg_dev_hydro_timesteps_finish on
+ *                                      mpg_resident_sph_arrays)
+ * mpg_resident_sph_end writes every array back to `A` (Entropy and the time bins included: the kicks and the bin assignment changed them)
+ * and leaves the mode; mpg_resident_end does the same for the table.  shim/timestep-hip.c forwards the reference's own entry points. */
+int mpg_resident_sph_begin(mpg_engine *eng, const mpg_particle_view *pv, const mpg_sph_arrays *A);
+int mpg_resident_sph_arrays(mpg_engine *eng, mpg_sph_arrays *device_arrays_out);
+int mpg_resident_sph_end(mpg_engine *eng, const mpg_sph_arrays *A);
+int mpg_resident_drift_all_particles(mpg_engine *eng, const mpg_particle_view *pv, double ddrift, const double random_shift[3]);
+int mpg_resident_apply_pm_half_kick(mpg_engine *eng, const mpg_particle_view *pv, double Fgravkick);
+int mpg_resident_apply_half_kick(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
+                                 const mpg_kick_factors *K);
+
+/* both halves on a resident gas run (mpg_resident_sph_begin), one rank: Hsml, DtHsml, MaxSignalVel and the time bins are the resident ones */
+int mpg_resident_find_hydro_timesteps(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
+                                      mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,
+                                      double atime, double hubble, int isFirstTimeStep, mpg_hydrostep_result *out);
+
 /* build_active_sublist (timestep.c:1435-1478): the entries of d_active (NULL = all n) that are not garbage, whose gravity bin
  * is <= maxtimebin and active at Ti_Current, order preserved.  d_out must hold NumActiveParticle entries. */
 int mpg_dev_build_active_sublist(mpg_engine *eng, const int *d_active, int64_t NumActiveParticle, const unsigned char *d_tb_grav,

@@ -600,6 +600,28 @@ int mpg_dev_timestep_gravity_dloga(mpg_engine *eng, int64_t n, const double *d_g
     API_END
 }
 
+int mpg_dev_timestep_hydro_dloga(mpg_engine *eng, int64_t n, const unsigned char *d_type, const double *d_hsml, const double *d_dthsml,
+                                 const double *d_maxsignalvel, const unsigned char *d_bh_mintimebin, const double *dloga_for_bin, double atime,
+                                 double hubble, double CourantFac, double *d_dloga, unsigned char *d_titype)
+{
+    API_BEGIN
+    MPG_CHECK(eng && d_dloga && n >= 0, "null argument");
+    MPG_CHECK(!d_type || (d_hsml && d_maxsignalvel), "timestep_hydro_dloga: gas needs Hsml and MaxSignalVel");
+    MPG_HIP(hipSetDevice(eng->device));
+    const double *d_bins = nullptr;
+    if(d_bh_mintimebin && dloga_for_bin) {
+        eng->hier_sp.reserve((size_t)MPG_TIMEBINS + 2);
+        MPG_HIP(hipMemcpyAsync(eng->hier_sp.p, dloga_for_bin, (MPG_TIMEBINS + 1) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+        d_bins = eng->hier_sp.p;
+    }
+    const double fac3 = pow(atime, 3 * (1 - 5.0 / 3.0) / 2.0); // timestep.c:1083, GAMMA = 5/3 (physconst.h:35)
+    launch_timestep_hydro(n, d_type, d_hsml, d_dthsml, d_maxsignalvel, d_bins ? d_bh_mintimebin : nullptr, d_bins, atime, hubble, CourantFac, fac3,
+                          d_dloga, d_titype, eng->stream);
+    if(d_bins)
+        MPG_HIP(hipStreamSynchronize(eng->stream)); // (the table sits in a scratch buffer the hierarchical loop shares)
+    API_END
+}
+
 int mpg_dev_peano_keys(mpg_engine *eng, int64_t n, const double *d_pos, double BoxSize, uint64_t *d_keys)
 {
     API_BEGIN
@@ -1005,6 +1027,78 @@ int mpg_dev_build_active_sublist(mpg_engine *eng, const int *d_active, int64_t N
     MPG_CHECK(eng && d_tb_grav && d_out && n_out && NumActiveParticle >= 0, "null argument");
     MPG_HIP(hipSetDevice(eng->device));
     *n_out = hier_sublist(eng, d_active, NumActiveParticle, d_tb_grav, d_flags, maxtimebin, Ti_Current, d_out);
+    API_END
+}
+
+__global__ void __launch_bounds__(256) k_set_bh_bins(int64_t n, const uint8_t *__restrict__ type, uint8_t *__restrict__ tb, int bin)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if(i < n && (type[i] & 7) == 5)
+        tb[i] = (uint8_t)bin;
+}
+
+int mpg_dev_find_hydro_timesteps(mpg_engine *eng, const mpg_hydrostep_arrays *A, const int *d_active, int64_t NumActiveParticle,
+                                 const mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,
+                                 double atime, double hubble, mpg_hydrostep_result *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && A && times && timeline && par && out, "null argument");
+    MPG_CHECK(A->d_tb_hydro, "find_hydro_timesteps: TimeBinHydro is needed");
+    MPG_CHECK(!A->d_type || (A->d_hsml && A->d_maxsignalvel), "find_hydro_timesteps: gas needs Hsml and MaxSignalVel");
+    MPG_CHECK(timeline->nsync >= 2 && timeline->loga, "find_hydro_timesteps: the timeline needs at least two sync points");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int64_t nact = d_active ? NumActiveParticle : eng->n;
+    // the timeline for the per-particle conversion, and behind it get_dloga_for_bin of every bin (timebinmgr.c:443-447)
+    eng->hier_sp.reserve((size_t)timeline->nsync + MPG_TIMEBINS + 2);
+    MPG_HIP(hipMemcpyAsync(eng->hier_sp.p, timeline->loga, (size_t)timeline->nsync * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    double bins[MPG_TIMEBINS + 1];
+    const double logDTime = host_dloga_interval(timeline, times->Ti_Current);
+    for(int b = 0; b <= MPG_TIMEBINS; b++)
+        bins[b] = (double)dti_from_timebin(b) * logDTime;
+    double *d_bins = eng->hier_sp.p + timeline->nsync;
+    MPG_HIP(hipMemcpyAsync(d_bins, bins, sizeof(bins), hipMemcpyHostToDevice, eng->stream));
+    HierTimeline T;
+    T.sp = eng->hier_sp.p;
+    T.nsync = (int)timeline->nsync;
+    T.loga_cur = host_loga_from_ti(timeline, times->Ti_Current);
+    T.ti0 = host_ti_from_loga(timeline, T.loga_cur);
+    T.MinSizeTimestep = par->MinSizeTimestep;
+    eng->hier_cnt.reserve(64);
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, (unsigned long long)MPG_TIMEBINS};
+    MPG_HIP(hipMemcpyAsync(eng->hier_cnt.p, h, sizeof(h), hipMemcpyHostToDevice, eng->stream));
+    const double fac3 = pow(atime, 3 * (1 - 5.0 / 3.0) / 2.0);
+    launch_find_hydro_timesteps(d_active, nact, A->d_type, A->d_flags, A->d_hsml, A->d_dthsml, A->d_maxsignalvel, A->d_bh_mintimebin, d_bins,
+                                A->d_tb_grav, A->d_tb_hydro, atime, hubble, CourantFac, fac3, T, times->PM_length, times->Ti_Current, eng->hier_cnt.p,
+                                eng->stream);
+    MPG_HIP(hipMemcpyAsync(h, eng->hier_cnt.p, sizeof(h), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    for(int k = 0; k < 5; k++)
+        out->ntitype[k] = (int64_t)h[k];
+    out->badstepsizecount = (int64_t)h[5];
+    out->badtimebins = (int64_t)h[6];
+    out->mTimeBin = (int)h[7];
+    API_END
+}
+
+int mpg_dev_hydro_timesteps_finish(mpg_engine *eng, int mTimeBin, int isFirstTimeStep, int64_t n, const unsigned char *d_type,
+                                   unsigned char *d_tb_hydro, mpg_drift_kick_times *times)
+{
+    API_BEGIN
+    MPG_CHECK(eng && times, "null argument");
+    // all gas of the shortest bin turned into stars: keep the step, or lengthen it if the next bin is active (timestep.c:709-715)
+    if(!is_timebin_active(mTimeBin, times->Ti_Current)) {
+        mTimeBin = times->mintimebin;
+        if(is_timebin_active(mTimeBin + 1, times->Ti_Current))
+            mTimeBin++;
+    }
+    if(isFirstTimeStep && d_type && d_tb_hydro && n > 0) { // set_bh_first_timestep, timestep.c:600-612
+        MPG_HIP(hipSetDevice(eng->device));
+        hipLaunchKernelGGL(k_set_bh_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, eng->stream, n, d_type, d_tb_hydro, mTimeBin);
+        MPG_HIP(hipGetLastError());
+    }
+    times->mintimebin = mTimeBin;
+    if(times->mintimebin > times->mingravtimebin && times->mingravtimebin > 0) // (a dark-matter particle in the shortest bin)
+        times->mintimebin = times->mingravtimebin;
     API_END
 }
 
@@ -1650,6 +1744,7 @@ int mpg_resident_end(mpg_engine *eng, const mpg_particle_view *P)
     resident_check(eng, P);
     if(mpg_resident_fetch(eng, P, MPG_FIELD_POS | MPG_FIELD_VEL | MPG_FIELD_ACCEL | MPG_FIELD_GRAVPM | MPG_FIELD_POTENTIAL))
         throw Error(g_err);
+    MPG_CHECK(!eng->sph_resident, "mpg_resident_end: the gas arrays are still resident (mpg_resident_sph_end first)");
     eng->resident = false;
     eng->res_has_vel = false;
     eng->res_base = nullptr;
@@ -1900,6 +1995,8 @@ const SphField SPH_FIELDS[19] = {{0, 1, true, true},  {1, 1, false, true}, {2, 3
 
 void stage_sph(mpg_engine *eng, const mpg_sph_arrays *host, mpg_sph_arrays *dev, int64_t n)
 {
+    // (the staging buffers ARE the resident copies of a gas run: another array set must wait for mpg_resident_sph_end)
+    MPG_CHECK(!eng->sph_resident, "SPH host call with arrays other than the resident gas run's (mpg_resident_sph_end first)");
     void *const *hp = (void *const *)host;
     void **dp = (void **)dev;
     for(int f = 0; f < 19; f++) {
@@ -1938,6 +2035,11 @@ void unstage_sph(mpg_engine *eng, const mpg_sph_arrays *host, const mpg_sph_arra
     }
     MPG_HIP(hipStreamSynchronize(eng->stream));
 }
+// the host arrays of a resident gas run (mpg_resident_sph_begin): their device copies are current, nothing is staged
+bool sph_is_resident(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_arrays *A)
+{
+    return eng->sph_resident && eng->resident && eng->res_base == P->base && A->hsml == eng->res_sph_host.hsml;
+}
 } // namespace
 
 int mpg_set_init_hsml(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, const mpg_sph_arrays *A, double MeanGasSeparation)
@@ -1964,7 +2066,11 @@ int mpg_density(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, con
     MPG_HIP(hipSetDevice(eng->device));
     stage_particles(eng, P, BoxSize);
     mpg_sph_arrays d;
-    stage_sph(eng, A, &d, P->n);
+    const bool res = sph_is_resident(eng, P, A); // a resident gas run: the arrays are in HBM already and stay there
+    if(res)
+        d = eng->res_sph_dev;
+    else
+        stage_sph(eng, A, &d, P->n);
     const int *d_act = nullptr;
     if(ActiveParticle) {
         eng->s_active.reserve((size_t)NumActiveParticle + 1);
@@ -1975,7 +2081,8 @@ int mpg_density(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, con
        mpg_dev_density(eng, &d, T, d_act, NumActiveParticle, update_hsml, DoEgyDensity, BlackHoleOn) ||
        (update_hsml && mpg_dev_force_tree_calc_hmax(eng)))
         throw Error(g_err);
-    unstage_sph(eng, A, &d, P->n, false);
+    if(!res)
+        unstage_sph(eng, A, &d, P->n, false);
     API_END
 }
 
@@ -1988,7 +2095,11 @@ int mpg_hydro_force(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_a
     MPG_CHECK(eng->tree_allocated && eng->tree.has_hmax, "Hydro called before hmax computed"); // hydra.c:172-173
     MPG_CHECK(P->n == eng->n, "hydro_force: particle table changed size since density()");
     mpg_sph_arrays d;
-    stage_sph(eng, A, &d, P->n);
+    const bool res = sph_is_resident(eng, P, A);
+    if(res)
+        d = eng->res_sph_dev;
+    else
+        stage_sph(eng, A, &d, P->n);
     const int *d_act = nullptr;
     if(ActiveParticle) {
         eng->s_active.reserve((size_t)NumActiveParticle + 1);
@@ -1997,7 +2108,169 @@ int mpg_hydro_force(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_a
     }
     if(mpg_dev_hydro_force(eng, &d, T, d_act, NumActiveParticle))
         throw Error(g_err);
-    unstage_sph(eng, A, &d, P->n, true);
+    if(!res)
+        unstage_sph(eng, A, &d, P->n, true);
+    API_END
+}
+
+/* ---- a resident gas run: the SPH arrays stay in HBM between the calls, the integrator runs there (include/mpgadget_hip.h) ---- */
+namespace {
+__global__ void __launch_bounds__(256) k_flags_from_type(int64_t n, const uint8_t *__restrict__ type, uint8_t *__restrict__ flags)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if(i < n)
+        flags[i] = (type[i] & 7) == 7 ? 1 : 0; // (stage_particles gave garbage and swallowed particles type 7)
+}
+void resident_sph_check(mpg_engine *eng, const mpg_particle_view *P)
+{
+    resident_check(eng, P);
+    MPG_CHECK(eng->sph_resident, "no resident gas arrays (mpg_resident_sph_begin first)");
+}
+} // namespace
+
+int mpg_resident_sph_begin(mpg_engine *eng, const mpg_particle_view *P, const mpg_sph_arrays *A)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && A, "null argument");
+    resident_check(eng, P);
+    MPG_CHECK(eng->res_has_vel, "mpg_resident_sph_begin: the resident table has no Vel column (the view's off_vel)");
+    MPG_CHECK(A->hsml && A->entropy && A->density && A->dhsmlegyfac && A->divvel && A->curlvel && A->hydroacc_out && A->dtentropy_out &&
+                  A->maxsignalvel,
+              "mpg_resident_sph_begin: hsml, entropy, density, dhsmlegyfac, divvel, curlvel, hydroacc_out, dtentropy_out and maxsignalvel are required");
+    const int64_t n = P->n;
+    mpg_sph_arrays d;
+    stage_sph(eng, A, &d, n);
+    // the arrays stage_sph only clears hold state of the previous step that the predictions and the drift read: DtHsml, HydroAccel, DtEntropy
+    void *const *hp = (void *const *)A;
+    void **dp = (void **)&d;
+    for(int f = 0; f < 19; f++) {
+        const SphField &F = SPH_FIELDS[f];
+        if(hp[f] && F.width > 0 && !F.in)
+            MPG_HIP(hipMemcpyAsync(dp[f], hp[f], (size_t)n * F.width * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    }
+    // one field each in the reference: SphP.HydroAccel and SphP.DtEntropy are what the next step's predictions read; P[].Vel,
+    // FullTreeGravAccel and GravPM are the resident table's
+    d.hydroacc_in = d.hydroacc_out;
+    d.dtentropy_in = d.dtentropy_out;
+    d.vel = eng->r_vel.p;
+    d.gacc = eng->r_accel.p;
+    d.gpm = eng->r_gravpm.p;
+    eng->r_flags.reserve((size_t)n + 1);
+    if(n > 0)
+        hipLaunchKernelGGL(k_flags_from_type, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, eng->stream, n, eng->s_type.p, eng->r_flags.p);
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    eng->res_sph_host = *A;
+    eng->res_sph_dev = d;
+    eng->sph_resident = true;
+    API_END
+}
+
+int mpg_resident_sph_arrays(mpg_engine *eng, mpg_sph_arrays *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && out && eng->sph_resident, "mpg_resident_sph_arrays: no resident gas arrays");
+    *out = eng->res_sph_dev;
+    API_END
+}
+
+int mpg_resident_sph_end(mpg_engine *eng, const mpg_sph_arrays *A)
+{
+    API_BEGIN
+    MPG_CHECK(eng && A && eng->sph_resident, "mpg_resident_sph_end: no resident gas arrays");
+    MPG_CHECK(A->hsml == eng->res_sph_host.hsml, "mpg_resident_sph_end: not the arrays mpg_resident_sph_begin took");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int64_t n = eng->res_n;
+    void *const *hp = (void *const *)A;
+    void *const *dp = (void *const *)&eng->res_sph_dev;
+    for(int f = 0; f < 19; f++) {
+        const SphField &F = SPH_FIELDS[f];
+        // everything the device may have changed: the outputs, Entropy (kicks), the time bins; not the aliases of the table's columns
+        const bool table_alias = (f >= 2 && f <= 4), pred_alias = (f == 5 || f == 9);
+        if(!hp[f] || table_alias || pred_alias)
+            continue;
+        const size_t bytes = F.width == 0 ? (size_t)n : (size_t)n * F.width * sizeof(double);
+        MPG_HIP(hipMemcpyAsync(hp[f], dp[f], bytes, hipMemcpyDeviceToHost, eng->stream));
+    }
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    eng->sph_resident = false;
+    API_END
+}
+
+int mpg_resident_drift_all_particles(mpg_engine *eng, const mpg_particle_view *P, double ddrift, const double random_shift[3])
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && random_shift, "null argument");
+    resident_check(eng, P);
+    MPG_CHECK(eng->res_has_vel, "resident drift: the resident table has no Vel column");
+    const bool gas = eng->sph_resident;
+    eng->r_flags.reserve((size_t)P->n + 1);
+    if(!gas && P->n > 0)
+        hipLaunchKernelGGL(k_flags_from_type, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, eng->stream, P->n, eng->s_type.p, eng->r_flags.p);
+    if(mpg_dev_drift_all_particles(eng, P->n, eng->s_pos.p, eng->r_vel.p, eng->s_type.p, eng->r_flags.p, gas ? eng->res_sph_dev.hsml : nullptr,
+                                   gas ? eng->res_sph_dev.dthsml : nullptr, ddrift, eng->box, random_shift))
+        throw Error(g_err);
+    API_END
+}
+
+int mpg_resident_apply_pm_half_kick(mpg_engine *eng, const mpg_particle_view *P, double Fgravkick)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P, "null argument");
+    resident_check(eng, P);
+    MPG_CHECK(eng->res_has_vel, "resident kick: the resident table has no Vel column");
+    eng->r_flags.reserve((size_t)P->n + 1);
+    if(!eng->sph_resident && P->n > 0)
+        hipLaunchKernelGGL(k_flags_from_type, dim3((unsigned)((P->n + 255) / 256)), dim3(256), 0, eng->stream, P->n, eng->s_type.p, eng->r_flags.p);
+    if(mpg_dev_apply_pm_half_kick(eng, P->n, eng->r_vel.p, eng->r_gravpm.p, eng->r_flags.p, Fgravkick))
+        throw Error(g_err);
+    API_END
+}
+
+int mpg_resident_apply_half_kick(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                 const mpg_kick_factors *K)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && K, "null argument");
+    resident_sph_check(eng, P);
+    const mpg_sph_arrays &d = eng->res_sph_dev;
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    if(mpg_dev_apply_half_kick(eng, P->n, d_act, NumActiveParticle, eng->r_vel.p, eng->r_accel.p, eng->s_type.p, eng->r_flags.p, d.tb_grav, d.tb_hydro,
+                               d.hydroacc_out, (double *)d.entropy, d.dtentropy_out, K))
+        throw Error(g_err);
+    API_END
+}
+
+int mpg_resident_find_hydro_timesteps(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                      mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,
+                                      double atime, double hubble, int isFirstTimeStep, mpg_hydrostep_result *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && times && out, "null argument");
+    resident_sph_check(eng, P);
+    const mpg_sph_arrays &d = eng->res_sph_dev;
+    MPG_CHECK(d.tb_hydro, "resident find_hydro_timesteps: the gas arrays have no TimeBinHydro");
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    mpg_hydrostep_arrays H{};
+    H.d_type = eng->s_type.p;
+    H.d_flags = eng->r_flags.p;
+    H.d_hsml = d.hsml;
+    H.d_dthsml = d.dthsml;
+    H.d_maxsignalvel = d.maxsignalvel;
+    H.d_tb_grav = d.tb_grav;
+    H.d_tb_hydro = (unsigned char *)d.tb_hydro;
+    if(mpg_dev_find_hydro_timesteps(eng, &H, d_act, NumActiveParticle, times, timeline, par, CourantFac, atime, hubble, out) ||
+       mpg_dev_hydro_timesteps_finish(eng, out->mTimeBin, isFirstTimeStep, P->n, eng->s_type.p, (unsigned char *)d.tb_hydro, times))
+        throw Error(g_err);
     API_END
 }
 

@@ -154,6 +154,11 @@ struct mpg_engine {
     const void *res_base = nullptr;
     int64_t res_n = -1;
     DevBuf<double> r_vel, r_accel, r_gravpm, r_pot;
+    // ... and a gas run's SPH arrays (mpg_resident_sph_begin): the host set they were taken from, their device copies (h_sph / h_sph_u8,
+    // with vel / gacc / gpm aliasing r_vel / r_accel / r_gravpm) and the garbage flags of the resident table for the integrator kernels
+    bool sph_resident = false;
+    mpg_sph_arrays res_sph_host{}, res_sph_dev{};
+    DevBuf<uint8_t> r_flags;
     double staged_box = 0;
     hipEvent_t chunk_ev[8] = {};
 };

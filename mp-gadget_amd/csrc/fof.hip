@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_fof_walk(const TreeView tv, const doubl
             const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<false, 2, FOF_MERGE>(tv, stack, sp, go, s, gshift, radius, px, py, pz, llist, nl, overflow); // (two child ranges per step, sibling leaves joined: ngb_walk.h)
+            nl = walk_stepk<false, 2, FOF_MERGE>(tv, tv.geoB, nullptr, stack, sp, go, s, gshift, radius, px, py, pz, llist, nl, overflow); // (two child ranges per step, sibling leaves joined: ngb_walk.h)
             if(ballot64(overflow) != 0)
                 break;
         }

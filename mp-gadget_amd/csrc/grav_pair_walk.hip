@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_grav_short_pair(const TreeView tv, cons
             const bool go = sp > 0 && nl + 16 <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<false, 2, true>(tv, stack, sp, go, s, gshift, rcut_abs, px, py, pz, llist, nl, overflow); // (two child ranges per step: ngb_walk.h)
+            nl = walk_stepk<false, 2, true>(tv, tv.geoB, nullptr, stack, sp, go, s, gshift, rcut_abs, px, py, pz, llist, nl, overflow); // (two child ranges per step: ngb_walk.h)
             if(ballot64(overflow) != 0)
                 break;
         }

@@ -112,6 +112,10 @@ struct TreeView {
     const Src4 *momB = nullptr;
     const NodeLinkB *linkB = nullptr;
     const double *hmaxB = nullptr;
+    // level-ordered SEARCH geometry of the SPH loops (TreeBuilder::calc_search_boxes / calc_search_hsmax), or null: per node the cube
+    // around the PARTICLES it holds instead of its cell, and the largest smoothing length among them
+    const NodeGeo *geoS = nullptr;
+    const double *hsmaxS = nullptr;
     double box = 0;
 };
 

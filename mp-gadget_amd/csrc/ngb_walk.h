@@ -110,9 +110,13 @@ __device__ __forceinline__ double group_sum(double v)
 // existing child of it was opened by this target, its first lane emitting the run.  The candidates are those of the opened leaves and no
 // others, so the reference's counters are unchanged.  (First form: the lanes compared start / count / contiguity with their neighbours
 // s ^ 1, s ^ 2, s ^ 4 at run time - 65 vector instructions per child range against ~20.)
+// sgeo / shm: the geometry the cull tests and, for SYM, the radius per node - the nodes' cells and `hmax` as in the reference (tv.geoB,
+// tv.hmaxB: FOF, the pair-wise gravity check), or the cubes around the nodes' particles and their largest Hsml (tv.geoS, tv.hsmaxS: the
+// SPH loops; TreeBuilder::calc_search_boxes).
 template <bool SYM, int K, bool MERGE = false, bool WRAP = true>
-__device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, int &sp, const bool valid_more, const int s, const int gshift,
-                                          const double hsml, const double px, const double py, const double pz, unsigned *llist, int nl, bool &overflow)
+__device__ __forceinline__ int walk_stepk(const TreeView &tv, const NodeGeo *__restrict__ sgeo, const double *__restrict__ shm, unsigned *stack, int &sp,
+                                          const bool valid_more, const int s, const int gshift, const double hsml, const double px, const double py,
+                                          const double pz, unsigned *llist, int nl, bool &overflow)
 {
     const bool can = valid_more;
     const double invbox = 1.0 / tv.box;
@@ -134,9 +138,9 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
     double hm[K];
 #pragma unroll
     for(int k = 0; k < K; k++) {
-        g[k] = tv.geoB[my[k]];
+        g[k] = sgeo[my[k]];
         lk[k] = tv.linkB[my[k]];
-        hm[k] = SYM ? tv.hmaxB[my[k]] : 0.0;
+        hm[k] = SYM ? shm[my[k]] : 0.0;
     }
     unsigned gl[K], gp[K], ent[K];
     unsigned long long m_leaf[K], m_push[K]; // lane masks: the children opened as leaves / whose own children are pushed
@@ -155,15 +159,29 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, unsigned *stack, i
         ent[k] = ((unsigned)lk[k].pstart << 4) | (unsigned)lk[k].pcount;
         if(MERGE) {
             const bool lf = __builtin_amdgcn_inverse_ballot_w64(m_leaf[k]);
+            unsigned pcm = lf ? (unsigned)lk[k].pcount : 0u;
+#ifdef NGB_MERGE_ANY_OPENED
+            // Round 5 experiment (measured, no gain - profiles/r05a_experiments): a set is joined as soon as the target opened ANY leaf of it, its first lane emitting the whole run - whether or not
+            // that lane's own leaf was opened.  One list entry is one test iteration of 8 lanes whatever it holds, so the particles of the
+            // set's other leaves ride along on lanes that would idle (they fail the distance test: their leaf was culled), while a set
+            // opened in part is one entry instead of one per opened leaf.  (The default joins a set only when ALL its existing leaves were
+            // opened, which the tighter cull on the particles' cubes makes rarer.)
+            const bool isleaf = tst[k] && lk[k].pcount > 0;
+            const unsigned h = isleaf ? (unsigned)lk[k].firstchild : 0u;              // (a leaf's merge hints: NodeLinkB)
+            const unsigned m = (unsigned)((m_leaf[k] >> gshift) & 0xffull);           // the children this target opened as leaves
+            const unsigned sq = (h >> 4) & 15u, sp = h & 15u;
+            pcm = (sp != 0u && (m & (3u << (s & 6))) != 0u) ? ((s & 1) == 0 ? sp : 0u) : pcm;
+            pcm = (sq != 0u && (m & (15u << (s & 4))) != 0u) ? ((s & 3) == 0 ? sq : 0u) : pcm;
+#else
             const unsigned h = lf ? (unsigned)lk[k].firstchild : 0u;                  // (a leaf's merge hints: NodeLinkB)
             const unsigned m = (unsigned)((m_leaf[k] >> gshift) & 0xffull);           // the children this target opened as leaves
             const unsigned x = m ^ ((1u << (r[k] & 15u)) - 1u);                       // existing children that are not among them
             const unsigned sq = (h >> 4) & 15u, sp = h & 15u;
-            unsigned pcm = lf ? (unsigned)lk[k].pcount : 0u;
             pcm = (sp != 0u && (x & (3u << (s & 6))) == 0u) ? ((s & 1) == 0 ? sp : 0u) : pcm;
             pcm = (sq != 0u && (x & (15u << (s & 4))) == 0u) ? ((s & 3) == 0 ? sq : 0u) : pcm;
 #ifdef NGB_MERGE_OCT // (all children as one run: cannot occur in a tree whose cells are split at their 9th particle)
             pcm = (((h >> 8) & 15u) != 0u && x == 0u) ? (s == 0 ? ((h >> 8) & 15u) : 0u) : pcm;
+#endif
 #endif
             ent[k] = ((unsigned)lk[k].pstart << 4) | pcm;
             m_leaf[k] = __builtin_amdgcn_ballot_w64(pcm != 0u);

@@ -15,6 +15,7 @@
 #include "sph.h"
 #include "ngb_walk.h"
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace mpg {
@@ -409,6 +410,8 @@ __global__ void __launch_bounds__(256, 4) k_density(const TreeView tv, const Sph
             vel_pred(A, T, i, ivel);
         hsml = A.hsml[i];
     }
+    // the search's geometry: the cubes around the nodes' particles when the tree carries them (TreeBuilder::calc_search_boxes), else the cells
+    const NodeGeo *__restrict__ sgeo = tv.geoS ? tv.geoS : tv.geoB;
     const DKernel kern = kernel_init(valid ? hsml : 1.0, C.ktype);
     const double kvol = NORM_COEFF * p3(kern.H);
     const double h2 = hsml * hsml;
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(256, 4) k_density(const TreeView tv, const Sph
             const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<false, SPH_WALK_K, SPH_MERGE, WRAP>(tv, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
+            nl = walk_stepk<false, SPH_WALK_K, SPH_MERGE, WRAP>(tv, sgeo, nullptr, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
             if(ballot64(overflow) != 0)
                 break;
         }
@@ -836,6 +839,11 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
             t.p_over_rho2_i = IPressure / (t.IDensity * t.IDensity);
         }
     }
+    // the symmetric search on the cubes around the nodes' particles with the largest Hsml below each node as its radius, when the tree carries
+    // both (calc_search_boxes, calc_search_hsmax); else on the cells with the reference's hmax
+    const bool tight = tv.geoS && tv.hsmaxS;
+    const NodeGeo *__restrict__ sgeo = tight ? tv.geoS : tv.geoB;
+    const double *__restrict__ shm = tight ? tv.hsmaxS : tv.hmaxB;
     const DKernel kernel_i = kernel_init(t.me.hsml, C.ktype);
     HydroAcc a;
     a.MaxSignalVel = t.soundspeed_i;
@@ -855,7 +863,7 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
             const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<true, SPH_WALK_K, SPH_MERGE, WRAP>(tv, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
+            nl = walk_stepk<true, SPH_WALK_K, SPH_MERGE, WRAP>(tv, sgeo, shm, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
 #ifdef SPH_HIST
             if(lane == 0)
                 atomicAdd(&stats[7], 1ull);
@@ -920,7 +928,7 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
     }
     };
     // symmetric search: the radius of a cull is max(node hmax, Hsml) <= max(root hmax, Hsml)
-    if(interior_wave(valid, t.px, t.py, t.pz, fmax(t.me.hsml, tv.hmaxB[0]), tv.box))
+    if(interior_wave(valid, t.px, t.py, t.pz, fmax(t.me.hsml, shm[0]), tv.box))
         loops(std::false_type{});
     else
         loops(std::true_type{});
@@ -960,7 +968,16 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
                         hipStream_t st)
 {
     tree.ensure_level_order(st); // the cooperative walk uses the level-ordered copy of the tree
-    const TreeView tv = tree.view();
+    // The asymmetric search of the density loop keeps the reference's CELL test (cull_node): on the cubes around the nodes' particles it
+    // tests 29 % fewer candidates (2 x 128^3: 686 M -> 487 M for 231 M neighbours) but runs 3 % longer - a candidate is a lane of a test
+    // iteration that runs anyway, and leaves dropped from a set of siblings break the join of the rest (profiles/r05a_experiments).  The
+    // hydro loop's symmetric search gains from the cubes (hydro_force below).  MPG_SPH_DENSITY_CUBES=1 switches them on here too.
+    static const bool density_cubes = getenv("MPG_SPH_DENSITY_CUBES") != nullptr && getenv("MPG_SPH_CELL_CULL") == nullptr;
+    if(density_cubes && !tree.has_boxes)
+        tree.calc_search_boxes(st);
+    TreeView tv = tree.view();
+    if(!density_cubes)
+        tv.geoS = nullptr;
     MPG_CHECK(tv.npart > 0 || n == 0, "density: the tree holds no gas particles");
     const int64_t nact = d_active ? nactive : n;
     left.reserve(n + 1);
@@ -1074,7 +1091,7 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
                             const int *d_active, int64_t nactive, int64_t n, hipStream_t st)
 {
     tree.ensure_level_order(st);
-    const TreeView tv = tree.view();
+    TreeView tv = tree.view();
     MPG_CHECK(tree.has_hmax && tv.hmax && tv.hmaxB, "Hydro called before hmax computed"); // hydra.c:172-173
     MPG_CHECK(entvarpred.p != nullptr, "hydro_force needs the predicted entropies of density()");
     hsrc.reserve(tv.npart + 1);
@@ -1091,6 +1108,15 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
     if(tv.npart > 0) {
         hipLaunchKernelGGL(k_slot_of, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, slot_of.p);
         hipLaunchKernelGGL(k_hydro_prepare, dim3(nblk(tv.npart)), dim3(256), 0, st, tv.npart, tv.order, A, T, HP, entvarpred.p, C.fac_mu, hsrc.p, hsml_t.p);
+        // the symmetric search runs on the cubes around the nodes' particles; its radius per node is the largest of the smoothing lengths
+        // the pair tests below read (hsml_t), where the reference has the reach beyond the cell's faces (hmax)
+        static const bool cell_cull = getenv("MPG_SPH_CELL_CULL") != nullptr;
+        if(!cell_cull) {
+            if(!tree.has_boxes)
+                tree.calc_search_boxes(st);
+            tree.calc_search_hsmax(hsml_t.p, st);
+            tv = tree.view();
+        }
     }
     // work queue: the active gas particles in tree order
     queue_a.reserve(tv.npart + 1);

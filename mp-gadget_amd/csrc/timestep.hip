@@ -195,6 +195,121 @@ __device__ __forceinline__ double gravity_dloga_dev(const int64_t i, const doubl
     return dt * hubble;
 }
 
+// get_timestep_hydro_dloga, timestep.c:1076-1118: the Courant criterion from the signal velocity and the Gadget-4 criterion on the change
+// of the smoothing length for gas; the neighbour limiter for black holes (minTimeBin of their gas neighbours, one bin up); dt = 1 for
+// every other type.  fac3 = pow(atime, 3 (1 - GAMMA) / 2) comes from the host (the caller's libm, as the reference computes it).
+// titype: enum TimeStepType, timestep.c:89-96 (0 ACCEL, 1 COURANT, 3 NEIGH, 4 HSML).
+__device__ __forceinline__ double hydro_dloga_dev(const int64_t i, const uint8_t *__restrict__ type, const double *__restrict__ hsml,
+                                                  const double *__restrict__ dthsml, const double *__restrict__ maxsig,
+                                                  const uint8_t *__restrict__ bh_mintimebin, const double *__restrict__ dloga_for_bin, const double atime,
+                                                  const double hubble, const double courant, const double fac3, int &titype)
+{
+    double dt = 1;
+    titype = 0;
+    const int ty = type ? (type[i] & 7) : 1;
+    if(ty == 0) {
+        const double dt_courant = 2 * courant * atime * hsml[i] / (fac3 * maxsig[i]);
+        dt = dt_courant;
+        titype = 1;
+        const double dt_hsml = courant * atime * atime * fabs(hsml[i] / ((dthsml ? dthsml[i] : 0.0) + 1e-20));
+        if(dt_hsml < dt) {
+            dt = dt_hsml;
+            titype = 4;
+        }
+    }
+    else if(ty == 5 && bh_mintimebin && dloga_for_bin) {
+        const int mb = bh_mintimebin[i];
+        if(mb > 0 && mb + 1 < MPG_TIMEBINS) {
+            dt = dloga_for_bin[mb + 1] / hubble; // get_dloga_for_bin(minTimeBin + 1, Ti_Current) / hubble
+            titype = 3;
+        }
+    }
+    return dt * hubble;
+}
+
+__global__ void __launch_bounds__(256) k_timestep_hydro(int64_t n, const uint8_t *__restrict__ type, const double *__restrict__ hsml,
+                                                        const double *__restrict__ dthsml, const double *__restrict__ maxsig,
+                                                        const uint8_t *__restrict__ bh_mintimebin, const double *__restrict__ dloga_for_bin, double atime,
+                                                        double hubble, double courant, double fac3, double *__restrict__ dloga, uint8_t *__restrict__ titype)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    int tt;
+    dloga[i] = hydro_dloga_dev(i, type, hsml, dthsml, maxsig, bh_mintimebin, dloga_for_bin, atime, hubble, courant, fac3, tt);
+    if(titype)
+        titype[i] = (uint8_t)tt;
+}
+
+// is_timebin_active, timestep.c:143-150
+__device__ __forceinline__ bool timebin_active_dev(const int bin, const int64_t Ti_Current)
+{
+    const int64_t dti = bin > 0 ? ((int64_t)1 << bin) : 0;
+    return bin <= 0 || (Ti_Current % dti) == 0;
+}
+
+// The particle loop of find_hydro_timesteps (timestep.c:629-698) without the dynamic-friction bins of the black holes: the new hydro bin
+// of every active gas / black-hole particle.  out[0..4]: particles by criterion (TI_ACCEL, TI_COURANT, TI_ACCRETE, TI_NEIGH, TI_HSML),
+// out[5]: badstepsizecount (bin_hydro < 1), out[6]: print_bad_timebin cases (dti <= 1 or > TIMEBASE), out[7]: the smallest bin + 1 as
+// atomicMin of (unsigned) - initialised to TIMEBINS + 1 by the caller.
+__global__ void __launch_bounds__(256) k_find_hydro_timesteps(const int *__restrict__ list, int64_t nlist, const uint8_t *__restrict__ type,
+                                                              const uint8_t *__restrict__ flags, const double *__restrict__ hsml,
+                                                              const double *__restrict__ dthsml, const double *__restrict__ maxsig,
+                                                              const uint8_t *__restrict__ bh_mintimebin, const double *__restrict__ dloga_for_bin,
+                                                              const uint8_t *__restrict__ tb_grav, uint8_t *__restrict__ tb_hydro, double atime,
+                                                              double hubble, double courant, double fac3, HierTimeline T, int64_t dti_max,
+                                                              int64_t Ti_Current, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned s_cnt[8];
+    __shared__ unsigned s_min;
+    if(threadIdx.x < 8)
+        s_cnt[threadIdx.x] = 0;
+    if(threadIdx.x == 0)
+        s_min = MPG_TIMEBINS + 1;
+    __syncthreads();
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < nlist) {
+        const int64_t i = list ? list[k] : k;
+        const int ty = type ? (type[i] & 7) : 1;
+        if(!(flags && (flags[i] & 3)) && (ty == 0 || ty == 5)) {
+            int titype;
+            const double dloga = hydro_dloga_dev(i, type, hsml, dthsml, maxsig, bh_mintimebin, dloga_for_bin, atime, hubble, courant, fac3, titype);
+            int64_t dti = convert_timestep_to_ti_dev(dloga, dti_max, T);
+            if(dti <= 1 || dti > ((int64_t)1 << MPG_TIMEBINS))
+                atomicAdd(&s_cnt[6], 1u);
+            // get_timebin_from_dti, timestep.c:166-182: round_down_power_of_two, get_timestep_bin, and a longer step only onto an active bin
+            int64_t ti_min = (int64_t)1 << MPG_TIMEBINS;
+            while(ti_min > dti)
+                ti_min >>= 1;
+            dti = ti_min;
+            int bin = 0;
+            if(dti > 1)
+                bin = 63 - __clzll((unsigned long long)dti);
+            const int binold = tb_hydro[i];
+            if(bin > binold)
+                while(!timebin_active_dev(bin, Ti_Current) && bin > binold && bin > 1)
+                    bin--;
+            // the hydro step never exceeds the gravity step (timestep.c:651-655)
+            const int bg = tb_grav ? tb_grav[i] : MPG_TIMEBINS;
+            if(bin > bg) {
+                bin = bg;
+                titype = 0;
+            }
+            if(bin < 1)
+                atomicAdd(&s_cnt[5], 1u);
+            atomicAdd(&s_cnt[titype], 1u);
+            if(timebin_active_dev(binold, Ti_Current) && timebin_active_dev(bin, Ti_Current))
+                tb_hydro[i] = (uint8_t)bin;
+            atomicMin(&s_min, (unsigned)bin);
+        }
+    }
+    __syncthreads();
+    if(threadIdx.x < 7 && s_cnt[threadIdx.x])
+        atomicAdd(&out[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    if(threadIdx.x == 0 && s_min <= MPG_TIMEBINS)
+        atomicMin(&out[7], (unsigned long long)s_min);
+}
+
 // The first loop of hierarchical_gravity_and_timesteps (timestep.c:345-370): new gravity bin of every particle of the list from
 // the stored acceleration; counts[bin] += 1; bad += 1 for dti <= 1 or > TIMEBASE (print_bad_timebin).
 __global__ void __launch_bounds__(256) k_assign_gravity_bins(const int *__restrict__ list, int64_t nlist, const double *__restrict__ gacc,
@@ -315,6 +430,27 @@ void launch_timestep_gravity(int64_t n, const double *gacc, const double *gpm, d
     MPG_HIP(hipGetLastError());
 }
 
+
+void launch_timestep_hydro(int64_t n, const uint8_t *type, const double *hsml, const double *dthsml, const double *maxsig, const uint8_t *bh_mintimebin,
+                           const double *dloga_for_bin, double atime, double hubble, double courant, double fac3, double *dloga, uint8_t *titype,
+                           hipStream_t st)
+{
+    if(n > 0)
+        hipLaunchKernelGGL(k_timestep_hydro, dim3(nblk(n)), dim3(256), 0, st, n, type, hsml, dthsml, maxsig, bh_mintimebin, dloga_for_bin, atime, hubble,
+                           courant, fac3, dloga, titype);
+    MPG_HIP(hipGetLastError());
+}
+
+void launch_find_hydro_timesteps(const int *list, int64_t nlist, const uint8_t *type, const uint8_t *flags, const double *hsml, const double *dthsml,
+                                 const double *maxsig, const uint8_t *bh_mintimebin, const double *dloga_for_bin, const uint8_t *tb_grav,
+                                 uint8_t *tb_hydro, double atime, double hubble, double courant, double fac3, const HierTimeline &T, int64_t dti_max,
+                                 int64_t Ti_Current, unsigned long long *out, hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_find_hydro_timesteps, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, type, flags, hsml, dthsml, maxsig, bh_mintimebin,
+                           dloga_for_bin, tb_grav, tb_hydro, atime, hubble, courant, fac3, T, dti_max, Ti_Current, out);
+    MPG_HIP(hipGetLastError());
+}
 
 void launch_assign_gravity_bins(const int *list, int64_t nlist, const double *gacc, const double *gpm, const uint8_t *flags, double atime,
                                 double hubble, double errtol, double soft, const HierTimeline &T, int64_t dti_max, int largest_active, uint8_t *tb,

@@ -75,6 +75,11 @@ struct TreeBuilder {
     DevBuf<NodeLinkB> linkB;
     DevBuf<double> hmaxB;
     bool has_bfs = false;
+    // search geometry of the SPH loops (level order): tight cubes around each node's particles, largest Hsml per node
+    DevBuf<double> aabb, hsmax;
+    DevBuf<NodeGeo> geoS;
+    DevBuf<double> hsmaxS;
+    bool has_boxes = false, has_hsmax = false;
 
     // force_tree_build (forcetree.c:196-270) without moments
     void build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box, hipStream_t st,
@@ -91,6 +96,15 @@ struct TreeBuilder {
     // d_flag_later: a zeroed device word the kernel raises instead of the check + synchronisation here (the caller reads it later)
     void top_set(int La, const double *d_sums, hipStream_t st, int *d_flag_later = nullptr);
     void ensure_level_order(hipStream_t st);
+    // The neighbour searches of the SPH loops need, per node, ANY region that contains the node's particles: the reference tests the
+    // node's cell (cull_node, treewalk.c:1015-1042); the cube around the particles themselves is contained in it and lets a search drop
+    // leaves (a cell split at its 9th particle leaves children of one or two: points and short segments inside cells a mean spacing wide)
+    // and whole branches that the cell test opens in vain.  The NEIGHBOUR set is unchanged - a particle within the search radius keeps every
+    // node above it alive under either test -, the candidates tested are fewer.  calc_search_boxes: cubes of the current tree (positions
+    // only; once per build).  calc_search_hsmax: the largest Hsml below each node, the symmetric search's radius (hydro), where the
+    // reference has `hmax`, the reach beyond the CELL's faces (forcetree.c:963).
+    void calc_search_boxes(hipStream_t st);
+    void calc_search_hsmax(const double *d_hsml_treeorder, hipStream_t st);
     TreeView view() const;
 };
 

@@ -457,7 +457,127 @@ __global__ void __launch_bounds__(256) k_permute_hmax(int64_t nnodes, const uint
         hmaxB[i] = hmax[dfs_of_bfs[i]];
 }
 
+// ---- search geometry of the SPH loops: the box around a node's particles, bottom-up; then a cube around the box, in level order
+__global__ void __launch_bounds__(256) k_aabb_leaf(int64_t nnodes, const NodeLink *__restrict__ link, const NodeGeo *__restrict__ geo,
+                                                   const Src4 *__restrict__ src, double *__restrict__ aabb)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount == 0 && !(j == 0 && nnodes == 1))
+        return;
+    double lo[3], hi[3];
+    if(lk.pcount == 0) { // the lone root of an empty tree: its cell's centre
+        const NodeGeo g = geo[j];
+        lo[0] = hi[0] = g.cx;
+        lo[1] = hi[1] = g.cy;
+        lo[2] = hi[2] = g.cz;
+    }
+    else {
+        const Src4 p0 = src[lk.pstart];
+        lo[0] = hi[0] = p0.x;
+        lo[1] = hi[1] = p0.y;
+        lo[2] = hi[2] = p0.z;
+        for(int k = 1; k < lk.pcount; k++) {
+            const Src4 p = src[lk.pstart + k];
+            lo[0] = fmin(lo[0], p.x);
+            hi[0] = fmax(hi[0], p.x);
+            lo[1] = fmin(lo[1], p.y);
+            hi[1] = fmax(hi[1], p.y);
+            lo[2] = fmin(lo[2], p.z);
+            hi[2] = fmax(hi[2], p.z);
+        }
+    }
+    for(int a = 0; a < 3; a++) {
+        aabb[6 * j + a] = lo[a];
+        aabb[6 * j + 3 + a] = hi[a];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_aabb_internal(int64_t nnodes, int level, const NodeLink *__restrict__ link, double *__restrict__ aabb)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount != 0 || lk.level != level || j + 1 >= nnodes)
+        return;
+    double b[6];
+    int c = (int)j + 1;
+    for(int a = 0; a < 6; a++)
+        b[a] = aabb[6 * (int64_t)c + a];
+    c = link[c].sibling;
+    while(c != lk.sibling) {
+        for(int a = 0; a < 3; a++) {
+            b[a] = fmin(b[a], aabb[6 * (int64_t)c + a]);
+            b[3 + a] = fmax(b[3 + a], aabb[6 * (int64_t)c + 3 + a]);
+        }
+        c = link[c].sibling;
+    }
+    for(int a = 0; a < 6; a++)
+        aabb[6 * j + a] = b[a];
+}
+
+// the cube of the cull test (centre, side) around the box; `pad` (a rounding's worth of the box size) keeps a particle ON the box's
+// face inside the cube whatever the rounding of the centre
+__global__ void __launch_bounds__(256) k_aabb_cubes(int64_t nnodes, const uint32_t *__restrict__ dfs_of_bfs, const double *__restrict__ aabb, double pad,
+                                                    NodeGeo *__restrict__ geoS)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nnodes)
+        return;
+    const int64_t j = dfs_of_bfs[i];
+    const double *b = aabb + 6 * j;
+    NodeGeo g;
+    g.cx = 0.5 * (b[0] + b[3]);
+    g.cy = 0.5 * (b[1] + b[4]);
+    g.cz = 0.5 * (b[2] + b[5]);
+    g.len = fmax(fmax(b[3] - b[0], b[4] - b[1]), b[5] - b[2]) + pad;
+    geoS[i] = g;
+}
+
+__global__ void __launch_bounds__(256) k_hsmax_leaf(int64_t nnodes, const NodeLink *__restrict__ link, const double *__restrict__ hsml, double *__restrict__ hsmax)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const NodeLink lk = link[j];
+    if(lk.pcount == 0 && !(j == 0 && nnodes == 1))
+        return;
+    double hm = 0;
+    for(int k = 0; k < lk.pcount; k++)
+        hm = fmax(hm, hsml[lk.pstart + k]); // (negative: a particle that is no SPH source)
+    hsmax[j] = hm;
+}
+
 static inline int nblk(int64_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+void TreeBuilder::calc_search_boxes(hipStream_t st)
+{
+    ensure_level_order(st);
+    aabb.reserve(6 * (size_t)nnodes + 6);
+    geoS.reserve(nnodes + 16);
+    hipLaunchKernelGGL(k_aabb_leaf, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, link.p, geo.p, src.p, aabb.p);
+    for(int l = maxlevel - 1; l >= 0; l--)
+        hipLaunchKernelGGL(k_aabb_internal, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, l, link.p, aabb.p);
+    hipLaunchKernelGGL(k_aabb_cubes, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, nid_b.p, aabb.p, 1e-13 * box, geoS.p);
+    MPG_HIP(hipGetLastError());
+    has_boxes = true;
+}
+
+void TreeBuilder::calc_search_hsmax(const double *d_hsml_treeorder, hipStream_t st)
+{
+    ensure_level_order(st);
+    hsmax.reserve(nnodes + 1);
+    hsmaxS.reserve(nnodes + 16);
+    hipLaunchKernelGGL(k_hsmax_leaf, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, link.p, d_hsml_treeorder, hsmax.p);
+    for(int l = maxlevel - 1; l >= 0; l--)
+        hipLaunchKernelGGL(k_only_hmax_internal, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, l, link.p, hsmax.p);
+    hipLaunchKernelGGL(k_permute_hmax, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, nid_b.p, hsmax.p, hsmaxS.p);
+    MPG_HIP(hipGetLastError());
+    has_hsmax = true;
+}
 
 void TreeBuilder::ensure_level_order(hipStream_t st)
 {
@@ -501,6 +621,8 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     has_moments = false;
     has_hmax = false;
     has_bfs = false;
+    has_boxes = false;
+    has_hsmax = false;
     if(tm)
         tm->start(st);
     keys_a.reserve(n + 1);
@@ -784,6 +906,8 @@ TreeView TreeBuilder::view() const
         v.momB = momB.p;
         v.linkB = linkB.p;
         v.hmaxB = has_hmax ? hmaxB.p : nullptr;
+        v.geoS = has_boxes ? geoS.p : nullptr;
+        v.hsmaxS = (has_boxes && has_hsmax) ? hsmaxS.p : nullptr;
     }
     v.box = box;
     return v;

@@ -172,6 +172,16 @@ class TimestepParams(C.Structure):
     _fields_ = [("ErrTolIntAccuracy", C.c_double), ("MinSizeTimestep", C.c_double)]
 
 
+class HydroStepArrays(C.Structure):
+    """mpg_hydrostep_arrays: device arrays of find_hydro_timesteps"""
+    _fields_ = [(k, C.c_void_p) for k in ("d_type", "d_flags", "d_hsml", "d_dthsml", "d_maxsignalvel", "d_tb_grav", "d_tb_hydro", "d_bh_mintimebin")]
+
+
+class HydroStepResult(C.Structure):
+    """mpg_hydrostep_result"""
+    _fields_ = [("mTimeBin", C.c_int), ("ntitype", C.c_int64 * 5), ("badstepsizecount", C.c_int64), ("badtimebins", C.c_int64)]
+
+
 class FofParams(C.Structure):
     """mpg_fof_params"""
     _fields_ = [("FOFPrimaryLinkTypes", C.c_int), ("FOFSecondaryLinkTypes", C.c_int), ("FOFHaloComovingLinkingLength", C.c_double),
@@ -365,6 +375,44 @@ class Engine:
         v = self._view(P)
         self._ck(self.lib.mpg_resident_end(self.h, C.byref(v)))
 
+    # a gas run stays resident too: the SPH arrays (host numpy arrays as for density() / hydro_force()) are uploaded once, the two loops and
+    # the integrator between them run on the device copies (include/mpgadget_hip.h, mpg_resident_sph_*)
+    def resident_sph_begin(self, P, arrays):
+        v = self._view(P)
+        a = self._sph_host_arrays(arrays)
+        self._ck(self.lib.mpg_resident_sph_begin(self.h, C.byref(v), C.byref(a)))
+
+    def resident_sph_end(self, arrays):
+        a = self._sph_host_arrays(arrays)
+        self._ck(self.lib.mpg_resident_sph_end(self.h, C.byref(a)))
+
+    def resident_drift_all_particles(self, P, ddrift, random_shift=(0.0, 0.0, 0.0)):
+        v = self._view(P)
+        self._ck(self.lib.mpg_resident_drift_all_particles(self.h, C.byref(v), C.c_double(ddrift), (C.c_double * 3)(*random_shift)))
+
+    def resident_apply_pm_half_kick(self, P, Fgravkick):
+        v = self._view(P)
+        self._ck(self.lib.mpg_resident_apply_pm_half_kick(self.h, C.byref(v), C.c_double(Fgravkick)))
+
+    def resident_apply_half_kick(self, P, K, ActiveParticle=None):
+        v = self._view(P)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        self._ck(self.lib.mpg_resident_apply_half_kick(self.h, C.byref(v), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                                       C.c_int64(0 if act is None else len(act)), C.byref(K)))
+
+    def resident_find_hydro_timesteps(self, P, times, sync_loga, MinSizeTimestep, CourantFac, atime, hubble, ActiveParticle=None, isFirstTimeStep=False):
+        v = self._view(P)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        loga = (C.c_double * len(sync_loga))(*[float(x) for x in sync_loga])
+        tl = Timeline(len(sync_loga), C.cast(loga, C.POINTER(C.c_double)))
+        par = TimestepParams(0.0, MinSizeTimestep)
+        res = HydroStepResult()
+        self._ck(self.lib.mpg_resident_find_hydro_timesteps(self.h, C.byref(v), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                                            C.c_int64(0 if act is None else len(act)), C.byref(times), C.byref(tl), C.byref(par),
+                                                            C.c_double(CourantFac), C.c_double(atime), C.c_double(hubble), int(bool(isFirstTimeStep)),
+                                                            C.byref(res)))
+        return dict(mTimeBin=res.mTimeBin, ntitype=list(res.ntitype), badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
+
     def resident_arrays(self):
         """device pointers of the resident columns (dict of ints; 0 = absent) and n"""
         class RV(C.Structure):
@@ -452,6 +500,33 @@ class Engine:
     def dev_timestep_gravity_dloga(self, gravaccel, gravpm, atime, hubble, ErrTolIntAccuracy, dloga):
         self._ck(self.lib.mpg_dev_timestep_gravity_dloga(self.h, C.c_int64(gravaccel.shape[0]), _ptr(gravaccel), _ptr(gravpm), C.c_double(atime),
                                                          C.c_double(hubble), C.c_double(ErrTolIntAccuracy), _ptr(dloga)))
+
+    def dev_timestep_hydro_dloga(self, type, hsml, dthsml, maxsignalvel, atime, hubble, CourantFac, dloga, titype=None, bh_mintimebin=None,
+                                 dloga_for_bin=None):
+        """get_timestep_hydro_dloga (timestep.c:1076-1118) for every particle; dloga_for_bin: TIMEBINS + 1 host values or None"""
+        tab = None
+        if dloga_for_bin is not None:
+            tab = (C.c_double * (TIMEBINS + 1))(*[float(x) for x in dloga_for_bin])
+        self._ck(self.lib.mpg_dev_timestep_hydro_dloga(self.h, C.c_int64(dloga.shape[0]), _ptr(type), _ptr(hsml), _ptr(dthsml), _ptr(maxsignalvel),
+                                                       _ptr(bh_mintimebin), tab, C.c_double(atime), C.c_double(hubble), C.c_double(CourantFac),
+                                                       _ptr(dloga), _ptr(titype)))
+
+    def dev_find_hydro_timesteps(self, arrays, active, times, sync_loga, MinSizeTimestep, CourantFac, atime, hubble, isFirstTimeStep=False):
+        """find_hydro_timesteps (timestep.c:617-733) on one rank: the particle loop on the device, then the tail that updates
+        times.mintimebin (several ranks: all-reduce the result's mTimeBin / counts between the two C-ABI calls).  arrays: dict of device
+        tensors type, flags, hsml, dthsml, maxsignalvel, tb_grav, tb_hydro, bh_mintimebin (missing: NULL).  Returns the loop's result."""
+        A = HydroStepArrays(*[_ptr(arrays.get(k)) for k in ("type", "flags", "hsml", "dthsml", "maxsignalvel", "tb_grav", "tb_hydro", "bh_mintimebin")])
+        loga = (C.c_double * len(sync_loga))(*[float(x) for x in sync_loga])
+        tl = Timeline(len(sync_loga), C.cast(loga, C.POINTER(C.c_double)))
+        par = TimestepParams(0.0, MinSizeTimestep)
+        res = HydroStepResult()
+        na = active.shape[0] if active is not None else 0
+        self._ck(self.lib.mpg_dev_find_hydro_timesteps(self.h, C.byref(A), _ptr(active), C.c_int64(na), C.byref(times), C.byref(tl), C.byref(par),
+                                                       C.c_double(CourantFac), C.c_double(atime), C.c_double(hubble), C.byref(res)))
+        n = arrays["tb_hydro"].shape[0]
+        self._ck(self.lib.mpg_dev_hydro_timesteps_finish(self.h, int(res.mTimeBin), int(bool(isFirstTimeStep)), C.c_int64(n), _ptr(arrays.get("type")),
+                                                         _ptr(arrays.get("tb_hydro")), C.byref(times)))
+        return dict(mTimeBin=res.mTimeBin, ntitype=list(res.ntitype), badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
 
     # particle order: Peano-Hilbert keys and the (type, key) sort (utils/peano.h, slotsmanager.c:404-452)
     def dev_peano_keys(self, pos, box, keys):

@@ -264,3 +264,83 @@ def hierarchical_gravity_accelerations(orc, S, act, num_active_gravity, times, p
         tmp = grav if grav is not None else S.get("stored")
         apply_hierarchical_grav_kick(S, sub, times, tmp, ti, largest_active, gravkick)
         lastact, last_grav = sub, len(sub)
+
+
+# ---- the hydro time step (round 5): get_timestep_hydro_dloga, timestep.c:1076-1118; get_timebin_from_dti :166-182;
+# find_hydro_timesteps :617-733 (without the dynamic-friction bins of the black holes, :676-695).  No reference test covers them: parity
+# unpinned, pinned by this restatement (plain IEEE arithmetic in the reference's order of operations: the device results are compared bit
+# for bit).
+GAMMA = 5.0 / 3.0       # physconst.h:35
+TI_ACCEL, TI_COURANT, TI_ACCRETE, TI_NEIGH, TI_HSML = 0, 1, 2, 3, 4     # enum TimeStepType, timestep.c:89-96
+
+
+def get_timestep_hydro_dloga(ptype, hsml, dthsml, maxsignalvel, atime, hubble, CourantFac, bh_mintimebin=None, dloga_for_bin=None):
+    """one particle; returns (dloga, titype)"""
+    import math
+    dt, titype = 1.0, TI_ACCEL
+    if ptype == 0:
+        fac3 = math.pow(atime, 3 * (1 - GAMMA) / 2.0)
+        dt_courant = 2 * CourantFac * atime * hsml / (fac3 * maxsignalvel)
+        dt, titype = dt_courant, TI_COURANT
+        dt_hsml = CourantFac * atime * atime * abs(hsml / (dthsml + 1e-20))
+        if dt_hsml < dt:
+            dt, titype = dt_hsml, TI_HSML
+    elif ptype == 5 and bh_mintimebin is not None and dloga_for_bin is not None:
+        if bh_mintimebin > 0 and bh_mintimebin + 1 < TIMEBINS:
+            dt, titype = dloga_for_bin[bh_mintimebin + 1] / hubble, TI_NEIGH
+    return dt * hubble, titype
+
+
+def get_timebin_from_dti(dti, binold, Ti_Current):
+    dti = int(round_down_power_of_two(np.array([dti]))[0])
+    b = int(get_timestep_bin(np.array([dti]))[0])
+    if b > binold:
+        while (not is_timebin_active(b, Ti_Current)) and b > binold and b > 1:
+            b -= 1
+    return b
+
+
+def find_hydro_timesteps(S, act, times, tl, MinSizeTimestep, CourantFac, atime, hubble, isFirstTimeStep=False):
+    """S: dict with type, flags (optional), hsml, dthsml, maxsignalvel, tb_grav, tb_hydro (updated in place), bh_mintimebin (optional).
+    Returns dict(mTimeBin (before the tail), ntitype[5], badstepsizecount, badtimebins) and updates times['mintimebin'] as the tail does
+    (one rank: no all-reduce)."""
+    dti_max = times["PM_length"]
+    Ti = times["Ti_Current"]
+    ntitype = [0] * 5
+    bad, badbins = 0, 0
+    mTimeBin = TIMEBINS
+    logDTime = tl.dloga_interval_ti(Ti)
+    dloga_for_bin = [dti_from_timebin(b) * logDTime for b in range(TIMEBINS + 1)]
+    flags = S.get("flags")
+    bhmin = S.get("bh_mintimebin")
+    for i in _listed(S, act):
+        if flags is not None and (flags[i] & 3):
+            continue
+        ty = int(S["type"][i]) & 7
+        if ty != 0 and ty != 5:
+            continue
+        dloga, titype = get_timestep_hydro_dloga(ty, float(S["hsml"][i]), float(S["dthsml"][i]), float(S["maxsignalvel"][i]), atime, hubble,
+                                                 CourantFac, None if bhmin is None else int(bhmin[i]), dloga_for_bin)
+        dti = int(convert_timestep_to_ti(np.array([dloga]), dti_max, Ti, tl, MinSizeTimestep)[0])
+        if dti <= 1 or dti > TIMEBASE:
+            badbins += 1
+        b = get_timebin_from_dti(dti, int(S["tb_hydro"][i]), Ti)
+        if b > int(S["tb_grav"][i]):
+            b, titype = int(S["tb_grav"][i]), TI_ACCEL
+        if b < 1:
+            bad += 1
+        ntitype[titype] += 1
+        if is_timebin_active(int(S["tb_hydro"][i]), Ti) and is_timebin_active(b, Ti):
+            S["tb_hydro"][i] = b
+        mTimeBin = min(mTimeBin, b)
+    res = dict(mTimeBin=mTimeBin, ntitype=ntitype, badstepsizecount=bad, badtimebins=badbins)
+    if not is_timebin_active(mTimeBin, Ti):
+        mTimeBin = times["mintimebin"]
+        if is_timebin_active(mTimeBin + 1, Ti):
+            mTimeBin += 1
+    if isFirstTimeStep:
+        S["tb_hydro"][(S["type"] & 7) == 5] = mTimeBin
+    times["mintimebin"] = mTimeBin
+    if times["mintimebin"] > times["mingravtimebin"] and times["mingravtimebin"] > 0:
+        times["mintimebin"] = times["mingravtimebin"]
+    return res

@@ -56,4 +56,22 @@ void mpg_shim_host_tree(ForceTree *tree);
 void mpg_shim_require_host_tree(const ForceTree *tree, const char *walk);
 double mpg_shim_margin(void); /* the ghost margin in force (0: no domain handed over yet) */
 mpg_particle_view mpg_shim_view(void);
+/* ---- a run whose table stays in HBM between two domain decompositions (timestep-hip.c) ----
+ * mpg_shim_resident_begin after the step's domain_decompose_full / domain_maintain, mpg_shim_resident_end before the next one and before
+ * any host module that reads P[] / SphP[]; in between density(), hydro_force(), gravpm_force(), force_tree_full(), grav_short_tree(),
+ * find_hydro_timesteps(), apply_half_kick(), apply_PM_half_kick() and drift_all_particles() run on the device copies. */
+void mpg_shim_resident_begin(double BoxSize);
+void mpg_shim_resident_end(void);
+int mpg_shim_resident(void);
+const mpg_sph_arrays *mpg_shim_resident_sph(void); /* the host set of the resident SPH arrays (sph-hip.c passes it instead of gathering) */
+/* four accessors the maintainer adds next to the file-static parameters they read (two lines each):
+ *   timestep.c:   double mpg_shim_max_gas_vel(void) { return TimestepParams.MaxGasVel; }            (timestep.c:40-60)
+ *                 double mpg_shim_min_size_timestep(void) { return TimestepParams.MinSizeTimestep; }
+ *                 double mpg_shim_courant_fac(void) { return TimestepParams.CourantFac; }
+ *   timebinmgr.c: void mpg_shim_timeline(mpg_timeline *tl): tl->nsync = NSyncPoints and tl->loga = an array of SyncPoints[i].loga
+ *                 (timebinmgr.c:18; kept alongside SyncPoints by setup_sync_points) */
+double mpg_shim_max_gas_vel(void);
+double mpg_shim_min_size_timestep(void);
+double mpg_shim_courant_fac(void);
+void mpg_shim_timeline(mpg_timeline *tl);
 #endif

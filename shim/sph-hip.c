@@ -175,6 +175,18 @@ void density(const ActiveParticles *act, int update_hsml, int DoEgyDensity, int 
     walltime_measure("/Misc");
     /* density() is the FIRST force call of a step (run.c:472, and of the start-up: init.c): the table may just have been drifted
      * and exchanged, the decomposition rewritten */
+    if(mpg_shim_resident()) {
+        /* a resident stretch (timestep-hip.c): the slot fields were gathered once and live in HBM; the loop runs on them in place and
+         * its results stay there (mpg_shim_resident_end scatters them).  |grad rho| is a host output of this call: not in this mode */
+        if(GradRho_mag)
+            endrun(5, "density(): GradRho_mag is not available inside a resident stretch (mpg_shim_resident_end first)\n");
+        mpg_particle_view rv = view();
+        fill_times(&t, &times, CP, 0);
+        ck(mpg_density(mpg_shim_engine(), &rv, tree->BoxSize, mpg_shim_resident_sph(), &t, act->ActiveParticle, act->NumActiveParticle, update_hsml,
+                       DoEgyDensity, BlackHoleOn));
+        walltime_add("/SPH/Density/WalkPrim", walltime_measure(WALLTIME_IGNORE));
+        return;
+    }
     mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, mpg_shim_dist() ? 1.26 * max_target_hsml() : 0);
     mpg_particle_view v = view();
     gather(&H);
@@ -247,6 +259,13 @@ void hydro_force(const ActiveParticles *act, const double atime, struct sph_pred
     walltime_measure("/Misc");
     /* hydro_force() follows density() of the same step on the same table (run.c:472-489): same epoch, and for several ranks the
      * local set, gas tree and ghost columns the density loop left in the library (mpg_dist_hydro_force checks that it is so) */
+    if(mpg_shim_resident()) { /* (see density()) */
+        mpg_particle_view rv = view();
+        fill_times(&t, &times, CP, atime);
+        ck(mpg_hydro_force(mpg_shim_engine(), &rv, mpg_shim_resident_sph(), &t, act->ActiveParticle, act->NumActiveParticle));
+        walltime_add("/SPH/Hydro/WalkPrim", walltime_measure(WALLTIME_IGNORE));
+        return;
+    }
     mpg_shim_sync(times.Ti_Current, 0, tree->BoxSize, 0);
     mpg_particle_view v = view();
     gather(&H);

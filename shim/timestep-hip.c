@@ -1,0 +1,246 @@
+/* libgadget/timestep-hip.c -- a run whose particle table STAYS IN HBM between two domain decompositions (resident mode).
+ *
+ * With gravity-hip.c / sph-hip.c alone every force call of a step moves Pos / Mass up and its results down, because drift_all_particles,
+ * apply_half_kick and find_timesteps run on the host in between (run.c:392-794): half of a 256^3 step (bench.py host_path).  This file
+ * takes the integrator over as well.  The maintainer brackets the stretch of run.c in which nothing reorders P[] -
+ *
+ *     domain_decompose_full(...) / domain_maintain(...)          run.c:422-434   (host; reorders and exchanges P[])
+ *     mpg_shim_resident_begin(PartManager->BoxSize);             <- one upload: P[] columns + the SPH slot fields in particle order
+ *     ... density, hydro_force, gravpm_force, force_tree_full, grav_short_tree, find_hydro_timesteps, apply_half_kick,
+ *         apply_PM_half_kick of this step, drift_all_particles at the top of the next ...      (all on the device copies)
+ *     mpg_shim_resident_end();                                   <- one fetch, before the next domain_maintain, a snapshot, FOF, or any
+ *                                                                   host module that reads P[] / SphP[] (cooling, star formation)
+ *
+ * - and compiles timestep.c and drift.c with the four entry points below renamed (one line in libgadget/Makefile, as for forcetree.o):
+ *     timestep.o: CFLAGS += -Dapply_half_kick=cpu_apply_half_kick -Dapply_PM_half_kick=cpu_apply_PM_half_kick -Dfind_hydro_timesteps=cpu_find_hydro_timesteps
+ *     drift.o:    CFLAGS += -Ddrift_all_particles=cpu_drift_all_particles
+ * Outside a resident stretch the definitions here call those cpu_ originals, so a run that never calls mpg_shim_resident_begin behaves as
+ * before.  Inside one, the factors come from the reference's own get_exact_*_factor / dloga_from_dti (host arithmetic on the integer
+ * timeline) and the per-particle loops run as mpg_resident_* on the device (include/mpgadget_hip.h).  One rank per GPU; NTask > 1 keeps the
+ * host path (the resident calls are one-rank forms: mpg_dist_* owns the multi-rank choreography).
+ * Not covered (the shim stops with a message): black-hole particles inside a resident stretch (drift.c:33-55 repositioning, the
+ * dynamic-friction kicks, timestep.c:1003-1010), hierarchical gravity (its level loop has its own device form, mpg_dev_hierarchical_*). */
+#include <mpi.h>
+#include <math.h>
+#include <string.h>
+#include "timestep.h"
+#include "drift.h"
+#include "timefac.h"
+#include "timebinmgr.h"
+#include "cosmology.h"
+#include "partmanager.h"
+#include "slotsmanager.h"
+#include "walltime.h"
+#include "utils/endrun.h"
+#include "utils/mymalloc.h"
+#include <mpgadget_hip.h>
+#include "mpg_shim.h"
+
+#define ck mpg_shim_ck
+#define view mpg_shim_view
+
+/* the renamed originals (timestep.c:873-929, 964-985, 617-733; drift.c:84-102) */
+void cpu_apply_half_kick(const ActiveParticles *act, Cosmology *CP, DriftKickTimes *times, const double atime);
+void cpu_apply_PM_half_kick(Cosmology *CP, DriftKickTimes *times);
+int cpu_find_hydro_timesteps(const ActiveParticles *act, DriftKickTimes *times, const double atime, const Cosmology *CP, const int isFirstTimeStep);
+void cpu_drift_all_particles(inttime_t ti0, inttime_t ti1, Cosmology *CP, const double random_shift[3]);
+
+/* ---- the resident stretch ---- */
+static struct {
+    int on;
+    double BoxSize;
+    mpg_sph_arrays A;  /* the SPH slot fields in particle order (host; the library keeps the device copies) */
+    double *block;
+    uint8_t *tb;
+} R;
+
+int mpg_shim_resident(void) { return R.on; }
+const mpg_sph_arrays *mpg_shim_resident_sph(void) { return R.on ? &R.A : NULL; }
+
+void mpg_shim_resident_begin(double BoxSize)
+{
+    const int64_t n = PartManager->NumPart;
+    int64_t i;
+    if(R.on)
+        endrun(5, "mpg_shim_resident_begin: already resident\n");
+    if(mpg_shim_ntask() > 1) /* (the host path stays in force) */
+        return;
+    for(i = 0; i < n; i++)
+        if(P[i].Type == 5 && !P[i].IsGarbage && !P[i].Swallowed)
+            endrun(5, "mpg_shim_resident_begin: black holes are not carried by the resident integrator (drift.c:33-55, timestep.c:1003-1010)\n");
+    mpg_particle_view v = view();
+    ck(mpg_resident_begin(mpg_shim_engine(), &v, BoxSize));
+    /* the slot fields, gathered once: what sph-hip.c gathers per call */
+    R.block = (double *)mymalloc("mpg_resident_sph", (size_t)n * 31 * sizeof(double));
+    R.tb = (uint8_t *)mymalloc("mpg_resident_tb", (size_t)n * 2);
+    double *q = R.block;
+#define COL(w) (q += (size_t)n * (w), q - (size_t)n * (w))
+    memset(&R.A, 0, sizeof(R.A));
+    double *hsml = COL(1), *dthsml = COL(1), *vel = COL(3), *gacc = COL(3), *gpm = COL(3), *hin = COL(3), *ent = COL(1), *dte = COL(1);
+    R.A.density = COL(1);
+    R.A.egywtdensity = COL(1);
+    R.A.dhsmlegyfac = COL(1);
+    R.A.divvel = COL(1);
+    R.A.curlvel = COL(1);
+    R.A.gradrho = COL(3);
+    R.A.hydroacc_out = COL(3);
+    R.A.dtentropy_out = COL(1);
+    R.A.maxsignalvel = COL(1);
+#undef COL
+    memset(R.block, 0, (size_t)n * 31 * sizeof(double));
+    #pragma omp parallel for
+    for(i = 0; i < n; i++) {
+        int k;
+        hsml[i] = P[i].Hsml;
+        dthsml[i] = P[i].DtHsml;
+        R.tb[i] = P[i].TimeBinHydro;
+        R.tb[n + i] = P[i].TimeBinGravity;
+        if(P[i].Type != 0)
+            continue;
+        ent[i] = SPHP(i).Entropy;
+        R.A.density[i] = SPHP(i).Density;
+        R.A.egywtdensity[i] = SPHP(i).EgyWtDensity;
+        R.A.dhsmlegyfac[i] = SPHP(i).DhsmlEgyDensityFactor;
+        R.A.divvel[i] = SPHP(i).DivVel;
+        R.A.curlvel[i] = SPHP(i).CurlVel;
+        R.A.dtentropy_out[i] = SPHP(i).DtEntropy;
+        R.A.maxsignalvel[i] = SPHP(i).MaxSignalVel;
+        for(k = 0; k < 3; k++)
+            R.A.hydroacc_out[3 * i + k] = SPHP(i).HydroAccel[k];
+    }
+    R.A.hsml = hsml;
+    R.A.dthsml = dthsml;
+    R.A.vel = vel;              /* (aliases of the resident table's columns on the device: never read on the host) */
+    R.A.gacc = gacc;
+    R.A.gpm = gpm;
+    R.A.hydroacc_in = hin;      /* (device: aliases hydroacc_out / dtentropy_out) */
+    R.A.dtentropy_in = dte;
+    R.A.entropy = ent;
+    R.A.tb_hydro = R.tb;
+    R.A.tb_grav = R.tb + n;
+    ck(mpg_resident_sph_begin(mpg_shim_engine(), &v, &R.A));
+    R.BoxSize = BoxSize;
+    R.on = 1;
+}
+
+void mpg_shim_resident_end(void)
+{
+    const int64_t n = PartManager->NumPart;
+    int64_t i;
+    if(!R.on)
+        return;
+    mpg_particle_view v = view();
+    ck(mpg_resident_sph_end(mpg_shim_engine(), &R.A));
+    ck(mpg_resident_end(mpg_shim_engine(), &v)); /* Pos, Vel, FullTreeGravAccel, GravPM, Potential back into P[] */
+    #pragma omp parallel for
+    for(i = 0; i < n; i++) {
+        int k;
+        if(P[i].Type != 0)
+            continue;
+        P[i].Hsml = R.A.hsml[i];
+        P[i].DtHsml = R.A.dthsml[i];
+        P[i].TimeBinHydro = R.tb[i];
+        SPHP(i).Entropy = R.A.entropy[i];
+        SPHP(i).Density = R.A.density[i];
+        SPHP(i).EgyWtDensity = R.A.egywtdensity[i];
+        SPHP(i).DhsmlEgyDensityFactor = R.A.dhsmlegyfac[i];
+        SPHP(i).DivVel = R.A.divvel[i];
+        SPHP(i).CurlVel = R.A.curlvel[i];
+        SPHP(i).DtEntropy = R.A.dtentropy_out[i];
+        SPHP(i).MaxSignalVel = R.A.maxsignalvel[i];
+        for(k = 0; k < 3; k++)
+            SPHP(i).HydroAccel[k] = R.A.hydroacc_out[3 * i + k];
+    }
+    myfree(R.tb);
+    myfree(R.block);
+    R.on = 0;
+    mpg_shim_particles_changed(); /* (the host table is current again and may now be reordered) */
+}
+
+/* ---- the reference's entry points ---- */
+
+/* apply_half_kick, timestep.c:873-929: the kick factors per bin on the host as there, the particle loop on the device */
+void apply_half_kick(const ActiveParticles *act, Cosmology *CP, DriftKickTimes *times, const double atime)
+{
+    if(!R.on) {
+        cpu_apply_half_kick(act, CP, times, atime);
+        return;
+    }
+    int bin;
+    mpg_kick_factors K;
+    walltime_measure("/Misc");
+    memset(&K, 0, sizeof(K));
+    for(bin = 0; bin <= TIMEBINS; bin++) {
+        K.bin_active[bin] = (unsigned char)is_timebin_active(bin, times->Ti_Current);
+        K.dt_entr[bin] = dloga_from_dti(dti_from_timebin(bin) / 2, times->Ti_Current); /* timestep.c:915-917 */
+        if(bin < times->mintimebin || !K.bin_active[bin])
+            continue;
+        const inttime_t newkick = times->Ti_kick[bin] + dti_from_timebin(bin) / 2;
+        K.gravkick[bin] = get_exact_gravkick_factor(CP, times->Ti_kick[bin], newkick);
+        K.hydrokick[bin] = get_exact_hydrokick_factor(CP, times->Ti_kick[bin], newkick);
+    }
+    K.atime = atime;
+    K.MaxGasVel = mpg_shim_max_gas_vel(); /* TimestepParams.MaxGasVel is static in timestep.c: one accessor added there */
+    mpg_particle_view v = view();
+    ck(mpg_resident_apply_half_kick(mpg_shim_engine(), &v, act->ActiveParticle, act->NumActiveParticle, &K));
+    walltime_measure("/Timeline/HalfKick/Short");
+}
+
+/* apply_PM_half_kick, timestep.c:964-985 */
+void apply_PM_half_kick(Cosmology *CP, DriftKickTimes *times)
+{
+    if(!R.on) {
+        cpu_apply_PM_half_kick(CP, times);
+        return;
+    }
+    const inttime_t tistart = times->PM_kick;
+    const inttime_t tiend = tistart + times->PM_length / 2;
+    const double Fgravkick = get_exact_gravkick_factor(CP, tistart, tiend);
+    mpg_particle_view v = view();
+    ck(mpg_resident_apply_pm_half_kick(mpg_shim_engine(), &v, Fgravkick));
+    times->PM_kick = tiend;
+    walltime_measure("/Timeline/HalfKick/Long");
+}
+
+/* drift_all_particles, drift.c:84-102 */
+void drift_all_particles(inttime_t ti0, inttime_t ti1, Cosmology *CP, const double random_shift[3])
+{
+    if(!R.on) {
+        cpu_drift_all_particles(ti0, ti1, CP, random_shift);
+        return;
+    }
+    if(ti1 < ti0)
+        endrun(12, "Trying to reverse time: ti0=%ld ti1=%ld\n", ti0, ti1);
+    const double ddrift = get_exact_drift_factor(CP, ti0, ti1);
+    mpg_particle_view v = view();
+    ck(mpg_resident_drift_all_particles(mpg_shim_engine(), &v, ddrift, random_shift));
+    int64_t i;
+    #pragma omp parallel for
+    for(i = 0; i < PartManager->NumPart; i++)
+        PartManager->Base[i].Ti_drift = ti1; /* (the host's record of where the particles are in time stays current) */
+    walltime_measure("/Drift");
+}
+
+/* find_hydro_timesteps, timestep.c:617-733: the particle loop and the update of times->mintimebin on the device copies */
+int find_hydro_timesteps(const ActiveParticles *act, DriftKickTimes *times, const double atime, const Cosmology *CP, const int isFirstTimeStep)
+{
+    if(!R.on)
+        return cpu_find_hydro_timesteps(act, times, atime, CP, isFirstTimeStep);
+    _Static_assert(TIMEBINS == MPG_TIMEBINS, "TIMEBINS (timebinmgr.h:8)");
+    _Static_assert(sizeof(DriftKickTimes) == sizeof(mpg_drift_kick_times), "DriftKickTimes (timestep.h:10-27)");
+    const double hubble = hubble_function(CP, atime);
+    mpg_timeline tl;
+    mpg_timestep_params par;
+    mpg_hydrostep_result res;
+    mpg_shim_timeline(&tl);                                 /* SyncPoints[].loga: static in timebinmgr.c, one accessor added there */
+    par.ErrTolIntAccuracy = 0;                              /* (not read by the hydro criterion) */
+    par.MinSizeTimestep = mpg_shim_min_size_timestep();     /* TimestepParams.MinSizeTimestep, the same accessor file */
+    mpg_particle_view v = view();
+    ck(mpg_resident_find_hydro_timesteps(mpg_shim_engine(), &v, act->ActiveParticle, act->NumActiveParticle, (mpg_drift_kick_times *)times, &tl, &par,
+                                         mpg_shim_courant_fac(), atime, hubble, isFirstTimeStep, &res));
+    message(0, "Hydro timesteps: Accel: %ld Soundspeed: %ld DivVel: %ld Accrete: %ld Neighbour: %ld\n", (long)res.ntitype[0], (long)res.ntitype[1],
+            (long)res.ntitype[4], (long)res.ntitype[2], (long)res.ntitype[3]);
+    walltime_measure("/Timeline/Hydro");
+    message(0, "Min grav timebin: %d mintimebin %d\n", times->mingravtimebin, times->mintimebin);
+    return (int)res.badstepsizecount;
+}

@@ -138,7 +138,7 @@ def test_reference_side_shim_compiles(tmp_path):
     (tmp_path / "gsl").mkdir()
     (tmp_path / "pfft.h").write_text("#include <stddef.h>\n#include <mpi.h>\ntypedef double pfft_complex[2];\ntypedef struct pfft_plan_s *pfft_plan;\n")
     (tmp_path / "gsl" / "gsl_interp.h").write_text("typedef struct gsl_interp gsl_interp;\ntypedef struct gsl_interp_accel gsl_interp_accel;\n")
-    for src in ("gravity-hip.c", "sph-hip.c", "forcetree-hip.c", "mpg_mpi_comm.c", "mpg_rccl_mpi.c"):
+    for src in ("gravity-hip.c", "sph-hip.c", "forcetree-hip.c", "timestep-hip.c", "mpg_mpi_comm.c", "mpg_rccl_mpi.c"):
         r = subprocess.run(["gcc", "-std=gnu11", "-fopenmp", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
                             "-I", str(tmp_path), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "shim"), "-I", mpi,
                             "-I", ref, "-I", os.path.dirname(ref), os.path.join(ROOT, "shim", src)], capture_output=True, text=True)

@@ -50,3 +50,37 @@ def test_bins_and_activity():
     S = dict(tb_grav=np.array([0, 1, 2, 3, 4], np.uint8), flags=np.array([0, 0, 1, 0, 0], np.uint8))
     assert H.build_active_sublist(S, None, 3, 8).tolist() == [0, 1, 3]
     assert H.build_active_sublist(S, np.array([4, 3, 1]), 4, 8).tolist() == [3, 1]   # order of the input list; bin 4 inactive at 8
+
+
+def test_hydro_timestep_restatement_closed_forms():
+    """get_timestep_hydro_dloga / get_timebin_from_dti / find_hydro_timesteps as restated in oracle/hiergrav_oracle.py (timestep.c:1076-1118,
+    166-182, 617-733; the reference holds no test of them) against values worked out by hand."""
+    import math
+    from oracle import hiergrav_oracle as H
+    a, hub, C = 0.5, 0.3, 0.15
+    # gas, Courant: dt = 2 C a h / (a^(3 (1 - 5/3) / 2) vsig) = 2 C a^2 h / vsig
+    dl, tt = H.get_timestep_hydro_dloga(0, 0.2, 0.0, 40.0, a, hub, C)
+    assert tt == H.TI_COURANT and abs(dl / (2 * C * a * a * 0.2 / 40.0 * hub) - 1) < 1e-14
+    # gas, a fast change of the smoothing length wins: dt = C a^2 |h / dh|
+    dl, tt = H.get_timestep_hydro_dloga(0, 0.2, -50.0, 40.0, a, hub, C)
+    assert tt == H.TI_HSML and abs(dl / (C * a * a * 0.2 / 50.0 * hub) - 1) < 1e-12
+    # black hole: the bin above the shortest neighbour's; none without a neighbour bin; other types dt = 1
+    tab = [float(b) for b in range(H.TIMEBINS + 1)]
+    assert H.get_timestep_hydro_dloga(5, 0, 0, 0, a, hub, C, 7, tab) == (tab[8] / hub * hub, H.TI_NEIGH)
+    assert H.get_timestep_hydro_dloga(5, 0, 0, 0, a, hub, C, 0, tab) == (hub, H.TI_ACCEL)
+    assert H.get_timestep_hydro_dloga(1, 0, 0, 0, a, hub, C) == (hub, H.TI_ACCEL)
+    # get_timebin_from_dti: a power of two rounded down; a longer step only onto an active bin
+    assert H.get_timebin_from_dti((1 << 20) + 5, 25, 1 << 30) == 20
+    assert H.get_timebin_from_dti(1 << 20, 12, 1 << 15) == 15 and H.get_timebin_from_dti(1 << 20, 12, 3 << 10) == 12
+    assert H.get_timebin_from_dti(1 << 20, 12, 1 << 11) == 12      # (bin 11 is active, but never below the old bin)
+    # find_hydro_timesteps: the hydro bin never exceeds the gravity bin, and the shortest bin is the new mintimebin
+    import numpy as np
+    tl = H.Timeline(np.log(np.array([0.25, 1.0])))
+    S = dict(type=np.array([0, 0, 1], np.uint8), hsml=np.array([0.5, 0.5, 0.5]), dthsml=np.zeros(3), maxsignalvel=np.array([1e3, 1e-6, 1.0]),
+             tb_grav=np.array([40, 33, 40], np.uint8), tb_hydro=np.array([30, 30, 30], np.uint8))
+    t = dict(mintimebin=30, maxtimebin=41, mingravtimebin=33, Ti_Current=0, PM_length=1 << 41, PM_start=0, PM_kick=0, Ti_kick=[0] * 47)
+    r = H.find_hydro_timesteps(S, None, t, tl, 1e-9, C, a, hub)
+    dl0 = 2 * C * a * a * 0.5 / 1e3 * hub
+    b0 = int(math.floor(math.log2(dl0 / (math.log(4.0) / (1 << H.TIMEBINS)))))
+    assert S["tb_hydro"][0] == b0 and S["tb_hydro"][1] == 33 and S["tb_hydro"][2] == 30
+    assert r["ntitype"] == [1, 1, 0, 0, 0] and r["mTimeBin"] == b0 and t["mintimebin"] == min(b0, 33)
