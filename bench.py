@@ -117,7 +117,22 @@ def quick_gravity_steps(pkg, torch, eng, ic, n, nmesh, dev, steps=3):
 
 def host_path_steps(pkg, eng, pos, mass, box, steps=3):
     """SURVEY 8(d)'s metric as the reference's callers see it: the drop-in (host pointer) calls on struct particle_data records in
-    host memory, results written back into them - PCIe transfers and AoS packing included.  Not `value`."""
+    host memory, results written back into them - PCIe transfers and AoS packing included.  Not `value`.  Measured twice: with the
+    overlap the shim switches on (mpg_set_host_overlap: one packing pass per epoch, OldAcc on the device, gravpm_force's results written
+    into P[] by a host thread while the tree build and the walk run; everything is in P[] when grav_short_tree returns) - `ms_per_step` -
+    and with every call finishing its own transfers before it returns - `synchronous`."""
+    eng.set_host_overlap(True)
+    out = _host_path_steps(pkg, eng, pos, mass, box, steps)
+    eng.set_host_overlap(False)
+    sync = _host_path_steps(pkg, eng, pos, mass, box, steps)
+    out["synchronous"] = {k: sync[k] for k in ("ms_per_step", "particles_per_s", "calls_ms")}
+    # (the same three columns of P[] by both routes; not bit for bit: the CIC deposit sums with atomics)
+    a, b = out.pop("_columns"), sync.pop("_columns")
+    out["max_rel_difference_to_synchronous"] = float(max(np.abs(x - y).max() / np.abs(y).max() for x, y in zip(a, b)))
+    return out
+
+
+def _host_path_steps(pkg, eng, pos, mass, box, steps=3):
     P = pkg.make_particles(pos, mass)
     N = len(pos)
     ts = []
@@ -137,12 +152,13 @@ def host_path_steps(pkg, eng, pos, mass, box, steps=3):
     ts = np.array(ts[2:])      # the first two steps allocate the pinned staging and run the Barnes-Hut walk
     tot = ts.sum(1).mean()
     return {"ms_per_step": round(1e3 * tot, 2), "particles_per_s": N / tot,
+            "_columns": (P["GravPM"].copy(), P["FullTreeGravAccel"].copy(), P["Potential"].copy()),
             "calls_ms": {"gravpm_force": round(1e3 * ts[:, 0].mean(), 2), "force_tree_full": round(1e3 * ts[:, 1].mean(), 2),
                          "grav_short_tree": round(1e3 * ts[:, 2].mean(), 2)},
             "note": "mpg_gravpm_force + mpg_force_tree_full + mpg_grav_short_tree on %d 160-byte particle_data records in pageable host "
-                    "memory, one table epoch per step as the shim declares it (one H2D of Pos/Mass per step, OldAcc up, GravPM / "
-                    "FullTreeGravAccel / Potential down, packing on host threads) = the force part of run.c:522-548 with shim/ in the link, "
-                    "no host tree anywhere; the device-resident rate is `value`" % N}
+                    "memory, one table epoch per step as the shim declares it (one packing pass and one H2D of Pos / Mass / Type / Potential / "
+                    "FullTreeGravAccel per step, GravPM / FullTreeGravAccel / Potential down, packing on host threads) = the force part of "
+                    "run.c:522-548 with shim/ in the link, no host tree anywhere; the device-resident rate is `value`" % N}
 
 
 def resident_path_steps(pkg, eng, pos, mass, box, steps=3):

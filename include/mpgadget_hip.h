@@ -109,6 +109,15 @@ void mpg_particle_view_reference_layout(mpg_particle_view *v, void *particles, i
  * one step, run.c:522-548).  Bump the epoch after anything that moves or reorders particles (drift, exchange, garbage collection);
  * 0 (the default) switches the reuse off. */
 int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch);
+/* Overlap of the host path's transfers with the device's work inside one epoch (default off).  When on - and only while a non-zero epoch is
+ * declared - (a) the first call of an epoch packs Pos / Mass / Type, Potential and FullTreeGravAccel in ONE pass over the records, and
+ * mpg_grav_short_tree takes OldAcc = |FullTreeGravAccel + GravPM| / G on the device from that upload and the device's own GravPM instead of
+ * reading P[] again; (b) mpg_gravpm_force RETURNS once its results are on their way: GravPM and Potential are copied down and written into
+ * P[] by a host thread while force_tree_full and grav_short_tree run, and are complete when the next call on the table that needs them
+ * returns (mpg_grav_short_tree at the latest) or when mpg_host_results_sync returns.  A caller whose host code reads P[].GravPM /
+ * P[].Potential between gravpm_force and grav_short_tree (energy_statistics, run.c:527) calls mpg_host_results_sync first. */
+int mpg_set_host_overlap(mpg_engine *eng, int on);
+int mpg_host_results_sync(mpg_engine *eng);
 /* gravpm_force, libgadget/gravpm.c:61-119: zero GravPM, CIC deposit, r2c, Green's function, 4 x (transfer, c2r,
  * CIC readout).  Writes P[i].GravPM[3] (=) and P[i].Potential (+=, as readout_potential does). */
 int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *pv);

@@ -47,9 +47,19 @@ void mpg_engine_destroy(mpg_engine *eng)
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+    eng->host_join();
     for(auto &e : eng->chunk_ev)
         if(e)
             (void)hipEventDestroy(e);
+    for(auto &e : eng->gchunk_ev)
+        if(e)
+            (void)hipEventDestroy(e);
+    if(eng->ev_pm_done)
+        (void)hipEventDestroy(eng->ev_pm_done);
+    if(eng->copy_stream) {
+        (void)hipStreamSynchronize(eng->copy_stream);
+        (void)hipStreamDestroy(eng->copy_stream);
+    }
     eng->pm.destroy();
     if(eng->aux_stream) {
         (void)hipStreamSynchronize(eng->aux_stream);
@@ -1304,6 +1314,7 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
     if(eng->host_epoch != 0 && eng->staged_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n &&
        eng->staged_box == BoxSize && eng->d_pos == eng->s_pos.p)
         return;
+    eng->host_join(); // (a pending write-back of the last epoch's GravPM touches the records this pass reads)
     eng->h_d.reserve(3 * (size_t)n + 1);
     eng->h_f.reserve((size_t)n + 1);
     eng->h_b.reserve((size_t)n + 1);
@@ -1315,6 +1326,21 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
     float *hf = eng->h_f.p;
     uint8_t *hb = eng->h_b.p;
     const mpg_particle_view V = *P;
+    // with overlap, the same pass also takes what the epoch's later calls would read from P[] again: Potential (gravpm_force accumulates
+    // into it) and FullTreeGravAccel (the walk's opening criterion)
+    const bool extras = eng->host_overlap && eng->host_epoch != 0 && V.off_accel >= 0;
+    const bool xpot = extras && V.off_potential >= 0;
+    double *hacc = nullptr, *hpot = nullptr;
+    if(extras) {
+        eng->h_acc.reserve(3 * (size_t)n + 1);
+        eng->s_prevacc.reserve(3 * (size_t)n + 1);
+        hacc = eng->h_acc.p;
+        if(xpot) {
+            eng->h_gpot.reserve((size_t)n + 1);
+            eng->s_pot.reserve((size_t)n + 1);
+            hpot = eng->h_gpot.p;
+        }
+    }
     int any_dead_store[HOST_CHUNKS] = {};
     int *any_dead = any_dead_store;
     for(int c = 0; c < HOST_CHUNKS; c++) {
@@ -1340,12 +1366,26 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
                 hb[i] = ty;
                 if(ty == 7)
                     any_dead[c] = 1;
+                if(hacc) {
+                    const double *aa = (const double *)(rec + V.off_accel);
+                    hacc[3 * i + 0] = aa[0];
+                    hacc[3 * i + 1] = aa[1];
+                    hacc[3 * i + 2] = aa[2];
+                    if(hpot)
+                        hpot[i] = *(const double *)(rec + V.off_potential);
+                }
             }
         });
         MPG_HIP(hipMemcpyAsync(eng->s_pos.p + 3 * lo, hd + 3 * lo, 3 * (hi - lo) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
         MPG_HIP(hipMemcpyAsync(eng->s_mass.p + lo, hf + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, eng->stream));
         MPG_HIP(hipMemcpyAsync(eng->s_type.p + lo, hb + lo, (hi - lo) * sizeof(uint8_t), hipMemcpyHostToDevice, eng->stream));
+        if(hpot)
+            MPG_HIP(hipMemcpyAsync(eng->s_pot.p + lo, hpot + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     }
+    if(hacc) // (needed by the walk only: behind the positions on the stream, beside the PM step on the bus)
+        MPG_HIP(hipMemcpyAsync(eng->s_prevacc.p, hacc, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    eng->staged_extra_epoch = extras ? eng->host_epoch : -1;
+    eng->gravpm_epoch = -1;
     // garbage and swallowed particles are not deposited and receive no mesh force either (gravpm.c:176-179: region -2): the PM takes a
     // live flag per particle when the table holds any
     bool dead = false;
@@ -1382,6 +1422,24 @@ int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch)
     API_END
 }
 
+int mpg_set_host_overlap(mpg_engine *eng, int on)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->host_join();
+    eng->host_overlap = on != 0;
+    API_END
+}
+
+int mpg_host_results_sync(mpg_engine *eng)
+{
+    API_BEGIN
+    MPG_CHECK(eng, "null engine");
+    eng->host_join();
+    MPG_CHECK(eng->unpack_error.empty(), "host path: the write-back of GravPM failed: " + eng->unpack_error);
+    API_END
+}
+
 int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
 {
     API_BEGIN
@@ -1389,6 +1447,8 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     MPG_HIP(hipSetDevice(eng->device));
     MPG_CHECK(eng->pm.nmesh > 0, "gravpm_force called before gravpm_init_periodic");
     MPG_CHECK(P->off_gravpm >= 0, "particle view needs GravPM");
+    eng->host_join(); // (the write-back of an earlier call)
+    MPG_CHECK(eng->unpack_error.empty(), "host path: the write-back of GravPM failed: " + eng->unpack_error);
     stage_particles(eng, P, eng->pm.box);
     const int64_t n = P->n;
     if(eng->resident && eng->res_base == P->base) { // results stay in HBM: GravPM assigned, Potential accumulated (gravpm.c:499-501)
@@ -1405,7 +1465,8 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     eng->h_d2.reserve(3 * (size_t)n + 1);
     eng->h_d3.reserve((size_t)n + 1);
     double *hg = eng->h_d2.p, *hp = eng->h_d3.p;
-    if(wantpot) {
+    const bool overlap = eng->host_overlap && eng->host_epoch != 0;
+    if(wantpot && !(overlap && eng->staged_extra_epoch == eng->host_epoch)) { // (with overlap the Potential went up with the positions)
         // readout_potential accumulates into P.Potential (gravpm.c:499-501), which is NOT zeroed first
         eng->s_pot.reserve((size_t)n + 1);
         parallel_for(n, [=](int64_t lo, int64_t hi) {
@@ -1417,7 +1478,66 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     if(eng->pm_live)
         MPG_HIP(hipMemsetAsync(eng->s_gravpm.p, 0, 3 * (size_t)n * sizeof(double), eng->stream));
     eng->pm.force(n, eng->d_pos, eng->d_mass, eng->pm_live, eng->s_gravpm.p, wantpot ? eng->s_pot.p : nullptr, eng->stream, &eng->timer);
+    eng->gravpm_epoch = eng->host_epoch;
     const double *dg = eng->s_gravpm.p, *dp = eng->s_pot.p;
+    if(overlap) {
+        // the results leave on a copy stream behind the PM step and are written into P[] by a host thread, chunk by chunk, while this
+        // thread returns and queues the tree build and the walk (the walk reads GravPM and the Potential it accumulates onto from the
+        // device buffers, which nothing overwrites before the next gravpm_force)
+        if(!eng->copy_stream) {
+            MPG_HIP(hipStreamCreateWithFlags(&eng->copy_stream, hipStreamNonBlocking));
+            MPG_HIP(hipEventCreateWithFlags(&eng->ev_pm_done, hipEventDisableTiming));
+        }
+        eng->h_gpm.reserve(3 * (size_t)n + 1);
+        double *ag = eng->h_gpm.p, *ap = nullptr;
+        if(wantpot) {
+            eng->h_gpot.reserve((size_t)n + 1);
+            ap = eng->h_gpot.p;
+        }
+        MPG_HIP(hipEventRecord(eng->ev_pm_done, eng->stream));
+        MPG_HIP(hipStreamWaitEvent(eng->copy_stream, eng->ev_pm_done, 0));
+        for(int c = 0; c < HOST_CHUNKS; c++) {
+            int64_t lo, hi;
+            chunk_range(n, c, lo, hi);
+            if(hi > lo) {
+                MPG_HIP(hipMemcpyAsync(ag + 3 * lo, dg + 3 * lo, 3 * (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, eng->copy_stream));
+                if(wantpot)
+                    MPG_HIP(hipMemcpyAsync(ap + lo, dp + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, eng->copy_stream));
+            }
+            if(!eng->gchunk_ev[c])
+                MPG_HIP(hipEventCreateWithFlags(&eng->gchunk_ev[c], hipEventDisableTiming));
+            MPG_HIP(hipEventRecord(eng->gchunk_ev[c], eng->copy_stream));
+        }
+        eng->unpack_error.clear();
+        const int device = eng->device;
+        eng->unpack_thread = std::thread([=] {
+            if(hipSetDevice(device) != hipSuccess) {
+                eng->unpack_error = "hipSetDevice";
+                return;
+            }
+            for(int c = 0; c < HOST_CHUNKS; c++) {
+                int64_t lo, hi;
+                chunk_range(n, c, lo, hi);
+                if(hipEventSynchronize(eng->gchunk_ev[c]) != hipSuccess) {
+                    eng->unpack_error = "hipEventSynchronize";
+                    return;
+                }
+                if(hi > lo)
+                    parallel_for(hi - lo, [=](int64_t a0, int64_t a1) {
+                        for(int64_t i = lo + a0; i < lo + a1; i++) {
+                            double *g = (double *)(b + i * V.stride + V.off_gravpm);
+                            g[0] = ag[3 * i + 0];
+                            g[1] = ag[3 * i + 1];
+                            g[2] = ag[3 * i + 2];
+                            if(ap)
+                                *(double *)(b + i * V.stride + V.off_potential) = ap[i];
+                        }
+                    });
+            }
+        });
+        mpg_err_slot().clear();
+        return 0;
+    }
     hipStream_t st = eng->stream;
     download_chunks(
         eng, n,
@@ -1516,27 +1636,34 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
         return 0;
     }
     const char *b = (const char *)P->base;
-    // fill: OldAcc = |FullTreeGravAccel + GravPM| / G (grav_short_copy, gravshort.h:82-86)
-    eng->h_d3.reserve((size_t)n + 1);
-    double *old = eng->h_d3.p;
-    const double G = eng->pm.G;
     const mpg_particle_view V = *P;
-    parallel_for(n, [=](int64_t lo, int64_t hi) {
-        for(int64_t i = lo; i < hi; i++) {
-            const double *a = (const double *)(b + i * V.stride + V.off_accel);
-            const double *g = (const double *)(b + i * V.stride + V.off_gravpm);
-            double s2 = 0;
-            for(int j = 0; j < 3; j++) {
-                const double ax = a[j] + g[j];
-                s2 += ax * ax;
-            }
-            old[i] = sqrt(s2) / G;
-        }
-    });
-    eng->s_old.reserve((size_t)n + 1);
+    // OldAcc = |FullTreeGravAccel + GravPM| / G (grav_short_copy, gravshort.h:82-86).  With overlap, and when this epoch's first call
+    // uploaded FullTreeGravAccel and this epoch's gravpm_force left GravPM on the device, it is taken there (k_oldacc / the list kernel:
+    // the same arithmetic); otherwise from P[] on the host.
+    const bool dev_old = eng->host_overlap && eng->host_epoch != 0 && eng->staged_extra_epoch == eng->host_epoch &&
+                         eng->gravpm_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n;
     eng->s_accel.reserve(3 * (size_t)n + 1);
     eng->s_pot.reserve((size_t)n + 1);
-    MPG_HIP(hipMemcpyAsync(eng->s_old.p, old, n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    if(!dev_old) {
+        eng->host_join(); // (GravPM is read from P[])
+        eng->h_d3.reserve((size_t)n + 1);
+        double *old = eng->h_d3.p;
+        const double G = eng->pm.G;
+        parallel_for(n, [=](int64_t lo, int64_t hi) {
+            for(int64_t i = lo; i < hi; i++) {
+                const double *a = (const double *)(b + i * V.stride + V.off_accel);
+                const double *g = (const double *)(b + i * V.stride + V.off_gravpm);
+                double s2 = 0;
+                for(int j = 0; j < 3; j++) {
+                    const double ax = a[j] + g[j];
+                    s2 += ax * ax;
+                }
+                old[i] = sqrt(s2) / G;
+            }
+        });
+        eng->s_old.reserve((size_t)n + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_old.p, old, n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    }
     const int *d_act = nullptr;
     if(ActiveParticle) {
         eng->s_active.reserve((size_t)NumActiveParticle + 1);
@@ -1546,11 +1673,20 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     const bool full = eng->full_particle_tree;
     const bool wantpot = full && P->off_potential >= 0;
     MPG_HIP(hipMemsetAsync(eng->s_accel.p, 0, 3 * n * sizeof(double), eng->stream));
-    int rc = mpg_dev_grav_short_tree(eng, eng->s_old.p, nullptr, nullptr, d_act, NumActiveParticle, eng->s_accel.p,
-                                     wantpot ? eng->s_pot.p : nullptr, rho0);
+    if(eng->copy_stream && eng->gravpm_epoch == eng->host_epoch && eng->gchunk_ev[HOST_CHUNKS - 1])
+        // (the PM step's Potential is still being copied down from s_pot, which this walk overwrites with the tree's)
+        MPG_HIP(hipStreamWaitEvent(eng->stream, eng->gchunk_ev[HOST_CHUNKS - 1], 0));
+    int rc = dev_old ? mpg_dev_grav_short_tree(eng, nullptr, eng->s_prevacc.p, eng->s_gravpm.p, d_act, NumActiveParticle, eng->s_accel.p,
+                                               wantpot ? eng->s_pot.p : nullptr, rho0)
+                     : mpg_dev_grav_short_tree(eng, eng->s_old.p, nullptr, nullptr, d_act, NumActiveParticle, eng->s_accel.p,
+                                               wantpot ? eng->s_pot.p : nullptr, rho0);
     if(rc)
         throw Error(g_err);
+    // (the PM step's GravPM / Potential must be in P[] before this call's Potential - the tree's, gravshort.h:94-95 - goes over it)
+    eng->host_join();
+    MPG_CHECK(eng->unpack_error.empty(), "host path: the write-back of GravPM failed: " + eng->unpack_error);
     eng->h_d2.reserve(3 * (size_t)n + 1);
+    eng->h_d3.reserve((size_t)n + 1);
     double *ha = eng->h_d2.p, *hp = eng->h_d3.p; // (OldAcc has been uploaded: its staging buffer is free again)
     char *wb = (char *)P->base;
     // (garbage / swallowed particles are no walk targets, treewalk.c:234: their fields stay as they are.  eng->h_b holds the live flags

@@ -161,6 +161,24 @@ struct mpg_engine {
     DevBuf<uint8_t> r_flags;
     double staged_box = 0;
     hipEvent_t chunk_ev[8] = {};
+    // Host path with overlap (mpg_set_host_overlap): within one particle-table epoch Pos / Mass / Type, Potential AND the
+    // previous FullTreeGravAccel go up in ONE pass over the records (the walk then takes OldAcc on the device from the uploaded
+    // acceleration and the device's GravPM: no second host pass), and the results of gravpm_force travel down and into P[] on a copy
+    // stream and a host thread while the tree build and the walk run.  host_join() waits for that thread.
+    bool host_overlap = false;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_pm_done = nullptr, gchunk_ev[8] = {};
+    std::thread unpack_thread;
+    std::string unpack_error;
+    HostBuf<double> h_acc, h_gpm, h_gpot;
+    DevBuf<double> s_prevacc;
+    int64_t staged_extra_epoch = -1; // the epoch whose Potential / FullTreeGravAccel are staged (s_pot, s_prevacc)
+    int64_t gravpm_epoch = -1;       // the epoch whose GravPM sits in s_gravpm
+    void host_join()
+    {
+        if(unpack_thread.joinable())
+            unpack_thread.join();
+    }
 };
 
 extern "C" void engine_tree_build_on(mpg_engine *eng, int mask, hipStream_t st); // engine.hip

@@ -359,6 +359,14 @@ class Engine:
     # calls gravpm_force / force_tree_* / grav_short_tree on it move no particle data
     FIELD_POS, FIELD_VEL, FIELD_ACCEL, FIELD_GRAVPM, FIELD_POTENTIAL = 1, 2, 4, 8, 16
 
+    def set_host_overlap(self, on=True):
+        """host path: one packing pass per epoch, OldAcc on the device, gravpm_force's results written back while the walk runs
+        (mpg_set_host_overlap; results complete when grav_short_tree or host_results_sync returns)"""
+        self._ck(self.lib.mpg_set_host_overlap(self.h, int(bool(on))))
+
+    def host_results_sync(self):
+        self._ck(self.lib.mpg_host_results_sync(self.h))
+
     def resident_begin(self, P, BoxSize):
         v = self._view(P)
         self._ck(self.lib.mpg_resident_begin(self.h, C.byref(v), C.c_double(BoxSize)))

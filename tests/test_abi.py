@@ -169,3 +169,24 @@ def test_stale_library_is_refused(monkeypatch):
     monkeypatch.setattr(pkg.build, "source_stamp", lambda: "0" * 32)
     with pytest.raises(E.EngineError, match="stale"):
         E.load_library()
+
+
+def test_link_reference_script_check_mode(tmp_path):
+    """tools/link_reference.sh builds a real MP-Gadget with the shim in the link where GSL + PFFT exist - which is not here, so it has never
+    run to completion.  Its --check mode goes as far as this image allows: a scratch copy of the reference's libgadget/, the shim copied
+    in, the Makefile and source hooks applied, and every shim file, every patched reference file and every renamed object parsed with
+    gcc -fsyntax-only against the reference's real headers (typedef stand-ins for <pfft.h> / <gsl/gsl_interp.h> in a temporary directory,
+    as test_shim_parses_against_the_reference_headers uses; files that include further GSL headers are reported and skipped).  Nothing is
+    compiled to an object, linked, run or kept."""
+    import shutil
+    import subprocess
+    if not os.path.isdir("/root/reference/libgadget") or not os.path.exists("/opt/conda/include/mpi.h") or not shutil.which("gcc"):
+        pytest.skip("needs the reference checkout, an mpi.h and gcc")
+    r = subprocess.run([os.path.join(ROOT, "tools", "link_reference.sh"), "/root/reference", str(tmp_path / "work"), "--check"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "check passed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    # the hooks INTEGRATION.md tells a maintainer to add are the ones the script writes
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for word in ("mpg_shim_particles_changed", "domain_decompose_full", "domain_maintain", "domain_exchange", "slots_gc_sorted", "mpg_shim_resident_begin",
+                 "mpg_shim_timeline", "tools/link_reference.sh"):
+        assert word in doc, word

@@ -729,6 +729,46 @@ def test_host_path_particle_epoch(pkg, engine):
     assert same(g3, g2)
 
 
+def test_host_path_overlap_gives_the_synchronous_results(pkg, engine):
+    """mpg_set_host_overlap: one packing pass per epoch (Pos / Mass / Type / Potential / FullTreeGravAccel), OldAcc on the device, and the
+    write-back of gravpm_force's GravPM / Potential on a copy stream + host thread while the tree build and the walk run.  The three calls
+    leave in P[] what the synchronous path leaves (GravPM, FullTreeGravAccel, the TREE's Potential - the PM step's write-back must land
+    before it), over three steps with changing positions, with garbage in the table, and with mpg_host_results_sync between the calls."""
+    n, nmesh = 20, 40
+    pos, mass, box = pkg.ics.s_clust(n, seed=3)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    N = len(pos)
+    rng = np.random.RandomState(2)
+    dead = rng.random_sample(N) < 0.02
+    res = {}
+    for mode in ("sync", "overlap", "overlap+sync_call"):
+        P = pkg.make_particles(pos, mass)
+        P["Flags"][dead] = 1
+        P["Potential"] = 0.125                                  # (gravpm_force accumulates onto it; the walk then assigns the tree's)
+        engine.set_host_overlap(mode != "sync")
+        out = []
+        for step in range(3):
+            engine.set_particle_epoch(100 * (1 + len(res)) + step + 1)
+            engine.gravpm_force(P)
+            if mode == "overlap+sync_call":
+                engine.host_results_sync()
+                assert np.abs(P["GravPM"][~dead]).max() > 0      # (in P[] now, as a host module reading it between the calls needs it)
+            engine.force_tree_full(P, box)
+            engine.grav_short_tree(P)
+            out.append((P["GravPM"].copy(), P["FullTreeGravAccel"].copy(), P["Potential"].copy()))
+            P["Pos"][:, 1] = np.mod(P["Pos"][:, 1] + 0.21 * box / n, box)
+            P["Pos"][P["Pos"] <= 0] += box
+        res[mode] = out
+        engine.set_particle_epoch(0)
+    engine.set_host_overlap(False)
+    for mode in ("overlap", "overlap+sync_call"):
+        for (g0, a0, p0), (g1, a1, p1) in zip(res["sync"], res[mode]):
+            assert np.abs(g1 - g0).max() <= 1e-10 * np.abs(g0).max() and np.abs(a1 - a0).max() <= 1e-9 * np.abs(a0).max(), mode
+            assert np.abs(p1 - p0).max() <= 1e-9 * np.abs(p0).max(), mode
+            assert np.all(g1[dead] == 0) and np.all(a1[dead] == 0) and np.all(p1[dead] == 0.125)         # garbage: GravPM zeroed, nothing else touched
+    assert np.abs(res["sync"][0][2][~dead] - 0.125).min() > 0 and np.abs(res["sync"][1][0] - res["sync"][0][0]).max() > 0
+
+
 def test_pm_power_spectrum(pkg, engine, tmp_path):
     """The matter power spectrum measured during gravpm_force (gravpm.c:331-382, powerspectrum.c:55-122) against the numpy
     restatement: mode counts equal, k and P(k) to rounding; the saved file has the reference's columns."""

@@ -355,7 +355,7 @@ def test_three_resident_gas_steps_track_the_oracle(pkg, orc):
         assert np.abs(g - o).max() <= 1e-8 * np.abs(o).max(), (k, np.abs(g - o).max() / np.abs(o).max())
     assert np.abs(a["hydroacc_out"][gas] - A.hydroacc_out[gas]).max() <= 1e-8 * np.abs(A.hydroacc_out[gas]).max()
     moved = np.abs(np.mod(A.pos - s["pos"] + box / 2, box) - box / 2).max()
-    assert moved > 0.05 * sp and np.abs(A.entropy[gas] / s["ent"][gas] - 1).max() > 1e-4        # the run did move particles and entropies
+    assert moved > 0.05 * sp and np.abs(A.entropy[gas] / s["ent"][gas] - 1).max() > 1e-6        # the run did move particles and entropies
 
 
 def make_times_like(pkg, atime=1.0, hubble=0.1, **kw):
