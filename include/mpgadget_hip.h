@@ -115,7 +115,9 @@ int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch);
  * reading P[] again; (b) mpg_gravpm_force RETURNS once its results are on their way: GravPM and Potential are copied down and written into
  * P[] by a host thread while force_tree_full and grav_short_tree run, and are complete when the next call on the table that needs them
  * returns (mpg_grav_short_tree at the latest) or when mpg_host_results_sync returns.  A caller whose host code reads P[].GravPM /
- * P[].Potential between gravpm_force and grav_short_tree (energy_statistics, run.c:527) calls mpg_host_results_sync first. */
+ * P[].Potential between gravpm_force and grav_short_tree (energy_statistics, run.c:527) calls mpg_host_results_sync first.  (c) A walk of all
+ * particles on a tree of all particles runs in slices of the tree order (4 from 2^20 particles on; `on` = 2 .. 8 forces that many at any
+ * size), the results of a slice travelling down and into P[] while the next is walked; results bit-identical to the unsliced walk. */
 int mpg_set_host_overlap(mpg_engine *eng, int on);
 int mpg_host_results_sync(mpg_engine *eng);
 /* gravpm_force, libgadget/gravpm.c:61-119: zero GravPM, CIC deposit, r2c, Green's function, 4 x (transfer, c2r,

@@ -6,6 +6,9 @@
 // return codes here; the in-tree shim maps failures to endrun()).  There is no CPU fallback anywhere:
 // without a HIP device mpg_engine_create fails.
 #include "engine_internal.h"
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 
 static thread_local std::string g_err;
 std::string &mpg_err_slot() { return g_err; }
@@ -56,6 +59,11 @@ void mpg_engine_destroy(mpg_engine *eng)
             (void)hipEventDestroy(e);
     if(eng->ev_pm_done)
         (void)hipEventDestroy(eng->ev_pm_done);
+    if(eng->ev_acc_up)
+        (void)hipEventDestroy(eng->ev_acc_up);
+    for(auto &e : eng->slice_ev)
+        if(e)
+            (void)hipEventDestroy(e);
     if(eng->copy_stream) {
         (void)hipStreamSynchronize(eng->copy_stream);
         (void)hipStreamDestroy(eng->copy_stream);
@@ -1271,6 +1279,30 @@ int mpg_dev_hierarchical_gravity_accelerations(mpg_engine *eng, const mpg_hiergr
 // The host <-> device staging of the AoS path is cut into chunks so that packing / unpacking on the host threads overlaps the
 // PCIe transfers of the neighbouring chunks (pinned buffers: the copies are asynchronous).
 constexpr int HOST_CHUNKS = 8;
+// MPG_HOST_TIMING=1: wall-clock marks of the host forms' phases on stderr (a diagnostic)
+struct HostClock {
+    bool on;
+    const char *name;
+    double t0;
+    std::string line;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    explicit HostClock(const char *n) : on(getenv("MPG_HOST_TIMING") != nullptr), name(n), t0(now()) {}
+    void mark(const char *what)
+    {
+        if(!on)
+            return;
+        const double t = now();
+        char buf[96];
+        snprintf(buf, sizeof(buf), " %s %.2f", what, t - t0);
+        line += buf;
+        t0 = t;
+    }
+    ~HostClock()
+    {
+        if(on)
+            fprintf(stderr, "HOST_TIMING %s:%s\n", name, line.c_str());
+    }
+};
 static inline void chunk_range(int64_t n, int c, int64_t &lo, int64_t &hi)
 {
     lo = n * c / HOST_CHUNKS;
@@ -1382,8 +1414,6 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
         if(hpot)
             MPG_HIP(hipMemcpyAsync(eng->s_pot.p + lo, hpot + lo, (hi - lo) * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     }
-    if(hacc) // (needed by the walk only: behind the positions on the stream, beside the PM step on the bus)
-        MPG_HIP(hipMemcpyAsync(eng->s_prevacc.p, hacc, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, eng->stream));
     eng->staged_extra_epoch = extras ? eng->host_epoch : -1;
     eng->gravpm_epoch = -1;
     // garbage and swallowed particles are not deposited and receive no mesh force either (gravpm.c:176-179: region -2): the PM takes a
@@ -1403,6 +1433,16 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
         eng->pm_live = eng->s_live.p;
     }
     MPG_HIP(hipStreamSynchronize(eng->stream));
+    if(hacc) { // (needed by the walk only: on the copy stream it travels while the PM step computes; its staging buffer is its own)
+        if(!eng->copy_stream) {
+            MPG_HIP(hipStreamCreateWithFlags(&eng->copy_stream, hipStreamNonBlocking));
+            MPG_HIP(hipEventCreateWithFlags(&eng->ev_pm_done, hipEventDisableTiming));
+        }
+        if(!eng->ev_acc_up)
+            MPG_HIP(hipEventCreateWithFlags(&eng->ev_acc_up, hipEventDisableTiming));
+        MPG_HIP(hipMemcpyAsync(eng->s_prevacc.p, hacc, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, eng->copy_stream));
+        MPG_HIP(hipEventRecord(eng->ev_acc_up, eng->copy_stream));
+    }
     eng->n = n;
     eng->d_pos = eng->s_pos.p;
     eng->d_mass = eng->s_mass.p;
@@ -1428,6 +1468,7 @@ int mpg_set_host_overlap(mpg_engine *eng, int on)
     MPG_CHECK(eng, "null engine");
     eng->host_join();
     eng->host_overlap = on != 0;
+    eng->host_slices = on > 1 ? on : 0; // (2 .. 8: that many slices of the walk whatever the size - the tests' way to the sliced path)
     API_END
 }
 
@@ -1447,9 +1488,11 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
     MPG_HIP(hipSetDevice(eng->device));
     MPG_CHECK(eng->pm.nmesh > 0, "gravpm_force called before gravpm_init_periodic");
     MPG_CHECK(P->off_gravpm >= 0, "particle view needs GravPM");
+    HostClock hc("gravpm_force");
     eng->host_join(); // (the write-back of an earlier call)
     MPG_CHECK(eng->unpack_error.empty(), "host path: the write-back of GravPM failed: " + eng->unpack_error);
     stage_particles(eng, P, eng->pm.box);
+    hc.mark("stage");
     const int64_t n = P->n;
     if(eng->resident && eng->res_base == P->base) { // results stay in HBM: GravPM assigned, Potential accumulated (gravpm.c:499-501)
         if(eng->pm_live) // (gravpm.c:88-92 zeroes GravPM of every particle; the readout reaches the live ones)
@@ -1535,6 +1578,7 @@ int mpg_gravpm_force(mpg_engine *eng, const mpg_particle_view *P)
                     });
             }
         });
+        hc.mark("queued");
         mpg_err_slot().clear();
         return 0;
     }
@@ -1586,6 +1630,21 @@ int mpg_force_tree_free(mpg_engine *eng)
     eng->full_particle_tree = false;
     eng->tree.has_moments = false;
     API_END
+}
+
+// the results of the targets [lo, hi) of the tree order, compacted in that order for a contiguous copy to the host
+__global__ void __launch_bounds__(256) k_gather_results(int64_t lo, int64_t hi, const int *__restrict__ order, const double *__restrict__ acc,
+                                                        const double *__restrict__ pot, double *__restrict__ acc_t, double *__restrict__ pot_t)
+{
+    const int64_t j = lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if(j >= hi)
+        return;
+    const int64_t i = order[j];
+    acc_t[3 * j + 0] = acc[3 * i + 0];
+    acc_t[3 * j + 1] = acc[3 * i + 1];
+    acc_t[3 * j + 2] = acc[3 * i + 2];
+    if(pot_t)
+        pot_t[j] = pot[i];
 }
 
 int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
@@ -1640,6 +1699,7 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     // OldAcc = |FullTreeGravAccel + GravPM| / G (grav_short_copy, gravshort.h:82-86).  With overlap, and when this epoch's first call
     // uploaded FullTreeGravAccel and this epoch's gravpm_force left GravPM on the device, it is taken there (k_oldacc / the list kernel:
     // the same arithmetic); otherwise from P[] on the host.
+    HostClock hc("grav_short_tree");
     const bool dev_old = eng->host_overlap && eng->host_epoch != 0 && eng->staged_extra_epoch == eng->host_epoch &&
                          eng->gravpm_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n;
     eng->s_accel.reserve(3 * (size_t)n + 1);
@@ -1673,17 +1733,125 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     const bool full = eng->full_particle_tree;
     const bool wantpot = full && P->off_potential >= 0;
     MPG_HIP(hipMemsetAsync(eng->s_accel.p, 0, 3 * n * sizeof(double), eng->stream));
-    if(eng->copy_stream && eng->gravpm_epoch == eng->host_epoch && eng->gchunk_ev[HOST_CHUNKS - 1])
-        // (the PM step's Potential is still being copied down from s_pot, which this walk overwrites with the tree's)
-        MPG_HIP(hipStreamWaitEvent(eng->stream, eng->gchunk_ev[HOST_CHUNKS - 1], 0));
+    if(dev_old && eng->ev_acc_up) // (FullTreeGravAccel went up on the copy stream)
+        MPG_HIP(hipStreamWaitEvent(eng->stream, eng->ev_acc_up, 0));
+    // ---- with overlap, all particles active, a tree of all of them: the walk in SLICES of the tree order, the results of slice k copied
+    // down (compacted in tree order: one contiguous copy) and written into P[] by a host thread while slice k + 1 is walked.  The slices
+    // are cut at multiples of 8 targets, i.e. between the waves of the list kernel: every target's lists, and with them its sums, are
+    // those of the unsliced walk bit for bit.  What stays on the critical path is the last slice's copy and write-back.
+    static const int nslices_env = getenv("MPG_HOST_WALK_SLICES") ? atoi(getenv("MPG_HOST_WALK_SLICES")) : 4;
+    const int64_t npart = eng->tree.npart;
+    const int nslices = eng->host_slices > 1 ? eng->host_slices : (npart >= (1 << 20) ? nslices_env : 1); // (small walks: not worth the calls)
+    if(eng->host_overlap && dev_old && !ActiveParticle && !AccelStore && full && eng->copy_stream && nslices > 1 && npart >= 8 * nslices) {
+        const int S = nslices < 8 ? nslices : 8;
+        const int *d_order = (const int *)eng->tree.idx_b.p; // tree slot -> particle
+        eng->h_order.reserve((size_t)npart + 1);
+        eng->s_acc_t.reserve(3 * (size_t)npart + 1);
+        eng->h_acc_t.reserve(3 * (size_t)npart + 1);
+        if(wantpot) {
+            eng->s_pot_t.reserve((size_t)npart + 1);
+            eng->h_pot_t.reserve((size_t)npart + 1);
+            eng->s_pot2.reserve((size_t)n + 1);
+        }
+        int *h_order = eng->h_order.p;
+        double *hat = eng->h_acc_t.p, *hpt = wantpot ? eng->h_pot_t.p : nullptr;
+        double *dat = eng->s_acc_t.p, *dpt = wantpot ? eng->s_pot_t.p : nullptr;
+        for(int k = 0; k <= S; k++)
+            if(!eng->slice_ev[k])
+                MPG_HIP(hipEventCreateWithFlags(&eng->slice_ev[k], hipEventDisableTiming));
+        // the tree order for the host thread (the tree is complete: force_tree_full waited for it)
+        MPG_HIP(hipMemcpyAsync(h_order, d_order, (size_t)npart * sizeof(int), hipMemcpyDeviceToHost, eng->copy_stream));
+        int64_t cut[9];
+        for(int k = 0; k <= S; k++)
+            cut[k] = k == S ? npart : ((npart * k / S) & ~(int64_t)7);
+        char *wbs = (char *)P->base;
+        std::string therr;
+        std::thread writer;
+        std::atomic<int> issued{0}; // slices whose copies are queued and whose event is recorded (an event not yet recorded "is complete")
+        std::atomic<bool> abandon{false};
+        for(int k = 0; k < S; k++) {
+            const int64_t lo = cut[k], hi = cut[k + 1];
+            if(hi > lo) {
+                if(mpg_dev_grav_short_tree(eng, nullptr, eng->s_prevacc.p, eng->s_gravpm.p, d_order + lo, hi - lo, eng->s_accel.p,
+                                           wantpot ? eng->s_pot2.p : nullptr, rho0)) {
+                    abandon = true;
+                    if(writer.joinable())
+                        writer.join();
+                    throw Error(g_err);
+                }
+                hipLaunchKernelGGL(k_gather_results, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, eng->stream, lo, hi, d_order, eng->s_accel.p,
+                                   wantpot ? eng->s_pot2.p : nullptr, dat, dpt);
+            }
+            MPG_HIP(hipEventRecord(eng->ev_pm_done, eng->stream)); // (re-used as "slice k gathered")
+            MPG_HIP(hipStreamWaitEvent(eng->copy_stream, eng->ev_pm_done, 0));
+            if(hi > lo) {
+                MPG_HIP(hipMemcpyAsync(hat + 3 * lo, dat + 3 * lo, 3 * (size_t)(hi - lo) * sizeof(double), hipMemcpyDeviceToHost, eng->copy_stream));
+                if(wantpot)
+                    MPG_HIP(hipMemcpyAsync(hpt + lo, dpt + lo, (size_t)(hi - lo) * sizeof(double), hipMemcpyDeviceToHost, eng->copy_stream));
+            }
+            MPG_HIP(hipEventRecord(eng->slice_ev[k], eng->copy_stream));
+            issued = k + 1;
+            if(k == 0) {
+                // (the PM step's GravPM / Potential must be in P[] before the tree's Potential goes over it)
+                eng->host_join();
+                MPG_CHECK(eng->unpack_error.empty(), "host path: the write-back of GravPM failed: " + eng->unpack_error);
+                const int device = eng->device;
+                mpg_engine *e = eng;
+                writer = std::thread([=, &therr, &issued, &abandon] {
+                    if(hipSetDevice(device) != hipSuccess) {
+                        therr = "hipSetDevice";
+                        return;
+                    }
+                    for(int q = 0; q < S; q++) {
+                        while(issued.load() <= q) { // (the main thread is inside the walk of slice q)
+                            if(abandon.load())
+                                return;
+                            std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        }
+                        if(hipEventSynchronize(e->slice_ev[q]) != hipSuccess) {
+                            therr = "hipEventSynchronize";
+                            return;
+                        }
+                        const int64_t a = cut[q], b = cut[q + 1];
+                        if(b > a)
+                            parallel_for(b - a, [=](int64_t j0, int64_t j1) {
+                                for(int64_t j = a + j0; j < a + j1; j++) {
+                                    const int64_t i = h_order[j];
+                                    double *acc = (double *)(wbs + i * V.stride + V.off_accel);
+                                    acc[0] = hat[3 * j + 0];
+                                    acc[1] = hat[3 * j + 1];
+                                    acc[2] = hat[3 * j + 2];
+                                    if(hpt)
+                                        *(double *)(wbs + i * V.stride + V.off_potential) = hpt[j];
+                                }
+                            });
+                    }
+                });
+            }
+        }
+        hc.mark("walk (sliced)");
+        writer.join();
+        MPG_CHECK(therr.empty(), "host path: the write-back of the walk's results failed: " + therr);
+        hc.mark("last slice down");
+        mpg_err_slot().clear();
+        return 0;
+    }
+    // (with overlap the PM step's Potential may still be on its way down from s_pot: the tree's goes to a buffer of its own)
+    double *d_treepot = eng->s_pot.p;
+    if(eng->host_overlap && wantpot) {
+        eng->s_pot2.reserve((size_t)n + 1);
+        d_treepot = eng->s_pot2.p;
+    }
     int rc = dev_old ? mpg_dev_grav_short_tree(eng, nullptr, eng->s_prevacc.p, eng->s_gravpm.p, d_act, NumActiveParticle, eng->s_accel.p,
-                                               wantpot ? eng->s_pot.p : nullptr, rho0)
+                                               wantpot ? d_treepot : nullptr, rho0)
                      : mpg_dev_grav_short_tree(eng, eng->s_old.p, nullptr, nullptr, d_act, NumActiveParticle, eng->s_accel.p,
-                                               wantpot ? eng->s_pot.p : nullptr, rho0);
+                                               wantpot ? d_treepot : nullptr, rho0);
     if(rc)
         throw Error(g_err);
+    hc.mark("walk");
     // (the PM step's GravPM / Potential must be in P[] before this call's Potential - the tree's, gravshort.h:94-95 - goes over it)
     eng->host_join();
+    hc.mark("join");
     MPG_CHECK(eng->unpack_error.empty(), "host path: the write-back of GravPM failed: " + eng->unpack_error);
     eng->h_d2.reserve(3 * (size_t)n + 1);
     eng->h_d3.reserve((size_t)n + 1);
@@ -1709,7 +1877,7 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                 *(double *)(wb + i * V.stride + V.off_potential) = hp[i];
         }
     };
-    const double *da = eng->s_accel.p, *dpot = eng->s_pot.p;
+    const double *da = eng->s_accel.p, *dpot = d_treepot;
     hipStream_t st = eng->stream;
     if(!ActiveParticle) // all particles: unpack chunk by chunk while the later chunks are still on the bus
         download_chunks(
@@ -1733,6 +1901,7 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                 put(ActiveParticle[k]);
         });
     }
+    hc.mark("download+unpack");
     API_END
 }
 

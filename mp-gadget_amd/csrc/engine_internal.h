@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -51,6 +54,84 @@ template <typename T> struct HostBuf {
 
 // f(lo, hi) over [0, n) on up to 32 host threads: packing 160-byte records into arrays (and back) is memory-bound and one
 // thread moves ~2 GB/s of them; the reference's callers have the cores of the rank idle while the GPU works anyway.
+// The threads are persistent (round 5): a pass over the table is cut into 8 chunks that overlap the PCIe transfers, i.e. 8 calls, and
+// creating 32 threads per call cost 0.3 - 0.5 ms of each (three passes per step on the critical path of the host forms).  A second
+// caller that finds the pool busy (the write-back thread of mpg_gravpm_force beside the main thread) starts its own threads as before.
+class HostPool {
+    std::vector<std::thread> th;
+    std::mutex m, busy;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int64_t, int64_t)> *job = nullptr;
+    int64_t n = 0, chunk = 0;
+    unsigned gen = 0, pending = 0;
+    bool stop = false;
+    void worker(unsigned t)
+    {
+        unsigned seen = 0;
+        for(;;) {
+            const std::function<void(int64_t, int64_t)> *f;
+            int64_t lo, hi;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || gen != seen; });
+                if(stop)
+                    return;
+                seen = gen;
+                f = job;
+                lo = (int64_t)t * chunk;
+                hi = lo + chunk < n ? lo + chunk : n;
+            }
+            if(lo < hi)
+                (*f)(lo, hi);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if(--pending == 0)
+                    cv_done.notify_all();
+            }
+        }
+    }
+
+  public:
+    explicit HostPool(unsigned T)
+    {
+        for(unsigned t = 0; t < T; t++)
+            th.emplace_back([this, t] { worker(t); });
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for(auto &x : th)
+            x.join();
+    }
+    unsigned size() const { return (unsigned)th.size(); }
+    // false: the pool is in use by another caller
+    bool run(int64_t count, const std::function<void(int64_t, int64_t)> &f)
+    {
+        std::unique_lock<std::mutex> one(busy, std::try_to_lock);
+        if(!one.owns_lock())
+            return false;
+        std::unique_lock<std::mutex> lk(m);
+        job = &f;
+        n = count;
+        chunk = (count + size() - 1) / size();
+        pending = size();
+        gen++;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+        return true;
+    }
+};
+
+inline HostPool &host_pool(unsigned T)
+{
+    static HostPool pool(T); // ONE pool per process (not one per instantiation of parallel_for); lives until the process ends
+    return pool;
+}
+
 template <class F> inline void parallel_for(int64_t n, F f)
 {
     static const unsigned cap = getenv("MPG_HOST_THREADS") ? (unsigned)atoi(getenv("MPG_HOST_THREADS")) : 32u;
@@ -60,6 +141,12 @@ template <class F> inline void parallel_for(int64_t n, F f)
     if(T < 2 || n < 131072) {
         f((int64_t)0, n);
         return;
+    }
+    static const bool use_pool = getenv("MPG_HOST_NO_POOL") == nullptr;
+    if(use_pool) {
+        const std::function<void(int64_t, int64_t)> fn = [&f](int64_t lo, int64_t hi) { f(lo, hi); };
+        if(host_pool(T).run(n, fn))
+            return;
     }
     const int64_t chunk = (n + T - 1) / T;
     std::vector<std::thread> th;
@@ -166,12 +253,16 @@ struct mpg_engine {
     // acceleration and the device's GravPM: no second host pass), and the results of gravpm_force travel down and into P[] on a copy
     // stream and a host thread while the tree build and the walk run.  host_join() waits for that thread.
     bool host_overlap = false;
+    int host_slices = 0;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_pm_done = nullptr, gchunk_ev[8] = {};
+    hipEvent_t ev_pm_done = nullptr, ev_acc_up = nullptr, gchunk_ev[8] = {};
     std::thread unpack_thread;
     std::string unpack_error;
     HostBuf<double> h_acc, h_gpm, h_gpot;
-    DevBuf<double> s_prevacc;
+    DevBuf<double> s_prevacc, s_pot2, s_acc_t, s_pot_t; // ... the walk's results compacted in tree order, slice by slice
+    HostBuf<double> h_acc_t, h_pot_t;
+    HostBuf<int> h_order;
+    hipEvent_t slice_ev[9] = {};
     int64_t staged_extra_epoch = -1; // the epoch whose Potential / FullTreeGravAccel are staged (s_pot, s_prevacc)
     int64_t gravpm_epoch = -1;       // the epoch whose GravPM sits in s_gravpm
     void host_join()

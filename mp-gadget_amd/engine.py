@@ -362,7 +362,7 @@ class Engine:
     def set_host_overlap(self, on=True):
         """host path: one packing pass per epoch, OldAcc on the device, gravpm_force's results written back while the walk runs
         (mpg_set_host_overlap; results complete when grav_short_tree or host_results_sync returns)"""
-        self._ck(self.lib.mpg_set_host_overlap(self.h, int(bool(on))))
+        self._ck(self.lib.mpg_set_host_overlap(self.h, int(on)))      # (2 .. 8: that many walk slices whatever the size)
 
     def host_results_sync(self):
         self._ck(self.lib.mpg_host_results_sync(self.h))

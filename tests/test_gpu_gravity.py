@@ -729,23 +729,26 @@ def test_host_path_particle_epoch(pkg, engine):
     assert same(g3, g2)
 
 
-def test_host_path_overlap_gives_the_synchronous_results(pkg, engine):
+@pytest.mark.parametrize("n", [20, 64])
+def test_host_path_overlap_gives_the_synchronous_results(pkg, engine, n):
     """mpg_set_host_overlap: one packing pass per epoch (Pos / Mass / Type / Potential / FullTreeGravAccel), OldAcc on the device, and the
     write-back of gravpm_force's GravPM / Potential on a copy stream + host thread while the tree build and the walk run.  The three calls
     leave in P[] what the synchronous path leaves (GravPM, FullTreeGravAccel, the TREE's Potential - the PM step's write-back must land
-    before it), over three steps with changing positions, with garbage in the table, and with mpg_host_results_sync between the calls."""
-    n, nmesh = 20, 40
-    pos, mass, box = pkg.ics.s_clust(n, seed=3)
+    before it), over three steps with changing positions, with garbage in the table, with mpg_host_results_sync between the calls, and
+    with the walk cut into slices whose results go down while the next slice is walked."""
+    nmesh = 2 * n                                               # (64^3: slices long enough for the write-back thread to run beside a walk)
+    pos, mass, box = pkg.ics.s_clust(n, seed=3) if n < 32 else pkg.ics.s_zel(n)
     setup_engine(engine, box, n, nmesh, TreeUseBH=0)
     N = len(pos)
     rng = np.random.RandomState(2)
     dead = rng.random_sample(N) < 0.02
     res = {}
-    for mode in ("sync", "overlap", "overlap+sync_call"):
+    for mode in ("sync", "overlap", "overlap+sync_call", "overlap_sliced"):
         P = pkg.make_particles(pos, mass)
         P["Flags"][dead] = 1
         P["Potential"] = 0.125                                  # (gravpm_force accumulates onto it; the walk then assigns the tree's)
-        engine.set_host_overlap(mode != "sync")
+        # (3: the walk in three slices of the tree order, each written back while the next is walked - the path a 256^3 table takes)
+        engine.set_host_overlap(0 if mode == "sync" else (3 if mode == "overlap_sliced" else 1))
         out = []
         for step in range(3):
             engine.set_particle_epoch(100 * (1 + len(res)) + step + 1)
@@ -761,7 +764,7 @@ def test_host_path_overlap_gives_the_synchronous_results(pkg, engine):
         res[mode] = out
         engine.set_particle_epoch(0)
     engine.set_host_overlap(False)
-    for mode in ("overlap", "overlap+sync_call"):
+    for mode in ("overlap", "overlap+sync_call", "overlap_sliced"):
         for (g0, a0, p0), (g1, a1, p1) in zip(res["sync"], res[mode]):
             assert np.abs(g1 - g0).max() <= 1e-10 * np.abs(g0).max() and np.abs(a1 - a0).max() <= 1e-9 * np.abs(a0).max(), mode
             assert np.abs(p1 - p0).max() <= 1e-9 * np.abs(p0).max(), mode
