@@ -81,7 +81,7 @@ def build(force=False, verbose=False):
         so = os.path.join(OBJ, "build_stamp.o")
         subprocess.check_call(["gcc", "-O1", "-fPIC", "-c", sc, "-o", so])
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [so] + \
-              ["-L/opt/rocm/lib", "-lhipfft", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
+              ["-L/opt/rocm/lib", "-lrocfft", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

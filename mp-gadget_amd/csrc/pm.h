@@ -2,17 +2,31 @@
 #pragma once
 #include "mpg_common.h"
 #include "tree_build.h"
-#include <hipfft/hipfft.h>
+#include <rocfft/rocfft.h>
 #include <vector>
 
 namespace mpg {
+
+// One rocFFT plan with its execution info and work buffer (the plans of the PM solver: rocFFT's own API - rocfft_plan_create with a
+// plan description where the layout is not the default, rocfft_execute on the engine's stream - not the hipFFT front end of rounds 1-4).
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    DevBuf<char> work;
+    // lengths: fastest dimension first (rocFFT's order); strides / distances in elements, 0 = contiguous default
+    void create(rocfft_result_placement placement, rocfft_transform_type type, int dims, const size_t *lengths, size_t batch,
+                const size_t *in_strides = nullptr, size_t in_dist = 0, const size_t *out_strides = nullptr, size_t out_dist = 0);
+    void exec(void *in, void *out, hipStream_t st);
+    void destroy();
+    bool ready() const { return plan != nullptr; }
+};
 
 struct PMesh {
     double box = 0, Asmth = 0, G = 0, cellsize = 0;
     int nmesh = 0;
     bool have_plans = false;
     bool kspace_force = false; // true: forces by four inverse transforms as the reference does; false: by differencing the potential (pm.hip)
-    hipfftHandle plan_r2c{}, plan_c2r{};
+    FftPlan plan_r2c, plan_c2r;
     DevBuf<double> real;    // Nmesh^3
     DevBuf<double> rho_k;   // 2 * Nmesh^2 (Nmesh/2+1): potential in Fourier space after the transfer
     DevBuf<double> work_k;  // same size: per-component work array (Z2D overwrites its input)
@@ -50,7 +64,7 @@ struct PMesh {
     struct Slab {
         int rank = 0, world = 1, P = 0, Py = 0;
         bool ready = false;
-        hipfftHandle p2d_r2c{}, p2d_c2r{}, p1d_fwd{};
+        FftPlan p2d_r2c, p2d_c2r, p1d_fwd, p1d_inv;
         DevBuf<double> phi;      // the potential: planes -2 .. P+2 of Nmesh^2 each (2 + 3 ghost planes around the slab)
         DevBuf<double> force;    // one force component on planes 0 .. P (and the density slab before the forward transform)
         DevBuf<double> C;        // 2 * P * Nmesh * (Nmesh/2+1): the slab after / before the 2-D transforms

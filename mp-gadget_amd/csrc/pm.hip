@@ -18,9 +18,9 @@ namespace mpg {
 
 #define MPG_FFT(expr)                                                                                          \
     do {                                                                                                       \
-        hipfftResult _r = (expr);                                                                              \
-        if(_r != HIPFFT_SUCCESS)                                                                               \
-            ::mpg::fail(__FILE__, __LINE__, std::string("hipFFT error ") + std::to_string((int)_r) + " in " #expr); \
+        rocfft_status _r = (expr);                                                                             \
+        if(_r != rocfft_status_success)                                                                        \
+            ::mpg::fail(__FILE__, __LINE__, std::string("rocFFT error ") + std::to_string((int)_r) + " in " #expr); \
     } while(0)
 
 __device__ __forceinline__ int wrap(int i, int n)
@@ -520,6 +520,52 @@ void PMesh::init(double BoxSize, double Asmth_, int Nmesh_, double G_, hipStream
     MPG_HIP(hipStreamSynchronize(st));
 }
 
+// ---- rocFFT plans (petapm.c:284-357 builds its PFFT plans here) ------------------------------------------------------------------
+void FftPlan::create(rocfft_result_placement placement, rocfft_transform_type type, int dims, const size_t *lengths, size_t batch,
+                     const size_t *in_strides, size_t in_dist, const size_t *out_strides, size_t out_dist)
+{
+    static const bool once = (rocfft_setup(), true);
+    (void)once;
+    destroy();
+    rocfft_plan_description desc = nullptr;
+    if(in_strides || out_strides) {
+        MPG_FFT(rocfft_plan_description_create(&desc));
+        const bool real_fwd = type == rocfft_transform_type_real_forward, real_inv = type == rocfft_transform_type_real_inverse;
+        const rocfft_array_type in_t = real_fwd ? rocfft_array_type_real : (real_inv ? rocfft_array_type_hermitian_interleaved : rocfft_array_type_complex_interleaved);
+        const rocfft_array_type out_t = real_fwd ? rocfft_array_type_hermitian_interleaved : (real_inv ? rocfft_array_type_real : rocfft_array_type_complex_interleaved);
+        MPG_FFT(rocfft_plan_description_set_data_layout(desc, in_t, out_t, nullptr, nullptr, in_strides ? (size_t)dims : 0, in_strides, in_dist,
+                                                        out_strides ? (size_t)dims : 0, out_strides, out_dist));
+    }
+    MPG_FFT(rocfft_plan_create(&plan, placement, type, rocfft_precision_double, (size_t)dims, lengths, batch, desc));
+    if(desc)
+        MPG_FFT(rocfft_plan_description_destroy(desc));
+    MPG_FFT(rocfft_execution_info_create(&info));
+    size_t wb = 0;
+    MPG_FFT(rocfft_plan_get_work_buffer_size(plan, &wb));
+    if(wb > 0) {
+        work.reserve(wb + 64);
+        MPG_FFT(rocfft_execution_info_set_work_buffer(info, work.p, wb));
+    }
+}
+
+void FftPlan::exec(void *in, void *out, hipStream_t st)
+{
+    MPG_FFT(rocfft_execution_info_set_stream(info, st));
+    void *ib[1] = {in}, *ob[1] = {out};
+    MPG_FFT(rocfft_execute(plan, ib, out == in ? nullptr : ob, info));
+}
+
+void FftPlan::destroy()
+{
+    if(info)
+        (void)rocfft_execution_info_destroy(info);
+    if(plan)
+        (void)rocfft_plan_destroy(plan);
+    info = nullptr;
+    plan = nullptr;
+    work.release();
+}
+
 void PMesh::ensure_single()
 {
     if(have_plans)
@@ -529,11 +575,10 @@ void PMesh::ensure_single()
     real.reserve(nreal);
     rho_k.reserve(2 * ncplx);
     work_k.reserve(2 * ncplx);
-    MPG_FFT(hipfftCreate(&plan_r2c));
-    MPG_FFT(hipfftCreate(&plan_c2r));
-    size_t ws1 = 0, ws2 = 0;
-    MPG_FFT(hipfftMakePlan3d(plan_r2c, nmesh, nmesh, nmesh, HIPFFT_D2Z, &ws1));
-    MPG_FFT(hipfftMakePlan3d(plan_c2r, nmesh, nmesh, nmesh, HIPFFT_Z2D, &ws2));
+    // x slowest, z fastest: rocFFT takes the lengths fastest first; contiguous real mesh <-> Nmesh^2 (Nmesh/2 + 1) Hermitian half
+    const size_t len3[3] = {(size_t)nmesh, (size_t)nmesh, (size_t)nmesh};
+    plan_r2c.create(rocfft_placement_notinplace, rocfft_transform_type_real_forward, 3, len3, 1);
+    plan_c2r.create(rocfft_placement_notinplace, rocfft_transform_type_real_inverse, 3, len3, 1);
     have_plans = true;
 }
 
@@ -549,8 +594,8 @@ void PMesh::ps_zero(hipStream_t st)
 void PMesh::destroy()
 {
     if(have_plans) {
-        (void)hipfftDestroy(plan_r2c);
-        (void)hipfftDestroy(plan_c2r);
+        plan_r2c.destroy();
+        plan_c2r.destroy();
         have_plans = false;
     }
     slab_destroy();
@@ -635,8 +680,6 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
     ensure_single();
     const size_t nreal = (size_t)nmesh * nmesh * nmesh;
     const size_t ncplx = (size_t)nmesh * nmesh * (nmesh / 2 + 1);
-    MPG_FFT(hipfftSetStream(plan_r2c, st));
-    MPG_FFT(hipfftSetStream(plan_c2r, st));
     float t_fft = 0, t_tr = 0, t_ro = 0, t;
     if(tm)
         tm->start(st);
@@ -646,7 +689,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
         deposit(n, d_pos, d_mass, d_active, real.p, 0, nmesh, dep_single, st, tm);
     if(tm)
         tm->lap(st, &tm->t.pm_deposit);
-    MPG_FFT(hipfftExecD2Z(plan_r2c, real.p, (hipfftDoubleComplex *)rho_k.p));
+    plan_r2c.exec(real.p, rho_k.p, st);
     if(tm) {
         tm->lap(st, &t);
         t_fft += t;
@@ -668,7 +711,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
     // forces by differencing it in real space (k_gradient_axis: the same operator as force_transfer); kspace_force restores
     // the reference's four inverse transforms.
     if(!kspace_force) {
-        MPG_FFT(hipfftExecZ2D(plan_c2r, (hipfftDoubleComplex *)rho_k.p, real.p)); // rho_k is consumed: it is not needed again
+        plan_c2r.exec(rho_k.p, real.p, st); // rho_k is consumed: it is not needed again
         if(tm) {
             tm->lap(st, &t);
             t_fft += t;
@@ -733,7 +776,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
             tm->lap(st, &t);
             t_tr += t;
         }
-        MPG_FFT(hipfftExecZ2D(plan_c2r, (hipfftDoubleComplex *)work_k.p, real.p));
+        plan_c2r.exec(work_k.p, real.p, st);
         if(tm) {
             tm->lap(st, &t);
             t_fft += t;
@@ -921,9 +964,10 @@ __global__ void __launch_bounds__(256) k_transpose(int rows, int cols, const dou
 void PMesh::slab_destroy()
 {
     if(slab.ready) {
-        (void)hipfftDestroy(slab.p2d_r2c);
-        (void)hipfftDestroy(slab.p2d_c2r);
-        (void)hipfftDestroy(slab.p1d_fwd);
+        slab.p2d_r2c.destroy();
+        slab.p2d_c2r.destroy();
+        slab.p1d_fwd.destroy();
+        slab.p1d_inv.destroy();
         slab.ready = false;
     }
     slab.phi.release();
@@ -951,19 +995,18 @@ void PMesh::slab_init(int rank, int world)
     slab.rho_k.reserve(2 * (size_t)nmesh * S);
     // the single-GPU meshes and plans are not needed in this form
     if(have_plans) {
-        (void)hipfftDestroy(plan_r2c);
-        (void)hipfftDestroy(plan_c2r);
+        plan_r2c.destroy();
+        plan_c2r.destroy();
         have_plans = false;
     }
     real.release();
     rho_k.release();
     work_k.release();
-    int n2[2] = {nmesh, nmesh};
-    MPG_FFT(hipfftPlanMany(&slab.p2d_r2c, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, slab.P));
-    MPG_FFT(hipfftPlanMany(&slab.p2d_c2r, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, slab.P));
-    int n1[1] = {nmesh};
-    int emb[1] = {nmesh};
-    MPG_FFT(hipfftPlanMany(&slab.p1d_fwd, 1, n1, emb, 1, nmesh, emb, 1, nmesh, HIPFFT_Z2Z, (int)S)); // contiguous rows of kx
+    const size_t len2[2] = {(size_t)nmesh, (size_t)nmesh}, len1[1] = {(size_t)nmesh};
+    slab.p2d_r2c.create(rocfft_placement_notinplace, rocfft_transform_type_real_forward, 2, len2, (size_t)slab.P); // the slab's planes
+    slab.p2d_c2r.create(rocfft_placement_notinplace, rocfft_transform_type_real_inverse, 2, len2, (size_t)slab.P);
+    slab.p1d_fwd.create(rocfft_placement_inplace, rocfft_transform_type_complex_forward, 1, len1, S); // contiguous rows of kx
+    slab.p1d_inv.create(rocfft_placement_inplace, rocfft_transform_type_complex_inverse, 1, len1, S);
     slab.work.reserve(2 * (size_t)nmesh * S);
     slab.ready = true;
 }
@@ -973,11 +1016,10 @@ void PMesh::slab_forward_a(int64_t n, const double *d_pos, const float *d_mass, 
     MPG_CHECK(slab.ready, "pm_slab: not initialised");
     const int nz = nmesh / 2 + 1;
     const size_t nreal = (size_t)slab.P * nmesh * nmesh;
-    MPG_FFT(hipfftSetStream(slab.p2d_r2c, st));
     MPG_HIP(hipMemsetAsync(slab.force.p, 0, nreal * sizeof(double), st)); // (the force buffer doubles as the density slab)
     if(n > 0)
         deposit(n, d_pos, d_mass, nullptr, slab.force.p, slab.rank * slab.P, slab.P, dep_slab, st, nullptr);
-    MPG_FFT(hipfftExecD2Z(slab.p2d_r2c, slab.force.p, (hipfftDoubleComplex *)slab.C.p));
+    slab.p2d_r2c.exec(slab.force.p, slab.C.p, st);
     hipLaunchKernelGGL(k_slab_pack_a, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, (const double2 *)slab.C.p,
                        (double2 *)sendA);
     MPG_HIP(hipGetLastError());
@@ -990,11 +1032,10 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
     const size_t ncplx = (size_t)nmesh * slab.Py * nz;
     const int y0 = slab.rank * slab.Py;
     const size_t S = (size_t)slab.Py * nz;
-    MPG_FFT(hipfftSetStream(slab.p1d_fwd, st));
     // [x][j] -> [j][x], j = (ky local, kz): the transforms along x run on contiguous rows
     const dim3 tgrid_f((unsigned)((S + 31) / 32), (unsigned)((nmesh + 31) / 32)), tgrid_b((unsigned)((nmesh + 31) / 32), (unsigned)((S + 31) / 32));
     hipLaunchKernelGGL(k_transpose, tgrid_f, dim3(256), 0, st, nmesh, (int)S, (const double2 *)recvA, S, (double2 *)slab.rho_k.p, (size_t)nmesh);
-    MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.rho_k.p, (hipfftDoubleComplex *)slab.rho_k.p, HIPFFT_FORWARD));
+    slab.p1d_fwd.exec(slab.rho_k.p, slab.rho_k.p, st);
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
     if(measure_power) { // this rank's ky rows: the caller sums the raw accumulators over the ranks (powerspectrum_sum's Allreduce)
@@ -1006,7 +1047,7 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
                        (double2 *)slab.rho_k.p);
     // only the potential is transformed back: the forces are its real-space differences (k_gradient_axis), which also cuts
     // the inverse all-to-all to a quarter
-    MPG_FFT(hipfftExecZ2Z(slab.p1d_fwd, (hipfftDoubleComplex *)slab.rho_k.p, (hipfftDoubleComplex *)slab.rho_k.p, HIPFFT_BACKWARD));
+    slab.p1d_inv.exec(slab.rho_k.p, slab.rho_k.p, st);
     // [j][x] -> sendB[x][j]: the block for rank d (its x-planes) is contiguous
     hipLaunchKernelGGL(k_transpose, tgrid_b, dim3(256), 0, st, (int)S, nmesh, (const double2 *)slab.rho_k.p, (size_t)nmesh, (double2 *)sendB, S);
     MPG_HIP(hipGetLastError());
@@ -1017,11 +1058,10 @@ void PMesh::slab_inverse_c(const double *recvB, double *ghost_send, hipStream_t 
     MPG_CHECK(slab.ready, "pm_slab: not initialised");
     const int nz = nmesh / 2 + 1;
     const size_t plane = (size_t)nmesh * nmesh;
-    MPG_FFT(hipfftSetStream(slab.p2d_c2r, st));
     hipLaunchKernelGGL(k_slab_unpack_b, dim3(nblk((size_t)slab.P * nmesh * nz)), dim3(256), 0, st, nmesh, slab.P, slab.Py, (const double2 *)recvB,
                        (double2 *)slab.C.p);
     double *phi0 = slab.phi.p + 2 * plane; // plane 0 of the slab; planes -2, -1 and P .. P+2 are ghosts
-    MPG_FFT(hipfftExecZ2D(slab.p2d_c2r, (hipfftDoubleComplex *)slab.C.p, phi0));
+    slab.p2d_c2r.exec(slab.C.p, phi0, st);
     // ghosts the neighbours need: the first 3 planes go to the previous rank, the last 2 to the next
     MPG_HIP(hipMemcpyAsync(ghost_send, phi0, 3 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
     MPG_HIP(hipMemcpyAsync(ghost_send + 3 * plane, phi0 + (size_t)(slab.P - 2) * plane, 2 * plane * sizeof(double), hipMemcpyDeviceToDevice, st));
