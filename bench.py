@@ -222,6 +222,94 @@ def walk_traffic(pkg, N, ic, variant):
     return e["hbm_bytes_per_launch"], "bytes per walk (%s) from %s; library build %s" % (e["kernel"], e["method"], stamp[:12])
 
 
+def _pmc_child_runs(child_args, kernels):
+    """{counter: {kernel key: {dispatch id: counter value}}} of `python bench.py --traffic-child <child_args>` run under rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no tracing domain: MI355X_MICROARCH.md, HBM / rocprofv3).  kernels: {key: (substring
+    of the kernel name, predicate on the full name or None)}.  Raises RuntimeError with the reason when a pass cannot be had."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="mpg_traffic_", dir="/tmp")
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--output-format", "csv", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-child"] + list(child_args)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-200:].replace("\n", " ")))
+            per = {k: {} for k in kernels}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    kn = row["Kernel_Name"]
+                    for k, (sub, pred) in kernels.items():
+                        if sub in kn and (pred is None or pred(kn)):
+                            d = int(row["Dispatch_Id"])
+                            per[k][d] = per[k].get(d, 0.0) + float(row["Counter_Value"])
+            res[counter] = per
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        raise RuntimeError("live PMC passes failed: %r" % (e,))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+PMC_METHOD = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on two child processes of this command (separate passes); KiB -> bytes, FETCH_SIZE "
+              "x 2 and WRITE_SIZE x 1 as calibrated on this rocprofv3 with known byte counts in the kernels' own access patterns "
+              "(tools/pmc_calib.hip, profiles/r05_calib/calibration.txt)")
+
+
+def live_walk_traffic(args):
+    """HBM bytes per walk measured IN THIS RUN: two child processes of this very command (--traffic-child: the headline workload, set-up +
+    1 warm-up + 2 steps, nothing else) under rocprofv3, and the counters of the walk's two kernels averaged over the last two walks.
+    FETCH_SIZE x 2, WRITE_SIZE x 1: calibrated (0.500 for 16-B, 4-B, grouped 4-B and 32-B gather reads alike; 1.000 / 1.07 for 4-B streaming
+    / run appends).  Returns (bytes, note) or (None, why)."""
+    kernels = {"lists": ("k_walk_lists8<", lambda kn: kn.split("k_walk_lists8<")[1].split(",")[0].strip() != "true"),   # (not the counting build)
+               "eval": ("k_walk_eval<", None)}
+    try:
+        res = _pmc_child_runs(["--ic", args.ic, "--n", str(args.n or 256), "--thresh", str(args.thresh), "--variant", str(args.variant)], kernels)
+    except RuntimeError as e:
+        return None, str(e)
+    if any(len(res[c][k]) < 2 for c in res for k in kernels):
+        return None, "the profiled child ran fewer than two walks"
+    last = lambda m: sum(m[d] for d in sorted(m)[-2:]) / 2.0
+    f = {k: 2.0 * 1024.0 * last(res["FETCH_SIZE"][k]) for k in kernels}
+    w = {k: 1024.0 * last(res["WRITE_SIZE"][k]) for k in kernels}
+    note = ("measured in this run: %s; the last two walks of each pass; per walk: k_walk_lists8 fetched %.2f + wrote %.2f GB, k_walk_eval "
+            "fetched %.2f + wrote %.2f GB" % (PMC_METHOD, f["lists"] / 1e9, w["lists"] / 1e9, f["eval"] / 1e9, w["eval"] / 1e9))
+    return sum(f.values()) + sum(w.values()), note
+
+
+def live_sph_traffic(n, PE):
+    """HBM bytes per full launch of k_density / k_hydro measured in this run (see live_walk_traffic): the mean of the three largest dispatches
+    of each kernel in a child that runs the hydro workload (the Hsml iteration's later passes are smaller launches).
+    Returns {kernel: (bytes, note)} or {kernel: (None, why)}."""
+    kernels = {"k_density": ("k_density(", None), "k_hydro": ("k_hydro(", None)}
+    try:
+        res = _pmc_child_runs(["--workload", "hydro", "--n", str(n), "--sph", "pe" if PE else "de"], kernels)
+    except RuntimeError as e:
+        return {k: (None, str(e)) for k in kernels}
+    out = {}
+    for k in kernels:
+        if not res["FETCH_SIZE"][k] or not res["WRITE_SIZE"][k]:
+            out[k] = (None, "kernel not seen by the profiled child")
+            continue
+        top3 = lambda m: sum(sorted(m.values())[-3:]) / len(sorted(m.values())[-3:])
+        f, w = 2.0 * 1024.0 * top3(res["FETCH_SIZE"][k]), 1024.0 * top3(res["WRITE_SIZE"][k])
+        out[k] = (f + w, "measured in this run: %s; mean of the three largest dispatches (full launches): fetched %.2f + wrote %.2f GB"
+                  % (PMC_METHOD, f / 1e9, w / 1e9))
+    return out
+
+
 def sph_traffic(pkg, n, kernel):
     """HBM bytes per full launch of k_density / k_hydro from the committed PMC passes (tools/prof.sh -> profiles/sph_traffic.json), for
     the library build they were taken with only (see walk_traffic)."""
@@ -351,9 +439,15 @@ def hydro_measure(pkg, torch, args, dev, n=128, steps=3, PE=0):
     b_dens = sd["targets"] * 128 + sd["candidates"] * 28 + sd["interactions"] * 32
     b_hyd = ngas * 176 + sh["candidates"] * 36 + sh["interactions"] * 100
 
+    live = {} if (args.no_live_traffic or args.traffic_child) else live_sph_traffic(n, PE)
+
     def roof(kernel, flops, b, t_ms, note):
         ach = flops / (t_ms * 1e-3) / 1e12
         traffic, tnote = sph_traffic(pkg, n, kernel)
+        if live.get(kernel, (None,))[0] is not None:
+            traffic, tnote = live[kernel]
+        elif kernel in live:
+            tnote += "; live measurement not available: " + live[kernel][1]
         return {"bound": "fp64_valu", "kernel": kernel, "achieved": ach, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TF,
                 "traffic": traffic, "traffic_note": tnote, "flop_per_launch": flops, "algorithmic_bytes_per_launch": b,
                 "algorithmic_bytes_over_hbm_peak": b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": t_ms, "note": note}
@@ -709,6 +803,9 @@ def gravity_bench_single(pkg, torch, args, dev, local_rank):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     walk_ms, walk_launches = eng.walk_events_collect()
+    if args.traffic_child:      # (a child of live_walk_traffic under rocprofv3: the walks above are what it wanted)
+        eng.close()
+        return None
     # ---- untimed diagnostic passes: phase times of one more step, interaction counters of another (the counting builds of the
     # walk kernels are slower: kept out of the phase times)
     eng.set_instrumentation(True, False)
@@ -723,6 +820,15 @@ def gravity_bench_single(pkg, torch, args, dev, local_rank):
     eng.walk_events_collect()
     variant = eng.walk_choice()[0]
     traffic, traffic_note = walk_traffic(pkg, N, args.ic, variant)
+    if variant == 6 and not args.no_extras and not args.no_live_traffic:
+        # the HBM traffic of the walk measured in THIS run (two short child processes under rocprofv3 --pmc); the committed summary of
+        # tools/prof.sh is the fall-back
+        t0 = time.perf_counter()
+        live, live_note = live_walk_traffic(args)
+        if live is not None:
+            traffic, traffic_note = live, live_note + " (%.0f s)" % (time.perf_counter() - t0)
+        else:
+            traffic_note += "; live measurement not available: " + live_note
     out = {
         "metric": "particle-updates/sec (gravity force step: PM + tree build + short-range walk)",
         "value": N * args.steps / elapsed, "unit": "particles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -831,6 +937,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1: skip the untimed legs (substeps, host_path, resident_path, other_inputs, hydro)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: take roofline.traffic from profiles/walk_traffic.json instead of two "
+                                                                   "rocprofv3 --pmc child runs of this command")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-parity-check", action="store_true", help="N > 1: skip the untimed self-check of the forces against the one-GPU path")
     ap.add_argument("--cpu-sample", type=int, default=1 << 22, help="targets walked by the CPU baseline")
     ap.add_argument("--thresh", type=int, default=16)
@@ -849,6 +958,8 @@ def main():
                     help="gravity: BASELINE.json configs[1] (default, the headline metric; its line also carries the sub-steps and configs[2]); "
                          "hydro: configs[2] / [4] as their own line; substep: the short-range-only step; integrate / fof / domain: SURVEY 8(f) rows")
     args = ap.parse_args()
+    if args.traffic_child:
+        args.steps, args.warmup, args.no_extras, args.no_cpu_baseline, args.gpus = 2, 1, True, True, 1
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -30,6 +30,10 @@ def test_default_workload_line():
     assert "workload" in j["config"] and "s_zel" in j["config"]["workload"]          # the headline set of SURVEY 8(d)
     r = j["roofline"]
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # roofline.traffic is measured in the run itself (two child processes under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): the walk's lists
+    # alone are 4 B per entry written once and read once
+    assert r["traffic"] and "measured in this run" in r["traffic_note"], r["traffic_note"]
+    assert r["traffic"] > 8 * (r["leaf_entries_per_launch"] + r["node_entries_per_launch"]) and 0 < r["hbm_measured_frac"] < 1
     cb = j["cpu_baseline"]
     assert cb["physical_cores"] >= 1 and len(cb["walk_s_all"]) == 3 and cb["cpu_model"] and cb["processes"] >= 1
     assert cb["cores"] == sum(cb["threads_per_process"]) and cb["pairs_per_s_per_thread"] > 1e6 and cb["tree_build_own_share_s"] >= 0
