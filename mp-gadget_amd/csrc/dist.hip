@@ -106,6 +106,16 @@ __global__ void __launch_bounds__(256) k_local_types(int64_t nl, int64_t n_own, 
         type[i] = (i < n_own && skip[i]) ? 7 : 1;
 }
 
+__global__ void __launch_bounds__(256) k_count_listed(int64_t n, const int *__restrict__ list, const unsigned char *__restrict__ flags,
+                                                       unsigned long long *__restrict__ count)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool hit = k < n && flags[list[k]] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if(m != 0ull && (threadIdx.x & 63) == 0)
+        atomicAdd(count, (unsigned long long)__builtin_popcountll(m));
+}
+
 __global__ void __launch_bounds__(256) k_count_nonzero(int64_t n, const unsigned char *__restrict__ b, unsigned long long *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,6 +665,7 @@ struct mpg_dist {
     int64_t ntarg = 0, n_own_tree = -1;
     // garbage / swallowed particles among the own rows (mpg_dist_dev_set_garbage): flags over n_skip_rows rows, n_skip of them set
     const unsigned char *d_skip = nullptr;
+    DevBuf<unsigned char> skip_own; // (the library's copy of the caller's flags)
     int64_t n_skip = 0, n_skip_rows = -1;
     DevBuf<uint8_t> ltype, o_skip;
     const unsigned char *skip_for(int64_t n) const { return (n_skip > 0 && n == n_skip_rows) ? d_skip : nullptr; }
@@ -1206,7 +1217,12 @@ int mpg_dist_dev_set_garbage(mpg_dist *d, int64_t n_own, const unsigned char *d_
         MPG_HIP(hipMemcpyAsync(&c, d->scount.p, sizeof(c), hipMemcpyDeviceToHost, st));
         sync(d);
         if(c > 0) {
-            d->d_skip = d_garbage;
+            // a COPY of the flags (the caller's pointer was kept "until the next call" and matched to a table by its row
+            // count alone - a caller moving to another table of the same size without calling this again would have had freed or stale
+            // flags applied to it); they stay in force until the next call of this function, as documented
+            d->skip_own.reserve((size_t)n_own + 1);
+            MPG_HIP(hipMemcpyAsync(d->skip_own.p, d_garbage, (size_t)n_own, hipMemcpyDeviceToDevice, st));
+            d->d_skip = d->skip_own.p;
             d->n_skip = (int64_t)c;
             d->n_skip_rows = n_own;
         }
@@ -1369,9 +1385,18 @@ int mpg_dist_dev_grav_short_tree_active(mpg_dist *d, const int *d_active, int64_
             MPG_HIP(hipMemcpyAsync(&bad, d->err.p, sizeof(bad), hipMemcpyDeviceToHost, st));
             sync(d);
             MPG_CHECK(bad == 0, "mpg_dist_dev_grav_short_tree_active: an active index is not an own particle");
-            // (garbage on the active list is skipped in place, treewalk.c:234: it is not in the tree, hence not among the targets)
-            MPG_CHECK((int64_t)c == nactive || (d->n_skip > 0 && (int64_t)c < nactive && (int64_t)c >= nactive - d->n_skip),
-                      "mpg_dist_dev_grav_short_tree_active: the active list holds duplicates");
+            // (garbage on the active list is skipped in place, treewalk.c:234: it is not in the tree, hence not among the targets.  The
+            // garbage entries ON the list are counted, so that a duplicate cannot hide behind them: ADVICE round 4)
+            int64_t ngarb = 0;
+            if(d->skip_for(d->n_own_tree)) {
+                MPG_HIP(hipMemsetAsync(d->scount.p, 0, sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(k_count_listed, dim3(nblk(nactive)), dim3(256), 0, st, nactive, d_active, d->d_skip, d->scount.p);
+                unsigned long long g = 0;
+                MPG_HIP(hipMemcpyAsync(&g, d->scount.p, sizeof(g), hipMemcpyDeviceToHost, st));
+                sync(d);
+                ngarb = (int64_t)g;
+            }
+            MPG_CHECK((int64_t)c + ngarb == nactive, "mpg_dist_dev_grav_short_tree_active: the active list holds duplicates");
             ntarg = (int64_t)c;
         }
         targets = d->act_targets.p;

@@ -53,13 +53,6 @@ struct SphEngine {
     DevBuf<double> hsml_t; // the sources' smoothing lengths in tree order (hydro distance tests)
     DevBuf<unsigned> ctr;
     DevBuf<unsigned long long> stats;
-    // the two-kernel form of the loops (sph.hip): leaf lists per target in HBM, list lengths, the targets whose lists did not fit
-    DevBuf<unsigned> lists;
-    DevBuf<int> lcount, fallback;
-    int dens_cap = 256, hydro_cap = 384;  // list entries per target (doubled when more than 2 % of a pass's targets do not fit)
-    int64_t split_min = getenv("MPG_SPH_SPLIT_MIN") ? atoll(getenv("MPG_SPH_SPLIT_MIN")) : 16384; // queue length from which the loops run as two kernels
-    bool split_off = getenv("MPG_SPH_FUSED") != nullptr; // experiment knob: the fused kernels only
-    int64_t last_fallback = 0;
     bool hmax_pending = false;
     SphView hsml_view{}; // the caller's arrays at the last density(): calc_hmax gathers Hsml from them
     int64_t last_iterations = 0, last_targets = 0, last_interactions = 0, last_candidates = 0;
