@@ -64,7 +64,8 @@ struct PMesh {
     struct Slab {
         int rank = 0, world = 1, P = 0, Py = 0;
         bool ready = false;
-        FftPlan p2d_r2c, p2d_c2r, p1d_fwd, p1d_inv;
+        FftPlan p2d_r2c, p2d_c2r, p1d_fwd, p1d_inv, p1d_fwd_t, p1d_inv_t;
+        bool strided = false;
         DevBuf<double> phi;      // the potential: planes -2 .. P+2 of Nmesh^2 each (2 + 3 ghost planes around the slab)
         DevBuf<double> force;    // one force component on planes 0 .. P (and the density slab before the forward transform)
         DevBuf<double> C;        // 2 * P * Nmesh * (Nmesh/2+1): the slab after / before the 2-D transforms

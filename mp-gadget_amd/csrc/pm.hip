@@ -968,6 +968,8 @@ void PMesh::slab_destroy()
         slab.p2d_c2r.destroy();
         slab.p1d_fwd.destroy();
         slab.p1d_inv.destroy();
+        slab.p1d_fwd_t.destroy();
+        slab.p1d_inv_t.destroy();
         slab.ready = false;
     }
     slab.phi.release();
@@ -1007,6 +1009,15 @@ void PMesh::slab_init(int rank, int world)
     slab.p2d_c2r.create(rocfft_placement_notinplace, rocfft_transform_type_real_inverse, 2, len2, (size_t)slab.P);
     slab.p1d_fwd.create(rocfft_placement_inplace, rocfft_transform_type_complex_forward, 1, len1, S); // contiguous rows of kx
     slab.p1d_inv.create(rocfft_placement_inplace, rocfft_transform_type_complex_inverse, 1, len1, S);
+    // the same transforms straight on the exchange buffers' [x][j] layout (element stride S along x, consecutive j one element apart):
+    // transform and transpose in one rocFFT plan each way, instead of k_transpose + a contiguous transform (MPG_PM_STRIDED_FFT=1; an
+    // experiment of round 5: profiles/r05a_experiments)
+    slab.strided = getenv("MPG_PM_STRIDED_FFT") != nullptr;
+    if(slab.strided) {
+        const size_t sS[1] = {S}, s1[1] = {1};
+        slab.p1d_fwd_t.create(rocfft_placement_notinplace, rocfft_transform_type_complex_forward, 1, len1, S, sS, 1, s1, (size_t)nmesh);
+        slab.p1d_inv_t.create(rocfft_placement_notinplace, rocfft_transform_type_complex_inverse, 1, len1, S, s1, (size_t)nmesh, sS, 1);
+    }
     slab.work.reserve(2 * (size_t)nmesh * S);
     slab.ready = true;
 }
@@ -1034,8 +1045,12 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
     const size_t S = (size_t)slab.Py * nz;
     // [x][j] -> [j][x], j = (ky local, kz): the transforms along x run on contiguous rows
     const dim3 tgrid_f((unsigned)((S + 31) / 32), (unsigned)((nmesh + 31) / 32)), tgrid_b((unsigned)((nmesh + 31) / 32), (unsigned)((S + 31) / 32));
-    hipLaunchKernelGGL(k_transpose, tgrid_f, dim3(256), 0, st, nmesh, (int)S, (const double2 *)recvA, S, (double2 *)slab.rho_k.p, (size_t)nmesh);
-    slab.p1d_fwd.exec(slab.rho_k.p, slab.rho_k.p, st);
+    if(slab.strided)
+        slab.p1d_fwd_t.exec(recvA, slab.rho_k.p, st);
+    else {
+        hipLaunchKernelGGL(k_transpose, tgrid_f, dim3(256), 0, st, nmesh, (int)S, (const double2 *)recvA, S, (double2 *)slab.rho_k.p, (size_t)nmesh);
+        slab.p1d_fwd.exec(slab.rho_k.p, slab.rho_k.p, st);
+    }
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
     if(measure_power) { // this rank's ky rows: the caller sums the raw accumulators over the ranks (powerspectrum_sum's Allreduce)
@@ -1047,9 +1062,13 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
                        (double2 *)slab.rho_k.p);
     // only the potential is transformed back: the forces are its real-space differences (k_gradient_axis), which also cuts
     // the inverse all-to-all to a quarter
-    slab.p1d_inv.exec(slab.rho_k.p, slab.rho_k.p, st);
-    // [j][x] -> sendB[x][j]: the block for rank d (its x-planes) is contiguous
-    hipLaunchKernelGGL(k_transpose, tgrid_b, dim3(256), 0, st, (int)S, nmesh, (const double2 *)slab.rho_k.p, (size_t)nmesh, (double2 *)sendB, S);
+    if(slab.strided)
+        slab.p1d_inv_t.exec(slab.rho_k.p, sendB, st);
+    else {
+        slab.p1d_inv.exec(slab.rho_k.p, slab.rho_k.p, st);
+        // [j][x] -> sendB[x][j]: the block for rank d (its x-planes) is contiguous
+        hipLaunchKernelGGL(k_transpose, tgrid_b, dim3(256), 0, st, (int)S, nmesh, (const double2 *)slab.rho_k.p, (size_t)nmesh, (double2 *)sendB, S);
+    }
     MPG_HIP(hipGetLastError());
 }
 

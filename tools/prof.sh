@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic $*"   # (bench.py would start rocprofv3 children of its own: not under a profiler)
 # (the counter passes run the headline workload alone: the traffic per walk is summed over all walks of the run, and the sub-step /
 # other-input legs of the default line are walks of other sizes)
 PARGS="$ARGS --no-extras"
@@ -19,7 +19,7 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS 
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python $ROOT/bench.py $PARGS > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o pmc -- python $ROOT/bench.py $PARGS > /dev/null 2> $OUT/pmc_write.err
 # 3. the SPH kernels of configs[2] (bench.py --workload hydro): trace + HBM traffic passes
-HARGS="--workload hydro --steps 2 --warmup 1"
+HARGS="--workload hydro --steps 2 --warmup 1 --no-live-traffic"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_hydro -o trace -- python $ROOT/bench.py $HARGS > $OUT/bench_hydro.json 2> $OUT/trace_hydro.err
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_hydro_fetch -o pmc -- python $ROOT/bench.py $HARGS > /dev/null 2> $OUT/pmc_hydro_fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_hydro_write -o pmc -- python $ROOT/bench.py $HARGS > /dev/null 2> $OUT/pmc_hydro_write.err
