@@ -49,7 +49,10 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
         spans = [(w["t1"] - w["t0"]) / 1e6 for w in timed]
         print("== walks (first list kernel start .. last evaluation kernel end):", len(walks), "of which", len(timed), "without counters")
         print("  span ms:", " ".join("%.2f" % x for x in spans), "  kernels per walk:", timed[-1]["n"])
-        print("  steady state (last %d): %.3f ms per walk" % (min(len(spans), 2), sum(spans[-2:]) / len(spans[-2:])))
+        # the headline steps come first in the command's run (set-up walk, warm-up, timed steps); the legs behind them (sub-steps, host
+        # path in slices, other inputs, hydro) are walks of other sizes
+        head = spans[1:1 + int(os.environ.get("MPG_HEADLINE_WALKS", "3"))] or spans[-2:]
+        print("  headline walks (spans 2 .. %d): %.3f ms per walk" % (1 + len(head), sum(head) / len(head)))
 
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
