@@ -116,6 +116,8 @@ struct TreeView {
     // around the PARTICLES it holds instead of its cell, and the largest smoothing length among them
     const NodeGeo *geoS = nullptr;
     const double *hsmaxS = nullptr;
+    // search links of the SPH loops (TreeBuilder::calc_search_links), or null: linkB with the small internal nodes as leaves
+    const NodeLinkB *linkS = nullptr;
     double box = 0;
 };
 

@@ -113,11 +113,16 @@ __device__ __forceinline__ double group_sum(double v)
 // sgeo / shm: the geometry the cull tests and, for SYM, the radius per node - the nodes' cells and `hmax` as in the reference (tv.geoB,
 // tv.hmaxB: FOF, the pair-wise gravity check), or the cubes around the nodes' particles and their largest Hsml (tv.geoS, tv.hsmaxS: the
 // SPH loops; TreeBuilder::calc_search_boxes).
-template <bool SYM, int K, bool MERGE = false, bool WRAP = true>
+// slink / NE (round 5): the links the search follows - tv.linkB, or the SEARCH links (tv.linkS, TreeBuilder::calc_search_links) in which an
+// internal node of <= 8 NE particles is a leaf of its whole particle range; such a leaf goes to the list as up to NE runs of <= 8.
+template <bool SYM, int K, bool MERGE = false, bool WRAP = true, int NE = 1>
 __device__ __forceinline__ int walk_stepk(const TreeView &tv, const NodeGeo *__restrict__ sgeo, const double *__restrict__ shm, unsigned *stack, int &sp,
                                           const bool valid_more, const int s, const int gshift, const double hsml, const double px, const double py,
-                                          const double pz, unsigned *llist, int nl, bool &overflow)
+                                          const double pz, unsigned *llist, int nl, bool &overflow, const NodeLinkB *__restrict__ slink = nullptr)
 {
+    static_assert(NE == 1 || NE == 2 || NE == 4, "runs per search leaf");
+    if(NE == 1 || slink == nullptr)
+        slink = tv.linkB;
     const bool can = valid_more;
     const double invbox = 1.0 / tv.box;
     const unsigned below = (1u << s) - 1u;
@@ -139,10 +144,12 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, const NodeGeo *__r
 #pragma unroll
     for(int k = 0; k < K; k++) {
         g[k] = sgeo[my[k]];
-        lk[k] = tv.linkB[my[k]];
+        lk[k] = slink[my[k]];
         hm[k] = SYM ? shm[my[k]] : 0.0;
     }
     unsigned gl[K], gp[K], ent[K];
+    unsigned pcn[K], gx[K][NE > 1 ? NE - 1 : 1]; // NE > 1: particles this lane lists; the group's lanes that list >= 2, >= 3, >= 4 runs
+    unsigned long long m_x[K][NE > 1 ? NE - 1 : 1];
     unsigned long long m_leaf[K], m_push[K]; // lane masks: the children opened as leaves / whose own children are pushed
 #pragma unroll
     for(int k = 0; k < K; k++) {
@@ -183,11 +190,22 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, const NodeGeo *__r
             pcm = (((h >> 8) & 15u) != 0u && x == 0u) ? (s == 0 ? ((h >> 8) & 15u) : 0u) : pcm;
 #endif
 #endif
-            ent[k] = ((unsigned)lk[k].pstart << 4) | pcm;
+            ent[k] = ((unsigned)lk[k].pstart << 4) | (NE > 1 ? min(pcm, 8u) : pcm);
             m_leaf[k] = __builtin_amdgcn_ballot_w64(pcm != 0u);
+            pcn[k] = pcm;
         }
+        else
+            pcn[k] = (unsigned)lk[k].pcount;
         gl[k] = (unsigned)((m_leaf[k] >> gshift) & 0xffull);
         gp[k] = (unsigned)((m_push[k] >> gshift) & 0xffull);
+        if(NE > 1) {
+            static_assert(NE == 1 || MERGE, "runs per search leaf: the merging form only");
+#pragma unroll
+            for(int e = 1; e < NE; e++) { // (pcn is 0 on the lanes that list nothing)
+                m_x[k][e - 1] = __builtin_amdgcn_ballot_w64(pcn[k] > 8u * (unsigned)e);
+                gx[k][e - 1] = (unsigned)((m_x[k][e - 1] >> gshift) & 0xffull);
+            }
+        }
     }
     const int taken = can ? (sp < take ? sp : take) : 0;
     const int base = sp - taken;
@@ -211,9 +229,27 @@ __device__ __forceinline__ int walk_stepk(const TreeView &tv, const NodeGeo *__r
         sp = base + npush;
 #pragma unroll
     for(int k = 0; k < K; k++) {
-        if(__builtin_amdgcn_inverse_ballot_w64(m_leaf[k]))
-            llist[nl + __popc(gl[k] & below)] = ent[k];
-        nl += can ? __popc(gl[k]) : 0;
+        if(NE == 1) {
+            if(__builtin_amdgcn_inverse_ballot_w64(m_leaf[k]))
+                llist[nl + __popc(gl[k] & below)] = ent[k];
+            nl += can ? __popc(gl[k]) : 0;
+        }
+        else {
+            // a lane's runs are consecutive list entries; its first one sits behind all runs of the lanes below it
+            int pos = nl + __popc(gl[k] & below), tot = __popc(gl[k]);
+#pragma unroll
+            for(int e = 1; e < NE; e++) {
+                pos += __popc(gx[k][e - 1] & below);
+                tot += __popc(gx[k][e - 1]);
+            }
+            if(__builtin_amdgcn_inverse_ballot_w64(m_leaf[k]))
+                llist[pos] = ent[k];
+#pragma unroll
+            for(int e = 1; e < NE; e++)
+                if(__builtin_amdgcn_inverse_ballot_w64(m_x[k][e - 1]))
+                    llist[pos + e] = (((unsigned)lk[k].pstart + 8u * (unsigned)e) << 4) | min(pcn[k] - 8u * (unsigned)e, 8u);
+            nl += can ? tot : 0;
+        }
     }
     return nl;
 }

@@ -149,6 +149,14 @@ __global__ void __launch_bounds__(256) k_sph_predict(int64_t npart, const int *_
 #define SPH_MERGE true // contiguous opened leaves of a child range joined into one list entry (walk_stepk, ngb_walk.h)
 #endif
 
+#ifndef SPH_NE
+// runs of <= 8 particles per search leaf: with -DSPH_NE=2 (or 4) the searches stop at nodes of <= 16 (32) particles and list their whole
+// particle range (TreeBuilder::calc_search_links; MPG_SPH_LEAF_CAP picks a smaller capacity at run time).  Measured at 2 x 128^3 on the
+// Zel'dovich set (profiles/r05a_experiments): fewer search steps, but 20 - 34 % more candidates and as many test iterations - density
+// 7.27 -> 7.32 ms, hydro 7.51 -> 7.41 ms - so the default stays 1 (the reference's leaves).
+#define SPH_NE 1
+#endif
+
 struct DensAcc {
     double EgyRho = 0, DhsmlEgy = 0, Rho = 0, DhsmlDensity = 0, Ngb = 0, Div = 0, Rot0 = 0, Rot1 = 0, Rot2 = 0, G0 = 0, G1 = 0, G2 = 0;
 };
@@ -430,10 +438,10 @@ __global__ void __launch_bounds__(256, 4) k_density(const TreeView tv, const Sph
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
         for(;;) {
-            const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 8 * SPH_WALK_K * SPH_NE <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<false, SPH_WALK_K, SPH_MERGE, WRAP>(tv, sgeo, nullptr, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow);
+            nl = walk_stepk<false, SPH_WALK_K, SPH_MERGE, WRAP, SPH_NE>(tv, sgeo, nullptr, stack, sp, go, s, gshift, hsml, px, py, pz, llist, nl, overflow, tv.linkS);
             if(ballot64(overflow) != 0)
                 break;
         }
@@ -860,10 +868,10 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
         // ---- phase A: walk; opened leaves go to the group's list
         int nl = 0;
         for(;;) {
-            const bool go = sp > 0 && nl + 8 * SPH_WALK_K <= SPH_LCAP;
+            const bool go = sp > 0 && nl + 8 * SPH_WALK_K * SPH_NE <= SPH_LCAP;
             if(ballot64(go) == 0)
                 break;
-            nl = walk_stepk<true, SPH_WALK_K, SPH_MERGE, WRAP>(tv, sgeo, shm, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow);
+            nl = walk_stepk<true, SPH_WALK_K, SPH_MERGE, WRAP, SPH_NE>(tv, sgeo, shm, stack, sp, go, s, gshift, t.me.hsml, t.px, t.py, t.pz, llist, nl, overflow, tv.linkS);
 #ifdef SPH_HIST
             if(lane == 0)
                 atomicAdd(&stats[7], 1ull);
@@ -956,6 +964,20 @@ static int kernel_index(int enumtype)
     return enumtype == 1 ? 0 : (enumtype == 2 ? 1 : 2);
 }
 
+// The SPH searches stop at nodes of <= this many particles and list their whole range (TreeBuilder::calc_search_links): 8 = the
+// reference's leaves only (also under MPG_SPH_CELL_CULL=1, where the candidates are the reference's one for one).
+static int search_leaf_cap()
+{
+    static const int cap = [] {
+        if(getenv("MPG_SPH_CELL_CULL"))
+            return 8;
+        const char *e = getenv("MPG_SPH_LEAF_CAP");
+        const int c = e ? atoi(e) : 8 * SPH_NE;
+        return c < 8 ? 8 : (c > 8 * SPH_NE ? 8 * SPH_NE : c);
+    }();
+    return cap;
+}
+
 double sph_desnumngb(const mpg_density_params &P)
 {
     const int t = kernel_index(P.DensityKernelType);
@@ -975,9 +997,14 @@ void SphEngine::density(TreeBuilder &tree, const SphView &A, const mpg_sph_times
     static const bool density_cubes = getenv("MPG_SPH_DENSITY_CUBES") != nullptr && getenv("MPG_SPH_CELL_CULL") == nullptr;
     if(density_cubes && !tree.has_boxes)
         tree.calc_search_boxes(st);
+    const int leaf_cap = search_leaf_cap();
+    if(leaf_cap > 8 && !(tree.has_slinks && tree.slink_cap == leaf_cap))
+        tree.calc_search_links(leaf_cap, st);
     TreeView tv = tree.view();
     if(!density_cubes)
         tv.geoS = nullptr;
+    if(leaf_cap <= 8)
+        tv.linkS = nullptr;
     MPG_CHECK(tv.npart > 0 || n == 0, "density: the tree holds no gas particles");
     const int64_t nact = d_active ? nactive : n;
     left.reserve(n + 1);
@@ -1115,8 +1142,15 @@ void SphEngine::hydro_force(TreeBuilder &tree, const SphView &A, const mpg_sph_t
             if(!tree.has_boxes)
                 tree.calc_search_boxes(st);
             tree.calc_search_hsmax(hsml_t.p, st);
+            const int leaf_cap = search_leaf_cap();
+            if(leaf_cap > 8 && !(tree.has_slinks && tree.slink_cap == leaf_cap))
+                tree.calc_search_links(leaf_cap, st);
             tv = tree.view();
+            if(leaf_cap <= 8)
+                tv.linkS = nullptr;
         }
+        else
+            tv.linkS = nullptr;
     }
     // work queue: the active gas particles in tree order
     queue_a.reserve(tv.npart + 1);

@@ -80,6 +80,10 @@ struct TreeBuilder {
     DevBuf<NodeGeo> geoS;
     DevBuf<double> hsmaxS;
     bool has_boxes = false, has_hsmax = false;
+    // search links of the SPH loops (level order): linkB with every internal node of <= slink_cap particles turned into a leaf
+    DevBuf<NodeLinkB> linkS;
+    bool has_slinks = false;
+    int slink_cap = 0;
 
     // force_tree_build (forcetree.c:196-270) without moments
     void build(int64_t n, const double *d_pos, const float *d_mass, const uint8_t *d_type, int mask, double box, hipStream_t st,
@@ -105,6 +109,12 @@ struct TreeBuilder {
     // reference has `hmax`, the reach beyond the CELL's faces (forcetree.c:963).
     void calc_search_boxes(hipStream_t st);
     void calc_search_hsmax(const double *d_hsml_treeorder, hipStream_t st);
+    // The reference's tree splits a cell at its 9th particle, which leaves children of one or two particles each: a neighbour search that
+    // descends to them tests 8 children to list a few short runs.  The particles below any node are contiguous in tree order, so a search
+    // may stop at a node of <= cap particles and list its whole range in runs of 8 (walk_stepk, ngb_walk.h): fewer search steps and fuller
+    // test lanes for more candidates; the neighbour set is unchanged (every particle below a node that is kept is tested).  Topology only:
+    // valid until the next build.
+    void calc_search_links(int cap, hipStream_t st);
     TreeView view() const;
 };
 

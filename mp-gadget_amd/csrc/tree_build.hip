@@ -579,6 +579,39 @@ void TreeBuilder::calc_search_hsmax(const double *d_hsml_treeorder, hipStream_t 
     has_hsmax = true;
 }
 
+// linkB with the internal nodes of <= cap particles as leaves of their whole particle range (tree order is depth-first: the particles
+// below node j end where those of the node after its subtree begin)
+__global__ void __launch_bounds__(256) k_search_links(int64_t nnodes, int64_t npart, int cap, const uint32_t *__restrict__ dfs_of_bfs,
+                                                      const NodeLink *__restrict__ link, const NodeLinkB *__restrict__ linkB, NodeLinkB *__restrict__ linkS)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= nnodes)
+        return;
+    NodeLinkB o = linkB[i];
+    if(o.pcount == 0 && o.nchild > 0) {
+        const NodeLink lk = link[dfs_of_bfs[i]];
+        const int64_t end = lk.sibling >= 0 ? (int64_t)link[lk.sibling].pstart : npart;
+        const int64_t total = end - (int64_t)lk.pstart;
+        if(total <= cap) {
+            o.pstart = lk.pstart;
+            o.pcount = (int)total;
+            o.nchild = 0;
+            o.firstchild = 0; // (no merge hints: its parent's children are not all leaves of <= 8)
+        }
+    }
+    linkS[i] = o;
+}
+
+void TreeBuilder::calc_search_links(int cap, hipStream_t st)
+{
+    ensure_level_order(st);
+    linkS.reserve(nnodes + 16);
+    hipLaunchKernelGGL(k_search_links, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, cap, nid_b.p, link.p, linkB.p, linkS.p);
+    MPG_HIP(hipGetLastError());
+    has_slinks = true;
+    slink_cap = cap;
+}
+
 void TreeBuilder::ensure_level_order(hipStream_t st)
 {
     if(!has_bfs)
@@ -623,6 +656,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     has_bfs = false;
     has_boxes = false;
     has_hsmax = false;
+    has_slinks = false;
     if(tm)
         tm->start(st);
     keys_a.reserve(n + 1);
@@ -908,6 +942,7 @@ TreeView TreeBuilder::view() const
         v.hmaxB = has_hmax ? hmaxB.p : nullptr;
         v.geoS = has_boxes ? geoS.p : nullptr;
         v.hsmaxS = (has_boxes && has_hsmax) ? hsmaxS.p : nullptr;
+        v.linkS = has_slinks ? linkS.p : nullptr;
     }
     v.box = box;
     return v;
