@@ -1769,16 +1769,24 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
         std::thread writer;
         std::atomic<int> issued{0}; // slices whose copies are queued and whose event is recorded (an event not yet recorded "is complete")
         std::atomic<bool> abandon{false};
+        // (an error thrown below while the writer runs: tell it to stop and wait for it - a joinable std::thread must not be destroyed)
+        struct JoinOnExit {
+            std::thread &t;
+            std::atomic<bool> &stop;
+            ~JoinOnExit()
+            {
+                if(t.joinable()) {
+                    stop = true;
+                    t.join();
+                }
+            }
+        } join_on_exit{writer, abandon};
         for(int k = 0; k < S; k++) {
             const int64_t lo = cut[k], hi = cut[k + 1];
             if(hi > lo) {
                 if(mpg_dev_grav_short_tree(eng, nullptr, eng->s_prevacc.p, eng->s_gravpm.p, d_order + lo, hi - lo, eng->s_accel.p,
-                                           wantpot ? eng->s_pot2.p : nullptr, rho0)) {
-                    abandon = true;
-                    if(writer.joinable())
-                        writer.join();
+                                           wantpot ? eng->s_pot2.p : nullptr, rho0))
                     throw Error(g_err);
-                }
                 hipLaunchKernelGGL(k_gather_results, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, eng->stream, lo, hi, d_order, eng->s_accel.p,
                                    wantpot ? eng->s_pot2.p : nullptr, dat, dpt);
             }

@@ -6,7 +6,7 @@
 //   force_transfer (gravpm.c:458-489) -> c2r (petapm.c:344) -> exchange back (:842-885) -> CIC readout (gravpm.c:499-510).
 // On one rank the regions / pencils only relocate cells: here particles deposit straight into
 // the global Nmesh^3 mesh with hardware fp64 atomics (global_atomic_add_f64) and read straight back from it.
-// PFFT (third-party, not vendored) is an unnormalised DFT; hipFFT/rocFFT D2Z / Z2D are the same transform.
+// PFFT (third-party, not vendored) is an unnormalised DFT; the real-to-complex / complex-to-real transforms of rocFFT are the same transform.
 // All kernels are HBM-streaming: per PM step ~ N*(28+128) + 5*3*2*R + 5*2*R + N*(24+256+32) bytes, R = 8*Nmesh^3.
 #include "pm.h"
 #include <cmath>
@@ -816,7 +816,7 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
 //   all-to-all (caller)                                                                               [recvB]
 //   inverse_c : unpack to [x local][ky][kz] -> 2-D c2r -> the potential slab; its first 3 / last 2 planes out as ghosts [ghost_send]
 //   neighbour exchange (caller) -> readout: forces by differencing the potential (k_gradient_axis), CIC readout.
-// hipFFT transforms are unnormalised like PFFT's; the three 1-D stages compose to the same 3-D DFT.
+// rocFFT transforms are unnormalised like PFFT's; the three 1-D stages compose to the same 3-D DFT.
 
 __global__ void __launch_bounds__(256) k_cic_deposit_slab(int64_t n, const double *__restrict__ pos, const float *__restrict__ mass,
                                                           double cellsize, int nmesh, int x0, int P, double *__restrict__ slab)
