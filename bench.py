@@ -199,8 +199,10 @@ def configure_gravity(eng, args, box, n, nmesh):
     eng.set_walk_variant(args.variant)
     eng.gravshort_fill_ntab(0, 1.5)
     eng.gravpm_init_periodic(box, 1.5, nmesh, G)
-    eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=0.175, MaxBHOpeningAngle=0.9, TreeUseBH=2, Rcut=6.0,
-                              FractionalGravitySoftening=1. / 30.)
+    # (timing experiments on ONE kernel with wrong results must not change the lists through the opening input: MPG_BENCH_TREEUSEBH=1
+    # walks every step with the geometric criterion, MPG_BENCH_BHANGLE sets its angle; diagnostics only, the line says so in `config`)
+    eng.set_gravshort_treepar(ErrTolForceAcc=0.002, BHOpeningAngle=float(os.environ.get("MPG_BENCH_BHANGLE", "0.175")), MaxBHOpeningAngle=0.9,
+                              TreeUseBH=int(os.environ.get("MPG_BENCH_TREEUSEBH", "2")), Rcut=6.0, FractionalGravitySoftening=1. / 30.)
     eng.gravshort_set_softenings(box / n)
 
 
@@ -840,6 +842,9 @@ def gravity_bench_single(pkg, torch, args, dev, local_rank):
         "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
         "phases_ms": {k: round(v, 3) for k, v in ph.items()},
     }
+    if os.environ.get("MPG_BENCH_TREEUSEBH") or os.environ.get("MPG_BENCH_BHANGLE"):   # (a diagnostic run: not BASELINE's configuration)
+        out["config"]["workload"] += " -- DIAGNOSTIC: TreeUseBH=%s BHOpeningAngle=%s from the environment" % (
+            os.environ.get("MPG_BENCH_TREEUSEBH", "2"), os.environ.get("MPG_BENCH_BHANGLE", "0.175"))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, d_pos.cpu().numpy(), mass, box, n, nmesh, prev.cpu().numpy() + gravpm.cpu().numpy(), args.cpu_sample)
     if not args.no_extras:

@@ -323,11 +323,23 @@ int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int
 }
 
 // tree of the bound particles + moments on the given stream (csrc/dist.hip: beside the PM step, from a second host thread)
+// What the default walk kernels read beside the depth-first tree - the level-ordered copy and the leaves' particles in blocks of 8 - made
+// with the tree, on the tree's stream (beside the PM force when one is queued), not at the start of the walk (rounds 1-5: 0.5 ms of every
+// walk at 256^3).  Not when the phases are being timed (the tree's phases are its own) or another kernel was selected.
+static void tree_walk_copies(mpg_engine *eng, hipStream_t st)
+{
+    if(eng->timer.enabled || !(eng->walk_variant == 0 || eng->walk_variant == 6) || eng->tree.npart < 4096)
+        return;
+    eng->tree.ensure_level_order(st);
+    eng->tree.ensure_leaf_pad(st);
+}
+
 void engine_tree_build_on(mpg_engine *eng, int mask, hipStream_t st)
 {
     eng->pm_queued = false;
     eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, st, nullptr);
     eng->tree.calc_moments(nullptr, st, nullptr);
+    tree_walk_copies(eng, st);
     eng->tree_allocated = true;
     eng->tree_mask = mask;
     eng->full_particle_tree = (eng->tree.npart == eng->n);
@@ -344,6 +356,7 @@ int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
         MPG_HIP(hipStreamWaitEvent(eng->aux_stream, eng->ev_inputs, 0));
         eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->aux_stream, nullptr);
         eng->tree.calc_moments(nullptr, eng->aux_stream, nullptr);
+        tree_walk_copies(eng, eng->aux_stream);
         MPG_HIP(hipEventRecord(eng->ev_tree_done, eng->aux_stream));
         MPG_HIP(hipStreamWaitEvent(eng->stream, eng->ev_tree_done, 0));
     }
@@ -351,6 +364,7 @@ int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
         eng->pm_queued = false;
         eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
         eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
+        tree_walk_copies(eng, eng->stream);
     }
     if(eng->timer.enabled)
         eng->timer.t.tree_total = eng->timer.t.tree_keys + eng->timer.t.tree_sort + eng->timer.t.tree_nodes + eng->timer.t.tree_moments;
@@ -484,6 +498,8 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     auto run_variant_io = [&](int v, const WalkIO &w) {
         if(v != 1)
             eng->tree.ensure_level_order(eng->stream); // variants 4 and 6 walk the level-ordered copy of the tree
+        if(v == 6)
+            eng->tree.ensure_leaf_pad(eng->stream);    // ... and 6 the leaves' particles in blocks of 8 (both made with the tree as a rule)
         if(v == 1)
             launch_grav_walk(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
         else if(v == 6)

@@ -39,8 +39,17 @@ namespace {
 // (69.2 -> 67.7 ms); round 3 had measured 4, 5 and 6 blocks as equal before the list kernel changed
 #define MPG_EVAL_BLOCKS 4
 #endif
+#ifndef MPG_LISTS_PREFETCH_MIN
+#define MPG_LISTS_PREFETCH_MIN 64
+#endif
+#ifndef MPG_LIST_BLOCKS
+#define MPG_LIST_BLOCKS 6 // resident 256-thread blocks per CU the list kernel is compiled for
+#endif
 #ifndef MPG_EVAL_BLOCKS_LONG
-#define MPG_EVAL_BLOCKS_LONG 6
+// ... and where the lists are long (capacity >= 4096: a clustered set).  6 (80 registers) until round 5, when "it waits for memory and the
+// waves count" held; with every source record requested two evaluations ahead the 4-block build wins there too (256^3 clustered set:
+// 125.0 -> 118.7 ms per step; 5 blocks 121.9)
+#define MPG_EVAL_BLOCKS_LONG 4
 #endif
 
 
@@ -117,58 +126,87 @@ __device__ __forceinline__ void softened_pair(const double r, const double m, co
     facpot = m * hinv * wpk;
 }
 
+// apply_accn_to_output, gravshort-tree.c:158-193, in three stages so that the evaluation loop can run TWO pairs side by side (their chains
+// of dependent fp64 operations are what the kernel waits for: with 2 / 3 / 4 resident waves per SIMD it takes 52.8 / 41.3 / 36.1 ms at 256^3,
+// i.e. 18 ms of issue + 69 ms / waves of exposed latency): the common arithmetic up to the softening test, the rare softened branch (taken
+// once for both pairs), the window table and the sums.
+struct PairTmp {
+    double dx, dy, dz, r2, rinv, r, fac, facpot, m;
+};
+
+__device__ __forceinline__ void pair_pre(const Src4 s, const double dx, const double dy, const double dz, PairTmp &t)
+{
+    t.dx = dx;
+    t.dy = dy;
+    t.dz = dz;
+    t.m = s.m;
+    t.r2 = dx * dx + dy * dy + dz * dz;
+    // (no clamp of r2 on the common path: for r2 = 0 - the self interaction - and below ~1e-300 rinv is not finite, and the softened
+    // branch, which such a pair always takes and which overwrites fac and facpot, puts r = 0 in its place)
+    t.rinv = rsqrt_nr(t.r2);
+    t.r = t.r2 * t.rinv;
+    const double mr = s.m * t.rinv;
+    t.fac = mr * t.rinv * t.rinv;
+    t.facpot = -mr;
+}
+
+// rare (the self interaction, close encounters): kept out of line so that its divisions and constants do not occupy registers in the pair loop
+__device__ __forceinline__ void pair_soft(const GravParams &gp, PairTmp &t)
+{
+#ifndef MPG_NO_SELF_FAST
+    if(t.r2 == 0.0) { // the self interaction, once per target and so in ~6 % of a wave's pair steps: the spline's inner branch at u = 0
+        t.r = 0.0;    // (bit for bit: c0 + 0 and c3 + 0), from literals - softened_pair's constant fetches are dependent vector loads whose
+        t.fac = t.m * gp.h3inv * 10.666666666667; // waits also drain the prefetched source records
+        t.facpot = t.m * gp.hinv * -2.8;
+    }
+    else
+#endif
+    {
+        if(!(t.rinv < 1e150))
+            t.r = 0.0;
+        softened_pair(t.r, t.m, gp.hinv, gp.h3inv, t.fac, t.facpot);
+    }
+}
+
+template <bool POT>
+__device__ __forceinline__ void pair_post(const PairTmp &t, const GravParams &gp, const double *__restrict__ wtab, double &ax, double &ay, double &az,
+                                          double &pot)
+{
+    // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
+    // the table's last row, which holds zeros
+    const double ti = t.r * gp.inv_cell_dx;
+    // row t holds {T[t], T[t+1] - T[t]} (the difference of two floats is exact in double): T[t] + (i - t) (T[t+1] - T[t]) is the
+    // interpolation of gravity.c:63 up to one rounding.  (i - t) = fract(i) exactly for i >= 0.
+    const int ix = min((int)ti, NTAB - 1);
+    const double w1 = __builtin_amdgcn_fract(ti);
+    // two tables of 16-byte rows, {T, dT} of the force, then (with POT) {T, dT} of the potential NTAB rows further on: both reads are
+    // issued together.  (One 32-byte row holding both put every force read on one half of the LDS banks and every potential read on
+    // the other half; with 16-byte rows the random rows of a wave's 64 lanes spread over all banks.  Round 3 also measured rows of four
+    // floats {F[t], F[t+1], P[t], P[t+1]} - one 16-byte read per pair, six more conversions: no change.  Round 5: rows {T[t] - t dT, dT}
+    // evaluated without the fraction - one instruction less, no change.)
+    const double *__restrict__ row = wtab + ix * 2;
+    const double2 f = *(const double2 *)row;
+    double2 p = f;
+    if(POT)
+        p = *(const double2 *)(row + 2 * NTAB);
+    const double fac = t.fac * fma(w1, f.y, f.x);
+    ax = fma(t.dx, fac, ax);
+    ay = fma(t.dy, fac, ay);
+    az = fma(t.dz, fac, az);
+    if(POT)
+        pot = fma(t.facpot, fma(w1, p.y, p.x), pot);
+}
+
 template <bool POT>
 __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const double dy, const double dz, const GravParams &gp,
                                            const double *__restrict__ wtab, double &ax, double &ay,
                                            double &az, double &pot)
 {
-    // apply_accn_to_output, gravshort-tree.c:158-193
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    // (no clamp of r2 on the common path: for r2 = 0 - the self interaction - and below ~1e-300 rinv is not finite, and the softened
-    // branch, which such a pair always takes and which overwrites fac and facpot, puts r = 0 in its place)
-    const double rinv = rsqrt_nr(r2);
-    double r = r2 * rinv;
-    const double mr = s.m * rinv;
-    double fac = mr * rinv * rinv;
-    double facpot = -mr;
-    if(r2 < gp.h * gp.h) { // rare (the self interaction, close encounters): kept out of line so that its divisions and
-                           // constants do not occupy registers in the pair loop
-#ifndef MPG_NO_SELF_FAST
-        if(r2 == 0.0) { // the self interaction, once per target and so in ~6 % of a wave's pair steps: the spline's inner branch at u = 0
-            r = 0.0;    // (bit for bit: c0 + 0 and c3 + 0), from literals - softened_pair's constant fetches are dependent vector loads whose
-            fac = s.m * gp.h3inv * 10.666666666667; // waits also drain the prefetched source records
-            facpot = s.m * gp.hinv * -2.8;
-        }
-        else
-#endif
-        {
-            if(!(rinv < 1e150))
-                r = 0.0;
-            softened_pair(r, s.m, gp.hinv, gp.h3inv, fac, facpot);
-        }
-    }
-    // r / cellsize / dx, gravity.c:57-58.  tabindex >= NTAB-1 contributes nothing (gravity.c:60-61): the clamp lands on
-    // the table's last row, which holds zeros
-    const double ti = r * gp.inv_cell_dx;
-    // row t holds {T[t], T[t+1] - T[t]} (the difference of two floats is exact in double): T[t] + (i - t) (T[t+1] - T[t]) is the
-    // interpolation of gravity.c:63 up to one rounding.  (i - t) = fract(i) exactly for i >= 0.
-    const int t = min((int)ti, NTAB - 1);
-    const double w1 = __builtin_amdgcn_fract(ti);
-    // two tables of 16-byte rows, {T, dT} of the force, then (with POT) {T, dT} of the potential NTAB rows further on: both reads are
-    // issued together.  (One 32-byte row holding both put every force read on one half of the LDS banks and every potential read on
-    // the other half; with 16-byte rows the random rows of a wave's 64 lanes spread over all banks.  Round 3 also measured rows of four
-    // floats {F[t], F[t+1], P[t], P[t+1]} - one 16-byte read per pair, six more conversions: no change.)
-    const double *__restrict__ row = wtab + t * 2;
-    const double2 f = *(const double2 *)row;
-    double2 p = f;
-    if(POT)
-        p = *(const double2 *)(row + 2 * NTAB);
-    fac *= fma(w1, f.y, f.x);
-    ax = fma(dx, fac, ax);
-    ay = fma(dy, fac, ay);
-    az = fma(dz, fac, az);
-    if(POT)
-        pot = fma(facpot, fma(w1, p.y, p.x), pot);
+    PairTmp t;
+    pair_pre(s, dx, dy, dz, t);
+    if(t.r2 < gp.h * gp.h)
+        pair_soft(gp, t);
+    pair_post<POT>(t, gp, wtab, ax, ay, az, pot);
 }
 
 // element i of a device array.  O32: the byte offset fits 32 bits (decided on the host), which lets the load use the
@@ -390,7 +428,7 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 st_al += (unsigned)nch;
             }
             if(COUNT || (bn | bl) != 0ull) { // (list entries this high in the tree: small trees, or coarse nodes far from the targets)
-                const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+                const unsigned ent_val = my; // a leaf entry = the leaf's level-order node number (its block of 8 source records: tv.srcL)
 #pragma unroll
                 for(int t = 0; t < 8; t++) {
                     const unsigned long long grp = 0xffull << (8 * t);
@@ -437,6 +475,52 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
             }
         }
     }
+#ifdef MPG_LISTS_PREFETCH
+    // Round 5 experiment, measured and left off (29.6 ms at 5 resident blocks, 34 at 6 with 37 spilled registers, against 25.3 ms without it;
+    // 20 more registers for the second batch cost a resident wave, which is worth what the prefetch hides; 7 blocks of the plain form: 25.7).
+    // Two batches of nodes in flight: the batch BELOW the one being tested is taken off the frontier and its 80 bytes per lane
+    // requested before the 8 passes over the current batch, which then hide that gather (the kernel is latency-bound: with 2 / 4 / 6 resident
+    // waves per SIMD it takes 55.5 / 33.1 / 25.7 ms at 256^3, i.e. 11 ms of issue + 89 ms / waves).  The batch below does not depend on
+    // what the current batch pushes, so the set of (node, target) tests is unchanged; the frontier is a batch deeper at most, and the order
+    // of a target's list entries changes (it already depended on its wave-mates).  When nothing waits below, the next batch is what the
+    // current one pushed, as before.
+    struct Batch {
+        unsigned my, qmask;
+        int n;
+        NodeGeo g;
+        Src4 mom;
+        NodeLinkB lk;
+    };
+    auto pop = [&](Batch &b) {
+        __builtin_amdgcn_wave_barrier();
+        b.n = sp < 64 ? sp : 64;
+        // (idle lanes read entry 0, which always holds a node index: no exec-mask regions around the two reads)
+        const int qi = lane < b.n ? sp - 1 - lane : 0;
+        b.my = q_node[qi];
+        b.qmask = lane < b.n ? (unsigned)q_mask[qi] : 0u;
+        sp -= b.n;
+        b.g = ld<O32>(tv.geoB, b.my);
+        b.mom = ld<O32>(tv.momB, b.my);
+        b.lk = ld<O32>(tv.linkB, b.my);
+    };
+    Batch cur, nxt;
+    pop(cur);
+    while(cur.n > 0 && live) {
+        if(++guard > guard_max) {
+            if(lane == 0)
+                atomicExch(&ctl[1], 1u);
+            return false;
+        }
+        nxt.n = 0;
+        if(sp >= MPG_LISTS_PREFETCH_MIN) // (a FULL batch waits below: a part of one would be tested with idle lanes, where the pure LIFO tops it up
+            pop(nxt);                    // with what the current batch pushes)
+        const int n = cur.n;
+        const unsigned my = cur.my;
+        const unsigned mask = cur.qmask & live;
+        const NodeGeo g = cur.g;
+        const Src4 mom = cur.mom;
+        const NodeLinkB lk = cur.lk;
+#else
     while(sp > 0 && live) {
         if(++guard > guard_max) {
             if(lane == 0)
@@ -454,11 +538,12 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const NodeGeo g = ld<O32>(tv.geoB, my);
         const Src4 mom = ld<O32>(tv.momB, my);
         const NodeLinkB lk = ld<O32>(tv.linkB, my);
+#endif
         const double eff = fma(0.5, g.len, gp.rcut);
         const double l2 = g.len * g.len;
         const double inside = 0.6 * g.len;
         const double ml2 = mom.m * l2;
-        const unsigned ent_val = ((unsigned)lk.pstart << 3) | (unsigned)(lk.pcount - 1);
+        const unsigned ent_val = my; // a leaf entry = the leaf's level-order node number (its block of 8 source records: tv.srcL)
         unsigned openmask = 0;
         if(COUNT) {
             st_a++;
@@ -541,6 +626,11 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
             pass(std::false_type{});
         if(!push_children(openmask != 0u, lk, openmask))
             break;
+#ifdef MPG_LISTS_PREFETCH
+        if(nxt.n == 0 && sp > 0)
+            pop(nxt); // nothing waited below: on with what this batch pushed
+        cur = nxt;
+#endif
     }
     wrapped = wmask != 0ull;
     return true;
@@ -548,13 +638,18 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
 
 // one wave = one chunk of k_walk_eval (8 consecutive targets)
 template <bool COUNT, bool FASTWRAP, bool O32>
-__global__ void __launch_bounds__(256, 6) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
+__global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
                                                       int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
                                                       unsigned *__restrict__ ctl, int *__restrict__ ovf)
 {
     __shared__ unsigned s_qnode[4 * QCAP];
     __shared__ unsigned char s_qmask[4 * QCAP];
     __shared__ __attribute__((aligned(32))) double s_tgt4[4 * 8 * 4];
+#ifdef MPG_EXP_LDSPAD_LISTS // timing experiment: fewer resident blocks per CU with the same code (bytes of unused LDS)
+    __shared__ unsigned s_pad[MPG_EXP_LDSPAD_LISTS / 4];
+    if(gp.box < 0)
+        s_pad[threadIdx.x] = 1u, s_qnode[0] = s_pad[(threadIdx.x + 1) & 255];
+#endif
     set_wave_prio(io.list_prio);
     const int lane = threadIdx.x & 63;
     unsigned *q_node = s_qnode + (threadIdx.x >> 6) * QCAP;
@@ -698,42 +793,27 @@ constexpr int RING_STRIDE = 17; // words per group: 16 used; the odd stride puts
 
 template <bool POT, bool WRAP, bool O32>
 __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams &gp, const unsigned *__restrict__ L, const int cap, const int nleaf,
-                                           const int nnode, const int s, const int gshift, const unsigned zero_src, const double px,
+                                           const int nnode, const int s, const int gshift, const double px,
                                            const double py, const double pz, const double *__restrict__ s_wtab, unsigned *__restrict__ ring_g,
                                            double &ax, double &ay, double &az, double &pot)
 {
-    const unsigned empty = (zero_src << 3) | 7u; // a full "leaf" of zero-mass padding records
-    // source s of leaf entry EJ.  O32: byte offsets formed directly (first particle * 32 = (entry & ~7) << 2)
-    const unsigned s32 = (unsigned)s * 32u, zoff = zero_src * 32u;
-    unsigned zoff_v = zoff;
-    asm volatile("" : "+v"(zoff_v));
-#define MPG_LOAD(EJ, SV)                                                                        \
+    const unsigned empty = (unsigned)tv.nnodes; // the block of zero-mass records behind the last node's (TreeBuilder::ensure_leaf_pad)
+    // source s of leaf entry EJ: record s of block EJ of tv.srcL - a leaf's particles filled up to 8 with zero-mass records, so that neither
+    // the leaf's count nor a select for the lanes beyond it is needed (rounds 3-5 read tv.src[first + s] with the count in the entry's low
+    // bits: v_and, v_and, v_lshl_add, v_cmp, v_cndmask per pair step where this form is one v_lshl_add)
+    const unsigned s32 = (unsigned)s * 32u;
+#define MPG_LOAD_REAL(EJ, SV)                                                                   \
     {                                                                                           \
         const unsigned ej_ = (EJ);                                                              \
-        if(O32) {                                                                               \
-            unsigned off_, cnt_; /* (first particle + s) * 32, or the padding record's offset for a lane beyond the leaf's particles; */ \
-            /* written out: hipcc forms (e << 2) & ~31 + a separate add, and moves the (scalar) padding offset into a register per use */ \
-            /* (v_cndmask reads vcc through the constant bus, which leaves no room for a scalar source: the offset is pinned in a VGPR) */ \
-            asm("v_and_b32 %0, -8, %2\n\tv_and_b32 %1, 7, %2\n\tv_lshl_add_u32 %0, %0, 2, %3\n\tv_cmp_le_u32 vcc, %4, %1\n\t" \
-                "v_cndmask_b32 %0, %5, %0, vcc"                                                  \
-                : "=&v"(off_), "=&v"(cnt_) : "v"(ej_), "v"(s32), "v"((unsigned)s), "v"(zoff_v) : "vcc"); \
-            SV = *(const Src4 *)((const char *)tv.src + (size_t)off_);                          \
-        }                                                                                       \
+        if(O32)                                                                                 \
+            SV = *(const Src4 *)((const char *)tv.srcL + (size_t)((ej_ << 8) + s32));           \
         else                                                                                    \
-            SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
+            SV = tv.srcL[(size_t)ej_ * 8 + (size_t)s];                                          \
     }
-#ifdef MPG_EVAL_BPERMUTE // rounds 1-4: the batch's entries in a register, entry J broadcast with ds_bpermute per pair (kept for same-box A/B runs)
-#define MPG_LOAD_BP(ENT, J, SV)                                                                    \
-    {                                                                                           \
-        const unsigned ej_ = (unsigned)__shfl((int)(ENT), gshift + (J));                        \
-        if(O32) {                                                                               \
-            unsigned off_; /* (first particle + s) * 32: hipcc forms (e << 2) & ~31 and a separate add */ \
-            asm("v_and_b32 %0, -8, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(off_) : "v"(ej_), "v"(s32)); \
-            SV = *(const Src4 *)((const char *)tv.src + (size_t)(((unsigned)s <= (ej_ & 7u)) ? off_ : zoff)); \
-        }                                                                                       \
-        else                                                                                    \
-            SV = tv.src[(s <= (int)(ej_ & 7u)) ? (ej_ >> 3) + (unsigned)s : zero_src];          \
-    }
+#ifdef MPG_EXP_NOLOAD // timing experiment (wrong results): the leaf loop keeps the records it started with - no load, no other instruction
+#define MPG_LOAD(EJ, SV) asm volatile("" : "+v"(SV.x), "+v"(SV.y), "+v"(SV.z), "+v"(SV.m) : "v"(EJ))
+#else
+#define MPG_LOAD(EJ, SV) MPG_LOAD_REAL(EJ, SV)
 #endif
 #define MPG_EVAL(SV)                                                              \
     {                                                                             \
@@ -755,27 +835,6 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // index of leaf entry e0 + s (e0 a multiple of 8)
         const unsigned ls = (unsigned)((gshift >> 3) * cap + s);
 #define MPG_LEAF_AT(E0) (ls + (unsigned)(E0))
-#ifdef MPG_EVAL_BPERMUTE
-        unsigned ent = (s < nleaf) ? ld<true>(L, MPG_LEAF_AT(0)) : empty;
-        unsigned ent_n = (8 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(8)) : empty;
-        Src4 A, B;
-        MPG_LOAD_BP(ent, 0, A);
-        for(int e0 = 0;; e0 += 8) {
-            if(!any_lane(e0 < nleaf))
-                break;
-            const unsigned ent_nn = (e0 + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e0 + 16)) : empty;
-#pragma unroll 1
-            for(int j = 0; j < 8; j += 2) {
-                MPG_LOAD_BP(ent, j + 1, B);
-                MPG_EVAL(A);
-                const unsigned en = (j + 2 < 8) ? ent : ent_n;
-                MPG_LOAD_BP(en, (j + 2) & 7, A);
-                MPG_EVAL(B);
-            }
-            ent = ent_n;
-            ent_n = ent_nn;
-        }
-#else
         // batch 0 into ring slot 0, batch 1 requested.  (LDS operations of one wave complete in order; the wave barriers only keep
         // hipcc from moving the ring's reads over its writes.)
         __builtin_amdgcn_wave_barrier(); // (the previous chunk's reads of the ring are done)
@@ -784,7 +843,10 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         __builtin_amdgcn_wave_barrier();
         unsigned eb = ring_g[1];
         Src4 A, B;
-        MPG_LOAD(ring_g[0], A);
+        MPG_LOAD_REAL(ring_g[0], A);
+#if defined(MPG_EXP_NOLOAD) || !defined(MPG_EVAL_PF2)
+        B = A;
+#endif
         // ONE loop over pairs of entries up to the longest leaf list of the wave's 8 targets (a loop over batches around a loop over
         // the pairs of a batch made hipcc copy the four accumulators out and back at every batch: 8 v_mov_b64 per 8 pair steps; and
         // whole batches ran up to 6 pair steps beyond the longest list)
@@ -792,6 +854,78 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         for(int off = 8; off < 64; off <<= 1)
             wmax = max(wmax, __shfl_xor(wmax, off));
         wmax = __builtin_amdgcn_readfirstlane(wmax);
+#ifdef MPG_EVAL_ILP2
+        // Round 5 experiment (measured: 38.2 against 35.9 ms per evaluation at 256^3, removed from the default): the two pairs of a trip
+        // side by side up to the softening test, one branch for both, then their table parts side by side.  The kernel's time falls with
+        // the resident waves (2 / 3 / 4 per SIMD: 52.8 / 41.3 / 36.1 ms), but what the waves hide is the latency of the source loads, not of
+        // the dependent arithmetic: here both records of a trip are needed at its start and are requested only after the previous
+        // trip's first half, i.e. closer to their use than in the alternating form below.
+        MPG_LOAD(eb, B);
+        const double h2 = gp.h * gp.h;
+#pragma unroll 1
+        for(int e = 0; e < wmax; e += 2) {
+            if((e & 7) == 0) {
+                ring_g[((e + 8) & 8) + s] = ent_n;
+                ent_n = (e + 16 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT(e + 16)) : empty;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const unsigned *__restrict__ rr = ring_g + ((e + 2) & 15);
+            const unsigned ea = rr[0];
+            eb = rr[1];
+            __builtin_amdgcn_sched_barrier(0);
+            PairTmp ta, tb;
+            {
+                double dx_ = A.x - px, dy_ = A.y - py, dz_ = A.z - pz;
+                double ex_ = B.x - px, ey_ = B.y - py, ez_ = B.z - pz;
+                if(WRAP) {
+                    dx_ = nearest_img(dx_, gp.box, gp.invbox);
+                    dy_ = nearest_img(dy_, gp.box, gp.invbox);
+                    dz_ = nearest_img(dz_, gp.box, gp.invbox);
+                    ex_ = nearest_img(ex_, gp.box, gp.invbox);
+                    ey_ = nearest_img(ey_, gp.box, gp.invbox);
+                    ez_ = nearest_img(ez_, gp.box, gp.invbox);
+                }
+                pair_pre(A, dx_, dy_, dz_, ta);
+                pair_pre(B, ex_, ey_, ez_, tb);
+            }
+            MPG_LOAD(ea, A);
+            MPG_LOAD(eb, B);
+            if((ta.r2 < h2) | (tb.r2 < h2)) { // rare: one branch for both pairs
+                if(ta.r2 < h2)
+                    pair_soft(gp, ta);
+                if(tb.r2 < h2)
+                    pair_soft(gp, tb);
+            }
+            pair_post<POT>(ta, gp, s_wtab, ax, ay, az, pot);
+            pair_post<POT>(tb, gp, s_wtab, ax, ay, az, pot);
+            asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(pot));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#elif !defined(MPG_EVAL_PF2)
+        // three source buffers: every record is requested TWO pair evaluations ahead of its use (rounds 1-5 alternated two buffers, one
+        // evaluation ahead - kept under MPG_EVAL_PF2: 36.1 - 36.4 against 34.6 ms per evaluation at 256^3 on one box; the kernel's time falls
+        // with the resident waves - 2 / 3 / 4 per SIMD: 52.8 / 41.3 / 36.1 ms - and what the waves hide is the latency of these loads:
+        // without them, MPG_EXP_NOLOAD, the evaluation of a fixed set of lists takes 20.3 instead of 24.5 ms)
+        Src4 Cq = A;
+        MPG_LOAD(eb, B);
+        int staged = 1; // batches of 8 entries written to the ring so far (batch `staged` is in flight in ent_n)
+#pragma unroll 1
+        for(int e = 0; e < wmax; e += 3) {
+            if(e + 4 >= 8 * staged) { // (wave-uniform) this trip reads into the next batch: write it over the one before the current
+                ring_g[(staged & 1) * 8 + s] = ent_n;
+                ent_n = ((staged + 1) * 8 + s < nleaf) ? ld<true>(L, MPG_LEAF_AT((staged + 1) * 8)) : empty;
+                staged++;
+                __builtin_amdgcn_wave_barrier();
+            }
+            const unsigned e2 = ring_g[(e + 2) & 15], e3 = ring_g[(e + 3) & 15], e4 = ring_g[(e + 4) & 15];
+            MPG_LOAD(e2, Cq);
+            MPG_EVAL(A);
+            MPG_LOAD(e3, A);
+            MPG_EVAL(B);
+            MPG_LOAD(e4, B);
+            MPG_EVAL(Cq);
+        }
+#else
 #pragma unroll 1
         for(int e = 0; e < wmax; e += 2) {
             if((e & 7) == 0) { // (wave-uniform) the next batch into the other half of the ring - its first entry is read in the
@@ -817,6 +951,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // index of node entry r0 + s counted from the top of the list (r0 a multiple of 8)
         const unsigned top = (unsigned)((gshift >> 3) * cap + cap - 1 - s);
 #define MPG_NODE_AT(R0) (top - (unsigned)(R0))
+#ifdef MPG_EVAL_PF2
         unsigned ne = (s < nnode) ? ld<true>(L, MPG_NODE_AT(0)) : NONE;
         unsigned ne_n = (8 + s < nnode) ? ld<true>(L, MPG_NODE_AT(8)) : NONE;
         Src4 sc = ld<O32>(tv.momB, ne);
@@ -829,11 +964,37 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
             MPG_EVAL(sc);
             sc = sc_n;
         }
+#else
+        // three moment buffers in rotation (no register copies): the moments of a batch are requested two evaluations ahead of their use,
+        // its entries three evaluations before that
+#define MPG_NODE_ENT(R0) (((R0) + s < nnode) ? ld<true>(L, MPG_NODE_AT(R0)) : NONE)
+        Src4 Sa = ld<O32>(tv.momB, MPG_NODE_ENT(0));
+        Src4 Sb = ld<O32>(tv.momB, MPG_NODE_ENT(8));
+        Src4 Sc;
+        unsigned nx = MPG_NODE_ENT(16), ny = MPG_NODE_ENT(24), nz = MPG_NODE_ENT(32);
+#pragma unroll 1
+        for(int r0 = 0;; r0 += 24) {
+            if(!any_lane(r0 < nnode))
+                break;
+            Sc = ld<O32>(tv.momB, nx);
+            nx = MPG_NODE_ENT(r0 + 40);
+            MPG_EVAL(Sa);
+            if(!any_lane(r0 + 8 < nnode))
+                break;
+            Sa = ld<O32>(tv.momB, ny);
+            ny = MPG_NODE_ENT(r0 + 48);
+            MPG_EVAL(Sb);
+            if(!any_lane(r0 + 16 < nnode))
+                break;
+            Sb = ld<O32>(tv.momB, nz);
+            nz = MPG_NODE_ENT(r0 + 56);
+            MPG_EVAL(Sc);
+        }
+#undef MPG_NODE_ENT
+#endif
     }
 #undef MPG_LOAD
-#ifdef MPG_EVAL_BPERMUTE
-#undef MPG_LOAD_BP
-#endif
+#undef MPG_LOAD_REAL
 #undef MPG_EVAL
 #undef MPG_LEAF_AT
 #undef MPG_NODE_AT
@@ -846,6 +1007,11 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
     constexpr int ROW = POT ? 4 : 2;
     __shared__ __attribute__((aligned(16))) double s_wtab[NTAB * ROW];
     __shared__ unsigned s_ring[4 * 8 * RING_STRIDE]; // per wave and group: two batches of leaf entries (eval_lists)
+#ifdef MPG_EXP_LDSPAD // timing experiment: fewer resident blocks per CU with the same code (bytes of unused LDS)
+    __shared__ unsigned s_pad[MPG_EXP_LDSPAD / 4];
+    if(gp.box < 0)
+        s_pad[threadIdx.x] = 1u, s_ring[0] = s_pad[(threadIdx.x + 1) & 255];
+#endif
     set_wave_prio(io.eval_prio);
     for(int i = threadIdx.x; i < NTAB; i += blockDim.x) {
         const bool last = i == NTAB - 1; // the row the clamp lands on: zeros
@@ -855,6 +1021,11 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
             s_wtab[2 * NTAB + i * 2 + 0] = last ? 0.0 : (double)io.tab_pot[i];
             s_wtab[2 * NTAB + i * 2 + 1] = last ? 0.0 : (double)io.tab_pot[i + 1] - (double)io.tab_pot[i];
         }
+#ifdef MPG_TAB_AFFINE
+        s_wtab[i * 2 + 0] -= (double)i * s_wtab[i * 2 + 1];
+        if(POT)
+            s_wtab[2 * NTAB + i * 2 + 0] -= (double)i * s_wtab[2 * NTAB + i * 2 + 1];
+#endif
     }
     __syncthreads();
 
@@ -864,7 +1035,6 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
     unsigned *__restrict__ ring_g = s_ring + ((threadIdx.x >> 6) * 8 + grp) * RING_STRIDE;
     const unsigned nchunks = (unsigned)((nslots + 7) / 8);
     const ChunkIter it(nchunks);
-    const unsigned zero_src = (unsigned)(tv.npart + tv.nnodes); // zero-mass padding records (TreeBuilder::build)
 
     for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
         const int64_t rel = (int64_t)chunk * 8 + grp;
@@ -891,9 +1061,9 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
         const unsigned *__restrict__ L = lists + (size_t)__builtin_amdgcn_readfirstlane((int)chunk) * (size_t)cap * 8; // wave-uniform
         double ax = 0, ay = 0, az = 0, pot = 0;
         if(!FASTWRAP || any_lane(wrapped)) // a target on a wrapped image in this wave: NEAREST() per pair for all 8
-            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ring_g, ax, ay, az, pot);
+            eval_lists<POT, true, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, px, py, pz, s_wtab, ring_g, ax, ay, az, pot);
         else
-            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, zero_src, px, py, pz, s_wtab, ring_g, ax, ay, az, pot);
+            eval_lists<POT, false, O32>(tv, gp, L, cap, nleaf, nnode, s, gshift, px, py, pz, s_wtab, ring_g, ax, ay, az, pot);
         // reduce the partial sums over the 8 lanes of the group
         for(int off = 1; off < 8; off <<= 1) {
             ax += __shfl_xor(ax, off);
@@ -1041,7 +1211,8 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
     MPG_CHECK(tv.npart < (1ll << 29), "split walk: more than 2^29 particles in one tree");
     ws.ctr.reserve(16);
     // 32-bit byte offsets into the source and node arrays (32-byte records, padding included)?
-    const bool o32 = !ws.split_offsets64 && (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32);
+    MPG_CHECK(tv.srcL != nullptr, "split walk: the tree carries no padded leaf sources (TreeBuilder::ensure_leaf_pad)");
+    const bool o32 = !ws.split_offsets64 && (tv.npart + tv.nnodes + 64) * 32 < (1ll << 32) && (tv.nnodes + 2) * 256 < (1ll << 32);
 #define MPG_WS(P, C)                                                \
     do {                                                            \
         if(fastwrap) {                                              \

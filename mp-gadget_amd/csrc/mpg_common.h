@@ -118,6 +118,8 @@ struct TreeView {
     const double *hsmaxS = nullptr;
     // search links of the SPH loops (TreeBuilder::calc_search_links), or null: linkB with the small internal nodes as leaves
     const NodeLinkB *linkS = nullptr;
+    // the leaves' particles in blocks of 8 records by level-order node number, zero-mass filled (TreeBuilder::ensure_leaf_pad), or null
+    const Src4 *srcL = nullptr;
     double box = 0;
 };
 

@@ -80,6 +80,11 @@ struct TreeBuilder {
     DevBuf<NodeGeo> geoS;
     DevBuf<double> hsmaxS;
     bool has_boxes = false, has_hsmax = false;
+    // the leaves' particles as blocks of 8 source records indexed by the leaf's level-order node number, short leaves filled up with
+    // zero-mass records (the evaluation kernel of the two-kernel gravity walk, grav_walk_split.hip): [(nnodes + 1) * 8], the last block
+    // all zero-mass
+    DevBuf<Src4> srcL;
+    bool has_leaf_pad = false;
     // search links of the SPH loops (level order): linkB with every internal node of <= slink_cap particles turned into a leaf
     DevBuf<NodeLinkB> linkS;
     bool has_slinks = false;
@@ -100,6 +105,8 @@ struct TreeBuilder {
     // d_flag_later: a zeroed device word the kernel raises instead of the check + synchronisation here (the caller reads it later)
     void top_set(int La, const double *d_sums, hipStream_t st, int *d_flag_later = nullptr);
     void ensure_level_order(hipStream_t st);
+    // srcL (above) for the current tree; needs the level-ordered copy.  Positions and masses only: valid until the next build.
+    void ensure_leaf_pad(hipStream_t st);
     // The neighbour searches of the SPH loops need, per node, ANY region that contains the node's particles: the reference tests the
     // node's cell (cull_node, treewalk.c:1015-1042); the cube around the particles themselves is contained in it and lets a search drop
     // leaves (a cell split at its 9th particle leaves children of one or two: points and short segments inside cells a mean spacing wide)

@@ -612,6 +612,38 @@ void TreeBuilder::calc_search_links(int cap, hipStream_t st)
     slink_cap = cap;
 }
 
+// the particles of leaf i (level order) as the 8 records srcL[8 i ..]: one thread per record; a slot beyond the leaf's count holds a
+// zero-mass record at the leaf's first particle (any finite position will do: its pair evaluates to exactly zero)
+__global__ void __launch_bounds__(256) k_pad_leaves(int64_t nnodes, const NodeLinkB *__restrict__ linkB, const Src4 *__restrict__ src, Src4 *__restrict__ srcL)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t >> 3;
+    const int s = (int)(t & 7);
+    if(i > nnodes)
+        return;
+    Src4 r{0, 0, 0, 0};
+    if(i < nnodes) {
+        const NodeLinkB lk = linkB[i];
+        if(lk.pcount <= 0)
+            return; // (an internal node's block is never read)
+        r = src[lk.pstart + (s < lk.pcount ? s : 0)];
+        if(s >= lk.pcount)
+            r.m = 0;
+    }
+    srcL[t] = r;
+}
+
+void TreeBuilder::ensure_leaf_pad(hipStream_t st)
+{
+    ensure_level_order(st);
+    if(has_leaf_pad)
+        return;
+    srcL.reserve(((size_t)nnodes + 1) * 8 + 8);
+    hipLaunchKernelGGL(k_pad_leaves, dim3(nblk((nnodes + 1) * 8)), dim3(256), 0, st, nnodes, linkB.p, src.p, srcL.p);
+    MPG_HIP(hipGetLastError());
+    has_leaf_pad = true;
+}
+
 void TreeBuilder::ensure_level_order(hipStream_t st)
 {
     if(!has_bfs)
@@ -657,6 +689,7 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     has_boxes = false;
     has_hsmax = false;
     has_slinks = false;
+    has_leaf_pad = false;
     if(tm)
         tm->start(st);
     keys_a.reserve(n + 1);
@@ -943,6 +976,7 @@ TreeView TreeBuilder::view() const
         v.geoS = has_boxes ? geoS.p : nullptr;
         v.hsmaxS = (has_boxes && has_hsmax) ? hsmaxS.p : nullptr;
         v.linkS = has_slinks ? linkS.p : nullptr;
+        v.srcL = has_leaf_pad ? srcL.p : nullptr;
     }
     v.box = box;
     return v;
