@@ -389,6 +389,7 @@ static GravParams make_gp(mpg_engine *eng, double rho0)
     MPG_CHECK(gp.h > 0, "grav_short_tree called before gravshort_set_softenings");
     gp.hinv = 1.0 / gp.h;
     gp.h3inv = 1.0 / gp.h / gp.h / gp.h;
+    gp.h2 = gp.h * gp.h;
     gp.inv_cell_dx = 1.0 / (cellsize * eng->tab_dx);
     gp.errtol = eng->treepar.ErrTolForceAcc;
     gp.use_bh = eng->treepar.TreeUseBH != 0;

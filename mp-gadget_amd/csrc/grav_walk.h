@@ -47,7 +47,9 @@ struct WalkScratch {
     bool split_overlap = false;       // true: build the lists of slice k+1 on a second stream while slice k is evaluated (two list areas);
                                       // the default of round 1, measured slower than serial slices in round 2 (see split_slice)
     bool split_offsets64 = false;     // take the 64-bit-offset variants of the kernels whatever the array sizes (tests: the forms a 512^3 tree needs)
-    int split_chunks_per_wave = 2;    // 0: persistent grids; > 0: chunks of 8 targets per wave (needed for the kernels to share CUs)
+    int split_chunks_per_wave = 1;    // 0: persistent grids; > 0: chunks of 8 targets per wave.  Blocks that are dispatched in tree order keep the
+                                      // resident waves on neighbouring targets (256^3, walk ms at 1 / 2 / 4 / 8 / 32 / 128 chunks and persistent:
+                                      // 62.3 / 62.7; 58.8 / 59.6 / 60.8 / 64.5 / 69.6 / 74.2 on two boxes)
     hipStream_t split_stream = nullptr;
     hipEvent_t ev_lists[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_begin = nullptr;
     ~WalkScratch()

@@ -204,7 +204,7 @@ __device__ __forceinline__ void pair_force(const Src4 s, const double dx, const 
 {
     PairTmp t;
     pair_pre(s, dx, dy, dz, t);
-    if(t.r2 < gp.h * gp.h)
+    if(t.r2 < gp.h2)
         pair_soft(gp, t);
     pair_post<POT>(t, gp, wtab, ax, ay, az, pot);
 }
@@ -861,7 +861,7 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
         // the dependent arithmetic: here both records of a trip are needed at its start and are requested only after the previous
         // trip's first half, i.e. closer to their use than in the alternating form below.
         MPG_LOAD(eb, B);
-        const double h2 = gp.h * gp.h;
+        const double h2 = gp.h2;
 #pragma unroll 1
         for(int e = 0; e < wmax; e += 2) {
             if((e & 7) == 0) {
@@ -1000,6 +1000,15 @@ __device__ __forceinline__ void eval_lists(const TreeView &tv, const GravParams 
 #undef MPG_NODE_AT
 }
 
+// grav_short_postprocess for the potential, gravshort.h:88-96.  Out of line: inlined, the constants of pow()'s expansion were hoisted out of
+// the loop over the wave's chunks and cost the evaluation loops two registers (spilled: 1 KB of scratch per wave)
+__device__ __attribute__((noinline)) double potential_postprocess(double pot, const double m, const double h, const double cbrtrho0, const double G)
+{
+    pot += m / (h / 2.8);
+    pot -= 2.8372975 * pow(m, 2.0 / 3) * cbrtrho0;
+    return pot * G;
+}
+
 template <bool POT, bool FASTWRAP, bool O32, int BLK>
 __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const GravParams gp, const WalkIO io, const unsigned *__restrict__ lists,
                                                     const int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots)
@@ -1077,14 +1086,8 @@ __global__ void __launch_bounds__(256, BLK) k_walk_eval(const TreeView tv, const
             io.accel[3 * (int64_t)ci + 0] = ax * gp.G;
             io.accel[3 * (int64_t)ci + 1] = ay * gp.G;
             io.accel[3 * (int64_t)ci + 2] = az * gp.G;
-            if(POT && io.potential) {
-                const double m = (double)io.mass[ci];
-                double p = pot;
-                p += m / (gp.h / 2.8);
-                p -= 2.8372975 * pow(m, 2.0 / 3) * gp.cbrtrho0;
-                p *= gp.G;
-                io.potential[ci] = p;
-            }
+            if(POT && io.potential)
+                io.potential[ci] = potential_postprocess(pot, (double)io.mass[ci], gp.h, gp.cbrtrho0, gp.G);
         }
     }
 }
@@ -1152,7 +1155,8 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
         }
         MPG_HIP(hipEventCreateWithFlags(&ws.ev_begin, hipEventDisableTiming));
     }
-    const int cpw = ws.split_chunks_per_wave;
+    static const int cpw_env = getenv("MPG_SPLIT_CPW") ? atoi(getenv("MPG_SPLIT_CPW")) : -1; // experiment knob
+    const int cpw = cpw_env >= 0 ? cpw_env : ws.split_chunks_per_wave;
     hipStream_t sl = overlap ? ws.split_stream : st; // list construction runs one slice ahead of the evaluation
     if(overlap) {
         MPG_HIP(hipEventRecord(ws.ev_begin, st)); // tree, counters and the control words are ready

@@ -127,6 +127,7 @@ struct GravParams {
     double box, invbox;
     double rcut, rcut2;
     double h, hinv, h3inv; // FORCE_SOFTENING and powers
+    double h2;             // h * h (a kernel argument, i.e. a scalar register: computed in the kernel it occupied a vector register pair)
     double inv_cell_dx;    // 1 / (cellsize * table dx)
     double errtol;         // ErrTolForceAcc
     double bhangle2;       // opening angle squared in effect for this walk

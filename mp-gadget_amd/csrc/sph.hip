@@ -391,6 +391,11 @@ __global__ void __launch_bounds__(256, 4) k_density(const TreeView tv, const Sph
     __shared__ unsigned s_stack[4 * 8 * SPH_STK];
     __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
     __shared__ unsigned s_llist[4 * 8 * SPH_LCAP];
+#ifdef MPG_EXP_LDSPAD_SPH // timing experiment: fewer resident blocks per CU with the same code (bytes of unused LDS)
+    __shared__ unsigned s_pad[MPG_EXP_LDSPAD_SPH / 4];
+    if(tv.box < 0)
+        s_pad[threadIdx.x] = 1u, s_llist[0] = s_pad[(threadIdx.x + 1) & 255];
+#endif
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;
@@ -811,6 +816,11 @@ __global__ void __launch_bounds__(256, 4) k_hydro(const TreeView tv, const SphVi
     __shared__ unsigned s_stack[4 * 8 * SPH_STK];
     __shared__ int s_cbuf[4 * 8 * SPH_CBUF];
     __shared__ unsigned s_llist[4 * 8 * SPH_LCAP];
+#ifdef MPG_EXP_LDSPAD_SPH // timing experiment: fewer resident blocks per CU with the same code (bytes of unused LDS)
+    __shared__ unsigned s_pad[MPG_EXP_LDSPAD_SPH / 4];
+    if(tv.box < 0)
+        s_pad[threadIdx.x] = 1u, s_llist[0] = s_pad[(threadIdx.x + 1) & 255];
+#endif
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, s = lane & 7, gshift = grp * 8;
     unsigned *stack = s_stack + ((threadIdx.x >> 6) * 8 + grp) * SPH_STK;

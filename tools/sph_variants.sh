@@ -6,7 +6,7 @@ cd $ROOT
 for f in "$@"; do
     if [ -n "$f" ]; then export MPG_EXTRA_FLAGS="sph.hip:$f"; else unset MPG_EXTRA_FLAGS; fi
     python mp-gadget_amd/build.py > /dev/null 2>&1 || echo "build failed: $f"
-    python bench.py --workload hydro --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
+    python bench.py --workload hydro --steps 8 --warmup 2 --no-live-traffic 2>/dev/null | tail -1 | python -c "
 import sys,json; j=json.loads(sys.stdin.read()); p=j['phases_ms']; print('[%s] density %.3f hydro %.3f step %.2f' % ('$f', p['density'], p['hydro'], j['ms_per_step']))"
 done
 unset MPG_EXTRA_FLAGS
