@@ -1179,7 +1179,8 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
                 MPG_HIP(hipEventCreate(&e));
             MPG_HIP(hipEventRecord(te[0], sl));
         }
-        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks, cpw)), dim3(256), 0, sl, tv, gp, io,
+        // (a counting walk ends every wave with 7 atomic adds on the same words: fewer, longer-lived waves there)
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_blocks(ws, (const void *)kl, nchunks, (COUNT && cpw > 0 && cpw < 8) ? 8 : cpw)), dim3(256), 0, sl, tv, gp, io,
                            lists, counts, cap, s0, ns, ws.ctr.p, ws.split_ovf.p);
         if(split_time)
             MPG_HIP(hipEventRecord(te[1], sl));
