@@ -74,6 +74,8 @@ void mpg_engine_destroy(mpg_engine *eng)
         (void)hipStreamDestroy(eng->aux_stream);
         (void)hipEventDestroy(eng->ev_inputs);
         (void)hipEventDestroy(eng->ev_tree_done);
+        if(eng->ev_pad_done)
+            (void)hipEventDestroy(eng->ev_pad_done);
     }
     if(eng->own_stream && eng->stream)
         (void)hipStreamDestroy(eng->stream);
@@ -243,6 +245,7 @@ int mpg_dev_gravpm_force(mpg_engine *eng, double *d_gravpm, double *d_potential)
             MPG_HIP(hipStreamCreateWithFlags(&eng->aux_stream, hipStreamNonBlocking));
             MPG_HIP(hipEventCreateWithFlags(&eng->ev_inputs, hipEventDisableTiming));
             MPG_HIP(hipEventCreateWithFlags(&eng->ev_tree_done, hipEventDisableTiming));
+            MPG_HIP(hipEventCreateWithFlags(&eng->ev_pad_done, hipEventDisableTiming));
         }
         MPG_HIP(hipEventRecord(eng->ev_inputs, eng->stream)); // everything queued so far: the particle arrays are final, the last walk is done
         eng->pm_queued = true;
@@ -326,17 +329,28 @@ int mpg_dev_pm_slab_readout(mpg_engine *eng, const double *ghost_recv, const int
 // What the default walk kernels read beside the depth-first tree - the level-ordered copy and the leaves' particles in blocks of 8 - made
 // with the tree, on the tree's stream (beside the PM force when one is queued), not at the start of the walk (rounds 1-5: 0.5 ms of every
 // walk at 256^3).  Not when the phases are being timed (the tree's phases are its own) or another kernel was selected.
-static void tree_walk_copies(mpg_engine *eng, hipStream_t st)
+static bool tree_walk_copies(mpg_engine *eng, hipStream_t st, bool leaf_blocks = true)
 {
     if(eng->timer.enabled || !(eng->walk_variant == 0 || eng->walk_variant == 6) || eng->tree.npart < 4096)
-        return;
+        return false;
     eng->tree.ensure_level_order(st);
-    eng->tree.ensure_leaf_pad(st);
+    if(leaf_blocks)
+        eng->tree.ensure_leaf_pad(st);
+    return true;
+}
+
+// a tree build on `st` overwrites what a leaf-block kernel still running on the tree stream reads
+static void wait_for_leaf_blocks(mpg_engine *eng, hipStream_t st)
+{
+    if(eng->pad_pending && st != eng->aux_stream)
+        MPG_HIP(hipStreamWaitEvent(st, eng->ev_pad_done, 0));
+    eng->pad_pending = false;
 }
 
 void engine_tree_build_on(mpg_engine *eng, int mask, hipStream_t st)
 {
     eng->pm_queued = false;
+    wait_for_leaf_blocks(eng, st);
     eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, st, nullptr);
     eng->tree.calc_moments(nullptr, st, nullptr);
     tree_walk_copies(eng, st);
@@ -353,15 +367,22 @@ int mpg_dev_force_tree_build(mpg_engine *eng, int mask)
     if(eng->pm_queued && !eng->timer.enabled) {
         // next to the PM force queued on the main stream; whatever is queued on the main stream after this call waits for the tree
         eng->pm_queued = false;
+        eng->pad_pending = false; // (a leaf-block kernel of the last tree runs on this same stream: ordered)
         MPG_HIP(hipStreamWaitEvent(eng->aux_stream, eng->ev_inputs, 0));
         eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->aux_stream, nullptr);
         eng->tree.calc_moments(nullptr, eng->aux_stream, nullptr);
-        tree_walk_copies(eng, eng->aux_stream);
+        const bool copies = tree_walk_copies(eng, eng->aux_stream, false);
         MPG_HIP(hipEventRecord(eng->ev_tree_done, eng->aux_stream));
         MPG_HIP(hipStreamWaitEvent(eng->stream, eng->ev_tree_done, 0));
+        if(copies) { // the leaf blocks are read by the walk's SECOND kernel only: made behind the event, beside the list kernel
+            eng->tree.ensure_leaf_pad(eng->aux_stream);
+            MPG_HIP(hipEventRecord(eng->ev_pad_done, eng->aux_stream));
+            eng->pad_pending = true;
+        }
     }
     else {
         eng->pm_queued = false;
+        wait_for_leaf_blocks(eng, eng->stream);
         eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
         eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
         tree_walk_copies(eng, eng->stream);
@@ -499,8 +520,10 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     auto run_variant_io = [&](int v, const WalkIO &w) {
         if(v != 1)
             eng->tree.ensure_level_order(eng->stream); // variants 4 and 6 walk the level-ordered copy of the tree
-        if(v == 6)
+        if(v == 6) {
             eng->tree.ensure_leaf_pad(eng->stream);    // ... and 6 the leaves' particles in blocks of 8 (both made with the tree as a rule)
+            eng->w3.ev_before_eval = eng->pad_pending ? eng->ev_pad_done : nullptr;
+        }
         if(v == 1)
             launch_grav_walk(eng->tree.view(), gp, w, w.potential != nullptr, eng->count, fastwrap, eng->walk_thresh, eng->stream);
         else if(v == 6)
@@ -774,6 +797,7 @@ int mpg_dev_fof_fof(mpg_engine *eng, const mpg_fof_params *par, const uint64_t *
         hipLaunchKernelGGL(k_include_live, dim3((unsigned)((eng->n + 255) / 256)), dim3(256), 0, eng->stream, eng->n, d_flags, eng->tree_incl.p);
         incl = eng->tree_incl.p;
     }
+    wait_for_leaf_blocks(eng, eng->stream);
     eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, par->FOFPrimaryLinkTypes, eng->box, eng->stream, &eng->timer, incl);
     eng->tree_allocated = true;
     eng->tree_mask = par->FOFPrimaryLinkTypes;
@@ -1626,6 +1650,7 @@ int mpg_force_tree_rebuild_mask(mpg_engine *eng, const mpg_particle_view *P, dou
     MPG_CHECK(eng && P, "null argument");
     MPG_HIP(hipSetDevice(eng->device));
     stage_particles(eng, P, BoxSize);
+    wait_for_leaf_blocks(eng, eng->stream);
     eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, BoxSize, eng->stream, &eng->timer);
     eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
     eng->tree_allocated = true;
@@ -2188,6 +2213,7 @@ int mpg_dev_force_tree_rebuild_mask(mpg_engine *eng, int mask, int with_moments)
     API_BEGIN
     MPG_CHECK(eng, "null engine");
     MPG_HIP(hipSetDevice(eng->device));
+    wait_for_leaf_blocks(eng, eng->stream);
     eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer);
     if(with_moments)
         eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
@@ -2220,6 +2246,7 @@ int mpg_dev_force_tree_active_moments(mpg_engine *eng, const int *d_active, int6
                                eng->tree_incl.p);
         incl = eng->tree_incl.p;
     }
+    wait_for_leaf_blocks(eng, eng->stream);
     eng->tree.build(eng->n, eng->d_pos, eng->d_mass, eng->d_type, mask, eng->box, eng->stream, &eng->timer, incl);
     eng->tree.calc_moments(nullptr, eng->stream, &eng->timer);
     eng->tree_allocated = true;

@@ -169,7 +169,8 @@ struct mpg_engine {
     // force has just been queued, force_tree_build runs on this second stream next to it (engine-internal; MPG_NO_TREE_OVERLAP=1
     // keeps everything on one stream)
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_inputs = nullptr, ev_tree_done = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_tree_done = nullptr, ev_pad_done = nullptr;
+    bool pad_pending = false; // the leaf blocks of the current tree were queued on aux_stream behind ev_tree_done (ev_pad_done)
     bool pm_queued = false;
     // module state (static variables of gravshort-tree.c:30-32, gravity.c:20, forcetree.c:30-37)
     mpg_gravshort_tree_params treepar{0.002, 0.175, 0.9, 2, 6.0, 1.0 / 30.};
