@@ -282,6 +282,45 @@ def test_resident_walk_in_place_with_list_retry(pkg, engine, orc):
     assert np.abs(res["resident"] - res["host"]).max() <= 1e-12 * np.abs(a_ref).mean()
 
 
+def test_leaf_blocks_behind_the_tree_event(pkg, engine):
+    """Round 5: with a PM force queued, force_tree_build runs on the engine's second stream and queues the leaves' source blocks (the
+    evaluation kernel's input) BEHIND the event the main stream waits for, so that they are made beside the list kernel.  Every order of
+    calls must give the walk of a tree built on the main stream: walk at once; a second build on the main stream while the first one's
+    leaf-block kernel may still run (nothing waited for it); a gas-tree density in between is covered by the hydro tests."""
+    import torch
+    n, nmesh = 32, 64
+    pos, mass, box = pkg.ics.s_zel(n)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=1)   # (the geometric criterion: the lists do not depend on an earlier walk)
+    dev = torch.device("cuda", 0)
+    d_pos, d_mass = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev)
+    N = len(pos)
+    z3 = lambda: torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    gpm, pot = z3(), torch.zeros(N, dtype=torch.float64, device=dev)
+    engine.dev_bind_particles(d_pos, d_mass, box)
+    res = {}
+    try:
+        engine.set_walk_variant(6)
+        for mode in ("main_stream", "beside_pm", "beside_pm_then_rebuilt", "beside_pm_twice"):
+            acc, p2 = z3(), torch.zeros(N, dtype=torch.float64, device=dev)
+            if mode != "main_stream":
+                engine.dev_gravpm_force(gpm, pot)          # queues the PM force: the next build goes to the second stream
+            engine.dev_force_tree_build()
+            if mode == "beside_pm_then_rebuilt":
+                engine.dev_force_tree_build()              # (no PM queued any more: on the main stream, over the tree the leaf-block kernel reads)
+            if mode == "beside_pm_twice":
+                engine.dev_gravpm_force(gpm, pot)
+                engine.dev_force_tree_build()
+            engine.dev_grav_short_tree(acc, potential=p2)
+            torch.cuda.synchronize()
+            res[mode] = (acc.cpu().numpy(), p2.cpu().numpy())
+    finally:
+        engine.set_walk_variant(0)
+    a0, p0 = res["main_stream"]
+    assert np.isfinite(a0).all() and np.abs(a0).max() > 0
+    for mode, (a, p) in res.items():
+        assert np.array_equal(a, a0) and np.array_equal(p, p0), mode
+
+
 @pytest.mark.parametrize("ic", ["s_zel", "s_grid"])
 def test_walk_64bit_offset_kernels(pkg, engine, orc, ic):
     """The two-kernel walk has variants with 64-bit offsets into the source / node arrays, taken when those exceed 4 GiB (512^3 particles in
