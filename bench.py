@@ -804,7 +804,7 @@ def gravity_bench_single(pkg, torch, args, dev, local_rank):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    walk_ms, walk_launches = eng.walk_events_collect()
+    walk_ms, walk_launches, lists_ms, eval_ms, nsplit = eng.walk_events_collect_split()
     if args.traffic_child:      # (a child of live_walk_traffic under rocprofv3: the walks above are what it wanted)
         eng.close()
         return None
@@ -842,6 +842,9 @@ def gravity_bench_single(pkg, torch, args, dev, local_rank):
         "roofline": walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note),
         "phases_ms": {k: round(v, 3) for k, v in ph.items()},
     }
+    if nsplit:      # the walk's two kernels one by one (an event between them on the engine stream, inside the timed region)
+        out["roofline"]["kernels_ms"] = {"k_walk_lists8": round(lists_ms / nsplit, 3), "k_walk_eval": round(eval_ms / nsplit, 3), "launches_timed": nsplit,
+                                         "frac_of_k_walk_eval_alone": round(out["roofline"]["frac"] * (walk_ms / walk_launches) / (eval_ms / nsplit), 4)}
     if os.environ.get("MPG_BENCH_TREEUSEBH") or os.environ.get("MPG_BENCH_BHANGLE"):   # (a diagnostic run: not BASELINE's configuration)
         out["config"]["workload"] += " -- DIAGNOSTIC: TreeUseBH=%s BHOpeningAngle=%s from the environment" % (
             os.environ.get("MPG_BENCH_TREEUSEBH", "2"), os.environ.get("MPG_BENCH_BHANGLE", "0.175"))

@@ -321,6 +321,8 @@ int mpg_set_instrumentation(mpg_engine *eng, int timing, int counters);
 /* HIP events are recorded (without synchronising) on the engine stream around every walk-kernel launch.  This call
  * synchronises the stream, returns the summed duration (ms) and number of launches since the last collect. */
 int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count);
+/* ... and, of the walks that ran as ONE list kernel + ONE evaluation kernel, the two kernels' times (an event between them) */
+int mpg_walk_events_collect2(mpg_engine *eng, double *total_ms, int *count, double *lists_ms, double *eval_ms, int *count_split);
 /* Device pointer to the tree-order permutation (int32 [NumParticles]: tree slot -> caller index) of the current tree;
  * a contiguous slice of it is a spatially compact active list (used to shard targets over GPUs). */
 const int *mpg_dev_tree_order(mpg_engine *eng);

@@ -50,6 +50,10 @@ void mpg_engine_destroy(mpg_engine *eng)
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+    for(auto &v : {&eng->walk_mid, &eng->free_mid})
+        for(auto &e : *v)
+            if(e)
+                (void)hipEventDestroy(e);
     eng->host_join();
     for(auto &e : eng->chunk_ev)
         if(e)
@@ -513,6 +517,15 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         MPG_HIP(hipEventCreate(&ev.second));
     }
     MPG_HIP(hipEventRecord(ev.first, eng->stream));
+    hipEvent_t mid = nullptr;
+    if(!eng->free_mid.empty()) {
+        mid = eng->free_mid.back();
+        eng->free_mid.pop_back();
+    }
+    else
+        MPG_HIP(hipEventCreate(&mid));
+    eng->w3.ev_mid = mid;
+    eng->w3.mid_recorded = false;
     // hoisting the minimum-image wrap out of the pair loop is valid when every source range shares the image of its
     // node: Rcut + 1.5 * (largest leaf side) < Box/2, and Rcut well below Box/4 (see grav_walk_coop.hip)
     const double maxleaf = 1.001 * gp.box / (double)(1 << eng->tree.minleaflevel);
@@ -551,9 +564,19 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         run_variant(variant);
     MPG_HIP(hipEventRecord(ev.second, eng->stream));
     eng->walk_events.push_back(ev);
+    eng->w3.ev_mid = nullptr;
+    if(eng->w3.mid_recorded)
+        eng->walk_mid.push_back(mid);
+    else {
+        eng->walk_mid.push_back(nullptr);
+        eng->free_mid.push_back(mid);
+    }
     if(eng->walk_events.size() > 4096) { // nobody is collecting: recycle the oldest
         eng->free_events.push_back(eng->walk_events.front());
         eng->walk_events.erase(eng->walk_events.begin());
+        if(eng->walk_mid.front())
+            eng->free_mid.push_back(eng->walk_mid.front());
+        eng->walk_mid.erase(eng->walk_mid.begin());
     }
     eng->timer.lap(eng->stream, &eng->timer.t.walk);
     eng->timer.t.walk_launches = 1;
@@ -2769,26 +2792,48 @@ int mpg_set_instrumentation(mpg_engine *eng, int timing, int counters)
     API_END
 }
 
-int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count)
+int mpg_walk_events_collect2(mpg_engine *eng, double *total_ms, int *count, double *lists_ms, double *eval_ms, int *count_split)
 {
     API_BEGIN
     MPG_CHECK(eng && total_ms && count, "null argument");
     MPG_HIP(hipSetDevice(eng->device));
     MPG_HIP(hipStreamSynchronize(eng->stream));
-    double tot = 0;
-    int c = 0;
-    for(auto &ev : eng->walk_events) {
+    double tot = 0, tl = 0, te = 0;
+    int c = 0, cs = 0;
+    for(size_t k = 0; k < eng->walk_events.size(); k++) {
+        auto &ev = eng->walk_events[k];
         float ms = 0;
         MPG_HIP(hipEventSynchronize(ev.second));
         MPG_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
         tot += ms;
         c++;
+        if(hipEvent_t mid = k < eng->walk_mid.size() ? eng->walk_mid[k] : nullptr) {
+            float a = 0, b = 0;
+            MPG_HIP(hipEventElapsedTime(&a, ev.first, mid));
+            MPG_HIP(hipEventElapsedTime(&b, mid, ev.second));
+            tl += a;
+            te += b;
+            cs++;
+            eng->free_mid.push_back(mid);
+        }
         eng->free_events.push_back(ev);
     }
     eng->walk_events.clear();
+    eng->walk_mid.clear();
     *total_ms = tot;
     *count = c;
+    if(lists_ms)
+        *lists_ms = tl;
+    if(eval_ms)
+        *eval_ms = te;
+    if(count_split)
+        *count_split = cs;
     API_END
+}
+
+int mpg_walk_events_collect(mpg_engine *eng, double *total_ms, int *count)
+{
+    return mpg_walk_events_collect2(eng, total_ms, count, nullptr, nullptr, nullptr);
 }
 
 const int *mpg_dev_tree_order(mpg_engine *eng) { return (eng && eng->tree_allocated) ? (const int *)eng->tree.idx_b.p : nullptr; }

@@ -199,6 +199,8 @@ struct mpg_engine {
     float *d_walk_cost = nullptr; // per-target work of the walks, caller order (mpg_dev_set_walk_cost; null: not recorded)
     // un-synchronised HIP event pairs around every walk launch (collected by mpg_walk_events_collect)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> walk_events, free_events;
+    // ... and, per walk, the event between the two kernels of a one-slice two-kernel walk (null otherwise)
+    std::vector<hipEvent_t> walk_mid, free_mid;
     // SPH module state (static variables of density.c:20, hydra.c:26-34)
     mpg_density_params denspar{1.0, 2.0, 2.0, 99999., 2 /* quintic */, 0.006};
     mpg_hydro_params hydropar{1, 100.0, 0.75};

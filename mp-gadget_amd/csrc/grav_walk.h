@@ -50,6 +50,8 @@ struct WalkScratch {
     int split_chunks_per_wave = 1;    // 0: persistent grids; > 0: chunks of 8 targets per wave.  Blocks that are dispatched in tree order keep the
                                       // resident waves on neighbouring targets (256^3, walk ms at 1 / 2 / 4 / 8 / 32 / 128 chunks and persistent:
                                       // 62.3 / 62.7; 58.8 / 59.6 / 60.8 / 64.5 / 69.6 / 74.2 on two boxes)
+    hipEvent_t ev_mid = nullptr;     // (not owned) recorded between the list kernel and the evaluation kernel of a one-slice walk (bench: the two kernels' times)
+    bool mid_recorded = false;
     hipEvent_t ev_before_eval = nullptr; // (not owned) recorded when the tree's leaf blocks are complete: the evaluation kernel waits for it, the list kernel does not need them
     hipStream_t split_stream = nullptr;
     hipEvent_t ev_lists[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_begin = nullptr;

@@ -1188,6 +1188,10 @@ void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, 
             MPG_HIP(hipEventRecord(ws.ev_lists[b], sl));
             MPG_HIP(hipStreamWaitEvent(st, ws.ev_lists[b], 0));
         }
+        if(ws.ev_mid && nslices == 1 && !overlap) {
+            MPG_HIP(hipEventRecord(ws.ev_mid, st));
+            ws.mid_recorded = true;
+        }
         if(ws.ev_before_eval && i == 0)
             MPG_HIP(hipStreamWaitEvent(st, ws.ev_before_eval, 0)); // the leaf blocks, made on the tree's stream beside the list kernel
         hipLaunchKernelGGL(ke, dim3((unsigned)grid_blocks(ws, (const void *)ke, nchunks, cpw)), dim3(256), 0, st, tv, gp, io, lists, counts, cap, s0,

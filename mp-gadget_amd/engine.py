@@ -764,6 +764,14 @@ class Engine:
         self._ck(self.lib.mpg_walk_events_collect(self.h, C.byref(tot), C.byref(cnt)))
         return tot.value, cnt.value
 
+    def walk_events_collect_split(self):
+        """(total_ms, launches, lists_ms, eval_ms, split_launches): as walk_events_collect, with the two kernels' times of the walks that
+        ran as one list kernel + one evaluation kernel."""
+        tot, tl, te = C.c_double(), C.c_double(), C.c_double()
+        cnt, cs = C.c_int(), C.c_int()
+        self._ck(self.lib.mpg_walk_events_collect2(self.h, C.byref(tot), C.byref(cnt), C.byref(tl), C.byref(te), C.byref(cs)))
+        return tot.value, cnt.value, tl.value, te.value, cs.value
+
     def dev_tree_order(self, n, device):
         """Zero-copy int32 torch view of the engine-owned tree-order permutation (tree slot -> caller index)."""
         import torch

@@ -34,6 +34,10 @@ def test_default_workload_line():
     # alone are 4 B per entry written once and read once
     assert r["traffic"] and "measured in this run" in r["traffic_note"], r["traffic_note"]
     assert r["traffic"] > 8 * (r["leaf_entries_per_launch"] + r["node_entries_per_launch"]) and 0 < r["hbm_measured_frac"] < 1
+    # the walk's two kernels one by one (an event between them inside the timed region)
+    k = r["kernels_ms"]
+    assert k["launches_timed"] == j["steps"] and k["k_walk_lists8"] > 0 and k["k_walk_eval"] > 0
+    assert abs(k["k_walk_lists8"] + k["k_walk_eval"] - r["avg_launch_ms"]) < 0.05 * r["avg_launch_ms"] + 0.05
     cb = j["cpu_baseline"]
     assert cb["physical_cores"] >= 1 and len(cb["walk_s_all"]) == 3 and cb["cpu_model"] and cb["processes"] >= 1
     assert cb["cores"] == sum(cb["threads_per_process"]) and cb["pairs_per_s_per_thread"] > 1e6 and cb["tree_build_own_share_s"] >= 0
