@@ -331,7 +331,10 @@ __device__ __forceinline__ void node_test_masks(const GravParams &gp, const Node
 // go back to the frontier (one entry per child: a prefix sum over the lanes by four ballots).
 // Per target the set of nodes tested and the outcome of every test are exactly those of its own walk (a node reaches the frontier
 // with bit t set iff target t opened its parent); the ORDER of a target's list entries depends on its 7 wave-mates.
-constexpr int QCAP = 1024; // frontier entries per wave (node index 4 B + target mask 1 B); a wave that would exceed it hands its targets to the fallback
+#ifndef MPG_QCAP
+#define MPG_QCAP 1024
+#endif
+constexpr int QCAP = MPG_QCAP; // frontier entries per wave (node index 4 B + target mask 1 B); a wave that would exceed it hands its targets to the fallback
 
 __device__ __forceinline__ unsigned mbcnt64(const unsigned long long b)
 {
