@@ -77,6 +77,9 @@ def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
          "node_steps_per_launch": cnt["node_steps"], "node_lanes_per_launch": cnt["node_lanes"],
          "leaf_entries_per_launch": cnt["int_steps"] if variant == 6 else None,
          "node_entries_per_launch": cnt["int_lanes"] if variant == 6 else None,
+         # round 6: target passes of the list kernel whose fp32 pre-classification was ambiguous and that ran the fp64 tests instead
+         # (counted by the COUNT builds; every other pass took its decisions from fp32 - DESIGN 3.2, round 6)
+         "fp32_fallback_passes_per_launch": cnt["cycles_a"] if variant == 6 else None,
          "note": "one launch = one short-range walk over all targets; the walk is bound by fp64 VALU issue (pairwise kernel with a "
                  "per-pair window-table lookup; MFMA does not apply), so frac = 38 flop x (N_pp + N_nodes_used) / t / 78.6 TFLOP/s; "
                  "hbm_measured_frac = PMC traffic / t / 8 TB/s; reuse = SURVEY 8(d) B_walk / PMC traffic"}

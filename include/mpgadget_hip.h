@@ -447,6 +447,24 @@ int mpg_dev_find_hydro_timesteps(mpg_engine *eng, const mpg_hydrostep_arrays *A,
  * set_bh_first_timestep on the first step (d_type / d_tb_hydro of n particles; may be NULL when isFirstTimeStep == 0), times->mintimebin */
 int mpg_dev_hydro_timesteps_finish(mpg_engine *eng, int mTimeBin_global, int isFirstTimeStep, int64_t n, const unsigned char *d_type,
                                    unsigned char *d_tb_hydro, mpg_drift_kick_times *times);
+/* find_timesteps (timestep.c:739-849): the step assignment of a run WITHOUT SplitGravityTimestepsOn (run.c:756) - gravity step from
+ * FullTreeGravAccel + GravPM (get_timestep_gravity_dloga), for gas / black holes the hydro step where it is shorter, TimeBinHydro and
+ * TimeBinGravity both set to the new bin when old and new bin are active.  On a PM step (Ti_Current == PM_start + PM_length) dti_max_pm is the
+ * caller's get_PM_timestep_ti and times->PM_length / PM_start are updated as the reference does; the finish call (after the caller's
+ * MPI_Allreduce of mTimeBin (MIN), maxTimeBin (MAX) and the counts, where it has ranks) shrinks the PM step onto the longest tree step and
+ * sets times->mintimebin / maxtimebin.  Not carried: ForceEqualTimesteps, set_bh_first_timestep (the caller keeps both). */
+typedef struct {
+    int mTimeBin, maxTimeBin;   /* smallest / largest new bin among this rank's active particles (MPG_TIMEBINS / 0 if it has none) */
+    int isPM;                   /* this was a PM step */
+    int64_t ntitype[5];         /* particles by criterion: TI_ACCEL, TI_COURANT, TI_ACCRETE, TI_NEIGH, TI_HSML */
+    int64_t badstepsizecount;   /* bin < 1 (the function's return value in the reference) */
+    int64_t badtimebins;        /* print_bad_timebin cases: dti <= 1 or > TIMEBASE */
+} mpg_timestep_result;
+int mpg_dev_find_timesteps(mpg_engine *eng, const mpg_hydrostep_arrays *A, const double *d_fulltree_accel, const double *d_gravpm,
+                           unsigned char *d_tb_grav, const int *d_active, int64_t NumActiveParticle, mpg_drift_kick_times *times,
+                           const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac, double atime, double hubble,
+                           int64_t dti_max_pm, mpg_timestep_result *out);
+int mpg_find_timesteps_finish(int mTimeBin_global, int maxTimeBin_global, int isPM, mpg_drift_kick_times *times);
 /* A GAS run stays resident too (round 5).  mpg_resident_sph_begin, on a resident table, uploads every array of `A` (host arrays in
  * particle order, as the host forms mpg_density / mpg_hydro_force take them) ONCE; its vel / gacc / gpm then alias the resident
  * P[].Vel / FullTreeGravAccel / GravPM, and the *_in arrays of the velocity / entropy prediction alias the *_out arrays (SphP.HydroAccel,
@@ -455,6 +473,7 @@ int mpg_dev_hydro_timesteps_finish(mpg_engine *eng, int mTimeBin_global, int isF
  *   mpg_resident_drift_all_particles   drift_all_particles (drift.c:84-102): Pos, and Hsml += DtHsml * ddrift for gas
  *   mpg_resident_apply_pm_half_kick    apply_PM_half_kick (timestep.c:964-985)
  *   mpg_resident_apply_half_kick       apply_half_kick (timestep.c:873-929): gravity kick, hydro kick, gas velocity limit, entropy
+ *   mpg_resident_find_timesteps        find_timesteps (timestep.c:739-849): the step assignment of run.c:756 (no SplitGravityTimestepsOn)
  *   mpg_resident_find_hydro_timesteps  find_hydro_timesteps (timestep.c:617-733) on TimeBinHydro (both halves, one rank; several ranks:
  *                                      mpg_dev_find_hydro_timesteps + the caller's MPI_Allreduce + mpg_dev_hydro_timesteps_finish on
  *                                      mpg_resident_sph_arrays)
@@ -463,11 +482,18 @@ int mpg_dev_hydro_timesteps_finish(mpg_engine *eng, int mTimeBin_global, int isF
 int mpg_resident_sph_begin(mpg_engine *eng, const mpg_particle_view *pv, const mpg_sph_arrays *A);
 int mpg_resident_sph_arrays(mpg_engine *eng, mpg_sph_arrays *device_arrays_out);
 int mpg_resident_sph_end(mpg_engine *eng, const mpg_sph_arrays *A);
+/* the resident time bins into host arrays of n bytes (either may be NULL): build_active_particles (timestep.c:1333-1420) reads
+ * P[].TimeBinHydro / TimeBinGravity on the host at the top of every step, so the shim copies them into P[] after every bin assignment */
+int mpg_resident_fetch_timebins(mpg_engine *eng, unsigned char *tb_hydro, unsigned char *tb_grav);
 int mpg_resident_drift_all_particles(mpg_engine *eng, const mpg_particle_view *pv, double ddrift, const double random_shift[3]);
 int mpg_resident_apply_pm_half_kick(mpg_engine *eng, const mpg_particle_view *pv, double Fgravkick);
 int mpg_resident_apply_half_kick(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
                                  const mpg_kick_factors *K);
 
+/* find_timesteps on a resident gas run, one rank (both halves): accelerations, Hsml, DtHsml, MaxSignalVel and the time bins are the resident ones */
+int mpg_resident_find_timesteps(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
+                                mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,
+                                double atime, double hubble, int64_t dti_max_pm, mpg_timestep_result *out);
 /* both halves on a resident gas run (mpg_resident_sph_begin), one rank: Hsml, DtHsml, MaxSignalVel and the time bins are the resident ones */
 int mpg_resident_find_hydro_timesteps(mpg_engine *eng, const mpg_particle_view *pv, const int *ActiveParticle, int64_t NumActiveParticle,
                                       mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,

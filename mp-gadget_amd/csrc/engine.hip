@@ -1162,6 +1162,77 @@ int mpg_dev_find_hydro_timesteps(mpg_engine *eng, const mpg_hydrostep_arrays *A,
     API_END
 }
 
+// find_timesteps (timestep.c:739-849), the step assignment of a run without SplitGravityTimestepsOn (run.c:756): the particle loop on the
+// device; the PM step (get_PM_timestep_ti) comes from the caller, the shrink of the PM step onto the longest tree step and
+// times->mintimebin / maxtimebin are done here as the reference does (one rank; several ranks reduce `out` first and call
+// mpg_find_timesteps_finish)
+int mpg_dev_find_timesteps(mpg_engine *eng, const mpg_hydrostep_arrays *A, const double *d_fulltree_accel, const double *d_gravpm,
+                           unsigned char *d_tb_grav, const int *d_active, int64_t NumActiveParticle, mpg_drift_kick_times *times,
+                           const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac, double atime, double hubble,
+                           int64_t dti_max_pm, mpg_timestep_result *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && A && times && timeline && par && out && d_fulltree_accel && d_gravpm && d_tb_grav, "null argument");
+    MPG_CHECK(A->d_tb_hydro, "find_timesteps: TimeBinHydro is needed");
+    MPG_CHECK(!A->d_type || (A->d_hsml && A->d_maxsignalvel), "find_timesteps: gas needs Hsml and MaxSignalVel");
+    MPG_CHECK(timeline->nsync >= 2 && timeline->loga, "find_timesteps: the timeline needs at least two sync points");
+    MPG_CHECK(eng->GravitySoftening > 0, "timestep: gravshort_set_softenings has not been called");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int64_t nact = d_active ? NumActiveParticle : eng->n;
+    // is_PM_timestep, timestep.c:153-159; the new PM step, timestep.c:748-755
+    MPG_CHECK(times->Ti_Current <= times->PM_start + times->PM_length, "Passed end of PM step!");
+    const bool isPM = times->Ti_Current == times->PM_start + times->PM_length;
+    int64_t dti_max = times->PM_length;
+    if(isPM) {
+        dti_max = dti_max_pm;
+        times->PM_length = dti_max;
+        times->PM_start = times->PM_kick;
+    }
+    eng->hier_sp.reserve((size_t)timeline->nsync + MPG_TIMEBINS + 2);
+    MPG_HIP(hipMemcpyAsync(eng->hier_sp.p, timeline->loga, (size_t)timeline->nsync * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+    double bins[MPG_TIMEBINS + 1];
+    const double logDTime = host_dloga_interval(timeline, times->Ti_Current);
+    for(int b = 0; b <= MPG_TIMEBINS; b++)
+        bins[b] = (double)dti_from_timebin(b) * logDTime;
+    double *d_bins = eng->hier_sp.p + timeline->nsync;
+    MPG_HIP(hipMemcpyAsync(d_bins, bins, sizeof(bins), hipMemcpyHostToDevice, eng->stream));
+    HierTimeline T;
+    T.sp = eng->hier_sp.p;
+    T.nsync = (int)timeline->nsync;
+    T.loga_cur = host_loga_from_ti(timeline, times->Ti_Current);
+    T.ti0 = host_ti_from_loga(timeline, T.loga_cur);
+    T.MinSizeTimestep = par->MinSizeTimestep;
+    eng->hier_cnt.reserve(64);
+    unsigned long long h[9] = {0, 0, 0, 0, 0, 0, 0, (unsigned long long)MPG_TIMEBINS, 0};
+    MPG_HIP(hipMemcpyAsync(eng->hier_cnt.p, h, sizeof(h), hipMemcpyHostToDevice, eng->stream));
+    const double fac3 = pow(atime, 3 * (1 - 5.0 / 3.0) / 2.0);
+    launch_find_timesteps(d_active, nact, A->d_type, A->d_flags, d_fulltree_accel, d_gravpm, A->d_hsml, A->d_dthsml, A->d_maxsignalvel,
+                          A->d_bh_mintimebin, d_bins, d_tb_grav, A->d_tb_hydro, atime, hubble, par->ErrTolIntAccuracy, 2.8 * eng->GravitySoftening, CourantFac,
+                          fac3, T, dti_max, times->Ti_Current, eng->hier_cnt.p, eng->stream);
+    MPG_HIP(hipMemcpyAsync(h, eng->hier_cnt.p, sizeof(h), hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    for(int k = 0; k < 5; k++)
+        out->ntitype[k] = (int64_t)h[k];
+    out->badstepsizecount = (int64_t)h[5];
+    out->badtimebins = (int64_t)h[6];
+    out->mTimeBin = (int)h[7];
+    out->maxTimeBin = (int)h[8];
+    out->isPM = isPM ? 1 : 0;
+    API_END
+}
+
+// the tail of find_timesteps (timestep.c:825-848) with the all-reduced smallest / largest bin
+int mpg_find_timesteps_finish(int mTimeBin, int maxTimeBin, int isPM, mpg_drift_kick_times *times)
+{
+    API_BEGIN
+    MPG_CHECK(times, "null argument");
+    if(isPM && times->PM_length > dti_from_timebin(maxTimeBin))
+        times->PM_length = dti_from_timebin(maxTimeBin);
+    times->mintimebin = mTimeBin;
+    times->maxtimebin = maxTimeBin;
+    API_END
+}
+
 int mpg_dev_hydro_timesteps_finish(mpg_engine *eng, int mTimeBin, int isFirstTimeStep, int64_t n, const unsigned char *d_type,
                                    unsigned char *d_tb_hydro, mpg_drift_kick_times *times)
 {
@@ -2576,6 +2647,24 @@ int mpg_resident_sph_end(mpg_engine *eng, const mpg_sph_arrays *A)
     API_END
 }
 
+// the resident time bins into host arrays (n bytes each; either may be NULL): build_active_particles (timestep.c:1333-1420) reads
+// P[].TimeBinHydro / TimeBinGravity on the host at the top of every step
+int mpg_resident_fetch_timebins(mpg_engine *eng, unsigned char *tb_hydro, unsigned char *tb_grav)
+{
+    API_BEGIN
+    MPG_CHECK(eng && eng->sph_resident, "mpg_resident_fetch_timebins: no resident gas arrays");
+    MPG_HIP(hipSetDevice(eng->device));
+    const int64_t n = eng->res_n;
+    const mpg_sph_arrays &d = eng->res_sph_dev;
+    MPG_CHECK((!tb_hydro || d.tb_hydro) && (!tb_grav || d.tb_grav), "mpg_resident_fetch_timebins: the resident arrays have no such bins");
+    if(tb_hydro)
+        MPG_HIP(hipMemcpyAsync(tb_hydro, d.tb_hydro, (size_t)n, hipMemcpyDeviceToHost, eng->stream));
+    if(tb_grav)
+        MPG_HIP(hipMemcpyAsync(tb_grav, d.tb_grav, (size_t)n, hipMemcpyDeviceToHost, eng->stream));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    API_END
+}
+
 int mpg_resident_drift_all_particles(mpg_engine *eng, const mpg_particle_view *P, double ddrift, const double random_shift[3])
 {
     API_BEGIN
@@ -2650,6 +2739,36 @@ int mpg_resident_find_hydro_timesteps(mpg_engine *eng, const mpg_particle_view *
     H.d_tb_hydro = (unsigned char *)d.tb_hydro;
     if(mpg_dev_find_hydro_timesteps(eng, &H, d_act, NumActiveParticle, times, timeline, par, CourantFac, atime, hubble, out) ||
        mpg_dev_hydro_timesteps_finish(eng, out->mTimeBin, isFirstTimeStep, P->n, eng->s_type.p, (unsigned char *)d.tb_hydro, times))
+        throw Error(g_err);
+    API_END
+}
+
+int mpg_resident_find_timesteps(mpg_engine *eng, const mpg_particle_view *P, const int *ActiveParticle, int64_t NumActiveParticle,
+                                mpg_drift_kick_times *times, const mpg_timeline *timeline, const mpg_timestep_params *par, double CourantFac,
+                                double atime, double hubble, int64_t dti_max_pm, mpg_timestep_result *out)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && times && out, "null argument");
+    resident_sph_check(eng, P);
+    const mpg_sph_arrays &d = eng->res_sph_dev;
+    MPG_CHECK(d.tb_hydro && d.tb_grav, "resident find_timesteps: the gas arrays have no time bins");
+    const int *d_act = nullptr;
+    if(ActiveParticle) {
+        eng->s_active.reserve((size_t)NumActiveParticle + 1);
+        MPG_HIP(hipMemcpyAsync(eng->s_active.p, ActiveParticle, NumActiveParticle * sizeof(int), hipMemcpyHostToDevice, eng->stream));
+        d_act = eng->s_active.p;
+    }
+    mpg_hydrostep_arrays H{};
+    H.d_type = eng->s_type.p;
+    H.d_flags = eng->r_flags.p;
+    H.d_hsml = d.hsml;
+    H.d_dthsml = d.dthsml;
+    H.d_maxsignalvel = d.maxsignalvel;
+    H.d_tb_grav = d.tb_grav;
+    H.d_tb_hydro = (unsigned char *)d.tb_hydro;
+    if(mpg_dev_find_timesteps(eng, &H, eng->r_accel.p, eng->r_gravpm.p, (unsigned char *)d.tb_grav, d_act, NumActiveParticle, times, timeline, par,
+                              CourantFac, atime, hubble, dti_max_pm, out) ||
+       mpg_find_timesteps_finish(out->mTimeBin, out->maxTimeBin, out->isPM, times))
         throw Error(g_err);
     API_END
 }

@@ -341,6 +341,35 @@ __device__ __forceinline__ unsigned mbcnt64(const unsigned long long b)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
 }
 
+
+// ---- Round 6: the node tests of a target pass pre-classified in fp32 (MODE 2 waves), fp64 only where fp32 cannot decide ------------------
+// 19 of the ~30 vector instructions of a target pass are the fp64 arithmetic and compares of the reference's two tests (node_test_masks), and
+// tools/valu_rates.hip measures fp64 add / mul / fma at 4.8 - 5.0 cycles per wave instruction against 2.4 for fp32, and a compare into a scalar
+// register pair at ~7 (fp64) / ~6 (fp32).  The fast path below takes the SAME decisions from fp32 arithmetic with proven error margins:
+//   * coordinates relative to a wave-local origin O (the first valid target): C = fl32(centre - O), S = fl32(cofm - O) once per popped node
+//     (amortised over the up to 8 targets that test it), P_t = fl32(p_t - O) once per wave;  D >= |p_t - O| per axis bounds the spread;
+//   * every predicate as a NORMALISED slack n = (x - threshold) / E with E an upper bound on twice the absolute error of (x - threshold):
+//       n1 = (r2 - rcut2) / E1            E1 = 24u rcut2 + 20u D rcut                       (u = 2^-24;  r2 error <= 7u r2 + 7u D r)
+//       n2 = (cmax - eff) / E23           E23 = 12u (len + D + rcut) >= 12u eff + 4u D      (cmax error <= 2u cmax + 2u D)
+//       n3 = (cmax - inside) / E23
+//       n4 = (r2 / T - 1) / d4            T = max(l2 / theta2, sqrt(m l2 / aold)),  d4 = 64u + 32u D theta / len
+//     ("m l2 > r2 r2 aold" <=> r2 < sqrt(m l2) / sqrt(aold): no r2^2 in fp32; aold = +inf - the Barnes-Hut switch - and aold = 0 come out right);
+//     a slack with |n| > 1 has the sign of the exact quantity (derivation: DESIGN.md 3.2, round 6);
+//   * discard <=> min(n1, n2) > 0, open <=> min(n3, n4) < 0, and the pass is AMBIGUOUS for a lane iff min(|min(n1, n2)|, |min(n3, n4)|) <= 1
+//     (a superset of the lanes where some deciding slack is within its margin): three compares instead of five;
+//   * a pass with an ambiguous active lane, a node or target outside the range fp32 handles (m l2 or aold beyond 1e-30 .. 1e30) re-reads the node
+//     and runs node_test_masks in fp64.  Decisions are therefore exactly the reference's; COUNT builds evaluate both and raise ctl[1] = 3 on any
+//     difference, and count the ambiguous passes (counters[7]).
+struct F32Wave {
+    double ox, oy, oz;   // the origin (wave-uniform)
+    float w1, c1;        // n1 = fma(r2, w1, c1)
+    float dr;            // D + rcut
+    float k4;            // 32u D theta
+    unsigned tweird;     // targets whose aold fp32 cannot carry: always fp64
+    const float *s_tgtf; // LDS: [t][4] = P_t, sqrt(aold_t)
+};
+constexpr float F32_U = 5.9604644775390625e-8f; // 2^-24
+
 // the 8 targets of a wave: list lengths and counters are wave-uniform (scalar registers); positions and opening parameters sit in
 // LDS (s_tgt: [t][4] doubles) and are read back with a wave-uniform address per target - as scalars they overflowed the SGPR file
 // (8 x 8 registers) and every use cost a v_readlane
@@ -350,12 +379,14 @@ struct WaveTargets {
 };
 
 // returns false on an internal error (loop guard)
-template <bool COUNT, int MODE, bool O32>
+template <bool COUNT, int MODE, bool O32, bool F32 = false>
 __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams &gp, unsigned *__restrict__ Lw, unsigned *__restrict__ q_node,
                                            unsigned char *__restrict__ q_mask, const double *__restrict__ s_tgt, const int cap, const int lane,
                                            const unsigned live0, WaveTargets &T, unsigned &overflowed, bool &wrapped, unsigned (&c_pp)[8],
-                                           const unsigned guard_max, unsigned *__restrict__ ctl, unsigned &st_a, unsigned &st_al)
+                                           const unsigned guard_max, unsigned *__restrict__ ctl, unsigned &st_a, unsigned &st_al,
+                                           const F32Wave &W = F32Wave(), unsigned *n_amb = nullptr)
 {
+    static_assert(!F32 || MODE == 2, "the fp32 pre-classification is written for plain differences");
     unsigned live = live0; // targets still walking (wave-uniform)
     int sp = 0;            // frontier entries (wave-uniform)
     unsigned guard = 0;
@@ -542,10 +573,36 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
         const Src4 mom = ld<O32>(tv.momB, my);
         const NodeLinkB lk = ld<O32>(tv.linkB, my);
 #endif
-        const double eff = fma(0.5, g.len, gp.rcut);
-        const double l2 = g.len * g.len;
-        const double inside = 0.6 * g.len;
-        const double ml2 = mom.m * l2;
+        // fp64 operands of the tests (F32: only the fall-back and the COUNT builds' cross-check use them, from a second read of the node)
+        double eff = 0, l2 = 0, inside = 0, ml2 = 0;
+        // F32: the node relative to the wave's origin and the normalising factors of its slacks (see F32Wave)
+        float Cx = 0, Cy = 0, Cz = 0, Sx = 0, Sy = 0, Sz = 0, rE = 0, c2 = 0, c3 = 0, wA = 0, wB = 0, c4 = 0;
+        unsigned long long m_nweird = 0ull;
+        if constexpr(F32) {
+            Cx = (float)(g.cx - W.ox);
+            Cy = (float)(g.cy - W.oy);
+            Cz = (float)(g.cz - W.oz);
+            Sx = (float)(mom.x - W.ox);
+            Sy = (float)(mom.y - W.oy);
+            Sz = (float)(mom.z - W.oz);
+            const float lenf = (float)g.len, mf = (float)mom.m;
+            const float l2f = lenf * lenf, ml2f = mf * l2f;
+            rE = __builtin_amdgcn_rcpf((12.0f * F32_U) * (lenf + W.dr));
+            c2 = -fmaf(0.5f, lenf, (float)gp.rcut) * rE;
+            c3 = -(0.6f * lenf) * rE;
+            // wA = (theta2 / l2) / d4 with d4 = 64u + 32u D theta / len, i.e. theta2 / (len (64u len + 32u D theta));  1 / d4 = wA l2 / theta2
+            wA = (float)gp.bhangle2 * __builtin_amdgcn_rcpf(lenf * fmaf(64.0f * F32_U, lenf, W.k4));
+            const float g4 = wA * l2f * (float)(1.0 / gp.bhangle2);
+            wB = __builtin_amdgcn_rsqf(ml2f) * g4;
+            c4 = -g4;
+            m_nweird = __builtin_amdgcn_ballot_w64(!(ml2f > 1e-30f && ml2f < 1e30f && lenf > 1e-12f && lenf < 1e12f));
+        }
+        else {
+            eff = fma(0.5, g.len, gp.rcut);
+            l2 = g.len * g.len;
+            inside = 0.6 * g.len;
+            ml2 = mom.m * l2;
+        }
         const unsigned ent_val = my; // a leaf entry = the leaf's level-order node number (its block of 8 source records: tv.srcL)
         unsigned openmask = 0;
         if(COUNT) {
@@ -572,8 +629,26 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
 #endif
         auto pass = [&](auto checked_tag) {
             constexpr bool CHECKED = decltype(checked_tag)::value;
+#ifdef MPG_LISTS_TGT_PREFETCH
+            // experiment: target t + 1's record is requested before target t's pass (the LDS read's latency under the pass before it)
+            float4 tf_pre[9];
+            if constexpr(F32) {
+                unsigned o0 = 0u;
+                asm volatile("" : "+v"(o0));
+                tf_pre[0] = *(const float4 *)(W.s_tgtf + o0);
+            }
+#endif
 #pragma unroll
             for(int t = 0; t < 8; t++) {
+#ifdef MPG_LISTS_TGT_PREFETCH
+                if constexpr(F32) {
+                    if(t < 7) {
+                        unsigned on = 4u * (t + 1);
+                        asm volatile("" : "+v"(on));
+                        tf_pre[t + 1] = *(const float4 *)(W.s_tgtf + on);
+                    }
+                }
+#endif
                 // (no lane for a target that overflowed, is absent or did not open the parent; measured: 28 % of the passes over a
                 // target find no lane with its bit - the entries popped late in a walk belong to few of the 8 targets)
                 const unsigned long long m_act = __builtin_amdgcn_ballot_w64((mask & (1u << t)) != 0u);
@@ -583,9 +658,56 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
                 // pass of the walk: hoisted out of the loop they would hold 64 registers)
                 unsigned ot = 4u * t;
                 asm volatile("" : "+v"(ot));
-                const double4 tg = *(const double4 *)(s_tgt + ot);
                 unsigned long long m_discard, m_open, m_wrap;
-                node_test_masks<MODE>(gp, g, mom, false, false, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
+                if constexpr(F32) {
+#ifdef MPG_LISTS_TGT_PREFETCH
+                    const float4 tf = tf_pre[t];
+#else
+                    const float4 tf = *(const float4 *)(W.s_tgtf + ot);
+#endif
+                    const float cdx = Cx - tf.x, cdy = Cy - tf.y, cdz = Cz - tf.z;
+                    const float dx = Sx - tf.x, dy = Sy - tf.y, dz = Sz - tf.z;
+                    const float cmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(cdx), __builtin_fabsf(cdy)), __builtin_fabsf(cdz));
+                    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    float wT; // min(wA, wB sqrt(aold)) - written out: for fminf hipcc first canonicalises wA (a v_max_f32 x, x per pass)
+                    asm("v_min_f32 %0, %1, %2" : "=v"(wT) : "v"(wA), "v"(wB * tf.w));
+                    const float n1 = fmaf(r2, W.w1, W.c1), n2 = fmaf(cmax, rE, c2), n3 = fmaf(cmax, rE, c3), n4 = fmaf(r2, wT, c4);
+                    const float dmin = __builtin_fminf(n1, n2), omin = __builtin_fminf(n3, n4);
+                    const float amb = __builtin_fminf(__builtin_fabsf(dmin), __builtin_fabsf(omin));
+                    m_discard = __builtin_amdgcn_ballot_w64(dmin > 0.0f);
+                    m_open = __builtin_amdgcn_ballot_w64(omin < 0.0f);
+                    m_wrap = 0ull;
+                    const unsigned long long m_amb = (__builtin_amdgcn_ballot_w64(!(amb > 1.0f)) | m_nweird) & m_act;
+                    const bool redo = m_amb != 0ull || ((W.tweird >> t) & 1u);
+#ifdef MPG_F32_NOEXPECT
+                    if(COUNT || redo) { // (rare: the node again, and the reference's arithmetic)
+#else
+                    if(COUNT || __builtin_expect(redo, 0)) { // (rare - out of line: the node again, and the reference's arithmetic)
+#endif
+                        unsigned my2 = my;
+                        asm volatile("" : "+v"(my2));
+                        const NodeGeo g2 = ld<O32>(tv.geoB, my2);
+                        const Src4 mom2 = ld<O32>(tv.momB, my2);
+                        const double4 tg = *(const double4 *)(s_tgt + ot);
+                        const double l2d = g2.len * g2.len;
+                        unsigned long long e_discard, e_open, e_wrap;
+                        node_test_masks<MODE>(gp, g2, mom2, false, false, fma(0.5, g2.len, gp.rcut), l2d, 0.6 * g2.len, mom2.m * l2d, tg.x, tg.y, tg.z,
+                                              tg.w, e_discard, e_open, e_wrap);
+                        if(COUNT && !redo) {
+                            // (the open decision of a discarded node is never used: compared on the kept lanes only)
+                            if((((m_discard ^ e_discard) | ((m_open ^ e_open) & ~e_discard)) & m_act) != 0ull && lane == 0)
+                                atomicExch(&ctl[1], 3u);
+                        }
+                        if(COUNT && redo && n_amb)
+                            (*n_amb)++;
+                        m_discard = e_discard;
+                        m_open = e_open;
+                    }
+                }
+                else {
+                    const double4 tg = *(const double4 *)(s_tgt + ot);
+                    node_test_masks<MODE>(gp, g, mom, false, false, eff, l2, inside, ml2, tg.x, tg.y, tg.z, tg.w, m_discard, m_open, m_wrap);
+                }
                 const unsigned long long keep = m_act & ~m_discard;
                 const unsigned long long bn0 = keep & ~m_open;              // used unopened
                 const unsigned long long bl0 = keep & m_open & m_leafnode;  // opened leaves
@@ -640,7 +762,7 @@ __device__ __forceinline__ bool walk_wave8(const TreeView &tv, const GravParams 
 }
 
 // one wave = one chunk of k_walk_eval (8 consecutive targets)
-template <bool COUNT, bool FASTWRAP, bool O32>
+template <bool COUNT, bool FASTWRAP, bool O32, bool F32>
 __global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const TreeView tv, const GravParams gp, const WalkIO io, unsigned *__restrict__ lists,
                                                       int2 *__restrict__ counts, const int cap, const int64_t slot0, const int64_t nslots,
                                                       unsigned *__restrict__ ctl, int *__restrict__ ovf)
@@ -648,6 +770,7 @@ __global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const Tree
     __shared__ unsigned s_qnode[4 * QCAP];
     __shared__ unsigned char s_qmask[4 * QCAP];
     __shared__ __attribute__((aligned(32))) double s_tgt4[4 * 8 * 4];
+    __shared__ __attribute__((aligned(16))) float s_tgtf4[F32 ? 4 * 8 * 4 : 4];
 #ifdef MPG_EXP_LDSPAD_LISTS // timing experiment: fewer resident blocks per CU with the same code (bytes of unused LDS)
     __shared__ unsigned s_pad[MPG_EXP_LDSPAD_LISTS / 4];
     if(gp.box < 0)
@@ -663,7 +786,8 @@ __global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const Tree
     const unsigned guard_max = (unsigned)min((long long)(8ll * (tv.nnodes + 1024)), 0x7fffffffll);
     const double face = gp.rcut + 0.002 * gp.box;
     unsigned long long n_pp = 0, n_vis = 0, n_used = 0, n_le = 0, n_se = 0;
-    unsigned st_a = 0, st_al = 0;
+    unsigned st_a = 0, st_al = 0, n_amb = 0, n_f32w = 0;
+    float *s_tgtf = s_tgtf4 + (F32 ? (threadIdx.x >> 6) * 32 : 0);
 
     for(unsigned chunk = it.lo + it.first; chunk < it.hi; chunk += it.stride) {
         // lane t < 8 fetches target t; the values are then made wave-uniform
@@ -710,8 +834,39 @@ __global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const Tree
         bool wrapped = false; // (one flag for the wave: k_walk_eval takes NEAREST() for a whole chunk anyway)
         bool ok;
         if(FASTWRAP) {
-            if(!any_lane(near_face))
-                ok = walk_wave8<COUNT, 2, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+            if(!any_lane(near_face)) {
+                if constexpr(F32) {
+                    // the wave's origin = its first valid target; D = the largest |p_t - O| of an axis; the targets relative to O and
+                    // sqrt(aold) as floats in LDS (see F32Wave)
+                    F32Wave W;
+                    const int l0 = live0 ? __builtin_ctz(live0) : 0;
+                    W.ox = __shfl(vx, l0);
+                    W.oy = __shfl(vy, l0);
+                    W.oz = __shfl(vz, l0);
+                    double dmax = tvalid ? fmax(fmax(fabs(vx - W.ox), fabs(vy - W.oy)), fabs(vz - W.oz)) : 0.0;
+                    for(int off = 1; off < 8; off <<= 1)
+                        dmax = fmax(dmax, __shfl_xor(dmax, off));
+                    const double D = __shfl(dmax, 0) * 1.000001;
+                    const double E1 = 24.0 * (double)F32_U * gp.rcut2 + 20.0 * (double)F32_U * D * gp.rcut;
+                    W.w1 = (float)(1.0 / E1);
+                    W.c1 = -(float)gp.rcut2 * W.w1;
+                    W.dr = (float)((D + gp.rcut) * 1.000001);
+                    W.k4 = (float)(32.0 * (double)F32_U * D * sqrt(gp.bhangle2) * 1.000001);
+                    // aold that fp32 carries: 0, +inf (the Barnes-Hut switch) or 1e-30 .. 1e30
+                    const bool tw = tvalid && !(vaold == 0.0 || vaold == __builtin_inf() || (vaold > 1e-30 && vaold < 1e30));
+                    W.tweird = (unsigned)(__builtin_amdgcn_ballot_w64(tw) & 0xffull);
+                    W.s_tgtf = s_tgtf;
+                    __builtin_amdgcn_wave_barrier();
+                    if(lane < 8)
+                        *(float4 *)(s_tgtf + 4 * lane) = make_float4((float)(vx - W.ox), (float)(vy - W.oy), (float)(vz - W.oz), (float)sqrt(vaold));
+                    __builtin_amdgcn_wave_barrier();
+                    n_f32w++;
+                    ok = walk_wave8<COUNT, 2, O32, true>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a,
+                                                         st_al, W, &n_amb);
+                }
+                else
+                    ok = walk_wave8<COUNT, 2, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
+            }
             else
                 ok = walk_wave8<COUNT, 1, O32>(tv, gp, L, q_node, q_mask, s_tgt, cap, lane, live0, T, overflowed, wrapped, c_pp, guard_max, ctl, st_a, st_al);
         }
@@ -774,6 +929,10 @@ __global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const Tree
             atomicAdd(&io.counters[2], c2);
             atomicAdd(&io.counters[3], c3);
             atomicAdd(&io.counters[4], c4);
+            if(F32 && n_amb)
+                atomicAdd(&io.counters[7], (unsigned long long)n_amb); // target passes that fell back to fp64 (lane 0 counts: wave-uniform)
+            if(F32 && n_f32w)
+                atomicAdd(&io.counters[8], (unsigned long long)n_f32w); // waves (chunks of 8 targets) whose main loop ran the fp32 tests
         }
     }
 }
@@ -1126,7 +1285,15 @@ int grid_blocks(WalkScratch &ws, const void *kern, int64_t nchunks, int chunks_p
 template <bool POT, bool COUNT, bool FASTWRAP, bool O32>
 void launch_split_t(const TreeView &tv, const GravParams &gp, const WalkIO &io, WalkScratch &ws, hipStream_t st)
 {
-    auto kl = k_walk_lists8<COUNT, FASTWRAP, O32>;
+    // fp32 pre-classification of the node tests (round 6): MODE 2 waves of a FASTWRAP walk whose constants fp32 carries.  Built, parity-tested
+    // (decisions identical, 1e-4 of the passes fall back to fp64) and measured SLOWER than the fp64 tests on gfx950 (list kernel 26.8 -> 28.4 ms
+    // at 256^3: only v_add / v_mul / v_fma_f32 issue at twice the fp64 rate, the min / max / compare half of the fp32 pass costs what fp64 costs,
+    // and every popped node pays ~25 more instructions for the conversion - DESIGN.md 3.2, profiles/r06a_lists_f32/): OFF unless MPG_LISTS_F32=1
+    // (read per launch: the tests switch it)
+    const char *f32_e = getenv("MPG_LISTS_F32");
+    const bool f32_env = f32_e && f32_e[0] == '1';
+    const bool f32 = FASTWRAP && f32_env && gp.bhangle2 > 1e-6 && gp.bhangle2 < 1e6 && gp.rcut > 1e-12 && gp.rcut < 1e12 && gp.box < 1e12;
+    auto kl = (FASTWRAP && f32) ? k_walk_lists8<COUNT, FASTWRAP, O32, FASTWRAP> : k_walk_lists8<COUNT, FASTWRAP, O32, false>;
     // 4 resident blocks per CU (128 registers, hardly a spill) where the lists are short - the evaluation is then bound by instruction issue -
     // and 6 (80 registers) where they are long (a clustered set: the list capacity has grown to >= 4096 entries), where it waits for memory and
     // the waves count: 256^3 clustered 148 -> 127 ms per walk with 6, Zel'dovich 69.2 -> 67.7 with 4

@@ -20,6 +20,10 @@ void launch_find_hydro_timesteps(const int *list, int64_t nlist, const uint8_t *
                                  const double *maxsig, const uint8_t *bh_mintimebin, const double *dloga_for_bin, const uint8_t *tb_grav,
                                  uint8_t *tb_hydro, double atime, double hubble, double courant, double fac3, const HierTimeline &T, int64_t dti_max,
                                  int64_t Ti_Current, unsigned long long *out, hipStream_t st);
+void launch_find_timesteps(const int *list, int64_t nlist, const uint8_t *type, const uint8_t *flags, const double *gacc, const double *gpm,
+                           const double *hsml, const double *dthsml, const double *maxsig, const uint8_t *bh_mintimebin, const double *dloga_for_bin,
+                           uint8_t *tb_grav, uint8_t *tb_hydro, double atime, double hubble, double errtol, double soft, double courant, double fac3,
+                           const HierTimeline &T, int64_t dti_max, int64_t Ti_Current, unsigned long long *out, hipStream_t st);
 void launch_assign_gravity_bins(const int *list, int64_t nlist, const double *gacc, const double *gpm, const uint8_t *flags, double atime,
                                 double hubble, double errtol, double soft, const HierTimeline &T, int64_t dti_max, int largest_active, uint8_t *tb,
                                 unsigned long long *counts, unsigned long long *bad, hipStream_t st);

@@ -245,13 +245,13 @@ __global__ void __launch_bounds__(256) k_timestep_hydro(int64_t n, const uint8_t
 __device__ __forceinline__ bool timebin_active_dev(const int bin, const int64_t Ti_Current)
 {
     const int64_t dti = bin > 0 ? ((int64_t)1 << bin) : 0;
-    return bin <= 0 || (Ti_Current % dti) == 0;
+    return bin <= 0 || Ti_Current <= 0 || (Ti_Current % dti) == 0; // ("bin 0 is always active and at time 0 all bins are active")
 }
 
 // The particle loop of find_hydro_timesteps (timestep.c:629-698) without the dynamic-friction bins of the black holes: the new hydro bin
 // of every active gas / black-hole particle.  out[0..4]: particles by criterion (TI_ACCEL, TI_COURANT, TI_ACCRETE, TI_NEIGH, TI_HSML),
-// out[5]: badstepsizecount (bin_hydro < 1), out[6]: print_bad_timebin cases (dti <= 1 or > TIMEBASE), out[7]: the smallest bin + 1 as
-// atomicMin of (unsigned) - initialised to TIMEBINS + 1 by the caller.
+// out[5]: badstepsizecount (bin_hydro < 1), out[6]: print_bad_timebin cases (dti <= 1 or > TIMEBASE), out[7]: the smallest bin, by
+// atomicMin - initialised to TIMEBINS by the caller.
 __global__ void __launch_bounds__(256) k_find_hydro_timesteps(const int *__restrict__ list, int64_t nlist, const uint8_t *__restrict__ type,
                                                               const uint8_t *__restrict__ flags, const double *__restrict__ hsml,
                                                               const double *__restrict__ dthsml, const double *__restrict__ maxsig,
@@ -308,6 +308,86 @@ __global__ void __launch_bounds__(256) k_find_hydro_timesteps(const int *__restr
         atomicAdd(&out[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     if(threadIdx.x == 0 && s_min <= MPG_TIMEBINS)
         atomicMin(&out[7], (unsigned long long)s_min);
+}
+
+// get_timebin_from_dti, timestep.c:166-182: round_down_power_of_two, get_timestep_bin, and a longer step only onto an active bin
+__device__ __forceinline__ int timebin_from_dti_dev(int64_t dti, const int binold, const int64_t Ti_Current)
+{
+    int64_t ti_min = (int64_t)1 << MPG_TIMEBINS;
+    while(ti_min > dti)
+        ti_min >>= 1;
+    dti = ti_min;
+    int bin = 0;
+    if(dti > 1)
+        bin = 63 - __clzll((unsigned long long)dti);
+    if(bin > binold)
+        while(!timebin_active_dev(bin, Ti_Current) && bin > binold && bin > 1)
+            bin--;
+    return bin;
+}
+
+// The particle loop of find_timesteps (timestep.c:765-823; the step assignment of a run WITHOUT SplitGravityTimestepsOn, run.c:756): per
+// active particle the gravity step from FullTreeGravAccel + GravPM, for gas / black holes the hydro step where it is shorter, both bins set
+// to the new bin when old and new bin are active.  Not carried: ForceEqualTimesteps (the caller refuses it).
+// out[0..4]: particles by criterion, out[5]: badstepsizecount (bin < 1), out[6]: print_bad_timebin cases, out[7]: smallest bin (atomicMin,
+// initialised to TIMEBINS), out[8]: largest bin (atomicMax, initialised to 0).
+__global__ void __launch_bounds__(256) k_find_timesteps(const int *__restrict__ list, int64_t nlist, const uint8_t *__restrict__ type,
+                                                        const uint8_t *__restrict__ flags, const double *__restrict__ gacc, const double *__restrict__ gpm,
+                                                        const double *__restrict__ hsml, const double *__restrict__ dthsml,
+                                                        const double *__restrict__ maxsig, const uint8_t *__restrict__ bh_mintimebin,
+                                                        const double *__restrict__ dloga_for_bin, uint8_t *__restrict__ tb_grav,
+                                                        uint8_t *__restrict__ tb_hydro, double atime, double hubble, double errtol, double soft,
+                                                        double courant, double fac3, HierTimeline T, int64_t dti_max, int64_t Ti_Current,
+                                                        unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned s_cnt[8];
+    __shared__ unsigned s_min, s_max;
+    if(threadIdx.x < 8)
+        s_cnt[threadIdx.x] = 0;
+    if(threadIdx.x == 0) {
+        s_min = MPG_TIMEBINS + 1;
+        s_max = 0;
+    }
+    __syncthreads();
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(k < nlist) {
+        const int64_t i = list ? list[k] : k;
+        if(!(flags && (flags[i] & 3))) {
+            const int ty = type ? (type[i] & 7) : 1;
+            int titype = 0;
+            const double dloga_gravity = gravity_dloga_dev(i, gacc, gpm, atime, hubble, errtol, soft);
+            int64_t dti = convert_timestep_to_ti_dev(dloga_gravity, dti_max, T);
+            if(ty == 0 || ty == 5) { // the hydro step: "always shorter"
+                int th;
+                const double dloga_hydro = hydro_dloga_dev(i, type, hsml, dthsml, maxsig, bh_mintimebin, dloga_for_bin, atime, hubble, courant, fac3, th);
+                const int64_t dti_hydro = convert_timestep_to_ti_dev(dloga_hydro, dti_max, T);
+                if(dti_hydro < dti) {
+                    dti = dti_hydro;
+                    titype = th;
+                }
+            }
+            if(dti <= 1 || dti > ((int64_t)1 << MPG_TIMEBINS))
+                atomicAdd(&s_cnt[6], 1u);
+            atomicAdd(&s_cnt[titype], 1u);
+            const int binold = tb_hydro[i];
+            const int bin = timebin_from_dti_dev(dti, binold, Ti_Current);
+            if(bin < 1)
+                atomicAdd(&s_cnt[5], 1u);
+            if(timebin_active_dev(binold, Ti_Current) && timebin_active_dev(bin, Ti_Current)) {
+                tb_hydro[i] = (uint8_t)bin;
+                tb_grav[i] = (uint8_t)bin;
+            }
+            atomicMin(&s_min, (unsigned)bin);
+            atomicMax(&s_max, (unsigned)bin);
+        }
+    }
+    __syncthreads();
+    if(threadIdx.x < 7 && s_cnt[threadIdx.x])
+        atomicAdd(&out[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    if(threadIdx.x == 0 && s_min <= MPG_TIMEBINS) {
+        atomicMin(&out[7], (unsigned long long)s_min);
+        atomicMax(&out[8], (unsigned long long)s_max);
+    }
 }
 
 // The first loop of hierarchical_gravity_and_timesteps (timestep.c:345-370): new gravity bin of every particle of the list from
@@ -449,6 +529,17 @@ void launch_find_hydro_timesteps(const int *list, int64_t nlist, const uint8_t *
     if(nlist > 0)
         hipLaunchKernelGGL(k_find_hydro_timesteps, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, type, flags, hsml, dthsml, maxsig, bh_mintimebin,
                            dloga_for_bin, tb_grav, tb_hydro, atime, hubble, courant, fac3, T, dti_max, Ti_Current, out);
+    MPG_HIP(hipGetLastError());
+}
+
+void launch_find_timesteps(const int *list, int64_t nlist, const uint8_t *type, const uint8_t *flags, const double *gacc, const double *gpm,
+                           const double *hsml, const double *dthsml, const double *maxsig, const uint8_t *bh_mintimebin, const double *dloga_for_bin,
+                           uint8_t *tb_grav, uint8_t *tb_hydro, double atime, double hubble, double errtol, double soft, double courant, double fac3,
+                           const HierTimeline &T, int64_t dti_max, int64_t Ti_Current, unsigned long long *out, hipStream_t st)
+{
+    if(nlist > 0)
+        hipLaunchKernelGGL(k_find_timesteps, dim3(nblk(nlist)), dim3(256), 0, st, list, nlist, type, flags, gacc, gpm, hsml, dthsml, maxsig, bh_mintimebin,
+                           dloga_for_bin, tb_grav, tb_hydro, atime, hubble, errtol, soft, courant, fac3, T, dti_max, Ti_Current, out);
     MPG_HIP(hipGetLastError());
 }
 

@@ -182,6 +182,12 @@ class HydroStepResult(C.Structure):
     _fields_ = [("mTimeBin", C.c_int), ("ntitype", C.c_int64 * 5), ("badstepsizecount", C.c_int64), ("badtimebins", C.c_int64)]
 
 
+class TimestepResult(C.Structure):
+    """mpg_timestep_result"""
+    _fields_ = [("mTimeBin", C.c_int), ("maxTimeBin", C.c_int), ("isPM", C.c_int), ("ntitype", C.c_int64 * 5), ("badstepsizecount", C.c_int64),
+                ("badtimebins", C.c_int64)]
+
+
 class FofParams(C.Structure):
     """mpg_fof_params"""
     _fields_ = [("FOFPrimaryLinkTypes", C.c_int), ("FOFSecondaryLinkTypes", C.c_int), ("FOFHaloComovingLinkingLength", C.c_double),
@@ -421,6 +427,28 @@ class Engine:
                                                             C.byref(res)))
         return dict(mTimeBin=res.mTimeBin, ntitype=list(res.ntitype), badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
 
+    def resident_find_timesteps(self, P, times, sync_loga, ErrTolIntAccuracy, MinSizeTimestep, CourantFac, atime, hubble, dti_max_pm=0,
+                                ActiveParticle=None):
+        """find_timesteps (timestep.c:739-849) on a resident gas run: both time bins of the active particles, times.PM_length on a PM step
+        (dti_max_pm = the caller's get_PM_timestep_ti), times.mintimebin / maxtimebin"""
+        v = self._view(P)
+        act = None if ActiveParticle is None else np.ascontiguousarray(ActiveParticle, np.int32)
+        loga = (C.c_double * len(sync_loga))(*[float(x) for x in sync_loga])
+        tl = Timeline(len(sync_loga), C.cast(loga, C.POINTER(C.c_double)))
+        par = TimestepParams(ErrTolIntAccuracy, MinSizeTimestep)
+        res = TimestepResult()
+        self._ck(self.lib.mpg_resident_find_timesteps(self.h, C.byref(v), None if act is None else act.ctypes.data_as(C.c_void_p),
+                                                      C.c_int64(0 if act is None else len(act)), C.byref(times), C.byref(tl), C.byref(par),
+                                                      C.c_double(CourantFac), C.c_double(atime), C.c_double(hubble), C.c_int64(dti_max_pm), C.byref(res)))
+        return dict(mTimeBin=res.mTimeBin, maxTimeBin=res.maxTimeBin, isPM=res.isPM, ntitype=list(res.ntitype),
+                    badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
+
+    def resident_fetch_timebins(self, n):
+        """(TimeBinHydro, TimeBinGravity) of a resident gas run as host arrays (what the shim copies into P[] for build_active_particles)"""
+        tbh, tbg = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        self._ck(self.lib.mpg_resident_fetch_timebins(self.h, tbh.ctypes.data_as(C.c_void_p), tbg.ctypes.data_as(C.c_void_p)))
+        return tbh, tbg
+
     def resident_arrays(self):
         """device pointers of the resident columns (dict of ints; 0 = absent) and n"""
         class RV(C.Structure):
@@ -535,6 +563,23 @@ class Engine:
         self._ck(self.lib.mpg_dev_hydro_timesteps_finish(self.h, int(res.mTimeBin), int(bool(isFirstTimeStep)), C.c_int64(n), _ptr(arrays.get("type")),
                                                          _ptr(arrays.get("tb_hydro")), C.byref(times)))
         return dict(mTimeBin=res.mTimeBin, ntitype=list(res.ntitype), badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
+
+    def dev_find_timesteps(self, arrays, gravaccel, gravpm, active, times, sync_loga, ErrTolIntAccuracy, MinSizeTimestep, CourantFac, atime, hubble,
+                           dti_max_pm=0):
+        """find_timesteps (timestep.c:739-849) on one rank: the particle loop on the device (both time bins), then the tail (PM step shrink,
+        times.mintimebin / maxtimebin).  arrays as dev_find_hydro_timesteps (tb_grav and tb_hydro are both updated)."""
+        A = HydroStepArrays(*[_ptr(arrays.get(k)) for k in ("type", "flags", "hsml", "dthsml", "maxsignalvel", "tb_grav", "tb_hydro", "bh_mintimebin")])
+        loga = (C.c_double * len(sync_loga))(*[float(x) for x in sync_loga])
+        tl = Timeline(len(sync_loga), C.cast(loga, C.POINTER(C.c_double)))
+        par = TimestepParams(ErrTolIntAccuracy, MinSizeTimestep)
+        res = TimestepResult()
+        na = active.shape[0] if active is not None else 0
+        self._ck(self.lib.mpg_dev_find_timesteps(self.h, C.byref(A), _ptr(gravaccel), _ptr(gravpm), _ptr(arrays["tb_grav"]), _ptr(active), C.c_int64(na),
+                                                 C.byref(times), C.byref(tl), C.byref(par), C.c_double(CourantFac), C.c_double(atime),
+                                                 C.c_double(hubble), C.c_int64(dti_max_pm), C.byref(res)))
+        self._ck(self.lib.mpg_find_timesteps_finish(int(res.mTimeBin), int(res.maxTimeBin), int(res.isPM), C.byref(times)))
+        return dict(mTimeBin=res.mTimeBin, maxTimeBin=res.maxTimeBin, isPM=res.isPM, ntitype=list(res.ntitype),
+                    badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
 
     # particle order: Peano-Hilbert keys and the (type, key) sort (utils/peano.h, slotsmanager.c:404-452)
     def dev_peano_keys(self, pos, box, keys):

@@ -344,3 +344,56 @@ def find_hydro_timesteps(S, act, times, tl, MinSizeTimestep, CourantFac, atime, 
     if times["mintimebin"] > times["mingravtimebin"] and times["mingravtimebin"] > 0:
         times["mintimebin"] = times["mingravtimebin"]
     return res
+
+
+def find_timesteps(orc, S, act, times, tl, ErrTolIntAccuracy, MinSizeTimestep, CourantFac, atime, hubble, soft, dti_max_pm=0):
+    """find_timesteps, timestep.c:739-849 (the step assignment of a run without SplitGravityTimestepsOn, run.c:756), without
+    ForceEqualTimesteps (:759-761, :778-779) and set_bh_first_timestep (:844-845).  S: dict with type, flags (optional), gacc
+    (FullTreeGravAccel), gravpm, hsml, dthsml, maxsignalvel, tb_grav and tb_hydro (both updated in place), bh_mintimebin (optional).
+    Updates times['PM_length' / 'PM_start'] on a PM step and times['mintimebin' / 'maxtimebin'] (one rank: no all-reduce).  No reference test
+    covers this function: parity unpinned, as for find_hydro_timesteps above."""
+    Ti = times["Ti_Current"]
+    assert Ti <= times["PM_start"] + times["PM_length"], "Passed end of PM step!"         # is_PM_timestep :153-159
+    isPM = Ti == times["PM_start"] + times["PM_length"]
+    dti_max = times["PM_length"]
+    if isPM:                                                                                # :748-755
+        dti_max = dti_max_pm
+        times["PM_length"] = dti_max
+        times["PM_start"] = times["PM_kick"]
+    ntitype = [0] * 5
+    bad, badbins = 0, 0
+    mTimeBin, maxTimeBin = TIMEBINS, 0
+    logDTime = tl.dloga_interval_ti(Ti)
+    dloga_for_bin = [dti_from_timebin(b) * logDTime for b in range(TIMEBINS + 1)]
+    flags = S.get("flags")
+    bhmin = S.get("bh_mintimebin")
+    idx = np.asarray(list(_listed(S, act)), dtype=np.int64)
+    dl_grav = _dloga(orc, S, S["gacc"], idx, atime, hubble, ErrTolIntAccuracy, soft) if len(idx) else np.zeros(0)
+    for k, i in enumerate(idx):
+        if flags is not None and (flags[i] & 3):
+            continue
+        ty = int(S["type"][i]) & 7
+        titype = TI_ACCEL
+        dti = int(convert_timestep_to_ti(np.array([dl_grav[k]]), dti_max, Ti, tl, MinSizeTimestep)[0])
+        if ty == 0 or ty == 5:                                                              # :786-794
+            dl_h, th = get_timestep_hydro_dloga(ty, float(S["hsml"][i]), float(S["dthsml"][i]), float(S["maxsignalvel"][i]), atime, hubble,
+                                                CourantFac, None if bhmin is None else int(bhmin[i]), dloga_for_bin)
+            dti_h = int(convert_timestep_to_ti(np.array([dl_h]), dti_max, Ti, tl, MinSizeTimestep)[0])
+            if dti_h < dti:
+                dti, titype = dti_h, th
+        if dti <= 1 or dti > TIMEBASE:
+            badbins += 1
+        ntitype[titype] += 1
+        b = get_timebin_from_dti(dti, int(S["tb_hydro"][i]), Ti)
+        if b < 1:
+            bad += 1
+        if is_timebin_active(int(S["tb_hydro"][i]), Ti) and is_timebin_active(b, Ti):       # :815-818
+            S["tb_hydro"][i] = b
+            S["tb_grav"][i] = b
+        mTimeBin = min(mTimeBin, b)
+        maxTimeBin = max(maxTimeBin, b)
+    if isPM and times["PM_length"] > dti_from_timebin(maxTimeBin):                          # :835-836
+        times["PM_length"] = dti_from_timebin(maxTimeBin)
+    times["mintimebin"] = mTimeBin
+    times["maxtimebin"] = maxTimeBin
+    return dict(mTimeBin=mTimeBin, maxTimeBin=maxTimeBin, isPM=int(isPM), ntitype=ntitype, badstepsizecount=bad, badtimebins=badbins)

@@ -59,19 +59,29 @@ mpg_particle_view mpg_shim_view(void);
 /* ---- a run whose table stays in HBM between two domain decompositions (timestep-hip.c) ----
  * mpg_shim_resident_begin after the step's domain_decompose_full / domain_maintain, mpg_shim_resident_end before the next one and before
  * any host module that reads P[] / SphP[]; in between density(), hydro_force(), gravpm_force(), force_tree_full(), grav_short_tree(),
- * find_hydro_timesteps(), apply_half_kick(), apply_PM_half_kick() and drift_all_particles() run on the device copies. */
+ * find_timesteps(), find_hydro_timesteps(), apply_half_kick(), apply_PM_half_kick() and drift_all_particles() run on the device copies;
+ * the hierarchical-gravity functions (apply_hydro_half_kick, hierarchical_gravity_*) stop the run there. */
 void mpg_shim_resident_begin(double BoxSize);
 void mpg_shim_resident_end(void);
 int mpg_shim_resident(void);
 const mpg_sph_arrays *mpg_shim_resident_sph(void); /* the host set of the resident SPH arrays (sph-hip.c passes it instead of gathering) */
-/* four accessors the maintainer adds next to the file-static parameters they read (two lines each):
+/* the accessors the maintainer adds next to the file-static parameters they read (two lines each):
  *   timestep.c:   double mpg_shim_max_gas_vel(void) { return TimestepParams.MaxGasVel; }            (timestep.c:40-60)
  *                 double mpg_shim_min_size_timestep(void) { return TimestepParams.MinSizeTimestep; }
  *                 double mpg_shim_courant_fac(void) { return TimestepParams.CourantFac; }
+ *                 double mpg_shim_err_tol_int_accuracy(void) { return TimestepParams.ErrTolIntAccuracy; }
+ *                 int mpg_shim_force_equal_timesteps(void) { return TimestepParams.ForceEqualTimesteps; }
+ *                 inttime_t mpg_shim_get_PM_timestep_ti(const DriftKickTimes *times, double atime, const Cosmology *CP, int FastParticleType,
+ *                     double asmth) { return get_PM_timestep_ti(times, atime, CP, FastParticleType, asmth); }      (static, timestep.c:1281-1300)
  *   timebinmgr.c: void mpg_shim_timeline(mpg_timeline *tl): tl->nsync = NSyncPoints and tl->loga = an array of SyncPoints[i].loga
  *                 (timebinmgr.c:18; kept alongside SyncPoints by setup_sync_points) */
 double mpg_shim_max_gas_vel(void);
 double mpg_shim_min_size_timestep(void);
 double mpg_shim_courant_fac(void);
+double mpg_shim_err_tol_int_accuracy(void);
+int mpg_shim_force_equal_timesteps(void);
+#include "timestep.h"
+#include "cosmology.h"
+inttime_t mpg_shim_get_PM_timestep_ti(const DriftKickTimes *times, double atime, const Cosmology *CP, int FastParticleType, double asmth);
 void mpg_shim_timeline(mpg_timeline *tl);
 #endif

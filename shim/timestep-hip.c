@@ -11,15 +11,25 @@
  *     mpg_shim_resident_end();                                   <- one fetch, before the next domain_maintain, a snapshot, FOF, or any
  *                                                                   host module that reads P[] / SphP[] (cooling, star formation)
  *
- * - and compiles timestep.c and drift.c with the four entry points below renamed (one line in libgadget/Makefile, as for forcetree.o):
+ * - and compiles timestep.c and drift.c with the entry points below renamed (one line each in libgadget/Makefile, as for forcetree.o):
  *     timestep.o: CFLAGS += -Dapply_half_kick=cpu_apply_half_kick -Dapply_PM_half_kick=cpu_apply_PM_half_kick -Dfind_hydro_timesteps=cpu_find_hydro_timesteps
+ *                           -Dfind_timesteps=cpu_find_timesteps -Dapply_hydro_half_kick=cpu_apply_hydro_half_kick
+ *                           -Dhierarchical_gravity_and_timesteps=cpu_hierarchical_gravity_and_timesteps
+ *                           -Dhierarchical_gravity_accelerations=cpu_hierarchical_gravity_accelerations
  *     drift.o:    CFLAGS += -Ddrift_all_particles=cpu_drift_all_particles
+ * These are ALL the functions of run.c's step that read or write the integrated columns (run.c:420, 498-499, 536-565, 754-794): a function of
+ * that set that stayed on the host inside a resident stretch would integrate the stale host copies and its work would be discarded by the
+ * fetch at the end.  The resident stretch carries the branch WITHOUT SplitGravityTimestepsOn (run.c:553-565, 754-759:
+ * find_timesteps + apply_half_kick); with All.HierarchicalGravity the three functions of that branch stop the run with a message instead
+ * of kicking host copies (its level loop has a device form of its own, mpg_dev_hierarchical_*, which takes device arrays the resident
+ * table does not hand out yet).
  * Outside a resident stretch the definitions here call those cpu_ originals, so a run that never calls mpg_shim_resident_begin behaves as
  * before.  Inside one, the factors come from the reference's own get_exact_*_factor / dloga_from_dti (host arithmetic on the integer
  * timeline) and the per-particle loops run as mpg_resident_* on the device (include/mpgadget_hip.h).  One rank per GPU; NTask > 1 keeps the
  * host path (the resident calls are one-rank forms: mpg_dist_* owns the multi-rank choreography).
  * Not covered (the shim stops with a message): black-hole particles inside a resident stretch (drift.c:33-55 repositioning, the
- * dynamic-friction kicks, timestep.c:1003-1010), hierarchical gravity (its level loop has its own device form, mpg_dev_hierarchical_*). */
+ * dynamic-friction kicks, timestep.c:1003-1010), hierarchical gravity (apply_hydro_half_kick, hierarchical_gravity_and_timesteps and
+ * hierarchical_gravity_accelerations below call endrun inside a resident stretch), ForceEqualTimesteps. */
 #include <mpi.h>
 #include <math.h>
 #include <string.h>
@@ -44,6 +54,15 @@ void cpu_apply_half_kick(const ActiveParticles *act, Cosmology *CP, DriftKickTim
 void cpu_apply_PM_half_kick(Cosmology *CP, DriftKickTimes *times);
 int cpu_find_hydro_timesteps(const ActiveParticles *act, DriftKickTimes *times, const double atime, const Cosmology *CP, const int isFirstTimeStep);
 void cpu_drift_all_particles(inttime_t ti0, inttime_t ti1, Cosmology *CP, const double random_shift[3]);
+/* (timestep.c:739-849, 930-968, 296-490, 502-599) */
+int cpu_find_timesteps(const ActiveParticles *act, DriftKickTimes *times, const double atime, int FastParticleType, const Cosmology *CP, const double asmth,
+                       const int isFirstTimeStep);
+void cpu_apply_hydro_half_kick(const ActiveParticles *act, Cosmology *CP, DriftKickTimes *times, const double atime);
+int cpu_hierarchical_gravity_and_timesteps(const ActiveParticles *act, PetaPM *pm, DomainDecomp *ddecomp, struct grav_accel_store StoredGravAccel,
+                                           DriftKickTimes *times, const double atime, int HybridNuGrav, int FastParticleType, Cosmology *CP,
+                                           const char *EmergencyOutputDir);
+int cpu_hierarchical_gravity_accelerations(const ActiveParticles *act, PetaPM *pm, DomainDecomp *ddecomp, struct grav_accel_store StoredGravAccel,
+                                           DriftKickTimes *times, int HybridNuGrav, Cosmology *CP, const char *EmergencyOutputDir);
 
 /* ---- the resident stretch ---- */
 static struct {
@@ -135,11 +154,12 @@ void mpg_shim_resident_end(void)
     #pragma omp parallel for
     for(i = 0; i < n; i++) {
         int k;
+        P[i].TimeBinHydro = R.tb[i];       /* (every type: find_timesteps sets both bins of every active particle) */
+        P[i].TimeBinGravity = R.tb[n + i];
         if(P[i].Type != 0)
             continue;
         P[i].Hsml = R.A.hsml[i];
         P[i].DtHsml = R.A.dthsml[i];
-        P[i].TimeBinHydro = R.tb[i];
         SPHP(i).Entropy = R.A.entropy[i];
         SPHP(i).Density = R.A.density[i];
         SPHP(i).EgyWtDensity = R.A.egywtdensity[i];
@@ -155,6 +175,20 @@ void mpg_shim_resident_end(void)
     myfree(R.block);
     R.on = 0;
     mpg_shim_particles_changed(); /* (the host table is current again and may now be reordered) */
+}
+
+/* the device's new time bins into P[]: build_active_particles (timestep.c:1333-1420, run.c:436) and update_kick_times read them on the
+ * host at the top of the next step.  2 bytes per particle; everything else of P[] stays stale until mpg_shim_resident_end. */
+static void fetch_timebins(void)
+{
+    const int64_t n = PartManager->NumPart;
+    int64_t i;
+    ck(mpg_resident_fetch_timebins(mpg_shim_engine(), R.tb, R.tb + n));
+    #pragma omp parallel for
+    for(i = 0; i < n; i++) {
+        P[i].TimeBinHydro = R.tb[i];
+        P[i].TimeBinGravity = R.tb[n + i];
+    }
 }
 
 /* ---- the reference's entry points ---- */
@@ -238,9 +272,78 @@ int find_hydro_timesteps(const ActiveParticles *act, DriftKickTimes *times, cons
     mpg_particle_view v = view();
     ck(mpg_resident_find_hydro_timesteps(mpg_shim_engine(), &v, act->ActiveParticle, act->NumActiveParticle, (mpg_drift_kick_times *)times, &tl, &par,
                                          mpg_shim_courant_fac(), atime, hubble, isFirstTimeStep, &res));
+    fetch_timebins();
     message(0, "Hydro timesteps: Accel: %ld Soundspeed: %ld DivVel: %ld Accrete: %ld Neighbour: %ld\n", (long)res.ntitype[0], (long)res.ntitype[1],
             (long)res.ntitype[4], (long)res.ntitype[2], (long)res.ntitype[3]);
     walltime_measure("/Timeline/Hydro");
     message(0, "Min grav timebin: %d mintimebin %d\n", times->mingravtimebin, times->mintimebin);
     return (int)res.badstepsizecount;
+}
+
+/* find_timesteps, timestep.c:739-849 (run.c:756, the branch without SplitGravityTimestepsOn): the particle loop, the PM step's shrink and
+ * times->mintimebin / maxtimebin on the device copies.  On a PM step the new PM length needs the rms velocities (get_PM_timestep_ti ->
+ * get_long_range_timestep_dloga, timestep.c:1201-1300, static there and a loop over P[].Vel): the velocities are fetched for it - a PM step
+ * is one step in many - and the reference's own function computes the length. */
+int find_timesteps(const ActiveParticles *act, DriftKickTimes *times, const double atime, int FastParticleType, const Cosmology *CP, const double asmth,
+                   const int isFirstTimeStep)
+{
+    if(!R.on)
+        return cpu_find_timesteps(act, times, atime, FastParticleType, CP, asmth, isFirstTimeStep);
+    if(mpg_shim_force_equal_timesteps())
+        endrun(5, "find_timesteps: ForceEqualTimesteps is not carried inside a resident stretch (timestep.c:759-761)\n");
+    walltime_measure("/Misc");
+    mpg_particle_view v = view();
+    inttime_t dti_max_pm = 0;
+    if(is_PM_timestep(times)) {
+        ck(mpg_resident_fetch(mpg_shim_engine(), &v, MPG_FIELD_VEL)); /* P[].Vel current for the rms velocities */
+        dti_max_pm = mpg_shim_get_PM_timestep_ti(times, atime, CP, FastParticleType, asmth);
+    }
+    const double hubble = hubble_function(CP, atime);
+    mpg_timeline tl;
+    mpg_timestep_params par;
+    mpg_timestep_result res;
+    mpg_shim_timeline(&tl);
+    par.ErrTolIntAccuracy = mpg_shim_err_tol_int_accuracy();
+    par.MinSizeTimestep = mpg_shim_min_size_timestep();
+    ck(mpg_resident_find_timesteps(mpg_shim_engine(), &v, act->ActiveParticle, act->NumActiveParticle, (mpg_drift_kick_times *)times, &tl, &par,
+                                   mpg_shim_courant_fac(), atime, hubble, dti_max_pm, &res));
+    fetch_timebins();
+    message(0, "PM timebin: %lx (dloga: %g). Criteria: Accel: %ld Soundspeed: %ld DivVel: %ld Accrete: %ld Neighbour: %ld\n", times->PM_length,
+            dloga_from_dti(times->PM_length, times->Ti_Current), (long)res.ntitype[0], (long)res.ntitype[1], (long)res.ntitype[4], (long)res.ntitype[2],
+            (long)res.ntitype[3]);
+    /* (set_bh_first_timestep, timestep.c:844-845: no black holes inside a resident stretch - mpg_shim_resident_begin refuses them) */
+    walltime_measure("/Timeline");
+    return (int)res.badstepsizecount;
+}
+
+/* The branch of run.c with All.HierarchicalGravity (run.c:498-499, 536-541, 766-775).  Outside a resident stretch: the originals.  Inside
+ * one they must not run - they would kick and re-bin the stale host copies, and mpg_shim_resident_end would then overwrite their work. */
+static void no_hierarchical_gravity(const char *fn)
+{
+    endrun(5, "%s inside mpg_shim_resident_begin / _end: hierarchical gravity (SplitGravityTimestepsOn) is not carried by the resident "
+              "integrator - set SplitGravityTimestepsOn = 0 or leave the resident stretch (mpg_shim_resident_end) first\n", fn);
+}
+
+void apply_hydro_half_kick(const ActiveParticles *act, Cosmology *CP, DriftKickTimes *times, const double atime)
+{
+    if(R.on)
+        no_hierarchical_gravity("apply_hydro_half_kick");
+    cpu_apply_hydro_half_kick(act, CP, times, atime);
+}
+
+int hierarchical_gravity_and_timesteps(const ActiveParticles *act, PetaPM *pm, DomainDecomp *ddecomp, struct grav_accel_store StoredGravAccel,
+                                       DriftKickTimes *times, const double atime, int HybridNuGrav, int FastParticleType, Cosmology *CP,
+                                       const char *EmergencyOutputDir)
+{
+    if(R.on)
+        no_hierarchical_gravity("hierarchical_gravity_and_timesteps");
+    return cpu_hierarchical_gravity_and_timesteps(act, pm, ddecomp, StoredGravAccel, times, atime, HybridNuGrav, FastParticleType, CP, EmergencyOutputDir);
+}
+
+int hierarchical_gravity_accelerations(const ActiveParticles *act, PetaPM *pm, DomainDecomp *ddecomp, struct grav_accel_store StoredGravAccel,
+                                       DriftKickTimes *times, int HybridNuGrav, Cosmology *CP, const char *EmergencyOutputDir)
+{
+    if(R.on)
+        no_hierarchical_gravity("hierarchical_gravity_accelerations");
+    return cpu_hierarchical_gravity_accelerations(act, pm, ddecomp, StoredGravAccel, times, HybridNuGrav, CP, EmergencyOutputDir);
 }

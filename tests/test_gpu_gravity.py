@@ -243,6 +243,50 @@ def test_walk_kernel_variants(pkg, engine, orc, ic, n, nmesh, variant, cap):
     assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
 
 
+@pytest.mark.parametrize("mode", ["relative", "bh", "aold0", "tiny_aold"])
+def test_walk_lists_f32_preclassification(pkg, engine, orc, mode, monkeypatch):
+    """Round 6: k_walk_lists8 with the node tests of a target pass pre-classified in fp32 (MPG_LISTS_F32=1; off by
+    default - it measured slower than the fp64 tests).  The decisions must stay exactly the reference's: interaction counters EQUAL
+    to the oracle's and accelerations to rounding, with the relative criterion, with the Barnes-Hut switch (aold = +inf in the kernel), with a
+    zero old acceleration (every node with mass opens) and with old accelerations below what fp32 carries (those targets take the fp64 tests:
+    the fall-back counter shows it).  The counting build evaluates BOTH forms for every pass and raises a device error on any difference on a
+    lane the fp32 form called decided, so a green run also says that no fp32 decision disagreed with fp64 anywhere."""
+    n, nmesh = 32, 64
+    pos, mass, box = pkg.ics.s_zel(n)
+    use_bh = 1 if mode == "bh" else 0
+    setup_engine(engine, box, n, nmesh, TreeUseBH=use_bh)
+    gpm_o, _ = O.gravpm_force(pos, mass, box, nmesh, 1.5, G)
+    tr = orc.tree(pos, mass, box)
+    par = O.make_grav_params(box, nmesh, npart_cbrt=n, G=G)
+    par.TreeUseBH = use_bh
+    scale = {"relative": 1.0, "bh": 1.0, "aold0": 0.0, "tiny_aold": 1e-40}[mode]
+    prev = scale * gpm_o
+    old = np.sqrt(((prev + scale * gpm_o) ** 2).sum(1)) / G
+    a_ref, p_ref, c_ref, _ = tr.grav_short_tree(par, oldacc=old, want_pot=True)
+    P = pkg.make_particles(pos, mass)
+    P["GravPM"] = scale * gpm_o
+    P["FullTreeGravAccel"] = prev
+    monkeypatch.setenv("MPG_LISTS_F32", "1")
+    try:
+        engine.set_walk_variant(6)
+        engine.set_instrumentation(False, True)
+        engine.force_tree_full(P, box)
+        engine.grav_short_tree(P)
+        c = engine.walk_counters()
+    finally:
+        engine.set_walk_variant(0)
+        engine.set_instrumentation(False, False)
+    assert (c["pp"], c["nodes_visited"], c["nodes_used"]) == tuple(c_ref)
+    assert_accel_parity(P["FullTreeGravAccel"], a_ref)
+    assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
+    f32_waves, fallback = c["cycles_b"], c["cycles_a"]
+    assert f32_waves > 0.2 * len(pos) / 8, (f32_waves, len(pos) // 8)        # the interior waves (no target near a face) did run the fp32 tests
+    if mode == "tiny_aold":
+        assert fallback > f32_waves          # every pass of those waves went to fp64 (aold outside 1e-30 .. 1e30)
+    else:
+        assert fallback < 0.01 * c["nodes_visited"] / 8, (fallback, c["nodes_visited"])
+
+
 def test_resident_walk_in_place_with_list_retry(pkg, engine, orc):
     """in resident mode the walk writes FullTreeGravAccel over its own opening input.  The two-kernel walk runs
     its list pass again with longer lists when more than a fifth of the targets overflow - after the evaluation has already stored new

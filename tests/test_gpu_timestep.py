@@ -228,6 +228,68 @@ def test_hydro_timestep_criterion_and_bins(pkg, engine):
         assert changed.any() and not changed[dead].any()
 
 
+def test_find_timesteps_bins(pkg, engine, orc):
+    """find_timesteps (timestep.c:739-849, the step assignment of run.c:756 - a run without SplitGravityTimestepsOn) on the device against
+    the restatement (oracle/hiergrav_oracle.py::find_timesteps; the reference holds no test of it: parity unpinned): the new bin of every
+    active particle from the gravity criterion and, for gas / black holes, the hydro criteria where they are shorter - BOTH time bins equal
+    to the restatement's, the counts per criterion, the smallest / largest bin, and the DriftKickTimes update; once as a PM step (new PM
+    length handed in, shrunk onto the longest tree step) with every particle active, once between PM steps with an active list."""
+    import torch
+    from oracle import hiergrav_oracle as H
+    from test_gpu_hiergrav import to_struct, from_struct
+    rng = np.random.RandomState(17)
+    n = 30011
+    typ = rng.choice([0, 0, 0, 1, 1, 4, 5], n).astype(np.uint8)
+    flags = ((rng.random_sample(n) < 0.03) * rng.randint(1, 4, n)).astype(np.uint8)
+    hsml = 10 ** rng.uniform(-1.5, 1.0, n)
+    dthsml = rng.standard_normal(n) * 10 ** rng.uniform(-3, 1, n)
+    maxsig = 10 ** rng.uniform(0.5, 3.5, n)
+    bhmin = rng.randint(0, 12, n).astype(np.uint8)
+    gacc = rng.standard_normal((n, 3)) * 10 ** rng.uniform(-2, 4, (n, 1))
+    gacc[5] = 0.0
+    gpm = rng.standard_normal((n, 3)) * 1e-1
+    gpm[5] = 0.0
+    atime, hubble, courant, errtol = 0.37, 0.21, 0.15, 0.025
+    sync = np.log(np.array([0.1, 0.25, 0.5, 1.0]))
+    tl = H.Timeline(sync)
+    engine.set_gravshort_treepar()
+    engine.gravshort_set_softenings(0.5)
+    soft = 2.8 * 0.5 / 30.
+    engine.dev_bind_particles(torch.zeros(n, 3, dtype=torch.float64, device="cuda") + 0.5, torch.ones(n, dtype=torch.float32, device="cuda"), 1.0)
+    d = {k: dev(torch, v) for k, v in dict(type=typ, flags=flags, hsml=hsml, dthsml=dthsml, maxsignalvel=maxsig, bh_mintimebin=bhmin).items()}
+    seen = set()
+    for case in range(2):
+        Ti_cur = (1 << H.TIMEBINS) + ((5 << 33) if case else 0)
+        tb = rng.randint(28, 42, n).astype(np.uint8)
+        act = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.int32) if case else None
+        # case 0: a PM step (Ti_Current == PM_start + PM_length); case 1: inside a PM step
+        times = dict(mintimebin=30, maxtimebin=41, mingravtimebin=31, Ti_Current=Ti_cur, PM_length=1 << 41, PM_start=Ti_cur - ((1 << 41) if not case else (5 << 33)),
+                     PM_kick=Ti_cur if not case else Ti_cur - (5 << 33), Ti_kick=[0] * (H.TIMEBINS + 1))
+        dti_pm = 1 << 43
+        S = dict(type=typ, flags=flags, gacc=gacc, gravpm=gpm, hsml=hsml, dthsml=dthsml, maxsignalvel=maxsig, tb_grav=tb.copy(), tb_hydro=tb.copy(),
+                 bh_mintimebin=bhmin)
+        t_o = dict(times, Ti_kick=list(times["Ti_kick"]))
+        ro = H.find_timesteps(orc, S, act, t_o, tl, errtol, 1e-7, courant, atime, hubble, soft, dti_max_pm=dti_pm)
+        d_tbg, d_tbh = dev(torch, tb), dev(torch, tb)
+        ts = to_struct(pkg, times)
+        rg = engine.dev_find_timesteps(dict(d, tb_grav=d_tbg, tb_hydro=d_tbh), dev(torch, gacc), dev(torch, gpm), dev(torch, act), ts, sync, errtol, 1e-7,
+                                       courant, atime, hubble, dti_max_pm=dti_pm)
+        engine.synchronize()
+        t_g = dict(times)
+        from_struct(ts, t_g)
+        assert np.array_equal(d_tbh.cpu().numpy(), S["tb_hydro"]) and np.array_equal(d_tbg.cpu().numpy(), S["tb_grav"]), case
+        assert rg == ro, (rg, ro)
+        assert rg["isPM"] == (0 if case else 1)
+        for k in ("mintimebin", "maxtimebin", "PM_length", "PM_start"):
+            assert t_g[k] == t_o[k], (case, k, t_g[k], t_o[k])
+        if not case:                                                  # the PM step was shrunk onto the longest tree step
+            assert t_g["PM_length"] == 1 << rg["maxTimeBin"] < dti_pm and t_g["PM_start"] == times["PM_kick"]
+        changed = d_tbh.cpu().numpy() != tb
+        assert changed.any() and not changed[(flags & 3) != 0].any()
+        seen |= {k for k in range(5) if rg["ntitype"][k] > 0}
+    assert {0, 1, 3, 4} <= seen          # gravity, Courant, the black holes' neighbour limiter and the smoothing-length criterion all decided bins
+
+
 # ---- a resident gas run (round 5): gravity + density + hydro + time bins + kicks + drift, three steps, one upload and one final fetch
 def _gas_run_setup(pkg, n=12):
     G = 43.0071
@@ -254,10 +316,15 @@ def _gas_run_factors(s, KF, sph_times):
 
 
 def _gas_run_times(s, step):
+    if s.get("pm_every_step"):          # (every step ends a PM step: Ti_Current == PM_start + PM_length)
+        return dict(mintimebin=30, maxtimebin=41, mingravtimebin=s["bg"], Ti_Current=step << 41, PM_length=1 << 41, PM_start=(step - 1) << 41,
+                    PM_kick=step << 41, Ti_kick=[0] * 47)
     return dict(mintimebin=30, maxtimebin=41, mingravtimebin=s["bg"], Ti_Current=step << 41, PM_length=1 << 41, PM_start=0, PM_kick=0, Ti_kick=[0] * 47)
 
 
-def _oracle_gas_run(pkg, orc, s, nsteps):
+def _oracle_gas_run(pkg, orc, s, nsteps, run_c_order=False):
+    """run_c_order: the sequence of run.c without SplitGravityTimestepsOn (run.c:553-565, 754-794) - forces, second half kick of the step
+    that ends, find_timesteps (both bins), first half kick of the step that begins, drift - instead of the round-5 sequence."""
     from oracle import hiergrav_oracle as H
     N, box, n, G = s["N"], s["box"], s["n"], s["G"]
     pos, vel, mass, typ = s["pos"].copy(), s["vel"].copy(), s["mass"], s["typ"].astype(np.int32)
@@ -285,6 +352,19 @@ def _oracle_gas_run(pkg, orc, s, nsteps):
         O.sph_hydro_force(orc, trg, dp, O.HydroParams(s["pe"], 100.0, 0.75), A, to)
         S = dict(type=typ8, hsml=A.hsml, dthsml=A.dthsml, maxsignalvel=A.maxsignalvel, tb_grav=A.tb_grav, tb_hydro=A.tb_hydro)
         times = _gas_run_times(s, step)
+        if run_c_order:
+            kick = lambda: O.apply_half_kick(orc, A.vel, acc, K, type=typ8, tb_grav=A.tb_grav, tb_hydro=A.tb_hydro, hydroaccel=A.hydroacc_out,
+                                             entropy=A.entropy, dtentropy=A.dtentropy_out)
+            assert kick() == 0                                                       # run.c:558: the second half of the step that ends
+            O.apply_pm_half_kick(orc, A.vel, gpm, 0.25 * s["dt"])                    # run.c:565
+            S.update(gacc=acc, gravpm=gpm)
+            r = H.find_timesteps(orc, S, None, times, tl, s["errtol_int"], 1e-9, s["courant"], s["atime"], s["hubble"], 2.8 * (box / n) / 30.,
+                                 dti_max_pm=1 << 41)                                 # run.c:756
+            hist.append((r, times["mintimebin"], np.bincount(A.tb_hydro, minlength=47)))
+            assert kick() == 0                                                       # run.c:759: the first half of the step that begins
+            O.apply_pm_half_kick(orc, A.vel, gpm, 0.25 * s["dt"])                    # run.c:794
+            assert O.drift_all_particles(orc, A.pos, A.vel, s["dt"], box, type=typ8, hsml=A.hsml, dthsml=A.dthsml) == 0
+            continue
         r = H.find_hydro_timesteps(S, None, times, tl, 1e-9, s["courant"], s["atime"], s["hubble"], isFirstTimeStep=(step == 0))
         hist.append((r, times["mintimebin"], np.bincount(A.tb_hydro[typ == 0], minlength=47)))
         O.apply_pm_half_kick(orc, A.vel, gpm, 0.5 * s["dt"])
@@ -356,6 +436,72 @@ def test_three_resident_gas_steps_track_the_oracle(pkg, orc):
     assert np.abs(a["hydroacc_out"][gas] - A.hydroacc_out[gas]).max() <= 1e-8 * np.abs(A.hydroacc_out[gas]).max()
     moved = np.abs(np.mod(A.pos - s["pos"] + box / 2, box) - box / 2).max()
     assert moved > 0.05 * sp and np.abs(A.entropy[gas] / s["ent"][gas] - 1).max() > 1e-6        # the run did move particles and entropies
+
+
+def test_resident_gas_steps_in_run_c_order_without_split_gravity(pkg, orc):
+    """the resident stretch must carry a set of integrator functions that one branch of run.c actually calls.  This
+    drives the branch WITHOUT SplitGravityTimestepsOn in run.c's own order (run.c:522-565, 754-794) on the C-ABI the shim forwards to - per
+    step gravpm_force, force_tree_full, grav_short_tree, density, hydro_force, apply_half_kick (second half), apply_PM_half_kick,
+    find_timesteps (gravity + hydro criteria, BOTH time bins, every step a PM step), apply_half_kick (first half), apply_PM_half_kick,
+    drift_all_particles - three steps, ONE upload and ONE fetch, against the same sequence on the CPU oracle.  The time bins are fetched after
+    every find_timesteps (mpg_resident_fetch_timebins: what build_active_particles reads on the host) and must equal the oracle's there too."""
+    from oracle import hiergrav_oracle as H
+    from test_gpu_hiergrav import to_struct, from_struct
+    s = _gas_run_setup(pkg)
+    s["errtol_int"] = 0.05
+    s["pm_every_step"] = True
+    N, box, n = s["N"], s["box"], s["n"]
+    nsteps = 3
+    A, o_acc, o_gpm, hist = _oracle_gas_run(pkg, orc, s, nsteps, run_c_order=True)
+    eng = pkg.Engine(0)
+    eng.gravshort_fill_ntab(0, 1.5)
+    eng.gravpm_init_periodic(box, 1.5, s["nmesh"], s["G"])
+    eng.set_gravshort_treepar(TreeUseBH=0)
+    eng.gravshort_set_softenings(box / n)
+    eng.set_densitypar(1.0, 2.0, 2.0, 99999., pkg.engine.DENSITY_KERNEL_QUINTIC_SPLINE, 0.006)
+    eng.set_hydropar(s["pe"], 100.0, 0.75)
+    P = pkg.make_particles(s["pos"], s["mass"], type=s["typ"])
+    P["Vel"] = s["vel"]
+    z = lambda *sh: np.zeros(sh)
+    a = dict(hsml=np.full(N, 2.5 * box / n), dthsml=z(N), vel=s["vel"].copy(), gacc=z(N, 3), gpm=z(N, 3), hydroacc_in=z(N, 3),
+             tb_hydro=np.full(N, 38, np.uint8), tb_grav=np.full(N, s["bg"], np.uint8), entropy=s["ent"].copy(), dtentropy_in=z(N), density=z(N),
+             egywtdensity=z(N), dhsmlegyfac=z(N), divvel=z(N), curlvel=z(N), hydroacc_out=z(N, 3), dtentropy_out=z(N), maxsignalvel=z(N))
+    K, t = _gas_run_factors(s, pkg.KickFactors, lambda **kw: make_times_like(pkg, **kw))
+    eng.resident_begin(P, box)
+    eng.resident_sph_begin(P, a)
+    res, bins = [], []
+    for step in range(nsteps):
+        eng.gravpm_force(P)
+        eng.force_tree_full(P, box)
+        eng.grav_short_tree(P)
+        eng.density(P, box, a, t, DoEgyDensity=s["pe"])
+        eng.hydro_force(P, a, t)
+        eng.resident_apply_half_kick(P, K)
+        eng.resident_apply_pm_half_kick(P, 0.25 * s["dt"])
+        ts = to_struct(pkg, _gas_run_times(s, step))
+        res.append((eng.resident_find_timesteps(P, ts, s["sync"], s["errtol_int"], 1e-9, s["courant"], s["atime"], s["hubble"], dti_max_pm=1 << 41),
+                    int(ts.mintimebin)))
+        bins.append(eng.resident_fetch_timebins(N))
+        eng.resident_apply_half_kick(P, K)
+        eng.resident_apply_pm_half_kick(P, 0.25 * s["dt"])
+        eng.resident_drift_all_particles(P, s["dt"])
+    eng.resident_sph_end(a)
+    eng.resident_end(P)
+    eng.close()
+    for (rg, mb_g), (ro, mb_o, hb), (tbh, tbg) in zip(res, hist, bins):
+        assert rg == ro and mb_g == mb_o, (rg, ro)
+        assert np.array_equal(np.bincount(tbh, minlength=47), hb) and np.array_equal(tbh, tbg)   # find_timesteps sets both bins alike
+    sp = box / n
+    gas = s["typ"] == 0
+    dpos = np.abs(np.mod(P["Pos"] - A.pos + box / 2, box) - box / 2).max()
+    assert dpos <= 1e-9 * sp, dpos
+    assert np.abs(P["Vel"] - A.vel).max() <= 1e-9 * np.abs(A.vel).max()
+    assert np.array_equal(a["tb_hydro"], A.tb_hydro) and np.array_equal(a["tb_grav"], A.tb_grav)
+    assert len(np.unique(a["tb_hydro"])) >= 3 and len(np.unique(a["tb_grav"][~gas])) >= 1
+    assert res[-1][0]["ntitype"][0] > 0 and res[-1][0]["ntitype"][1] > 0                 # gravity and Courant both set bins
+    for k in ("hsml", "entropy", "density", "dtentropy_out", "maxsignalvel"):
+        g, o = a[k][gas], getattr(A, k)[gas]
+        assert np.abs(g - o).max() <= 1e-8 * np.abs(o).max(), (k, np.abs(g - o).max() / np.abs(o).max())
 
 
 def make_times_like(pkg, atime=1.0, hubble=0.1, **kw):

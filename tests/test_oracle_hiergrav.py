@@ -84,3 +84,39 @@ def test_hydro_timestep_restatement_closed_forms():
     b0 = int(math.floor(math.log2(dl0 / (math.log(4.0) / (1 << H.TIMEBINS)))))
     assert S["tb_hydro"][0] == b0 and S["tb_hydro"][1] == 33 and S["tb_hydro"][2] == 30
     assert r["ntitype"] == [1, 1, 0, 0, 0] and r["mTimeBin"] == b0 and t["mintimebin"] == min(b0, 33)
+
+
+def test_find_timesteps_restatement_closed_forms(orc):
+    """find_timesteps as restated in oracle/hiergrav_oracle.py (timestep.c:739-849; the reference holds no test of it) against values worked
+    out by hand: the gravity step dt = sqrt(2 eta a eps / |a_phys|), eps = FORCE_SOFTENING / 2.8, a_phys = (FullTreeGravAccel + GravPM) / a^2;
+    gas takes the shorter of the two steps and BOTH bins follow; a PM step takes the handed-in length and is shrunk onto the longest tree
+    step; an inactive old bin keeps its bins but still enters the extrema."""
+    import math
+    a, hub, C, eta, soft = 0.5, 0.3, 0.15, 0.025, 0.07
+    tl = H.Timeline(np.log(np.array([0.25, 1.0])))
+    iv = math.log(4.0) / (1 << H.TIMEBINS)
+    g = np.array([[3.0, 0, 0], [0, 4.0e4, 0], [0, 0, 1e-3], [1.0, 1.0, 1.0]])
+    pm = np.array([[1.0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0]])
+    S = dict(type=np.array([1, 1, 0, 0], np.uint8), gacc=g, gravpm=pm, hsml=np.full(4, 0.5), dthsml=np.zeros(4), maxsignalvel=np.array([1.0, 1.0, 1e3, 1e-9]),
+             tb_grav=np.array([30, 30, 30, 30], np.uint8), tb_hydro=np.array([30, 30, 30, 30], np.uint8))
+    t = dict(mintimebin=30, maxtimebin=41, mingravtimebin=30, Ti_Current=0, PM_length=1 << 40, PM_start=-(1 << 40), PM_kick=0, Ti_kick=[0] * 47)
+    r = H.find_timesteps(orc, S, None, t, tl, eta, 1e-12, C, a, hub, soft, dti_max_pm=1 << 44)
+
+    def bin_of(dloga):
+        return int(math.floor(math.log2(dloga / iv)))
+    dl_g = [math.sqrt(2 * eta * a * (soft / 2.8) / (x / (a * a))) * hub for x in (4.0, 4.0e4, 1e-3, math.sqrt(3.0))]
+    dl_h2 = 2 * C * a * a * 0.5 / 1e3 * hub
+    want = [bin_of(dl_g[0]), bin_of(dl_g[1]), min(bin_of(dl_g[2]), bin_of(dl_h2)), bin_of(dl_g[3])]
+    want = [min(b, 44) for b in want]                                   # capped at the PM step
+    assert S["tb_hydro"].tolist() == want and S["tb_grav"].tolist() == want
+    assert bin_of(dl_h2) < bin_of(dl_g[2])                              # (the gas particle's bin did come from the Courant criterion)
+    assert r["ntitype"] == [3, 1, 0, 0, 0] and r["isPM"] == 1
+    assert r["mTimeBin"] == min(want) and r["maxTimeBin"] == max(want)
+    assert t["mintimebin"] == min(want) and t["maxtimebin"] == max(want)
+    assert t["PM_length"] == min(1 << 44, 1 << max(want)) and t["PM_start"] == 0
+    # between PM steps, at a time where the old bin 30 is not active: the bins stay, the extrema still see the new bins
+    S2 = dict(S, tb_grav=np.full(4, 30, np.uint8), tb_hydro=np.full(4, 30, np.uint8))
+    t2 = dict(mintimebin=30, maxtimebin=41, mingravtimebin=30, Ti_Current=1 << 29, PM_length=1 << 40, PM_start=0, PM_kick=0, Ti_kick=[0] * 47)
+    r2 = H.find_timesteps(orc, S2, None, t2, tl, eta, 1e-12, C, a, hub, soft)
+    assert S2["tb_hydro"].tolist() == [30] * 4 and S2["tb_grav"].tolist() == [30] * 4 and r2["isPM"] == 0 and t2["PM_length"] == 1 << 40
+    assert r2["mTimeBin"] <= 30 and t2["mintimebin"] == r2["mTimeBin"]

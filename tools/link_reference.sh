@@ -12,7 +12,7 @@
 #   1. copy the checkout (the reference tree itself is never modified);
 #   2. copy shim/*.c, shim/*.h and include/mpgadget_hip.h into <copy>/libgadget/;
 #   3. patch <copy>/libgadget/Makefile: drop gravpm.o gravshort-tree.o gravshort-pair.o gravity.o from GADGET_OBJS and add the shim
-#      objects; rename the five tree constructors in forcetree.o and the four integrator entry points in timestep.o / drift.o
+#      objects; rename the five tree constructors in forcetree.o and the eight integrator entry points in timestep.o / drift.o
 #      (-Dname=cpu_name); guard the three SPH loops of density.c / hydra.c (-DMPGADGET_HIP);
 #   4. add the two parameter hooks (set_densitypar, set_hydro_params), the accessors of mpg_shim.h and the
 #      mpg_shim_particles_changed() calls listed in INTEGRATION.md ("Where P[] is reordered") with sed;
@@ -68,7 +68,7 @@ cat >> "$MK" <<MKEOF
 # ---- MP-Gadget on libmpgadget_hip (tools/link_reference.sh)
 CFLAGS += -DMPGADGET_HIP -I$ROOT/include
 .objs/forcetree.o: CFLAGS += -Dforce_tree_full=cpu_force_tree_full -Dforce_tree_rebuild_mask=cpu_force_tree_rebuild_mask -Dforce_tree_active_moments=cpu_force_tree_active_moments -Dforce_tree_calc_moments=cpu_force_tree_calc_moments -Dforce_tree_free=cpu_force_tree_free
-.objs/timestep.o: CFLAGS += -Dapply_half_kick=cpu_apply_half_kick -Dapply_PM_half_kick=cpu_apply_PM_half_kick -Dfind_hydro_timesteps=cpu_find_hydro_timesteps
+.objs/timestep.o: CFLAGS += -Dapply_half_kick=cpu_apply_half_kick -Dapply_PM_half_kick=cpu_apply_PM_half_kick -Dfind_hydro_timesteps=cpu_find_hydro_timesteps -Dfind_timesteps=cpu_find_timesteps -Dapply_hydro_half_kick=cpu_apply_hydro_half_kick -Dhierarchical_gravity_and_timesteps=cpu_hierarchical_gravity_and_timesteps -Dhierarchical_gravity_accelerations=cpu_hierarchical_gravity_accelerations
 .objs/drift.o: CFLAGS += -Ddrift_all_particles=cpu_drift_all_particles
 MKEOF
 
@@ -125,7 +125,11 @@ before_return(T + "/libgadget/hydra.c", "set_hydro_params",
 # the accessors of mpg_shim.h next to the file-static parameters they read
 append(T + "/libgadget/timestep.c", "double mpg_shim_max_gas_vel(void) { return TimestepParams.MaxGasVel; }\n"
        "double mpg_shim_min_size_timestep(void) { return TimestepParams.MinSizeTimestep; }\n"
-       "double mpg_shim_courant_fac(void) { return TimestepParams.CourantFac; }")
+       "double mpg_shim_courant_fac(void) { return TimestepParams.CourantFac; }\n"
+       "double mpg_shim_err_tol_int_accuracy(void) { return TimestepParams.ErrTolIntAccuracy; }\n"
+       "int mpg_shim_force_equal_timesteps(void) { return TimestepParams.ForceEqualTimesteps; }\n"
+       "inttime_t mpg_shim_get_PM_timestep_ti(const DriftKickTimes *times, double atime, const Cosmology *CP, int FastParticleType, double asmth)\n"
+       "{ return get_PM_timestep_ti(times, atime, CP, FastParticleType, asmth); }")
 append(T + "/libgadget/timebinmgr.c", "#include <mpgadget_hip.h>\nvoid mpg_shim_timeline(mpg_timeline *tl)\n{\n    static double loga[8192];\n    int i;\n"
        "    for(i = 0; i < NSyncPoints && i < 8192; i++)\n        loga[i] = SyncPoints[i].loga;\n    tl->nsync = NSyncPoints;\n    tl->loga = loga;\n}")
 # P[] is reordered / exchanged: the shim's upload cache must hear of it (the 64-record hash of mpg_shim_epoch.h is only a backstop)
@@ -143,7 +147,7 @@ if [ "$CHECK" = "--check" ]; then
         extra=""
         case $f in
             forcetree.c) extra="-Dforce_tree_full=cpu_force_tree_full -Dforce_tree_rebuild_mask=cpu_force_tree_rebuild_mask -Dforce_tree_active_moments=cpu_force_tree_active_moments -Dforce_tree_calc_moments=cpu_force_tree_calc_moments -Dforce_tree_free=cpu_force_tree_free";;
-            timestep.c) extra="-Dapply_half_kick=cpu_apply_half_kick -Dapply_PM_half_kick=cpu_apply_PM_half_kick -Dfind_hydro_timesteps=cpu_find_hydro_timesteps";;
+            timestep.c) extra="-Dapply_half_kick=cpu_apply_half_kick -Dapply_PM_half_kick=cpu_apply_PM_half_kick -Dfind_hydro_timesteps=cpu_find_hydro_timesteps -Dfind_timesteps=cpu_find_timesteps -Dapply_hydro_half_kick=cpu_apply_hydro_half_kick -Dhierarchical_gravity_and_timesteps=cpu_hierarchical_gravity_and_timesteps -Dhierarchical_gravity_accelerations=cpu_hierarchical_gravity_accelerations";;
             drift.c) extra="-Ddrift_all_particles=cpu_drift_all_particles";;
         esac
         if ! gcc -std=gnu11 -fopenmp -fsyntax-only -DMPGADGET_HIP $extra -I "$STUB" -I "$MPIINC" -I "$ROOT/include" -I "$T/libgadget" -I "$T" "$T/libgadget/$f" 2> "$STUB/err"; then

@@ -56,6 +56,40 @@ KERNEL(k_rsq_f32, float f[NCH]; for(int q = 0; q < NCH; q++) f[q] = threadIdx.x 
 KERNEL(k_bpermute, , asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(ia[j]) : "v"(ia[(j + 1) % NCH] & 252)))
 KERNEL(k_dpp_mov, , asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(ia[j]) : "v"(ia[(j + 1) % NCH])))
 
+// round 6: the fp32 instructions a pre-classification of the node tests would be made of (plain and packed)
+#define F32DECL float f[NCH]; for(int q = 0; q < NCH; q++) f[q] = threadIdx.x + q + 1; float fb = (float)b, fc = (float)c
+#define F32USE ia[j] = __float_as_int(f[j])
+KERNEL(k_add_f32, F32DECL, asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fc)); F32USE)
+KERNEL(k_mul_f32, F32DECL, asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fb)); F32USE)
+KERNEL(k_max_f32, F32DECL, asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[j]) : "v"(fc)); F32USE)
+KERNEL(k_max3_f32, F32DECL, asm volatile("v_max3_f32 %0, |%0|, |%1|, |%2|" : "+v"(f[j]) : "v"(fb), "v"(fc)); F32USE)
+KERNEL(k_cmp_f32_vcc, F32DECL, asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(f[j]), "v"(fb) : "vcc"); F32USE)
+KERNEL(k_cmp_f32_sgpr, F32DECL; unsigned long long m = 0, asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m) : "v"(f[j]), "v"(fb)); ia[j] += (int)m)
+KERNEL(k_cmp_f64_sgpr, unsigned long long m = 0, asm volatile("v_cmp_lt_f64 %0, %1, %2" : "=s"(m) : "v"(a[j]), "v"(b)); ia[j] += (int)m)
+KERNEL(k_sqrt_f32, F32DECL, asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[j])); F32USE)
+// packed fp32: a[j] (a VGPR pair) carries two floats
+KERNEL(k_pk_add_f32, , asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[j]) : "v"(c)))
+KERNEL(k_pk_mul_f32, , asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[j]) : "v"(b)))
+KERNEL(k_pk_fma_f32, , asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "v"(c)))
+KERNEL(k_pk_add_f32_bc, , asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(a[j]) : "v"(c)))
+// a fp64 and a fp32 stream side by side: do they share the issue slots?
+KERNEL(k_mix_f64_f32, F32DECL, asm volatile("v_add_f64 %0, %0, %2\n v_add_f32 %1, %1, %3" : "+v"(a[j]), "+v"(f[j]) : "v"(c), "v"(fc)); F32USE)
+KERNEL(k_mix_f64_pk, double a2[NCH]; for(int q = 0; q < NCH; q++) a2[q] = a[q], asm volatile("v_add_f64 %0, %0, %2\n v_pk_add_f32 %1, %1, %2" : "+v"(a[j]), "+v"(a2[j]) : "v"(c)); ia[j] += (int)a2[j])
+
+KERNEL(k_min_i32, , asm volatile("v_min_i32 %0, %0, %1" : "+v"(ia[j]) : "v"(ia[(j + 1) % NCH])))
+KERNEL(k_min3_f32, F32DECL, asm volatile("v_min3_f32 %0, |%0|, |%1|, |%2|" : "+v"(f[j]) : "v"(fb), "v"(fc)); F32USE)
+KERNEL(k_min_f32_abs, F32DECL, asm volatile("v_min_f32 %0, |%0|, |%1|" : "+v"(f[j]) : "v"(fb)); F32USE)
+KERNEL(k_and_or_b32, , asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(ia[j]) : "v"(ia[(j + 1) % NCH]), "v"(ia[(j + 2) % NCH])))
+KERNEL(k_cmp_i32_sgpr, unsigned long long m = 0, asm volatile("v_cmp_lt_i32 %0, %1, %2" : "=s"(m) : "v"(ia[j]), "v"(ia[(j + 1) % NCH])); ia[j] += (int)m)
+KERNEL(k_cmp_f32_vcc_mov, F32DECL; unsigned long long m = 0, asm volatile("v_cmp_lt_f32 vcc, %1, %2\n s_mov_b64 %0, vcc" : "=s"(m) : "v"(f[j]), "v"(fb) : "vcc"); ia[j] += (int)m)
+KERNEL(k_cmp_f32_lit, F32DECL; unsigned long long m = 0, asm volatile("v_cmp_lt_f32 %0, 0, %1" : "=s"(m) : "v"(f[j])); ia[j] += (int)m)
+KERNEL(k_cmp_class_f32, F32DECL; unsigned long long m = 0, asm volatile("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(f[j]), "v"(ia[j])); ia[j] += (int)m)
+KERNEL(k_mbcnt, , asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0\n v_mbcnt_hi_u32_b32 %0, %1, %0" : "+v"(ia[j]) : "s"(j * 77)))
+KERNEL(k_sub_f32_x6_cmp, F32DECL; unsigned long long m = 0, asm volatile("v_sub_f32 %1, %1, %2\n v_sub_f32 %1, %1, %2\n v_fma_f32 %1, %1, %2, %2\n v_cmp_lt_f32 %0, %1, %2" : "=s"(m), "+v"(f[j]) : "v"(fb)); ia[j] += (int)m)
+
+KERNEL(k_cmp_f32_sgpr4, F32DECL; unsigned long long m[4]; m[0] = m[1] = m[2] = m[3] = 0, asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m[j & 3]) : "v"(f[j]), "v"(fb)); ia[j] += (int)m[j & 3])
+KERNEL(k_cmp_f64_sgpr4, unsigned long long m[4]; m[0] = m[1] = m[2] = m[3] = 0, asm volatile("v_cmp_lt_f64 %0, %1, %2" : "=s"(m[j & 3]) : "v"(a[j]), "v"(b)); ia[j] += (int)m[j & 3])
+
 __global__ void __launch_bounds__(256) k_lds128(double *out, double seed)
 {
     __shared__ double tab[2048];
@@ -125,5 +159,31 @@ int main()
     R(k_bpermute);
     R(k_dpp_mov);
     R(k_lds128);
+    R(k_add_f32);
+    R(k_mul_f32);
+    R(k_max_f32);
+    R(k_max3_f32);
+    R(k_cmp_f32_vcc);
+    R(k_cmp_f32_sgpr);
+    R(k_cmp_f64_sgpr);
+    R(k_sqrt_f32);
+    R(k_pk_add_f32);
+    R(k_pk_mul_f32);
+    R(k_pk_fma_f32);
+    R(k_pk_add_f32_bc);
+    R(k_mix_f64_f32);
+    R(k_mix_f64_pk);
+    R(k_min_i32);
+    R(k_min3_f32);
+    R(k_min_f32_abs);
+    R(k_and_or_b32);
+    R(k_cmp_i32_sgpr);
+    R(k_cmp_f32_vcc_mov);
+    R(k_cmp_f32_lit);
+    R(k_cmp_class_f32);
+    R(k_mbcnt);
+    R(k_sub_f32_x6_cmp);
+    R(k_cmp_f32_sgpr4);
+    R(k_cmp_f64_sgpr4);
     return 0;
 }
