@@ -79,7 +79,7 @@ def walk_roofline(eng, cnt, walk_ms, walk_launches, traffic, traffic_note):
          "node_entries_per_launch": cnt["int_lanes"] if variant == 6 else None,
          # round 6: target passes of the list kernel whose fp32 pre-classification was ambiguous and that ran the fp64 tests instead
          # (counted by the COUNT builds; every other pass took its decisions from fp32 - DESIGN 3.2, round 6)
-         "fp32_fallback_passes_per_launch": cnt["cycles_a"] if variant == 6 else None,
+         "fp32_fallback_passes_per_launch": cnt.get("f32_fallback") if variant == 6 else None,
          "note": "one launch = one short-range walk over all targets; the walk is bound by fp64 VALU issue (pairwise kernel with a "
                  "per-pair window-table lookup; MFMA does not apply), so frac = 38 flop x (N_pp + N_nodes_used) / t / 78.6 TFLOP/s; "
                  "hbm_measured_frac = PMC traffic / t / 8 TB/s; reuse = SURVEY 8(d) B_walk / PMC traffic"}
@@ -712,6 +712,7 @@ def gravity_bench_ranks(pkg, torch, dist, args, dev, rank, world, local_rank):
     step()
     sync()
     cnt = eng.walk_counters()
+    cnt["f32_fallback"] = eng.walk_f32_stats()[0] if os.environ.get("MPG_LISTS_F32") == "1" else None
     eng.set_instrumentation(False, False)
     eng.walk_events_collect()
     per_rank = ranks_roofline(pkg, torch, dist, dev, rank, world, eng, cnt, walk_ms, walk_launches, n_own, st["ghosts"], args.ic)
@@ -821,6 +822,7 @@ def gravity_bench_single(pkg, torch, args, dev, local_rank):
     step()
     torch.cuda.synchronize()
     cnt = eng.walk_counters()
+    cnt["f32_fallback"] = eng.walk_f32_stats()[0] if os.environ.get("MPG_LISTS_F32") == "1" else None
     eng.set_instrumentation(False, False)
     eng.walk_events_collect()
     variant = eng.walk_choice()[0]

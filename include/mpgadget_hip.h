@@ -308,6 +308,9 @@ int mpg_tree_export_order(mpg_engine *eng, int32_t *order);
  * treewalk.c:904-912), [1] nodes visited, [2] nodes used unopened, [3] targets, [4..7] phase statistics of the
  * cooperative kernel: phase-A group steps, nodes consumed by them (of 8 tested each), phase-B lane-steps issued, of which active; [8],[9] wave clock cycles spent in phase A / phase B (summed over waves). */
 int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[10]);
+/* ... and of the list kernel's fp32 pre-classification of the node tests (MPG_LISTS_F32=1; counting walks only): [0] target passes that fell
+ * back to the fp64 tests, [1] waves (8 targets) whose main loop ran the fp32 form */
+int mpg_walk_get_f32_stats(mpg_engine *eng, int64_t out[2]);
 /* Per-phase device times (ms, HIP events on the engine stream) of the last call of each phase. */
 typedef struct mpg_phase_times {
     float pm_deposit, pm_fft, pm_transfer, pm_readout, pm_total;

@@ -526,6 +526,23 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
         MPG_HIP(hipEventCreate(&mid));
     eng->w3.ev_mid = mid;
     eng->w3.mid_recorded = false;
+    //  a walk that throws - a loop guard, an overflow - must not leave w3.ev_mid pointing at an event nobody owns, nor
+    // lose the three events: the guard hands them back unless the normal path below has filed them
+    struct EventGuard {
+        mpg_engine *e;
+        std::pair<hipEvent_t, hipEvent_t> *ev;
+        hipEvent_t *mid;
+        bool filed = false;
+        ~EventGuard()
+        {
+            if(filed)
+                return;
+            e->w3.ev_mid = nullptr;
+            e->w3.mid_recorded = false;
+            e->free_events.push_back(*ev);
+            e->free_mid.push_back(*mid);
+        }
+    } ev_guard{eng, &ev, &mid};
     // hoisting the minimum-image wrap out of the pair loop is valid when every source range shares the image of its
     // node: Rcut + 1.5 * (largest leaf side) < Box/2, and Rcut well below Box/4 (see grav_walk_coop.hip)
     const double maxleaf = 1.001 * gp.box / (double)(1 << eng->tree.minleaflevel);
@@ -563,6 +580,7 @@ int mpg_dev_grav_short_tree(mpg_engine *eng, const double *d_oldacc, const doubl
     if(variant > 0)
         run_variant(variant);
     MPG_HIP(hipEventRecord(ev.second, eng->stream));
+    ev_guard.filed = true;
     eng->walk_events.push_back(ev);
     eng->w3.ev_mid = nullptr;
     if(eng->w3.mid_recorded)
@@ -1977,6 +1995,9 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
         writer.join();
         MPG_CHECK(therr.empty(), "host path: the write-back of the walk's results failed: " + therr);
         hc.mark("last slice down");
+        //  P[].FullTreeGravAccel now holds THIS walk's result: the copy staged at the epoch's first upload is no longer
+        // what grav_short_copy (gravshort.h:82-86) would read.  A second walk of the same epoch takes OldAcc from P[] again.
+        eng->staged_extra_epoch = -1;
         mpg_err_slot().clear();
         return 0;
     }
@@ -2046,6 +2067,8 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
         });
     }
     hc.mark("download+unpack");
+    if(full) // (as above: a walk wrote P[].FullTreeGravAccel; the staged copy of the old one must not open nodes for a second walk of the epoch)
+        eng->staged_extra_epoch = -1;
     API_END
 }
 
@@ -2891,6 +2914,19 @@ int mpg_walk_get_counters(mpg_engine *eng, int64_t counters[10])
     counters[3] = eng->last_targets;
     for(int k = 0; k < 6; k++)
         counters[4 + k] = (int64_t)c[3 + k];
+    API_END
+}
+
+int mpg_walk_get_f32_stats(mpg_engine *eng, int64_t out[2])
+{
+    API_BEGIN
+    MPG_CHECK(eng && out, "null argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    MPG_HIP(hipStreamSynchronize(eng->stream));
+    unsigned long long c[16] = {0};
+    MPG_HIP(hipMemcpy(c, eng->counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    out[0] = (int64_t)c[12];
+    out[1] = (int64_t)c[13];
     API_END
 }
 

@@ -359,7 +359,7 @@ __device__ __forceinline__ unsigned mbcnt64(const unsigned long long b)
 //     (a superset of the lanes where some deciding slack is within its margin): three compares instead of five;
 //   * a pass with an ambiguous active lane, a node or target outside the range fp32 handles (m l2 or aold beyond 1e-30 .. 1e30) re-reads the node
 //     and runs node_test_masks in fp64.  Decisions are therefore exactly the reference's; COUNT builds evaluate both and raise ctl[1] = 3 on any
-//     difference, and count the ambiguous passes (counters[7]).
+//     difference, and count the ambiguous passes (counters[12]; [13]: the waves that ran the fp32 form).
 struct F32Wave {
     double ox, oy, oz;   // the origin (wave-uniform)
     float w1, c1;        // n1 = fma(r2, w1, c1)
@@ -930,9 +930,9 @@ __global__ void __launch_bounds__(256, MPG_LIST_BLOCKS) k_walk_lists8(const Tree
             atomicAdd(&io.counters[3], c3);
             atomicAdd(&io.counters[4], c4);
             if(F32 && n_amb)
-                atomicAdd(&io.counters[7], (unsigned long long)n_amb); // target passes that fell back to fp64 (lane 0 counts: wave-uniform)
+                atomicAdd(&io.counters[12], (unsigned long long)n_amb); // target passes that fell back to fp64 (lane 0 counts: wave-uniform)
             if(F32 && n_f32w)
-                atomicAdd(&io.counters[8], (unsigned long long)n_f32w); // waves (chunks of 8 targets) whose main loop ran the fp32 tests
+                atomicAdd(&io.counters[13], (unsigned long long)n_f32w); // waves (chunks of 8 targets) whose main loop ran the fp32 tests
         }
     }
 }
@@ -1440,6 +1440,10 @@ void launch_grav_walk_split(const TreeView &tv, const GravParams &gp, const Walk
         // four times the capacity a fraction of one.  (Not when the interaction counters are on: they would count twice.)
         if(!count && (int64_t)ctl[0] * 5 > io.ntargets && ws.split_cap < 8192) {
             ws.split_cap = ws.split_cap * 4 < 8192 ? ws.split_cap * 4 : 8192;
+            // (the event between the two kernels was recorded in the pass that is now repeated: a lists / eval split taken from it would
+            // count a whole first pass as list construction - no split for this walk)
+            ws.mid_recorded = false;
+            ws.ev_mid = nullptr;
             continue;
         }
         break;

@@ -258,6 +258,10 @@ int cb_alltoallv(void *ctx, const void *send, const int64_t *sb, const int64_t *
 {
     mpg_rccl *r = (mpg_rccl *)ctx;
     r->calls[2]++;
+    if(r->dead) { // (every callback fails at once on an aborted communicator; cb_alltoall_i64 and the self-test come through here)
+        r->error = "the communicator was aborted after a failed collective";
+        return 1;
+    }
     HIP_TRY(r, hipSetDevice(r->device));
     for(int p = 0; p < r->nt; p++)
         if(p != r->me)
@@ -475,10 +479,15 @@ void mpg_rccl_destroy(mpg_rccl *r)
     if(!r)
         return;
     (void)hipSetDevice(r->device);
-    if(r->stream)
-        (void)hipStreamSynchronize(r->stream);
-    if(r->comm && api().CommDestroy)
-        api().CommDestroy(r->comm);
+    //  a communicator that died half-way through a group - and could not be aborted because this RCCL exports no
+    // ncclCommAbort - still has operations enqueued whose peers will never arrive: neither wait for the stream nor ask RCCL to tear the
+    // communicator down (both can block for ever); the process is on its way out anyway
+    if(!r->dead) {
+        if(r->stream)
+            (void)hipStreamSynchronize(r->stream);
+        if(r->comm && api().CommDestroy)
+            api().CommDestroy(r->comm);
+    }
     if(r->own_stream)
         (void)hipStreamDestroy(r->own_stream);
     delete r;

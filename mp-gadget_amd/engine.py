@@ -802,6 +802,12 @@ class Engine:
         return dict(pp=c[0], nodes_visited=c[1], nodes_used=c[2], targets=c[3], node_steps=c[4], node_lanes=c[5],
                     int_steps=c[6], int_lanes=c[7], cycles_a=c[8], cycles_b=c[9])
 
+    def walk_f32_stats(self):
+        """(fp64 fall-back passes, waves on the fp32 node tests) of the last counting walk with MPG_LISTS_F32=1"""
+        c = (C.c_int64 * 2)()
+        self._ck(self.lib.mpg_walk_get_f32_stats(self.h, c))
+        return int(c[0]), int(c[1])
+
     def walk_events_collect(self):
         """(total_ms, launches) of the walk kernel since the last collect, from HIP events on the engine stream."""
         tot = C.c_double()

@@ -273,13 +273,13 @@ def test_walk_lists_f32_preclassification(pkg, engine, orc, mode, monkeypatch):
         engine.force_tree_full(P, box)
         engine.grav_short_tree(P)
         c = engine.walk_counters()
+        fallback, f32_waves = engine.walk_f32_stats()
     finally:
         engine.set_walk_variant(0)
         engine.set_instrumentation(False, False)
     assert (c["pp"], c["nodes_visited"], c["nodes_used"]) == tuple(c_ref)
     assert_accel_parity(P["FullTreeGravAccel"], a_ref)
     assert np.abs(P["Potential"] - p_ref).max() <= 1e-10 * np.abs(p_ref).mean()
-    f32_waves, fallback = c["cycles_b"], c["cycles_a"]
     assert f32_waves > 0.2 * len(pos) / 8, (f32_waves, len(pos) // 8)        # the interior waves (no target near a face) did run the fp32 tests
     if mode == "tiny_aold":
         assert fallback > f32_waves          # every pass of those waves went to fp64 (aold outside 1e-30 .. 1e30)
@@ -853,6 +853,39 @@ def test_host_path_overlap_gives_the_synchronous_results(pkg, engine, n):
             assert np.abs(p1 - p0).max() <= 1e-9 * np.abs(p0).max(), mode
             assert np.all(g1[dead] == 0) and np.all(a1[dead] == 0) and np.all(p1[dead] == 0.125)         # garbage: GravPM zeroed, nothing else touched
     assert np.abs(res["sync"][0][2][~dead] - 0.125).min() > 0 and np.abs(res["sync"][1][0] - res["sync"][0][0]).max() > 0
+
+
+def test_host_overlap_second_walk_of_an_epoch_opens_with_the_new_acceleration(pkg, engine):
+    """with mpg_set_host_overlap the first walk of an epoch takes OldAcc on the device from the FullTreeGravAccel that
+    went up with the epoch's one packing pass.  A SECOND grav_short_tree in the same epoch (the hierarchical level loop, a repeated call) must
+    open its nodes with what the first walk wrote into P[] - grav_short_copy reads P[].FullTreeGravAccel (gravshort.h:82-86) - not with the
+    staged pre-step copy: results of two walks per epoch with overlap equal those of the synchronous calls, and differ from a walk that keeps
+    the first opening input (so the test can see the difference)."""
+    n, nmesh = 24, 48
+    pos, mass, box = pkg.ics.s_clust(n, seed=5)
+    setup_engine(engine, box, n, nmesh, TreeUseBH=0)
+    N = len(pos)
+    rng = np.random.RandomState(4)
+    res = {}
+    for mode in ("sync", "overlap"):
+        P = pkg.make_particles(pos, mass)
+        P["FullTreeGravAccel"] = 1e-6 * rng.standard_normal((N, 3)) if mode == "sync" else res["start"]
+        if mode == "sync":
+            res["start"] = P["FullTreeGravAccel"].copy()          # a tiny old acceleration: the first walk opens far more nodes than the second
+        engine.set_host_overlap(0 if mode == "sync" else 1)
+        engine.set_particle_epoch(7000 + len(res))
+        engine.gravpm_force(P)
+        engine.force_tree_full(P, box)
+        engine.grav_short_tree(P)
+        first = P["FullTreeGravAccel"].copy()
+        engine.grav_short_tree(P)                                 # same epoch, same tree: OldAcc is now |first + GravPM| / G
+        res[mode] = (first, P["FullTreeGravAccel"].copy())
+        engine.set_particle_epoch(0)
+    engine.set_host_overlap(False)
+    (f0, s0), (f1, s1) = res["sync"], res["overlap"]
+    scale = np.abs(f0).max()
+    assert np.abs(f1 - f0).max() <= 1e-9 * scale and np.abs(s1 - s0).max() <= 1e-9 * scale
+    assert np.abs(s0 - f0).max() > 1e-6 * scale                  # (the two opening inputs do give different forces: the check above is not vacuous)
 
 
 def test_pm_power_spectrum(pkg, engine, tmp_path):
