@@ -78,25 +78,28 @@ def kernel_W(kernel, r, H):
     return W, dWdr, dWdH
 
 
-def sph_paper(pos, mass, vel, A, H, box, atime=1.0, hubble=0.0, alpha=0.75, kernel=1, formulation="density", dlna=None,
-              active=None):
-    """All pairs, periodic minimum image.  pos [N,3], mass [N], vel = u [N,3], A [N] entropic function, H [N] support radii.
-    formulation: "density" (SH02 / S05) or "pressure" (H13).  dlna [N]: the particles' steps in ln a for the bound on the viscous
-    force (None: bound off).  Returns the density-loop fields and the hydro force for every particle."""
+def _pairs(pos, box):
+    pos = np.asarray(pos, float)
+    d = pos[:, None, :] - pos[None, :, :]
+    d -= box * np.rint(d / box)                 # x_ij = x_i - x_j on the nearest image
+    r = np.sqrt((d ** 2).sum(-1))
+    return d, r
+
+
+def paper_density(pos, mass, vel, A, H, box, kernel=1, formulation="density"):
+    """The density loop for every particle as target (S05 eq 5, SH02 eqs 27-28, H13 eq 19), all pairs.  vel / A are the velocities and
+    entropic functions the SUMS see - the predicted ones when particles carry pending kicks.  Returns a dict of per-particle fields:
+    density, dhsml (SH02's f), divvel, curlvel, and for the pressure-entropy form y, dy_dH, egywtdensity, dhsmlegy."""
     pos = np.asarray(pos, float)
     N = len(pos)
     m = np.asarray(mass, float)
     u = np.asarray(vel, float)
     A = np.asarray(A, float)
     H = np.asarray(H, float)
-    d = pos[:, None, :] - pos[None, :, :]
-    d -= box * np.rint(d / box)                 # x_ij = x_i - x_j on the nearest image
-    r = np.sqrt((d ** 2).sum(-1))
+    d, r = _pairs(pos, box)
     du = u[:, None, :] - u[None, :, :]          # u_ij
     offd = ~np.eye(N, dtype=bool)
     rs = np.where(offd, r, 1.0)
-
-    # ---- density loop: S05 eq 5, SH02 eq 27-28 (grad-h), the SPH velocity gradients
     Wi, dWi, dWHi = kernel_W(kernel, r, H[:, None])        # kernels of i's support, [i, j]
     inside = r < H[:, None]
     Wi, dWi, dWHi = Wi * inside, dWi * inside, dWHi * inside
@@ -108,24 +111,49 @@ def sph_paper(pos, mass, vel, A, H, box, atime=1.0, hubble=0.0, alpha=0.75, kern
     curl = np.cross(du, gradW_i)
     curlu = np.linalg.norm((m[None, :, None] * curl).sum(1), axis=1) / rho
     out = dict(density=rho, dhsml=f_grad, divvel=divu, curlvel=curlu)
+    if formulation != "density":
+        # H13 eq 19: y_i = Pbar_i^(1/gamma) = sum_j m_j A_j^(1/gamma) W_ij(h_i)
+        a_g = A ** (1.0 / GAMMA)
+        y = (m[None, :] * a_g[None, :] * Wi).sum(1)
+        dy_dH = (m[None, :] * a_g[None, :] * dWHi).sum(1)
+        out["y"] = y
+        out["egywtdensity"] = y / a_g                       # "energy weighted density" (the reference's EgyWtDensity)
+        # H13 eq 18 with the smoothing length tied to rho (x~_j = m_j, y~ = rho):
+        # f_ij - 1 = -(1 / A_j^(1/gamma)) (h_i / 3 rho_i) (d y_i / d h_i) [1 + (h_i / 3 rho_i) d rho_i / d h_i]^-1
+        out["dhsmlegy"] = -(dy_dH * H / (3.0 * y)) * f_grad   # the reference stores this combination (times y/rho it is the bracket)
+    return out
 
-    # ---- thermodynamics
+
+def paper_hydro(pos, mass, vel, A, H, box, F, atime=1.0, hubble=0.0, alpha=0.75, kernel=1, formulation="density", dlna=None,
+                contrast_limit=None):
+    """The hydro force of every particle as target from per-particle FIELDS F (what paper_density returns, or the stored / predicted values
+    of particles that were not active in the density loop): density, dhsml, divvel, curlvel and, pressure-entropy, egywtdensity and dhsmlegy.
+    vel / A as in paper_density.  contrast_limit (pressure-entropy; a limiter of the code, not of H13): the grad-h correction of a particle is
+    scaled down where its y / (A^(1/gamma) rho) exceeds the limit (None: no limit)."""
+    pos = np.asarray(pos, float)
+    N = len(pos)
+    m = np.asarray(mass, float)
+    u = np.asarray(vel, float)
+    A = np.asarray(A, float)
+    H = np.asarray(H, float)
+    d, r = _pairs(pos, box)
+    du = u[:, None, :] - u[None, :, :]
+    offd = ~np.eye(N, dtype=bool)
+    rs = np.where(offd, r, 1.0)
+    rho, f_grad, divu, curlu = (np.asarray(F[k], float) for k in ("density", "dhsml", "divvel", "curlvel"))
+    _, dWi, _ = kernel_W(kernel, r, H[:, None])
+    dWi = dWi * (r < H[:, None])
+    out = {}
     if formulation == "density":
         P = A * rho ** GAMMA
         eom = rho                                   # the density of the equations of motion
         c = np.sqrt(GAMMA * P / rho)
     else:
-        # H13 eq 19: y_i = Pbar_i^(1/gamma) = sum_j m_j A_j^(1/gamma) W_ij(h_i)
         a_g = A ** (1.0 / GAMMA)
-        y = (m[None, :] * a_g[None, :] * Wi).sum(1)
-        dy_dH = (m[None, :] * a_g[None, :] * dWHi).sum(1)
+        eom = np.asarray(F["egywtdensity"], float)
+        y = eom * a_g
         P = y ** GAMMA
-        eom = y / a_g                               # "energy weighted density" (the reference's EgyWtDensity)
         c = np.sqrt(GAMMA * P / eom)
-        out["egywtdensity"] = eom
-        # H13 eq 18 with the smoothing length tied to rho (x~_j = m_j, y~ = rho):
-        # f_ij - 1 = -(1 / A_j^(1/gamma)) (h_i / 3 rho_i) (d y_i / d h_i) [1 + (h_i / 3 rho_i) d rho_i / d h_i]^-1
-        out["dhsmlegy"] = -(dy_dH * H / (3.0 * y)) * f_grad   # the reference stores this combination (times y/rho it is the bracket)
     fac_mu = atime ** (3 * (GAMMA - 1) / 2) / atime
     hubble_a2 = hubble * atime ** 2
 
@@ -140,7 +168,11 @@ def sph_paper(pos, mass, vel, A, H, box, atime=1.0, hubble=0.0, alpha=0.75, kern
         tj = (f_grad * P / rho ** 2)[None, :] * dWj
     else:
         # H13 eq 21: -sum_j m_j (A_i A_j)^(1/gamma) [ f_ij Pbar_i^(1-2/gamma) grad_i W_ij(h_i) + f_ji Pbar_j^(1-2/gamma) grad_i W_ij(h_j) ]
-        corr = (dy_dH * H / (3.0 * rho)) * f_grad                    # (h_i / 3 rho_i) (dy_i/dh_i) [...]^-1
+        # with f_ij - 1 = -(1 / A_j^(1/gamma)) (h_i / 3 rho_i) (dy_i / dh_i) f_i  =  dhsmlegy_i (y_i / rho_i) / A_j^(1/gamma)
+        corr = -np.asarray(F["dhsmlegy"], float) * y / rho           # (h_i / 3 rho_i) (dy_i/dh_i) [...]^-1
+        if contrast_limit is not None:
+            rr = eom / rho
+            corr = corr * np.minimum(rr, contrast_limit) / rr
         f_ij = 1.0 - corr[:, None] / a_g[None, :]
         f_ji = 1.0 - corr[None, :] / a_g[:, None]
         pw = P ** (1.0 - 2.0 / GAMMA)
@@ -171,4 +203,14 @@ def sph_paper(pos, mass, vel, A, H, box, atime=1.0, hubble=0.0, alpha=0.75, kern
     sig = np.where(pair, c[:, None] + c[None, :], 0.0)
     sig = np.where(appr, np.maximum(sig, vsig), sig)
     out.update(hydroacc=acc, dtentropy=dA, maxsignalvel=np.maximum(c, sig.max(1)), pressure=P, soundspeed=c, balsara=fbal)
+    return out
+
+
+def sph_paper(pos, mass, vel, A, H, box, atime=1.0, hubble=0.0, alpha=0.75, kernel=1, formulation="density", dlna=None,
+              active=None):
+    """All pairs, periodic minimum image.  pos [N,3], mass [N], vel = u [N,3], A [N] entropic function, H [N] support radii.
+    formulation: "density" (SH02 / S05) or "pressure" (H13).  dlna [N]: the particles' steps in ln a for the bound on the viscous
+    force (None: bound off).  Returns the density-loop fields and the hydro force for every particle."""
+    out = paper_density(pos, mass, vel, A, H, box, kernel, formulation)
+    out.update(paper_hydro(pos, mass, vel, A, H, box, out, atime, hubble, alpha, kernel, formulation, dlna))
     return out

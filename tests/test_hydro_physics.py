@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from sph_paper import GAMMA, sph_paper
+from sph_paper import GAMMA, paper_density, paper_hydro, sph_paper
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -278,3 +278,211 @@ def test_gpu_hydro_closed_form_states_and_energy(pkg):
     pos, mass, vel, ent, box = gas_state(pkg, seed=8)
     F = engine_loops(pkg, pos, mass, vel, ent, box, "density", 1, 1.0, 1e-9, 0.0)
     gate_energy(F, mass, vel, ent, 1.0, 1e-9, "density")
+
+
+# ---- the PREDICTION layer: particles with pending kicks, neighbours that were not active in the density loop ---------
+# density() and hydro_force() do not see a particle's stored state but its state PREDICTED to the current drift time (density.c:69-132,
+# hydra.c:57-77, 195-214, 300-312, 396-401).  What that prediction must be follows from how the integrator stores things (timestep.c:873-929,
+# do_grav_short_range_kick / do_hydro_kick): P[].Vel is the velocity at the particle's last KICK time, which lags the drift time by half a
+# step of its bin, separately for the tree force (bin TimeBinGravity), the PM force (one kick time for all) and the hydro force (bin
+# TimeBinHydro); SphP.Entropy likewise at the last hydro kick; SphP.Density and the velocity gradients at the last drift at which the
+# particle's bin was active.  To first order in the pending intervals, independently of any code:
+#     u_pred = u + a_tree K_grav[bin_g] + a_PM K_grav,PM + a_hydro K_hydro[bin_h]         (the kick integrals from the kick time to now)
+#     A_pred = A + (dA/dln a) dln a[bin_h], floored at 5 % of A (a limiter of the code);  P_pred = A_pred rho_pred^gamma
+#     rho_pred = rho (1 - div v  D[bin_h])  (continuity equation; D = the drift integral since the last active drift, 0 for an active bin),
+#                floored at 1e-6 rho (a limiter of the code); the density of the equations of motion of the pressure-entropy form likewise.
+# The test evaluates these with numpy, feeds the PREDICTED state to the published equations (paper_density / paper_hydro, all pairs) and asks
+# the restatement - and the HIP kernels under -m gpu - for the same numbers on the active targets.  Kick tables differ per bin, gravity and
+# hydro bins differ per particle, the PM kick is non-zero, a few entropies hit the 5 % floor, and in the pressure-entropy run the
+# DensityContrastLimit is set where it bites (rr = y / (A^(1/gamma) rho) scatters around 1; limit 0.97).
+def prediction_state(pkg, formulation):
+    pos, mass, vel, ent, box = gas_state(pkg, n=9, seed=12)
+    N = len(pos)
+    rng = np.random.RandomState(21)
+    tb_h = rng.choice([3, 4, 5], N).astype(np.uint8)
+    tb_g = (tb_h + rng.choice([0, 1, 2], N)).astype(np.uint8)                 # the gravity step is never shorter than the hydro step
+    S = dict(pos=pos, mass=mass, vel=vel, ent=ent, box=box, tb_hydro=tb_h, tb_grav=tb_g, gacc=4.0 * rng.standard_normal((N, 3)),
+             gpm=3.0 * rng.standard_normal((N, 3)), hydroacc_in=5.0 * rng.standard_normal((N, 3)), dtentropy_in=15.0 * rng.standard_normal(N))
+    S["dtentropy_in"][rng.choice(N, 12, replace=False)] = -4.0e3              # these predict a negative entropy: the 5 % floor
+    S["active"] = np.flatnonzero(tb_h == 3).astype(np.int32)
+    b = np.arange(47, dtype=float)
+    S["tables"] = dict(FgravkickB=0.013, gravkicks=list(0.004 * (b + 1)), hydrokicks=list(0.003 * (b + 2)), dloga_kick=list(0.0015 * b),
+                       drifts=[0.0] * 4 + [0.012, 0.025] + [0.0] * 41, dloga_bin=list(0.01 * 2.0 ** (b - 3)))
+    S["contrast_limit"] = 0.97 if formulation == "pressure" else 100.0
+    return S
+
+
+def predicted(S):
+    """(u_pred, A_pred) of every particle from the kick definitions (see above) - numpy, nothing of the restatement"""
+    T = S["tables"]
+    kg, kh, dl = np.array(T["gravkicks"]), np.array(T["hydrokicks"]), np.array(T["dloga_kick"])
+    u = S["vel"] + kg[S["tb_grav"]][:, None] * S["gacc"] + T["FgravkickB"] * S["gpm"] + kh[S["tb_hydro"]][:, None] * S["hydroacc_in"]
+    A = np.maximum(S["ent"] + S["dtentropy_in"] * dl[S["tb_hydro"]], 0.05 * S["ent"])
+    return u, A
+
+
+def paper_with_predictions(S, stored, H, formulation, kernel, atime, hubble):
+    """stored: the density-loop fields the inactive particles carry (dict of arrays over all particles).  Returns paper fields for all particles;
+    only the active targets' are meaningful (theirs are the sums of a density loop at the current time)."""
+    u, A = predicted(S)
+    act = np.zeros(len(u), bool)
+    act[S["active"]] = True
+    fresh = paper_density(S["pos"], S["mass"], u, A, H, S["box"], kernel, formulation)
+    drift = np.array(S["tables"]["drifts"])[S["tb_hydro"]]
+    F = {}
+    for k in ("density", "divvel", "curlvel", "dhsml") + (("egywtdensity", "dhsmlegy") if formulation == "pressure" else ()):
+        F[k] = np.where(act, fresh[k], stored[k])
+    for k in ("density",) + (("egywtdensity",) if formulation == "pressure" else ()):          # the continuity equation over the pending drift
+        pred = F[k] * (1.0 - F["divvel"] * drift)
+        F[k] = np.where(act, F[k], np.maximum(pred, 1e-6 * F[k]))
+    dlna = np.array(S["tables"]["dloga_bin"])[S["tb_hydro"]]
+    out = paper_hydro(S["pos"], S["mass"], u, A, H, S["box"], F, atime, hubble, 0.75, kernel, formulation, dlna=dlna,
+                      contrast_limit=S["contrast_limit"] if formulation == "pressure" else None)
+    out.update(fresh)
+    return out
+
+
+def stored_fields(S, H, formulation, kernel):
+    """what the inactive particles carry: the sums of an EARLIER density loop - here the current ones scaled by a few per cent, so that a
+    kernel that recomputed them, or ignored the prediction, gives other numbers"""
+    u, A = predicted(S)
+    f = paper_density(S["pos"], S["mass"], u, A, H, S["box"], kernel, formulation)
+    rng = np.random.RandomState(33)
+    N = len(H)
+    st = dict(density=f["density"] * (1 + 0.04 * rng.standard_normal(N)), divvel=f["divvel"] * 1.1, curlvel=f["curlvel"] * 0.9, dhsml=f["dhsml"])
+    if formulation == "pressure":
+        st["egywtdensity"] = f["egywtdensity"] * st["density"] / f["density"] * (1 + 0.03 * rng.standard_normal(N))
+        st["dhsmlegy"] = f["dhsmlegy"]
+    return st
+
+
+def oracle_with_predictions(orc, S, formulation, kernel, atime, hubble, stored=None):
+    pos, mass, box = S["pos"], S["mass"], S["box"]
+    N = len(pos)
+    pe = 1 if formulation == "pressure" else 0
+    dp = O.DensityParams(1.0, 2.0, 2.0, 99999., kernel, 0.006)
+    O.sph_set_softening(orc, 1e-3)
+    A = O.SphArrays(pos, mass, hsml=np.full(N, 2.2 * box / round(N ** (1 / 3.))), vel=S["vel"], entropy=S["ent"])
+    for k in ("gacc", "gpm", "hydroacc_in", "dtentropy_in", "tb_hydro", "tb_grav"):
+        getattr(A, k)[...] = S[k]
+    to = O.sph_times(atime=atime, hubble=hubble, **S["tables"])
+    typ = np.zeros(N, np.int32)
+    if stored is None:      # first: every particle active once, for smoothing lengths that belong to the particle distribution
+        tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=np.ones(N, np.uint8), mask=1, moments=False)
+        O.sph_density(orc, tr, dp, A, to, DoEgyDensity=pe)
+        return A
+    A.hsml[...] = stored["hsml"]
+    for k, f in (("density", "density"), ("divvel", "divvel"), ("curlvel", "curlvel"), ("egywtdensity", "egywtdensity"),
+                 ("dhsmlegyfac", "dhsmlegy" if pe else "dhsml")):
+        if f in stored:
+            getattr(A, k)[...] = stored[f]
+    flags = np.zeros(N, np.uint8)
+    flags[S["active"]] = 1
+    tr = orc.tree(pos, mass, box, type=typ, hsml=A.hsml, hydro_active=flags, mask=1, moments=False)
+    O.sph_density(orc, tr, dp, A, to, active=S["active"], DoEgyDensity=pe)
+    tr.calc_moments()
+    O.sph_hydro_force(orc, tr, dp, O.HydroParams(pe, S["contrast_limit"], 0.75), A, to, active=S["active"])
+    return A
+
+
+def gate_predictions(F, ref, S, formulation, tol=2e-10):
+    a = S["active"]
+    pick = lambda x: np.asarray(x)[a]
+    assert rel(pick(F.density), pick(ref["density"])) <= tol, "Density"
+    assert rel(pick(F.divvel), pick(ref["divvel"])) <= tol, "DivVel (VelPred of the neighbours)"
+    assert rel(pick(F.curlvel), pick(ref["curlvel"])) <= tol, "CurlVel"
+    if formulation == "pressure":
+        assert rel(pick(F.egywtdensity), pick(ref["egywtdensity"])) <= tol, "EgyWtDensity (EntVarPred of the neighbours)"
+    assert rel(pick(F.hydroacc_out), pick(ref["hydroacc"])) <= tol, "HydroAccel"
+    assert rel(pick(F.dtentropy_out), pick(ref["dtentropy"])) <= tol, "DtEntropy"
+    assert rel(pick(F.maxsignalvel), pick(ref["maxsignalvel"])) <= 1e-12, "MaxSignalVel"
+
+
+PRED_CASES = [("density", 1, 0.5, 0.3), ("pressure", 2, 0.5, 0.3)]
+
+
+def prediction_gates(pkg, orc):
+    for formulation, kernel, atime, hubble in PRED_CASES:
+        S = prediction_state(pkg, formulation)
+        H = oracle_with_predictions(orc, S, formulation, kernel, atime, hubble).hsml.copy()
+        stored = stored_fields(S, H, formulation, kernel)
+        stored["hsml"] = H
+        A = oracle_with_predictions(orc, S, formulation, kernel, atime, hubble, stored)
+        assert np.array_equal(A.hsml, H)                      # (the active targets' smoothing lengths had converged: same particle set)
+        ref = paper_with_predictions(S, stored, H, formulation, kernel, atime, hubble)
+        gate_predictions(A, ref, S, formulation)
+        # the state does exercise what it claims to
+        u, Ap = predicted(S)
+        assert np.abs(u - S["vel"]).max() > 0.1 * np.abs(S["vel"]).max() and (Ap == 0.05 * S["ent"]).sum() >= 10
+        if formulation == "pressure":
+            rr = ref["egywtdensity"] / ref["density"]
+            assert 0.2 < (rr[S["active"]] > S["contrast_limit"]).mean() < 0.98     # the limit bites for some targets and not for others
+
+
+def test_oracle_predictions_follow_from_the_kick_definitions(pkg, orc):
+    prediction_gates(pkg, orc)
+
+
+PRED_MUTATIONS = {
+    "hydro kick of VelPred taken from the gravity bin": ("T->hydrokicks[A->tb_hydro ? A->tb_hydro[i] : 0]", "T->hydrokicks[A->tb_grav ? A->tb_grav[i] : 0]"),
+    "PM kick dropped from VelPred": ("(A->gpm ? A->gpm[3 * i + j] : 0.0) * T->FgravkickB +", "(A->gpm ? A->gpm[3 * i + j] : 0.0) * 0.0 +"),
+    "density prediction: sign of the divergence": ("const double DensityPred = Density - DivVel * Density * dtdrift;",
+                                                   "const double DensityPred = Density + DivVel * Density * dtdrift;"),
+    "entropy prediction over the bin's whole step": ("const double dloga = T->dloga_kick[bin];", "const double dloga = T->dloga_bin[bin];"),
+}
+MUTATIONS.update(PRED_MUTATIONS)
+
+
+@pytest.mark.parametrize("name", sorted(PRED_MUTATIONS))
+def test_prediction_gates_catch_mutations(pkg, tmp_path, name):
+    mut = mutated_oracle(tmp_path, name)
+    with pytest.raises(AssertionError):
+        prediction_gates(pkg, mut)
+
+
+def engine_with_predictions(pkg, S, formulation, kernel, atime, hubble, stored):
+    import torch
+    from test_gpu_sph import gpu_arrays, make_times
+    N = len(S["pos"])
+    pe = 1 if formulation == "pressure" else 0
+    eng = pkg.Engine(0)
+    try:
+        eng.set_gravshort_treepar(FractionalGravitySoftening=1.0)
+        eng.gravshort_set_softenings(1e-3 / 2.8)
+        eng.set_densitypar(1.0, 2.0, 2.0, 99999., kernel, 0.006)
+        eng.set_hydropar(pe, S["contrast_limit"], 0.75)
+        extra = {k: S[k] for k in ("gacc", "gpm", "hydroacc_in", "dtentropy_in", "tb_hydro", "tb_grav")}
+        a, keep = gpu_arrays(torch, S["pos"], S["mass"], np.zeros(N, np.int32), stored["hsml"], S["vel"], S["ent"], extra=extra)
+        for k, f in (("density", "density"), ("divvel", "divvel"), ("curlvel", "curlvel"), ("egywtdensity", "egywtdensity"),
+                     ("dhsmlegyfac", "dhsmlegy" if pe else "dhsml")):
+            if f in stored:
+                a[k] = torch.from_numpy(np.ascontiguousarray(stored[f])).cuda()
+        eng.dev_bind_particles(keep["pos"], keep["mass"], S["box"], type=keep["type"])
+        eng.dev_force_tree_rebuild_mask(pkg.engine.GASMASK)
+        t = make_times(pkg, atime=atime, hubble=hubble, **S["tables"])
+        act = torch.from_numpy(S["active"]).cuda()
+        eng.dev_density(a, t, active=act, DoEgyDensity=pe)
+        eng.dev_force_tree_calc_hmax()
+        eng.dev_hydro_force(a, t, active=act)
+        eng.synchronize()
+        F = _Fields()
+        for k in ("hsml", "density", "egywtdensity", "dhsmlegyfac", "divvel", "curlvel", "hydroacc_out", "dtentropy_out", "maxsignalvel"):
+            setattr(F, k, a[k].cpu().numpy())
+        return F
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("formulation,kernel,atime,hubble", PRED_CASES)
+def test_gpu_predictions_follow_from_the_kick_definitions(pkg, orc, formulation, kernel, atime, hubble):
+    """the same gate on the HIP kernels: VelPred / EntVarPred of the neighbours in the density loop, DensityPred / PressurePred of inactive
+    neighbours and the DensityContrastLimit in the hydro loop, against the numpy evaluation of the kick definitions"""
+    S = prediction_state(pkg, formulation)
+    H = oracle_with_predictions(orc, S, formulation, kernel, atime, hubble).hsml.copy()      # (smoothing lengths of the particle set; CPU)
+    stored = stored_fields(S, H, formulation, kernel)
+    stored["hsml"] = H
+    F = engine_with_predictions(pkg, S, formulation, kernel, atime, hubble, stored)
+    assert np.abs(F.hsml / H - 1).max() <= 1e-12
+    ref = paper_with_predictions(S, stored, H, formulation, kernel, atime, hubble)
+    gate_predictions(F, ref, S, formulation)
