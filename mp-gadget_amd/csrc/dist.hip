@@ -2202,6 +2202,24 @@ int mpg_dist_domain_exchange(mpg_dist *d, int64_t n, int ncols, const void *cons
         hipLaunchKernelGGL(k_task_mask, dim3(nblk(n)), dim3(256), 0, st, n, d->dom_task.p, d->mask.p);
     build_plan(d, d->dom_plan, n, d->mask.p);
     Plan &pl = d->dom_plan;
+    // Invariant (round 6; the one multi-rank failure of round 4 was its Python twin, PeanoDomain.exchange: "send counts and live rows unequal
+    // on one rank"): the rows per destination counted from the per-particle task array by the plan's split pass must be the per-task counts the
+    // decomposition's k_topleaf pass summed over the TopLeaves - two kernels, two reductions, one truth.  A difference names the rank, both
+    // count vectors and the particle number instead of surfacing as a short exchange somewhere downstream.
+    {
+        bool same = (int)d->dom_send_counts.size() == d->nt;
+        for(int r = 0; same && r < d->nt; r++)
+            same = pl.scnt[(size_t)r] == d->dom_send_counts[(size_t)r];
+        if(!same) {
+            std::string a, b;
+            for(int r = 0; r < d->nt; r++) {
+                a += " " + std::to_string(r < (int)d->dom_send_counts.size() ? d->dom_send_counts[(size_t)r] : -1);
+                b += " " + std::to_string(pl.scnt[(size_t)r]);
+            }
+            MPG_CHECK(false, "mpg_dist_domain_exchange: rank " + std::to_string(d->me) + " of " + std::to_string(d->nt) + ", " + std::to_string(n) +
+                                 " particles: send counts of the decomposition [" + a + " ] differ from the rows per task of its task array [" + b + " ]");
+        }
+    }
     Cols c;
     memset(&c, 0, sizeof(c));
     c.n = ncols;

@@ -81,6 +81,10 @@ def run_ranks(cmd, env, log_path, timeout=900):
         # a worker SIGABRT in rounds 2-3, a count mismatch in the decomposition on a box's first multi-process use in round 4).
         # The suite runs under -x: ONE repeat, and the first failure is kept in gpurun_out/flake/RETRIED.log and in a warning, so
         # that a repeat is never silent.  A failure that repeats fails the test.
+        # Round 6: the repeat is OPT-IN (MPG_TEST_RETRY=1) and off by default - a product-side race that shows once in 50 runs must fail
+        # the suite, not hide behind a repeat (profiles/r06b_flake_stress/: 200 clean iterations of the four tests concerned).
+        if os.environ.get("MPG_TEST_RETRY") != "1":
+            assert r.returncode == 0, r.stderr[-3000:]
         import warnings
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         try:
