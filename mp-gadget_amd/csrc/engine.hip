@@ -1485,7 +1485,18 @@ template <class Issue, class Unpack> static void download_chunks(mpg_engine *eng
 }
 extern "C" {
 
+static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, double BoxSize);
 static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
+{
+    eng->host_join(); // (a pending write-back of the last epoch's GravPM touches the records this pass reads; a prefetch of this epoch ends here)
+    if(!eng->prefetch_error.empty()) {
+        const std::string e = eng->prefetch_error;
+        eng->prefetch_error.clear();
+        MPG_CHECK(false, "host path: the prefetch of the particle table failed: " + e);
+    }
+    stage_particles_body(eng, P, BoxSize);
+}
+static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
 {
     MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
     MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
@@ -1499,7 +1510,6 @@ static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double 
     if(eng->host_epoch != 0 && eng->staged_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n &&
        eng->staged_box == BoxSize && eng->d_pos == eng->s_pos.p)
         return;
-    eng->host_join(); // (a pending write-back of the last epoch's GravPM touches the records this pass reads)
     eng->h_d.reserve(3 * (size_t)n + 1);
     eng->h_f.reserve((size_t)n + 1);
     eng->h_b.reserve((size_t)n + 1);
@@ -1611,7 +1621,38 @@ int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch)
 {
     API_BEGIN
     MPG_CHECK(eng, "null engine");
+    if(epoch != eng->host_epoch)
+        eng->host_join(); // (a prefetch reads host_epoch on its own thread)
     eng->host_epoch = epoch;
+    API_END
+}
+
+// The epoch's one packing pass and its uploads, started EARLY: a caller that knows P[] is final for the step - the end of
+// drift_all_particles (drift.c:84-102), where nothing of run.c touches Pos / Mass / FullTreeGravAccel / Potential again before gravpm_force
+// (run.c:420-522: domain_maintain reads them; an exchange or a garbage collection declares a new epoch, and this upload is then simply not used)
+// - calls this after mpg_set_particle_epoch; the pass runs on a host thread of its own and the first entry point of the epoch joins it
+// instead of packing.  Needs the overlap mode (the pass must also take Potential / FullTreeGravAccel); without it, or resident, a no-op.
+int mpg_host_prefetch(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
+{
+    API_BEGIN
+    MPG_CHECK(eng && P && BoxSize > 0, "mpg_host_prefetch: bad argument");
+    MPG_HIP(hipSetDevice(eng->device));
+    eng->host_join();
+    if(!eng->host_overlap || eng->host_epoch == 0 || eng->resident || P->n == 0) {
+        mpg_err_slot().clear();
+        return 0;
+    }
+    eng->prefetch_error.clear();
+    eng->prefetch_view = *P;
+    eng->prefetch_thread = std::thread([eng, BoxSize] {
+        try {
+            MPG_HIP(hipSetDevice(eng->device));
+            stage_particles_body(eng, &eng->prefetch_view, BoxSize);
+        }
+        catch(const std::exception &e) {
+            eng->prefetch_error = e.what();
+        }
+    });
     API_END
 }
 

@@ -268,10 +268,17 @@ struct mpg_engine {
     hipEvent_t slice_ev[9] = {};
     int64_t staged_extra_epoch = -1; // the epoch whose Potential / FullTreeGravAccel are staged (s_pot, s_prevacc)
     int64_t gravpm_epoch = -1;       // the epoch whose GravPM sits in s_gravpm
+    // mpg_host_prefetch (round 6): the epoch's packing pass + uploads on a host thread of their own, started by the caller as soon as P[] is
+    // final for the step (the end of drift_all_particles) and joined by the first entry point that needs the staged columns
+    std::thread prefetch_thread;
+    std::string prefetch_error;
+    mpg_particle_view prefetch_view{};
     void host_join()
     {
         if(unpack_thread.joinable())
             unpack_thread.join();
+        if(prefetch_thread.joinable())
+            prefetch_thread.join();
     }
 };
 

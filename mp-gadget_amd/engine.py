@@ -443,6 +443,12 @@ class Engine:
         return dict(mTimeBin=res.mTimeBin, maxTimeBin=res.maxTimeBin, isPM=res.isPM, ntitype=list(res.ntitype),
                     badstepsizecount=res.badstepsizecount, badtimebins=res.badtimebins)
 
+    def host_prefetch(self, P, box):
+        """mpg_host_prefetch: start this epoch's packing pass + uploads of P[] on a host thread (after set_particle_epoch; needs
+        set_host_overlap)"""
+        v = self._view(P)
+        self._ck(self.lib.mpg_host_prefetch(self.h, C.byref(v), C.c_double(box)))
+
     def resident_fetch_timebins(self, n):
         """(TimeBinHydro, TimeBinGravity) of a resident gas run as host arrays (what the shim copies into P[] for build_active_particles)"""
         tbh, tbg = np.zeros(n, np.uint8), np.zeros(n, np.uint8)

@@ -92,7 +92,24 @@ mpg_particle_view mpg_shim_view(void)
 #define view mpg_shim_view
 
 void mpg_shim_set_domain(DomainDecomp *ddecomp) { Domain = ddecomp; }
-void mpg_shim_particles_changed(void) { Table.dirty = 1; }
+void mpg_shim_particles_changed(void)
+{
+    Table.dirty = 1;
+    if(E) /* (a prefetch of the table - mpg_shim_prefetch - may still be reading P[]: it ends before the caller rewrites the records) */
+        mpg_host_results_sync(E);
+}
+
+/* The end of drift_all_particles (timestep-hip.c calls this after the reference's own drift): P[] is final for the step, so the epoch's one
+ * packing pass and its uploads can start now, on a host thread, while run.c goes on with domain_maintain and the active list (run.c:420-470);
+ * the step's first force call joins it.  One rank, host path only. */
+void mpg_shim_prefetch(inttime_t Ti_Current, double BoxSize)
+{
+    if(NTask > 1 || mpg_shim_resident())
+        return;
+    mpg_shim_sync(Ti_Current, 0, BoxSize, 0);
+    mpg_particle_view v = mpg_shim_view();
+    ck(mpg_host_prefetch(eng(), &v, BoxSize));
+}
 void mpg_shim_dist_tree_replaced(void) { DistTreeEpoch = -1; }
 double mpg_shim_margin(void) { return DomainMargin; }
 

@@ -28,6 +28,8 @@ void mpg_shim_ck(int rc);           /* endrun(5, mpg_last_error()) on a non-zero
 void mpg_shim_set_domain(DomainDecomp *ddecomp);
 /* P[] was moved / reordered / resized by something the shim cannot see */
 void mpg_shim_particles_changed(void);
+/* P[] is final for the step (the end of drift_all_particles): start the epoch's packing pass + uploads on a host thread (one rank, host path) */
+void mpg_shim_prefetch(inttime_t Ti_Current, double BoxSize);
 /* Start of every entry point.  Ti_Current < 0: not known to the caller (gravpm_force: matched through Time = get_atime(Ti)).
  * margin_want: the interaction range this call needs covered by ghosts (Rcut in length units; the largest smoothing length for the
  * SPH loops); the domain is (re-)set when the decomposition changed or the margin in force is smaller. */

@@ -241,6 +241,7 @@ void drift_all_particles(inttime_t ti0, inttime_t ti1, Cosmology *CP, const doub
 {
     if(!R.on) {
         cpu_drift_all_particles(ti0, ti1, CP, random_shift);
+        mpg_shim_prefetch(ti1, PartManager->BoxSize); /* (round 6: the step's upload starts here instead of inside gravpm_force) */
         return;
     }
     if(ti1 < ti0)

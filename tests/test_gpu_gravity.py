@@ -826,15 +826,27 @@ def test_host_path_overlap_gives_the_synchronous_results(pkg, engine, n):
     rng = np.random.RandomState(2)
     dead = rng.random_sample(N) < 0.02
     res = {}
-    for mode in ("sync", "overlap", "overlap+sync_call", "overlap_sliced"):
+    for mode in ("sync", "overlap", "overlap+sync_call", "overlap_sliced", "overlap+prefetch"):
         P = pkg.make_particles(pos, mass)
         P["Flags"][dead] = 1
         P["Potential"] = 0.125                                  # (gravpm_force accumulates onto it; the walk then assigns the tree's)
         # (3: the walk in three slices of the tree order, each written back while the next is walked - the path a 256^3 table takes)
-        engine.set_host_overlap(0 if mode == "sync" else (3 if mode == "overlap_sliced" else 1))
+        engine.set_host_overlap(0 if mode == "sync" else (3 if mode == "overlap_sliced" else 1))       # ("overlap+prefetch": 1)
         out = []
         for step in range(3):
             engine.set_particle_epoch(100 * (1 + len(res)) + step + 1)
+            if mode == "overlap+prefetch":
+                # (round 6) the packing pass + uploads started as soon as P[] is final for the step - the end of drift_all_particles in run.c -
+                # on a host thread; gravpm_force joins it.  Once a step the upload is made useless by a new epoch (an exchange after the
+                # drift): the calls must then pack again and not use what the prefetch staged.
+                engine.host_prefetch(P, box)
+                if step == 1:
+                    engine.set_particle_epoch(100 * (1 + len(res)) + 50)     # (what mpg_shim_particles_changed leads to: joins the prefetch FIRST)
+                    P["Pos"][:, 2] = np.mod(P["Pos"][:, 2] + 0.13 * box / n, box)
+                    P["Pos"][P["Pos"] <= 0] += box
+            elif step == 1:
+                P["Pos"][:, 2] = np.mod(P["Pos"][:, 2] + 0.13 * box / n, box)       # (the same move in every mode)
+                P["Pos"][P["Pos"] <= 0] += box
             engine.gravpm_force(P)
             if mode == "overlap+sync_call":
                 engine.host_results_sync()
@@ -847,7 +859,7 @@ def test_host_path_overlap_gives_the_synchronous_results(pkg, engine, n):
         res[mode] = out
         engine.set_particle_epoch(0)
     engine.set_host_overlap(False)
-    for mode in ("overlap", "overlap+sync_call", "overlap_sliced"):
+    for mode in ("overlap", "overlap+sync_call", "overlap_sliced", "overlap+prefetch"):
         for (g0, a0, p0), (g1, a1, p1) in zip(res["sync"], res[mode]):
             assert np.abs(g1 - g0).max() <= 1e-10 * np.abs(g0).max() and np.abs(a1 - a0).max() <= 1e-9 * np.abs(a0).max(), mode
             assert np.abs(p1 - p0).max() <= 1e-9 * np.abs(p0).max(), mode
