@@ -1485,18 +1485,18 @@ template <class Issue, class Unpack> static void download_chunks(mpg_engine *eng
 }
 extern "C" {
 
-static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, double BoxSize);
+static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, bool on_prefetch_thread);
 static void stage_particles(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
 {
-    eng->host_join(); // (a pending write-back of the last epoch's GravPM touches the records this pass reads; a prefetch of this epoch ends here)
+    eng->prefetch_join(); // (a prefetch of this epoch ends here; the write-back thread of gravpm_force is waited for only if P[] is read again)
     if(!eng->prefetch_error.empty()) {
         const std::string e = eng->prefetch_error;
         eng->prefetch_error.clear();
         MPG_CHECK(false, "host path: the prefetch of the particle table failed: " + e);
     }
-    stage_particles_body(eng, P, BoxSize);
+    stage_particles_body(eng, P, BoxSize, false);
 }
-static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, double BoxSize)
+static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, double BoxSize, bool on_prefetch_thread)
 {
     MPG_CHECK(P && (P->n == 0 || P->base), "null particle view");
     MPG_CHECK(P->off_pos >= 0 && P->off_mass >= 0, "particle view needs Pos and Mass");
@@ -1510,6 +1510,8 @@ static void stage_particles_body(mpg_engine *eng, const mpg_particle_view *P, do
     if(eng->host_epoch != 0 && eng->staged_epoch == eng->host_epoch && eng->staged_base == P->base && eng->staged_n == n &&
        eng->staged_box == BoxSize && eng->d_pos == eng->s_pos.p)
         return;
+    if(!on_prefetch_thread) // (mpg_host_prefetch joined before it started this thread)
+        eng->host_join();   // a pending write-back of the last epoch's GravPM touches the records this pass reads
     eng->h_d.reserve(3 * (size_t)n + 1);
     eng->h_f.reserve((size_t)n + 1);
     eng->h_b.reserve((size_t)n + 1);
@@ -1647,7 +1649,7 @@ int mpg_host_prefetch(mpg_engine *eng, const mpg_particle_view *P, double BoxSiz
     eng->prefetch_thread = std::thread([eng, BoxSize] {
         try {
             MPG_HIP(hipSetDevice(eng->device));
-            stage_particles_body(eng, &eng->prefetch_view, BoxSize);
+            stage_particles_body(eng, &eng->prefetch_view, BoxSize, true);
         }
         catch(const std::exception &e) {
             eng->prefetch_error = e.what();

@@ -273,12 +273,16 @@ struct mpg_engine {
     std::thread prefetch_thread;
     std::string prefetch_error;
     mpg_particle_view prefetch_view{};
+    void prefetch_join()
+    {
+        if(prefetch_thread.joinable())
+            prefetch_thread.join();
+    }
     void host_join()
     {
         if(unpack_thread.joinable())
             unpack_thread.join();
-        if(prefetch_thread.joinable())
-            prefetch_thread.join();
+        prefetch_join();
     }
 };
 

@@ -12,10 +12,13 @@ eng.gravpm_init_periodic(box, 1.5, 2 * n, 43.0071)
 eng.set_gravshort_treepar(TreeUseBH=0)
 eng.gravshort_set_softenings(box / n)
 P = pkg.make_particles(pos, mass)
-for overlap in (True, False):
-    eng.set_host_overlap(overlap)
+for overlap in (2, True, False):          # 2: overlap + mpg_host_prefetch 40 ms ahead (round 6)
+    eng.set_host_overlap(bool(overlap))
     for it in range(5):
         eng.set_particle_epoch(10 * overlap + it + 1)
+        if overlap == 2:
+            eng.host_prefetch(P, box)
+            time.sleep(0.04)
         t0 = time.perf_counter()
         eng.gravpm_force(P)
         t1 = time.perf_counter()
