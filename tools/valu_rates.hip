@@ -90,6 +90,19 @@ KERNEL(k_sub_f32_x6_cmp, F32DECL; unsigned long long m = 0, asm volatile("v_sub_
 KERNEL(k_cmp_f32_sgpr4, F32DECL; unsigned long long m[4]; m[0] = m[1] = m[2] = m[3] = 0, asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m[j & 3]) : "v"(f[j]), "v"(fb)); ia[j] += (int)m[j & 3])
 KERNEL(k_cmp_f64_sgpr4, unsigned long long m[4]; m[0] = m[1] = m[2] = m[3] = 0, asm volatile("v_cmp_lt_f64 %0, %1, %2" : "=s"(m[j & 3]) : "v"(a[j]), "v"(b)); ia[j] += (int)m[j & 3])
 
+// round 6, last experiment: the five comparisons of a list-kernel target pass as v_cmpx (exec narrowing: 2 for "discard", 3 negated for
+// "not open") in one asm block, against five v_cmp into scalar pairs + scalar and / or
+KERNEL(k_cmpx5_block, unsigned long long md = 0; unsigned long long mno = 0; unsigned long long sv = 0; unsigned long long act = 0xffffffffffff0fffull,
+       asm volatile("s_mov_b64 %2, exec\n s_mov_b64 exec, %3\n v_cmpx_lt_f64 %5, %4\n v_cmpx_gt_f64 %4, %6\n s_mov_b64 %0, exec\n s_mov_b64 exec, %3\n"
+                    "v_cmpx_ngt_f64 %4, %5\n v_cmpx_ngt_f64 %6, %4\n v_cmpx_nlt_f64 %4, %6\n s_mov_b64 %1, exec\n s_mov_b64 exec, %2"
+                    : "=&s"(md), "=&s"(mno), "=&s"(sv) : "s"(act), "v"(a[j]), "v"(b), "v"(c) : "vcc");
+       ia[j] += (int)(md ^ mno))
+KERNEL(k_cmp5_sgpr, unsigned long long m0 = 0; unsigned long long m1 = 0; unsigned long long m2 = 0; unsigned long long m3 = 0; unsigned long long m4 = 0,
+       asm volatile("v_cmp_lt_f64 %0, %6, %5\n v_cmp_gt_f64 %1, %5, %7\n v_cmp_gt_f64 %2, %5, %6\n v_cmp_gt_f64 %3, %7, %5\n v_cmp_lt_f64 %4, %5, %7\n"
+                    "s_and_b64 %0, %0, %1\n s_or_b64 %2, %2, %3\n s_or_b64 %2, %2, %4"
+                    : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4) : "v"(a[j]), "v"(b), "v"(c));
+       ia[j] += (int)(m0 ^ m2))
+
 __global__ void __launch_bounds__(256) k_lds128(double *out, double seed)
 {
     __shared__ double tab[2048];
@@ -185,5 +198,7 @@ int main()
     R(k_sub_f32_x6_cmp);
     R(k_cmp_f32_sgpr4);
     R(k_cmp_f64_sgpr4);
+    R(k_cmpx5_block);
+    R(k_cmp5_sgpr);
     return 0;
 }
