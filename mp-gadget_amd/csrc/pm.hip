@@ -214,10 +214,12 @@ __global__ void __launch_bounds__(256) k_potential_transfer(int nmesh, int ny, i
 // it) m = |delta_k|^2 de-convolved with the CIC window once (invwindow^2), weight 2 except on the kz = 0 and Nyquist planes,
 // logarithmic bins in |k| (Nmesh bins up to sqrt(3) Nmesh / 2); the k = 0 mode is the normalisation.  acc = [Power[nbins],
 // kk[nbins], Norm], modes[nbins]; the reference's per-thread copies are per-block LDS histograms here.
-template <bool XLAST>
+// FUSE (round 6): the potential transfer of the same cell in the same pass (k_potential_transfer's arithmetic, after the mode has been
+// measured: gravpm.c measures before it multiplies) - one read of the 1.07 GB of rho_k instead of two
+template <bool XLAST, bool FUSE = false>
 __global__ void __launch_bounds__(256) k_power_spectrum(int nmesh, int ny, int y0, const double *__restrict__ invsinc2,
-                                                        const double2 *__restrict__ cplx, double *__restrict__ acc,
-                                                        unsigned long long *__restrict__ modes)
+                                                        double2 *__restrict__ cplx, double *__restrict__ acc,
+                                                        unsigned long long *__restrict__ modes, double asmth2 = 0, double pot_factor = 0)
 {
     extern __shared__ double s_ps[]; // Power[nbins], kk[nbins], then modes[nbins] (u64)
     const int nbins = nmesh;
@@ -254,13 +256,21 @@ __global__ void __launch_bounds__(256) k_power_spectrum(int nmesh, int ny, int y
         const double m = v.x * v.x + v.y * v.y;
         if(k2 == 0) {
             acc[2 * nbins] = m; // Norm
+            if(FUSE)
+                cplx[ip] = make_double2(0.0, 0.0);
             continue;
+        }
+        const double f = invsinc2[ix] * invsinc2[iy] * invsinc2[iz];
+        if(FUSE) { // (k_potential_transfer, same expressions in the same order.  exp(-k2 asmth2) / k2 and the bin from tables indexed by k2 -
+                   // 2.4 MB of them at Nmesh 512 - measured SLOWER than the exp and the log: 1.06 against 0.64 ms, the gathers miss)
+            const double smth = exp(-(double)k2 * asmth2) / (double)k2;
+            const double fac = pot_factor * smth * f * f;
+            cplx[ip] = make_double2(v.x * fac, v.y * fac);
         }
         const int kint = (int)floor(binsperunit * log((double)k2) / 2.);
         if(kint >= nbins)
             continue;
         const int w = (kz == 0 || kz == nmesh / 2) ? 1 : 2;
-        const double f = invsinc2[ix] * invsinc2[iy] * invsinc2[iz];
         __hip_atomic_fetch_add(&s_pow[kint], w * m * f * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&s_kk[kint], w * sqrt((double)k2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&s_n[kint], (unsigned long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -696,13 +706,21 @@ void PMesh::force(int64_t n, const double *d_pos, const float *d_mass, const uin
     }
     const double asmth2 = pow((2 * M_PI) * Asmth / nmesh, 2);
     const double pot_factor = -G / (M_PI * box);
-    if(measure_power) {
+    static const bool fuse_ps = !(getenv("MPG_PM_FUSE_PS") && getenv("MPG_PM_FUSE_PS")[0] == '0');
+    if(measure_power && fuse_ps) { // P(k) and the potential transfer in one pass over rho_k (round 6)
         ps_zero(st);
-        hipLaunchKernelGGL(k_power_spectrum<false>, dim3(2048), dim3(256), ps_lds_bytes(), st, nmesh, nmesh, 0, invsinc2.p,
-                           (const double2 *)rho_k.p, ps_acc.p, ps_modes.p);
+        hipLaunchKernelGGL((k_power_spectrum<false, true>), dim3(2048), dim3(256), ps_lds_bytes(), st, nmesh, nmesh, 0, invsinc2.p, (double2 *)rho_k.p,
+                           ps_acc.p, ps_modes.p, asmth2, pot_factor);
     }
-    hipLaunchKernelGGL(k_potential_transfer<false>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, asmth2, pot_factor, invsinc2.p,
-                       (double2 *)rho_k.p);
+    else {
+        if(measure_power) {
+            ps_zero(st);
+            hipLaunchKernelGGL((k_power_spectrum<false, false>), dim3(2048), dim3(256), ps_lds_bytes(), st, nmesh, nmesh, 0, invsinc2.p,
+                               (double2 *)rho_k.p, ps_acc.p, ps_modes.p, 0.0, 0.0);
+        }
+        hipLaunchKernelGGL(k_potential_transfer<false>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, nmesh, 0, asmth2, pot_factor, invsinc2.p,
+                           (double2 *)rho_k.p);
+    }
     if(tm) {
         tm->lap(st, &t);
         t_tr += t;
@@ -1055,8 +1073,8 @@ void PMesh::slab_forward_b(double *recvA, double *sendB, hipStream_t st)
     const double pot_factor = -G / (M_PI * box);
     if(measure_power) { // this rank's ky rows: the caller sums the raw accumulators over the ranks (powerspectrum_sum's Allreduce)
         ps_zero(st);
-        hipLaunchKernelGGL(k_power_spectrum<true>, dim3(1024), dim3(256), ps_lds_bytes(), st, nmesh, slab.Py, y0, invsinc2.p,
-                           (const double2 *)slab.rho_k.p, ps_acc.p, ps_modes.p);
+        hipLaunchKernelGGL((k_power_spectrum<true, false>), dim3(1024), dim3(256), ps_lds_bytes(), st, nmesh, slab.Py, y0, invsinc2.p,
+                           (double2 *)slab.rho_k.p, ps_acc.p, ps_modes.p, 0.0, 0.0);
     }
     hipLaunchKernelGGL(k_potential_transfer<true>, dim3(nblk(ncplx)), dim3(256), 0, st, nmesh, slab.Py, y0, asmth2, pot_factor, invsinc2.p,
                        (double2 *)slab.rho_k.p);

@@ -60,7 +60,7 @@ struct TreeBuilder {
     DevBuf<uint32_t> idx_a, idx_b; // idx_b: tree order -> caller index
     DevBuf<uint32_t> hi_a, hi_b, pos_a, pos_b; // short sort: top key bits and positions (tree_build.hip)
     DevBuf<uint8_t> leaflevel;
-    DevBuf<uint32_t> cnt, base;
+    DevBuf<uint32_t> cnt, base, node_head; // (node_head: the leaf head each node starts at, round 6)
     DevBuf<int64_t> flags;
     DevBuf<int> wave_ext; // per-wave leaf-level extrema of k_leaflevel
     DevBuf<char> tmp;

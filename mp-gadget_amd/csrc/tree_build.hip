@@ -213,10 +213,27 @@ __global__ void __launch_bounds__(256) k_fill_nodes(int64_t n, const uint64_t *_
             }
             else {
                 lk.pcount = 0;
-                // first particle after i that leaves this level-l cell: keys are sorted, binary search
+                // first particle after i that leaves this level-l cell: keys are sorted.  Nine internal nodes in ten are parents of leaves and
+                // hold 9 .. 64 particles, so the end is looked for by doubling steps from the leaf's end first (probes within a few hundred
+                // bytes of keys[i]) and by bisection inside the bracket that finds (round 6: a bisection over [i, n) from the start took
+                // ~24 dependent loads, the first dozen of them megabytes apart - 0.90 ms of the 3.5 ms tree build at 256^3)
                 const int shift = 3 * (MAXLEVEL - l);
                 const uint64_t pref = (l == 0) ? 0 : (ki >> shift);
                 int64_t lo = i + pc, hi = n; // everything in the leaf shares the prefix
+                if(l > 0)
+                    for(int64_t step = 8;; step <<= 1) {
+                        const int64_t p = lo - 1 + step;
+                        if(p >= n)
+                            break;
+                        if((keys[p] >> shift) == pref)
+                            lo = p + 1;
+                        else {
+                            hi = p;
+                            break;
+                        }
+                    }
+                else
+                    lo = n; // (the root holds everything)
                 while(lo < hi) {
                     const int64_t mid = (lo + hi) >> 1;
                     const uint64_t km = keys[mid];
@@ -240,6 +257,89 @@ __global__ void __launch_bounds__(256) k_fill_nodes(int64_t n, const uint64_t *_
             len *= 0.5;
         }
     }
+}
+
+// Round 6: the same records, one thread per NODE.  k_fill_nodes above runs one thread per particle of which only the leaf heads (one in
+// eight) have work, and of those one in eight a bracket search: 0.55 ms at 256^3 after the doubling steps.  k_node_heads scatters every
+// head's index to the nodes it starts; k_fill_nodes_n then lets node j descend from the root to its own level along its head's key - the
+// reference's arithmetic (centre +- len / 4, len / 2) in the same order, so the geometry is bit-identical - and finds its end.
+__global__ void __launch_bounds__(256) k_node_heads(int64_t n, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base,
+                                                    uint32_t *__restrict__ head)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n)
+        return;
+    const uint32_t c = cnt[i];
+    const uint32_t b = c ? base[i] : 0u;
+    for(uint32_t k = 0; k < c; k++)
+        head[b + k] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_fill_nodes_n(int64_t nnodes, int64_t n, const uint32_t *__restrict__ head, const uint64_t *__restrict__ keys,
+                                                      const uint8_t *__restrict__ leaflevel, const uint32_t *__restrict__ cnt,
+                                                      const uint32_t *__restrict__ base, double box, NodeGeo *__restrict__ geo,
+                                                      NodeLink *__restrict__ link)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= nnodes)
+        return;
+    const int64_t i = head[j];
+    const uint64_t ki = keys[i];
+    const int L = leaflevel[i];
+    const int first = L - (int)cnt[i] + 1;
+    const int l = first + (int)(j - (int64_t)base[i]); // this node's level
+    double cx = box / 2., cy = box / 2., cz = box / 2.;
+    double len = box * 1.001;
+    for(int a = 0; a < l; a++) {
+        const int d = (int)((ki >> (3 * (MAXLEVEL - 1 - a))) & 7);
+        const double q = 0.25 * len;
+        cx += (d & 1) ? q : -q;
+        cy += (d & 2) ? q : -q;
+        cz += (d & 4) ? q : -q;
+        len *= 0.5;
+    }
+    geo[j] = NodeGeo{cx, cy, cz, len};
+    int pc = 1;
+    while(i + pc < n && cnt[i + pc] == 0)
+        pc++;
+    NodeLink lk;
+    lk.level = l;
+    lk.pstart = (int)i;
+    int64_t e;
+    if(l == L) {
+        lk.pcount = pc;
+        e = i + pc;
+    }
+    else {
+        lk.pcount = 0;
+        const int shift = 3 * (MAXLEVEL - l);
+        const uint64_t pref = (l == 0) ? 0 : (ki >> shift);
+        int64_t lo = i + pc, hi = n;
+        if(l > 0)
+            for(int64_t step = 8;; step <<= 1) {
+                const int64_t p = lo - 1 + step;
+                if(p >= n)
+                    break;
+                if((keys[p] >> shift) == pref)
+                    lo = p + 1;
+                else {
+                    hi = p;
+                    break;
+                }
+            }
+        else
+            lo = n;
+        while(lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if((keys[mid] >> shift) == pref)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        e = lo;
+    }
+    lk.sibling = (e < n) ? (int)base[e] : -1;
+    link[j] = lk;
 }
 
 // Leaf moments: add_particle_moment_to_node + force_update_particle_node (forcetree.c:947-966, :985-1004).
@@ -804,8 +904,15 @@ void TreeBuilder::build(int64_t n, const double *d_pos, const float *d_mass, con
     MPG_HIP(hipMemsetAsync(src.p + npart + nnodes, 0, 16 * sizeof(Src4), st));
     if(npart > 0) {
         hipLaunchKernelGGL(k_gather_src, dim3(nblk(npart)), dim3(256), 0, st, npart, idx_b.p, d_pos, d_mass, src.p);
-        hipLaunchKernelGGL(k_fill_nodes, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, base.p, box, geo.p,
-                           link.p);
+        static const bool per_particle = getenv("MPG_TREE_FILL_PER_PARTICLE") != nullptr; // (rounds 1-5: one thread per particle)
+        if(per_particle)
+            hipLaunchKernelGGL(k_fill_nodes, dim3(nblk(npart)), dim3(256), 0, st, npart, keys_b.p, leaflevel.p, cnt.p, base.p, box, geo.p, link.p);
+        else {
+            node_head.reserve((size_t)nnodes + 1);
+            hipLaunchKernelGGL(k_node_heads, dim3(nblk(npart)), dim3(256), 0, st, npart, cnt.p, base.p, node_head.p);
+            hipLaunchKernelGGL(k_fill_nodes_n, dim3(nblk(nnodes)), dim3(256), 0, st, nnodes, npart, node_head.p, keys_b.p, leaflevel.p, cnt.p, base.p,
+                               box, geo.p, link.p);
+        }
     }
     else {
         NodeGeo g{box / 2., box / 2., box / 2., box * 1.001};
