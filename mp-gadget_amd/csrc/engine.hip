@@ -1958,9 +1958,13 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                 MPG_HIP(hipEventCreateWithFlags(&eng->slice_ev[k], hipEventDisableTiming));
         // the tree order for the host thread (the tree is complete: force_tree_full waited for it)
         MPG_HIP(hipMemcpyAsync(h_order, d_order, (size_t)npart * sizeof(int), hipMemcpyDeviceToHost, eng->copy_stream));
+        // (what nothing hides is the LAST slice's copy and write-back, so the last slice is the small one: MPG_HOST_SLICE_LAST of the targets,
+        // the slices before it share the rest equally)
+        static const double last_env = getenv("MPG_HOST_SLICE_LAST") ? atof(getenv("MPG_HOST_SLICE_LAST")) : 0.10;
+        const double last_frac = (last_env > 0 && last_env < 1.0 / S) ? last_env : 1.0 / S;
         int64_t cut[9];
         for(int k = 0; k <= S; k++)
-            cut[k] = k == S ? npart : ((npart * k / S) & ~(int64_t)7);
+            cut[k] = k == S ? npart : ((int64_t)((double)npart * (1.0 - last_frac) * k / (S - 1)) & ~(int64_t)7);
         char *wbs = (char *)P->base;
         std::string therr;
         std::thread writer;
