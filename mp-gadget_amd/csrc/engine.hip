@@ -1936,7 +1936,7 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
     // down (compacted in tree order: one contiguous copy) and written into P[] by a host thread while slice k + 1 is walked.  The slices
     // are cut at multiples of 8 targets, i.e. between the waves of the list kernel: every target's lists, and with them its sums, are
     // those of the unsliced walk bit for bit.  What stays on the critical path is the last slice's copy and write-back.
-    static const int nslices_env = getenv("MPG_HOST_WALK_SLICES") ? atoi(getenv("MPG_HOST_WALK_SLICES")) : 4;
+    static const int nslices_env = getenv("MPG_HOST_WALK_SLICES") ? atoi(getenv("MPG_HOST_WALK_SLICES")) : 5;
     const int64_t npart = eng->tree.npart;
     const int nslices = eng->host_slices > 1 ? eng->host_slices : (npart >= (1 << 20) ? nslices_env : 1); // (small walks: not worth the calls)
     if(eng->host_overlap && dev_old && !ActiveParticle && !AccelStore && full && eng->copy_stream && nslices > 1 && npart >= 8 * nslices) {
@@ -1958,13 +1958,23 @@ int mpg_grav_short_tree(mpg_engine *eng, const mpg_particle_view *P, const int *
                 MPG_HIP(hipEventCreateWithFlags(&eng->slice_ev[k], hipEventDisableTiming));
         // the tree order for the host thread (the tree is complete: force_tree_full waited for it)
         MPG_HIP(hipMemcpyAsync(h_order, d_order, (size_t)npart * sizeof(int), hipMemcpyDeviceToHost, eng->copy_stream));
-        // (what nothing hides is the LAST slice's copy and write-back, so the last slice is the small one: MPG_HOST_SLICE_LAST of the targets,
-        // the slices before it share the rest equally)
-        static const double last_env = getenv("MPG_HOST_SLICE_LAST") ? atof(getenv("MPG_HOST_SLICE_LAST")) : 0.10;
-        const double last_frac = (last_env > 0 && last_env < 1.0 / S) ? last_env : 1.0 / S;
+        // (what nothing hides is the write-back that is still running when the last walk ends.  The writer needs about half as long for a slice's
+        // results as the walk of that slice took, so slice k + 1 may be about half of slice k and still cover it: the slices shrink geometrically,
+        // MPG_HOST_SLICE_RATIO per step, and the last - the one nothing covers - is the smallest.  1 = equal slices)
+        static const double ratio_env = getenv("MPG_HOST_SLICE_RATIO") ? atof(getenv("MPG_HOST_SLICE_RATIO")) : 0.55;
+        const double ratio = (ratio_env > 0.05 && ratio_env < 1.0) ? ratio_env : 1.0;
         int64_t cut[9];
-        for(int k = 0; k <= S; k++)
-            cut[k] = k == S ? npart : ((int64_t)((double)npart * (1.0 - last_frac) * k / (S - 1)) & ~(int64_t)7);
+        {
+            double w = 1.0, tot = 0.0, acc = 0.0;
+            for(int k = 0; k < S; k++, w *= ratio)
+                tot += w;
+            w = 1.0;
+            for(int k = 0; k <= S; k++) {
+                cut[k] = k == S ? npart : ((int64_t)((double)npart * (acc / tot)) & ~(int64_t)7);
+                acc += w;
+                w *= ratio;
+            }
+        }
         char *wbs = (char *)P->base;
         std::string therr;
         std::thread writer;
