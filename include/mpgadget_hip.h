@@ -116,14 +116,17 @@ int mpg_set_particle_epoch(mpg_engine *eng, int64_t epoch);
  * P[] by a host thread while force_tree_full and grav_short_tree run, and are complete when the next call on the table that needs them
  * returns (mpg_grav_short_tree at the latest) or when mpg_host_results_sync returns.  A caller whose host code reads P[].GravPM /
  * P[].Potential between gravpm_force and grav_short_tree (energy_statistics, run.c:527) calls mpg_host_results_sync first.  (c) A walk of all
- * particles on a tree of all particles runs in slices of the tree order (4 from 2^20 particles on; `on` = 2 .. 8 forces that many at any
- * size), the results of a slice travelling down and into P[] while the next is walked; results bit-identical to the unsliced walk. */
+ * particles on a tree of all particles runs in slices of the tree order (5 from 2^20 particles on, each 0.55 of the one before it so that
+ * the write-back nothing hides is the smallest; `on` = 2 .. 8 forces that many at any size), the results of a slice travelling down and into
+ * P[] while the next is walked; results bit-identical to the unsliced walk. */
 int mpg_set_host_overlap(mpg_engine *eng, int on);
 /* The epoch's packing pass + uploads started early (round 6): call after mpg_set_particle_epoch as soon as P[] is final for the step - the
  * end of drift_all_particles (drift.c:84-102) - and the pass (Pos, Mass, Type, Potential, FullTreeGravAccel) runs on a host thread while the
  * caller goes on (run.c:420-522: domain_maintain, the active list); mpg_gravpm_force / mpg_density / ... of the same epoch and table join it
  * instead of packing.  A new epoch in between (an exchange, a garbage collection) simply leaves the upload unused.  Needs
- * mpg_set_host_overlap; a no-op without it or in resident mode.  P[] must not be written until the epoch's first entry point has returned. */
+ * mpg_set_host_overlap; a no-op without it or in resident mode.  P[] must not be written until the epoch's first entry point has returned,
+ * and that entry point (or mpg_set_particle_epoch / mpg_host_results_sync, which wait for the pass) is the next call on this engine: the
+ * pass uses the engine's stream. */
 int mpg_host_prefetch(mpg_engine *eng, const mpg_particle_view *pv, double BoxSize);
 int mpg_host_results_sync(mpg_engine *eng);
 /* gravpm_force, libgadget/gravpm.c:61-119: zero GravPM, CIC deposit, r2c, Green's function, 4 x (transfer, c2r,

@@ -227,6 +227,7 @@ int mpg_dev_bind_particles(mpg_engine *eng, int64_t n, const double *d_pos, cons
     MPG_CHECK(eng, "null engine");
     MPG_CHECK(n >= 0 && (n == 0 || (d_pos && d_mass)), "mpg_dev_bind_particles: null particle arrays");
     MPG_CHECK(BoxSize > 0, "mpg_dev_bind_particles: BoxSize must be positive");
+    eng->host_join(); // (a prefetch or a write-back of the host-pointer calls still uses the binding and the stream)
     eng->n = n;
     eng->d_pos = d_pos;
     eng->d_mass = d_mass;
@@ -2192,6 +2193,7 @@ int mpg_resident_begin(mpg_engine *eng, const mpg_particle_view *P, double BoxSi
     MPG_CHECK(eng && P, "null argument");
     MPG_CHECK(P->off_accel >= 0 && P->off_gravpm >= 0 && P->off_potential >= 0, "resident mode needs FullTreeGravAccel, GravPM and Potential in the view");
     MPG_HIP(hipSetDevice(eng->device));
+    eng->host_join(); // (a prefetch in flight writes the staging state set below)
     eng->resident = false;
     eng->staged_epoch = -1; // (force the upload whatever epoch the caller declared)
     stage_particles(eng, P, BoxSize);
