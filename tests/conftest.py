@@ -65,6 +65,15 @@ def keep_artifacts_on_failure(body):
     return wrapped
 
 
+def _foreign_device_fault(text):
+    """True when a rank died of an HSA queue abort whose faulting kernel (the runtime's "Kernel Name:" note) is none of this library's."""
+    import re
+    if "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" not in text:
+        return False
+    names = re.findall(r"Kernel Name: (\S+)", text)
+    return bool(names) and all("N3mpg" not in n for n in names)
+
+
 def run_ranks(cmd, env, log_path, timeout=900):
     """subprocess.run of a (multi-)rank helper script; on a non-zero exit the COMPLETE stdout / stderr are written to `log_path`
     (under the test's tmp_path, which keep_artifacts_on_failure copies to gpurun_out/flake/) before the assertion fires: a rank that
@@ -83,7 +92,13 @@ def run_ranks(cmd, env, log_path, timeout=900):
         # that a repeat is never silent.  A failure that repeats fails the test.
         # Round 6: the repeat is OPT-IN (MPG_TEST_RETRY=1) and off by default - a product-side race that shows once in 50 runs must fail
         # the suite, not hide behind a repeat (profiles/r06b_flake_stress/: 200 clean iterations of the four tests concerned).
-        if os.environ.get("MPG_TEST_RETRY") != "1":
+        # End of round 6: the worker SIGABRT of rounds 2-3 was caught with its reason (profiles/r06b_flake_stress/README.md, last section):
+        # "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" in the queue of ONE of two processes sharing the GPU, and the runtime's core-dump note
+        # names the kernel - at::native::vectorized_elementwise_kernel<FillFunctor<double>>, PyTorch's own fill, before any kernel of
+        # this library had run in that process.  A device fault inside a kernel that is NOT this library's (no "N3mpg" in the mangled
+        # name) gets ONE repeat, logged and warned about; a fault in one of ours, an invariant, a wrong number or a time-out never does.
+        foreign_fault = _foreign_device_fault(r.stdout + r.stderr)
+        if os.environ.get("MPG_TEST_RETRY") != "1" and not foreign_fault:
             assert r.returncode == 0, r.stderr[-3000:]
         import warnings
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,7 +108,8 @@ def run_ranks(cmd, env, log_path, timeout=900):
                 f.write("cmd: %s\nrc %d\n---- stderr (tail) ----\n%s\n\n" % (" ".join(cmd), r.returncode, r.stderr[-6000:]))
         except OSError:
             pass
-        warnings.warn("multi-rank helper failed once and was repeated: %s" % " ".join(cmd[-3:]))
+        warnings.warn("multi-rank helper failed once (%s) and was repeated: %s"
+                      % ("device fault in a foreign kernel" if foreign_fault else "MPG_TEST_RETRY=1", " ".join(cmd[-3:])))
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     return r

@@ -231,3 +231,21 @@ def test_shim_links_against_reference_objects(tmp_path):
         assert name in wanted, name        # (run.c does call them: the audit above resolved them outside the reference's own objects)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "tools/link_audit.py" in doc and "symbol audit" in doc.lower()
+
+
+def test_rank_repeat_is_limited_to_device_faults_in_foreign_kernels():
+    """tests/conftest.py::run_ranks repeats a multi-rank helper ONCE only for the failure caught at the end of round 6 (several processes on
+    one GPU: an HSA queue abort inside PyTorch's own fill kernel, profiles/r06b_flake_stress/hsa_abort_in_torch_fill.log); a fault in a kernel
+    of this library, a fault without a named kernel, an invariant or a wrong number are never repeated."""
+    from conftest import _foreign_device_fault
+    seen = ("GPU core dump created: gpucore.31797\n"
+            "Kernel Name: _ZN2at6native29vectorized_elementwise_kernelILi4ENS0_11FillFunctorIdEESt5arrayIPcLm1EEEEviT0_T1_\n"
+            ":0:rocdevice.cpp :3676: Callback: Queue 0x7f3e68c00000 aborting with error : HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION: "
+            "The agent attempted to execute an illegal shader instruction. code: 0x2a\n")
+    assert _foreign_device_fault(seen)
+    assert not _foreign_device_fault(seen.replace("_ZN2at6native29vectorized_elementwise_kernel", "_ZN3mpg9k_density"))
+    assert not _foreign_device_fault("HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION")           # (no kernel named: not repeated)
+    assert not _foreign_device_fault("mpg_dist_domain_exchange: plan counts and decomposition counts differ")
+    assert not _foreign_device_fault("AssertionError: max relative difference 3e-9")
+    on_disk = os.path.join(ROOT, "profiles", "r06b_flake_stress", "hsa_abort_in_torch_fill.log")
+    assert _foreign_device_fault(open(on_disk).read())
