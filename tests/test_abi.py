@@ -249,3 +249,29 @@ def test_rank_repeat_is_limited_to_device_faults_in_foreign_kernels():
     assert not _foreign_device_fault("AssertionError: max relative difference 3e-9")
     on_disk = os.path.join(ROOT, "profiles", "r06b_flake_stress", "hsa_abort_in_torch_fill.log")
     assert _foreign_device_fault(open(on_disk).read())
+
+
+def test_run_ranks_repeat_paths(tmp_path, monkeypatch):
+    """run_ranks on a stand-in helper: a first run that dies with the foreign-kernel device fault is repeated once (with a warning); the same
+    death with one of this library's kernels named, or any other failure, fails at once."""
+    import sys
+    from conftest import run_ranks
+    monkeypatch.delenv("MPG_TEST_RETRY", raising=False)
+    helper = tmp_path / "helper.py"
+    helper.write_text(
+        "import os, sys\n"
+        "marker, kernel = sys.argv[1], sys.argv[2]\n"
+        "if os.path.exists(marker):\n"
+        "    sys.exit(0)\n"
+        "open(marker, 'w').close()\n"
+        "print('Kernel Name: ' + kernel)\n"
+        "sys.stderr.write('Queue aborting with error : HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION: illegal shader instruction\\n')\n"
+        "sys.exit(134)\n")
+    foreign = "_ZN2at6native29vectorized_elementwise_kernelILi4ENS0_11FillFunctorIdEEEEviT0_T1_"
+    with pytest.warns(UserWarning, match="device fault in a foreign kernel"):
+        r = run_ranks([sys.executable, str(helper), str(tmp_path / "m1"), foreign], os.environ, tmp_path / "log1")
+    assert r.returncode == 0 and os.path.exists(str(tmp_path / "log1") + ".failed.log")
+    with pytest.raises(AssertionError):
+        run_ranks([sys.executable, str(helper), str(tmp_path / "m2"), "_ZN3mpg9k_densityENS_8TreeViewE"], os.environ, tmp_path / "log2")
+    with pytest.raises(AssertionError):
+        run_ranks([sys.executable, "-c", "import sys; sys.exit(3)"], os.environ, tmp_path / "log3")
